@@ -1,0 +1,9 @@
+"""
+firstordersolvers.jl_amd -- MI355X-native hot path of FirstOrderSolvers.jl.
+
+Host-side mirror of the reference's solver interface (GAP/DR/AP/GAPA/FISTA constructors,
+FOSMathProgModel with loadproblem/optimize/status/getobjval/getsolution, model.history) over the
+C-ABI shared library `csrc/libfoship.so` (hand-written HIP kernels for gfx950).  There is no CPU
+fallback: every compute call goes through the library and fails loudly if it is missing.
+"""
+from . import workloads  # noqa: F401

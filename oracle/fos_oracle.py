@@ -1,0 +1,879 @@
+"""
+fos_oracle.py -- CPU restatement (numpy/scipy, fp64) of the FirstOrderSolvers.jl hot path.
+
+*** TEST INFRASTRUCTURE ONLY. ***  This module is the parity checker for the HIP path.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import
+it.  The product (`firstordersolvers.jl_amd`) never imports or falls back to it.
+
+What it restates (paths under /root/reference; every function cites the lines it follows):
+
+  src/utilities/conjugategradients.jl:31-55      conjugategradient!
+  src/utilities/affinepluslinear.jl:4-15,37-52   KKTMatrix, mul!
+  src/utilities/affinepluslinear.jl:58-126       AffinePlusLinear, prox!
+  src/problemforms/HSDE/HSDEAffine.jl:2-65       HSDEMatrixQ, mul!, transpose mul!
+  src/problemforms/HSDE/HSDEAffine.jl:68-147     HSDEMatrix, prox!, mul!
+  src/cones.jl:4-14,31-142                       conemap, ConeProduct, proxDual!, DualConeProduct
+  src/solvers/gap.jl, gapa.jl, fista.jl, dykstra.jl, solvers.jl   step / getsol / S1! / S2!
+  src/solverwrapper.jl:2-41                      solve!, iterate
+  src/problemforms/HSDE/HSDE.jl:7-61             HSDE assembly, initial value, solution
+  src/problemforms/HSDE/HSDEStatus.jl:27-102     checkstatus, print formats, getvalues
+  src/FOSSolverInterface.jl:8-64                 loadproblem!, optimize!
+
+Third-party arithmetic NOT under /root/reference: the per-cone projections are calls into
+ProximalOperators.jl (Project.toml:10, version UNPINNED, no Manifest).  They are restated
+here from that package's published algorithm (IndFree/IndZero/IndPoint/IndNonnegative/
+IndNonpositive/IndSOC/IndRotatedSOC/IndPSD(scaling=true)).  Pinning status:
+  * IndPSD: pinned by the reference's RNG-free known answer test/testPSD.jl:3-4,14-25.
+  * IndNonnegative / Zero / Free: pinned through the DR/GAPA solves of test/testDRandGAPA.jl
+    (problem shape; Julia's RNG stream is unavailable, optimum checked with scipy nnls).
+  * IndSOC / IndRotatedSOC: PARITY UNPINNED -- no reference test touches them.
+The Julia reference itself cannot be executed in the build container (no julia binary), so
+the oracle is pinned against the reference's own tests restated in tests/test_oracle_*.py
+(identities vs dense linear algebra, CG property test, PSD known answer, print formats).
+
+Indices are 0-based here; the z layout is the reference's  [x(n); y(m); tau; r(n); s(m); kappa]
+(src/cones.jl:126-141, src/problemforms/HSDE/HSDEStatus.jl:93-101).
+"""
+from __future__ import annotations
+
+import math
+import time
+import warnings
+
+import numpy as np
+import scipy.sparse as sp
+
+EPS = float(np.finfo(np.float64).eps)   # Julia eps()
+
+# ----------------------------------------------------------------------------------------
+# HSDEMatrixQ            src/problemforms/HSDE/HSDEAffine.jl:2-65
+# ----------------------------------------------------------------------------------------
+
+
+class HSDEMatrixQ:
+    """Matrix-free  Q = [0 A' c; -A 0 b; -c' -b' 0]   (HSDEAffine.jl:2-20)."""
+
+    def __init__(self, A, b, c):
+        A = sp.csc_matrix(A) if not sp.issparse(A) else A.tocsc()
+        self.A = A
+        self.At = A.T.tocsr()        # transpose(A) of a CSC matrix: a CSR view, row gather
+        self.b = np.asarray(b, dtype=np.float64).reshape(-1)
+        self.c = np.asarray(c, dtype=np.float64).reshape(-1)
+        self.am, self.an = A.shape
+        assert self.b.shape[0] == self.am      # HSDEAffine.jl:15
+        assert self.c.shape[0] == self.an      # HSDEAffine.jl:16
+
+    @property
+    def shape(self):                            # HSDEAffine.jl:20
+        l = self.am + self.an + 1
+        return (l, l)
+
+    def mul(self, Y, B):
+        """mul!(Y, Q, B)   HSDEAffine.jl:41-59."""
+        n, m = self.an, self.am
+        assert self.shape == (Y.shape[0], B.shape[0])
+        b1 = B[:n]
+        b2 = B[n:n + m]
+        b3 = B[n + m]
+        y1 = self.At @ b2                       # :51  mul!(y1, transpose(A), b2)
+        y2 = self.A @ b1                        # :52  mul!(y2, A, b1)
+        y1 = y1 + b3 * self.c                   # :54  y1 .+= b3.*c
+        y2 = y2 - b3 * self.b                   # :55  y2 .-= b3.*b
+        y2 = -y2                                # :56  y2 .= .-y2
+        last = -np.dot(self.c, b1) - np.dot(self.b, b2)   # :57 (computed before Y is written: B may not alias Y)
+        Y[:n] = y1
+        Y[n:n + m] = y2
+        Y[n + m] = last
+        return Y
+
+    def mul_t(self, Y, B):
+        """mul!(Y, transpose(Q), B) = -(Q*B)   HSDEAffine.jl:61-65."""
+        self.mul(Y, B)
+        np.negative(Y, out=Y)
+        return Y
+
+    def todense(self):
+        n, m = self.an, self.am
+        l = n + m + 1
+        Q = np.zeros((l, l))
+        Ad = self.A.toarray()
+        Q[:n, n:n + m] = Ad.T
+        Q[:n, l - 1] = self.c
+        Q[n:n + m, :n] = -Ad
+        Q[n:n + m, l - 1] = self.b
+        Q[l - 1, :n] = -self.c
+        Q[l - 1, n:n + m] = -self.b
+        return Q
+
+
+class _PlainMatrix:
+    """Adapter giving a dense/sparse matrix the mul/mul_t protocol (used by KKTMatrix tests,
+    test/affinepluslinear.jl:7-19 where the inner operator is a plain randn(10,20))."""
+
+    def __init__(self, A):
+        self.A = A
+        self.shape = A.shape
+
+    def mul(self, Y, B):
+        Y[:] = self.A @ B
+        return Y
+
+    def mul_t(self, Y, B):
+        Y[:] = self.A.T @ B
+        return Y
+
+
+def _as_operator(A):
+    return A if hasattr(A, "mul") else _PlainMatrix(A)
+
+
+# ----------------------------------------------------------------------------------------
+# KKTMatrix              src/utilities/affinepluslinear.jl:4-15,37-52
+# ----------------------------------------------------------------------------------------
+
+
+class KKTMatrix:
+    """Matrix-free [I A'; A -I]."""
+
+    def __init__(self, A):
+        self.A = _as_operator(A)
+        self.am, self.an = self.A.shape
+
+    @property
+    def shape(self):
+        return (self.am + self.an, self.am + self.an)
+
+    def mul(self, y, x):
+        """mul!(y, M, x)   affinepluslinear.jl:37-49."""
+        an, am = self.an, self.am
+        x1, x2 = x[:an], x[an:an + am]
+        y1, y2 = y[:an], y[an:an + am]
+        self.A.mul_t(y1, x2)        # :45
+        y1 += x1                    # :46
+        self.A.mul(y2, x1)          # :47
+        y2 -= x2                    # :48
+        return y
+
+    mul_t = mul                     # :52  transpose == self
+
+
+# ----------------------------------------------------------------------------------------
+# conjugategradient!     src/utilities/conjugategradients.jl:31-55
+# ----------------------------------------------------------------------------------------
+
+
+def conjugategradient(x, A, b, r, p, Ap, tol=None, max_iters=10000):
+    """Golub/Van Loan CG exactly as the reference runs it (also on the indefinite KKT system).
+    Returns the iteration count (>= 1).  x is the warm start and receives the solution."""
+    if tol is None:
+        tol = A.shape[1] * EPS                   # :31 default
+    A.mul(Ap, x)                                 # :32
+    np.subtract(b, Ap, out=r)                    # :33
+    p[:] = r                                     # :34
+    rn = np.float64(np.dot(r, r))                # :35   (np.float64: x/0 -> inf/nan silently, as in Julia)
+    it = 1                                       # :36
+    while True:
+        A.mul(Ap, p)                             # :38
+        with np.errstate(divide="ignore", invalid="ignore"):
+            alpha = rn / np.float64(np.dot(Ap, p))   # :39
+        x += alpha * p                           # :40
+        r -= alpha * Ap                          # :41
+        if np.linalg.norm(r) <= tol or it >= max_iters:   # :42
+            break
+        rnold = rn                               # :45
+        rn = np.float64(np.dot(r, r))            # :46
+        with np.errstate(divide="ignore", invalid="ignore"):
+            beta = rn / rnold                    # :47
+        p *= beta                                # :49
+        p += r                                   # :50
+        it += 1                                  # :51
+    if it == max_iters:                          # :53
+        warnings.warn("CG reached max iterations, result may be inaccurate")
+    return it
+
+
+class CGdata:
+    """conjugategradients.jl:1-11."""
+
+    def __init__(self, size):
+        self.r = np.empty(size)
+        self.p = np.empty(size)
+        self.z = np.empty(size)
+        self.xinit = np.empty(size)
+        self.firstrun = True
+
+
+# ----------------------------------------------------------------------------------------
+# AffinePlusLinear       src/utilities/affinepluslinear.jl:58-126
+# ----------------------------------------------------------------------------------------
+
+
+class AffinePlusLinear:
+    """f([x;z]) = q'x + indicator(Ax - beta z == b), beta = +-1."""
+
+    def __init__(self, A, b, q, beta, decreasing_accuracy=False):
+        self.A = _as_operator(A)
+        am, an = self.A.shape
+        assert beta == 1 or beta == -1                       # :73
+        self.M = KKTMatrix(self.A)
+        self.beta = beta
+        self.b = np.asarray(b, dtype=np.float64)
+        self.q = np.asarray(q, dtype=np.float64)
+        self.rhs = np.empty(am + an)
+        self.rhs[an:] = self.b                               # :76-77
+        self.decreasing_accuracy = decreasing_accuracy
+        self.i = 1                                           # :78 call counter (decides tol)
+        self.cgiter = 0
+        self.cgdata = CGdata(am + an)
+
+    def getcgiter(self):                                     # :81
+        return self.cgiter
+
+    def tolerance(self):
+        """:108-112 -- tolerance that the *next* prox! call will use."""
+        if self.decreasing_accuracy:
+            return max(0.2 ** math.sqrt(self.i), self.A.shape[1] * EPS)
+        return self.A.shape[1] * EPS
+
+    def prox(self, y, x):
+        """prox!(y, S, x)   affinepluslinear.jl:83-126."""
+        an, am = self.M.an, self.M.am
+        rhs1 = self.rhs[:an]
+        x1 = x[:an]
+        x2 = x[an:an + am]
+        beta = self.beta
+        self.A.mul_t(rhs1, x2)                               # :94
+        rhs1[:] = beta * rhs1 + x1 - self.q                  # :95
+        cg = self.cgdata
+        if cg.firstrun:                                      # :101-104
+            cg.xinit[:] = x
+            cg.firstrun = False
+        y[:] = cg.xinit                                      # :106
+        tol = self.tolerance()                               # :108-112
+        self.i += 1                                          # :114
+        max_iters = 1000                                     # :115
+        it = conjugategradient(y, self.M, self.rhs, cg.r, cg.p, cg.z, tol=tol, max_iters=max_iters)  # :117
+        self.cgiter = it                                     # :121
+        cg.xinit[:] = y                                      # :122
+        y[an:an + am] *= beta                                # :124
+        return 0.0
+
+
+# ----------------------------------------------------------------------------------------
+# HSDEMatrix             src/problemforms/HSDE/HSDEAffine.jl:68-147
+# ----------------------------------------------------------------------------------------
+
+
+class HSDEMatrix:
+    """Matrix-free [I Q'; Q -I] with its own CG state (HSDEAffine.jl:68-89)."""
+
+    def __init__(self, Q):
+        self.Q = Q
+        self.cgdata = CGdata(2 * Q.shape[0])
+
+    @property
+    def shape(self):
+        m = self.Q.shape[0]
+        return (2 * m, 2 * m)
+
+    def mul(self, Y, B):
+        """HSDEAffine.jl:131-144."""
+        mQ = self.Q.shape[0]
+        y1, y2 = Y[:mQ], Y[mQ:2 * mQ]
+        b1, b2 = B[:mQ], B[mQ:2 * mQ]
+        self.Q.mul_t(y1, b2)     # :139
+        self.Q.mul(y2, b1)       # :140
+        y1 += b1                 # :141
+        y2 -= b2                 # :142
+        return Y
+
+    mul_t = mul                  # :146-147
+
+    def prox(self, y, x):
+        """argmin ||x-y|| s.t. Q u == v, [u;v] = y   HSDEAffine.jl:105-126."""
+        tol = self.shape[1] * EPS                # :106
+        max_iters = 1000                         # :107
+        cg = self.cgdata
+        if cg.firstrun:                          # :109-112
+            cg.xinit[:] = x
+            cg.firstrun = False
+        y[:] = cg.xinit                          # :114
+        it = conjugategradient(y, self, x, cg.r, cg.p, cg.z, tol=tol, max_iters=max_iters)  # :116
+        cg.xinit[:] = y                          # :119
+        m = self.Q.shape[0]
+        u = y[:m].copy()
+        self.Q.mul(y[m:2 * m], u)                # :122-124   v = Q*u
+        self.cgiter = it
+        return 0.0
+
+
+# ----------------------------------------------------------------------------------------
+# Cone projections (ProximalOperators.jl -- third-party, restated from its published algorithm)
+# ----------------------------------------------------------------------------------------
+
+CONE_FREE, CONE_ZERO, CONE_NONNEG, CONE_NONPOS, CONE_SOC, CONE_SOCROT, CONE_SDP, CONE_EXPP, CONE_EXPD = range(9)
+
+# Symbol -> code, the keys of conemap  (src/cones.jl:4-14)
+CONE_CODES = {
+    "Free": CONE_FREE, "Zero": CONE_ZERO, "NonNeg": CONE_NONNEG, "NonPos": CONE_NONPOS,
+    "SOC": CONE_SOC, "SOCRotated": CONE_SOCROT, "SDP": CONE_SDP,
+    "ExpPrimal": CONE_EXPP, "ExpDual": CONE_EXPD,
+}
+CONE_NAMES = {v: k for k, v in CONE_CODES.items()}
+
+
+def prox_free(y, x):            # IndFree: identity
+    y[:] = x
+
+
+def prox_zero(y, x):            # IndZero / IndPoint(): the origin
+    y[:] = 0.0
+
+
+def prox_nonneg(y, x):          # IndNonnegative
+    np.maximum(x, 0.0, out=y)
+
+
+def prox_nonpos(y, x):          # IndNonpositive
+    np.minimum(x, 0.0, out=y)
+
+
+def prox_soc(y, x):
+    """IndSOC: {(t, v): ||v|| <= t}, t first.  (ProximalOperators indSOC.jl)"""
+    nx = float(np.linalg.norm(x[1:]))
+    t = float(x[0])
+    if t <= -nx:
+        y[:] = 0.0
+    elif t >= nx:
+        y[:] = x
+    else:
+        r = 0.5 * (1.0 + t / nx)
+        y[0] = r * nx
+        y[1:] = r * x[1:]
+
+
+_S45 = 0.7071067811865475
+
+
+def prox_socrot(y, x):
+    """IndRotatedSOC: {(p, q, v): ||v||^2 <= 2pq, p,q >= 0} via a pi/4 rotation onto IndSOC."""
+    x1 = _S45 * x[0] + _S45 * x[1]
+    x2 = _S45 * x[0] - _S45 * x[1]
+    nx = math.sqrt(x2 * x2 + float(np.dot(x[2:], x[2:])))
+    t = x1
+    if t <= -nx:
+        y[:] = 0.0
+    elif t >= nx:
+        y[0] = x1
+        y[1] = x2
+        y[2:] = x[2:]
+    else:
+        r = 0.5 * (1.0 + t / nx)
+        y[0] = r * nx
+        y[1] = r * x2
+        y[2:] = r * x[2:]
+    y1 = _S45 * y[0] + _S45 * y[1]
+    y2 = _S45 * y[0] - _S45 * y[1]
+    y[0] = y1
+    y[1] = y2
+
+
+def psd_dim(length):
+    """Matrix order k with k(k+1)/2 == length."""
+    k = int(round(math.sqrt(0.25 + 2.0 * length) - 0.5))
+    assert k * (k + 1) // 2 == length, "PSD cone length is not triangular"
+    return k
+
+
+def svec_to_mat(x, k):
+    """Lower triangle, column-major packed vector -> full symmetric k x k matrix."""
+    M = np.zeros((k, k))
+    idx = 0
+    for j in range(k):
+        cnt = k - j
+        M[j:, j] = x[idx:idx + cnt]
+        M[j, j:] = x[idx:idx + cnt]
+        idx += cnt
+    return M
+
+
+def mat_to_svec(M, y):
+    k = M.shape[0]
+    idx = 0
+    for j in range(k):
+        cnt = k - j
+        y[idx:idx + cnt] = M[j:, j]
+        idx += cnt
+
+
+def prox_psd_scaled(y, x):
+    """IndPSD(scaling=true) on the packed lower triangle with off-diagonals pre-multiplied by
+    sqrt(2) (the MathProgBase/SCS svec convention; conemap :SDP, src/cones.jl:11).
+    ProximalOperators' vector method: scale the DIAGONAL by sqrt(2) (so the whole packed
+    matrix is sqrt(2) x the true one), symmetric eigendecomposition of the packed matrix,
+    clamp eigenvalues at 0, rebuild, repack the lower triangle, scale the diagonal back."""
+    k = psd_dim(x.shape[0])
+    w = np.array(x, dtype=np.float64, copy=True)
+    dpos = np.cumsum([0] + [k - j for j in range(k - 1)])      # positions of the diagonal entries
+    w[dpos] *= math.sqrt(2.0)
+    M = svec_to_mat(w, k)
+    lam, V = np.linalg.eigh(M)
+    lam = np.maximum(lam, 0.0)
+    P = (V * lam) @ V.T
+    mat_to_svec(P, y)
+    y[dpos] *= 1.0 / math.sqrt(2.0)
+
+
+def prox_psd_matrix(Y):
+    """IndPSD() matrix method (test/testPSD.jl:14-16): projection of a symmetric matrix."""
+    lam, V = np.linalg.eigh(Y)
+    lam = np.maximum(lam, 0.0)
+    return (V * lam) @ V.T
+
+
+_PROX = {
+    CONE_FREE: prox_free, CONE_ZERO: prox_zero, CONE_NONNEG: prox_nonneg, CONE_NONPOS: prox_nonpos,
+    CONE_SOC: prox_soc, CONE_SOCROT: prox_socrot, CONE_SDP: prox_psd_scaled,
+}
+
+
+def cone_prox(code, y, x):
+    try:
+        f = _PROX[code]
+    except KeyError:
+        raise NotImplementedError("cone %s not restated" % CONE_NAMES.get(code, code))
+    f(y, x)
+
+
+def cone_prox_dual(code, y, x):
+    """proxDual!   src/cones.jl:80-85 (Moreau: y = x + P_K(-x)) with the shortcuts :97-102."""
+    if code == CONE_ZERO:            # :98   dual of Zero is Free
+        prox_free(y, x)
+    elif code == CONE_FREE:          # :100  dual of Free is the origin (IndPoint())
+        prox_zero(y, x)
+    elif code == CONE_NONNEG:        # :101  self dual
+        prox_nonneg(y, x)
+    elif code == CONE_NONPOS:        # :102
+        prox_nonpos(y, x)
+    else:                            # :80-85 generic
+        cone_prox(code, y, -x)
+        y += x
+
+
+class ConeProduct:
+    """src/cones.jl:31-77.  `cones` = list of (code, start0, length); contiguous, ordered, gap-free."""
+
+    def __init__(self, cones=()):
+        self.cones = []
+        prev_end = 0
+        for (code, start, length) in cones:
+            if isinstance(code, str):
+                code = CONE_CODES[code]
+            assert start == prev_end, "ranges must be contiguous and ordered (cones.jl:66-72)"
+            prev_end = start + length
+            self.cones.append((code, start, length))
+        self.total = prev_end
+
+    @staticmethod
+    def from_lengths(pairs):
+        cones, start = [], 0
+        for code, length in pairs:
+            cones.append((code, start, length))
+            start += length
+        return ConeProduct(cones)
+
+    def prox(self, y, x):            # :89-94
+        for code, s, ln in self.cones:
+            cone_prox(code, y[s:s + ln], x[s:s + ln])
+
+    def prox_dual(self, y, x):       # :106-111
+        for code, s, ln in self.cones:
+            cone_prox_dual(code, y[s:s + ln], x[s:s + ln])
+
+
+class DualConeProduct:
+    """K2 x K1* x R+ x K2* x K1 x R+   src/cones.jl:113-142."""
+
+    def __init__(self, K1, K2):
+        self.K1, self.K2 = K1, K2
+        self.m, self.n = K1.total, K2.total      # :121
+
+    def prox(self, y, x):
+        m, n = self.m, self.n
+        nu = n + m + 1
+        self.K2.prox(y[0:n], x[0:n])                                  # :136
+        self.K1.prox_dual(y[n:n + m], x[n:n + m])                     # :137
+        y[nu - 1] = max(x[nu - 1], 0.0)                               # :138
+        self.K2.prox_dual(y[nu:nu + n], x[nu:nu + n])                 # :139
+        self.K1.prox(y[nu + n:nu + n + m], x[nu + n:nu + n + m])      # :140
+        y[2 * nu - 1] = max(x[2 * nu - 1], 0.0)                       # :141
+
+
+# ----------------------------------------------------------------------------------------
+# Model / HSDE assembly    src/types.jl:30-60, src/FOSSolverInterface.jl:27-64, HSDE.jl:7-61
+# ----------------------------------------------------------------------------------------
+
+class Model:
+    """The fields of FOSMathProgModel the hot path reads (types.jl:30-52)."""
+
+    def __init__(self, A, b, c, K1, K2):
+        self.A = sp.csc_matrix(A) if not sp.issparse(A) else A.tocsc()     # loadproblem! sparsifies, :27-29
+        self.b = np.asarray(b, dtype=np.float64).reshape(-1)
+        self.c = np.asarray(c, dtype=np.float64).reshape(-1)
+        self.K1 = K1 if isinstance(K1, ConeProduct) else ConeProduct.from_lengths(K1)
+        self.K2 = K2 if isinstance(K2, ConeProduct) else ConeProduct.from_lengths(K2)
+        m, n = self.A.shape
+        assert self.K1.total == m and self.K2.total == n
+        self.history = {}
+        self.init_duration = 0
+
+
+def hsde_sets(model):
+    """HSDE(model; direct=false)   HSDE.jl:7-29  ->  (S1, S2, N)."""
+    Q = HSDEMatrixQ(model.A, model.b, model.c)                              # :17
+    l = Q.shape[0]
+    S1 = AffinePlusLinear(Q, np.zeros(l), np.zeros(l), 1, decreasing_accuracy=True)   # :22
+    S2 = DualConeProduct(model.K1, model.K2)                                # :24
+    return S1, S2, 2 * l                                                    # :28
+
+
+def hsde_initialvalue(model):
+    """HSDE_getinitialvalue   HSDE.jl:40-47."""
+    m, n = model.A.shape
+    l = m + n + 1
+    x = np.zeros(2 * l)
+    x[l - 1] = 1.0
+    x[2 * l - 1] = 1.0
+    return x
+
+
+def hsde_populatesolution(model, z, status):
+    """HSDE_populatesolution   HSDE.jl:49-61  ->  (x, y, s, status)."""
+    m, n = model.A.shape
+    l = m + n + 1
+    assert z.shape[0] == 2 * l
+    tau = z[l - 1]
+    endstatus = status.status
+    if endstatus == "Continue":
+        endstatus = "Indeterminate"
+    return z[0:n] / tau, z[n:n + m] / tau, z[l + n:l + n + m] / tau, endstatus
+
+
+# ----------------------------------------------------------------------------------------
+# HSDEStatus / checkstatus    src/problemforms/HSDE/HSDEStatus.jl:2-102
+# ----------------------------------------------------------------------------------------
+
+HEADER_CG = " Iter | pri res | dua res | rel gap | pri obj | dua obj | kap/tau | cg  | time"     # :79-81
+HEADER_DIRECT = " Iter | pri res | dua res | rel gap | pri obj | dua obj | kap/tau | time"
+
+
+def _jl_e(v, prec=2, width=9):
+    """C printf '% {width}.{prec}e' (Julia @printf follows C)."""
+    return "% *.*e" % (width, prec, v)
+
+
+def format_status_iter(i, p, d, g, ctx, bty, kt, cgiter, t_ns):
+    """printstatusiter   HSDEStatus.jl:85-91 (prints -bty as the dual objective)."""
+    if cgiter is None:
+        return "%6d|% 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % .1es" % (i, p, d, g, ctx, -bty, kt, t_ns / 1e9)
+    return "%6d|% 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 4d % .1es" % (i, p, d, g, ctx, -bty, kt, cgiter, t_ns / 1e9)
+
+
+def residuals(model, z):
+    """The scalars checkstatus derives from z   HSDEStatus.jl:33-38,58-61.
+    Returns dict(p, d, g, ctx, bty, kappa, tau, nAxs, nATy, nb, nc)."""
+    m, n = model.A.shape
+    nu = n + m + 1
+    x = z[0:n]
+    y = z[n:n + m]
+    r = z[nu:nu + n]
+    s = z[nu + n:nu + n + m]
+    tau = z[nu - 1]
+    kappa = z[2 * nu - 1]
+    A, b, c = model.A, model.b, model.c
+    nb = float(np.linalg.norm(b))
+    nc = float(np.linalg.norm(c))
+    Ax = A @ x
+    ATy = A.T @ y
+    p = float(np.linalg.norm(Ax / tau + s / tau - b)) / abs(1 + nb)           # :34
+    d = float(np.linalg.norm(ATy / tau + c - r / tau)) / abs(1 + nc)          # :35
+    ctx = float(np.dot(c, x))                                                 # :36
+    bty = float(np.dot(b, y))                                                 # :37
+    g = abs(ctx / tau + bty / tau) / (1 + abs(ctx / tau) + abs(bty / tau))    # :38
+    return dict(p=p, d=d, g=g, ctx=ctx, bty=bty, kappa=float(kappa), tau=float(tau),
+                nAxs=float(np.linalg.norm(Ax + s)), nATy=float(np.linalg.norm(ATy)), nb=nb, nc=nc)
+
+
+def decide_status(res, eps):
+    """Status decision   HSDEStatus.jl:53-63 (doubly normalised, reproduced as is)."""
+    p, d, g, ctx, bty, tau = res["p"], res["d"], res["g"], res["ctx"], res["bty"], res["tau"]
+    nb, nc = res["nb"], res["nc"]
+    if p <= eps * (1 + nb) and d <= eps * (1 + nc) and g <= eps * (1 + abs(ctx / tau) + abs(bty / tau)):
+        return "Optimal"
+    # Julia: x/0.0 = +-Inf / NaN silently; comparisons with NaN are false
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ub = np.float64(-ctx) / np.float64(nc)
+        if res["nAxs"] <= eps * ub:
+            return "Unbounded"
+        ib = np.float64(-bty) / np.float64(nb)
+        if res["nATy"] <= eps * ib:
+            return "Infeasible"
+    return "Continue"
+
+
+class HSDEStatus:
+    """HSDEStatus.jl:2-16 + checkstatus :27-71."""
+
+    def __init__(self, model, checki, eps, verbose, debug, S1=None, out=None):
+        self.model = model
+        self.i = 0
+        self.status = "Continue"
+        self.checki = checki
+        self.eps = eps
+        self.verbose = verbose
+        self.checked = False
+        self.direct = False
+        self.debug = debug
+        self.init_time = time.perf_counter_ns()
+        self.S1 = S1
+        self.lines = [] if out is None else out
+
+    def _println(self, s):
+        self.lines.append(s)
+
+    def printstatusheader(self):                           # :73-83
+        if self.verbose > 0:
+            self._println("Time to initialize: %ss" % (self.model.init_duration / 1e9))
+            width = 76 + (0 if self.direct else 5)
+            self._println("-" * width)
+            self._println(HEADER_DIRECT if self.direct else HEADER_CG)
+            self._println("-" * width)
+
+    def checkstatus(self, z, override=False):              # :27-71
+        if self.i % self.checki == 0 or override:
+            t = time.perf_counter_ns() - self.init_time
+            model, i = self.model, self.i
+            res = residuals(model, z)
+            if self.debug > 0:                             # :39-41, savedata :125-139
+                h = model.history
+                for key in ("p", "d", "g", "ctx", "bty", "kappa", "tau"):
+                    h.setdefault(key, []).append((i, res[key]))
+                h.setdefault("t", []).append((i, t))
+                if self.debug > 1:
+                    m, n = model.A.shape
+                    nu = n + m + 1
+                    h.setdefault("x", []).append((i, z[0:n].copy()))
+                    h.setdefault("y", []).append((i, z[n:n + m].copy()))
+                    h.setdefault("s", []).append((i, z[nu + n:nu + n + m].copy()))
+            if self.verbose > 0:                           # :43-51
+                cgiter = self.S1.getcgiter() if self.S1 is not None else 0
+                model.history.setdefault("cgiter", []).append((i, cgiter))
+                self._println(format_status_iter(i, res["p"], res["d"], res["g"], res["ctx"], res["bty"],
+                                                 res["kappa"] / res["tau"], cgiter, t))
+            status = decide_status(res, self.eps)
+            if status == "Optimal" and self.verbose > 0:   # :55-57
+                self._println("Found solution i=%d" % i)
+            self.status = status
+            self.checked = True
+            self.last = res
+            return True
+        self.checked = False
+        return False
+
+
+# ----------------------------------------------------------------------------------------
+# Algorithms     src/solvers/{gap,gapa,fista,dykstra,solvers}.jl
+# ----------------------------------------------------------------------------------------
+
+class GAP:
+    """GAP(alpha=0.8, alpha1=1.8, alpha2=1.8)   gap.jl:6-13."""
+
+    def __init__(self, alpha=0.8, alpha1=1.8, alpha2=1.8, **options):
+        self.alpha, self.alpha1, self.alpha2 = alpha, alpha1, alpha2
+        self.options = options
+
+    def init(self, model):                                  # gap.jl:23-28
+        self.S1, self.S2, n = hsde_sets(model)
+        self.tmp1 = np.empty(n)
+        self.tmp2 = np.empty(n)
+
+    def S1_(self, y, x):                                    # gap.jl:42-51
+        self.S1.prox(y, x)
+        y[:] = self.alpha1 * y + (1 - self.alpha1) * x
+
+    def S2_(self, y, x, status):                            # gap.jl:53-59
+        self.S2.prox(y, x)
+        status.checkstatus(y)
+        y[:] = self.alpha2 * y + (1 - self.alpha2) * x
+
+    def step(self, x, i, status):                           # gap.jl:61-80
+        self.S1_(self.tmp1, x)
+        self.S2_(self.tmp2, self.tmp1, status)
+        x[:] = self.alpha * self.tmp2 + (1 - self.alpha) * x
+
+    def getsol(self, x):                                    # gap.jl:82-87
+        self.S1.prox(self.tmp1, x)
+        self.S2.prox(self.tmp2, self.tmp1)
+        return self.tmp2
+
+
+def DR(alpha=0.5, **kw):                                    # solvers.jl:10
+    return GAP(alpha, 2.0, 2.0, **kw)
+
+
+def AP(alpha=1, **kw):                                      # solvers.jl:11
+    return GAP(alpha, 1.0, 1.0, **kw)
+
+
+def normed_scalar(x1, x2, y1, y2):
+    """normedScalar   gapa.jl:36-47."""
+    d1 = x1 - x2
+    d2 = y1 - y2
+    s = float(np.dot(d1, d2))
+    n1 = float(np.dot(d1, d1))
+    n2 = float(np.dot(d2, d2))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return float(np.float64(abs(s)) / np.sqrt(np.float64(n1 * n2)))
+
+
+class GAPA:
+    """GAPA(alpha=1.0, beta=0.0)   gapa.jl:9-15."""
+
+    def __init__(self, alpha=1.0, beta=0.0, **options):
+        self.alpha, self.beta = alpha, beta
+        self.options = options
+
+    def init(self, model):                                  # gapa.jl:27-32
+        self.S1, self.S2, n = hsde_sets(model)
+        self.alpha12 = 2.0
+        self.tmp1 = np.empty(n)
+        self.tmp2 = np.empty(n)
+
+    def step(self, x, i, status):                           # gapa.jl:80-105
+        a12 = self.alpha12
+        self.S1.prox(self.tmp1, x)                          # S1!  :61-70
+        self.tmp1[:] = a12 * self.tmp1 + (1 - a12) * x
+        self.S2.prox(self.tmp2, self.tmp1)                  # S2!  :72-78
+        status.checkstatus(self.tmp2)
+        self.tmp2[:] = a12 * self.tmp2 + (1 - a12) * self.tmp1
+        scl = normed_scalar(self.tmp2, self.tmp1, self.tmp1, x)     # :96
+        scl = 0.0 if math.isnan(scl) else min(max(scl, 0.0), 1.0)   # :96-97 (clamp then NaN -> 0)
+        s = math.sqrt(1 - scl ** 2)                         # :98
+        aopt = 2 / (1 + s)                                  # :100
+        self.alpha12 = (1 - self.beta) * aopt + self.beta * 2.0     # :101
+        x[:] = self.alpha * self.tmp2 + (1 - self.alpha) * x        # :103
+
+    def getsol(self, x):                                    # gapa.jl:107-112
+        self.S1.prox(self.tmp1, x)
+        self.S2.prox(self.tmp2, self.tmp1)
+        return self.tmp2
+
+
+class FISTA:
+    """FISTA(alpha=1.0)   fista.jl:6-11."""
+
+    def __init__(self, alpha=1.0, **options):
+        self.alpha = alpha
+        self.options = options
+
+    def init(self, model):                                  # fista.jl:20-25
+        self.S1, self.S2, n = hsde_sets(model)
+        self.t = 1.0
+        self.y = np.zeros(n)
+        self.xold = np.zeros(n)
+        self.tmp1 = np.empty(n)
+
+    def step(self, x, i, status):                           # fista.jl:28-48
+        if i == 1:
+            self.y[:] = x                                   # :31-33
+        self.S1.prox(self.tmp1, self.y)                     # :35
+        self.tmp1[:] = self.alpha * self.tmp1 + (1 - self.alpha) * self.y   # :37
+        self.xold[:] = x                                    # :39
+        self.S2.prox(x, self.tmp1)                          # :40
+        status.checkstatus(x)                               # :41
+        told = self.t
+        self.t = (1 + math.sqrt(1 + 4 * self.t ** 2)) / 2   # :45
+        self.y[:] = x + (told - 1) / self.t * (x - self.xold)   # :46
+
+    def getsol(self, x):                                    # fista.jl:50-56
+        tmp2 = np.empty_like(x)
+        self.S1.prox(self.tmp1, x)
+        self.S2.prox(tmp2, self.tmp1)
+        return tmp2
+
+
+class Dykstra:
+    """Dykstra()   dykstra.jl:5-9."""
+
+    def __init__(self, **options):
+        self.options = options
+
+    def init(self, model):                                  # dykstra.jl:19-23
+        self.S1, self.S2, n = hsde_sets(model)
+        self.p = np.zeros(n)
+        self.q = np.zeros(n)
+        self.y = np.empty(n)
+
+    def step(self, x, i, status):                           # dykstra.jl:25-36
+        self.S1.prox(self.y, x + self.p)
+        self.p[:] = x + self.p - self.y
+        self.S2.prox(x, self.y + self.q)
+        status.checkstatus(x)
+        self.q[:] = self.y + self.q - x
+
+    def getsol(self, x):                                    # dykstra.jl:38-44
+        tmp1 = np.empty_like(x)
+        self.S1.prox(tmp1, x)
+        self.S2.prox(self.y, tmp1)
+        return self.y
+
+
+# ----------------------------------------------------------------------------------------
+# solve! / iterate       src/solverwrapper.jl:2-41, src/FOSSolverInterface.jl:8-21
+# ----------------------------------------------------------------------------------------
+
+
+def iterate(alg, status, x, max_iters):
+    """iterate   solverwrapper.jl:20-41."""
+    t1 = time.time()
+    status.printstatusheader()
+    for i in range(1, max_iters + 1):
+        status.i = i
+        alg.step(x, i, status)
+        if status.status != "Continue":
+            break
+    guess = alg.getsol(x)
+    if not status.checked:
+        status.checkstatus(guess, override=True)
+    if status.verbose > 0:
+        status._println("Time for iterations: ")
+        status._println("%s s" % (time.time() - t1))
+    return guess
+
+
+class Solution:
+    def __init__(self, x, y, s, status):
+        self.x, self.y, self.s, self.status = x, y, s, status
+
+
+def solve(model, alg, out=None):
+    """loadproblem! + optimize! for an already conic-form model.
+    Option defaults: solverwrapper.jl:5-10 (max_iters=10000, verbose=1, debug=1, eps=1e-5, checki=100)."""
+    opts = dict(alg.options)
+    max_iters = opts.get("max_iters", 10000)
+    verbose = opts.get("verbose", 1)
+    debug = opts.get("debug", 1)
+    eps = opts.get("eps", 1e-5)
+    checki = opts.get("checki", 100)
+    alg.init(model)                                          # init_algorithm!  (loadproblem! :58)
+    x = opts["initx"] if "initx" in opts else hsde_initialvalue(model)
+    model.history = {}                                       # optimize! :10
+    status = HSDEStatus(model, checki, eps, verbose, debug, S1=alg.S1, out=out)
+    guess = iterate(alg, status, x, max_iters)
+    xs, ys, ss, st = hsde_populatesolution(model, guess, status)
+    sol = Solution(xs, ys, ss, st)
+    sol.obj_val = float(np.dot(model.c, xs))                 # optimize! :20
+    sol.iterations = status.i
+    sol.status_obj = status
+    sol.z = guess
+    return sol
