@@ -6,4 +6,8 @@ FOSMathProgModel with loadproblem/optimize/status/getobjval/getsolution, model.h
 C-ABI shared library `csrc/libfoship.so` (hand-written HIP kernels for gfx950).  There is no CPU
 fallback: every compute call goes through the library and fails loudly if it is missing.
 """
-from . import workloads  # noqa: F401
+from . import _lib as lib          # noqa: F401
+from . import workloads            # noqa: F401
+from .interface import (AP, DR, FISTA, GAP, GAPA, Dykstra, FOSAlgorithm, FOSMathProgModel, HipHSDE, HSDEStatus,  # noqa: F401
+                        Solution, solve, HEADER_CG, HEADER_DIRECT)
+from . import sharding             # noqa: F401

@@ -1,0 +1,167 @@
+// Internal declarations of libfoship (not part of the ABI).
+//
+// Device data layout (DESIGN.md "Data layout in HBM"):
+//   * every N-vector of the reference (N = 2l, l = n+m+1, layout [x;y;tau;r;s;kappa]) lives on the device
+//     as l `double2` elements, INTERLEAVED:  v[i] = (part1[i], part2[i])  with part1 = [x;y;tau],
+//     part2 = [r;s;kappa].  All CG / relaxation kernels are elementwise or reductions, so the layout is
+//     free; interleaving makes the dual-right-hand-side KKT SpMV gather ONE 16-byte element per non-zero and
+//     lets one cone workgroup project the primal and the dual copy of a cone from the same loads.
+//   * the operator is stored once as the stacked matrix S = [[0, A'],[A, 0]] ((n+m) x (n+m)) in a
+//     block-padded CSR (fp64 values, int32 columns into the stacked vector [x(n); y(m)]).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "foship.h"
+
+namespace fos {
+
+// ---------------------------------------------------------------------------------- errors
+void set_error(const char* fmt, ...);
+
+#define FOS_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ::fos::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return FOS_EHIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+#define FOS_TRY(expr)                    \
+    do {                                 \
+        int _r = (expr);                 \
+        if (_r != FOS_OK) return _r;     \
+    } while (0)
+
+// ---------------------------------------------------------------------------------- SpMV storage
+constexpr int SPMV_THREADS = 256;
+constexpr int NNZ_BLK = 1024;       // non-zeros staged through LDS per row block (16 B each for 2 RHS)
+constexpr int ROWS_BLK = 256;       // max rows per row block (>= 1 epilogue thread per row)
+constexpr int NNZ_ALIGN = 4;        // every row block starts at a multiple of 4 entries (16/32-byte aligned)
+
+// Host-side result of building the stacked operator; uploaded verbatim.
+struct HostBlkCsr {
+    int64_t nrows = 0, nnz = 0, nnz_padded = 0;
+    std::vector<double> val;
+    std::vector<int32_t> col;
+    std::vector<int32_t> blk_row0;     // [nblk+1]
+    std::vector<int64_t> blk_nnz0;     // [nblk]   aligned first entry
+    std::vector<int64_t> blk_nnz1;     // [nblk]   true end
+    std::vector<uint16_t> row_rel;     // [nrows]  row start relative to blk_nnz0 (stream blocks)
+    std::vector<int32_t> wg_blk0;      // [nwg+1]  row blocks owned by each workgroup
+    int32_t nblk = 0, nwg = 0;
+};
+
+struct DevBlkCsr {
+    int64_t nrows, nnz, nnz_padded;
+    const double* val;
+    const int32_t* col;
+    const int32_t* blk_row0;
+    const int64_t* blk_nnz0;
+    const int64_t* blk_nnz1;
+    const uint16_t* row_rel;
+    const int32_t* wg_blk0;
+    int32_t nblk, nwg;
+};
+
+// Builds S = [[0, A'],[A, 0]] from Julia CSC (1-based).  Returns FOS_EINVAL on malformed input.
+int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                      int nwg_target, HostBlkCsr* out);
+void partition_workgroups(HostBlkCsr* S, int nwg_target);
+
+// ---------------------------------------------------------------------------------- device scalar state
+// One struct in device memory; kernels read/write it, the host polls a pinned copy.
+struct DevState {
+    // CG  (conjugategradients.jl:31-55)
+    double rn, rn_old, alpha, beta, pAp, rr, tol;
+    int32_t iter, done, maxit, hit_max;
+    // algorithm scalars
+    double alpha12;        // GAPAData.alpha12 (gapa.jl:29,101)
+    double gapa_scl;       // last normedScalar value (diagnostic)
+    // status sums, filled by status_finalize: see StatusIdx
+    double stat[12];
+};
+
+enum StatusIdx { ST_RP2 = 0, ST_RD2, ST_CTX, ST_BTY, ST_AXS2, ST_ATY2, ST_TAU, ST_KAPPA, ST_COUNT };
+
+// ---------------------------------------------------------------------------------- cone tables
+// Elementwise op per (index, part):  2 bits each.
+enum EwOp : uint8_t { EW_COPY = 0, EW_ZERO = 1, EW_MAX0 = 2, EW_MIN0 = 3 };
+constexpr uint8_t EW_SKIP = 0xFF;   // index belongs to a SOC / PSD cone (handled by the batched kernels)
+
+struct ConeDesc {          // a SOC / rotated SOC / PSD cone in stacked index space [0, n+m)
+    int64_t start;         // first stacked index
+    int32_t len;           // number of entries
+    int32_t k;             // PSD order (0 for SOC)
+    int32_t dual_part;     // which part (0: part1, 1: part2) takes the DUAL projection (Moreau); the other takes the primal
+    int32_t type;          // FOS_CONE_*
+};
+
+// ---------------------------------------------------------------------------------- kernel launchers (kernels.hip / psd.hip)
+struct LaunchCtx {
+    hipStream_t stream;
+    DevBlkCsr S;
+    const double* cb;      // [n+m] = [c; b]
+    int64_t n, m, l;       // l = n+m+1
+    DevState* st;
+    double* partials;      // scratch for per-workgroup partial sums
+    double* reduced;       // small buffer of locally reduced sums (all-reduced in place when sharded)
+    int32_t vec_blocks;    // grid of the vector kernels
+};
+
+// KKT apply, 2 RHS interleaved:  out = [I Q'; Q -I] * w   (rows 0..n+m-1; the tau row is written by kkt_finalize)
+void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate);
+// mode 0: finish tau rows only (CG init / test entry); mode 1: also pAp and alpha = rn/pAp (CG iteration)
+void launch_kkt_reduce(const LaunchCtx& c, int gate);     // partials -> reduced[0..2]   (sharded path)
+void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int mode, int gate, int from_reduced);
+
+// single right-hand side Q apply on component `comp` of an interleaved vector
+//   Q_PLAIN : out_plain[i] = sign * (Q v)_i            (rows 0..n+m-1; tau row by q1_finalize)
+//   Q_RHS   : out[i] = (x[i].x - (Q x.y)_i, 0)         (affinepluslinear.jl:94-95 with beta=1, q=0, b=0)
+//   Q_STATUS: residual sums of checkstatus             (HSDEStatus.jl:34-38,59,61)
+enum QMode { Q_PLAIN = 0, Q_RHS = 1, Q_STATUS = 2, Q_VFROMU = 3 };
+void launch_q1(const LaunchCtx& c, QMode mode, const double2* v, int comp, double sign, void* out);
+void launch_q1_reduce(const LaunchCtx& c, QMode mode);
+void launch_q1_finalize(const LaunchCtx& c, QMode mode, const double2* v, int comp, double sign, void* out, int from_reduced);
+
+// CG vector kernels
+void launch_cg_init(const LaunchCtx& c, const double2* rhs, const double2* Ap, double2* r, double2* p);
+void launch_cg_init_finalize(const LaunchCtx& c, const double2* r, double tol, int maxit, int from_reduced);
+void launch_cg_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, const double2* Ap);
+void launch_cg_update_finalize(const LaunchCtx& c, const double2* r, int from_reduced);
+void launch_cg_pupdate(const LaunchCtx& c, double2* p, const double2* r);
+void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate);   // partials[count x nacc] -> reduced[nacc]
+
+// outer-loop vector kernels (gap.jl:48,58,78; gapa.jl:67,77,96-103; fista.jl:31-46; dykstra.jl)
+void launch_axpby(const LaunchCtx& c, double2* out, double a, const double2* x, double b, const double2* y);          // out = a x + b y
+void launch_relax_a12(const LaunchCtx& c, double2* out, const double2* y, const double2* x);                          // out = a12 y + (1-a12) x, a12 from state
+void launch_gap_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha, double alpha2);   // x = alpha(alpha2 t2+(1-alpha2)t1) + (1-alpha) x
+void launch_gapa_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha);           // + normedScalar partials
+void launch_gapa_finalize(const LaunchCtx& c, double beta, const double2* x_old_tau_unused, int from_reduced);
+void launch_fista_extrap(const LaunchCtx& c, double2* y, const double2* x, const double2* xold, double coef);         // y = x + coef (x - xold)
+void launch_add(const LaunchCtx& c, double2* out, const double2* a, const double2* b);                                // out = a + b
+void launch_dykstra_corr(const LaunchCtx& c, double2* p, const double2* x, const double2* y);                         // p = x + p - y
+
+// layout conversion at the ABI boundary
+void launch_interleave(const LaunchCtx& c, double2* out, const double* plain);    // plain [part1(l); part2(l)] -> interleaved
+void launch_deinterleave(const LaunchCtx& c, double* plain, const double2* in);
+void launch_set_comp(const LaunchCtx& c, double2* out, const double* plain_l, int comp);   // out[i].comp = plain[i], other comp = 0
+void launch_get_plain(const LaunchCtx& c, double* plain_l, const double2* in, int comp);
+
+// cones (cones.jl:122-142)
+void launch_cones_elementwise(const LaunchCtx& c, double2* out, const double2* in, const uint8_t* ew_op);
+void launch_cones_soc(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones);
+int  launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones,
+                      int kmax, double* gscratch);
+size_t psd_scratch_bytes(int kmax, int ncones);
+
+void launch_status_finalize(const LaunchCtx& c, const double2* z, int from_reduced);
+
+}  // namespace fos

@@ -1,0 +1,426 @@
+// Hand-written gfx950 kernels for the GAP/DR/GAPA/FISTA-over-HSDE hot path (everything except the batched PSD
+// eigen-solver, psd.hip).  See DESIGN.md for the roofline of each kernel.
+//
+//   kkt2_kernel      fused dual-right-hand-side KKT apply  out = [I Q'; Q -I] w          (dominant, HBM bound)
+//                    = 4 reference SpMV sweeps (affinepluslinear.jl:45-48 -> HSDEAffine.jl:51-52, twice)
+//                    in ONE sweep over the stacked operator S = [[0,A'],[A,0]], plus the Q epilogue
+//                    (HSDEAffine.jl:54-57), the KKT identity terms and the three reductions CG needs.
+//   q1_kernel        single right-hand side Q apply with fused epilogues: rhs build (affinepluslinear.jl:94-95),
+//                    plain Q / Q' apply (HSDEAffine.jl:41-65), status residual sums (HSDEStatus.jl:34-38,59,61).
+//   cg_*             CG vector updates with in-pass reductions (conjugategradients.jl:33-50); scalars stay on
+//                    the device, every CG kernel is gated on DevState.done so the host enqueues iterations
+//                    ahead and polls once per chunk.
+//   cones_*          segmented elementwise cones + batched SOC (cones.jl:122-142).
+//   relaxation / extrapolation passes of gap.jl:48,58,78  gapa.jl:67,77,96-103  fista.jl:31-46.
+//
+// Wavefront = 64 lanes; workgroups of 256 threads (4 waves) unless noted; all arithmetic fp64.
+#include "fos_internal.hpp"
+
+namespace fos {
+
+typedef double2 d2;
+
+// ------------------------------------------------------------------------------------------------ helpers
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch); give every XCD one contiguous slice of the row blocks so
+// its private L2 sees a compact window of the gathered vector.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int g, int nwg) {
+    if (nwg & 7) return g;
+    return (g & 7) * (nwg >> 3) + (g >> 3);
+}
+
+template <int NACC, int THREADS>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* smem, double* out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = THREADS / 64;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        double v = wave_sum(acc[a]);
+        if (lane == 0) smem[wave * NACC + a] = v;
+    }
+    __syncthreads();
+    if (tid < NACC) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += smem[w * NACC + tid];
+        out[tid] = s;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ row-block SpMV core
+//
+// One persistent workgroup walks its slice of row blocks.  Stream block: the block's <= NNZ_BLK entries are
+// loaded lane-consecutively (coalesced 8 B value + 4 B column per lane), multiplied by the gathered vector
+// element(s) and staged in LDS; then `tpr` lanes per row sum that row's LDS segment (tpr = power of two chosen
+// from the number of rows in the block) and finish with an in-wave butterfly.  Long row: the whole workgroup
+// strides the row and block-reduces.  Summation order is fixed by the storage -> bit-reproducible run to run.
+
+template <int NRHS>
+struct Gather;
+template <>
+struct Gather<2> {
+    const d2* w;
+    __device__ __forceinline__ d2 operator()(double v, int c) const {
+        d2 x = w[c];
+        return make_double2(v * x.x, v * x.y);
+    }
+};
+template <>
+struct Gather<1> {
+    const double* w;   // points at the chosen component of an interleaved vector: element c at w[2c]
+    __device__ __forceinline__ double operator()(double v, int c) const { return v * w[2 * (int64_t)c]; }
+};
+
+template <int NRHS, class Epi>
+__device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>& gat, Epi& epi, double* prod, double* red) {
+    const int tid = threadIdx.x;
+    const int g = xcd_remap(blockIdx.x, S.nwg);
+    const int b_lo = S.wg_blk0[g], b_hi = S.wg_blk0[g + 1];
+    for (int b = b_lo; b < b_hi; ++b) {
+        const int r0 = S.blk_row0[b], r1 = S.blk_row0[b + 1];
+        const int64_t e0 = S.blk_nnz0[b], e1 = S.blk_nnz1[b];
+        const int64_t cnt64 = e1 - e0;
+        if (cnt64 > NNZ_BLK) {
+            // ---------------- long row r0
+            double a1 = 0.0, a2 = 0.0;
+            const double* __restrict__ val = S.val;
+            const int32_t* __restrict__ col = S.col;
+            int64_t k = e0 + tid;
+            for (; k + 3 * SPMV_THREADS < e1; k += 4 * SPMV_THREADS) {
+                double v0 = val[k], v1 = val[k + SPMV_THREADS], v2 = val[k + 2 * SPMV_THREADS], v3 = val[k + 3 * SPMV_THREADS];
+                int c0 = col[k], c1 = col[k + SPMV_THREADS], c2 = col[k + 2 * SPMV_THREADS], c3 = col[k + 3 * SPMV_THREADS];
+                if constexpr (NRHS == 2) {
+                    d2 p0 = gat(v0, c0), p1 = gat(v1, c1), p2 = gat(v2, c2), p3 = gat(v3, c3);
+                    a1 += p0.x; a2 += p0.y; a1 += p1.x; a2 += p1.y; a1 += p2.x; a2 += p2.y; a1 += p3.x; a2 += p3.y;
+                } else {
+                    a1 += gat(v0, c0); a1 += gat(v1, c1); a1 += gat(v2, c2); a1 += gat(v3, c3);
+                }
+            }
+            for (; k < e1; k += SPMV_THREADS) {
+                if constexpr (NRHS == 2) { d2 p0 = gat(val[k], col[k]); a1 += p0.x; a2 += p0.y; }
+                else { a1 += gat(val[k], col[k]); }
+            }
+            a1 = wave_sum(a1);
+            if constexpr (NRHS == 2) a2 = wave_sum(a2);
+            const int lane = tid & 63, wave = tid >> 6;
+            if (lane == 0) { red[wave * 2] = a1; red[wave * 2 + 1] = a2; }
+            __syncthreads();
+            if (tid == 0) {
+                double u1 = (red[0] + red[2]) + (red[4] + red[6]);
+                double u2 = (red[1] + red[3]) + (red[5] + red[7]);
+                epi.row(r0, u1, u2);
+            }
+            __syncthreads();
+        } else {
+            // ---------------- stream block: rows r0..r1-1, cnt entries
+            const int cnt = (int)cnt64;
+            const double* __restrict__ val = S.val + e0;
+            const int32_t* __restrict__ col = S.col + e0;
+            {
+                double v[4]; int c[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int k = tid + j * SPMV_THREADS;
+                    bool ok = k < cnt;
+                    v[j] = ok ? val[k] : 0.0;
+                    c[j] = ok ? col[k] : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int k = tid + j * SPMV_THREADS;
+                    if (k < cnt) {
+                        if constexpr (NRHS == 2) reinterpret_cast<d2*>(prod)[k] = gat(v[j], c[j]);
+                        else prod[k] = gat(v[j], c[j]);
+                    }
+                }
+            }
+            __syncthreads();
+            const int R = r1 - r0;
+            // lanes per row: 256 / nextpow2(R), at most one wave
+            int p2 = (R <= 1) ? 1 : (1 << (32 - __clz(R - 1)));
+            int tpr = SPMV_THREADS / p2;
+            if (tpr > 64) tpr = 64;
+            const int sh = 31 - __clz(tpr);
+            const int row = tid >> sh, lig = tid & (tpr - 1);
+            double a1 = 0.0, a2 = 0.0;
+            if (row < R) {
+                const int s = S.row_rel[r0 + row];
+                const int e = (row + 1 < R) ? (int)S.row_rel[r0 + row + 1] : cnt;
+                for (int k = s + lig; k < e; k += tpr) {
+                    if constexpr (NRHS == 2) { d2 p = reinterpret_cast<const d2*>(prod)[k]; a1 += p.x; a2 += p.y; }
+                    else { a1 += prod[k]; }
+                }
+            }
+            for (int off = tpr >> 1; off > 0; off >>= 1) {
+                a1 += __shfl_xor(a1, off, 64);
+                if constexpr (NRHS == 2) a2 += __shfl_xor(a2, off, 64);
+            }
+            if (row < R && lig == 0) epi.row(r0 + row, a1, a2);
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ KKT apply, 2 RHS
+
+struct EpiKkt {
+    const d2* w;
+    d2* out;
+    const double* cb;
+    int n;
+    d2 wt;             // (p1_tau, p2_tau)
+    double acc[3];     // S1 = sum Ap.p (non-tau rows), T1 = [c;b].p1, T2 = [c;b].p2
+    __device__ __forceinline__ void row(int i, double u1, double u2) {
+        const d2 p = w[i];
+        const double c = cb[i];
+        double q1, q2;                                  // (Q p1)_i, (Q p2)_i   HSDEAffine.jl:51-56
+        if (i < n) { q1 = u1 + wt.x * c; q2 = u2 + wt.y * c; }
+        else { q1 = -(u1 - wt.x * c); q2 = -(u2 - wt.y * c); }
+        const double a1 = p.x - q2;                     // y1 = Q'x2 + x1 = -(Q x2) + x1     affinepluslinear.jl:45-46
+        const double a2 = q1 - p.y;                     // y2 = Q x1 - x2                    affinepluslinear.jl:47-48
+        out[i] = make_double2(a1, a2);
+        acc[0] += a1 * p.x + a2 * p.y;
+        acc[1] += c * p.x;
+        acc[2] += c * p.y;
+    }
+};
+
+__global__ __launch_bounds__(SPMV_THREADS) void kkt2_kernel(DevBlkCsr S, const d2* __restrict__ w, d2* __restrict__ out,
+                                                            const double* __restrict__ cb, int n, int nm,
+                                                            double* __restrict__ partials, const DevState* st, int gate) {
+    if (gate && st->done) return;
+    __shared__ __attribute__((aligned(16))) double prod[NNZ_BLK * 2];
+    __shared__ double red[16];
+    EpiKkt epi;
+    epi.w = w; epi.out = out; epi.cb = cb; epi.n = n; epi.wt = w[nm];
+    epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
+    Gather<2> gat{w};
+    spmv_walk<2>(S, gat, epi, prod, red);
+    block_reduce_store<3, SPMV_THREADS>(epi.acc, red, partials + 3 * (int64_t)blockIdx.x);
+}
+
+// sums partials[count][NACC] -> sums[NACC] in a fixed order (1024 threads, one block)
+template <int NACC>
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int count, double* sums /*shared, NACC*/, double* smem /*shared 16*NACC*/) {
+    double acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] += partials[(int64_t)i * NACC + a];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        double v = wave_sum(acc[a]);
+        if (lane == 0) smem[wave * NACC + a] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += smem[w * NACC + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
+constexpr int FIN_THREADS = 1024;
+
+// generic: partials[count][nacc] -> reduced[nacc]   (sharded path: the all-reduce runs on `reduced`)
+__global__ __launch_bounds__(FIN_THREADS) void reduce_kernel(const double* __restrict__ partials, int count, int nacc,
+                                                             double* __restrict__ reduced, const DevState* st, int gate) {
+    if (gate && st->done) return;
+    __shared__ double sums[8];
+    __shared__ double smem[16 * 8];
+    // nacc <= 8; instantiate by value
+    switch (nacc) {
+        case 1: reduce_partials<1>(partials, count, sums, smem); break;
+        case 3: reduce_partials<3>(partials, count, sums, smem); break;
+        case 6: reduce_partials<6>(partials, count, sums, smem); break;
+        default: return;
+    }
+    if ((int)threadIdx.x < nacc) reduced[threadIdx.x] = sums[threadIdx.x];
+}
+
+// mode 0: tau rows only.  mode 1: tau rows + pAp + alpha = rn / pAp   (conjugategradients.jl:39)
+__global__ __launch_bounds__(FIN_THREADS) void kkt_finalize_kernel(const double* __restrict__ partials, int count,
+                                                                   const double* __restrict__ reduced, int from_reduced,
+                                                                   const d2* __restrict__ w, d2* __restrict__ out, int nm,
+                                                                   DevState* st, int mode, int gate) {
+    if (gate && st->done) return;
+    __shared__ double sums[3];
+    __shared__ double smem[16 * 3];
+    if (from_reduced) {
+        if (threadIdx.x < 3) sums[threadIdx.x] = reduced[threadIdx.x];
+        __syncthreads();
+    } else {
+        reduce_partials<3>(partials, count, sums, smem);
+    }
+    if (threadIdx.x == 0) {
+        const d2 pt = w[nm];
+        const double S1 = sums[0], T1 = sums[1], T2 = sums[2];
+        // (Q v)_tau = -c'v_x - b'v_y = -T(v)                          HSDEAffine.jl:57
+        const double a1 = pt.x + T2;        // p1_tau - (Q p2)_tau
+        const double a2 = -T1 - pt.y;       // (Q p1)_tau - p2_tau
+        out[nm] = make_double2(a1, a2);
+        if (mode == 1) {
+            const double pAp = S1 + (a1 * pt.x + a2 * pt.y);
+            st->pAp = pAp;
+            st->alpha = st->rn / pAp;
+        }
+    }
+}
+
+void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
+    hipLaunchKernelGGL(kkt2_kernel, dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, w, out, c.cb, (int)c.n,
+                       (int)(c.n + c.m), c.partials, c.st, gate);
+}
+void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate) {
+    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, count, nacc, c.reduced, c.st, gate);
+}
+void launch_kkt_reduce(const LaunchCtx& c, int gate) { launch_reduce1(c, c.S.nwg, 3, gate); }
+void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int mode, int gate, int from_reduced) {
+    hipLaunchKernelGGL(kkt_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.nwg, c.reduced,
+                       from_reduced, w, out, (int)(c.n + c.m), c.st, mode, gate);
+}
+
+// ------------------------------------------------------------------------------------------------ single RHS Q apply
+
+struct EpiQPlain {     // out_plain[i] = sign * (Q v)_i ; acc[0] = [c;b].v
+    const double* vcomp; double* out; const double* cb; int n; double vt, sign; double acc[1];
+    __device__ __forceinline__ void init(double vtau) { vt = vtau; }
+    __device__ __forceinline__ void row(int i, double u, double) {
+        const double c = cb[i];
+        const double q = (i < n) ? (u + vt * c) : -(u - vt * c);
+        out[i] = sign * q;
+        acc[0] += c * vcomp[2 * (int64_t)i];
+    }
+};
+struct EpiQRhs {       // out[i] = (x1_i - (Q x2)_i, 0)      affinepluslinear.jl:94-95 (beta = 1, q = 0, rhs2 = b = 0)
+    const d2* x; d2* out; const double* cb; int n; double vt; double acc[1];
+    __device__ __forceinline__ void init(double vtau) { vt = vtau; }
+    __device__ __forceinline__ void row(int i, double u, double) {
+        const double c = cb[i];
+        const d2 xi = x[i];
+        const double q = (i < n) ? (u + vt * c) : -(u - vt * c);
+        out[i] = make_double2(-q + xi.x, 0.0);          // rhs1 .= beta.*rhs1 .+ x1 .- q with rhs1 = Q'x2 = -(Q x2)
+        acc[0] += c * xi.y;
+    }
+};
+struct EpiQVfromU {    // out[i] = (y_i.x, (Q y.x)_i)        HSDEAffine.jl:122-124  v = Q u
+    const d2* y; d2* out; const double* cb; int n; double vt; double acc[1];
+    __device__ __forceinline__ void init(double vtau) { vt = vtau; }
+    __device__ __forceinline__ void row(int i, double u, double) {
+        const double c = cb[i];
+        const d2 yi = y[i];
+        const double q = (i < n) ? (u + vt * c) : -(u - vt * c);
+        out[i] = make_double2(yi.x, q);
+        acc[0] += c * yi.x;
+    }
+};
+struct EpiQStatus {    // residual sums of checkstatus  HSDEStatus.jl:34-38,59,61  (z = [x;y;tau | r;s;kappa] interleaved)
+    const d2* z; const double* cb; int n; double tau; double acc[6];
+    __device__ __forceinline__ void init(double vtau) { tau = vtau; }
+    __device__ __forceinline__ void row(int i, double u, double) {
+        const d2 zi = z[i];
+        const double c = cb[i];
+        if (i < n) {                       // u = (A'y)_i, zi = (x_i, r_i), c = c_i
+            const double rd = (u / tau + c) - zi.y / tau;
+            acc[ST_RD2] += rd * rd;
+            acc[ST_ATY2] += u * u;
+            acc[ST_CTX] += c * zi.x;
+        } else {                           // u = (A x)_j, zi = (y_j, s_j), c = b_j
+            const double rp = (u / tau + zi.y / tau) - c;
+            acc[ST_RP2] += rp * rp;
+            const double t = u + zi.y;
+            acc[ST_AXS2] += t * t;
+            acc[ST_BTY] += c * zi.x;
+        }
+    }
+};
+
+template <class Epi, int NACC>
+__global__ __launch_bounds__(SPMV_THREADS) void q1_kernel(DevBlkCsr S, const double* __restrict__ vcomp, Epi epi, int nm,
+                                                          double* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) double prod[NNZ_BLK];
+    __shared__ double red[8 * NACC > 16 ? 8 * NACC : 16];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
+    epi.init(vcomp[2 * (int64_t)nm]);      // the tau entry of the gathered component
+    Gather<1> gat{vcomp};
+    spmv_walk<1>(S, gat, epi, prod, red);
+    block_reduce_store<NACC, SPMV_THREADS>(epi.acc, red, partials + NACC * (int64_t)blockIdx.x);
+}
+
+__global__ __launch_bounds__(FIN_THREADS) void q1_finalize_kernel(const double* __restrict__ partials, int count,
+                                                                  const double* __restrict__ reduced, int from_reduced,
+                                                                  int mode, const d2* __restrict__ v, double sign, void* out, int nm) {
+    __shared__ double sums[1];
+    __shared__ double smem[16];
+    if (from_reduced) {
+        if (threadIdx.x == 0) sums[0] = reduced[0];
+        __syncthreads();
+    } else {
+        reduce_partials<1>(partials, count, sums, smem);
+    }
+    if (threadIdx.x == 0) {
+        const double T = sums[0];            // [c;b].v ;  (Q v)_tau = -T
+        if (mode == Q_PLAIN) reinterpret_cast<double*>(out)[nm] = sign * (-T);
+        else if (mode == Q_RHS) reinterpret_cast<d2*>(out)[nm] = make_double2(T + v[nm].x, 0.0);   // x1_tau - (Q x2)_tau
+        else if (mode == Q_VFROMU) reinterpret_cast<d2*>(out)[nm] = make_double2(v[nm].x, -T);
+    }
+}
+
+// status: sums -> DevState.stat (tau and kappa appended)
+__global__ __launch_bounds__(FIN_THREADS) void status_finalize_kernel(const double* __restrict__ partials, int count,
+                                                                      const double* __restrict__ reduced, int from_reduced,
+                                                                      const d2* __restrict__ z, int nm, DevState* st) {
+    __shared__ double sums[6];
+    __shared__ double smem[16 * 6];
+    if (from_reduced) {
+        if (threadIdx.x < 6) sums[threadIdx.x] = reduced[threadIdx.x];
+        __syncthreads();
+    } else {
+        reduce_partials<6>(partials, count, sums, smem);
+    }
+    if (threadIdx.x < 6) st->stat[threadIdx.x] = sums[threadIdx.x];
+    if (threadIdx.x == 0) { st->stat[ST_TAU] = z[nm].x; st->stat[ST_KAPPA] = z[nm].y; }
+}
+
+void launch_q1(const LaunchCtx& c, QMode mode, const double2* v, int comp, double sign, void* out) {
+    const double* vcomp = reinterpret_cast<const double*>(v) + comp;
+    const int nm = (int)(c.n + c.m);
+    dim3 grid(c.S.nwg), block(SPMV_THREADS);
+    if (mode == Q_PLAIN) {
+        EpiQPlain e; e.vcomp = vcomp; e.out = (double*)out; e.cb = c.cb; e.n = (int)c.n; e.vt = 0; e.sign = sign;
+        hipLaunchKernelGGL((q1_kernel<EpiQPlain, 1>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
+    } else if (mode == Q_RHS) {
+        EpiQRhs e; e.x = v; e.out = (d2*)out; e.cb = c.cb; e.n = (int)c.n; e.vt = 0;
+        hipLaunchKernelGGL((q1_kernel<EpiQRhs, 1>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
+    } else if (mode == Q_VFROMU) {
+        EpiQVfromU e; e.y = v; e.out = (d2*)out; e.cb = c.cb; e.n = (int)c.n; e.vt = 0;
+        hipLaunchKernelGGL((q1_kernel<EpiQVfromU, 1>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
+    } else {
+        EpiQStatus e; e.z = v; e.cb = c.cb; e.n = (int)c.n; e.tau = 0;
+        hipLaunchKernelGGL((q1_kernel<EpiQStatus, 6>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
+    }
+}
+void launch_q1_reduce(const LaunchCtx& c, QMode mode) { launch_reduce1(c, c.S.nwg, mode == Q_STATUS ? 6 : 1, 0); }
+void launch_q1_finalize(const LaunchCtx& c, QMode mode, const double2* v, int comp, double sign, void* out, int from_reduced) {
+    (void)comp;
+    hipLaunchKernelGGL(q1_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.nwg, c.reduced,
+                       from_reduced, (int)mode, v, sign, out, (int)(c.n + c.m));
+}
+void launch_status_finalize(const LaunchCtx& c, const double2* z, int from_reduced) {
+    hipLaunchKernelGGL(status_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.nwg, c.reduced,
+                       from_reduced, z, (int)(c.n + c.m), c.st);
+}
+
+}  // namespace fos

@@ -1,0 +1,197 @@
+// Batched projection onto the PSD cone -- IndPSD(scaling=true) of ProximalOperators.jl as the reference uses it
+// (conemap :SDP, src/cones.jl:11; called from ConeProduct.prox!/proxDual!, src/cones.jl:80-94).
+//
+// Input per cone: the packed lower triangle (column-major) of a k x k symmetric matrix with the off-diagonal
+// entries pre-multiplied by sqrt(2) (MathProgBase svec).  ProximalOperators' vector method: scale the DIAGONAL by
+// sqrt(2) (the packed matrix is then sqrt(2) x the true one), symmetric eigen-decomposition, clamp eigenvalues
+// at 0, rebuild, repack the lower triangle, scale the diagonal back by 1/sqrt(2).  The dual copy of the cone is
+// Moreau's  y = x + P(-x)  (cones.jl:80-85).
+//
+// One workgroup (256 threads) per (cone, part) matrix; G (k x k) and V (k x k) live in LDS (global scratch for
+// orders that do not fit).  Eigen-solver: one-sided (Hestenes) Jacobi on the SHIFTED matrix M + sigma I,
+// sigma = ||M||_F, which is positive semidefinite, so its SVD is its eigen-decomposition (plain one-sided Jacobi
+// on an indefinite M cannot separate +lambda from -lambda).  Column pairs of a round-robin tournament step are
+// disjoint, so a step needs one barrier; every pair is handled by `tpp` lanes (a power of two <= 64) that
+// butterfly-reduce the three column dot products.  After convergence G = V diag(lambda + sigma):
+// lambda_j = ||g_j|| - sigma, and  P = sum_{lambda_j > 0} lambda_j v_j v_j'.
+// Accuracy: absolute error O(eps ||M||), the same class as LAPACK's dspev that the reference calls.
+#include "fos_internal.hpp"
+
+namespace fos {
+
+typedef double2 d2;
+
+constexpr int PSD_THREADS = 256;
+constexpr int PSD_MAX_SWEEPS = 40;
+constexpr double SQRT2 = 1.4142135623730951;
+constexpr double INV_SQRT2 = 0.7071067811865475;
+
+__host__ __device__ inline int psd_ld(int k) {
+    // leading dimension == 8 (mod 32) doubles: the 4 pair groups of a 32-lane half hit distinct bank quarters
+    int ld = ((k + 23) / 32) * 32 + 8;
+    if (ld < k) ld += 32;
+    return ld;
+}
+
+__host__ inline size_t psd_lds_bytes(int k) { return (size_t)(16 + 2 * k * psd_ld(k) + k + 16) * sizeof(double); }
+
+__device__ __forceinline__ void idx_to_ij(int idx, int k, int& i, int& j) {
+    // packed lower triangle, column-major: column j starts at S(j) = j k - j (j-1)/2
+    const double b = 2.0 * k + 1.0;
+    int jj = (int)floor((b - sqrt(b * b - 8.0 * (double)idx)) * 0.5);
+    if (jj < 0) jj = 0;
+    if (jj > k - 1) jj = k - 1;
+    while (jj + 1 < k && ((jj + 1) * k - ((jj + 1) * jj) / 2) <= idx) ++jj;
+    while (jj > 0 && (jj * k - (jj * (jj - 1)) / 2) > idx) --jj;
+    j = jj;
+    i = jj + (idx - (jj * k - (jj * (jj - 1)) / 2));
+}
+
+__device__ __forceinline__ double group_sum(double v, int tpp) {
+    for (int off = tpp >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, const d2* __restrict__ in,
+                                                          const ConeDesc* __restrict__ cones,
+                                                          double* __restrict__ gscratch, size_t scratch_stride) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x;
+    const int cone = blockIdx.x >> 1, part = blockIdx.x & 1;
+    const ConeDesc cd = cones[cone];
+    const int k = cd.k, len = cd.len, ld = psd_ld(k);
+    const bool dual = (cd.dual_part == part);
+    const double sgn = dual ? -1.0 : 1.0;
+    const double* __restrict__ x = reinterpret_cast<const double*>(in + cd.start) + part;   // element idx at x[2 idx]
+    double* __restrict__ y = reinterpret_cast<double*>(out + cd.start) + part;
+
+    // all LDS comes from the one dynamic array (no static __shared__ in front of it: keeps its base 16-byte aligned)
+    double* red = smem;                          // [0..3] wave partials, [4] sigma
+    double* G;                                   // address space known at compile time: ds_* vs global_* accesses
+    if constexpr (USE_LDS) G = smem + 16;
+    else G = gscratch + (size_t)blockIdx.x * scratch_stride;
+    double* V = G + (size_t)k * ld;
+    double* wgt = V + (size_t)k * ld;           // k eigen-weights
+
+    // ---- load: M = smat(sgn x) with the diagonal scaled by sqrt(2); V = I
+    double fro = 0.0;
+    for (int idx = tid; idx < len; idx += PSD_THREADS) {
+        int i, j;
+        idx_to_ij(idx, k, i, j);
+        double v = sgn * x[2 * (int64_t)idx];
+        if (i == j) { v *= SQRT2; fro += v * v; }
+        else fro += 2.0 * v * v;
+        G[i + (size_t)j * ld] = v;
+        G[j + (size_t)i * ld] = v;
+    }
+    for (int e = tid; e < k * k; e += PSD_THREADS) {
+        const int i = e % k, j = e / k;
+        V[i + (size_t)j * ld] = (i == j) ? 1.0 : 0.0;
+    }
+    for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = fro;
+    __syncthreads();
+    if (tid == 0) red[4] = sqrt((red[0] + red[1]) + (red[2] + red[3]));
+    __syncthreads();
+    const double sigma = red[4];
+    for (int i = tid; i < k; i += PSD_THREADS) G[i + (size_t)i * ld] += sigma;
+    __syncthreads();
+
+    // ---- one-sided Jacobi sweeps
+    const int K = (k + 1) & ~1;               // even number of players (one bye when k is odd)
+    const int npair = K >> 1;
+    int tpp = 64;
+    while (tpp > 1 && npair * tpp > PSD_THREADS) tpp >>= 1;
+    const int sh = 31 - __clz(tpp);
+    const int slot = tid >> sh, lig = tid & (tpp - 1), nslot = PSD_THREADS >> sh;
+    const double tol = sqrt((double)k) * 2.220446049250313e-16;
+
+    if (k > 1 && sigma > 0.0) {
+        for (int sweep = 0; sweep < PSD_MAX_SWEEPS; ++sweep) {
+            int rotated = 0;
+            for (int step = 0; step < K - 1; ++step) {
+                for (int pr = slot; pr < npair; pr += nslot) {
+                    int p, q;
+                    if (pr == 0) { p = step % (K - 1); q = K - 1; }
+                    else { p = (step + pr) % (K - 1); q = (step + (K - 1) - pr) % (K - 1); }
+                    if (p >= k || q >= k) continue;       // bye (uniform within the lane group)
+                    double* gp = G + (size_t)p * ld;
+                    double* gq = G + (size_t)q * ld;
+                    double a = 0.0, b = 0.0, g = 0.0;
+                    for (int i = lig; i < k; i += tpp) {
+                        const double u = gp[i], v = gq[i];
+                        a += u * u; b += v * v; g += u * v;
+                    }
+                    a = group_sum(a, tpp); b = group_sum(b, tpp); g = group_sum(g, tpp);
+                    if (fabs(g) <= tol * sqrt(a * b)) continue;
+                    rotated = 1;
+                    const double zeta = (b - a) / (2.0 * g);
+                    const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                    double* vp = V + (size_t)p * ld;
+                    double* vq = V + (size_t)q * ld;
+                    for (int i = lig; i < k; i += tpp) {
+                        const double u = gp[i], v = gq[i];
+                        gp[i] = cs * u - sn * v;
+                        gq[i] = sn * u + cs * v;
+                        const double uu = vp[i], vv = vq[i];
+                        vp[i] = cs * uu - sn * vv;
+                        vq[i] = sn * uu + cs * vv;
+                    }
+                }
+                __syncthreads();
+            }
+            if (!__syncthreads_or(rotated)) break;
+        }
+    }
+
+    // ---- eigenvalues: lambda_j = ||g_j|| - sigma ; weights max(lambda_j, 0)
+    for (int j = tid; j < k; j += PSD_THREADS) {
+        double s = 0.0;
+        const double* gj = G + (size_t)j * ld;
+        for (int i = 0; i < k; ++i) s += gj[i] * gj[i];
+        const double lam = sqrt(s) - sigma;
+        wgt[j] = lam > 0.0 ? lam : 0.0;
+    }
+    __syncthreads();
+
+    // ---- rebuild the lower triangle of P = V diag(w) V', repack, unscale the diagonal; dual: y = x + P(-x)
+    for (int idx = tid; idx < len; idx += PSD_THREADS) {
+        int i, j;
+        idx_to_ij(idx, k, i, j);
+        double s = 0.0;
+        for (int t = 0; t < k; ++t) s += wgt[t] * V[i + (size_t)t * ld] * V[j + (size_t)t * ld];
+        if (i == j) s *= INV_SQRT2;
+        if (dual) s = x[2 * (int64_t)idx] + s;
+        y[2 * (int64_t)idx] = s;
+    }
+}
+
+size_t psd_scratch_bytes(int kmax, int ncones) {
+    if (ncones <= 0) return 0;
+    if (psd_lds_bytes(kmax) <= 160 * 1024 - 256) return 0;
+    return (size_t)2 * ncones * (size_t)(2 * kmax * psd_ld(kmax) + kmax + 16) * sizeof(double);
+}
+
+// cones must be sorted so that all of them can run with the same storage choice; the launcher splits the list by
+// whether the order fits in LDS.
+int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones, int kmax, double* gscratch) {
+    if (ncones <= 0) return FOS_OK;
+    const size_t lds = psd_lds_bytes(kmax);
+    const bool use_lds = lds <= 160 * 1024 - 256;
+    static bool attr_set = false;
+    if (use_lds && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(psd_kernel): %s", hipGetErrorString(e)); return FOS_EHIP; }
+        attr_set = true;
+    }
+    const size_t stride = (size_t)(2 * kmax * psd_ld(kmax) + kmax + 16);
+    if (use_lds)
+        hipLaunchKernelGGL(psd_kernel<true>, dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride);
+    else
+        hipLaunchKernelGGL(psd_kernel<false>, dim3(2 * ncones), dim3(PSD_THREADS), 16 * sizeof(double), c.stream, out, in, cones, gscratch, stride);
+    return FOS_OK;
+}
+
+}  // namespace fos

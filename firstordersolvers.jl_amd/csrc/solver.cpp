@@ -1,0 +1,908 @@
+// libfoship: handle life cycle, the device-resident CG driver, the GAP/GAPA/FISTA/Dykstra step loops, the status
+// check and the C ABI of include/foship.h.  Host C++ only orchestrates launches on ONE HIP stream; all data stays
+// in HBM between fos_create and fos_destroy (the only transfers are N doubles at set/get-iterate and ~100 bytes of
+// scalars per CG poll / convergence check).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "fos_internal.hpp"
+
+namespace fos {
+const char* last_error_cstr();
+
+typedef double2 d2;
+
+// ------------------------------------------------------------------------------------------------ RCCL via dlopen
+// (no link-time dependency: single-GPU users never load it; inside a torch process dlopen returns the copy torch
+// already mapped, so both share one RCCL instance)
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl g_rccl;
+
+static int rccl_load() {
+    if (g_rccl.lib) return FOS_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* nm : names) {
+        lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) { set_error("cannot dlopen librccl.so: %s", dlerror()); return FOS_ECOMM; }
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+        set_error("librccl.so lacks a required symbol");
+        return FOS_ECOMM;
+    }
+    g_rccl.lib = lib;
+    return FOS_OK;
+}
+
+#define FOS_NCCL(expr)                                                                                     \
+    do {                                                                                                   \
+        ncclResult_t _r = (expr);                                                                          \
+        if (_r != ncclSuccess) {                                                                           \
+            set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,                                        \
+                      g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error");                   \
+            return FOS_ECOMM;                                                                              \
+        }                                                                                                  \
+    } while (0)
+
+}  // namespace fos
+
+using namespace fos;
+
+// ------------------------------------------------------------------------------------------------ the handle
+struct fos_solver {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t m = 0, n = 0, l = 0, nnz = 0;
+    int64_t l_global = 0;                      // == l unless sharded (tolerance floor uses the global size)
+
+    // operator
+    HostBlkCsr hostS;                          // kept only for re-partitioning (indices freed after upload)
+    DevBlkCsr S{};
+    std::vector<void*> owned;                  // every hipMalloc'd pointer
+    double* cb = nullptr;
+    double nb = 0.0, nc = 0.0;                 // ||b||, ||c|| (global)
+
+    // vectors: l double2 each
+    d2 *X = nullptr, *T1 = nullptr, *T2 = nullptr;          // iterate, tmp1, tmp2
+    d2 *SOL = nullptr, *RHS = nullptr, *R = nullptr, *P = nullptr, *AP = nullptr;   // CG: xinit/y, rhs, r, p, z
+    d2 *Y = nullptr, *XOLD = nullptr;                       // FISTA y / xold ; Dykstra p / q
+    d2 *W = nullptr;                                        // scratch (Dykstra sums, test entries)
+    d2 *SOL2 = nullptr;                                     // HSDEMatrix.cgdata.xinit
+    double* plain = nullptr;                                // 2l doubles: ABI staging
+
+    // cones
+    uint8_t* ew_op = nullptr;
+    ConeDesc* soc = nullptr; int nsoc = 0;
+    ConeDesc* psd = nullptr; int npsd = 0; int psd_kmax = 0;
+    double* psd_scratch = nullptr;
+
+    // scalars
+    DevState* st = nullptr;
+    DevState* st_host = nullptr;               // pinned
+    double* partials = nullptr;
+    double* reduced = nullptr;                 // 16 doubles
+    int vec_blocks = 0;
+
+    // algorithm (gap.jl:6-21, gapa.jl:9-25, fista.jl:6-18, dykstra.jl:5-17)
+    int alg = FOS_ALG_GAP;
+    double alpha = 0.8, alpha1 = 1.8, alpha2 = 1.8, beta = 0.0;
+    double fista_t = 1.0;
+
+    // S1 = AffinePlusLinear state (affinepluslinear.jl:58-69)
+    int64_t prox_i = 1;
+    bool firstrun = true;
+    int64_t cgiter = 0;
+    int hit_max_accum = 0;
+    bool firstrun2 = true;                     // HSDEMatrix.cgdata.firstrun
+    int last_cg_pred = 0;
+    const d2* last_checked = nullptr;          // vector the last checkstatus was evaluated on
+
+    // sharding
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+
+    // tuning / measurement
+    int cg_chunk = 8;
+    int nwg_target = 2048;
+    bool prof = false;
+    std::vector<hipEvent_t> ev;                // pairs
+    size_t ev_used = 0;
+    static constexpr size_t EV_CAP = 2 * 16384;
+
+    LaunchCtx ctx() const {
+        LaunchCtx c;
+        c.stream = stream; c.S = S; c.cb = cb; c.n = n; c.m = m; c.l = l; c.st = st;
+        c.partials = partials; c.reduced = reduced; c.vec_blocks = vec_blocks;
+        return c;
+    }
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(fos_solver* h, T** p, size_t count) {
+    void* q = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) { set_error("hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); return FOS_ENOMEM; }
+    h->owned.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return FOS_OK;
+}
+
+template <class T>
+int dev_upload(fos_solver* h, T** p, const std::vector<T>& v) {
+    FOS_TRY(dev_alloc(h, p, v.size()));
+    if (!v.empty()) FOS_HIP(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return FOS_OK;
+}
+
+int psd_order(int64_t len) {
+    int64_t k = (int64_t)std::llround(std::sqrt(0.25 + 2.0 * (double)len) - 0.5);
+    if (k * (k + 1) / 2 != len) return -1;
+    return (int)k;
+}
+
+// all-reduce of `count` doubles in h->reduced (in place, in stream) when sharded
+int allreduce(fos_solver* h, int count) {
+    if (!h->comm) return FOS_OK;
+    FOS_NCCL(g_rccl.AllReduce(h->reduced, h->reduced, (size_t)count, ncclDouble, ncclSum, h->comm, h->stream));
+    return FOS_OK;
+}
+
+// partials[count][nacc] --(sharded: local reduce + all-reduce)--> returns from_reduced flag for the finalize kernel
+int finish_reduce(fos_solver* h, const LaunchCtx& c, int count, int nacc, int gate, int* from_reduced) {
+    if (!h->comm) { *from_reduced = 0; return FOS_OK; }
+    launch_reduce1(c, count, nacc, gate);
+    FOS_TRY(allreduce(h, nacc));
+    *from_reduced = 1;
+    return FOS_OK;
+}
+
+int poll_state(fos_solver* h) {
+    FOS_HIP(hipMemcpyAsync(h->st_host, h->st, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    return FOS_OK;
+}
+
+int kkt_apply_full(fos_solver* h, const LaunchCtx& c, const d2* w, d2* out, int mode, int gate) {
+    bool rec = h->prof && mode == 1 && h->ev_used + 2 <= fos_solver::EV_CAP;
+    if (rec) {
+        while (h->ev.size() < h->ev_used + 2) {
+            hipEvent_t e;
+            FOS_HIP(hipEventCreate(&e));
+            h->ev.push_back(e);
+        }
+        FOS_HIP(hipEventRecord(h->ev[h->ev_used], h->stream));
+    }
+    launch_kkt2(c, w, out, gate);
+    if (rec) {
+        FOS_HIP(hipEventRecord(h->ev[h->ev_used + 1], h->stream));
+        h->ev_used += 2;
+    }
+    int fr = 0;
+    FOS_TRY(finish_reduce(h, c, c.S.nwg, 3, gate, &fr));
+    launch_kkt_finalize(c, w, out, mode, gate, fr);
+    return FOS_OK;
+}
+
+// conjugategradient!(x, KKTMatrix(Q), rhs, r, p, Ap; tol, max_iters)      conjugategradients.jl:31-55
+int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t* iters) {
+    LaunchCtx c = h->ctx();
+    int fr = 0;
+    FOS_TRY(kkt_apply_full(h, c, x, h->AP, 0, 0));                     // :32  mul!(Ap, A, x)
+    launch_cg_init(c, rhs, h->AP, h->R, h->P);                         // :33-34
+    FOS_TRY(finish_reduce(h, c, c.vec_blocks, 1, 0, &fr));
+    launch_cg_init_finalize(c, h->R, tol, maxit, fr);                  // :35-36
+    auto enqueue = [&](int count) -> int {
+        for (int j = 0; j < count; ++j) {
+            FOS_TRY(kkt_apply_full(h, c, h->P, h->AP, 1, 1));          // :38-39
+            launch_cg_update(c, x, h->R, h->P, h->AP);                 // :40-41
+            int f2 = 0;
+            FOS_TRY(finish_reduce(h, c, c.vec_blocks, 1, 1, &f2));
+            launch_cg_update_finalize(c, h->R, f2);                    // :42-47,51
+            launch_cg_pupdate(c, h->P, h->R);                          // :49-50
+        }
+        return FOS_OK;
+    };
+    int first = h->last_cg_pred > 0 ? h->last_cg_pred + 2 : h->cg_chunk;
+    first = std::max(1, std::min(first, maxit));
+    FOS_TRY(enqueue(first));
+    FOS_TRY(poll_state(h));
+    while (!h->st_host->done) {
+        FOS_TRY(enqueue(h->cg_chunk));
+        FOS_TRY(poll_state(h));
+    }
+    *iters = h->st_host->iter;
+    h->last_cg_pred = h->st_host->iter;
+    if (h->st_host->hit_max) h->hit_max_accum = 1;
+    return FOS_OK;
+}
+
+// prox!(y, S1::AffinePlusLinear, x) with the result left in h->SOL       affinepluslinear.jl:83-126
+int prox_affine(fos_solver* h, const d2* x) {
+    LaunchCtx c = h->ctx();
+    int fr = 0;
+    launch_q1(c, Q_RHS, x, 1, 1.0, h->RHS);                            // :94-95
+    FOS_TRY(finish_reduce(h, c, c.S.nwg, 1, 0, &fr));
+    launch_q1_finalize(c, Q_RHS, x, 1, 1.0, h->RHS, fr);
+    if (h->firstrun) {                                                  // :101-104
+        FOS_HIP(hipMemcpyAsync(h->SOL, x, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));
+        h->firstrun = false;
+    }
+    // :108-112   tol = max(0.2^sqrt(i), size(A,2)*eps())
+    const double eps = 2.220446049250313e-16;
+    double tol = std::max(std::pow(0.2, std::sqrt((double)h->prox_i)), (double)h->l_global * eps);
+    h->prox_i += 1;                                                     // :114
+    int64_t it = 0;
+    FOS_TRY(cg_solve(h, h->SOL, h->RHS, tol, 1000, &it));               // :115-117 ; y aliases xinit (:106,:122)
+    h->cgiter = it;                                                     // :121
+    return FOS_OK;                                                      // :124 y2 .*= beta with beta = 1
+}
+
+// prox!(y, S2::DualConeProduct, x)                                        cones.jl:122-142
+int prox_cones(fos_solver* h, d2* out, const d2* in) {
+    LaunchCtx c = h->ctx();
+    launch_cones_elementwise(c, out, in, h->ew_op);
+    launch_cones_soc(c, out, in, h->soc, h->nsoc);
+    FOS_TRY(launch_cones_psd(c, out, in, h->psd, h->npsd, h->psd_kmax, h->psd_scratch));
+    return FOS_OK;
+}
+
+// checkstatus(status, z, override=true) values + decision               HSDEStatus.jl:27-63
+int status_check(fos_solver* h, const d2* z, double eps, fos_check_result* res) {
+    LaunchCtx c = h->ctx();
+    int fr = 0;
+    launch_q1(c, Q_STATUS, z, 0, 1.0, nullptr);
+    FOS_TRY(finish_reduce(h, c, c.S.nwg, 6, 0, &fr));
+    launch_status_finalize(c, z, fr);
+    FOS_TRY(poll_state(h));
+    const double* s = h->st_host->stat;
+    const double tau = s[ST_TAU], kappa = s[ST_KAPPA];
+    const double nb = h->nb, nc = h->nc;
+    const double ctx = s[ST_CTX], bty = s[ST_BTY];
+    res->p = std::sqrt(s[ST_RP2]) / std::fabs(1 + nb);                                   // :34
+    res->d = std::sqrt(s[ST_RD2]) / std::fabs(1 + nc);                                   // :35
+    res->ctx = ctx;                                                                      // :36
+    res->bty = bty;                                                                      // :37
+    res->g = std::fabs(ctx / tau + bty / tau) / (1 + std::fabs(ctx / tau) + std::fabs(bty / tau));   // :38
+    res->kappa = kappa;
+    res->tau = tau;
+    res->norm_axs = std::sqrt(s[ST_AXS2]);
+    res->norm_aty = std::sqrt(s[ST_ATY2]);
+    res->norm_b = nb;
+    res->norm_c = nc;
+    res->cgiter = h->cgiter;
+    res->cg_maxiter_hit = h->hit_max_accum;
+    h->hit_max_accum = 0;
+    int status = FOS_STATUS_CONTINUE;                                                    // :53-63
+    if (res->p <= eps * (1 + nb) && res->d <= eps * (1 + nc) &&
+        res->g <= eps * (1 + std::fabs(ctx / tau) + std::fabs(bty / tau))) {
+        status = FOS_STATUS_OPTIMAL;
+    } else if (res->norm_axs <= eps * (-ctx / nc)) {
+        status = FOS_STATUS_UNBOUNDED;
+    } else if (res->norm_aty <= eps * (-bty / nb)) {
+        status = FOS_STATUS_INFEASIBLE;
+    }
+    res->status = status;
+    return FOS_OK;
+}
+
+// one outer iteration; *check_on receives the vector checkstatus is evaluated on (the cone-feasible point)
+int step_once(fos_solver* h, int64_t i, const d2** check_on) {
+    LaunchCtx c = h->ctx();
+    switch (h->alg) {
+        case FOS_ALG_GAP: {                                              // gap.jl:61-80
+            FOS_TRY(prox_affine(h, h->X));                               // S1!: prox!(y,S1,x)          :45
+            launch_axpby(c, h->T1, h->alpha1, h->SOL, 1 - h->alpha1, h->X);   //   y = a1 y + (1-a1) x     :48
+            FOS_TRY(prox_cones(h, h->T2, h->T1));                        // S2!: prox!(y,S2,x)          :55
+            *check_on = h->T2;                                           //   checkstatus(status, y)    :56
+            return FOS_OK;
+        }
+        case FOS_ALG_GAPA: {                                             // gapa.jl:80-105
+            FOS_TRY(prox_affine(h, h->X));
+            launch_relax_a12(c, h->T1, h->SOL, h->X);                    // :67
+            FOS_TRY(prox_cones(h, h->T2, h->T1));
+            *check_on = h->T2;                                           // :75
+            return FOS_OK;
+        }
+        case FOS_ALG_FISTA: {                                            // fista.jl:28-48
+            if (i == 1) FOS_HIP(hipMemcpyAsync(h->Y, h->X, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));   // :31-33
+            FOS_TRY(prox_affine(h, h->Y));                               // :35
+            launch_axpby(c, h->T1, h->alpha, h->SOL, 1 - h->alpha, h->Y);     // :37
+            FOS_HIP(hipMemcpyAsync(h->XOLD, h->X, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));           // :39
+            FOS_TRY(prox_cones(h, h->X, h->T1));                         // :40
+            *check_on = h->X;                                            // :41
+            return FOS_OK;
+        }
+        case FOS_ALG_DYKSTRA: {                                          // dykstra.jl:25-36   (p = Y, q = XOLD)
+            launch_add(c, h->W, h->X, h->Y);                             // x .+ p
+            FOS_TRY(prox_affine(h, h->W));                               // prox!(y, S1, x .+ p)        :28
+            launch_dykstra_corr(c, h->Y, h->X, h->SOL);                  // p .= x .+ p .- y            :30
+            launch_add(c, h->W, h->SOL, h->XOLD);                        // y .+ q
+            FOS_TRY(prox_cones(h, h->X, h->W));                          // prox!(x, S2, y .+ q)        :31
+            *check_on = h->X;                                            // :32
+            return FOS_OK;
+        }
+    }
+    set_error("unknown algorithm %d", h->alg);
+    return FOS_EINVAL;
+}
+
+// the part of the step after checkstatus
+int step_finish(fos_solver* h) {
+    LaunchCtx c = h->ctx();
+    switch (h->alg) {
+        case FOS_ALG_GAP:
+            launch_gap_final(c, h->X, h->T2, h->T1, h->alpha, h->alpha2);          // gap.jl:58,78
+            return FOS_OK;
+        case FOS_ALG_GAPA: {
+            launch_gapa_final(c, h->X, h->T2, h->T1, h->alpha);                    // gapa.jl:77,96,103
+            int fr = 0;
+            FOS_TRY(finish_reduce(h, c, c.vec_blocks, 3, 0, &fr));
+            launch_gapa_finalize(c, h->beta, nullptr, fr);                         // gapa.jl:96-101
+            return FOS_OK;
+        }
+        case FOS_ALG_FISTA: {
+            const double told = h->fista_t;                                        // fista.jl:44-46
+            h->fista_t = (1 + std::sqrt(1 + 4 * told * told)) / 2;
+            launch_fista_extrap(c, h->Y, h->X, h->XOLD, (told - 1) / h->fista_t);
+            return FOS_OK;
+        }
+        case FOS_ALG_DYKSTRA:
+            launch_dykstra_corr(c, h->XOLD, h->SOL, h->X);                         // q .= y .+ q .- x   dykstra.jl:34
+            return FOS_OK;
+    }
+    return FOS_EINVAL;
+}
+
+int upload_plain(fos_solver* h, d2* dst, const double* z) {
+    LaunchCtx c = h->ctx();
+    FOS_HIP(hipMemcpyAsync(h->plain, z, sizeof(double) * 2 * h->l, hipMemcpyHostToDevice, h->stream));
+    launch_interleave(c, dst, h->plain);
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    return FOS_OK;
+}
+int download_plain(fos_solver* h, double* z, const d2* src) {
+    LaunchCtx c = h->ctx();
+    launch_deinterleave(c, h->plain, src);
+    FOS_HIP(hipMemcpyAsync(z, h->plain, sizeof(double) * 2 * h->l, hipMemcpyDeviceToHost, h->stream));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    return FOS_OK;
+}
+
+int validate_cones(const char* which, int64_t total, int64_t nK, const int32_t* type, const int64_t* start, const int64_t* len) {
+    int64_t prev_end = 0;                                   // cones.jl:66-72
+    for (int64_t i = 0; i < nK; ++i) {
+        if (start[i] != prev_end + 1) { set_error("%s cone %lld: range starts at %lld, expected %lld (ranges must be contiguous and ordered)", which, (long long)i + 1, (long long)start[i], (long long)prev_end + 1); return FOS_EINVAL; }
+        if (len[i] < 1) { set_error("%s cone %lld: empty range", which, (long long)i + 1); return FOS_EINVAL; }
+        prev_end = start[i] + len[i] - 1;
+        switch (type[i]) {
+            case FOS_CONE_FREE: case FOS_CONE_ZERO: case FOS_CONE_NONNEG: case FOS_CONE_NONPOS: case FOS_CONE_SOC: break;
+            case FOS_CONE_SOCROT:
+                if (len[i] < 2) { set_error("%s cone %lld: rotated SOC needs >= 2 entries", which, (long long)i + 1); return FOS_EINVAL; }
+                break;
+            case FOS_CONE_SDP:
+                if (psd_order(len[i]) < 0) { set_error("%s cone %lld: SDP length %lld is not k(k+1)/2", which, (long long)i + 1, (long long)len[i]); return FOS_EINVAL; }
+                break;
+            case FOS_CONE_EXPPRIMAL: case FOS_CONE_EXPDUAL:
+                set_error("%s cone %lld: exponential cones are not implemented by the HIP path", which, (long long)i + 1);
+                return FOS_EUNSUPPORTED;
+            default:
+                set_error("%s cone %lld: unknown cone code %d", which, (long long)i + 1, (int)type[i]);
+                return FOS_EINVAL;
+        }
+    }
+    if (prev_end != total) { set_error("%s cones cover 1..%lld, expected 1..%lld", which, (long long)prev_end, (long long)total); return FOS_EINVAL; }
+    return FOS_OK;
+}
+
+void add_cones(int64_t offset, bool is_K1, int64_t nK, const int32_t* type, const int64_t* start, const int64_t* len,
+               std::vector<uint8_t>& ew, std::vector<ConeDesc>& soc, std::vector<ConeDesc>& psd) {
+    // K2 cone on [x | r]: part1 primal, part2 dual.   K1 cone on [y | s]: part1 dual, part2 primal.   cones.jl:136-140
+    for (int64_t i = 0; i < nK; ++i) {
+        const int64_t s0 = offset + start[i] - 1;
+        uint8_t prim = 0, dual = 0;
+        bool ewise = true;
+        switch (type[i]) {
+            case FOS_CONE_FREE: prim = EW_COPY; dual = EW_ZERO; break;      // cones.jl:100
+            case FOS_CONE_ZERO: prim = EW_ZERO; dual = EW_COPY; break;      // cones.jl:98
+            case FOS_CONE_NONNEG: prim = dual = EW_MAX0; break;             // cones.jl:101
+            case FOS_CONE_NONPOS: prim = dual = EW_MIN0; break;             // cones.jl:102
+            default: ewise = false;
+        }
+        if (ewise) {
+            const uint8_t op = is_K1 ? (uint8_t)(dual | (prim << 2)) : (uint8_t)(prim | (dual << 2));
+            for (int64_t k = 0; k < len[i]; ++k) ew[s0 + k] = op;
+        } else {
+            for (int64_t k = 0; k < len[i]; ++k) ew[s0 + k] = EW_SKIP;
+            ConeDesc cd;
+            cd.start = s0; cd.len = (int32_t)len[i]; cd.type = type[i];
+            cd.dual_part = is_K1 ? 0 : 1;
+            cd.k = type[i] == FOS_CONE_SDP ? psd_order(len[i]) : 0;
+            (type[i] == FOS_CONE_SDP ? psd : soc).push_back(cd);
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int fos_abi_version(void) { return FOS_ABI_VERSION; }
+const char* fos_last_error(void) { return fos::last_error_cstr(); }
+
+int fos_device_count(int* count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        if (count) *count = 0;
+        set_error("no HIP device visible (%s): libfoship has no CPU fallback", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return FOS_ENODEVICE;
+    }
+    if (count) *count = n;
+    return FOS_OK;
+}
+
+int fos_device_name(int device, char* buf, int buflen) {
+    hipDeviceProp_t prop;
+    FOS_HIP(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return FOS_OK;
+}
+
+int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+               const double* b, const double* c,
+               int64_t nK1, const int32_t* K1type, const int64_t* K1start, const int64_t* K1len,
+               int64_t nK2, const int32_t* K2type, const int64_t* K2start, const int64_t* K2len,
+               int device, fos_handle* out) {
+    if (!out) { set_error("out handle is NULL"); return FOS_EINVAL; }
+    *out = nullptr;
+    if (m < 0 || n < 0 || !colptr || (!rowval && colptr[n] > 1) || (!b && m) || (!c && n)) { set_error("NULL or negative argument"); return FOS_EINVAL; }
+    int ndev = 0;
+    FOS_TRY(fos_device_count(&ndev));
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (0..%d)", device, ndev - 1); return FOS_EINVAL; }
+    FOS_TRY(validate_cones("K1", m, nK1, K1type, K1start, K1len));
+    FOS_TRY(validate_cones("K2", n, nK2, K2type, K2start, K2len));
+    FOS_HIP(hipSetDevice(device));
+
+    struct Guard {                       // frees everything on an early error return
+        fos_solver* h;
+        ~Guard() { if (h) fos_destroy(h); }
+    } guard{new fos_solver()};
+    fos_solver* h = guard.h;
+    h->device = device;
+    h->m = m; h->n = n; h->l = n + m + 1; h->l_global = h->l;
+    h->nnz = colptr[n] - 1;
+    FOS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+
+    hipDeviceProp_t prop;
+    FOS_HIP(hipGetDeviceProperties(&prop, device));
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("FOS_SPMV_WG")) h->nwg_target = std::max(1, atoi(e));
+    else h->nwg_target = cus * 8;
+
+    // ---- operator
+    HostBlkCsr& hs = h->hostS;
+    FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, h->nwg_target, &hs));
+    double* dval; int32_t* dcol; int32_t* dbr; int64_t* dn0; int64_t* dn1; uint16_t* drr; int32_t* dwg;
+    FOS_TRY(dev_upload(h, &dval, hs.val));
+    FOS_TRY(dev_upload(h, &dcol, hs.col));
+    FOS_TRY(dev_upload(h, &dbr, hs.blk_row0));
+    FOS_TRY(dev_upload(h, &dn0, hs.blk_nnz0));
+    FOS_TRY(dev_upload(h, &dn1, hs.blk_nnz1));
+    FOS_TRY(dev_upload(h, &drr, hs.row_rel));
+    // room for re-partitioning up to 16384 workgroups
+    {
+        std::vector<int32_t> wg(std::max<size_t>(hs.wg_blk0.size(), 16385 + 8), 0);
+        std::copy(hs.wg_blk0.begin(), hs.wg_blk0.end(), wg.begin());
+        FOS_TRY(dev_upload(h, &dwg, wg));
+    }
+    h->S.nrows = hs.nrows; h->S.nnz = hs.nnz; h->S.nnz_padded = hs.nnz_padded;
+    h->S.val = dval; h->S.col = dcol; h->S.blk_row0 = dbr; h->S.blk_nnz0 = dn0; h->S.blk_nnz1 = dn1;
+    h->S.row_rel = drr; h->S.wg_blk0 = dwg; h->S.nblk = hs.nblk; h->S.nwg = hs.nwg;
+    // free the big host arrays (keep block table for re-partitioning)
+    std::vector<double>().swap(hs.val);
+    std::vector<int32_t>().swap(hs.col);
+    std::vector<uint16_t>().swap(hs.row_rel);
+
+    std::vector<double> cbv((size_t)(n + m));
+    double nb2 = 0, nc2 = 0;
+    for (int64_t j = 0; j < n; ++j) { cbv[j] = c[j]; }
+    for (int64_t i = 0; i < m; ++i) { cbv[n + i] = b[i]; }
+    // norm(b), norm(c): plain sums of squares (values are O(1)-scaled problem data)
+    for (int64_t j = 0; j < n; ++j) nc2 += c[j] * c[j];
+    for (int64_t i = 0; i < m; ++i) nb2 += b[i] * b[i];
+    h->nb = std::sqrt(nb2); h->nc = std::sqrt(nc2);
+    FOS_TRY(dev_upload(h, &h->cb, cbv));
+
+    // ---- vectors
+    const size_t l = (size_t)h->l;
+    d2** vecs[] = {&h->X, &h->T1, &h->T2, &h->SOL, &h->RHS, &h->R, &h->P, &h->AP, &h->Y, &h->XOLD, &h->W, &h->SOL2};
+    for (d2** v : vecs) {
+        FOS_TRY(dev_alloc(h, v, l));
+        FOS_HIP(hipMemset(*v, 0, sizeof(d2) * l));
+    }
+    FOS_TRY(dev_alloc(h, &h->plain, 2 * l));
+    h->vec_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((h->l + 255) / 256, 1024));
+
+    // ---- cones
+    std::vector<uint8_t> ew(l, 0);
+    std::vector<ConeDesc> soc, psd;
+    add_cones(0, false, nK2, K2type, K2start, K2len, ew, soc, psd);
+    add_cones(n, true, nK1, K1type, K1start, K1len, ew, soc, psd);
+    ew[l - 1] = (uint8_t)(EW_MAX0 | (EW_MAX0 << 2));            // tau, kappa  cones.jl:138,141
+    FOS_TRY(dev_upload(h, &h->ew_op, ew));
+    h->nsoc = (int)soc.size();
+    h->npsd = (int)psd.size();
+    FOS_TRY(dev_upload(h, &h->soc, soc));
+    for (auto& cd : psd) h->psd_kmax = std::max(h->psd_kmax, cd.k);
+    FOS_TRY(dev_upload(h, &h->psd, psd));
+    size_t sb = psd_scratch_bytes(h->psd_kmax, h->npsd);
+    if (sb) FOS_TRY(dev_alloc(h, &h->psd_scratch, sb / sizeof(double)));
+
+    // ---- scalars
+    FOS_TRY(dev_alloc(h, &h->st, 1));
+    FOS_HIP(hipMemset(h->st, 0, sizeof(DevState)));
+    FOS_HIP(hipHostMalloc((void**)&h->st_host, sizeof(DevState), hipHostMallocDefault));
+    memset(h->st_host, 0, sizeof(DevState));
+    FOS_TRY(dev_alloc(h, &h->partials, (size_t)6 * 16392));
+    FOS_TRY(dev_alloc(h, &h->reduced, 16));
+    FOS_HIP(hipMemset(h->reduced, 0, sizeof(double) * 16));
+    if (const char* e = getenv("FOS_CG_CHUNK")) h->cg_chunk = std::max(1, atoi(e));
+
+    FOS_TRY(fos_set_alg(h, FOS_ALG_GAP, 0.8, 1.8, 1.8, 0.0));
+    FOS_TRY(fos_set_iterate(h, nullptr));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    *out = h;
+    guard.h = nullptr;
+    return FOS_OK;
+}
+
+int fos_destroy(fos_handle h) {
+    if (!h) return FOS_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    for (void* p : h->owned) (void)hipFree(p);
+    if (h->st_host) (void)hipHostFree(h->st_host);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return FOS_OK;
+}
+
+int fos_sizes(fos_handle h, int64_t* m, int64_t* n, int64_t* N, int64_t* nnz) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    if (m) *m = h->m;
+    if (n) *n = h->n;
+    if (N) *N = 2 * h->l;
+    if (nnz) *nnz = h->nnz;
+    return FOS_OK;
+}
+
+int fos_comm_get_unique_id(void* id128) {
+    FOS_TRY(rccl_load());
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    FOS_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return FOS_OK;
+}
+
+int fos_comm_init(fos_handle h, int nranks, int rank, const void* id128) {
+    if (!h || nranks < 1 || rank < 0 || rank >= nranks) { set_error("bad comm arguments"); return FOS_EINVAL; }
+    FOS_TRY(rccl_load());
+    FOS_HIP(hipSetDevice(h->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    FOS_NCCL(g_rccl.CommInitRank(&h->comm, nranks, id, rank));
+    h->nranks = nranks; h->rank = rank;
+    // global size and norms: all-reduce [n+m, ||b||^2, ||c||^2]
+    double loc[3] = {(double)(h->n + h->m), h->nb * h->nb, h->nc * h->nc};
+    FOS_HIP(hipMemcpyAsync(h->reduced, loc, sizeof(loc), hipMemcpyHostToDevice, h->stream));
+    FOS_TRY(allreduce(h, 3));
+    FOS_HIP(hipMemcpyAsync(loc, h->reduced, sizeof(loc), hipMemcpyDeviceToHost, h->stream));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    h->l_global = (int64_t)std::llround(loc[0]) + 1;
+    h->nb = std::sqrt(loc[1]);
+    h->nc = std::sqrt(loc[2]);
+    return FOS_OK;
+}
+
+int fos_set_alg(fos_handle h, int alg, double alpha, double alpha1, double alpha2, double beta) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    if (alg < FOS_ALG_GAP || alg > FOS_ALG_DYKSTRA) { set_error("unknown algorithm %d", alg); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    h->alg = alg; h->alpha = alpha; h->alpha1 = alpha1; h->alpha2 = alpha2; h->beta = beta;
+    h->fista_t = 1.0;                                                   // fista.jl:24
+    // fresh *Data: alpha12 = 2.0 (gapa.jl:29); y = xold = 0 (fista.jl:24); p = q = 0 (dykstra.jl:21)
+    DevState z;
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    FOS_HIP(hipMemcpy(&z, h->st, sizeof(DevState), hipMemcpyDeviceToHost));
+    z.alpha12 = 2.0;
+    z.gapa_scl = 0.0;
+    FOS_HIP(hipMemcpy(h->st, &z, sizeof(DevState), hipMemcpyHostToDevice));
+    FOS_HIP(hipMemsetAsync(h->Y, 0, sizeof(d2) * h->l, h->stream));
+    FOS_HIP(hipMemsetAsync(h->XOLD, 0, sizeof(d2) * h->l, h->stream));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    return FOS_OK;
+}
+
+int fos_reset_affine(fos_handle h) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    h->prox_i = 1; h->firstrun = true; h->cgiter = 0; h->hit_max_accum = 0; h->last_cg_pred = 0;
+    h->firstrun2 = true;
+    return FOS_OK;
+}
+
+int fos_set_iterate(fos_handle h, const double* z) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    if (z) return upload_plain(h, h->X, z);
+    // HSDE_getinitialvalue: zeros, tau = kappa = 1     HSDE.jl:40-47
+    FOS_HIP(hipMemsetAsync(h->X, 0, sizeof(d2) * h->l, h->stream));
+    const d2 one = make_double2(1.0, 1.0);
+    FOS_HIP(hipMemcpyAsync(h->X + (h->l - 1), &one, sizeof(d2), hipMemcpyHostToDevice, h->stream));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    return FOS_OK;
+}
+
+int fos_get_iterate(fos_handle h, double* z) {
+    if (!h || !z) { set_error("NULL argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    return download_plain(h, z, h->X);
+}
+
+int fos_get_checked(fos_handle h, double* z) {
+    if (!h || !z) { set_error("NULL argument"); return FOS_EINVAL; }
+    if (!h->last_checked) { set_error("no convergence check has run yet"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    return download_plain(h, z, h->last_checked);
+}
+
+int fos_step(fos_handle h, int64_t i_first, int64_t count, int64_t checki, double eps,
+             int64_t* iters_done, int32_t* checked, fos_check_result* res) {
+    if (!h || checki < 1 || count < 0) { set_error("bad fos_step arguments"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    if (checked) *checked = 0;
+    int64_t done = 0;
+    for (int64_t i = i_first; done < count; ++i) {
+        const d2* check_on = nullptr;
+        FOS_TRY(step_once(h, i, &check_on));
+        const bool do_check = (i % checki) == 0;                         // HSDEStatus.jl:28
+        fos_check_result r;
+        if (do_check) {
+            FOS_TRY(status_check(h, check_on, eps, &r));
+            h->last_checked = check_on;
+        }
+        FOS_TRY(step_finish(h));
+        ++done;
+        if (do_check) {
+            if (res) *res = r;
+            if (checked) *checked = 1;
+            break;
+        }
+    }
+    if (iters_done) *iters_done = done;
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    return FOS_OK;
+}
+
+int fos_getsol(fos_handle h, double* z_out, int32_t force_check, double eps, fos_check_result* res) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FOS_TRY(prox_affine(h, h->X));                       // prox!(tmp1, S1, x)
+    FOS_TRY(prox_cones(h, h->T2, h->SOL));               // prox!(tmp2, S2, tmp1)
+    if (force_check && res) {                                              // solverwrapper.jl:32-34
+        FOS_TRY(status_check(h, h->T2, eps, res));
+        h->last_checked = h->T2;
+    }
+    if (z_out) FOS_TRY(download_plain(h, z_out, h->T2));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    return FOS_OK;
+}
+
+int fos_get_cgiter(fos_handle h, int64_t* cgiter) {
+    if (!h || !cgiter) { set_error("NULL argument"); return FOS_EINVAL; }
+    *cgiter = h->cgiter;
+    return FOS_OK;
+}
+
+int fos_get_alpha12(fos_handle h, double* a) {
+    if (!h || !a) { set_error("NULL argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FOS_TRY(poll_state(h));
+    *a = h->st_host->alpha12;
+    return FOS_OK;
+}
+
+int fos_get_prox_count(fos_handle h, int64_t* i) {
+    if (!h || !i) { set_error("NULL argument"); return FOS_EINVAL; }
+    *i = h->prox_i;
+    return FOS_OK;
+}
+
+// ---- fine-grained entries ----------------------------------------------------------------------------
+
+int fos_q_apply(fos_handle h, double* y, const double* x, int32_t transpose) {
+    if (!h || !y || !x) { set_error("NULL argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    LaunchCtx c = h->ctx();
+    const size_t l = (size_t)h->l;
+    FOS_HIP(hipMemcpyAsync(h->plain, x, sizeof(double) * l, hipMemcpyHostToDevice, h->stream));
+    launch_set_comp(c, h->W, h->plain, 0);
+    const double sign = transpose ? -1.0 : 1.0;           // HSDEAffine.jl:61-65
+    int fr = 0;
+    launch_q1(c, Q_PLAIN, h->W, 0, sign, h->plain + l);
+    FOS_TRY(finish_reduce(h, c, c.S.nwg, 1, 0, &fr));
+    launch_q1_finalize(c, Q_PLAIN, h->W, 0, sign, h->plain + l, fr);
+    FOS_HIP(hipMemcpyAsync(y, h->plain + l, sizeof(double) * l, hipMemcpyDeviceToHost, h->stream));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    return FOS_OK;
+}
+
+int fos_kkt_apply(fos_handle h, double* y, const double* x) {
+    if (!h || !y || !x) { set_error("NULL argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    LaunchCtx c = h->ctx();
+    FOS_TRY(upload_plain(h, h->W, x));
+    FOS_TRY(kkt_apply_full(h, c, h->W, h->AP, 0, 0));
+    return download_plain(h, y, h->AP);
+}
+
+int fos_cg_kkt(fos_handle h, double* x, const double* rhs, double tol, int64_t max_iters, int64_t* iters) {
+    if (!h || !x || !rhs || max_iters < 1) { set_error("bad argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FOS_TRY(upload_plain(h, h->W, x));
+    FOS_TRY(upload_plain(h, h->RHS, rhs));
+    int64_t it = 0;
+    int pred = h->last_cg_pred;
+    h->last_cg_pred = 0;
+    FOS_TRY(cg_solve(h, h->W, h->RHS, tol, (int)std::min<int64_t>(max_iters, INT32_MAX), &it));
+    h->last_cg_pred = pred;
+    if (iters) *iters = it;
+    return download_plain(h, x, h->W);
+}
+
+int fos_prox_affine(fos_handle h, double* y, const double* x) {
+    if (!h || !y || !x) { set_error("NULL argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FOS_TRY(upload_plain(h, h->W, x));
+    FOS_TRY(prox_affine(h, h->W));
+    return download_plain(h, y, h->SOL);
+}
+
+int fos_hsdematrix_prox(fos_handle h, double* y, const double* x) {
+    if (!h || !y || !x) { set_error("NULL argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    LaunchCtx c = h->ctx();
+    FOS_TRY(upload_plain(h, h->RHS, x));                               // rhs = x   HSDEAffine.jl:116
+    if (h->firstrun2) {                                                // :109-112
+        FOS_HIP(hipMemcpyAsync(h->SOL2, h->RHS, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));
+        h->firstrun2 = false;
+    }
+    const double eps = 2.220446049250313e-16;
+    const double tol = (double)(2 * h->l_global) * eps;                // :106
+    int64_t it = 0;
+    int pred = h->last_cg_pred;
+    h->last_cg_pred = 0;
+    FOS_TRY(cg_solve(h, h->SOL2, h->RHS, tol, 1000, &it));             // :116 ; xinit .= y :119
+    h->last_cg_pred = pred;
+    h->cgiter = it;
+    // v = Q*u                                                          :122-124
+    int fr = 0;
+    launch_q1(c, Q_VFROMU, h->SOL2, 0, 1.0, h->W);
+    FOS_TRY(finish_reduce(h, c, c.S.nwg, 1, 0, &fr));
+    launch_q1_finalize(c, Q_VFROMU, h->SOL2, 0, 1.0, h->W, fr);
+    return download_plain(h, y, h->W);
+}
+
+int fos_prox_cones(fos_handle h, double* y, const double* x) {
+    if (!h || !y || !x) { set_error("NULL argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FOS_TRY(upload_plain(h, h->W, x));
+    FOS_TRY(prox_cones(h, h->T2, h->W));
+    return download_plain(h, y, h->T2);
+}
+
+int fos_check(fos_handle h, const double* z, double eps, fos_check_result* res) {
+    if (!h || !z || !res) { set_error("NULL argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FOS_TRY(upload_plain(h, h->W, z));
+    return status_check(h, h->W, eps, res);
+}
+
+// ---- measurement -------------------------------------------------------------------------------------
+
+int fos_profile(fos_handle h, int32_t enable) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    h->prof = enable != 0;
+    return FOS_OK;
+}
+
+static double kkt_bytes(const fos_solver* h) {
+    // B_kkt,min = 24 nnz + 4(m+n+2) + 32(m+n)
+    return 24.0 * (double)h->nnz + 4.0 * (double)(h->m + h->n + 2) + 32.0 * (double)(h->m + h->n);
+}
+
+int fos_profile_read(fos_handle h, int64_t* launches, double* total_ms, double* bytes_per_launch) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        float ms = 0.f;
+        FOS_HIP(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        tot += ms;
+    }
+    if (launches) *launches = (int64_t)(h->ev_used / 2);
+    if (total_ms) *total_ms = tot;
+    if (bytes_per_launch) *bytes_per_launch = kkt_bytes(h);
+    h->ev_used = 0;
+    return FOS_OK;
+}
+
+int fos_bench_kkt(fos_handle h, int32_t reps, double* total_ms) {
+    if (!h || reps < 1) { set_error("bad argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    LaunchCtx c = h->ctx();
+    hipEvent_t e0, e1;
+    FOS_HIP(hipEventCreate(&e0));
+    FOS_HIP(hipEventCreate(&e1));
+    launch_kkt2(c, h->X, h->AP, 0);           // warm
+    FOS_HIP(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps; ++i) launch_kkt2(c, h->X, h->AP, 0);
+    FOS_HIP(hipEventRecord(e1, h->stream));
+    FOS_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FOS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (total_ms) *total_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return FOS_OK;
+}
+
+int fos_sync(fos_handle h) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    return FOS_OK;
+}
+
+int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int32_t use_graph) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    (void)use_graph;
+    FOS_HIP(hipSetDevice(h->device));
+    if (cg_chunk > 0) h->cg_chunk = cg_chunk;
+    if (spmv_workgroups > 0) {
+        if (spmv_workgroups > 16384) spmv_workgroups = 16384;
+        FOS_HIP(hipStreamSynchronize(h->stream));
+        partition_workgroups(&h->hostS, spmv_workgroups);
+        FOS_HIP(hipMemcpy(const_cast<int32_t*>(h->S.wg_blk0), h->hostS.wg_blk0.data(),
+                          h->hostS.wg_blk0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        h->S.nwg = h->hostS.nwg;
+        h->nwg_target = spmv_workgroups;
+    }
+    return FOS_OK;
+}
+
+}  // extern "C"

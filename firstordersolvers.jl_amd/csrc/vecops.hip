@@ -1,0 +1,429 @@
+// Streaming vector kernels of the hot path: CG updates with in-pass reductions, relaxation / extrapolation
+// passes, layout conversion, elementwise cones and the batched second-order-cone projection.
+// All of them are HBM-bound streams over l = n+m+1 `double2` elements (16 B per lane per access).
+//
+// FP contraction is OFF in this file: the reference evaluates e.g. `y .= a1.*y .+ (1-a1).*x` (gap.jl:48) as
+// two multiplies and an add; keeping that keeps the iterates as close to the reference as the reduction
+// order allows.
+#include "fos_internal.hpp"
+
+#pragma clang fp contract(off)
+
+namespace fos {
+
+typedef double2 d2;
+
+constexpr int VEC_THREADS = 256;
+constexpr int FIN_THREADS = 1024;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int NACC>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* out) {
+    __shared__ double smem[4 * NACC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        double v = wave_sum(acc[a]);
+        if (lane == 0) smem[wave * NACC + a] = v;
+    }
+    __syncthreads();
+    if (tid < NACC) out[tid] = (smem[tid] + smem[NACC + tid]) + (smem[2 * NACC + tid] + smem[3 * NACC + tid]);
+}
+
+template <int NACC>
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int count, double* sums) {
+    __shared__ double smem[16 * NACC];
+    double acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] += partials[(int64_t)i * NACC + a];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        double v = wave_sum(acc[a]);
+        if (lane == 0) smem[wave * NACC + a] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += smem[w * NACC + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ CG
+
+// r = rhs - Ap ; p = r ; partial r.r over the non-tau rows          conjugategradients.jl:33-35
+__global__ __launch_bounds__(VEC_THREADS) void cg_init_kernel(int64_t l, const d2* __restrict__ rhs, const d2* __restrict__ Ap,
+                                                              d2* __restrict__ r, d2* __restrict__ p, double* __restrict__ partials) {
+    double acc[1] = {0.0};
+    for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
+        const d2 b = rhs[i], a = Ap[i];
+        const d2 ri = make_double2(b.x - a.x, b.y - a.y);
+        r[i] = ri;
+        p[i] = ri;
+        if (i != l - 1) acc[0] += ri.x * ri.x + ri.y * ri.y;
+    }
+    block_reduce_store<1>(acc, partials + blockIdx.x);
+}
+
+__global__ __launch_bounds__(FIN_THREADS) void cg_init_finalize_kernel(const double* __restrict__ partials, int count,
+                                                                       const double* __restrict__ reduced, int from_reduced,
+                                                                       const d2* __restrict__ r, int64_t l, DevState* st, double tol, int maxit) {
+    __shared__ double sums[1];
+    if (from_reduced) { if (threadIdx.x == 0) sums[0] = reduced[0]; __syncthreads(); }
+    else reduce_partials<1>(partials, count, sums);
+    if (threadIdx.x == 0) {
+        const d2 rt = r[l - 1];
+        st->rn = sums[0] + (rt.x * rt.x + rt.y * rt.y);     // rn = dot(r,r)      :35
+        st->rn_old = 0.0;
+        st->iter = 1;                                        // :36
+        st->done = 0;
+        st->hit_max = 0;
+        st->tol = tol;
+        st->maxit = maxit;
+    }
+}
+
+// x += alpha p ; r -= alpha Ap ; partial r.r                          conjugategradients.jl:40-41,46
+__global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* __restrict__ x, d2* __restrict__ r,
+                                                                const d2* __restrict__ p, const d2* __restrict__ Ap,
+                                                                const DevState* st, double* __restrict__ partials) {
+    if (st->done) return;
+    const double alpha = st->alpha;
+    double acc[1] = {0.0};
+    for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
+        const d2 pi = p[i], ai = Ap[i];
+        d2 xi = x[i], ri = r[i];
+        xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+        ri.x -= alpha * ai.x; ri.y -= alpha * ai.y;
+        x[i] = xi;
+        r[i] = ri;
+        if (i != l - 1) acc[0] += ri.x * ri.x + ri.y * ri.y;
+    }
+    block_reduce_store<1>(acc, partials + blockIdx.x);
+}
+
+// norm(r) <= tol || iter >= max_iters -> done ; else rnold = rn, rn = r.r, beta = rn/rnold, iter += 1    :42-51
+__global__ __launch_bounds__(FIN_THREADS) void cg_update_finalize_kernel(const double* __restrict__ partials, int count,
+                                                                         const double* __restrict__ reduced, int from_reduced,
+                                                                         const d2* __restrict__ r, int64_t l, DevState* st) {
+    if (st->done) return;
+    __shared__ double sums[1];
+    if (from_reduced) { if (threadIdx.x == 0) sums[0] = reduced[0]; __syncthreads(); }
+    else reduce_partials<1>(partials, count, sums);
+    if (threadIdx.x == 0) {
+        const d2 rt = r[l - 1];
+        const double rr = sums[0] + (rt.x * rt.x + rt.y * rt.y);
+        st->rr = rr;
+        const int iter = st->iter;
+        if (sqrt(rr) <= st->tol || iter >= st->maxit) {
+            st->done = 1;
+            st->hit_max = (iter == st->maxit) ? 1 : 0;      // :53
+        } else {
+            const double rnold = st->rn;
+            st->rn_old = rnold;
+            st->rn = rr;
+            st->beta = rr / rnold;
+            st->iter = iter + 1;
+        }
+    }
+}
+
+// p .*= beta ; p .+= r                                                conjugategradients.jl:49-50
+__global__ __launch_bounds__(VEC_THREADS) void cg_pupdate_kernel(int64_t l, d2* __restrict__ p, const d2* __restrict__ r, const DevState* st) {
+    if (st->done) return;
+    const double beta = st->beta;
+    for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
+        d2 pi = p[i];
+        const d2 ri = r[i];
+        pi.x = pi.x * beta + ri.x;
+        pi.y = pi.y * beta + ri.y;
+        p[i] = pi;
+    }
+}
+
+void launch_cg_init(const LaunchCtx& c, const double2* rhs, const double2* Ap, double2* r, double2* p) {
+    hipLaunchKernelGGL(cg_init_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, rhs, Ap, r, p, c.partials);
+}
+void launch_cg_init_finalize(const LaunchCtx& c, const double2* r, double tol, int maxit, int from_reduced) {
+    hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.vec_blocks, c.reduced,
+                       from_reduced, r, c.l, c.st, tol, maxit);
+}
+void launch_cg_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, const double2* Ap) {
+    hipLaunchKernelGGL(cg_update_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, r, p, Ap, c.st, c.partials);
+}
+void launch_cg_update_finalize(const LaunchCtx& c, const double2* r, int from_reduced) {
+    hipLaunchKernelGGL(cg_update_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.vec_blocks, c.reduced,
+                       from_reduced, r, c.l, c.st);
+}
+void launch_cg_pupdate(const LaunchCtx& c, double2* p, const double2* r) {
+    hipLaunchKernelGGL(cg_pupdate_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p, r, c.st);
+}
+
+// ------------------------------------------------------------------------------------------------ outer-loop passes
+
+#define GRID_STRIDE(i, l) for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < (l); i += (int64_t)gridDim.x * VEC_THREADS)
+
+// out = a x + b y          (gap.jl:48  y .= a1.*y .+ (1-a1).*x ; fista.jl:37)
+__global__ __launch_bounds__(VEC_THREADS) void axpby_kernel(int64_t l, d2* __restrict__ out, double a, const d2* __restrict__ x,
+                                                            double b, const d2* __restrict__ y) {
+    GRID_STRIDE(i, l) {
+        const d2 xi = x[i], yi = y[i];
+        out[i] = make_double2(a * xi.x + b * yi.x, a * xi.y + b * yi.y);
+    }
+}
+// out = a12 y + (1-a12) x with a12 from the device state          gapa.jl:67
+__global__ __launch_bounds__(VEC_THREADS) void relax_a12_kernel(int64_t l, d2* __restrict__ out, const d2* __restrict__ y,
+                                                                const d2* __restrict__ x, const DevState* st) {
+    const double a = st->alpha12, b = 1 - a;
+    GRID_STRIDE(i, l) {
+        const d2 xi = x[i], yi = y[i];
+        out[i] = make_double2(a * yi.x + b * xi.x, a * yi.y + b * xi.y);
+    }
+}
+// tmp2 = a2 tmp2 + (1-a2) tmp1 ; x = a tmp2 + (1-a) x           gap.jl:58,78
+__global__ __launch_bounds__(VEC_THREADS) void gap_final_kernel(int64_t l, d2* __restrict__ x, const d2* __restrict__ t2,
+                                                                const d2* __restrict__ t1, double alpha, double alpha2) {
+    const double b2 = 1 - alpha2, b = 1 - alpha;
+    GRID_STRIDE(i, l) {
+        const d2 u = t2[i], v = t1[i];
+        d2 xi = x[i];
+        const double rx = alpha2 * u.x + b2 * v.x, ry = alpha2 * u.y + b2 * v.y;
+        xi.x = alpha * rx + b * xi.x;
+        xi.y = alpha * ry + b * xi.y;
+        x[i] = xi;
+    }
+}
+// GAPA: same with a12 from the state, plus the three sums of normedScalar(tmp2,tmp1,tmp1,x)   gapa.jl:36-47,77,96,103
+// tau-row contributions go to reduced[8..10] (replicated across shards, added after the all-reduce).
+__global__ __launch_bounds__(VEC_THREADS) void gapa_final_kernel(int64_t l, d2* __restrict__ x, const d2* __restrict__ t2,
+                                                                 const d2* __restrict__ t1, double alpha, const DevState* st,
+                                                                 double* __restrict__ partials, double* __restrict__ reduced) {
+    const double a12 = st->alpha12, b12 = 1 - a12, b = 1 - alpha;
+    double acc[3] = {0.0, 0.0, 0.0};
+    GRID_STRIDE(i, l) {
+        const d2 u = t2[i], v = t1[i];
+        d2 xi = x[i];
+        const double rx = a12 * u.x + b12 * v.x, ry = a12 * u.y + b12 * v.y;
+        const double d1x = rx - v.x, d1y = ry - v.y;      // tmp2 - tmp1
+        const double d2x = v.x - xi.x, d2y = v.y - xi.y;  // tmp1 - x
+        const double s = d1x * d2x + d1y * d2y, n1 = d1x * d1x + d1y * d1y, n2 = d2x * d2x + d2y * d2y;
+        if (i != l - 1) { acc[0] += s; acc[1] += n1; acc[2] += n2; }
+        else { reduced[8] = s; reduced[9] = n1; reduced[10] = n2; }
+        xi.x = alpha * rx + b * xi.x;
+        xi.y = alpha * ry + b * xi.y;
+        x[i] = xi;
+    }
+    block_reduce_store<3>(acc, partials + 3 * (int64_t)blockIdx.x);
+}
+// scl = clamp(|sum|/sqrt(n1 n2),0,1), NaN -> 0 ; s = sqrt(1-scl^2) ; a12 = (1-beta) 2/(1+s) + 2 beta     gapa.jl:96-101
+__global__ __launch_bounds__(FIN_THREADS) void gapa_finalize_kernel(const double* __restrict__ partials, int count,
+                                                                    double* __restrict__ reduced, int from_reduced, double beta, DevState* st) {
+    __shared__ double sums[3];
+    if (from_reduced) { if (threadIdx.x < 3) sums[threadIdx.x] = reduced[threadIdx.x]; __syncthreads(); }
+    else reduce_partials<3>(partials, count, sums);
+    if (threadIdx.x == 0) {
+        const double sum = sums[0] + reduced[8], n1 = sums[1] + reduced[9], n2 = sums[2] + reduced[10];
+        double scl = fabs(sum) / sqrt(n1 * n2);
+        if (scl != scl) scl = 0.0;                // isnan -> 0 (clamp of NaN stays NaN in Julia, then :97)
+        else scl = fmin(fmax(scl, 0.0), 1.0);
+        const double s = sqrt(1 - scl * scl);
+        const double aopt = 2 / (1 + s);
+        st->gapa_scl = scl;
+        st->alpha12 = (1 - beta) * aopt + beta * 2.0;
+    }
+}
+// y = x + coef (x - xold)                                          fista.jl:46
+__global__ __launch_bounds__(VEC_THREADS) void fista_extrap_kernel(int64_t l, d2* __restrict__ y, const d2* __restrict__ x,
+                                                                   const d2* __restrict__ xold, double coef) {
+    GRID_STRIDE(i, l) {
+        const d2 xi = x[i], xo = xold[i];
+        y[i] = make_double2(xi.x + coef * (xi.x - xo.x), xi.y + coef * (xi.y - xo.y));
+    }
+}
+__global__ __launch_bounds__(VEC_THREADS) void add_kernel(int64_t l, d2* __restrict__ out, const d2* __restrict__ a, const d2* __restrict__ b) {
+    GRID_STRIDE(i, l) { const d2 u = a[i], v = b[i]; out[i] = make_double2(u.x + v.x, u.y + v.y); }
+}
+// p .= x .+ p .- y                                                 dykstra.jl:29,33
+__global__ __launch_bounds__(VEC_THREADS) void dykstra_corr_kernel(int64_t l, d2* __restrict__ p, const d2* __restrict__ x, const d2* __restrict__ y) {
+    GRID_STRIDE(i, l) {
+        const d2 xi = x[i], yi = y[i];
+        d2 pi = p[i];
+        pi.x = (xi.x + pi.x) - yi.x;
+        pi.y = (xi.y + pi.y) - yi.y;
+        p[i] = pi;
+    }
+}
+
+void launch_axpby(const LaunchCtx& c, double2* out, double a, const double2* x, double b, const double2* y) {
+    hipLaunchKernelGGL(axpby_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, a, x, b, y);
+}
+void launch_relax_a12(const LaunchCtx& c, double2* out, const double2* y, const double2* x) {
+    hipLaunchKernelGGL(relax_a12_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, y, x, c.st);
+}
+void launch_gap_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha, double alpha2) {
+    hipLaunchKernelGGL(gap_final_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, t2, t1, alpha, alpha2);
+}
+void launch_gapa_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha) {
+    hipLaunchKernelGGL(gapa_final_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, t2, t1, alpha, c.st, c.partials, c.reduced);
+}
+void launch_gapa_finalize(const LaunchCtx& c, double beta, const double2*, int from_reduced) {
+    hipLaunchKernelGGL(gapa_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.vec_blocks, c.reduced, from_reduced, beta, c.st);
+}
+void launch_fista_extrap(const LaunchCtx& c, double2* y, const double2* x, const double2* xold, double coef) {
+    hipLaunchKernelGGL(fista_extrap_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, y, x, xold, coef);
+}
+void launch_add(const LaunchCtx& c, double2* out, const double2* a, const double2* b) {
+    hipLaunchKernelGGL(add_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, a, b);
+}
+void launch_dykstra_corr(const LaunchCtx& c, double2* p, const double2* x, const double2* y) {
+    hipLaunchKernelGGL(dykstra_corr_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p, x, y);
+}
+
+// ------------------------------------------------------------------------------------------------ layout conversion
+
+__global__ __launch_bounds__(VEC_THREADS) void interleave_kernel(int64_t l, d2* __restrict__ out, const double* __restrict__ plain) {
+    GRID_STRIDE(i, l) out[i] = make_double2(plain[i], plain[l + i]);
+}
+__global__ __launch_bounds__(VEC_THREADS) void deinterleave_kernel(int64_t l, double* __restrict__ plain, const d2* __restrict__ in) {
+    GRID_STRIDE(i, l) { const d2 v = in[i]; plain[i] = v.x; plain[l + i] = v.y; }
+}
+__global__ __launch_bounds__(VEC_THREADS) void set_comp_kernel(int64_t l, d2* __restrict__ out, const double* __restrict__ plain, int comp) {
+    GRID_STRIDE(i, l) { const double v = plain[i]; out[i] = comp ? make_double2(0.0, v) : make_double2(v, 0.0); }
+}
+__global__ __launch_bounds__(VEC_THREADS) void get_plain_kernel(int64_t l, double* __restrict__ plain, const d2* __restrict__ in, int comp) {
+    GRID_STRIDE(i, l) { const d2 v = in[i]; plain[i] = comp ? v.y : v.x; }
+}
+void launch_interleave(const LaunchCtx& c, double2* out, const double* plain) {
+    hipLaunchKernelGGL(interleave_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, plain);
+}
+void launch_deinterleave(const LaunchCtx& c, double* plain, const double2* in) {
+    hipLaunchKernelGGL(deinterleave_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, plain, in);
+}
+void launch_set_comp(const LaunchCtx& c, double2* out, const double* plain_l, int comp) {
+    hipLaunchKernelGGL(set_comp_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, plain_l, comp);
+}
+void launch_get_plain(const LaunchCtx& c, double* plain_l, const double2* in, int comp) {
+    hipLaunchKernelGGL(get_plain_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, plain_l, in, comp);
+}
+
+// ------------------------------------------------------------------------------------------------ cones
+
+__device__ __forceinline__ double ew_apply(int op, double v) {
+    switch (op) {
+        case EW_COPY: return v;               // IndFree / dual of IndZero           cones.jl:98
+        case EW_ZERO: return 0.0;             // IndZero / dual of IndFree (IndPoint) cones.jl:100
+        case EW_MAX0: return fmax(v, 0.0);    // IndNonnegative (self dual)           cones.jl:101 ; tau, kappa :138,141
+        default:      return fmin(v, 0.0);    // IndNonpositive                       cones.jl:102
+    }
+}
+// every index whose cone is Free/Zero/NonNeg/NonPos, plus the (tau,kappa) element; op byte: part1 | part2 << 2
+__global__ __launch_bounds__(VEC_THREADS) void cones_elementwise_kernel(int64_t l, d2* __restrict__ out, const d2* __restrict__ in,
+                                                                        const uint8_t* __restrict__ ew_op) {
+    GRID_STRIDE(i, l) {
+        const uint8_t op = ew_op[i];
+        if (op == EW_SKIP) continue;
+        const d2 v = in[i];
+        out[i] = make_double2(ew_apply(op & 3, v.x), ew_apply((op >> 2) & 3, v.y));
+    }
+}
+void launch_cones_elementwise(const LaunchCtx& c, double2* out, const double2* in, const uint8_t* ew_op) {
+    hipLaunchKernelGGL(cones_elementwise_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, in, ew_op);
+}
+
+// Second-order cones, one wavefront per cone, both copies (primal on one part, Moreau dual x + P(-x) on the
+// other: cones.jl:80-85) from the same 16-byte loads.  IndSOC: t = first entry; 0 if t <= -||v||, x if t >= ||v||,
+// else r = (1 + t/||v||)/2, y = (r ||v||, r v).  IndRotatedSOC: rotate entries (0,1) by pi/4, project, rotate back.
+struct SocOut { double y0, y1, r; int kase; };   // kase 0: zero, 1: identity, 2: scale by r
+
+__device__ __forceinline__ SocOut soc_decide(double t, double nx) {
+    SocOut o;
+    if (t <= -nx) { o.kase = 0; o.r = 0.0; o.y0 = 0.0; }
+    else if (t >= nx) { o.kase = 1; o.r = 1.0; o.y0 = t; }
+    else { o.kase = 2; o.r = 0.5 * (1.0 + t / nx); o.y0 = o.r * nx; }
+    o.y1 = 0.0;
+    return o;
+}
+
+constexpr double S45 = 0.7071067811865475;
+
+__global__ __launch_bounds__(VEC_THREADS) void cones_soc_kernel(d2* __restrict__ out, const d2* __restrict__ in,
+                                                                const ConeDesc* __restrict__ cones, int ncones) {
+    const int lane = threadIdx.x & 63;
+    const int cone = blockIdx.x * (VEC_THREADS / 64) + (threadIdx.x >> 6);
+    if (cone >= ncones) return;
+    const ConeDesc cd = cones[cone];
+    const d2* __restrict__ x = in + cd.start;
+    d2* __restrict__ y = out + cd.start;
+    const int len = cd.len;
+    const bool rot = cd.type == FOS_CONE_SOCROT;
+    const int head = rot ? 2 : 1;
+    // sign applied to the input of each part: the dual part projects -x
+    const double sg0 = (cd.dual_part == 0) ? -1.0 : 1.0, sg1 = (cd.dual_part == 1) ? -1.0 : 1.0;
+    double n0 = 0.0, n1 = 0.0;
+    for (int k = head + lane; k < len; k += 64) {
+        const d2 v = x[k];
+        n0 += v.x * v.x;
+        n1 += v.y * v.y;
+    }
+    n0 = wave_sum(n0);
+    n1 = wave_sum(n1);
+    const d2 h0 = x[0];
+    d2 h1 = make_double2(0.0, 0.0);
+    if (rot) h1 = x[1];
+    double t0, t1, x20 = 0.0, x21 = 0.0;     // t = first (rotated) entry of the (sign-flipped) input
+    if (rot) {
+        const double a0 = sg0 * h0.x, b0 = sg0 * h1.x, a1 = sg1 * h0.y, b1 = sg1 * h1.y;
+        t0 = S45 * a0 + S45 * b0; x20 = S45 * a0 - S45 * b0;
+        t1 = S45 * a1 + S45 * b1; x21 = S45 * a1 - S45 * b1;
+        n0 += x20 * x20;
+        n1 += x21 * x21;
+    } else {
+        t0 = sg0 * h0.x;
+        t1 = sg1 * h0.y;
+    }
+    const double nx0 = sqrt(n0), nx1 = sqrt(n1);
+    const SocOut o0 = soc_decide(t0, nx0), o1 = soc_decide(t1, nx1);
+    // tail entries
+    for (int k = head + lane; k < len; k += 64) {
+        const d2 v = x[k];
+        double p0 = (o0.kase == 0) ? 0.0 : ((o0.kase == 1) ? sg0 * v.x : o0.r * (sg0 * v.x));
+        double p1 = (o1.kase == 0) ? 0.0 : ((o1.kase == 1) ? sg1 * v.y : o1.r * (sg1 * v.y));
+        if (cd.dual_part == 0) p0 = v.x + p0;     // y = x + P(-x)    cones.jl:81-84
+        if (cd.dual_part == 1) p1 = v.y + p1;
+        y[k] = make_double2(p0, p1);
+    }
+    if (lane == 0) {
+        double y00, y01 = 0.0, y10, y11 = 0.0;    // yPQ: part P, entry Q
+        if (rot) {
+            double a0 = o0.y0, b0 = (o0.kase == 0) ? 0.0 : ((o0.kase == 1) ? x20 : o0.r * x20);
+            double a1 = o1.y0, b1 = (o1.kase == 0) ? 0.0 : ((o1.kase == 1) ? x21 : o1.r * x21);
+            y00 = S45 * a0 + S45 * b0; y01 = S45 * a0 - S45 * b0;
+            y10 = S45 * a1 + S45 * b1; y11 = S45 * a1 - S45 * b1;
+        } else {
+            y00 = o0.y0;
+            y10 = o1.y0;
+        }
+        if (cd.dual_part == 0) { y00 = h0.x + y00; y01 = h1.x + y01; }
+        if (cd.dual_part == 1) { y10 = h0.y + y10; y11 = h1.y + y11; }
+        y[0] = make_double2(y00, y10);
+        if (rot) y[1] = make_double2(y01, y11);
+    }
+}
+void launch_cones_soc(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones) {
+    if (ncones <= 0) return;
+    const int per_block = VEC_THREADS / 64;
+    hipLaunchKernelGGL(cones_soc_kernel, dim3((ncones + per_block - 1) / per_block), dim3(VEC_THREADS), 0, c.stream, out, in, cones, ncones);
+}
+
+}  // namespace fos

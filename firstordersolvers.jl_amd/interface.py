@@ -1,0 +1,464 @@
+"""
+Host-side mirror of the reference's solver interface for the HSDE hot path.
+
+Same names, argument meaning and behaviour as the Julia reference (paths under the reference checkout):
+
+  GAP / DR / AP / GAPA / FISTA / Dykstra constructors   src/solvers/gap.jl:13, solvers.jl:10-11, gapa.jl:15,
+                                                        fista.jl:11, dykstra.jl:9
+  FOSMathProgModel + loadproblem! / optimize! / status / getobjval / getsolution / numvar / numconstr
+                                                        src/types.jl:30-60, src/FOSSolverInterface.jl:5-69
+  solve! option handling, iterate                       src/solverwrapper.jl:2-41
+  HSDEStatus printing, history keys                     src/problemforms/HSDE/HSDEStatus.jl:73-91,125-139
+  HSDE_populatesolution                                 src/problemforms/HSDE/HSDE.jl:49-61
+
+Every numerical operation is a call into libfoship.so (HIP, gfx950) through `_lib`; nothing here computes on
+the CPU beyond scalar bookkeeping, and there is no fallback when the library or a GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+
+HEADER_CG = " Iter | pri res | dua res | rel gap | pri obj | dua obj | kap/tau | cg  | time"       # HSDEStatus.jl:79-81
+HEADER_DIRECT = " Iter | pri res | dua res | rel gap | pri obj | dua obj | kap/tau | time"
+
+
+# ---------------------------------------------------------------------------------------------- algorithms
+
+class FOSAlgorithm:
+    """abstract type FOSAlgorithm (src/types.jl:13)."""
+    direct = False
+    options: dict
+
+    def _alg_args(self):
+        raise NotImplementedError
+
+
+class GAP(FOSAlgorithm):
+    """GAP(alpha=0.8, alpha1=1.8, alpha2=1.8; direct=false, kwargs...)   gap.jl:6-13"""
+
+    def __init__(self, alpha=0.8, alpha1=1.8, alpha2=1.8, direct=False, **kwargs):
+        self.alpha, self.alpha1, self.alpha2, self.direct, self.options = alpha, alpha1, alpha2, direct, kwargs
+
+    def _alg_args(self):
+        return (_lib.ALG_GAP, self.alpha, self.alpha1, self.alpha2, 0.0)
+
+
+def DR(alpha=0.5, **kwargs):
+    """DR(alpha=0.5) = GAP(alpha, 2.0, 2.0)   solvers.jl:10"""
+    return GAP(alpha, 2.0, 2.0, **kwargs)
+
+
+def AP(alpha=1, **kwargs):
+    """AP(alpha=1) = GAP(alpha, 1.0, 1.0)   solvers.jl:11"""
+    return GAP(alpha, 1.0, 1.0, **kwargs)
+
+
+class GAPA(FOSAlgorithm):
+    """GAPA(alpha=1.0, beta=0.0; direct=false, kwargs...)   gapa.jl:9-15"""
+
+    def __init__(self, alpha=1.0, beta=0.0, direct=False, **kwargs):
+        self.alpha, self.beta, self.direct, self.options = alpha, beta, direct, kwargs
+
+    def _alg_args(self):
+        return (_lib.ALG_GAPA, self.alpha, 0.0, 0.0, self.beta)
+
+
+class FISTA(FOSAlgorithm):
+    """FISTA(alpha=1.0; direct=false, kwargs...)   fista.jl:6-11"""
+
+    def __init__(self, alpha=1.0, direct=False, **kwargs):
+        self.alpha, self.direct, self.options = alpha, direct, kwargs
+
+    def _alg_args(self):
+        return (_lib.ALG_FISTA, self.alpha, 0.0, 0.0, 0.0)
+
+
+class Dykstra(FOSAlgorithm):
+    """Dykstra(; direct=false, kwargs...)   dykstra.jl:5-9"""
+
+    def __init__(self, direct=False, **kwargs):
+        self.direct, self.options = direct, kwargs
+
+    def _alg_args(self):
+        return (_lib.ALG_DYKSTRA, 0.0, 0.0, 0.0, 0.0)
+
+
+# ---------------------------------------------------------------------------------------------- device handle
+
+def _normalize_cones(cones, total, what):
+    """(name, length) or (name, 1-based index range/list) tuples -> (types int32, starts int64 1-based, lens int64).
+    Index lists must be contiguous: toRanges, src/cones.jl:44-56."""
+    types, starts, lens = [], [], []
+    run = 1
+    for name, spec in cones:
+        if name not in _lib.CONE_CODES:
+            raise KeyError("Cone type %s not supported" % name)          # FOSSolverInterface.jl:37-42
+        if isinstance(spec, (int, np.integer)):
+            s, ln = run, int(spec)
+        else:
+            idx = np.asarray(list(spec), dtype=np.int64)
+            if idx.size == 0 or not np.array_equal(idx, np.arange(idx[0], idx[-1] + 1)):
+                raise ValueError("Invalid range in input")               # cones.jl:50
+            s, ln = int(idx[0]), int(idx.size)
+        types.append(_lib.CONE_CODES[name])
+        starts.append(s)
+        lens.append(ln)
+        run = s + ln
+    return (np.asarray(types, dtype=np.int32), np.asarray(starts, dtype=np.int64), np.asarray(lens, dtype=np.int64))
+
+
+class HipHSDE:
+    """Owns one fos_handle: the device-resident S1 (AffinePlusLinear over HSDEMatrixQ), S2 (DualConeProduct),
+    iterate and algorithm data.  == what init_algorithm!/get_sets_and_status build (FOSSolverInterface.jl:76-79)."""
+
+    def __init__(self, A, b, c, K1, K2, device=0):
+        self._lib = _lib.load()
+        A = sp.csc_matrix(A)                       # loadproblem! sparsifies dense input, FOSSolverInterface.jl:27-29
+        A.sort_indices()
+        m, n = A.shape
+        self.m, self.n, self.l, self.N = m, n, m + n + 1, 2 * (m + n + 1)
+        self.nnz = int(A.nnz)
+        b = _lib.as_f64(b, m)
+        c = _lib.as_f64(c, n)
+        colptr = np.ascontiguousarray(A.indptr, dtype=np.int64) + 1          # Julia 1-based
+        rowval = np.ascontiguousarray(A.indices, dtype=np.int64) + 1
+        nzval = np.ascontiguousarray(A.data, dtype=np.float64)
+        k1t, k1s, k1l = _normalize_cones(K1, m, "K1")
+        k2t, k2s, k2l = _normalize_cones(K2, n, "K2")
+        h = C.c_void_p()
+        i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+        i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        _lib.check(self._lib.fos_create(m, n, i64(colptr), i64(rowval), _lib.dptr(nzval), _lib.dptr(b), _lib.dptr(c),
+                                        len(k1t), i32(k1t), i64(k1s), i64(k1l),
+                                        len(k2t), i32(k2t), i64(k2s), i64(k2l), device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fos_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- algorithm / state
+    def set_alg(self, alg: FOSAlgorithm):
+        code, a, a1, a2, beta = alg._alg_args()
+        _lib.check(self._lib.fos_set_alg(self._h, code, a, a1, a2, beta))
+
+    def reset_affine(self):
+        _lib.check(self._lib.fos_reset_affine(self._h))
+
+    def set_iterate(self, z=None):
+        if z is None:
+            _lib.check(self._lib.fos_set_iterate(self._h, None))
+        else:
+            z = _lib.as_f64(z, self.N)
+            _lib.check(self._lib.fos_set_iterate(self._h, _lib.dptr(z)))
+
+    def get_iterate(self):
+        z = np.empty(self.N)
+        _lib.check(self._lib.fos_get_iterate(self._h, _lib.dptr(z)))
+        return z
+
+    def get_checked(self):
+        z = np.empty(self.N)
+        _lib.check(self._lib.fos_get_checked(self._h, _lib.dptr(z)))
+        return z
+
+    def step(self, i_first, count, checki, eps):
+        done = C.c_int64(0)
+        checked = C.c_int32(0)
+        res = _lib.CheckResult()
+        _lib.check(self._lib.fos_step(self._h, i_first, count, checki, eps, C.byref(done), C.byref(checked), C.byref(res)))
+        return done.value, bool(checked.value), res
+
+    def getsol(self, force_check=False, eps=1e-5):
+        z = np.empty(self.N)
+        res = _lib.CheckResult()
+        _lib.check(self._lib.fos_getsol(self._h, _lib.dptr(z), 1 if force_check else 0, eps, C.byref(res)))
+        return z, (res if force_check else None)
+
+    def cgiter(self):
+        v = C.c_int64(0)
+        _lib.check(self._lib.fos_get_cgiter(self._h, C.byref(v)))
+        return v.value
+
+    def alpha12(self):
+        v = C.c_double(0)
+        _lib.check(self._lib.fos_get_alpha12(self._h, C.byref(v)))
+        return v.value
+
+    def prox_count(self):
+        v = C.c_int64(0)
+        _lib.check(self._lib.fos_get_prox_count(self._h, C.byref(v)))
+        return v.value
+
+    # -- fine grained operators (each: host -> device -> host)
+    def q_apply(self, x, transpose=False):
+        x = _lib.as_f64(x, self.l)
+        y = np.empty(self.l)
+        _lib.check(self._lib.fos_q_apply(self._h, _lib.dptr(y), _lib.dptr(x), 1 if transpose else 0))
+        return y
+
+    def kkt_apply(self, x):
+        x = _lib.as_f64(x, self.N)
+        y = np.empty(self.N)
+        _lib.check(self._lib.fos_kkt_apply(self._h, _lib.dptr(y), _lib.dptr(x)))
+        return y
+
+    def cg_kkt(self, x0, rhs, tol, max_iters=10000):
+        x = _lib.as_f64(x0, self.N).copy()
+        rhs = _lib.as_f64(rhs, self.N)
+        it = C.c_int64(0)
+        _lib.check(self._lib.fos_cg_kkt(self._h, _lib.dptr(x), _lib.dptr(rhs), tol, max_iters, C.byref(it)))
+        return x, it.value
+
+    def prox_affine(self, x):
+        x = _lib.as_f64(x, self.N)
+        y = np.empty(self.N)
+        _lib.check(self._lib.fos_prox_affine(self._h, _lib.dptr(y), _lib.dptr(x)))
+        return y
+
+    def hsdematrix_prox(self, x):
+        x = _lib.as_f64(x, self.N)
+        y = np.empty(self.N)
+        _lib.check(self._lib.fos_hsdematrix_prox(self._h, _lib.dptr(y), _lib.dptr(x)))
+        return y
+
+    def prox_cones(self, x):
+        x = _lib.as_f64(x, self.N)
+        y = np.empty(self.N)
+        _lib.check(self._lib.fos_prox_cones(self._h, _lib.dptr(y), _lib.dptr(x)))
+        return y
+
+    def check(self, z, eps=1e-5):
+        z = _lib.as_f64(z, self.N)
+        res = _lib.CheckResult()
+        _lib.check(self._lib.fos_check(self._h, _lib.dptr(z), eps, C.byref(res)))
+        return res
+
+    # -- measurement
+    def profile(self, enable):
+        _lib.check(self._lib.fos_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        n = C.c_int64(0)
+        ms = C.c_double(0)
+        by = C.c_double(0)
+        _lib.check(self._lib.fos_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(by)))
+        return n.value, ms.value, by.value
+
+    def bench_kkt(self, reps):
+        ms = C.c_double(0)
+        _lib.check(self._lib.fos_bench_kkt(self._h, reps, C.byref(ms)))
+        return ms.value
+
+    def sync(self):
+        _lib.check(self._lib.fos_sync(self._h))
+
+    def set_tuning(self, spmv_workgroups=0, cg_chunk=0, use_graph=0):
+        _lib.check(self._lib.fos_set_tuning(self._h, spmv_workgroups, cg_chunk, use_graph))
+
+    # -- sharding; the host side hands over an ncclUniqueId obtained on rank 0
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_ubyte * 128)()
+        _lib.check(_lib.load().fos_comm_get_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, unique_id: bytes):
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        _lib.check(self._lib.fos_comm_init(self._h, nranks, rank, buf))
+
+
+# ---------------------------------------------------------------------------------------------- status
+
+class HSDEStatus:
+    """HSDEStatus (HSDEStatus.jl:2-16): fields the outer loop reads/writes + printing + history."""
+
+    def __init__(self, model, checki, eps, verbose, debug, out=None):
+        self.model = model
+        self.i = 0
+        self.status = "Continue"
+        self.checki, self.eps, self.verbose, self.debug = checki, eps, verbose, debug
+        self.checked = False
+        self.direct = False
+        self.init_time = time.perf_counter_ns()
+        self._out = out
+
+    def _println(self, s):
+        if self._out is None:
+            print(s)
+        else:
+            self._out.append(s)
+
+    def printstatusheader(self):                                   # HSDEStatus.jl:73-83
+        if self.verbose > 0:
+            self._println("Time to initialize: %ss" % (self.model.init_duration / 1e9))
+            width = 76 + (0 if self.direct else 5)
+            self._println("-" * width)
+            self._println(HEADER_DIRECT if self.direct else HEADER_CG)
+            self._println("-" * width)
+
+    def record(self, res, z=None):
+        """What checkstatus does once the residual scalars are known (HSDEStatus.jl:39-65)."""
+        t = time.perf_counter_ns() - self.init_time
+        i, h = self.i, self.model.history
+        if self.debug > 0:                                         # savedata :125-139
+            for key, val in (("p", res.p), ("d", res.d), ("g", res.g), ("ctx", res.ctx), ("bty", res.bty),
+                             ("κ", res.kappa), ("τ", res.tau), ("t", t)):
+                h.setdefault(key, []).append((i, val))
+            if self.debug > 1 and z is not None:
+                m, n = self.model.m, self.model.n
+                nu = n + m + 1
+                h.setdefault("x", []).append((i, z[0:n].copy()))
+                h.setdefault("y", []).append((i, z[n:n + m].copy()))
+                h.setdefault("s", []).append((i, z[nu + n:nu + n + m].copy()))
+        if self.verbose > 0:                                       # :43-51
+            h.setdefault("cgiter", []).append((i, int(res.cgiter)))
+            self._println("%6d|% 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 4d % .1es" %
+                          (i, res.p, res.d, res.g, res.ctx, -res.bty, res.kappa / res.tau, res.cgiter, t / 1e9))
+        if res.cg_maxiter_hit:
+            import warnings
+            warnings.warn("CG reached max iterations, result may be inaccurate")     # conjugategradients.jl:53
+        self.status = _lib.STATUS_NAMES[res.status]
+        if self.status == "Optimal" and self.verbose > 0:
+            self._println("Found solution i=%d" % i)               # :55-57
+        self.checked = True
+        self.last = res
+
+
+class Solution:                                                    # src/types.jl:6-11
+    def __init__(self, x, y, s, status):
+        self.x, self.y, self.s, self.status = x, y, s, status
+
+
+# ---------------------------------------------------------------------------------------------- model
+
+class FOSMathProgModel:
+    """FOSMathProgModel (src/types.jl:30-60) with the MathProgBase methods of src/FOSSolverInterface.jl."""
+
+    def __init__(self, alg: FOSAlgorithm, device=0, **kwargs):
+        self.alg = alg
+        self.options = dict(alg.options)
+        self.options.update(kwargs)
+        self.device = device
+        self.input_numconstr = 0
+        self.input_numvar = 0
+        self.solve_stat = "NotSolved"
+        self.obj_val = 0.0
+        self.primal_sol = np.zeros(0)
+        self.dual_sol = np.zeros(0)
+        self.slack = np.zeros(0)
+        self.history = {}
+        self.init_duration = 1
+        self.data = None
+        self.out = None            # list collecting printed lines (None -> stdout)
+
+    # loadproblem!(model, c, A, b, constr_cones, var_cones)        FOSSolverInterface.jl:27-64
+    def loadproblem(self, c, A, b, constr_cones, var_cones):
+        if self.alg.direct:
+            raise NotImplementedError("direct=true (sparse factorisation, HSDE.jl:12-15) is out of the HIP path's scope")
+        t1 = time.perf_counter_ns()
+        A = sp.csc_matrix(A)
+        self.input_numconstr, self.input_numvar = A.shape
+        self.m, self.n = A.shape
+        self.A, self.b, self.c = A, _lib.as_f64(b, A.shape[0]), _lib.as_f64(c, A.shape[1])
+        self.K1, self.K2 = list(constr_cones), list(var_cones)
+        if self.data is not None:
+            self.data.close()
+        self.data = HipHSDE(A, self.b, self.c, self.K1, self.K2, device=self.device)     # init_algorithm!  :58
+        self.data.set_alg(self.alg)
+        self.init_duration = time.perf_counter_ns() - t1
+        return self
+
+    def numvar(self):
+        return self.input_numvar
+
+    def numconstr(self):
+        return self.input_numconstr
+
+    @staticmethod
+    def supportedcones():                                          # FOSSolverInterface.jl:69
+        return ["Free", "Zero", "NonNeg", "NonPos", "SOC", "SDP", "ExpPrimal", "ExpDual"]
+
+    # optimize!(m)                                                 FOSSolverInterface.jl:8-21
+    def optimize(self):
+        self.history = {}
+        sol = self._solve()
+        self.solve_stat = sol.status
+        self.primal_sol, self.dual_sol, self.slack = sol.x, sol.y, sol.s
+        self.obj_val = float(np.dot(self.c, self.primal_sol))
+        return self
+
+    def status(self):
+        return self.solve_stat
+
+    def getobjval(self):
+        return self.obj_val
+
+    def getsolution(self):
+        return self.primal_sol.copy()
+
+    # solve!(model) + iterate                                      solverwrapper.jl:2-41
+    def _solve(self):
+        opts = self.options
+        max_iters = opts.get("max_iters", 10000)
+        verbose = opts.get("verbose", 1)
+        debug = opts.get("debug", 1)
+        eps = opts.get("eps", 1e-5)
+        checki = opts.get("checki", 100)
+        dev = self.data
+        dev.set_alg(self.alg)                                      # a fresh *Data struct per solve (model.data persists S1)
+        dev.set_iterate(opts.get("initx", None))                   # :10
+        status = HSDEStatus(self, checki, eps, verbose, debug, out=self.out)
+        self.status_obj = status
+        t1 = time.time()
+        status.printstatusheader()
+        i = 0
+        while i < max_iters:                                       # for i = 1:max_iters   :23
+            count = min(max_iters - i, checki - (i % checki))
+            done, checked, res = dev.step(i + 1, count, checki, eps)
+            i += done
+            status.i = i
+            if checked:
+                z = dev.get_checked() if debug > 1 else None      # debug=2 stores x,y,s of the checked point
+                status.record(res, z)
+                if status.status != "Continue":                    # :26
+                    break
+            else:
+                status.checked = False
+        guess, res = dev.getsol(force_check=not status.checked, eps=eps)       # :31-34
+        if not status.checked:
+            status.record(res, guess)
+        if verbose > 0:                                            # :35-39
+            status._println("Time for iterations: ")
+            status._println("%s s" % (time.time() - t1))
+        self.iterations = i
+        self.guess = guess
+        # HSDE_populatesolution                                    HSDE.jl:49-61
+        m, n = self.m, self.n
+        l = m + n + 1
+        tau = guess[l - 1]
+        endstatus = status.status if status.status != "Continue" else "Indeterminate"
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return Solution(guess[0:n] / tau, guess[n:n + m] / tau, guess[l + n:l + n + m] / tau, endstatus)
+
+
+def solve(problem, alg, device=0, out=None):
+    """Convenience: ConicModel(alg) -> loadproblem! -> optimize!  for a workloads.ConicProblem."""
+    model = FOSMathProgModel(alg, device=device)
+    model.out = out
+    model.loadproblem(problem.c, problem.A, problem.b, problem.K1, problem.K2)
+    model.optimize()
+    return model

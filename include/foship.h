@@ -1,0 +1,184 @@
+/*
+ * foship.h -- C ABI of libfoship.so: the MI355X (gfx950) implementation of the per-iteration hot path of
+ * FirstOrderSolvers.jl (GAP / DR / AP / GAPA / FISTA over the homogeneous self-dual embedding).
+ *
+ * This is the drop-in boundary.  The reference has no FFI; the seam it offers is
+ * Julia multiple dispatch on the algorithm type.  Each entry point below names the reference function a
+ * Julia `ccall` shim (firstordersolvers.jl_amd/julia/FOSHip.jl) replaces with it.
+ * All paths are relative to the reference checkout.
+ *
+ * Conventions
+ *   - plain C, no exceptions across the boundary, no callbacks into the host language;
+ *   - every function returns 0 on success, a negative FOS_E* code on failure; fos_last_error() returns a
+ *     thread-local message for the last failure;
+ *   - host arrays are owned by the caller and never retained; device memory is owned by the handle;
+ *   - a handle is not thread safe (the reference is single threaded);
+ *   - matrix input is Julia's SparseMatrixCSC{Float64,Int64}: 1-based colptr / rowval  (src/types.jl:35);
+ *   - iterates use the reference's layout z = [x(n); y(m); tau; r(n); s(m); kappa], N = 2(n+m+1) doubles
+ *     (src/cones.jl:126-141, src/problemforms/HSDE/HSDEStatus.jl:93-101);
+ *   - all arithmetic is IEEE fp64.
+ */
+#ifndef FOSHIP_H
+#define FOSHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FOS_ABI_VERSION 1
+
+/* error codes */
+#define FOS_OK            0
+#define FOS_EINVAL       -1   /* bad argument (the reference would fail an @assert)            */
+#define FOS_EHIP         -2   /* HIP runtime error                                            */
+#define FOS_ENOMEM       -3
+#define FOS_EUNSUPPORTED -4   /* cone / option not implemented by the HIP path                */
+#define FOS_ECOMM        -5   /* RCCL error                                                   */
+#define FOS_ENODEVICE    -6   /* no MI355X visible: the product path has no CPU fallback      */
+
+/* cone codes: the keys of `conemap`, src/cones.jl:4-14 */
+#define FOS_CONE_FREE       0   /* :Free       IndFree()              */
+#define FOS_CONE_ZERO       1   /* :Zero       IndZero()              */
+#define FOS_CONE_NONNEG     2   /* :NonNeg     IndNonnegative()       */
+#define FOS_CONE_NONPOS     3   /* :NonPos     IndNonpositive()       */
+#define FOS_CONE_SOC        4   /* :SOC        IndSOC()               */
+#define FOS_CONE_SOCROT     5   /* :SOCRotated IndRotatedSOC()        */
+#define FOS_CONE_SDP        6   /* :SDP        IndPSD(scaling=true)   */
+#define FOS_CONE_EXPPRIMAL  7   /* :ExpPrimal  (not implemented: FOS_EUNSUPPORTED) */
+#define FOS_CONE_EXPDUAL    8   /* :ExpDual    (not implemented: FOS_EUNSUPPORTED) */
+
+/* algorithms: src/solvers/{gap,gapa,fista,dykstra}.jl */
+#define FOS_ALG_GAP     0   /* GAP(alpha, alpha1, alpha2); DR = GAP(a,2,2), AP = GAP(a,1,1)  (solvers.jl:10-11) */
+#define FOS_ALG_GAPA    1   /* GAPA(alpha, beta)                                                              */
+#define FOS_ALG_FISTA   2   /* FISTA(alpha)                                                                   */
+#define FOS_ALG_DYKSTRA 3   /* Dykstra()                                                                      */
+
+/* status codes <-> Symbols of HSDEStatus.status (src/problemforms/HSDE/HSDEStatus.jl:53-63) */
+#define FOS_STATUS_CONTINUE   0
+#define FOS_STATUS_OPTIMAL    1
+#define FOS_STATUS_UNBOUNDED  2
+#define FOS_STATUS_INFEASIBLE 3
+
+/* what a convergence check returns: the values checkstatus computes / savedata stores
+ * (HSDEStatus.jl:33-38, 127-131) plus the CG count printed in the table (:44-47). */
+typedef struct fos_check_result {
+    double p;        /* relative primal residual   HSDEStatus.jl:34 */
+    double d;        /* relative dual residual     :35 */
+    double g;        /* relative duality gap       :38 */
+    double ctx;      /* c'x                        :36 */
+    double bty;      /* b'y                        :37 */
+    double kappa;
+    double tau;
+    double norm_axs; /* ||A x + s||                :59 */
+    double norm_aty; /* ||A'y||                    :61 */
+    double norm_b;
+    double norm_c;
+    int64_t cgiter;  /* getcgiter(data): CG iterations of the last affine projection (defaults.jl:25) */
+    int32_t status;  /* FOS_STATUS_*               :53-63 */
+    int32_t cg_maxiter_hit; /* 1 if any CG since the previous check stopped on max_iters (the reference @warns, conjugategradients.jl:53) */
+} fos_check_result;
+
+typedef struct fos_solver* fos_handle;
+
+/* ---- library ------------------------------------------------------------------------------------ */
+int         fos_abi_version(void);
+const char* fos_last_error(void);
+int         fos_device_count(int* count);                  /* FOS_ENODEVICE if HIP sees no GPU */
+int         fos_device_name(int device, char* buf, int buflen);
+
+/* ---- problem set-up: replaces HSDE(model) + init_algorithm! ---------------------------------------
+ * fos_create: loadproblem! -> init_algorithm! -> get_sets_and_status -> HSDE(model; direct=false)
+ *   (src/FOSSolverInterface.jl:27-64,76-79; src/problemforms/HSDE/HSDE.jl:7-29).
+ *   Problem: minimize c'x  s.t.  b - A x in K1,  x in K2;  A is m x n CSC, 1-based.
+ *   Cones: K?type[i] a FOS_CONE_* code, K?start[i] 1-based first index, K?len[i] length; ranges must be
+ *   contiguous, ordered and cover 1..m (K1) / 1..n (K2) exactly -- the ConeProduct assertion,
+ *   src/cones.jl:66-72 -- else FOS_EINVAL.  Builds S1 = AffinePlusLinear(Q,0,0,1,decreasing_accuracy=true)
+ *   and S2 = DualConeProduct(K1,K2) on the device `device`. */
+int fos_create(int64_t m, int64_t n,
+               const int64_t* colptr, const int64_t* rowval, const double* nzval,
+               const double* b, const double* c,
+               int64_t nK1, const int32_t* K1type, const int64_t* K1start, const int64_t* K1len,
+               int64_t nK2, const int32_t* K2type, const int64_t* K2start, const int64_t* K2len,
+               int device, fos_handle* out);
+int fos_destroy(fos_handle h);                             /* Julia finalizer */
+int fos_sizes(fos_handle h, int64_t* m, int64_t* n, int64_t* N, int64_t* nnz);
+
+/* Multi-GPU: the problem given to fos_create is this rank's SHARD of a
+ * block-separable problem (whole cones of K1 with the matching rows/columns of a block-diagonal A; tau and
+ * kappa replicated).  Only scalars cross GPUs: one RCCL all-reduce per reduction point of the CG / status.
+ * fos_comm_get_unique_id: rank 0 obtains an ncclUniqueId (128 bytes), the host broadcasts it;
+ * fos_comm_init: collective over all ranks.  Without it the handle is a single-GPU solver. */
+int fos_comm_get_unique_id(void* id128);
+int fos_comm_init(fos_handle h, int nranks, int rank, const void* id128);
+
+/* ---- algorithm state: replaces init_algorithm!(alg, model) data structs ---------------------------
+ * fos_set_alg: GAP/GAPA/FISTA/Dykstra constructor arguments (gap.jl:13, gapa.jl:15, fista.jl:11) and a
+ *   fresh *Data struct (gap.jl:23-28, gapa.jl:27-32: alpha12 = 2.0, fista.jl:20-25: t = 1, y = xold = 0,
+ *   dykstra.jl:19-23: p = q = 0).  Does NOT reset S1 (call counter i, CG warm start): in the reference
+ *   those live in the model and persist across solve! calls (affinepluslinear.jl:66,114).
+ * fos_reset_affine: a fresh AffinePlusLinear (i = 1, firstrun = true) == a new loadproblem!. */
+int fos_set_alg(fos_handle h, int alg, double alpha, double alpha1, double alpha2, double beta);
+int fos_reset_affine(fos_handle h);
+
+/* getinitialvalue / option initx (solverwrapper.jl:10, HSDE.jl:40-47): z = 0, tau = kappa = 1 when z == NULL */
+int fos_set_iterate(fos_handle h, const double* z);
+int fos_get_iterate(fos_handle h, double* z);              /* the current x of `iterate` */
+int fos_get_checked(fos_handle h, double* z);              /* the vector the last checkstatus saw (debug=2 history of
+                                                              x,y,s: savedata, HSDEStatus.jl:133-136); valid until the next step */
+
+/* ---- the hot loop: replaces Base.step + checkstatus inside iterate --------------------------------
+ * fos_step runs outer iterations i = i_first, i_first+1, ... (1-based, solverwrapper.jl:23-29) entirely on
+ * the device.  It returns after `count` iterations, or earlier right after an iteration on which
+ * i % checki == 0 (the convergence check of S2!/step: gap.jl:56, gapa.jl:75, fista.jl:41), whichever comes
+ * first.  *iters_done = iterations performed.  If the last iteration was a check iteration, *checked = 1
+ * and *res holds the values (res->status != CONTINUE means `iterate` must break); else *checked = 0. */
+int fos_step(fos_handle h, int64_t i_first, int64_t count, int64_t checki, double eps,
+             int64_t* iters_done, int32_t* checked, fos_check_result* res);
+
+/* getsol(alg, data, x): one more S1 prox + S2 prox (gap.jl:82-87, gapa.jl:107-112, fista.jl:50-56); advances
+ * the CG call counter like the reference.  z_out (N doubles) receives `guess`.  If force_check != 0 the
+ * override check of solverwrapper.jl:31-34 is evaluated on the guess. */
+int fos_getsol(fos_handle h, double* z_out, int32_t force_check, double eps, fos_check_result* res);
+
+int fos_get_cgiter(fos_handle h, int64_t* cgiter);         /* getcgiter(data), defaults.jl:25-30 */
+int fos_get_alpha12(fos_handle h, double* alpha12);        /* GAPAData.alpha12 */
+int fos_get_prox_count(fos_handle h, int64_t* i);          /* AffinePlusLinear.i (next call's counter) */
+
+/* ---- fine-grained operator entry points (test boundary; each does H2D, compute, D2H) -------------
+ * fos_q_apply:      mul!(Y, Q, B) / mul!(Y, transpose(Q), B), l = n+m+1   (HSDEAffine.jl:41-65)
+ * fos_kkt_apply:    mul!(y, KKTMatrix(Q), x), 2l                          (affinepluslinear.jl:37-52)
+ *                   == mul!(Y, HSDEMatrix(Q), B)                          (HSDEAffine.jl:131-147)
+ * fos_cg_kkt:       conjugategradient!(x, KKTMatrix(Q), rhs, ...; tol, max_iters), x = warm start in/out;
+ *                   *iters = return value                                 (conjugategradients.jl:31-55)
+ * fos_prox_affine:  prox!(y, S1::AffinePlusLinear, x)  (stateful: i, xinit) (affinepluslinear.jl:83-126)
+ * fos_hsdematrix_prox: prox!(y, HSDEMatrix(Q), x) with its own CGdata     (HSDEAffine.jl:105-126)
+ * fos_prox_cones:   prox!(y, S2::DualConeProduct, x)                      (cones.jl:122-142)
+ * fos_check:        checkstatus(status, z, override=true) values          (HSDEStatus.jl:27-63)           */
+int fos_q_apply(fos_handle h, double* y, const double* x, int32_t transpose);
+int fos_kkt_apply(fos_handle h, double* y, const double* x);
+int fos_cg_kkt(fos_handle h, double* x, const double* rhs, double tol, int64_t max_iters, int64_t* iters);
+int fos_prox_affine(fos_handle h, double* y, const double* x);
+int fos_hsdematrix_prox(fos_handle h, double* y, const double* x);
+int fos_prox_cones(fos_handle h, double* y, const double* x);
+int fos_check(fos_handle h, const double* z, double eps, fos_check_result* res);
+
+/* ---- measurement ---------------------------------------------------------------------------------
+ * fos_profile: when enabled, every launch of the dominant kernel (the fused dual-right-hand-side KKT
+ *   SpMV of the CG loop) is bracketed by HIP events on the solver's stream.
+ * fos_profile_read: synchronises and returns launches, summed kernel milliseconds, and the ALGORITHMIC
+ *   bytes of one launch (B_kkt,min = 24 nnz + 4(m+n+2) + 32(m+n)); resets the counters.
+ * fos_bench_kkt: `reps` back-to-back KKT-apply launches on device-resident vectors; total ms by HIP events. */
+int fos_profile(fos_handle h, int32_t enable);
+int fos_profile_read(fos_handle h, int64_t* launches, double* total_ms, double* bytes_per_launch);
+int fos_bench_kkt(fos_handle h, int32_t reps, double* total_ms);
+int fos_sync(fos_handle h);
+
+/* tuning knobs (0 keeps the default): workgroups of the SpMV grid, CG iterations enqueued per host poll */
+int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int32_t use_graph);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOSHIP_H */

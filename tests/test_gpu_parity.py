@@ -1,0 +1,438 @@
+"""
+GPU parity tests: the HIP path (through the C ABI, via the ctypes host mirror) against the oracle on the same
+seeded inputs.  fp64 everywhere; tolerances are stated per test.  The operator / cone entry points agree to
+rounding (different summation order only); anything that runs CG is compared at the accuracy the CG tolerance
+of that call allows, and whole solves are compared at convergence (residuals and solution).
+"""
+import math
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import fos_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _codes(cones):
+    return [(orc.CONE_CODES[k], l) for k, l in cones]
+
+
+def omodel(prob):
+    return orc.Model(prob.A, prob.b, prob.c, _codes(prob.K1), _codes(prob.K2))
+
+
+def relerr(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(1e-300, np.linalg.norm(b)))
+
+
+def random_problem(pkg, rng, m, n, density, K1=None, K2=None):
+    A = sp.random(m, n, density=density, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    K1 = K1 or [("Zero", m)]
+    K2 = K2 or [("NonNeg", n)]
+    return pkg.workloads.from_complementary_pair("rand", A, K1, K2, rng)
+
+
+def shapes(pkg):
+    """Operator test matrices: empty rows/cols, long rows (> NNZ_BLK = 1024 entries), many tiny rows, dense."""
+    rng = np.random.default_rng(7)
+    out = []
+    out.append(("tiny-dense", sp.csc_matrix(rng.standard_normal((3, 2)))))
+    out.append(("sparse", sp.random(300, 500, density=0.02, format="csc", random_state=rng, data_rvs=rng.standard_normal)))
+    A = sp.random(400, 700, density=0.004, format="lil", random_state=rng, data_rvs=rng.standard_normal)
+    A[17, :] = 0
+    A[:, 5] = 0
+    out.append(("empty-rows-cols", A.tocsc()))
+    out.append(("long-rows", sp.csc_matrix(rng.standard_normal((5, 3000)))))           # rows of A: 3000 nnz; rows of A': 5
+    out.append(("tall-dense", sp.csc_matrix(rng.standard_normal((2500, 4)))))
+    out.append(("identity-like", sp.identity(1500, format="csc") * 2.0))
+    out.append(("mixed-lengths", sp.vstack([sp.csc_matrix(rng.standard_normal((2, 1300))),
+                                            sp.random(600, 1300, density=0.01, format="csc", random_state=rng,
+                                                      data_rvs=rng.standard_normal)]).tocsc()))
+    out.append(("all-zero", sp.csc_matrix((6, 9))))
+    return out
+
+
+@pytest.fixture(scope="module")
+def dev_ops(pkg):
+    made = []
+
+    def make(A, b=None, c=None, K1=None, K2=None):
+        m, n = A.shape
+        rng = np.random.default_rng(m * 1000 + n)
+        b = rng.standard_normal(m) if b is None else b
+        c = rng.standard_normal(n) if c is None else c
+        d = pkg.HipHSDE(A, b, c, K1 or [("Free", m)], K2 or [("Free", n)])
+        made.append(d)
+        return d, b, c
+    yield make
+    for d in made:
+        d.close()
+
+
+# ---------------------------------------------------------------------------------------------- operators
+
+
+def test_q_apply_and_transpose(pkg, dev_ops):
+    """mul!(Y,Q,B), mul!(Y,transpose(Q),B)  (HSDEAffine.jl:41-65; test/HSDEAffine.jl:26-43).  rtol 1e-13."""
+    for name, A in shapes(pkg):
+        d, b, c = dev_ops(A)
+        Q = orc.HSDEMatrixQ(A, b, c)
+        rng = np.random.default_rng(3)
+        x = rng.standard_normal(d.l)
+        x0 = x.copy()
+        y_ref = np.empty(d.l)
+        Q.mul(y_ref, x)
+        y = d.q_apply(x)
+        assert np.array_equal(x, x0)
+        assert relerr(y, y_ref) < 1e-13, name
+        Q.mul_t(y_ref, x)
+        assert relerr(d.q_apply(x, transpose=True), y_ref) < 1e-13, name
+
+
+def test_kkt_apply(pkg, dev_ops):
+    """mul!(y, KKTMatrix(Q), x) == mul!(Y, HSDEMatrix(Q), B)  (affinepluslinear.jl:37-52, HSDEAffine.jl:131-147)."""
+    for name, A in shapes(pkg):
+        d, b, c = dev_ops(A)
+        M = orc.KKTMatrix(orc.HSDEMatrixQ(A, b, c))
+        rng = np.random.default_rng(4)
+        x = rng.standard_normal(d.N)
+        y_ref = np.empty(d.N)
+        M.mul(y_ref, x)
+        assert relerr(d.kkt_apply(x), y_ref) < 1e-13, name
+        H = orc.HSDEMatrix(orc.HSDEMatrixQ(A, b, c))
+        H.mul(y_ref, x)
+        assert relerr(d.kkt_apply(x), y_ref) < 1e-13, name
+
+
+def test_cg_kkt_matches_dense_solve_and_oracle_count(pkg, dev_ops):
+    """conjugategradient! on the indefinite KKT system (conjugategradients.jl:31-55)."""
+    rng = np.random.default_rng(5)
+    A = sp.random(100, 200, density=0.05, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    d, b, c = dev_ops(A)
+    Q = orc.HSDEMatrixQ(A, b, c)
+    M = orc.KKTMatrix(Q)
+    rhs = rng.standard_normal(d.N)
+    x0 = rng.standard_normal(d.N)
+    tol = d.N * np.finfo(float).eps
+    x, it = d.cg_kkt(x0, rhs, tol, 10000)
+    Qd = Q.todense()
+    Md = np.block([[np.eye(d.l), Qd.T], [Qd, -np.eye(d.l)]])
+    xs = np.linalg.solve(Md, rhs)
+    assert relerr(x, xs) < 1e-12
+    xo = x0.copy()
+    it_o = orc.conjugategradient(xo, M, rhs, np.empty(d.N), np.empty(d.N), np.empty(d.N), tol=tol, max_iters=10000)
+    assert abs(it - it_o) <= 2, (it, it_o)
+    # loose tolerance: stops at the same iteration, same iterate to rounding
+    x, it = d.cg_kkt(x0, rhs, 1e-3, 10000)
+    xo = x0.copy()
+    it_o = orc.conjugategradient(xo, M, rhs, np.empty(d.N), np.empty(d.N), np.empty(d.N), tol=1e-3, max_iters=10000)
+    assert it == it_o
+    assert relerr(x, xo) < 1e-11
+    # max_iters cap (conjugategradients.jl:42): returns max_iters
+    x, it = d.cg_kkt(x0, rhs, 1e-300, 7)
+    assert it == 7
+
+
+def test_prox_affine_sequence(pkg, dev_ops):
+    """prox!(y, S1::AffinePlusLinear, x): call counter, tolerance schedule, warm start (affinepluslinear.jl:83-126)."""
+    rng = np.random.default_rng(6)
+    A = sp.random(60, 90, density=0.1, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    d, b, c = dev_ops(A)
+    Q = orc.HSDEMatrixQ(A, b, c)
+    S = orc.AffinePlusLinear(Q, np.zeros(d.l), np.zeros(d.l), 1, decreasing_accuracy=True)
+    Qd = Q.todense()
+    Md = np.block([[np.eye(d.l), Qd.T], [Qd, -np.eye(d.l)]])
+    for call in range(1, 7):
+        x = rng.standard_normal(d.N)
+        tol = S.tolerance()
+        y_ref = np.empty(d.N)
+        S.prox(y_ref, x)
+        y = d.prox_affine(x)
+        assert d.prox_count() == S.i == call + 1
+        exact = np.linalg.solve(Md, np.concatenate([x[:d.l] + Qd.T @ x[d.l:], np.zeros(d.l)]))
+        # both are CG iterates stopped at ||r|| <= tol of the same system from the same warm start
+        assert abs(d.cgiter() - S.getcgiter()) <= 1
+        if d.cgiter() == S.getcgiter():
+            assert relerr(y, y_ref) < 1e-10
+        assert np.linalg.norm(Md @ y - np.concatenate([x[:d.l] + Qd.T @ x[d.l:], np.zeros(d.l)])) <= tol * (1 + 1e-9)
+        assert np.linalg.norm(y - exact) <= 2 * tol + 1e-12
+    d.reset_affine()
+    assert d.prox_count() == 1
+
+
+def test_hsdematrix_prox(pkg, dev_ops):
+    """prox!(y, HSDEMatrix(Q), x): projection onto {Qu = v} (HSDEAffine.jl:105-126; test/HSDEAffine.jl:71-81)."""
+    rng = np.random.default_rng(8)
+    A = rng.standard_normal((40, 70))
+    d, b, c = dev_ops(sp.csc_matrix(A))
+    Q1 = orc.HSDEMatrixQ(A, b, c).todense()
+    x = rng.standard_normal(d.N)
+    y = d.hsdematrix_prox(x)
+    l = d.l
+    u = np.linalg.solve(np.eye(l) + Q1.T @ Q1, x[:l] + Q1.T @ x[l:])
+    assert relerr(y, np.concatenate([u, Q1 @ u])) < 1e-10      # reference test uses isapprox (rtol 1.5e-8)
+
+
+# ---------------------------------------------------------------------------------------------- cones
+
+
+def test_prox_cones_all_kinds(pkg, dev_ops):
+    """prox!(y, S2::DualConeProduct, x) (cones.jl:122-142) on every supported cone kind, both sides.
+    Elementwise cones: bit exact.  SOC: 1e-14.  PSD (Jacobi vs LAPACK): 1e-12 absolute x ||x||."""
+    prob = pkg.workloads.small_mixed()
+    d, _, _ = dev_ops(prob.A, prob.b, prob.c, prob.K1 + [], prob.K2 + [])
+    S2 = orc.DualConeProduct(orc.ConeProduct.from_lengths(_codes(prob.K1)), orc.ConeProduct.from_lengths(_codes(prob.K2)))
+    rng = np.random.default_rng(9)
+    for trial in range(5):
+        z = rng.standard_normal(d.N) * (10.0 ** (trial - 2))
+        ref = np.empty(d.N)
+        S2.prox(ref, z)
+        out = d.prox_cones(z)
+        assert np.linalg.norm(out - ref) <= 1e-12 * np.linalg.norm(z)
+    # elementwise-only problem: exact
+    K1 = [("Zero", 3), ("NonNeg", 4), ("NonPos", 2), ("Free", 1)]
+    K2 = [("NonNeg", 2), ("Free", 2), ("Zero", 1), ("NonPos", 1)]
+    A = sp.random(10, 6, density=0.5, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    d2, _, _ = dev_ops(A, None, None, K1, K2)
+    S2 = orc.DualConeProduct(orc.ConeProduct.from_lengths(_codes(K1)), orc.ConeProduct.from_lengths(_codes(K2)))
+    z = rng.standard_normal(d2.N)
+    ref = np.empty(d2.N)
+    S2.prox(ref, z)
+    assert np.array_equal(d2.prox_cones(z), ref)
+
+
+def test_soc_cases_and_rotated(pkg, dev_ops):
+    rng = np.random.default_rng(10)
+    K1 = [("SOC", 1), ("SOC", 2), ("SOC", 5), ("SOC", 70), ("SOC", 300), ("SOCRotated", 2), ("SOCRotated", 9)]
+    m = sum(l for _, l in K1)
+    K2 = [("SOC", 4), ("SOCRotated", 3)]
+    n = 7
+    A = sp.random(m, n, density=0.2, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    d, _, _ = dev_ops(A, None, None, K1, K2)
+    S2 = orc.DualConeProduct(orc.ConeProduct.from_lengths(_codes(K1)), orc.ConeProduct.from_lengths(_codes(K2)))
+    for trial in range(8):
+        z = rng.standard_normal(d.N)
+        if trial == 1:
+            z[:] = 0.0
+        if trial == 2:      # inside the cones: head large
+            for s in (n, n + 1, n + 3, n + 8):
+                z[s] = 50.0
+                z[d.l + s] = 50.0
+        if trial == 3:      # in the polar cone: head very negative
+            for s in (n, n + 1, n + 3, n + 8):
+                z[s] = -50.0
+                z[d.l + s] = -50.0
+        ref = np.empty(d.N)
+        S2.prox(ref, z)
+        assert np.linalg.norm(d.prox_cones(z) - ref) <= 1e-14 * max(1.0, np.linalg.norm(z)), trial
+
+
+YS = np.array([[-0.0064709, -0.22443], [-0.22443, -1.02411]])                 # test/testPSD.jl:3-4
+PSD_KNOWN = np.array([[0.03909044662082823, -0.00823811392936668],
+                      [-0.00823811392936668, 0.00173614084718757]])
+
+
+def test_psd_known_answer_and_sizes(pkg, dev_ops):
+    """test/testPSD.jl:14-19 known answer through the GPU PSD kernel; random orders 1..100 (LDS path) and 120
+    (global-scratch path); degenerate spectra (+-lambda pairs, zero matrix, rank one)."""
+    r2 = math.sqrt(2)
+    K1 = [("SDP", 3)]
+    d, _, _ = dev_ops(sp.csc_matrix(np.eye(3, 2)), None, None, K1, [("Free", 2)])
+    z = np.zeros(d.N)
+    xs = np.array([YS[0, 0], r2 * YS[1, 0], YS[1, 1]])
+    z[d.l + 2:d.l + 5] = xs                   # s part: primal PSD projection
+    z[2:5] = -xs                              # y part: dual = x + P(-x) -> for x = -xs:  -xs + P(xs)
+    out = d.prox_cones(z)
+    want = np.array([PSD_KNOWN[0, 0], r2 * PSD_KNOWN[1, 0], PSD_KNOWN[1, 1]])
+    assert np.allclose(out[d.l + 2:d.l + 5], want, atol=1e-14, rtol=0)
+    assert np.allclose(out[2:5], -xs + want, atol=1e-14, rtol=0)
+
+    rng = np.random.default_rng(11)
+    for k in (1, 2, 3, 5, 8, 17, 33, 64, 96, 100, 120):
+        ln = k * (k + 1) // 2
+        d, _, _ = dev_ops(sp.random(ln, 3, density=0.1, format="csc", random_state=rng), None, None, [("SDP", ln)], [("Free", 3)])
+        S2 = orc.DualConeProduct(orc.ConeProduct.from_lengths([(orc.CONE_SDP, ln)]), orc.ConeProduct.from_lengths([(orc.CONE_FREE, 3)]))
+        cases = [rng.standard_normal(d.N), np.zeros(d.N)]
+        # +-lambda pairs: M = [[0,1],[1,0]] pattern embedded (the case plain one-sided Jacobi gets wrong)
+        G = np.zeros((k, k))
+        for i in range(0, k - 1, 2):
+            G[i, i + 1] = G[i + 1, i] = 1.0 + i
+        zz = np.zeros(d.N)
+        sv = pkg.workloads._svec(G)
+        zz[3:3 + ln] = sv
+        zz[d.l + 3:d.l + 3 + ln] = sv
+        cases.append(zz)
+        v = rng.standard_normal(k)
+        zz = np.zeros(d.N)
+        zz[d.l + 3:d.l + 3 + ln] = pkg.workloads._svec(np.outer(v, v))      # rank one PSD: projection = itself
+        zz[3:3 + ln] = pkg.workloads._svec(-np.outer(v, v))
+        cases.append(zz)
+        for z in cases:
+            ref = np.empty(d.N)
+            S2.prox(ref, z)
+            out = d.prox_cones(z)
+            assert np.linalg.norm(out - ref) <= 5e-13 * max(1.0, np.linalg.norm(z)), k
+
+
+# ---------------------------------------------------------------------------------------------- status
+
+
+def test_check_residuals(pkg, dev_ops):
+    """checkstatus values (HSDEStatus.jl:33-38,53-63) on arbitrary points, rtol 1e-12."""
+    prob = pkg.workloads.small_mixed()
+    d, _, _ = dev_ops(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    mo = omodel(prob)
+    rng = np.random.default_rng(12)
+    for trial in range(4):
+        z = rng.standard_normal(d.N)
+        z[d.l - 1] = abs(z[d.l - 1]) + 0.1
+        res = d.check(z, 1e-5)
+        ref = orc.residuals(mo, z)
+        for key in ("p", "d", "g", "ctx", "bty", "kappa", "tau"):
+            assert getattr(res, key) == pytest.approx(ref[key], rel=1e-12, abs=1e-14), key
+        assert res.norm_axs == pytest.approx(ref["nAxs"], rel=1e-12)
+        assert res.norm_aty == pytest.approx(ref["nATy"], rel=1e-12)
+        assert pkg.lib.STATUS_NAMES[res.status] == orc.decide_status(ref, 1e-5)
+    # an optimal point is reported optimal
+    z = np.concatenate([prob.x0, prob.y0, [1.0], prob.c + prob.A.T @ prob.y0, prob.s0, [0.0]])
+    res = d.check(z, 1e-8)
+    assert pkg.lib.STATUS_NAMES[res.status] == "Optimal"
+
+
+# ---------------------------------------------------------------------------------------------- iterate-level parity
+
+
+@pytest.mark.parametrize("algname", ["DR", "GAP", "GAPA", "FISTA", "Dykstra", "AP"])
+def test_first_iterations_match_oracle(pkg, algname):
+    """Outer iterates of the first 25 iterations agree with the oracle to 1e-9 (the CG stop decisions coincide
+    on this well conditioned problem; summation order is the only difference)."""
+    prob = pkg.workloads.small_mixed()
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    mk = {"DR": lambda M: M.DR(), "GAP": lambda M: M.GAP(), "GAPA": lambda M: M.GAPA(0.8, 0.5), "FISTA": lambda M: M.FISTA(),
+          "Dykstra": lambda M: M.Dykstra(), "AP": lambda M: M.AP()}[algname]
+    alg_o = mk(orc)
+    mo = omodel(prob)
+    alg_o.init(mo)
+    x = orc.hsde_initialvalue(mo)
+    st = orc.HSDEStatus(mo, 10 ** 9, 1e-5, 0, 0)
+    d.set_alg(mk(pkg))
+    d.set_iterate(None)
+    for i in range(1, 26):
+        st.i = i
+        alg_o.step(x, i, st)
+        done, checked, _ = d.step(i, 1, 10 ** 9, 1e-5)
+        assert done == 1 and not checked
+        assert d.cgiter() == alg_o.S1.getcgiter(), (i, d.cgiter(), alg_o.S1.getcgiter())
+        assert np.linalg.norm(d.get_iterate() - x) <= 1e-9 * max(1.0, np.linalg.norm(x)), i
+        if algname == "GAPA":
+            assert d.alpha12() == pytest.approx(alg_o.alpha12, rel=1e-9)
+    zg, _ = d.getsol()
+    assert np.linalg.norm(zg - alg_o.getsol(x)) <= 1e-9 * max(1.0, np.linalg.norm(x))
+    d.close()
+
+
+# ---------------------------------------------------------------------------------------------- whole solves
+
+
+def solve_both(pkg, prob, mk, **opts):
+    out = []
+    model = pkg.solve(prob, mk(pkg, **opts), out=out)
+    sol = orc.solve(omodel(prob), mk(orc, **opts), out=[])
+    return model, sol, out
+
+
+def test_readme_nnls_dr_gapa(pkg):
+    """test/testDRandGAPA.jl:9-49 on the GPU path (optimum checked against scipy nnls, as in the oracle test)."""
+    import scipy.optimize
+    prob = pkg.workloads.c1_readme_nnls(seed=2)
+    n = prob.meta["n"]
+    xs, rnorm = scipy.optimize.nnls(prob.meta["Ad"], prob.meta["bd"])
+    opt = rnorm ** 2
+    eps = 1e-8
+    model, sol, out = solve_both(pkg, prob, lambda M, **o: M.DR(**o), eps=eps, verbose=1)
+    assert model.status() == "Optimal" == sol.status
+    assert model.getobjval() == pytest.approx(opt, rel=1e-6)
+    x = model.getsolution()
+    assert abs(min(x[:n].min(), 0.0)) < 10 * eps
+    assert np.max(np.abs(x[:n] - sol.x[:n])) < 1e-7
+    assert abs(model.iterations - sol.iterations) <= model.options.get("checki", 100)
+    # residuals at convergence within 1e-8 of the oracle's (BASELINE.json: "residuals within 1e-8 of reference")
+    last, olast = model.status_obj.last, sol.status_obj.last
+    for key in ("p", "d", "g"):
+        assert abs(getattr(last, key) - olast[key]) < 1e-8
+    # printed table (test/testprint.jl:15-19)
+    assert out[2] == pkg.HEADER_CG and out[1] == "-" * 81
+    assert out[4].startswith("   100|")
+    assert any(s.startswith("Found solution i=") for s in out)
+    for key in ("p", "d", "g", "ctx", "bty", "κ", "τ", "t", "cgiter"):
+        assert key in model.history
+    model, sol, _ = solve_both(pkg, prob, lambda M, **o: M.GAPA(**o), eps=1e-4, verbose=0)
+    assert model.status() == "Optimal"
+    assert abs((model.getobjval() - opt) / opt) < 2e-3
+    model, sol, _ = solve_both(pkg, prob, lambda M, **o: M.GAPA(0.5, 0.9, **o), eps=1e-9, verbose=0)
+    assert model.status() == "Optimal"
+    assert abs((model.getobjval() - opt) / opt) < 1e-6
+    assert np.max(np.abs(model.getsolution()[:n] - xs)) < 1e-5
+
+
+def test_psd_dr_solve(pkg):
+    """test/testPSD.jl:22-25: DR(eps=1e-8) through the PSD kernel == projection, atol 1e-8."""
+    prob = pkg.workloads.psd2x2_reference_problem()
+    model = pkg.solve(prob, pkg.DR(eps=1e-8, verbose=0))
+    assert model.status() == "Optimal"
+    v = model.getsolution()[1:]
+    Y = np.array([[v[0], v[1] / math.sqrt(2)], [v[1] / math.sqrt(2), v[2]]])
+    assert np.allclose(Y, PSD_KNOWN, atol=1e-8, rtol=0)
+
+
+@pytest.mark.parametrize("algname", ["DR", "GAPA", "FISTA"])
+def test_mixed_cone_solve_matches_oracle(pkg, algname):
+    prob = pkg.workloads.small_mixed()
+    mk = {"DR": lambda M, **o: M.DR(**o), "GAPA": lambda M, **o: M.GAPA(**o), "FISTA": lambda M, **o: M.FISTA(**o)}[algname]
+    opts = dict(eps=1e-7, verbose=0, max_iters=3000 if algname != "FISTA" else 600, checki=50)
+    model, sol, _ = solve_both(pkg, prob, mk, **opts)
+    assert model.status() == sol.status
+    assert abs(model.iterations - sol.iterations) <= 50
+    if sol.status == "Optimal":
+        assert np.max(np.abs(model.getsolution() - sol.x)) < 1e-5
+        assert model.getobjval() == pytest.approx(float(prob.c @ prob.x0), abs=1e-4)
+    last, olast = model.status_obj.last, sol.status_obj.last
+    for key in ("p", "d", "g"):
+        assert abs(getattr(last, key) - olast[key]) < 1e-8
+
+
+def test_max_iters_forced_check_and_history(pkg):
+    """solverwrapper.jl:31-34: forced check on the guess when the last iteration was not a check iteration."""
+    prob = pkg.workloads.c1_readme_nnls(seed=2)
+    model = pkg.solve(prob, pkg.GAP(0.5, 2.0, 2.0, max_iters=150, verbose=0, debug=2))
+    assert model.iterations == 150
+    assert [i for i, _ in model.history["p"]] == [100, 150]
+    assert model.history["x"][0][1].shape == (prob.n,)
+    assert model.status() in ("Indeterminate", "Optimal")
+
+
+def test_infeasible_and_unbounded_detection(pkg):
+    """HSDEStatus.jl:58-63 through the GPU residual kernel, same verdict as the oracle."""
+    # primal infeasible: x >= 0, x = -1
+    A = sp.csc_matrix(np.array([[1.0]]))
+    inf = pkg.workloads.ConicProblem("infeasible", A, np.array([-1.0]), np.array([1.0]), [("Zero", 1)], [("NonNeg", 1)])
+    # unbounded: min -x s.t. x >= 0 (one free row to keep m >= 1)
+    unb = pkg.workloads.ConicProblem("unbounded", sp.csc_matrix(np.array([[0.0]])), np.array([0.0]), np.array([-1.0]),
+                                     [("NonNeg", 1)], [("NonNeg", 1)])
+    for prob in (inf, unb):
+        model, sol, _ = solve_both(pkg, prob, lambda M, **o: M.DR(**o), eps=1e-6, verbose=0, max_iters=2000, checki=20)
+        assert model.status() == sol.status, prob.name
+
+
+def test_bad_inputs_fail_loudly(pkg):
+    A = sp.csc_matrix(np.eye(3))
+    with pytest.raises(pkg.lib.FosError):          # gap in the cone ranges (cones.jl:69)
+        pkg.HipHSDE(A, np.zeros(3), np.zeros(3), [("Zero", 2)], [("Free", 3)])
+    with pytest.raises(pkg.lib.FosError):          # SDP length not triangular
+        pkg.HipHSDE(sp.csc_matrix(np.eye(4)), np.zeros(4), np.zeros(4), [("SDP", 4)], [("Free", 4)])
+    with pytest.raises(pkg.lib.FosError):          # exponential cones: unsupported, not silently ignored
+        pkg.HipHSDE(A, np.zeros(3), np.zeros(3), [("ExpPrimal", 3)], [("Free", 3)])
+    with pytest.raises(ValueError):
+        pkg.HipHSDE(A, np.zeros(3), np.zeros(3), [("Zero", [1, 3, 2])], [("Free", 3)])
