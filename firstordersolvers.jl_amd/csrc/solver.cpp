@@ -721,6 +721,24 @@ int fos_getsol(fos_handle h, double* z_out, int32_t force_check, double eps, fos
     return FOS_OK;
 }
 
+int fos_get_affine_state(fos_handle h, double* xinit, int64_t* i, int32_t* firstrun) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    if (xinit) FOS_TRY(download_plain(h, xinit, h->SOL));
+    if (i) *i = h->prox_i;
+    if (firstrun) *firstrun = h->firstrun ? 1 : 0;
+    return FOS_OK;
+}
+
+int fos_set_affine_state(fos_handle h, const double* xinit, int64_t i) {
+    if (!h || !xinit || i < 1) { set_error("bad argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FOS_TRY(upload_plain(h, h->SOL, xinit));
+    h->firstrun = false;
+    h->prox_i = i;
+    return FOS_OK;
+}
+
 int fos_get_cgiter(fos_handle h, int64_t* cgiter) {
     if (!h || !cgiter) { set_error("NULL argument"); return FOS_EINVAL; }
     *cgiter = h->cgiter;

@@ -188,6 +188,18 @@ class HipHSDE:
         _lib.check(self._lib.fos_getsol(self._h, _lib.dptr(z), 1 if force_check else 0, eps, C.byref(res)))
         return z, (res if force_check else None)
 
+    def get_affine_state(self):
+        """(xinit, i, firstrun): CGdata.xinit, AffinePlusLinear.i, CGdata.firstrun."""
+        z = np.empty(self.N)
+        i = C.c_int64(0)
+        fr = C.c_int32(0)
+        _lib.check(self._lib.fos_get_affine_state(self._h, _lib.dptr(z), C.byref(i), C.byref(fr)))
+        return z, i.value, bool(fr.value)
+
+    def set_affine_state(self, xinit, i):
+        xinit = _lib.as_f64(xinit, self.N)
+        _lib.check(self._lib.fos_set_affine_state(self._h, _lib.dptr(xinit), int(i)))
+
     def cgiter(self):
         v = C.c_int64(0)
         _lib.check(self._lib.fos_get_cgiter(self._h, C.byref(v)))

@@ -142,6 +142,13 @@ int fos_step(fos_handle h, int64_t i_first, int64_t count, int64_t checki, doubl
  * override check of solverwrapper.jl:31-34 is evaluated on the guess. */
 int fos_getsol(fos_handle h, double* z_out, int32_t force_check, double eps, fos_check_result* res);
 
+/* S1's persistent state -- CGdata.xinit (the CG warm start, affinepluslinear.jl:101-106,122) and the call counter
+ * AffinePlusLinear.i (:66,114) -- for checkpoint/resume and for handing a steady-state point to the CPU baseline.
+ * get: xinit (N doubles, may be NULL), *i = counter the NEXT prox! call will use, *firstrun = CGdata.firstrun.
+ * set: installs xinit (firstrun becomes false) and the counter. */
+int fos_get_affine_state(fos_handle h, double* xinit, int64_t* i, int32_t* firstrun);
+int fos_set_affine_state(fos_handle h, const double* xinit, int64_t i);
+
 int fos_get_cgiter(fos_handle h, int64_t* cgiter);         /* getcgiter(data), defaults.jl:25-30 */
 int fos_get_alpha12(fos_handle h, double* alpha12);        /* GAPAData.alpha12 */
 int fos_get_prox_count(fos_handle h, int64_t* i);          /* AffinePlusLinear.i (next call's counter) */

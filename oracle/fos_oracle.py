@@ -556,7 +556,8 @@ def hsde_populatesolution(model, z, status):
     endstatus = status.status
     if endstatus == "Continue":
         endstatus = "Indeterminate"
-    return z[0:n] / tau, z[n:n + m] / tau, z[l + n:l + n + m] / tau, endstatus
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return z[0:n] / tau, z[n:n + m] / tau, z[l + n:l + n + m] / tau, endstatus
 
 
 # ----------------------------------------------------------------------------------------
@@ -595,11 +596,12 @@ def residuals(model, z):
     nc = float(np.linalg.norm(c))
     Ax = A @ x
     ATy = A.T @ y
-    p = float(np.linalg.norm(Ax / tau + s / tau - b)) / abs(1 + nb)           # :34
-    d = float(np.linalg.norm(ATy / tau + c - r / tau)) / abs(1 + nc)          # :35
-    ctx = float(np.dot(c, x))                                                 # :36
-    bty = float(np.dot(b, y))                                                 # :37
-    g = abs(ctx / tau + bty / tau) / (1 + abs(ctx / tau) + abs(bty / tau))    # :38
+    with np.errstate(divide="ignore", invalid="ignore"):      # Julia: x/0.0 -> Inf/NaN silently
+        p = float(np.linalg.norm(Ax / tau + s / tau - b)) / abs(1 + nb)           # :34
+        d = float(np.linalg.norm(ATy / tau + c - r / tau)) / abs(1 + nc)          # :35
+        ctx = float(np.dot(c, x))                                                 # :36
+        bty = float(np.dot(b, y))                                                 # :37
+        g = abs(ctx / tau + bty / tau) / (1 + abs(ctx / tau) + abs(bty / tau))    # :38
     return dict(p=p, d=d, g=g, ctx=ctx, bty=bty, kappa=float(kappa), tau=float(tau),
                 nAxs=float(np.linalg.norm(Ax + s)), nATy=float(np.linalg.norm(ATy)), nb=nb, nc=nc)
 
