@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""
+bench.py -- GAP/DR outer iterations per second + achieved HBM GB/s of the CG SpMV (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C4|C2|C3|C5|...]
+
+A "step" is ONE outer iteration of the solver (solverwrapper.jl:23-29: affine projection by warm-started CG over
+the KKT operator -> cone projection -> relaxations) on a synthetic problem already resident in HBM.  Warm-up
+defaults to 200 iterations so that the CG tolerance schedule max(0.2^sqrt(i), l*eps) has reached its floor
+(steady state, ~all of the per-iteration work).  The timed region excludes set-up and the every-`checki` status.
+
+Default workload (all N): C4, BASELINE.json configs[3] "Block-diagonal SDP, 512 PSD blocks of size 64x64, DR,
+cone-sharded across 1/2/4/8 MI355X via RCCL" -- the configuration the metric ("... at 1/2/4/8 GPUs") and the
+north-star targets (1e6-variable problem, >=3.5x at 8 GPUs on the block-PSD workload) are quoted on; it fits one
+GPU.  N > 1 is STRONG scaling of that one problem: rank g owns blocks [512 g/N, 512 (g+1)/N) and only scalars
+cross GPUs (RCCL all-reduce, in stream).  `--workload C2` runs configs[1] (dense 5000x10000 LP) on one GPU.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = fused dual-RHS KKT SpMV,
+HIP events on the solver's stream around every launch in the timed region) and, at N = 1, `cpu_baseline`
+(the oracle restatement timed on one host core for ONE steady-state outer iteration from the GPU's state).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+
+
+def build_problem(pkg, workload, nranks, rank, small):
+    w = pkg.workloads
+    if workload == "C4":
+        nb = 64 if small else 512
+        lo, hi = (nb * rank) // nranks, (nb * (rank + 1)) // nranks
+        prob = w.c4_block_sdp(nblocks=nb, block_range=(lo, hi))
+        desc = "C4 block-diagonal SDP, %d PSD(64) blocks, 32 free vars/block, DR" % nb
+        alg = pkg.DR()
+        glob = dict(m=nb * 2080, n=nb * 32, nnz=nb * 2080 * 32)
+    elif workload == "C5":
+        nb = 8
+        if nranks > nb or nb % nranks:
+            raise SystemExit("C5 has 8 blocks: --gpus must divide 8")
+        lo, hi = (nb * rank) // nranks, (nb * (rank + 1)) // nranks
+        kw = dict(nb_cols=6250, nonneg=3125, nsoc=25, npsd=1) if small else {}
+        prob = w.c5_mixed(nblocks=nb, block_range=(lo, hi), **kw)
+        desc = "C5 mixed cones (NonNeg+SOC+PSD), 8 blocks, FISTA"
+        alg = pkg.FISTA()
+        glob = None
+    elif workload == "C2":
+        if nranks != 1:
+            raise SystemExit("C2 (dense LP) is not block separable: single GPU only")
+        prob = w.c2_lp(m=500, n=1000) if small else w.c2_lp()
+        desc = "C2 random LP, dense A %dx%d stored sparse, Zero/NonNeg cones, DR" % prob.A.shape
+        alg = pkg.DR()
+        glob = None
+    elif workload == "C3":
+        if nranks != 1:
+            raise SystemExit("C3 is generated unsharded: single GPU only")
+        prob = w.c3_socp(n=2000, ncones=100) if small else w.c3_socp()
+        desc = "C3 sparse SOCP, %d x SOC(50), GAPA" % len(prob.K1)
+        alg = pkg.GAPA()
+        glob = None
+    else:
+        raise SystemExit("unknown workload %s" % workload)
+    return prob, alg, desc, glob
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="C4")
+    ap.add_argument("--small", action="store_true", help="reduced sizes (smoke / CI); not a valid benchmark number")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spmv-wg", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+
+    t0 = time.time()
+    prob, alg, desc, glob = build_problem(pkg, args.workload, world, rank, args.small)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2, device=local_rank)
+    if world > 1:
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(pkg.HipHSDE.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        dev.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
+    if args.spmv_wg:
+        dev.set_tuning(spmv_workgroups=args.spmv_wg)
+    dev.set_alg(alg)
+    dev.set_iterate(None)
+    t_setup = time.time() - t0
+
+    BIG = 10 ** 12
+
+    def barrier():
+        dev.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # ---- warm-up (untimed): W outer iterations
+    it = 0
+    cg_hist = []
+    if args.warmup > 0:
+        done, _, _ = dev.step(1, args.warmup, BIG, 1e-8)
+        it += done
+    # ---- timed: exactly K outer iterations
+    dev.profile(True)
+    dev.profile_read()
+    barrier()
+    t1 = time.perf_counter()
+    done, _, _ = dev.step(it + 1, args.steps, BIG, 1e-8)
+    dev.sync()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    it += done
+    elapsed = t2 - t1
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    launches, kms, kbytes = dev.profile_read()
+    dev.profile(False)
+    barrier()
+
+    # one check on the current point (not timed): residuals for the record
+    _, _, chk = dev.step(it + 1, 1, 1, 1e-8)
+    it += 1
+
+    ms_per_step = 1e3 * elapsed / max(1, args.steps)
+    value = args.steps / elapsed
+    avg_kernel_ms = kms / max(1, launches)
+    achieved = kbytes / (avg_kernel_ms * 1e-3) / 1e9 if launches else 0.0
+    out = {
+        "metric": "GAP/DR outer iterations/sec (+ achieved HBM GB/s of the CG SpMV in `roofline`)",
+        "value": round(value, 4),
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic (numpy default_rng, seeds in firstordersolvers.jl_amd/workloads.py)",
+        "config": {
+            "workload": desc + (" [SMALL]" if args.small else ""),
+            "solver": type(alg).__name__,
+            "local_m": int(prob.m), "local_n": int(prob.n), "local_nnz": int(prob.nnz),
+            "cg_iters_per_step": round(launches / max(1, args.steps), 2),
+            "parallelism": "cone-sharded x%d (scalar RCCL all-reduce)" % world if world > 1 else "single GPU",
+            "residuals_after_run": {"p": chk.p, "d": chk.d, "g": chk.g, "iteration": it},
+            "setup_s": round(t_setup, 2), "generate_s": round(t_gen, 2),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "kkt2_kernel (fused dual-RHS KKT SpMV)",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac_of_measured_copy_6290": round(achieved / 6290.0, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": kbytes,
+            "avg_kernel_ms": round(avg_kernel_ms, 5),
+            "launches_timed": launches,
+            "kernel_share_of_step": round(kms / (1e3 * elapsed), 4) if elapsed > 0 else None,
+        },
+    }
+
+    # ---- CPU baseline (rank 0, N = 1): the oracle restatement, one core, ONE steady-state outer iteration
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, str(ROOT / "oracle"))
+        import fos_oracle as orc
+        z = dev.get_iterate()
+        xinit, pi, _ = dev.get_affine_state()
+        om = orc.Model(prob.A, prob.b, prob.c, [(orc.CONE_CODES[k], l) for k, l in prob.K1],
+                       [(orc.CONE_CODES[k], l) for k, l in prob.K2])
+        oalg = {"GAP": lambda: orc.GAP(alg.alpha, alg.alpha1, alg.alpha2), "GAPA": lambda: orc.GAPA(alg.alpha, alg.beta),
+                "FISTA": lambda: orc.FISTA(alg.alpha)}[type(alg).__name__]()
+        oalg.init(om)
+        oalg.S1.cgdata.xinit[:] = xinit
+        oalg.S1.cgdata.firstrun = False
+        oalg.S1.i = pi
+        if isinstance(oalg, orc.GAPA):
+            oalg.alpha12 = dev.alpha12()
+        ost = orc.HSDEStatus(om, BIG, 1e-8, 0, 0)
+        ost.i = it + 1
+        xo = z.copy()
+        if isinstance(oalg, orc.FISTA):
+            cpu = None          # FISTA's y/xold/t live on the device only; skip the hand-off
+        else:
+            tc = time.perf_counter()
+            oalg.step(xo, it + 1, ost)
+            tcpu = time.perf_counter() - tc
+            dev.step(it + 1, 1, BIG, 1e-8)
+            zg = dev.get_iterate()
+            cpu = {
+                "value": round(1.0 / tcpu, 5), "unit": "iterations/s", "cores": 1, "kind": "port",
+                "sample": "1 steady-state outer iteration (i=%d, %d CG iterations) of oracle/fos_oracle.py (numpy/scipy, "
+                          "CSC SpMV as the reference: 4 sweeps per KKT apply) from the GPU's state" % (it + 1, oalg.S1.getcgiter()),
+                "seconds": round(tcpu, 3),
+                "gpu_vs_cpu_same_step_rel_dev": float(np.linalg.norm(zg - xo) / max(1.0, np.linalg.norm(xo))),
+                "gpu_cg_iters_same_step": dev.cgiter(),
+            }
+            out["cpu_baseline"] = cpu
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    dev.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,14 +116,32 @@ def _pairs_for(rng, cones):
     return (np.concatenate(ss) if ss else np.zeros(0)), (np.concatenate(ys) if ys else np.zeros(0))
 
 
-def from_complementary_pair(name, A, K1, K2, rng, meta=None):
+TARGET_NORM = 10.0     # ||b|| and ||c|| of the generated problems (see normalize_data)
+
+
+def normalize_data(x0, s0, y0, r0, A, target=TARGET_NORM):
+    """The reference does not equilibrate its data, and the HSDE iteration started from tau = kappa = 1 spends
+    hundreds of iterations at tau = 0 when ||b||, ||c|| are in the hundreds.  Cones are positively homogeneous, so
+    scaling the primal pair (x0, s0) and the dual pair (y0, r0) by positive constants gives an equivalent problem:
+    pick the constants that make ||b|| = ||c|| = target."""
+    b = A @ x0 + s0
+    c = r0 - A.T @ y0
+    nb, nc = np.linalg.norm(b), np.linalg.norm(c)
+    sp_, sd_ = (target / nb if nb > 0 else 1.0), (target / nc if nc > 0 else 1.0)
+    return x0 * sp_, s0 * sp_, y0 * sd_, r0 * sd_, b * sp_, c * sd_
+
+
+def from_complementary_pair(name, A, K1, K2, rng, meta=None, normalize=True):
     """b = A x0 + s0, c = r0 - A'y0 with (s0,y0) and (x0,r0) complementary cone pairs."""
     A = sp.csc_matrix(A)
     A.sort_indices()
     s0, y0 = _pairs_for(rng, K1)
     x0, r0 = _pairs_for(rng, K2)
-    b = A @ x0 + s0
-    c = r0 - A.T @ y0
+    if normalize:
+        x0, s0, y0, r0, b, c = normalize_data(x0, s0, y0, r0, A)
+    else:
+        b = A @ x0 + s0
+        c = r0 - A.T @ y0
     return ConicProblem(name, A, b, c, list(K1), list(K2), x0=x0, y0=y0, s0=s0, meta=meta or {})
 
 
@@ -191,8 +209,7 @@ def c2_lp(seed=1, m=5000, n=10000, scale=100.0):
     mask[basis] = True
     x0[mask] = rng.uniform(0.5, 1.5, size=int(mask.sum()))
     r0[~mask] = rng.uniform(0.5, 1.5, size=int((~mask).sum()))
-    b = A @ x0 + s0
-    c = r0 - A.T @ y0
+    x0, s0, y0, r0, b, c = normalize_data(x0, s0, y0, r0, A)
     return ConicProblem("C2-lp-dense-%dx%d" % (m, n), A, b, c, K1, K2, x0=x0, y0=y0, s0=s0,
                         meta=dict(scale=scale))
 
@@ -239,9 +256,13 @@ def c4_block_sdp(seed=3, nblocks=512, k=64, p=32, scale=None, block_range=None):
         x0s.append(rng.standard_normal(p))
     A = sp.block_diag([sp.csc_matrix(D) for D in datas], format="csc")
     A.sort_indices()
-    x0 = np.concatenate(x0s)
-    s0 = np.concatenate(s0s)
-    y0 = np.concatenate(y0s)
+    # data scaling (see normalize_data): per-block norms are ~ k/2 for b and ~ k/12 for c, so these constants put
+    # ||b|| and ||c|| near TARGET_NORM for any number of blocks; a shard only needs the GLOBAL block count.
+    sig_p = TARGET_NORM / (0.52 * k * math.sqrt(nblocks))
+    sig_d = TARGET_NORM / (0.086 * k * math.sqrt(nblocks))
+    x0 = np.concatenate(x0s) * sig_p
+    s0 = np.concatenate(s0s) * sig_p
+    y0 = np.concatenate(y0s) * sig_d
     b = A @ x0 + s0
     c = -(A.T @ y0)                                       # K2 = Free  ->  r0 = 0
     K1 = [("SDP", d)] * nb
@@ -271,9 +292,13 @@ def c5_mixed(seed=4, nblocks=8, nb_cols=62500, nonneg=31250, nsoc=250, socdim=50
         x0s.append(rng.standard_normal(nb_cols))
     A = sp.block_diag(blocks, format="csc")
     A.sort_indices()
-    x0 = np.concatenate(x0s)
-    s0 = np.concatenate(s0s)
-    y0 = np.concatenate(y0s)
+    # deterministic data scaling from global quantities only (see normalize_data / c4_block_sdp)
+    est_b = math.sqrt(nblocks * mb * (1.0 + density * nb_cols))
+    est_c = math.sqrt(nblocks * nb_cols * density * mb * 0.5)
+    sig_p, sig_d = TARGET_NORM / est_b, TARGET_NORM / est_c
+    x0 = np.concatenate(x0s) * sig_p
+    s0 = np.concatenate(s0s) * sig_p
+    y0 = np.concatenate(y0s) * sig_d
     b = A @ x0 + s0
     c = -(A.T @ y0)
     K2 = [("Free", nb_cols * (hi - lo))]
