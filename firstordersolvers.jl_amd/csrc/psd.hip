@@ -7,14 +7,19 @@
 // at 0, rebuild, repack the lower triangle, scale the diagonal back by 1/sqrt(2).  The dual copy of the cone is
 // Moreau's  y = x + P(-x)  (cones.jl:80-85).
 //
-// One workgroup (256 threads) per (cone, part) matrix; G (k x k) and V (k x k) live in LDS (global scratch for
-// orders that do not fit).  Eigen-solver: one-sided (Hestenes) Jacobi on the SHIFTED matrix M + sigma I,
-// sigma = ||M||_F, which is positive semidefinite, so its SVD is its eigen-decomposition (plain one-sided Jacobi
-// on an indefinite M cannot separate +lambda from -lambda).  Column pairs of a round-robin tournament step are
-// disjoint, so a step needs one barrier; every pair is handled by `tpp` lanes (a power of two <= 64) that
-// butterfly-reduce the three column dot products.  After convergence G = V diag(lambda + sigma):
-// lambda_j = ||g_j|| - sigma, and  P = sum_{lambda_j > 0} lambda_j v_j v_j'.
-// Accuracy: absolute error O(eps ||M||), the same class as LAPACK's dspev that the reference calls.
+// One workgroup (256 threads) per (cone, part) matrix; ONE k x k array G lives in LDS (global scratch for orders
+// that do not fit).  Eigen-solver: one-sided (Hestenes) Jacobi on the SHIFTED matrix M' = M + sigma I:
+//   * G starts as M' and column pairs are rotated until all columns are mutually orthogonal; then G = V diag(l'),
+//     |l'_j| = ||g_j||, v_j = g_j / ||g_j||: the eigenvectors are read off G itself, no accumulated V is kept
+//     (halves LDS footprint and traffic).
+//   * sigma = 0.505 ||M||_F >= |lambda_min| / 2 is enough: an eigenvalue kept by the projection (lambda > 0) has
+//     ||g|| = lambda + sigma > sigma, every other column has ||g|| <= max(sigma, |lambda_min| - sigma) <= sigma, and two
+//     columns whose l' = +-same magnitude (which plain one-sided Jacobi cannot separate) are both dropped ones.
+//     So  P = sum_{||g_j|| > sigma} (||g_j|| - sigma) / ||g_j||^2  g_j g_j'.
+//   * column pairs of a round-robin tournament step are disjoint, so a step needs one barrier; every pair is
+//     handled by `tpp` lanes (a power of two <= 64) that reduce the three column dot products in-register (DPP
+//     for the common 8-lane case).
+// Accuracy: absolute error O(k eps ||M||), the class of LAPACK's dspev that the reference calls.
 #include "fos_internal.hpp"
 
 namespace fos {
@@ -33,7 +38,7 @@ __host__ __device__ inline int psd_ld(int k) {
     return ld;
 }
 
-__host__ inline size_t psd_lds_bytes(int k) { return (size_t)(16 + 2 * k * psd_ld(k) + k + 16) * sizeof(double); }
+__host__ inline size_t psd_lds_bytes(int k) { return (size_t)(16 + k * psd_ld(k) + k + 16) * sizeof(double); }
 
 __device__ __forceinline__ void idx_to_ij(int idx, int k, int& i, int& j) {
     // packed lower triangle, column-major: column j starts at S(j) = j k - j (j-1)/2
@@ -47,9 +52,32 @@ __device__ __forceinline__ void idx_to_ij(int idx, int k, int& i, int& j) {
     i = jj + (idx - (jj * k - (jj * (jj - 1)) / 2));
 }
 
+// ---- in-register reductions over a lane group
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over aligned groups of 8 lanes: lane i + lane 7-i (row_half_mirror), then xor 2, xor 1 inside the quad
+__device__ __forceinline__ double group8_sum(double v) {
+    v += dpp_f64<0x141>(v);        // row_half_mirror
+    v += dpp_f64<0x4E>(v);         // quad_perm [2,3,0,1]
+    v += dpp_f64<0xB1>(v);         // quad_perm [1,0,3,2]
+    return v;
+}
 __device__ __forceinline__ double group_sum(double v, int tpp) {
     for (int off = tpp >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+}
+
+// 1/sqrt(x) to ~1 ulp: hardware estimate + two Newton steps (no IEEE division/sqrt sequences on the critical path)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
 }
 
 template <bool USE_LDS>
@@ -71,10 +99,9 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
     double* G;                                   // address space known at compile time: ds_* vs global_* accesses
     if constexpr (USE_LDS) G = smem + 16;
     else G = gscratch + (size_t)blockIdx.x * scratch_stride;
-    double* V = G + (size_t)k * ld;
-    double* wgt = V + (size_t)k * ld;           // k eigen-weights
+    double* wgt = G + (size_t)k * ld;           // k eigen-weights
 
-    // ---- load: M = smat(sgn x) with the diagonal scaled by sqrt(2); V = I
+    // ---- load: M = smat(sgn x) with the diagonal scaled by sqrt(2)
     double fro = 0.0;
     for (int idx = tid; idx < len; idx += PSD_THREADS) {
         int i, j;
@@ -85,14 +112,10 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
         G[i + (size_t)j * ld] = v;
         G[j + (size_t)i * ld] = v;
     }
-    for (int e = tid; e < k * k; e += PSD_THREADS) {
-        const int i = e % k, j = e / k;
-        V[i + (size_t)j * ld] = (i == j) ? 1.0 : 0.0;
-    }
     for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
     if ((tid & 63) == 0) red[tid >> 6] = fro;
     __syncthreads();
-    if (tid == 0) red[4] = sqrt((red[0] + red[1]) + (red[2] + red[3]));
+    if (tid == 0) red[4] = 0.505 * sqrt((red[0] + red[1]) + (red[2] + red[3]));
     __syncthreads();
     const double sigma = red[4];
     for (int i = tid; i < k; i += PSD_THREADS) G[i + (size_t)i * ld] += sigma;
@@ -105,7 +128,8 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
     while (tpp > 1 && npair * tpp > PSD_THREADS) tpp >>= 1;
     const int sh = 31 - __clz(tpp);
     const int slot = tid >> sh, lig = tid & (tpp - 1), nslot = PSD_THREADS >> sh;
-    const double tol = sqrt((double)k) * 2.220446049250313e-16;
+    const double tol = (double)k * 2.220446049250313e-16;
+    const double tol2 = tol * tol;
 
     if (k > 1 && sigma > 0.0) {
         for (int sweep = 0; sweep < PSD_MAX_SWEEPS; ++sweep) {
@@ -123,21 +147,22 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
                         const double u = gp[i], v = gq[i];
                         a += u * u; b += v * v; g += u * v;
                     }
-                    a = group_sum(a, tpp); b = group_sum(b, tpp); g = group_sum(g, tpp);
-                    if (fabs(g) <= tol * sqrt(a * b)) continue;
+                    if (tpp == 8) { a = group8_sum(a); b = group8_sum(b); g = group8_sum(g); }
+                    else { a = group_sum(a, tpp); b = group_sum(b, tpp); g = group_sum(g, tpp); }
+                    if (g * g <= tol2 * (a * b)) continue;
                     rotated = 1;
-                    const double zeta = (b - a) / (2.0 * g);
-                    const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-                    double* vp = V + (size_t)p * ld;
-                    double* vq = V + (size_t)q * ld;
+                    // rotation that makes the two columns orthogonal: tan(2 theta) = 2g / (b - a), |theta| <= pi/4
+                    //   h = sqrt(d^2 + 4 g^2), cos^2 = (1 + |d|/h)/2, sin = sign(d) g / (h cos)
+                    const double d = b - a;
+                    const double rh = fast_rsqrt(d * d + 4.0 * g * g);
+                    const double c2 = 0.5 + 0.5 * fabs(d) * rh;
+                    const double rc = fast_rsqrt(c2);
+                    const double cs = c2 * rc;
+                    const double sn = copysign(g * rh * rc, d * g);
                     for (int i = lig; i < k; i += tpp) {
                         const double u = gp[i], v = gq[i];
                         gp[i] = cs * u - sn * v;
                         gq[i] = sn * u + cs * v;
-                        const double uu = vp[i], vv = vq[i];
-                        vp[i] = cs * uu - sn * vv;
-                        vq[i] = sn * uu + cs * vv;
                     }
                 }
                 __syncthreads();
@@ -146,22 +171,22 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
         }
     }
 
-    // ---- eigenvalues: lambda_j = ||g_j|| - sigma ; weights max(lambda_j, 0)
+    // ---- weights: kept columns have ||g_j|| > sigma ; P = sum_j wgt_j g_j g_j', wgt_j = (||g_j|| - sigma) / ||g_j||^2
     for (int j = tid; j < k; j += PSD_THREADS) {
         double s = 0.0;
         const double* gj = G + (size_t)j * ld;
         for (int i = 0; i < k; ++i) s += gj[i] * gj[i];
-        const double lam = sqrt(s) - sigma;
-        wgt[j] = lam > 0.0 ? lam : 0.0;
+        const double nr = sqrt(s);
+        wgt[j] = nr > sigma ? (nr - sigma) / s : 0.0;
     }
     __syncthreads();
 
-    // ---- rebuild the lower triangle of P = V diag(w) V', repack, unscale the diagonal; dual: y = x + P(-x)
+    // ---- rebuild the lower triangle, repack, unscale the diagonal; dual: y = x + P(-x)
     for (int idx = tid; idx < len; idx += PSD_THREADS) {
         int i, j;
         idx_to_ij(idx, k, i, j);
         double s = 0.0;
-        for (int t = 0; t < k; ++t) s += wgt[t] * V[i + (size_t)t * ld] * V[j + (size_t)t * ld];
+        for (int t = 0; t < k; ++t) s += wgt[t] * G[i + (size_t)t * ld] * G[j + (size_t)t * ld];
         if (i == j) s *= INV_SQRT2;
         if (dual) s = x[2 * (int64_t)idx] + s;
         y[2 * (int64_t)idx] = s;
@@ -171,7 +196,7 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
 size_t psd_scratch_bytes(int kmax, int ncones) {
     if (ncones <= 0) return 0;
     if (psd_lds_bytes(kmax) <= 160 * 1024 - 256) return 0;
-    return (size_t)2 * ncones * (size_t)(2 * kmax * psd_ld(kmax) + kmax + 16) * sizeof(double);
+    return (size_t)2 * ncones * (size_t)(kmax * psd_ld(kmax) + kmax + 16) * sizeof(double);
 }
 
 // cones must be sorted so that all of them can run with the same storage choice; the launcher splits the list by
@@ -186,7 +211,7 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(psd_kernel): %s", hipGetErrorString(e)); return FOS_EHIP; }
         attr_set = true;
     }
-    const size_t stride = (size_t)(2 * kmax * psd_ld(kmax) + kmax + 16);
+    const size_t stride = (size_t)(kmax * psd_ld(kmax) + kmax + 16);
     if (use_lds)
         hipLaunchKernelGGL(psd_kernel<true>, dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride);
     else
