@@ -6,11 +6,16 @@
 //   rows n..n+m-1 = rows of A                  : entries (i, a_ji)      -> gather from the x part
 // S * [vx; vy] = [A'vy; A vx] -- the two SpMVs of HSDEMatrixQ.mul! (HSDEAffine.jl:51-52) in one sweep.
 //
-// Rows are grouped into ROW BLOCKS (CSR-adaptive): consecutive rows with at most NNZ_BLK non-zeros and at
-// most ROWS_BLK rows form a "stream" block (staged through LDS, then reduced per row); a row with more than
-// NNZ_BLK non-zeros is a block of its own ("long" row, reduced by the whole workgroup).  Each block's entries
-// start at a multiple of NNZ_ALIGN in the padded arrays (pad: value 0, a valid column; never summed).
-// Row blocks are then split among the persistent workgroups of the SpMV grid, balanced by non-zeros.
+// Rows are grouped into ROW BLOCKS, the unit of work of ONE wavefront.  Three kinds:
+//   ELL   consecutive rows of similar length (<= WROWS rows, padding <= ~1/6): `tpr` = 64 / nextpow2(rows) lanes per
+//         row, entries stored LANE-MAJOR (entry e of row i at step e / tpr, lane i*tpr + e % tpr), so the
+//         wavefront's coalesced 64-entry loads land every product in the lane that sums it -- no LDS, no shuffles
+//         beyond log2(tpr) DPP steps;
+//   LDS   irregular rows (<= WNNZ entries): CSR order, products staged through the wavefront's LDS slice and
+//         reduced per row;
+//   LONG  a row with more than ELL_MAX entries: strided by the wavefront, reduced in-register.
+// Each block's entries start at a multiple of NNZ_ALIGN (pad: value 0, column 0; masked in the kernel).
+// Row blocks are then split among the persistent wavefronts of the SpMV grid, balanced by stored entries.
 #include <algorithm>
 #include <cstdarg>
 
@@ -30,29 +35,27 @@ void set_error(const char* fmt, ...) {
 const char* last_error_cstr() { return g_err; }
 
 void partition_workgroups(HostBlkCsr* S, int nwg_target) {
-    int nblk = S->nblk;
-    int nwg = std::max(1, std::min(nwg_target, nblk));
+    const int nblk = S->nblk;
+    int nwg = std::max(1, std::min(nwg_target, (nblk + SPMV_WAVES - 1) / SPMV_WAVES));
     if (nwg >= 8) nwg -= nwg % 8;     // XCD remap in the kernel wants a multiple of 8
-    // cost of a block: its padded non-zeros plus a per-row term for the epilogue
+    const int nwaves = nwg * SPMV_WAVES;
+    // cost of a block: its non-zeros plus a per-row term for the epilogue and a fixed per-block term
     std::vector<double> cost(nblk + 1, 0.0);
-    for (int b = 0; b < nblk; ++b) {
-        double nz = double(S->blk_nnz1[b] - S->blk_nnz0[b]);
-        double rows = double(S->blk_row0[b + 1] - S->blk_row0[b]);
-        cost[b + 1] = cost[b] + nz + 4.0 * rows + 32.0;
-    }
-    double total = cost[nblk];
-    S->wg_blk0.assign(nwg + 1, 0);
+    for (int b = 0; b < nblk; ++b)
+        cost[b + 1] = cost[b] + double(S->blk[b].cnt) + 4.0 * double(S->blk[b].nrows()) + 32.0;
+    const double total = cost[nblk];
+    S->wave_blk0.assign(nwaves + 1, 0);
     int b = 0;
-    for (int g = 1; g < nwg; ++g) {
-        double target = total * double(g) / double(nwg);
+    for (int g = 1; g < nwaves; ++g) {
+        const double target = total * double(g) / double(nwaves);
         while (b < nblk && cost[b + 1] <= target) ++b;
-        // choose the closer boundary
-        if (b < nblk && (target - cost[b]) > (cost[b + 1] - target)) ++b;
-        if (b < S->wg_blk0[g - 1]) b = S->wg_blk0[g - 1];
-        S->wg_blk0[g] = b;
+        if (b < nblk && (target - cost[b]) > (cost[b + 1] - target)) ++b;     // the closer boundary
+        if (b < S->wave_blk0[g - 1]) b = S->wave_blk0[g - 1];
+        S->wave_blk0[g] = b;
     }
-    S->wg_blk0[nwg] = nblk;
+    S->wave_blk0[nwaves] = nblk;
     S->nwg = nwg;
+    S->nwaves = nwaves;
 }
 
 int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
@@ -80,44 +83,117 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     S.nrows = nrows;
     S.nnz = 2 * nnz;
     S.row_rel.assign(nrows, 0);
-    std::vector<int64_t> row_pos(nrows, 0);   // position of every row's first entry in the padded arrays
+    // where the e-th entry of row r goes: ELL rows (tpr > 0): base + (e / tpr) * 64 + lane0 + e % tpr ; else base + e
+    std::vector<int64_t> row_base(nrows, 0);
+    std::vector<uint8_t> row_tpr(nrows, 0), row_lane0(nrows, 0);
+    auto nextpow2 = [](int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; };
     int64_t pos = 0;
     int64_t r = 0;
     while (r < nrows) {
-        int64_t r0 = r;
-        int64_t len0 = rp[r + 1] - rp[r];
-        int64_t blk_start = (pos + NNZ_ALIGN - 1) / NNZ_ALIGN * NNZ_ALIGN;
-        int64_t cnt = 0;
-        if (len0 > NNZ_BLK) {                   // long row: a block of its own
-            row_pos[r] = blk_start;
-            cnt = len0;
+        const int64_t r0 = r;
+        const int64_t len0 = rp[r + 1] - rp[r];
+        const int64_t blk_start = (pos + NNZ_ALIGN - 1) / NNZ_ALIGN * NNZ_ALIGN;
+        BlkDesc d;
+        d.nnz0 = blk_start;
+        d.row0 = (int32_t)r0;
+        if (len0 > ELL_MAX) {                   // long row: a block of its own, strided by one wavefront
+            row_base[r] = blk_start;
+            d.cnt = len0;
+            d.info = 1 | (BLK_LONG << 8);
             r += 1;
         } else {
-            while (r < nrows && (r - r0) < ROWS_BLK) {
-                int64_t len = rp[r + 1] - rp[r];
-                if (cnt + len > NNZ_BLK) break;
-                row_pos[r] = blk_start + cnt;
-                S.row_rel[r] = (uint16_t)cnt;
+            // candidate lane-major block: up to WROWS rows / ELL_MAX entries
+            int64_t cnt = 0, maxlen = 0, rr = r;
+            while (rr < nrows && (rr - r0) < WROWS) {
+                const int64_t len = rp[rr + 1] - rp[rr];
+                if (cnt + len > ELL_MAX) break;
+                const int64_t R1 = rr - r0 + 1;
+                const int64_t tpr1 = 64 / nextpow2(R1);
+                const int64_t ml = std::max(maxlen, len);
+                const int64_t T1 = (ml + tpr1 - 1) / tpr1;
+                if (64 * T1 > ELL_MAX) break;
                 cnt += len;
-                r += 1;
+                maxlen = ml;
+                rr += 1;
+            }
+            // pick the largest row count (the greedy one, else the powers of two below it) whose lane-major layout
+            // wastes at most ~1/6 of the stored entries
+            int64_t R = rr - r0, tpr = 1, T = 0, padded = 0;
+            bool ell_ok = false;
+            for (int64_t Rc = R; Rc >= 1; Rc = (Rc == nextpow2(Rc) ? Rc / 2 : nextpow2(Rc) / 2)) {
+                int64_t c2 = 0, ml = 0;
+                for (int64_t i = 0; i < Rc; ++i) {
+                    const int64_t len = rp[r0 + i + 1] - rp[r0 + i];
+                    c2 += len;
+                    ml = std::max(ml, len);
+                }
+                const int64_t tp = 64 / nextpow2(Rc);
+                const int64_t Tc = (ml + tp - 1) / tp;
+                if (64 * Tc <= c2 + c2 / 6 + 32 && 64 * Tc <= ELL_MAX) {
+                    R = Rc; tpr = tp; T = Tc; padded = 64 * Tc; cnt = c2; rr = r0 + Rc;
+                    ell_ok = true;
+                    break;
+                }
+                if (Rc == 1) break;
+            }
+            if (ell_ok) {
+                // ---- ELL block: lane = row * tpr + (e % tpr), step = e / tpr
+                for (int64_t i = 0; i < R; ++i) {
+                    row_base[r0 + i] = blk_start;
+                    row_tpr[r0 + i] = (uint8_t)tpr;
+                    row_lane0[r0 + i] = (uint8_t)(i * tpr);
+                    S.row_rel[r0 + i] = (uint16_t)(rp[r0 + i + 1] - rp[r0 + i]);      // row LENGTH
+                }
+                d.cnt = padded;
+                d.info = (int32_t)R | (BLK_ELL << 8) | ((int32_t)T << 16);
+                r = rr;
+            } else {
+                // ---- irregular rows: LDS-staged block of at most WNNZ entries (a row longer than that alone: ELL, 64 lanes)
+                cnt = 0;
+                rr = r;
+                while (rr < nrows && (rr - r0) < WROWS) {
+                    const int64_t len = rp[rr + 1] - rp[rr];
+                    if (cnt + len > WNNZ) break;
+                    row_base[rr] = blk_start + cnt;
+                    S.row_rel[rr] = (uint16_t)cnt;                                      // row START
+                    cnt += len;
+                    rr += 1;
+                }
+                if (rr == r) {       // first row alone exceeds WNNZ (but <= ELL_MAX): one row, 64 lanes, lane-major
+                    const int64_t T1 = (len0 + 63) / 64;
+                    row_base[r] = blk_start;
+                    row_tpr[r] = 64;
+                    row_lane0[r] = 0;
+                    S.row_rel[r] = (uint16_t)len0;
+                    d.cnt = 64 * T1;
+                    d.info = 1 | (BLK_ELL << 8) | ((int32_t)T1 << 16);
+                    r += 1;
+                } else {
+                    d.cnt = cnt;
+                    d.info = (int32_t)(rr - r0) | (BLK_LDS << 8);
+                    r = rr;
+                }
             }
         }
-        S.blk_row0.push_back((int32_t)r0);
-        S.blk_nnz0.push_back(blk_start);
-        S.blk_nnz1.push_back(blk_start + cnt);
-        pos = blk_start + cnt;
+        S.blk.push_back(d);
+        pos = blk_start + d.cnt;
     }
-    S.blk_row0.push_back((int32_t)nrows);
-    S.nblk = (int32_t)S.blk_nnz0.size();
+    S.nblk = (int32_t)S.blk.size();
     S.nnz_padded = (pos + NNZ_ALIGN - 1) / NNZ_ALIGN * NNZ_ALIGN;
     if (S.nnz_padded == 0) S.nnz_padded = NNZ_ALIGN;
 
     S.val.assign(S.nnz_padded, 0.0);
     S.col.assign(S.nnz_padded, 0);
+    auto place = [&](int64_t row, int64_t e) -> int64_t {
+        const int64_t tpr = row_tpr[row];
+        if (tpr == 0) return row_base[row] + e;
+        return row_base[row] + (e / tpr) * 64 + row_lane0[row] + (e % tpr);
+    };
     // ---- fill A' rows (row j of S = column j of A, entries already sorted by row index)
     for (int64_t j = 0; j < n; ++j) {
-        int64_t dst = row_pos[j];
-        for (int64_t k = colptr[j] - 1; k < colptr[j + 1] - 1; ++k, ++dst) {
+        int64_t e = 0;
+        for (int64_t k = colptr[j] - 1; k < colptr[j + 1] - 1; ++k, ++e) {
+            const int64_t dst = place(j, e);
             S.val[dst] = nzval[k];
             S.col[dst] = (int32_t)(n + rowval[k] - 1);
         }
@@ -127,8 +203,8 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         std::vector<int64_t> fill(m, 0);
         for (int64_t j = 0; j < n; ++j) {
             for (int64_t k = colptr[j] - 1; k < colptr[j + 1] - 1; ++k) {
-                int64_t i = rowval[k] - 1;
-                int64_t dst = row_pos[n + i] + fill[i]++;
+                const int64_t i = rowval[k] - 1;
+                const int64_t dst = place(n + i, fill[i]++);
                 S.val[dst] = nzval[k];
                 S.col[dst] = (int32_t)j;
             }

@@ -41,34 +41,44 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------------------------- SpMV storage
-constexpr int SPMV_THREADS = 256;
-constexpr int NNZ_BLK = 1024;       // non-zeros staged through LDS per row block (16 B each for 2 RHS)
-constexpr int ROWS_BLK = 256;       // max rows per row block (>= 1 epilogue thread per row)
+constexpr int SPMV_THREADS = 256;   // 4 independent wavefronts per workgroup
+constexpr int SPMV_WAVES = SPMV_THREADS / 64;
+constexpr int WNNZ = 256;           // LDS-staged row block: max non-zeros (16 B each for 2 RHS in the wavefront's LDS slice)
+constexpr int ELL_MAX = 1024;       // lane-major ("ELL") row block: max padded entries (a multiple of 64)
+constexpr int WROWS = 64;           // max rows per row block (>= 1 epilogue lane per row)
 constexpr int NNZ_ALIGN = 4;        // every row block starts at a multiple of 4 entries (16/32-byte aligned)
+
+enum BlkKind : int32_t { BLK_LDS = 0, BLK_ELL = 1, BLK_LONG = 2 };
+
+struct BlkDesc {                    // one row block = the unit of work of ONE wavefront
+    int64_t nnz0;                   // first entry in the padded arrays (multiple of NNZ_ALIGN)
+    int64_t cnt;                    // stored entries (ELL: 64 * steps, padding included)
+    int32_t row0;                   // first row
+    int32_t info;                   // nrows (bits 0..7) | kind << 8 | ELL steps T << 16
+    __host__ __device__ int nrows() const { return info & 0xFF; }
+    __host__ __device__ int kind() const { return (info >> 8) & 0x3; }
+    __host__ __device__ int steps() const { return (info >> 16) & 0xFFFF; }
+};
 
 // Host-side result of building the stacked operator; uploaded verbatim.
 struct HostBlkCsr {
     int64_t nrows = 0, nnz = 0, nnz_padded = 0;
     std::vector<double> val;
     std::vector<int32_t> col;
-    std::vector<int32_t> blk_row0;     // [nblk+1]
-    std::vector<int64_t> blk_nnz0;     // [nblk]   aligned first entry
-    std::vector<int64_t> blk_nnz1;     // [nblk]   true end
-    std::vector<uint16_t> row_rel;     // [nrows]  row start relative to blk_nnz0 (stream blocks)
-    std::vector<int32_t> wg_blk0;      // [nwg+1]  row blocks owned by each workgroup
-    int32_t nblk = 0, nwg = 0;
+    std::vector<BlkDesc> blk;          // [nblk]
+    std::vector<uint16_t> row_rel;     // [nrows]  row start relative to its block's nnz0 (stream blocks)
+    std::vector<int32_t> wave_blk0;    // [nwaves+1]  row blocks owned by each wavefront of the grid
+    int32_t nblk = 0, nwg = 0, nwaves = 0;
 };
 
 struct DevBlkCsr {
     int64_t nrows, nnz, nnz_padded;
     const double* val;
     const int32_t* col;
-    const int32_t* blk_row0;
-    const int64_t* blk_nnz0;
-    const int64_t* blk_nnz1;
+    const BlkDesc* blk;
     const uint16_t* row_rel;
-    const int32_t* wg_blk0;
-    int32_t nblk, nwg;
+    const int32_t* wave_blk0;
+    int32_t nblk, nwg, nwaves;
 };
 
 // Builds S = [[0, A'],[A, 0]] from Julia CSC (1-based).  Returns FOS_EINVAL on malformed input.

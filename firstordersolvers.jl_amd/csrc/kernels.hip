@@ -56,11 +56,36 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
 
 // ------------------------------------------------------------------------------------------------ row-block SpMV core
 //
-// One persistent workgroup walks its slice of row blocks.  Stream block: the block's <= NNZ_BLK entries are
-// loaded lane-consecutively (coalesced 8 B value + 4 B column per lane), multiplied by the gathered vector
-// element(s) and staged in LDS; then `tpr` lanes per row sum that row's LDS segment (tpr = power of two chosen
-// from the number of rows in the block) and finish with an in-wave butterfly.  Long row: the whole workgroup
-// strides the row and block-reduces.  Summation order is fixed by the storage -> bit-reproducible run to run.
+// The unit of work is ONE WAVEFRONT (no workgroup barrier anywhere in the sweep): each of the grid's persistent
+// wavefronts walks its own slice of row blocks.
+//   Stream block: the block's <= WNNZ entries are loaded lane-consecutively (coalesced 8 B value + 4 B column per
+//   lane, non-temporal: the matrix is read once per sweep and must not evict the gathered vector from L2),
+//   multiplied by the gathered vector element(s) and staged in the wavefront's private LDS slice; then `tpr` lanes
+//   per row (a power of two chosen from the number of rows in the block) sum that row's LDS segment and finish with
+//   an in-register DPP butterfly.  Wave-synchronous: LDS operations of one wavefront execute in order.
+//   Long row (> WNNZ entries): the wavefront strides the row, 4 loads in flight per lane, and reduces in-register.
+// Summation order is fixed by the storage -> bit-reproducible run to run.
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over aligned groups of `tpr` lanes (tpr a power of two, wave-uniform); every lane of a group gets the total
+__device__ __forceinline__ double group_sum(double v, int tpr) {
+    if (tpr >= 2) v += dpp_f64<0xB1>(v);       // quad_perm [1,0,3,2]
+    if (tpr >= 4) v += dpp_f64<0x4E>(v);       // quad_perm [2,3,0,1]
+    if (tpr >= 8) v += dpp_f64<0x141>(v);      // row_half_mirror
+    if (tpr >= 16) v += dpp_f64<0x140>(v);     // row_mirror
+    if (tpr >= 32) v += __shfl_xor(v, 16, 64);
+    if (tpr >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <class T>
+__device__ __forceinline__ T nt_load(const T* p) { return __builtin_nontemporal_load(p); }
 
 template <int NRHS>
 struct Gather;
@@ -78,92 +103,127 @@ struct Gather<1> {
     __device__ __forceinline__ double operator()(double v, int c) const { return v * w[2 * (int64_t)c]; }
 };
 
+constexpr int WPL = WNNZ / 64;      // stream entries per lane
+
 template <int NRHS, class Epi>
-__device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>& gat, Epi& epi, double* prod, double* red) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>& gat, Epi& epi, double* prod_all) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = xcd_remap(blockIdx.x, S.nwg);
-    const int b_lo = S.wg_blk0[g], b_hi = S.wg_blk0[g + 1];
+    double* prod = prod_all + (size_t)wv * (WNNZ * NRHS);          // this wavefront's LDS slice
+    const int wave = g * SPMV_WAVES + wv;
+    const int b_lo = S.wave_blk0[wave], b_hi = S.wave_blk0[wave + 1];
     for (int b = b_lo; b < b_hi; ++b) {
-        const int r0 = S.blk_row0[b], r1 = S.blk_row0[b + 1];
-        const int64_t e0 = S.blk_nnz0[b], e1 = S.blk_nnz1[b];
-        const int64_t cnt64 = e1 - e0;
-        if (cnt64 > NNZ_BLK) {
-            // ---------------- long row r0
+        const BlkDesc d = S.blk[b];
+        const int kind = d.kind();
+        if (kind == BLK_LONG) {
+            // ---------------- long row d.row0
             double a1 = 0.0, a2 = 0.0;
             const double* __restrict__ val = S.val;
             const int32_t* __restrict__ col = S.col;
-            int64_t k = e0 + tid;
-            for (; k + 3 * SPMV_THREADS < e1; k += 4 * SPMV_THREADS) {
-                double v0 = val[k], v1 = val[k + SPMV_THREADS], v2 = val[k + 2 * SPMV_THREADS], v3 = val[k + 3 * SPMV_THREADS];
-                int c0 = col[k], c1 = col[k + SPMV_THREADS], c2 = col[k + 2 * SPMV_THREADS], c3 = col[k + 3 * SPMV_THREADS];
+            const int64_t e1 = d.nnz0 + d.cnt;
+            int64_t k = d.nnz0 + lane;
+            for (; k + 3 * 64 < e1; k += 4 * 64) {
+                const double v0 = nt_load(val + k), v1 = nt_load(val + k + 64), v2 = nt_load(val + k + 128), v3 = nt_load(val + k + 192);
+                const int c0 = nt_load(col + k), c1 = nt_load(col + k + 64), c2 = nt_load(col + k + 128), c3 = nt_load(col + k + 192);
                 if constexpr (NRHS == 2) {
-                    d2 p0 = gat(v0, c0), p1 = gat(v1, c1), p2 = gat(v2, c2), p3 = gat(v3, c3);
+                    const d2 p0 = gat(v0, c0), p1 = gat(v1, c1), p2 = gat(v2, c2), p3 = gat(v3, c3);
                     a1 += p0.x; a2 += p0.y; a1 += p1.x; a2 += p1.y; a1 += p2.x; a2 += p2.y; a1 += p3.x; a2 += p3.y;
                 } else {
                     a1 += gat(v0, c0); a1 += gat(v1, c1); a1 += gat(v2, c2); a1 += gat(v3, c3);
                 }
             }
-            for (; k < e1; k += SPMV_THREADS) {
-                if constexpr (NRHS == 2) { d2 p0 = gat(val[k], col[k]); a1 += p0.x; a2 += p0.y; }
-                else { a1 += gat(val[k], col[k]); }
+            for (; k < e1; k += 64) {
+                if constexpr (NRHS == 2) { const d2 p0 = gat(nt_load(val + k), nt_load(col + k)); a1 += p0.x; a2 += p0.y; }
+                else { a1 += gat(nt_load(val + k), nt_load(col + k)); }
             }
-            a1 = wave_sum(a1);
-            if constexpr (NRHS == 2) a2 = wave_sum(a2);
-            const int lane = tid & 63, wave = tid >> 6;
-            if (lane == 0) { red[wave * 2] = a1; red[wave * 2 + 1] = a2; }
-            __syncthreads();
-            if (tid == 0) {
-                double u1 = (red[0] + red[2]) + (red[4] + red[6]);
-                double u2 = (red[1] + red[3]) + (red[5] + red[7]);
-                epi.row(r0, u1, u2);
+            a1 = group_sum(a1, 64);
+            if constexpr (NRHS == 2) a2 = group_sum(a2, 64);
+            if (lane == 0) epi.row(d.row0, a1, a2);
+        } else if (kind == BLK_ELL) {
+            // ---------------- lane-major block: lane (row, lig) owns entries lig, lig + tpr, ... of its row
+            const int R = d.nrows(), T = d.steps();
+            const int p2 = (R <= 1) ? 1 : (1 << (32 - __clz(R - 1)));
+            const int tpr = 64 / p2;
+            const int sh = 31 - __clz(tpr);
+            const int row = lane >> sh, lig = lane & (tpr - 1);
+            const int len = (row < R) ? (int)S.row_rel[d.row0 + row] : 0;
+            const double* __restrict__ val = S.val + d.nnz0 + lane;
+            const int32_t* __restrict__ col = S.col + d.nnz0 + lane;
+            double a1 = 0.0, a2 = 0.0;
+            int t = 0;
+            for (; t + 4 <= T; t += 4) {
+                const double v0 = nt_load(val + 64 * t), v1 = nt_load(val + 64 * t + 64), v2 = nt_load(val + 64 * t + 128), v3 = nt_load(val + 64 * t + 192);
+                const int c0 = nt_load(col + 64 * t), c1 = nt_load(col + 64 * t + 64), c2 = nt_load(col + 64 * t + 128), c3 = nt_load(col + 64 * t + 192);
+                const int e0 = t * tpr + lig;
+                if constexpr (NRHS == 2) {
+                    const d2 p0 = gat(v0, c0), p1 = gat(v1, c1), p2 = gat(v2, c2), p3 = gat(v3, c3);
+                    if (e0 < len) { a1 += p0.x; a2 += p0.y; }
+                    if (e0 + tpr < len) { a1 += p1.x; a2 += p1.y; }
+                    if (e0 + 2 * tpr < len) { a1 += p2.x; a2 += p2.y; }
+                    if (e0 + 3 * tpr < len) { a1 += p3.x; a2 += p3.y; }
+                } else {
+                    const double p0 = gat(v0, c0), p1 = gat(v1, c1), p2 = gat(v2, c2), p3 = gat(v3, c3);
+                    if (e0 < len) a1 += p0;
+                    if (e0 + tpr < len) a1 += p1;
+                    if (e0 + 2 * tpr < len) a1 += p2;
+                    if (e0 + 3 * tpr < len) a1 += p3;
+                }
             }
-            __syncthreads();
+            for (; t < T; ++t) {
+                const double v0 = nt_load(val + 64 * t);
+                const int c0 = nt_load(col + 64 * t);
+                if constexpr (NRHS == 2) { const d2 p0 = gat(v0, c0); if (t * tpr + lig < len) { a1 += p0.x; a2 += p0.y; } }
+                else { const double p0 = gat(v0, c0); if (t * tpr + lig < len) a1 += p0; }
+            }
+            a1 = group_sum(a1, tpr);
+            if constexpr (NRHS == 2) a2 = group_sum(a2, tpr);
+            if (row < R && lig == 0) epi.row(d.row0 + row, a1, a2);
         } else {
-            // ---------------- stream block: rows r0..r1-1, cnt entries
-            const int cnt = (int)cnt64;
-            const double* __restrict__ val = S.val + e0;
-            const int32_t* __restrict__ col = S.col + e0;
+            // ---------------- LDS-staged block: rows row0 .. row0+nrows-1, cnt entries in CSR order
+            const int cnt = (int)d.cnt;
+            const double* __restrict__ val = S.val + d.nnz0;
+            const int32_t* __restrict__ col = S.col + d.nnz0;
             {
-                double v[4]; int c[4];
+                double v[WPL]; int c[WPL];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int k = tid + j * SPMV_THREADS;
-                    bool ok = k < cnt;
-                    v[j] = ok ? val[k] : 0.0;
-                    c[j] = ok ? col[k] : 0;
+                for (int j = 0; j < WPL; ++j) {
+                    const int k = lane + j * 64;
+                    const bool ok = k < cnt;
+                    v[j] = ok ? nt_load(val + k) : 0.0;
+                    c[j] = ok ? nt_load(col + k) : 0;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int k = tid + j * SPMV_THREADS;
+                for (int j = 0; j < WPL; ++j) {
+                    const int k = lane + j * 64;
                     if (k < cnt) {
                         if constexpr (NRHS == 2) reinterpret_cast<d2*>(prod)[k] = gat(v[j], c[j]);
                         else prod[k] = gat(v[j], c[j]);
                     }
                 }
             }
-            __syncthreads();
-            const int R = r1 - r0;
-            // lanes per row: 256 / nextpow2(R), at most one wave
-            int p2 = (R <= 1) ? 1 : (1 << (32 - __clz(R - 1)));
-            int tpr = SPMV_THREADS / p2;
-            if (tpr > 64) tpr = 64;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int R = d.nrows();
+            const int p2 = (R <= 1) ? 1 : (1 << (32 - __clz(R - 1)));
+            const int tpr = 64 / p2;
             const int sh = 31 - __clz(tpr);
-            const int row = tid >> sh, lig = tid & (tpr - 1);
+            const int row = lane >> sh, lig = lane & (tpr - 1);
             double a1 = 0.0, a2 = 0.0;
             if (row < R) {
-                const int s = S.row_rel[r0 + row];
-                const int e = (row + 1 < R) ? (int)S.row_rel[r0 + row + 1] : cnt;
-                for (int k = s + lig; k < e; k += tpr) {
-                    if constexpr (NRHS == 2) { d2 p = reinterpret_cast<const d2*>(prod)[k]; a1 += p.x; a2 += p.y; }
+                const int s0 = S.row_rel[d.row0 + row];
+                const int e = (row + 1 < R) ? (int)S.row_rel[d.row0 + row + 1] : cnt;
+                for (int k = s0 + lig; k < e; k += tpr) {
+                    if constexpr (NRHS == 2) { const d2 p = reinterpret_cast<const d2*>(prod)[k]; a1 += p.x; a2 += p.y; }
                     else { a1 += prod[k]; }
                 }
             }
-            for (int off = tpr >> 1; off > 0; off >>= 1) {
-                a1 += __shfl_xor(a1, off, 64);
-                if constexpr (NRHS == 2) a2 += __shfl_xor(a2, off, 64);
-            }
-            if (row < R && lig == 0) epi.row(r0 + row, a1, a2);
-            __syncthreads();
+            a1 = group_sum(a1, tpr);
+            if constexpr (NRHS == 2) a2 = group_sum(a2, tpr);
+            if (row < R && lig == 0) epi.row(d.row0 + row, a1, a2);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -196,13 +256,13 @@ __global__ __launch_bounds__(SPMV_THREADS) void kkt2_kernel(DevBlkCsr S, const d
                                                             const double* __restrict__ cb, int n, int nm,
                                                             double* __restrict__ partials, const DevState* st, int gate) {
     if (gate && st->done) return;
-    __shared__ __attribute__((aligned(16))) double prod[NNZ_BLK * 2];
+    __shared__ __attribute__((aligned(16))) double prod[SPMV_WAVES * WNNZ * 2];
     __shared__ double red[16];
     EpiKkt epi;
     epi.w = w; epi.out = out; epi.cb = cb; epi.n = n; epi.wt = w[nm];
     epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
     Gather<2> gat{w};
-    spmv_walk<2>(S, gat, epi, prod, red);
+    spmv_walk<2>(S, gat, epi, prod);
     block_reduce_store<3, SPMV_THREADS>(epi.acc, red, partials + 3 * (int64_t)blockIdx.x);
 }
 
@@ -349,13 +409,13 @@ struct EpiQStatus {    // residual sums of checkstatus  HSDEStatus.jl:34-38,59,6
 template <class Epi, int NACC>
 __global__ __launch_bounds__(SPMV_THREADS) void q1_kernel(DevBlkCsr S, const double* __restrict__ vcomp, Epi epi, int nm,
                                                           double* __restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) double prod[NNZ_BLK];
+    __shared__ __attribute__((aligned(16))) double prod[SPMV_WAVES * WNNZ];
     __shared__ double red[8 * NACC > 16 ? 8 * NACC : 16];
 #pragma unroll
     for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
     epi.init(vcomp[2 * (int64_t)nm]);      // the tau entry of the gathered component
     Gather<1> gat{vcomp};
-    spmv_walk<1>(S, gat, epi, prod, red);
+    spmv_walk<1>(S, gat, epi, prod);
     block_reduce_store<NACC, SPMV_THREADS>(epi.acc, red, partials + NACC * (int64_t)blockIdx.x);
 }
 

@@ -498,27 +498,25 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
     FOS_HIP(hipGetDeviceProperties(&prop, device));
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("FOS_SPMV_WG")) h->nwg_target = std::max(1, atoi(e));
-    else h->nwg_target = cus * 8;
+    else h->nwg_target = cus * 4;       // 4 workgroups (16 wavefronts) per CU measured best for the KKT sweep
 
     // ---- operator
     HostBlkCsr& hs = h->hostS;
     FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, h->nwg_target, &hs));
-    double* dval; int32_t* dcol; int32_t* dbr; int64_t* dn0; int64_t* dn1; uint16_t* drr; int32_t* dwg;
+    double* dval; int32_t* dcol; BlkDesc* dblk; uint16_t* drr; int32_t* dwv;
     FOS_TRY(dev_upload(h, &dval, hs.val));
     FOS_TRY(dev_upload(h, &dcol, hs.col));
-    FOS_TRY(dev_upload(h, &dbr, hs.blk_row0));
-    FOS_TRY(dev_upload(h, &dn0, hs.blk_nnz0));
-    FOS_TRY(dev_upload(h, &dn1, hs.blk_nnz1));
+    FOS_TRY(dev_upload(h, &dblk, hs.blk));
     FOS_TRY(dev_upload(h, &drr, hs.row_rel));
     // room for re-partitioning up to 16384 workgroups
     {
-        std::vector<int32_t> wg(std::max<size_t>(hs.wg_blk0.size(), 16385 + 8), 0);
-        std::copy(hs.wg_blk0.begin(), hs.wg_blk0.end(), wg.begin());
-        FOS_TRY(dev_upload(h, &dwg, wg));
+        std::vector<int32_t> wv(std::max<size_t>(hs.wave_blk0.size(), (size_t)SPMV_WAVES * 16384 + 16), 0);
+        std::copy(hs.wave_blk0.begin(), hs.wave_blk0.end(), wv.begin());
+        FOS_TRY(dev_upload(h, &dwv, wv));
     }
     h->S.nrows = hs.nrows; h->S.nnz = hs.nnz; h->S.nnz_padded = hs.nnz_padded;
-    h->S.val = dval; h->S.col = dcol; h->S.blk_row0 = dbr; h->S.blk_nnz0 = dn0; h->S.blk_nnz1 = dn1;
-    h->S.row_rel = drr; h->S.wg_blk0 = dwg; h->S.nblk = hs.nblk; h->S.nwg = hs.nwg;
+    h->S.val = dval; h->S.col = dcol; h->S.blk = dblk;
+    h->S.row_rel = drr; h->S.wave_blk0 = dwv; h->S.nblk = hs.nblk; h->S.nwg = hs.nwg; h->S.nwaves = hs.nwaves;
     // free the big host arrays (keep block table for re-partitioning)
     std::vector<double>().swap(hs.val);
     std::vector<int32_t>().swap(hs.col);
@@ -915,9 +913,10 @@ int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int3
         if (spmv_workgroups > 16384) spmv_workgroups = 16384;
         FOS_HIP(hipStreamSynchronize(h->stream));
         partition_workgroups(&h->hostS, spmv_workgroups);
-        FOS_HIP(hipMemcpy(const_cast<int32_t*>(h->S.wg_blk0), h->hostS.wg_blk0.data(),
-                          h->hostS.wg_blk0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        FOS_HIP(hipMemcpy(const_cast<int32_t*>(h->S.wave_blk0), h->hostS.wave_blk0.data(),
+                          h->hostS.wave_blk0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         h->S.nwg = h->hostS.nwg;
+        h->S.nwaves = h->hostS.nwaves;
         h->nwg_target = spmv_workgroups;
     }
     return FOS_OK;
