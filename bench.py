@@ -217,6 +217,11 @@ def main():
         oalg.S1.i = pi
         if isinstance(oalg, orc.GAPA):
             oalg.alpha12 = dev.alpha12()
+        try:                                    # one host core, like the single-threaded reference
+            from threadpoolctl import threadpool_limits
+            threadpool_limits(1)
+        except Exception:
+            pass
         ost = orc.HSDEStatus(om, BIG, 1e-8, 0, 0)
         ost.i = it + 1
         xo = z.copy()

@@ -222,6 +222,7 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
         }
         return FOS_OK;
     };
+    const size_t ev_start = h->ev_used;      // profiling: only the launches of REAL iterations are kept (below)
     int first = h->last_cg_pred > 0 ? h->last_cg_pred + 2 : h->cg_chunk;
     first = std::max(1, std::min(first, maxit));
     FOS_TRY(enqueue(first));
@@ -231,6 +232,10 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
         FOS_TRY(poll_state(h));
     }
     *iters = h->st_host->iter;
+    {   // iterations 1..iter each did exactly one gated KKT launch; launches enqueued past convergence were no-ops
+        const size_t real = std::min<size_t>((size_t)h->st_host->iter, (h->ev_used - ev_start) / 2);
+        h->ev_used = ev_start + 2 * real;
+    }
     h->last_cg_pred = h->st_host->iter;
     if (h->st_host->hit_max) h->hit_max_accum = 1;
     return FOS_OK;

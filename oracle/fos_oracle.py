@@ -45,6 +45,55 @@ import scipy.sparse as sp
 
 EPS = float(np.finfo(np.float64).eps)   # Julia eps()
 
+
+# ----------------------------------------------------------------------------------------
+# Reduction "space": where inner products live.  The reference is one process (LocalSpace).  For the
+# cone-sharded multi-GPU design (no reference equivalent) a rank holds a SHARD
+# z_g = [x_g; y_g; tau; r_g; s_g; kappa] with tau/kappa replicated; every inner product is then
+# all-reduced over ranks with the replicated entries counted once.  tests/test_sharding_gloo.py plugs
+# a torch.distributed(gloo) all-reduce in here to check the reduction points the HIP path uses.
+# ----------------------------------------------------------------------------------------
+
+class LocalSpace:
+    def allsum(self, v):
+        return v
+
+    def global_l(self, l_local):
+        return l_local
+
+    def dotN(self, a, b):
+        """dot of two N-vectors (N = 2l, layout [part1(l); part2(l)], tau-like entries at l-1 and 2l-1)."""
+        return np.float64(np.dot(a, b))
+
+    def dotL(self, a, b):
+        """dot of two vectors without replicated entries (x-, y-, r-, s-like)."""
+        return np.float64(np.dot(a, b))
+
+
+class ShardedSpace(LocalSpace):
+    """allreduce: callable mapping a float64 ndarray to its sum over ranks."""
+
+    def __init__(self, allreduce, l_global):
+        self._ar = allreduce
+        self.l_global = l_global
+
+    def allsum(self, v):
+        return np.float64(self._ar(np.array([v], dtype=np.float64))[0])
+
+    def global_l(self, l_local):
+        return self.l_global
+
+    def dotN(self, a, b):
+        l = a.shape[0] // 2
+        rep = a[l - 1] * b[l - 1] + a[2 * l - 1] * b[2 * l - 1]
+        return self.allsum(np.dot(a, b) - rep) + rep
+
+    def dotL(self, a, b):
+        return self.allsum(np.dot(a, b))
+
+
+LOCAL = LocalSpace()
+
 # ----------------------------------------------------------------------------------------
 # HSDEMatrixQ            src/problemforms/HSDE/HSDEAffine.jl:2-65
 # ----------------------------------------------------------------------------------------
@@ -53,8 +102,9 @@ EPS = float(np.finfo(np.float64).eps)   # Julia eps()
 class HSDEMatrixQ:
     """Matrix-free  Q = [0 A' c; -A 0 b; -c' -b' 0]   (HSDEAffine.jl:2-20)."""
 
-    def __init__(self, A, b, c):
+    def __init__(self, A, b, c, space=LOCAL):
         A = sp.csc_matrix(A) if not sp.issparse(A) else A.tocsc()
+        self.space = space
         self.A = A
         self.At = A.T.tocsr()        # transpose(A) of a CSC matrix: a CSR view, row gather
         self.b = np.asarray(b, dtype=np.float64).reshape(-1)
@@ -68,6 +118,10 @@ class HSDEMatrixQ:
         l = self.am + self.an + 1
         return (l, l)
 
+    @property
+    def global_size(self):
+        return self.space.global_l(self.am + self.an + 1)
+
     def mul(self, Y, B):
         """mul!(Y, Q, B)   HSDEAffine.jl:41-59."""
         n, m = self.an, self.am
@@ -80,7 +134,7 @@ class HSDEMatrixQ:
         y1 = y1 + b3 * self.c                   # :54  y1 .+= b3.*c
         y2 = y2 - b3 * self.b                   # :55  y2 .-= b3.*b
         y2 = -y2                                # :56  y2 .= .-y2
-        last = -np.dot(self.c, b1) - np.dot(self.b, b2)   # :57 (computed before Y is written: B may not alias Y)
+        last = -self.space.dotL(self.c, b1) - self.space.dotL(self.b, b2)   # :57 (computed before Y is written: B may not alias Y)
         Y[:n] = y1
         Y[n:n + m] = y2
         Y[n + m] = last
@@ -162,7 +216,7 @@ class KKTMatrix:
 # ----------------------------------------------------------------------------------------
 
 
-def conjugategradient(x, A, b, r, p, Ap, tol=None, max_iters=10000):
+def conjugategradient(x, A, b, r, p, Ap, tol=None, max_iters=10000, space=LOCAL):
     """Golub/Van Loan CG exactly as the reference runs it (also on the indefinite KKT system).
     Returns the iteration count (>= 1).  x is the warm start and receives the solution."""
     if tol is None:
@@ -170,18 +224,18 @@ def conjugategradient(x, A, b, r, p, Ap, tol=None, max_iters=10000):
     A.mul(Ap, x)                                 # :32
     np.subtract(b, Ap, out=r)                    # :33
     p[:] = r                                     # :34
-    rn = np.float64(np.dot(r, r))                # :35   (np.float64: x/0 -> inf/nan silently, as in Julia)
+    rn = space.dotN(r, r)                        # :35   (np.float64: x/0 -> inf/nan silently, as in Julia)
     it = 1                                       # :36
     while True:
         A.mul(Ap, p)                             # :38
         with np.errstate(divide="ignore", invalid="ignore"):
-            alpha = rn / np.float64(np.dot(Ap, p))   # :39
+            alpha = rn / space.dotN(Ap, p)           # :39
         x += alpha * p                           # :40
         r -= alpha * Ap                          # :41
-        if np.linalg.norm(r) <= tol or it >= max_iters:   # :42
+        if np.sqrt(space.dotN(r, r)) <= tol or it >= max_iters:   # :42  norm(r)
             break
         rnold = rn                               # :45
-        rn = np.float64(np.dot(r, r))            # :46
+        rn = space.dotN(r, r)                    # :46
         with np.errstate(divide="ignore", invalid="ignore"):
             beta = rn / rnold                    # :47
         p *= beta                                # :49
@@ -231,9 +285,10 @@ class AffinePlusLinear:
 
     def tolerance(self):
         """:108-112 -- tolerance that the *next* prox! call will use."""
+        size2 = getattr(self.A, "global_size", self.A.shape[1])      # size(S.A, 2)
         if self.decreasing_accuracy:
-            return max(0.2 ** math.sqrt(self.i), self.A.shape[1] * EPS)
-        return self.A.shape[1] * EPS
+            return max(0.2 ** math.sqrt(self.i), size2 * EPS)
+        return size2 * EPS
 
     def prox(self, y, x):
         """prox!(y, S, x)   affinepluslinear.jl:83-126."""
@@ -252,7 +307,8 @@ class AffinePlusLinear:
         tol = self.tolerance()                               # :108-112
         self.i += 1                                          # :114
         max_iters = 1000                                     # :115
-        it = conjugategradient(y, self.M, self.rhs, cg.r, cg.p, cg.z, tol=tol, max_iters=max_iters)  # :117
+        it = conjugategradient(y, self.M, self.rhs, cg.r, cg.p, cg.z, tol=tol, max_iters=max_iters,
+                               space=getattr(self.A, "space", LOCAL))                                 # :117
         self.cgiter = it                                     # :121
         cg.xinit[:] = y                                      # :122
         y[an:an + am] *= beta                                # :124
@@ -516,7 +572,8 @@ class DualConeProduct:
 class Model:
     """The fields of FOSMathProgModel the hot path reads (types.jl:30-52)."""
 
-    def __init__(self, A, b, c, K1, K2):
+    def __init__(self, A, b, c, K1, K2, space=LOCAL):
+        self.space = space
         self.A = sp.csc_matrix(A) if not sp.issparse(A) else A.tocsc()     # loadproblem! sparsifies, :27-29
         self.b = np.asarray(b, dtype=np.float64).reshape(-1)
         self.c = np.asarray(c, dtype=np.float64).reshape(-1)
@@ -530,7 +587,7 @@ class Model:
 
 def hsde_sets(model):
     """HSDE(model; direct=false)   HSDE.jl:7-29  ->  (S1, S2, N)."""
-    Q = HSDEMatrixQ(model.A, model.b, model.c)                              # :17
+    Q = HSDEMatrixQ(model.A, model.b, model.c, space=model.space)           # :17
     l = Q.shape[0]
     S1 = AffinePlusLinear(Q, np.zeros(l), np.zeros(l), 1, decreasing_accuracy=True)   # :22
     S2 = DualConeProduct(model.K1, model.K2)                                # :24
@@ -592,18 +649,20 @@ def residuals(model, z):
     tau = z[nu - 1]
     kappa = z[2 * nu - 1]
     A, b, c = model.A, model.b, model.c
-    nb = float(np.linalg.norm(b))
-    nc = float(np.linalg.norm(c))
+    sp_ = getattr(model, "space", LOCAL)
+    norm = lambda v: float(np.sqrt(sp_.dotL(v, v)))          # norm over the (possibly sharded) vector
+    nb = norm(b)
+    nc = norm(c)
     Ax = A @ x
     ATy = A.T @ y
     with np.errstate(divide="ignore", invalid="ignore"):      # Julia: x/0.0 -> Inf/NaN silently
-        p = float(np.linalg.norm(Ax / tau + s / tau - b)) / abs(1 + nb)           # :34
-        d = float(np.linalg.norm(ATy / tau + c - r / tau)) / abs(1 + nc)          # :35
-        ctx = float(np.dot(c, x))                                                 # :36
-        bty = float(np.dot(b, y))                                                 # :37
+        p = norm(Ax / tau + s / tau - b) / abs(1 + nb)                            # :34
+        d = norm(ATy / tau + c - r / tau) / abs(1 + nc)                           # :35
+        ctx = float(sp_.dotL(c, x))                                               # :36
+        bty = float(sp_.dotL(b, y))                                               # :37
         g = abs(ctx / tau + bty / tau) / (1 + abs(ctx / tau) + abs(bty / tau))    # :38
     return dict(p=p, d=d, g=g, ctx=ctx, bty=bty, kappa=float(kappa), tau=float(tau),
-                nAxs=float(np.linalg.norm(Ax + s)), nATy=float(np.linalg.norm(ATy)), nb=nb, nc=nc)
+                nAxs=norm(Ax + s), nATy=norm(ATy), nb=nb, nc=nc)
 
 
 def decide_status(res, eps):
@@ -727,13 +786,13 @@ def AP(alpha=1, **kw):                                      # solvers.jl:11
     return GAP(alpha, 1.0, 1.0, **kw)
 
 
-def normed_scalar(x1, x2, y1, y2):
+def normed_scalar(x1, x2, y1, y2, space=LOCAL):
     """normedScalar   gapa.jl:36-47."""
     d1 = x1 - x2
     d2 = y1 - y2
-    s = float(np.dot(d1, d2))
-    n1 = float(np.dot(d1, d1))
-    n2 = float(np.dot(d2, d2))
+    s = float(space.dotN(d1, d2))
+    n1 = float(space.dotN(d1, d1))
+    n2 = float(space.dotN(d2, d2))
     with np.errstate(divide="ignore", invalid="ignore"):
         return float(np.float64(abs(s)) / np.sqrt(np.float64(n1 * n2)))
 
@@ -758,7 +817,7 @@ class GAPA:
         self.S2.prox(self.tmp2, self.tmp1)                  # S2!  :72-78
         status.checkstatus(self.tmp2)
         self.tmp2[:] = a12 * self.tmp2 + (1 - a12) * self.tmp1
-        scl = normed_scalar(self.tmp2, self.tmp1, self.tmp1, x)     # :96
+        scl = normed_scalar(self.tmp2, self.tmp1, self.tmp1, x, getattr(self.S1.A, "space", LOCAL))     # :96
         scl = 0.0 if math.isnan(scl) else min(max(scl, 0.0), 1.0)   # :96-97 (clamp then NaN -> 0)
         s = math.sqrt(1 - scl ** 2)                         # :98
         aopt = 2 / (1 + s)                                  # :100

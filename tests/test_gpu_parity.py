@@ -487,3 +487,22 @@ def test_bad_inputs_fail_loudly(pkg):
         pkg.HipHSDE(A, np.zeros(3), np.zeros(3), [("ExpPrimal", 3)], [("Free", 3)])
     with pytest.raises(ValueError):
         pkg.HipHSDE(A, np.zeros(3), np.zeros(3), [("Zero", [1, 3, 2])], [("Free", 3)])
+
+
+def test_rccl_reduction_path_single_rank(pkg):
+    """The sharded code path (local reduce kernel -> in-stream RCCL all-reduce -> finalize from the reduced buffer)
+    with a 1-rank communicator must reproduce the single-GPU path bit for bit (same summation order)."""
+    prob = pkg.workloads.small_mixed()
+    outs = []
+    for use_comm in (False, True):
+        d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+        if use_comm:
+            d.comm_init(1, 0, pkg.HipHSDE.comm_unique_id())
+        d.set_alg(pkg.GAPA(0.8, 0.5))
+        d.set_iterate(None)
+        done, checked, res = d.step(1, 30, 30, 1e-6)
+        assert done == 30 and checked
+        outs.append((d.get_iterate(), d.cgiter(), res.p, res.d, res.g, d.alpha12()))
+        d.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1:] == outs[1][1:]

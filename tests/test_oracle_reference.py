@@ -278,8 +278,8 @@ def test_readme_gap_max_iters_forced_check(nnls):
 
 def test_fista_and_dykstra_run(nnls):
     prob, model, xs, opt = nnls
-    for alg in (orc.FISTA(eps=1e-3, verbose=0, max_iters=3000), orc.Dykstra(eps=1e-3, verbose=0, max_iters=3000),
-                orc.AP(eps=1e-3, verbose=0, max_iters=3000)):
+    for alg in (orc.FISTA(eps=1e-3, verbose=0, max_iters=300), orc.Dykstra(eps=1e-3, verbose=0, max_iters=300),
+                orc.AP(eps=1e-3, verbose=0, max_iters=300)):
         sol = orc.solve(model, alg)
         assert sol.status in ("Optimal", "Indeterminate")
         assert np.isfinite(sol.obj_val)

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/<round>/ (rocprofv3 csv output) into small tracked summaries under profiles/."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join("gpurun_out", rnd)
+dst = "profiles"
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    name = name.replace("fos::", "")
+    return name.split("(")[0][:60]
+
+
+for tag in ("trace_c4", "trace_c2"):
+    files = glob.glob(os.path.join(src, tag, "**", "*kernel_stats.csv"), recursive=True)
+    if not files:
+        continue
+    rows = list(csv.DictReader(open(files[0])))
+    with open(os.path.join(dst, "%s_%s_kernel_stats.md" % (rnd, tag)), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats : `python bench.py --steps 20 --no-cpu-baseline%s`\n\n" % (" --workload C2" if tag.endswith("c2") else ""))
+        f.write("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
+        for r in rows:
+            f.write("| %s | %s | %.3f | %.2f | %.2f | %.2f | %s |\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                                     float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    # steady-state average of the dominant kernel (last 20 x cg launches) from the trace
+    tf = glob.glob(os.path.join(src, tag, "**", "*kernel_trace.csv"), recursive=True)
+    if tf:
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(tf[0])) if "kkt2_kernel" in r["Kernel_Name"]]
+        real = [d for d in durs if d > 0.25 * max(durs)]      # launches enqueued past CG convergence exit at once (gated no-ops, ~3 us)
+        tail = real[len(real) // 2:]
+        with open(os.path.join(dst, "%s_%s_kernel_stats.md" % (rnd, tag)), "a") as f:
+            f.write("\nkkt2_kernel: %d launches, %d of them gated no-ops (enqueued past CG convergence, ~3 us each); "
+                    "average of the real launches = %.2f us, over the second half of the run (steady state) = %.2f us\n"
+                    % (len(durs), len(durs) - len(real), sum(real) / len(real) / 1e3, sum(tail) / len(tail) / 1e3))
+
+for tag, counter in (("pmc_fetch_c4", "FETCH_SIZE"), ("pmc_write_c4", "WRITE_SIZE")):
+    files = glob.glob(os.path.join(src, tag, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        continue
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        if r.get("Counter_Name") == counter:
+            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    with open(os.path.join(dst, "%s_%s.md" % (rnd, tag)), "w") as f:
+        f.write("# rocprofv3 --pmc %s (own pass) : `python bench.py --steps 3 --warmup 20 --no-cpu-baseline`\n\n" % counter)
+        f.write("| kernel | dispatches | mean %s per dispatch (counter units: KB) | as MB |\n|---|---|---|---|\n" % counter)
+        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            if "kkt2" in k or "cg_" in k:      # drop gated no-op dispatches (counter ~0)
+                v = [x for x in v if x > 0.25 * max(v)] or v
+            f.write("| %s | %d | %.1f | %.2f |\n" % (k, len(v), sum(v) / len(v), sum(v) / len(v) / 1024))
+        f.write("\n(gated no-op dispatches of the CG kernels -- enqueued past convergence -- are excluded from the means)\n")
+
+for b in ("bench_c4", "bench_c2", "bench_c3"):
+    p = os.path.join(src, b + ".json")
+    if os.path.exists(p):
+        txt = open(p).read().strip()
+        try:
+            json.loads(txt)
+            open(os.path.join(dst, "%s_%s.json" % (rnd, b)), "w").write(txt + "\n")
+        except Exception:
+            open(os.path.join(dst, "%s_%s.FAILED.txt" % (rnd, b)), "w").write(txt + "\n")
+print("\n".join(sorted(os.listdir(dst))))
