@@ -97,7 +97,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("FOS_FORCE_DIST") == "1"      # exercise the distributed path with one rank (testing)
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -110,7 +111,7 @@ def main():
     t_gen = time.time() - t0
     t0 = time.time()
     dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2, device=local_rank)
-    if world > 1:
+    if dist is not None:
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(pkg.HipHSDE.comm_unique_id()), dtype=torch.uint8))
