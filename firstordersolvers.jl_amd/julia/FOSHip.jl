@@ -1,0 +1,203 @@
+# FOSHip.jl -- thin Julia shim that routes FirstOrderSolvers.jl's HSDE hot path to libfoship.so (MI355X / HIP).
+#
+# STATUS: written against the reference sources but NOT EXECUTED -- the build container has no Julia binary
+# (SURVEY.md section 8(c)).  The same C ABI is exercised end to end by the Python mirror
+# (firstordersolvers.jl_amd/interface.py, tests/test_gpu_parity.py); this file is the binding a maintainer adds.
+#
+# How it plugs in (reference files in brackets):
+#   * `include("FOSHip.jl")` at the end of src/FirstOrderSolvers.jl (after solvers/*.jl are loaded).
+#   * The user passes `gpu=true` with any solver:  solve!(problem, DR(eps=1e-8, gpu=true)).  Keyword arguments are
+#     captured in `alg.options` and splatted into `model.options` [FOSSolverInterface.jl:5, types.jl:57]; unknown keys
+#     are ignored by the reference, so nothing else changes.
+#   * `init_algorithm!` [gap.jl:23, gapa.jl:27, fista.jl:20, dykstra.jl:19] is intercepted for FOSMathProgModel when
+#     `gpu=true`: it returns a `HipData` (a FOSSolverData) instead of GAPData/GAPAData/...; everything downstream
+#     dispatches on that data type:  `iterate` [solverwrapper.jl:20-41], `Base.step`, `getsol`, `getcgiter`.
+#   * FOSMathProgModel, loadproblem!, optimize!, status/getobjval/getsolution, model.history, the printed table and
+#     HSDE_populatesolution stay the reference's own code.
+module FOSHip
+
+using ..FirstOrderSolvers
+import ..FirstOrderSolvers: FOSAlgorithm, FOSSolverData, FOSMathProgModel, HSDEStatus, GAP, GAPA, FISTA, Dykstra,
+                            init_algorithm!, getsol, getcgiter, iterate, printstatusheader, printstatusiter,
+                            savedata, get_sets_and_status, ConeProduct
+import ProximalOperators
+using SparseArrays, Printf
+
+const libfoship = get(ENV, "FOSHIP_LIB", "libfoship.so")
+
+# ---- mirror of include/foship.h ------------------------------------------------------------------------------
+const FOS_ALG_GAP, FOS_ALG_GAPA, FOS_ALG_FISTA, FOS_ALG_DYKSTRA = Cint(0), Cint(1), Cint(2), Cint(3)
+const STATUS_SYMBOLS = (:Continue, :Optimal, :Unbounded, :Infeasible)        # FOS_STATUS_*
+
+struct CheckResult            # struct fos_check_result
+    p::Cdouble; d::Cdouble; g::Cdouble; ctx::Cdouble; bty::Cdouble
+    kappa::Cdouble; tau::Cdouble; norm_axs::Cdouble; norm_aty::Cdouble; norm_b::Cdouble; norm_c::Cdouble
+    cgiter::Int64; status::Int32; cg_maxiter_hit::Int32
+end
+
+function check(code::Cint)
+    code == 0 && return
+    msg = unsafe_string(ccall((:fos_last_error, libfoship), Cstring, ()))
+    error("libfoship error $code: $msg")
+end
+
+# cone codes: keys of conemap [cones.jl:4-14]
+conecode(::ProximalOperators.IndFree) = Int32(0)
+conecode(::ProximalOperators.IndZero) = Int32(1)
+conecode(::ProximalOperators.IndNonnegative) = Int32(2)
+conecode(::ProximalOperators.IndNonpositive) = Int32(3)
+conecode(::ProximalOperators.IndSOC) = Int32(4)
+conecode(::ProximalOperators.IndRotatedSOC) = Int32(5)
+conecode(::ProximalOperators.IndPSD) = Int32(6)
+conecode(::ProximalOperators.IndExpPrimal) = Int32(7)
+conecode(::ProximalOperators.IndExpDual) = Int32(8)
+
+function conearrays(K::ConeProduct)
+    N = length(K.cones)
+    types = Int32[conecode(K.cones[i]) for i in 1:N]
+    starts = Int64[first(K.ranges[i]) for i in 1:N]
+    lens = Int64[length(K.ranges[i]) for i in 1:N]
+    return types, starts, lens
+end
+
+# ---- the device-resident solver data ---------------------------------------------------------------------------
+mutable struct HipData <: FOSSolverData
+    handle::Ptr{Cvoid}
+    m::Int
+    n::Int
+    cgiter::Int64
+    function HipData(model::FOSMathProgModel, device::Integer)
+        A = model.A                       # SparseMatrixCSC{Float64,Int}: colptr/rowval are Int64 and 1-based, as the ABI wants
+        m, n = size(A)
+        b = convert(Vector{Float64}, vec(model.b))
+        c = convert(Vector{Float64}, vec(model.c))
+        t1, s1, l1 = conearrays(model.K1)
+        t2, s2, l2 = conearrays(model.K2)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve A b c t1 s1 l1 t2 s2 l2 begin
+            check(ccall((:fos_create, libfoship), Cint,
+                        (Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                         Int64, Ptr{Int32}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{Int64},
+                         Cint, Ref{Ptr{Cvoid}}),
+                        m, n, A.colptr, A.rowval, A.nzval, b, c,
+                        length(t1), t1, s1, l1, length(t2), t2, s2, l2, Cint(device), h))
+        end
+        d = new(h[], m, n, 0)
+        finalizer(x -> (x.handle != C_NULL && ccall((:fos_destroy, libfoship), Cint, (Ptr{Cvoid},), x.handle); x.handle = C_NULL), d)
+        return d
+    end
+end
+
+algargs(a::GAP) = (FOS_ALG_GAP, a.α, a.α1, a.α2, 0.0)              # gap.jl:6-13
+algargs(a::GAPA) = (FOS_ALG_GAPA, a.α, 0.0, 0.0, a.β)              # gapa.jl:9-15
+algargs(a::FISTA) = (FOS_ALG_FISTA, a.α, 0.0, 0.0, 0.0)            # fista.jl:6-11
+algargs(a::Dykstra) = (FOS_ALG_DYKSTRA, 0.0, 0.0, 0.0, 0.0)        # dykstra.jl:5-9
+
+set_alg!(d::HipData, alg) = check(ccall((:fos_set_alg, libfoship), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cdouble, Cdouble),
+                                        d.handle, algargs(alg)...))
+
+usegpu(model::FOSMathProgModel) = get(model.options, :gpu, false) === true
+
+# ---- init_algorithm!: return HipData when gpu=true, otherwise fall through to the reference method --------------
+for T in (:GAP, :GAPA, :FISTA, :Dykstra)
+    @eval function init_algorithm!(alg::$T, model::FOSMathProgModel)
+        if usegpu(model)
+            alg.direct && error("direct=true is not available on the HIP path")     # HSDE.jl:12-15 is CPU only
+            # status_generator is the reference's closure [HSDE.jl:26-27]; sets S1/S2 are not built on the host
+            _, _, _, status_generator = get_sets_and_status(alg, model)
+            data = HipData(model, get(model.options, :device, 0))
+            set_alg!(data, alg)
+            return data, status_generator
+        end
+        return invoke(init_algorithm!, Tuple{$T,FirstOrderSolvers.AbstractFOSModel}, alg, model)
+    end
+end
+
+getcgiter(d::HipData) = d.cgiter                                              # defaults.jl:25-30
+
+# ---- what checkstatus does once the device has produced the scalars [HSDEStatus.jl:39-65] ----------------------
+function record!(stat::HSDEStatus, data::HipData, r::CheckResult)
+    t = time_ns() - stat.init_time
+    i, model = stat.i, stat.model
+    data.cgiter = r.cgiter
+    if stat.debug > 0           # savedata [HSDEStatus.jl:125-139]; debug=2 vectors need fos_get_checked (below)
+        x = y = s = Float64[]
+        if stat.debug > 1
+            z = Vector{Float64}(undef, 2 * (data.m + data.n + 1))
+            check(ccall((:fos_get_checked, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, z))
+            nu = data.n + data.m + 1
+            x, y, s = z[1:data.n], z[data.n+1:data.n+data.m], z[nu+data.n+1:nu+data.n+data.m]
+        end
+        savedata(i, r.p, r.d, r.g, r.ctx, r.bty, r.kappa, r.tau, x, y, s, t, model, stat.debug)
+    end
+    if stat.verbose > 0
+        push!(model.history, :cgiter, i, r.cgiter)
+        printstatusiter(i, r.p, r.d, r.g, r.ctx, r.bty, r.kappa / r.tau, r.cgiter, t)
+    end
+    r.cg_maxiter_hit != 0 && @warn "CG reached max iterations, result may be inaccurate"   # conjugategradients.jl:53
+    stat.status = STATUS_SYMBOLS[r.status+1]
+    if stat.status == :Optimal && stat.verbose > 0
+        println("Found solution i=$i")
+    end
+    stat.checked = true
+    return
+end
+
+# ---- iterate [solverwrapper.jl:20-41], device resident: the host sees one ccall per check interval ---------------
+function iterate(alg::FOSAlgorithm, data::HipData, status::HSDEStatus, x, max_iters)
+    t1 = time()
+    printstatusheader(status)
+    check(ccall((:fos_set_iterate, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, x))     # initx / z0
+    i = 0
+    done, checked, res = Ref{Int64}(0), Ref{Int32}(0), Ref{CheckResult}()
+    while i < max_iters
+        count = min(max_iters - i, status.checki - (i % status.checki))
+        check(ccall((:fos_step, libfoship), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Int64, Cdouble, Ref{Int64}, Ref{Int32}, Ref{CheckResult}),
+                    data.handle, i + 1, count, status.checki, status.eps, done, checked, res))
+        i += done[]
+        status.i = i
+        if checked[] != 0
+            record!(status, data, res[])
+            status.status != :Continue && break
+        else
+            status.checked = false
+        end
+    end
+    guess = Vector{Float64}(undef, length(x))
+    force = status.checked ? Int32(0) : Int32(1)                                   # solverwrapper.jl:31-34
+    check(ccall((:fos_getsol, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int32, Cdouble, Ref{CheckResult}),
+                data.handle, guess, force, status.eps, res))
+    force != 0 && record!(status, data, res[])
+    if status.verbose > 0
+        println("Time for iterations: ")
+        println("$(time() - t1) s")
+    end
+    return guess
+end
+
+# ---- single-step entry points, so wrappers written against step/getsol keep working (one ccall per iteration) -----
+function Base.step(alg::FOSAlgorithm, data::HipData, x, i, status::HSDEStatus, longstep = nothing)
+    i == 1 && check(ccall((:fos_set_iterate, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, x))
+    done, checked, res = Ref{Int64}(0), Ref{Int32}(0), Ref{CheckResult}()
+    check(ccall((:fos_step, libfoship), Cint,
+                (Ptr{Cvoid}, Int64, Int64, Int64, Cdouble, Ref{Int64}, Ref{Int32}, Ref{CheckResult}),
+                data.handle, i, 1, status.checki, status.eps, done, checked, res))
+    if checked[] != 0
+        record!(status, data, res[])
+    else
+        status.checked = false
+    end
+    check(ccall((:fos_get_iterate, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, x))
+    return
+end
+
+function getsol(alg::FOSAlgorithm, data::HipData, x)
+    guess = Vector{Float64}(undef, length(x))
+    res = Ref{CheckResult}()
+    check(ccall((:fos_getsol, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int32, Cdouble, Ref{CheckResult}),
+                data.handle, guess, Int32(0), 0.0, res))
+    return guess
+end
+
+end # module

@@ -246,7 +246,7 @@ PSD_KNOWN = np.array([[0.03909044662082823, -0.00823811392936668],
 
 
 def test_psd_known_answer_and_sizes(pkg, dev_ops):
-    """test/testPSD.jl:14-19 known answer through the GPU PSD kernel; random orders 1..100 (LDS path) and 120
+    """test/testPSD.jl:14-19 known answer through the GPU PSD kernel; random orders 1..120 (LDS path) and 150
     (global-scratch path); degenerate spectra (+-lambda pairs, zero matrix, rank one)."""
     r2 = math.sqrt(2)
     K1 = [("SDP", 3)]
@@ -261,7 +261,7 @@ def test_psd_known_answer_and_sizes(pkg, dev_ops):
     assert np.allclose(out[2:5], -xs + want, atol=1e-14, rtol=0)
 
     rng = np.random.default_rng(11)
-    for k in (1, 2, 3, 5, 8, 17, 33, 64, 96, 100, 120):
+    for k in (1, 2, 3, 5, 8, 17, 33, 64, 96, 120, 150):
         ln = k * (k + 1) // 2
         d, _, _ = dev_ops(sp.random(ln, 3, density=0.1, format="csc", random_state=rng), None, None, [("SDP", ln)], [("Free", 3)])
         S2 = orc.DualConeProduct(orc.ConeProduct.from_lengths([(orc.CONE_SDP, ln)]), orc.ConeProduct.from_lengths([(orc.CONE_FREE, 3)]))
