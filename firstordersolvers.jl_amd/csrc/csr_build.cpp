@@ -14,10 +14,14 @@
 //   LDS   irregular rows (<= WNNZ entries): CSR order, products staged through the wavefront's LDS slice and
 //         reduced per row;
 //   LONG  a row with more than ELL_MAX entries: strided by the wavefront, reduced in-register.
+// Index compression: a block whose rows all have CONSECUTIVE column indices (dense blocks of an SDP, dense LP rows,
+// banded matrices) is a RUN block: it stores one first-column per row instead of 4 bytes per entry (8 instead of
+// 12 bytes per non-zero on the wire).  Blocks are homogeneous in run-ness.
 // Each block's entries start at a multiple of NNZ_ALIGN (pad: value 0, column 0; masked in the kernel).
 // Row blocks are then split among the persistent wavefronts of the SpMV grid, balanced by stored entries.
 #include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 
 #include "fos_internal.hpp"
 
@@ -42,7 +46,7 @@ void partition_workgroups(HostBlkCsr* S, int nwg_target) {
     // cost of a block: its non-zeros plus a per-row term for the epilogue and a fixed per-block term
     std::vector<double> cost(nblk + 1, 0.0);
     for (int b = 0; b < nblk; ++b)
-        cost[b + 1] = cost[b] + double(S->blk[b].cnt) + 4.0 * double(S->blk[b].nrows()) + 32.0;
+        cost[b + 1] = cost[b] + double(S->blk[b].cnt) * (S->blk[b].kind() == BLK_LONG ? S->blk[b].nrows() : 1) + 4.0 * double(S->blk[b].nrows()) + 32.0;
     const double total = cost[nblk];
     S->wave_blk0.assign(nwaves + 1, 0);
     int b = 0;
@@ -77,6 +81,27 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     for (int64_t r = 0; r < nrows; ++r) rp[r + 1] += rp[r];
     if (rp[nrows] != 2 * nnz) { set_error("internal: stacked nnz mismatch"); return FOS_EINVAL; }
 
+    // ---- which rows have consecutive column indices ("runs": dense blocks, banded rows) -> index compression
+    std::vector<uint8_t> is_run(nrows, 1);
+    std::vector<int32_t> first_col(nrows, 0);
+    for (int64_t j = 0; j < n; ++j) {                       // A' rows: the row indices of column j of A
+        const int64_t k0 = colptr[j] - 1, k1 = colptr[j + 1] - 1;
+        if (k1 > k0) first_col[j] = (int32_t)(n + rowval[k0] - 1);
+        for (int64_t k = k0 + 1; k < k1; ++k)
+            if (rowval[k] != rowval[k - 1] + 1) { is_run[j] = 0; break; }
+    }
+    {
+        std::vector<int64_t> last(m, -1);
+        for (int64_t j = 0; j < n; ++j) {                   // A rows: columns arrive in ascending order
+            for (int64_t k = colptr[j] - 1; k < colptr[j + 1] - 1; ++k) {
+                const int64_t i = rowval[k] - 1;
+                if (last[i] < 0) first_col[n + i] = (int32_t)j;
+                else if (last[i] != j - 1) is_run[n + i] = 0;
+                last[i] = j;
+            }
+        }
+    }
+
     // ---- row blocks
     HostBlkCsr& S = *out;
     S = HostBlkCsr();
@@ -84,27 +109,47 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     S.nnz = 2 * nnz;
     S.row_rel.assign(nrows, 0);
     // where the e-th entry of row r goes: ELL rows (tpr > 0): base + (e / tpr) * 64 + lane0 + e % tpr ; else base + e
-    std::vector<int64_t> row_base(nrows, 0);
+    std::vector<int64_t> row_base(nrows, 0), row_cbase(nrows, -1);      // value position / column position (-1: run block)
     std::vector<uint8_t> row_tpr(nrows, 0), row_lane0(nrows, 0);
     auto nextpow2 = [](int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; };
-    int64_t pos = 0;
+    auto align = [](int64_t v) { return (v + NNZ_ALIGN - 1) / NNZ_ALIGN * NNZ_ALIGN; };
+    const bool compress = getenv("FOS_NO_INDEX_COMPRESSION") == nullptr;
+    int64_t pos = 0, cpos = 0;
     int64_t r = 0;
     while (r < nrows) {
         const int64_t r0 = r;
         const int64_t len0 = rp[r + 1] - rp[r];
-        const int64_t blk_start = (pos + NNZ_ALIGN - 1) / NNZ_ALIGN * NNZ_ALIGN;
+        const int64_t blk_start = align(pos), col_start = align(cpos);
+        const bool run0 = compress && is_run[r];
+        // a block is homogeneous in run-ness; its rows end where the flag flips
+        int64_t r_lim = r;
+        while (r_lim < nrows && (r_lim - r0) < WROWS && (compress && is_run[r_lim]) == run0) ++r_lim;
         BlkDesc d;
         d.nnz0 = blk_start;
+        d.colpos = col_start;
         d.row0 = (int32_t)r0;
-        if (len0 > ELL_MAX) {                   // long row: a block of its own, strided by one wavefront
-            row_base[r] = blk_start;
+        int64_t ncol_used = 0;
+        int64_t stored = -1;                    // values the block occupies (default: d.cnt)
+        if (len0 > ELL_MAX) {                   // long row(s): strided by one wavefront
+            // consecutive long RUN rows over the SAME column range (a dense block) are processed together, up to
+            // LONG_ROWS at a time: the gathered vector element is loaded once per LONG_ROWS matrix values
+            int64_t nr = 1;
+            if (run0) {
+                while (nr < LONG_ROWS && r + nr < r_lim && (rp[r + nr + 1] - rp[r + nr]) == len0 &&
+                       first_col[r + nr] == first_col[r]) ++nr;
+                if (nr == 3) nr = 2;
+            }
+            const int64_t stride = align(len0);
+            for (int64_t i = 0; i < nr; ++i) row_base[r + i] = blk_start + i * stride;
             d.cnt = len0;
-            d.info = 1 | (BLK_LONG << 8);
-            r += 1;
+            d.info = (int32_t)nr | (BLK_LONG << 8) | ((run0 ? 1 : 0) << 10);
+            stored = nr * stride;
+            if (run0) { ncol_used = 1; } else { row_cbase[r] = col_start; ncol_used = len0; }
+            r += nr;
         } else {
             // candidate lane-major block: up to WROWS rows / ELL_MAX entries
             int64_t cnt = 0, maxlen = 0, rr = r;
-            while (rr < nrows && (rr - r0) < WROWS) {
+            while (rr < r_lim) {
                 const int64_t len = rp[rr + 1] - rp[rr];
                 if (cnt + len > ELL_MAX) break;
                 const int64_t R1 = rr - r0 + 1;
@@ -143,18 +188,21 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
                     row_tpr[r0 + i] = (uint8_t)tpr;
                     row_lane0[r0 + i] = (uint8_t)(i * tpr);
                     S.row_rel[r0 + i] = (uint16_t)(rp[r0 + i + 1] - rp[r0 + i]);      // row LENGTH
+                    if (!run0) row_cbase[r0 + i] = col_start;
                 }
                 d.cnt = padded;
-                d.info = (int32_t)R | (BLK_ELL << 8) | ((int32_t)T << 16);
+                d.info = (int32_t)R | (BLK_ELL << 8) | ((run0 ? 1 : 0) << 10) | ((int32_t)T << 16);
+                ncol_used = run0 ? R : padded;
                 r = rr;
             } else {
-                // ---- irregular rows: LDS-staged block of at most WNNZ entries (a row longer than that alone: ELL, 64 lanes)
+                // ---- irregular rows: LDS-staged block of at most WNNZ entries, always with per-entry indices
                 cnt = 0;
                 rr = r;
-                while (rr < nrows && (rr - r0) < WROWS) {
+                while (rr < r_lim) {
                     const int64_t len = rp[rr + 1] - rp[rr];
                     if (cnt + len > WNNZ) break;
                     row_base[rr] = blk_start + cnt;
+                    row_cbase[rr] = col_start + cnt;
                     S.row_rel[rr] = (uint16_t)cnt;                                      // row START
                     cnt += len;
                     rr += 1;
@@ -165,37 +213,46 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
                     row_tpr[r] = 64;
                     row_lane0[r] = 0;
                     S.row_rel[r] = (uint16_t)len0;
+                    if (!run0) row_cbase[r] = col_start;
                     d.cnt = 64 * T1;
-                    d.info = 1 | (BLK_ELL << 8) | ((int32_t)T1 << 16);
+                    d.info = 1 | (BLK_ELL << 8) | ((run0 ? 1 : 0) << 10) | ((int32_t)T1 << 16);
+                    ncol_used = run0 ? 1 : d.cnt;
                     r += 1;
                 } else {
                     d.cnt = cnt;
                     d.info = (int32_t)(rr - r0) | (BLK_LDS << 8);
+                    ncol_used = cnt;
                     r = rr;
                 }
             }
         }
         S.blk.push_back(d);
-        pos = blk_start + d.cnt;
+        pos = blk_start + (stored >= 0 ? stored : d.cnt);
+        cpos = col_start + ncol_used;
     }
     S.nblk = (int32_t)S.blk.size();
-    S.nnz_padded = (pos + NNZ_ALIGN - 1) / NNZ_ALIGN * NNZ_ALIGN;
-    if (S.nnz_padded == 0) S.nnz_padded = NNZ_ALIGN;
+    S.nnz_padded = std::max<int64_t>(align(pos), NNZ_ALIGN);
+    S.ncol_stored = std::max<int64_t>(align(cpos), NNZ_ALIGN);
 
     S.val.assign(S.nnz_padded, 0.0);
-    S.col.assign(S.nnz_padded, 0);
-    auto place = [&](int64_t row, int64_t e) -> int64_t {
+    S.col.assign(S.ncol_stored, 0);
+    // run blocks: one first-column per row
+    for (const BlkDesc& d : S.blk) {
+        if (!d.run()) continue;
+        for (int i = 0; i < d.nrows(); ++i) S.col[d.colpos + i] = first_col[d.row0 + i];
+    }
+    auto place = [&](int64_t row, int64_t e) -> int64_t {        // offset of entry e of `row` relative to its block base
         const int64_t tpr = row_tpr[row];
-        if (tpr == 0) return row_base[row] + e;
-        return row_base[row] + (e / tpr) * 64 + row_lane0[row] + (e % tpr);
+        if (tpr == 0) return e;
+        return (e / tpr) * 64 + row_lane0[row] + (e % tpr);
     };
     // ---- fill A' rows (row j of S = column j of A, entries already sorted by row index)
     for (int64_t j = 0; j < n; ++j) {
         int64_t e = 0;
         for (int64_t k = colptr[j] - 1; k < colptr[j + 1] - 1; ++k, ++e) {
-            const int64_t dst = place(j, e);
-            S.val[dst] = nzval[k];
-            S.col[dst] = (int32_t)(n + rowval[k] - 1);
+            const int64_t off = place(j, e);
+            S.val[row_base[j] + off] = nzval[k];
+            if (row_cbase[j] >= 0) S.col[row_cbase[j] + off] = (int32_t)(n + rowval[k] - 1);
         }
     }
     // ---- fill A rows by a counting transpose (column order inside each row = ascending column index)
@@ -204,9 +261,9 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         for (int64_t j = 0; j < n; ++j) {
             for (int64_t k = colptr[j] - 1; k < colptr[j + 1] - 1; ++k) {
                 const int64_t i = rowval[k] - 1;
-                const int64_t dst = place(n + i, fill[i]++);
-                S.val[dst] = nzval[k];
-                S.col[dst] = (int32_t)j;
+                const int64_t off = place(n + i, fill[i]++);
+                S.val[row_base[n + i] + off] = nzval[k];
+                if (row_cbase[n + i] >= 0) S.col[row_cbase[n + i] + off] = (int32_t)j;
             }
         }
     }

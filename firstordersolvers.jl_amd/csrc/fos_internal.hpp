@@ -44,25 +44,29 @@ void set_error(const char* fmt, ...);
 constexpr int SPMV_THREADS = 256;   // 4 independent wavefronts per workgroup
 constexpr int SPMV_WAVES = SPMV_THREADS / 64;
 constexpr int WNNZ = 256;           // LDS-staged row block: max non-zeros (16 B each for 2 RHS in the wavefront's LDS slice)
-constexpr int ELL_MAX = 1024;       // lane-major ("ELL") row block: max padded entries (a multiple of 64)
+constexpr int ELL_MAX = 2048;       // lane-major ("ELL") row block: max padded entries (a multiple of 64)
 constexpr int WROWS = 64;           // max rows per row block (>= 1 epilogue lane per row)
+constexpr int LONG_ROWS = 4;        // long run-rows over one column range handled together by a wavefront
 constexpr int NNZ_ALIGN = 4;        // every row block starts at a multiple of 4 entries (16/32-byte aligned)
 
 enum BlkKind : int32_t { BLK_LDS = 0, BLK_ELL = 1, BLK_LONG = 2 };
 
-struct BlkDesc {                    // one row block = the unit of work of ONE wavefront
-    int64_t nnz0;                   // first entry in the padded arrays (multiple of NNZ_ALIGN)
-    int64_t cnt;                    // stored entries (ELL: 64 * steps, padding included)
+struct BlkDesc {                    // one row block = the unit of work of ONE wavefront (32 bytes)
+    int64_t nnz0;                   // first value in `val` (multiple of NNZ_ALIGN)
+    int64_t colpos;                 // first entry in `col`: per-entry column indices, or -- for a RUN block, whose rows
+                                    // all have consecutive columns -- one first-column per row (index compression)
+    int64_t cnt;                    // stored values (ELL: 64 * steps, padding included; LONG: entries per row, rows at stride align4(cnt))
     int32_t row0;                   // first row
-    int32_t info;                   // nrows (bits 0..7) | kind << 8 | ELL steps T << 16
+    int32_t info;                   // nrows (bits 0..7) | kind << 8 | run << 10 | ELL steps T << 16
     __host__ __device__ int nrows() const { return info & 0xFF; }
     __host__ __device__ int kind() const { return (info >> 8) & 0x3; }
+    __host__ __device__ int run() const { return (info >> 10) & 0x1; }
     __host__ __device__ int steps() const { return (info >> 16) & 0xFFFF; }
 };
 
 // Host-side result of building the stacked operator; uploaded verbatim.
 struct HostBlkCsr {
-    int64_t nrows = 0, nnz = 0, nnz_padded = 0;
+    int64_t nrows = 0, nnz = 0, nnz_padded = 0, ncol_stored = 0;
     std::vector<double> val;
     std::vector<int32_t> col;
     std::vector<BlkDesc> blk;          // [nblk]

@@ -105,6 +105,124 @@ struct Gather<1> {
 
 constexpr int WPL = WNNZ / 64;      // stream entries per lane
 
+// NR long run-rows over the same column range [c00, c00+cnt): each gathered element feeds NR matrix values
+template <int NR, int NRHS, class Epi>
+__device__ __forceinline__ void long_run_rows(const Gather<NRHS>& gat, Epi& epi, const double* __restrict__ val, int64_t stride,
+                                              int cnt, int c00, int row0, int lane) {
+    double a1[NR], a2[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { a1[i] = 0.0; a2[i] = 0.0; }
+    constexpr int U = (NR >= 4) ? 2 : (NR == 2 ? 4 : 8);
+    int k = lane;
+    for (; k + (U - 1) * 64 < cnt; k += U * 64) {
+        double v[NR][U];
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[i][u] = nt_load(val + i * stride + k + 64 * u);
+        if constexpr (NRHS == 2) {
+            d2 x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = gat.w[c00 + k + 64 * u];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < NR; ++i) { a1[i] += v[i][u] * x[u].x; a2[i] += v[i][u] * x[u].y; }
+        } else {
+            double x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = gat.w[2 * (int64_t)(c00 + k + 64 * u)];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < NR; ++i) a1[i] += v[i][u] * x[u];
+        }
+    }
+    for (; k < cnt; k += 64) {
+        if constexpr (NRHS == 2) {
+            const d2 x = gat.w[c00 + k];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) { const double v = nt_load(val + i * stride + k); a1[i] += v * x.x; a2[i] += v * x.y; }
+        } else {
+            const double x = gat.w[2 * (int64_t)(c00 + k)];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) a1[i] += nt_load(val + i * stride + k) * x;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        a1[i] = group_sum(a1[i], 64);
+        if constexpr (NRHS == 2) a2[i] = group_sum(a2[i], 64);
+    }
+    // lane i finishes row i
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+        if (lane == i) epi.row(row0 + i, a1[i], a2[i]);
+}
+
+// U lane-major steps of an ELL block starting at step t: all U value (and index) loads are issued before the first
+// use, so a wavefront keeps U x 512 B (+ indices, + gathers) in flight.
+template <int U, int NRHS, bool RUN>
+__device__ __forceinline__ void ell_steps(const Gather<NRHS>& gat, const double* __restrict__ val, const int32_t* __restrict__ col,
+                                          int t, int tpr, int lig, int len, int c0, double& a1, double& a2) {
+    double v[U];
+    int c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = nt_load(val + 64 * (t + u));
+    if constexpr (!RUN) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = nt_load(col + 64 * (t + u));
+    }
+    bool m[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int e = (t + u) * tpr + lig;
+        m[u] = e < len;
+        if constexpr (RUN) c[u] = c0 + (m[u] ? e : 0);
+    }
+    if constexpr (NRHS == 2) {
+        d2 p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = gat(v[u], c[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (m[u]) { a1 += p[u].x; a2 += p[u].y; }
+    } else {
+        double p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = gat(v[u], c[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (m[u]) a1 += p[u];
+    }
+}
+
+// U strided steps of a long row starting at entry k (lane-consecutive, 64 entries per step)
+template <int U, int NRHS, bool RUN>
+__device__ __forceinline__ void long_steps(const Gather<NRHS>& gat, const double* __restrict__ val, const int32_t* __restrict__ col,
+                                           int k, int c00, double& a1, double& a2) {
+    double v[U];
+    int c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = nt_load(val + k + 64 * u);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if constexpr (RUN) c[u] = c00 + k + 64 * u;
+        else c[u] = nt_load(col + k + 64 * u);
+    }
+    if constexpr (NRHS == 2) {
+        d2 p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = gat(v[u], c[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a1 += p[u].x; a2 += p[u].y; }
+    } else {
+        double p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = gat(v[u], c[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) a1 += p[u];
+    }
+}
+
 template <int NRHS, class Epi>
 __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>& gat, Epi& epi, double* prod_all) {
     const int lane = threadIdx.x & 63;
@@ -119,23 +237,22 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
         if (kind == BLK_LONG) {
             // ---------------- long row d.row0
             double a1 = 0.0, a2 = 0.0;
-            const double* __restrict__ val = S.val;
-            const int32_t* __restrict__ col = S.col;
-            const int64_t e1 = d.nnz0 + d.cnt;
-            int64_t k = d.nnz0 + lane;
-            for (; k + 3 * 64 < e1; k += 4 * 64) {
-                const double v0 = nt_load(val + k), v1 = nt_load(val + k + 64), v2 = nt_load(val + k + 128), v3 = nt_load(val + k + 192);
-                const int c0 = nt_load(col + k), c1 = nt_load(col + k + 64), c2 = nt_load(col + k + 128), c3 = nt_load(col + k + 192);
-                if constexpr (NRHS == 2) {
-                    const d2 p0 = gat(v0, c0), p1 = gat(v1, c1), p2 = gat(v2, c2), p3 = gat(v3, c3);
-                    a1 += p0.x; a2 += p0.y; a1 += p1.x; a2 += p1.y; a1 += p2.x; a2 += p2.y; a1 += p3.x; a2 += p3.y;
-                } else {
-                    a1 += gat(v0, c0); a1 += gat(v1, c1); a1 += gat(v2, c2); a1 += gat(v3, c3);
-                }
-            }
-            for (; k < e1; k += 64) {
-                if constexpr (NRHS == 2) { const d2 p0 = gat(nt_load(val + k), nt_load(col + k)); a1 += p0.x; a2 += p0.y; }
-                else { a1 += gat(nt_load(val + k), nt_load(col + k)); }
+            const double* __restrict__ val = S.val + d.nnz0;
+            const int32_t* __restrict__ col = S.col + d.colpos;
+            const int cnt = (int)d.cnt;           // a row of S has < 2^31 entries
+            int k = lane;
+            if (d.run()) {
+                const int c00 = S.col[d.colpos];  // consecutive columns: col(e) = c00 + e
+                const int nr = d.nrows();
+                const int64_t stride = (d.cnt + NNZ_ALIGN - 1) / NNZ_ALIGN * NNZ_ALIGN;
+                if (nr == 4) long_run_rows<4, NRHS>(gat, epi, val, stride, cnt, c00, d.row0, lane);
+                else if (nr == 2) long_run_rows<2, NRHS>(gat, epi, val, stride, cnt, c00, d.row0, lane);
+                else long_run_rows<1, NRHS>(gat, epi, val, stride, cnt, c00, d.row0, lane);
+                continue;
+            } else {
+                for (; k + 7 * 64 < cnt; k += 8 * 64) long_steps<8, NRHS, false>(gat, val, col, k, 0, a1, a2);
+                for (; k + 1 * 64 < cnt; k += 2 * 64) long_steps<2, NRHS, false>(gat, val, col, k, 0, a1, a2);
+                for (; k < cnt; k += 64) long_steps<1, NRHS, false>(gat, val, col, k, 0, a1, a2);
             }
             a1 = group_sum(a1, 64);
             if constexpr (NRHS == 2) a2 = group_sum(a2, 64);
@@ -149,32 +266,20 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
             const int row = lane >> sh, lig = lane & (tpr - 1);
             const int len = (row < R) ? (int)S.row_rel[d.row0 + row] : 0;
             const double* __restrict__ val = S.val + d.nnz0 + lane;
-            const int32_t* __restrict__ col = S.col + d.nnz0 + lane;
             double a1 = 0.0, a2 = 0.0;
             int t = 0;
-            for (; t + 4 <= T; t += 4) {
-                const double v0 = nt_load(val + 64 * t), v1 = nt_load(val + 64 * t + 64), v2 = nt_load(val + 64 * t + 128), v3 = nt_load(val + 64 * t + 192);
-                const int c0 = nt_load(col + 64 * t), c1 = nt_load(col + 64 * t + 64), c2 = nt_load(col + 64 * t + 128), c3 = nt_load(col + 64 * t + 192);
-                const int e0 = t * tpr + lig;
-                if constexpr (NRHS == 2) {
-                    const d2 p0 = gat(v0, c0), p1 = gat(v1, c1), p2 = gat(v2, c2), p3 = gat(v3, c3);
-                    if (e0 < len) { a1 += p0.x; a2 += p0.y; }
-                    if (e0 + tpr < len) { a1 += p1.x; a2 += p1.y; }
-                    if (e0 + 2 * tpr < len) { a1 += p2.x; a2 += p2.y; }
-                    if (e0 + 3 * tpr < len) { a1 += p3.x; a2 += p3.y; }
-                } else {
-                    const double p0 = gat(v0, c0), p1 = gat(v1, c1), p2 = gat(v2, c2), p3 = gat(v3, c3);
-                    if (e0 < len) a1 += p0;
-                    if (e0 + tpr < len) a1 += p1;
-                    if (e0 + 2 * tpr < len) a1 += p2;
-                    if (e0 + 3 * tpr < len) a1 += p3;
-                }
-            }
-            for (; t < T; ++t) {
-                const double v0 = nt_load(val + 64 * t);
-                const int c0 = nt_load(col + 64 * t);
-                if constexpr (NRHS == 2) { const d2 p0 = gat(v0, c0); if (t * tpr + lig < len) { a1 += p0.x; a2 += p0.y; } }
-                else { const double p0 = gat(v0, c0); if (t * tpr + lig < len) a1 += p0; }
+            if (d.run()) {
+                // consecutive columns: entry e = t*tpr + lig of this lane's row sits in column c0 + e; lanes past their
+                // row's length (and padding lanes) read column c0 (valid) and are masked
+                const int c0 = (row < R) ? S.col[d.colpos + row] : 0;
+                for (; t + 8 <= T; t += 8) ell_steps<8, NRHS, true>(gat, val, nullptr, t, tpr, lig, len, c0, a1, a2);
+                for (; t + 2 <= T; t += 2) ell_steps<2, NRHS, true>(gat, val, nullptr, t, tpr, lig, len, c0, a1, a2);
+                for (; t < T; ++t) ell_steps<1, NRHS, true>(gat, val, nullptr, t, tpr, lig, len, c0, a1, a2);
+            } else {
+                const int32_t* __restrict__ col = S.col + d.colpos + lane;
+                for (; t + 8 <= T; t += 8) ell_steps<8, NRHS, false>(gat, val, col, t, tpr, lig, len, 0, a1, a2);
+                for (; t + 2 <= T; t += 2) ell_steps<2, NRHS, false>(gat, val, col, t, tpr, lig, len, 0, a1, a2);
+                for (; t < T; ++t) ell_steps<1, NRHS, false>(gat, val, col, t, tpr, lig, len, 0, a1, a2);
             }
             a1 = group_sum(a1, tpr);
             if constexpr (NRHS == 2) a2 = group_sum(a2, tpr);
@@ -183,7 +288,7 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
             // ---------------- LDS-staged block: rows row0 .. row0+nrows-1, cnt entries in CSR order
             const int cnt = (int)d.cnt;
             const double* __restrict__ val = S.val + d.nnz0;
-            const int32_t* __restrict__ col = S.col + d.nnz0;
+            const int32_t* __restrict__ col = S.col + d.colpos;
             {
                 double v[WPL]; int c[WPL];
 #pragma unroll

@@ -503,11 +503,16 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
     FOS_HIP(hipGetDeviceProperties(&prop, device));
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("FOS_SPMV_WG")) h->nwg_target = std::max(1, atoi(e));
-    else h->nwg_target = cus * 4;       // 4 workgroups (16 wavefronts) per CU measured best for the KKT sweep
+    else h->nwg_target = cus * 12;      // ~1.7x the resident workgroups (7/CU): measured best for the KKT sweep (dynamic balance)
 
     // ---- operator
     HostBlkCsr& hs = h->hostS;
     FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, h->nwg_target, &hs));
+    if (!getenv("FOS_SPMV_WG") && hs.nblk / SPMV_WAVES < h->nwg_target) {
+        // small operators: one or two row blocks per wavefront is the latency floor; more workgroups only add partials
+        h->nwg_target = std::max(cus, hs.nblk / (2 * SPMV_WAVES));
+        partition_workgroups(&hs, h->nwg_target);
+    }
     double* dval; int32_t* dcol; BlkDesc* dblk; uint16_t* drr; int32_t* dwv;
     FOS_TRY(dev_upload(h, &dval, hs.val));
     FOS_TRY(dev_upload(h, &dcol, hs.col));
