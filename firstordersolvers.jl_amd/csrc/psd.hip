@@ -38,7 +38,7 @@ __host__ __device__ inline int psd_ld(int k) {
     return ld;
 }
 
-__host__ inline size_t psd_lds_bytes(int k) { return (size_t)(16 + k * psd_ld(k) + k + 16) * sizeof(double); }
+__host__ inline size_t psd_lds_bytes(int k) { return (size_t)(16 + k * psd_ld(k) + 2 * k + 16) * sizeof(double); }
 
 __device__ __forceinline__ void idx_to_ij(int idx, int k, int& i, int& j) {
     // packed lower triangle, column-major: column j starts at S(j) = j k - j (j-1)/2
@@ -80,10 +80,16 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return y;
 }
 
-template <bool USE_LDS>
+// WARM: start the Jacobi iteration from G0 = (M + sigma I) V_prev, V_prev = the eigenvector basis this (cone, copy)
+// ended with at the previous outer iteration (read from vin, the new basis is written to vout).  The iterates of the
+// solver change slowly, so V_prev nearly diagonalises the new matrix and 3-5 sweeps replace 9-10 (the convergence
+// test -- a full sweep without a rotation -- is unchanged, so accuracy does not depend on the start).  Orders <= 64.
+template <bool USE_LDS, bool WARM>
 __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, const d2* __restrict__ in,
                                                           const ConeDesc* __restrict__ cones,
-                                                          double* __restrict__ gscratch, size_t scratch_stride) {
+                                                          double* __restrict__ gscratch, size_t scratch_stride,
+                                                          const double* __restrict__ vin, double* __restrict__ vout,
+                                                          size_t vstride, int have_prev) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
     const int cone = blockIdx.x >> 1, part = blockIdx.x & 1;
@@ -115,11 +121,42 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
     for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
     if ((tid & 63) == 0) red[tid >> 6] = fro;
     __syncthreads();
-    if (tid == 0) red[4] = 0.505 * sqrt((red[0] + red[1]) + (red[2] + red[3]));
+    // WARM needs every shifted eigenvalue strictly positive (well defined column directions): sigma > |lambda_min|
+    if (tid == 0) red[4] = (WARM ? 1.001 : 0.505) * sqrt((red[0] + red[1]) + (red[2] + red[3]));
     __syncthreads();
     const double sigma = red[4];
     for (int i = tid; i < k; i += PSD_THREADS) G[i + (size_t)i * ld] += sigma;
     __syncthreads();
+
+    if constexpr (WARM) {
+        if (have_prev && sigma > 0.0) {
+            // G0 = M' V_prev : thread (row i = lane, columns j = wave + 4 jj); M' rows from LDS, V_prev (wave-uniform) from L2
+            const double* __restrict__ Vp = vin + (size_t)blockIdx.x * vstride;
+            const int i = tid & 63, w = tid >> 6;
+            double acc[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) acc[jj] = 0.0;
+            if (i < k) {
+                for (int t = 0; t < k; ++t) {
+                    const double mv = G[i + (size_t)t * ld];
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) {
+                        const int j = w + 4 * jj;
+                        if (j < k) acc[jj] += mv * Vp[t + (size_t)j * k];
+                    }
+                }
+            }
+            __syncthreads();
+            if (i < k) {
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int j = w + 4 * jj;
+                    if (j < k) G[i + (size_t)j * ld] = acc[jj];
+                }
+            }
+            __syncthreads();
+        }
+    }
 
     // ---- one-sided Jacobi sweeps
     const int K = (k + 1) & ~1;               // even number of players (one bye when k is odd)
@@ -172,14 +209,25 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
     }
 
     // ---- weights: kept columns have ||g_j|| > sigma ; P = sum_j wgt_j g_j g_j', wgt_j = (||g_j|| - sigma) / ||g_j||^2
+    double* inv = wgt + k;                      // 1/||g_j|| (WARM: to store the new basis)
     for (int j = tid; j < k; j += PSD_THREADS) {
         double s = 0.0;
         const double* gj = G + (size_t)j * ld;
         for (int i = 0; i < k; ++i) s += gj[i] * gj[i];
         const double nr = sqrt(s);
         wgt[j] = nr > sigma ? (nr - sigma) / s : 0.0;
+        if constexpr (WARM) inv[j] = nr > 0.0 ? 1.0 / nr : 0.0;
     }
     __syncthreads();
+    if constexpr (WARM) {
+        // new basis: v_j = g_j / ||g_j|| (identity column if the matrix was all zero)
+        double* __restrict__ Vn = vout + (size_t)blockIdx.x * vstride;
+        for (int e = tid; e < k * k; e += PSD_THREADS) {
+            const int i = e % k, j = e / k;
+            const double s = inv[j];
+            Vn[e] = (sigma > 0.0 && s > 0.0) ? G[i + (size_t)j * ld] * s : (i == j ? 1.0 : 0.0);
+        }
+    }
 
     // ---- rebuild the lower triangle, repack, unscale the diagonal; dual: y = x + P(-x)
     for (int idx = tid; idx < len; idx += PSD_THREADS) {
@@ -196,26 +244,35 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
 size_t psd_scratch_bytes(int kmax, int ncones) {
     if (ncones <= 0) return 0;
     if (psd_lds_bytes(kmax) <= 160 * 1024 - 256) return 0;
-    return (size_t)2 * ncones * (size_t)(kmax * psd_ld(kmax) + kmax + 16) * sizeof(double);
+    return (size_t)2 * ncones * (size_t)(kmax * psd_ld(kmax) + 2 * kmax + 16) * sizeof(double);
 }
 
-// cones must be sorted so that all of them can run with the same storage choice; the launcher splits the list by
-// whether the order fits in LDS.
-int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones, int kmax, double* gscratch) {
+size_t psd_basis_doubles(int kmax, int ncones) {       // one warm-start basis buffer (two are kept, ping-pong)
+    if (ncones <= 0 || kmax > 64) return 0;
+    return (size_t)2 * ncones * (size_t)kmax * kmax;
+}
+
+int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones, int kmax, double* gscratch,
+                     const double* vin, double* vout, int have_prev) {
     if (ncones <= 0) return FOS_OK;
     const size_t lds = psd_lds_bytes(kmax);
     const bool use_lds = lds <= 160 * 1024 - 256;
+    const bool warm = vin && vout && kmax <= 64 && use_lds;
     static bool attr_set = false;
     if (use_lds && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(psd_kernel): %s", hipGetErrorString(e)); return FOS_EHIP; }
         attr_set = true;
     }
-    const size_t stride = (size_t)(kmax * psd_ld(kmax) + kmax + 16);
-    if (use_lds)
-        hipLaunchKernelGGL(psd_kernel<true>, dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride);
+    const size_t stride = (size_t)(kmax * psd_ld(kmax) + 2 * kmax + 16);
+    const size_t vstride = (size_t)kmax * kmax;
+    if (warm)
+        hipLaunchKernelGGL((psd_kernel<true, true>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev);
+    else if (use_lds)
+        hipLaunchKernelGGL((psd_kernel<true, false>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, nullptr, nullptr, vstride, 0);
     else
-        hipLaunchKernelGGL(psd_kernel<false>, dim3(2 * ncones), dim3(PSD_THREADS), 16 * sizeof(double), c.stream, out, in, cones, gscratch, stride);
+        hipLaunchKernelGGL((psd_kernel<false, false>), dim3(2 * ncones), dim3(PSD_THREADS), 16 * sizeof(double), c.stream, out, in, cones, gscratch, stride, nullptr, nullptr, vstride, 0);
     return FOS_OK;
 }
 

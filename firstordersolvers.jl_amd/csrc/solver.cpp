@@ -92,6 +92,8 @@ struct fos_solver {
     ConeDesc* soc = nullptr; int nsoc = 0;
     ConeDesc* psd = nullptr; int npsd = 0; int psd_kmax = 0;
     double* psd_scratch = nullptr;
+    double* psd_V[2] = {nullptr, nullptr};     // warm-start eigenvector bases (ping-pong), orders <= 64
+    int psd_cur = 0, psd_have_prev = 0;
 
     // scalars
     DevState* st = nullptr;
@@ -267,7 +269,9 @@ int prox_cones(fos_solver* h, d2* out, const d2* in) {
     LaunchCtx c = h->ctx();
     launch_cones_elementwise(c, out, in, h->ew_op);
     launch_cones_soc(c, out, in, h->soc, h->nsoc);
-    FOS_TRY(launch_cones_psd(c, out, in, h->psd, h->npsd, h->psd_kmax, h->psd_scratch));
+    FOS_TRY(launch_cones_psd(c, out, in, h->psd, h->npsd, h->psd_kmax, h->psd_scratch,
+                             h->psd_V[h->psd_cur], h->psd_V[1 - h->psd_cur], h->psd_have_prev));
+    if (h->npsd > 0 && h->psd_V[0]) { h->psd_cur = 1 - h->psd_cur; h->psd_have_prev = 1; }
     return FOS_OK;
 }
 
@@ -566,6 +570,10 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
     FOS_TRY(dev_upload(h, &h->psd, psd));
     size_t sb = psd_scratch_bytes(h->psd_kmax, h->npsd);
     if (sb) FOS_TRY(dev_alloc(h, &h->psd_scratch, sb / sizeof(double)));
+    if (!getenv("FOS_PSD_COLD")) {
+        const size_t vb = psd_basis_doubles(h->psd_kmax, h->npsd);
+        if (vb) { FOS_TRY(dev_alloc(h, &h->psd_V[0], vb)); FOS_TRY(dev_alloc(h, &h->psd_V[1], vb)); }
+    }
 
     // ---- scalars
     FOS_TRY(dev_alloc(h, &h->st, 1));

@@ -19,10 +19,10 @@ def short(name):
 
 
 for tag in ("trace_c4", "trace_c2"):
-    files = glob.glob(os.path.join(src, tag, "**", "*kernel_stats.csv"), recursive=True)
+    files = sorted(glob.glob(os.path.join(src, tag, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if not files:
         continue
-    rows = list(csv.DictReader(open(files[0])))
+    rows = list(csv.DictReader(open(files[-1])))
     with open(os.path.join(dst, "%s_%s_kernel_stats.md" % (rnd, tag)), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats : `python bench.py --steps 20 --no-cpu-baseline%s`\n\n" % (" --workload C2" if tag.endswith("c2") else ""))
         f.write("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
@@ -30,9 +30,9 @@ for tag in ("trace_c4", "trace_c2"):
             f.write("| %s | %s | %.3f | %.2f | %.2f | %.2f | %s |\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                                      float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
     # steady-state average of the dominant kernel (last 20 x cg launches) from the trace
-    tf = glob.glob(os.path.join(src, tag, "**", "*kernel_trace.csv"), recursive=True)
+    tf = sorted(glob.glob(os.path.join(src, tag, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     if tf:
-        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(tf[0])) if "kkt2_kernel" in r["Kernel_Name"]]
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(tf[-1])) if "kkt2_kernel" in r["Kernel_Name"]]
         real = [d for d in durs if d > 0.25 * max(durs)]      # launches enqueued past CG convergence exit at once (gated no-ops, ~3 us)
         tail = real[len(real) // 2:]
         with open(os.path.join(dst, "%s_%s_kernel_stats.md" % (rnd, tag)), "a") as f:
@@ -41,11 +41,11 @@ for tag in ("trace_c4", "trace_c2"):
                     % (len(durs), len(durs) - len(real), sum(real) / len(real) / 1e3, sum(tail) / len(tail) / 1e3))
 
 for tag, counter in (("pmc_fetch_c4", "FETCH_SIZE"), ("pmc_write_c4", "WRITE_SIZE")):
-    files = glob.glob(os.path.join(src, tag, "**", "*counter_collection.csv"), recursive=True)
+    files = sorted(glob.glob(os.path.join(src, tag, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     if not files:
         continue
     acc = defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(files[-1])):
         if r.get("Counter_Name") == counter:
             acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     with open(os.path.join(dst, "%s_%s.md" % (rnd, tag)), "w") as f:
