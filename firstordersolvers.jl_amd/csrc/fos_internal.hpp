@@ -95,6 +95,8 @@ void partition_workgroups(HostBlkCsr* S, int nwg_target);
 struct DevState {
     // CG  (conjugategradients.jl:31-55)
     double rn, rn_old, alpha, beta, pAp, rr, tol;
+    double rn2[2];         // r.r ping-pong: CG iteration j reads rn2[j&1] and writes rn2[(j+1)&1] (lets every workgroup of the
+                           // fused finalize+p-update kernel derive beta itself without racing the one that stores it)
     int32_t iter, done, maxit, hit_max;
     // algorithm scalars
     double alpha12;        // GAPAData.alpha12 (gapa.jl:29,101)
@@ -134,7 +136,7 @@ struct LaunchCtx {
 void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate);
 // mode 0: finish tau rows only (CG init / test entry); mode 1: also pAp and alpha = rn/pAp (CG iteration)
 void launch_kkt_reduce(const LaunchCtx& c, int gate);     // partials -> reduced[0..2]   (sharded path)
-void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int mode, int gate, int from_reduced);
+void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int mode, int gate, int from_reduced, int j = 1);
 
 // single right-hand side Q apply on component `comp` of an interleaved vector
 //   Q_PLAIN : out_plain[i] = sign * (Q v)_i            (rows 0..n+m-1; tau row by q1_finalize)
@@ -151,6 +153,8 @@ void launch_cg_init_finalize(const LaunchCtx& c, const double2* r, double tol, i
 void launch_cg_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, const double2* Ap);
 void launch_cg_update_finalize(const LaunchCtx& c, const double2* r, int from_reduced);
 void launch_cg_pupdate(const LaunchCtx& c, double2* p, const double2* r);
+// cg_update_finalize + cg_pupdate in one launch (iteration number j known at enqueue time)
+void launch_cg_finalize_pupdate(const LaunchCtx& c, double2* p, const double2* r, int from_reduced, int j);
 void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate);   // partials[count x nacc] -> reduced[nacc]
 
 // outer-loop vector kernels (gap.jl:48,58,78; gapa.jl:67,77,96-103; fista.jl:31-46; dykstra.jl)

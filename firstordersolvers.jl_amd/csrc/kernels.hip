@@ -418,7 +418,7 @@ __global__ __launch_bounds__(FIN_THREADS) void reduce_kernel(const double* __res
 __global__ __launch_bounds__(FIN_THREADS) void kkt_finalize_kernel(const double* __restrict__ partials, int count,
                                                                    const double* __restrict__ reduced, int from_reduced,
                                                                    const d2* __restrict__ w, d2* __restrict__ out, int nm,
-                                                                   DevState* st, int mode, int gate) {
+                                                                   DevState* st, int mode, int gate, int j) {
     if (gate && st->done) return;
     __shared__ double sums[3];
     __shared__ double smem[16 * 3];
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(FIN_THREADS) void kkt_finalize_kernel(const double*
         if (mode == 1) {
             const double pAp = S1 + (a1 * pt.x + a2 * pt.y);
             st->pAp = pAp;
-            st->alpha = st->rn / pAp;
+            st->alpha = st->rn2[j & 1] / pAp;
         }
     }
 }
@@ -451,9 +451,9 @@ void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate) {
     hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, count, nacc, c.reduced, c.st, gate);
 }
 void launch_kkt_reduce(const LaunchCtx& c, int gate) { launch_reduce1(c, c.S.nwg, 3, gate); }
-void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int mode, int gate, int from_reduced) {
+void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int mode, int gate, int from_reduced, int j) {
     hipLaunchKernelGGL(kkt_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.nwg, c.reduced,
-                       from_reduced, w, out, (int)(c.n + c.m), c.st, mode, gate);
+                       from_reduced, w, out, (int)(c.n + c.m), c.st, mode, gate, j);
 }
 
 // ------------------------------------------------------------------------------------------------ single RHS Q apply

@@ -184,7 +184,7 @@ int poll_state(fos_solver* h) {
     return FOS_OK;
 }
 
-int kkt_apply_full(fos_solver* h, const LaunchCtx& c, const d2* w, d2* out, int mode, int gate) {
+int kkt_apply_full(fos_solver* h, const LaunchCtx& c, const d2* w, d2* out, int mode, int gate, int j = 1) {
     bool rec = h->prof && mode == 1 && h->ev_used + 2 <= fos_solver::EV_CAP;
     if (rec) {
         while (h->ev.size() < h->ev_used + 2) {
@@ -201,7 +201,7 @@ int kkt_apply_full(fos_solver* h, const LaunchCtx& c, const d2* w, d2* out, int 
     }
     int fr = 0;
     FOS_TRY(finish_reduce(h, c, c.S.nwg, 3, gate, &fr));
-    launch_kkt_finalize(c, w, out, mode, gate, fr);
+    launch_kkt_finalize(c, w, out, mode, gate, fr, j);
     return FOS_OK;
 }
 
@@ -213,14 +213,14 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     launch_cg_init(c, rhs, h->AP, h->R, h->P);                         // :33-34
     FOS_TRY(finish_reduce(h, c, c.vec_blocks, 1, 0, &fr));
     launch_cg_init_finalize(c, h->R, tol, maxit, fr);                  // :35-36
+    int next_j = 1;                          // iteration number of the next enqueued launch group (if CG still runs)
     auto enqueue = [&](int count) -> int {
-        for (int j = 0; j < count; ++j) {
-            FOS_TRY(kkt_apply_full(h, c, h->P, h->AP, 1, 1));          // :38-39
+        for (int q = 0; q < count; ++q, ++next_j) {
+            FOS_TRY(kkt_apply_full(h, c, h->P, h->AP, 1, 1, next_j));  // :38-39
             launch_cg_update(c, x, h->R, h->P, h->AP);                 // :40-41
             int f2 = 0;
             FOS_TRY(finish_reduce(h, c, c.vec_blocks, 1, 1, &f2));
-            launch_cg_update_finalize(c, h->R, f2);                    // :42-47,51
-            launch_cg_pupdate(c, h->P, h->R);                          // :49-50
+            launch_cg_finalize_pupdate(c, h->P, h->R, f2, next_j);     // :42-51 (stop test, beta, p update)
         }
         return FOS_OK;
     };

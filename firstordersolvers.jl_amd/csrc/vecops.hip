@@ -85,6 +85,8 @@ __global__ __launch_bounds__(FIN_THREADS) void cg_init_finalize_kernel(const dou
     if (threadIdx.x == 0) {
         const d2 rt = r[l - 1];
         st->rn = sums[0] + (rt.x * rt.x + rt.y * rt.y);     // rn = dot(r,r)      :35
+        st->rn2[1] = st->rn;                                 // iteration 1 reads slot 1
+        st->rn2[0] = 0.0;
         st->rn_old = 0.0;
         st->iter = 1;                                        // :36
         st->done = 0;
@@ -150,6 +152,51 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_pupdate_kernel(int64_t l, d2* 
         pi.y = pi.y * beta + ri.y;
         p[i] = pi;
     }
+}
+
+// cg_update_finalize + cg_pupdate fused: EVERY workgroup reduces the <= 1024 r.r partials in the same fixed order (so all
+// derive the same stop decision and beta), workgroup 0 stores the scalars.  `j` = the iteration this launch belongs
+// to if CG is still running (known at enqueue time).  A workgroup that starts after workgroup 0 has set `done` simply
+// exits: p is not needed once CG has stopped.                       conjugategradients.jl:42-51
+__global__ __launch_bounds__(VEC_THREADS) void cg_finalize_pupdate_kernel(int64_t l, d2* __restrict__ p, const d2* __restrict__ r,
+                                                                          DevState* st, const double* __restrict__ partials, int count,
+                                                                          const double* __restrict__ reduced, int from_reduced, int j) {
+    if (st->done) return;
+    __shared__ double sums[1];
+    if (from_reduced) { if (threadIdx.x == 0) sums[0] = reduced[0]; __syncthreads(); }
+    else reduce_partials<1>(partials, count, sums);
+    const d2 rt = r[l - 1];
+    const double rr = sums[0] + (rt.x * rt.x + rt.y * rt.y);
+    const double rnold = st->rn2[j & 1];
+    const bool stop = (sqrt(rr) <= st->tol) || (j >= st->maxit);
+    const double beta = rr / rnold;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->rr = rr;
+        if (stop) {
+            st->iter = j;
+            st->hit_max = (j == st->maxit) ? 1 : 0;      // :53
+            __threadfence();
+            st->done = 1;
+        } else {
+            st->rn_old = rnold;
+            st->rn = rr;
+            st->rn2[(j + 1) & 1] = rr;
+            st->beta = beta;
+            st->iter = j + 1;
+        }
+    }
+    if (stop) return;
+    for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
+        d2 pi = p[i];
+        const d2 ri = r[i];
+        pi.x = pi.x * beta + ri.x;
+        pi.y = pi.y * beta + ri.y;
+        p[i] = pi;
+    }
+}
+void launch_cg_finalize_pupdate(const LaunchCtx& c, double2* p, const double2* r, int from_reduced, int j) {
+    hipLaunchKernelGGL(cg_finalize_pupdate_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p, r, c.st,
+                       c.partials, c.vec_blocks, c.reduced, from_reduced, j);
 }
 
 void launch_cg_init(const LaunchCtx& c, const double2* rhs, const double2* Ap, double2* r, double2* p) {
