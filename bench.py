@@ -160,6 +160,14 @@ def main():
     _, _, chk = dev.step(it + 1, 1, 1, 1e-8)
     it += 1
 
+    # HBM traffic of the dominant kernel measured offline with PMC counters on this workload (profiles/, per launch)
+    traffic = None
+    try:
+        cands = sorted(Path(ROOT / "profiles").glob("r*_kkt_traffic.json"))
+        if cands and not args.small and world == 1:
+            traffic = json.load(open(cands[-1])).get(args.workload, {}).get("traffic_bytes")
+    except Exception:
+        traffic = None
     ms_per_step = 1e3 * elapsed / max(1, args.steps)
     value = args.steps / elapsed
     avg_kernel_ms = kms / max(1, launches)
@@ -194,7 +202,8 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "frac_of_measured_copy_6290": round(achieved / 6290.0, 4),
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_note": "bytes per launch from rocprofv3 PMC passes committed under profiles/ (not collected in this run)" if traffic else None,
             "algorithmic_bytes_per_launch": kbytes,
             "avg_kernel_ms": round(avg_kernel_ms, 5),
             "launches_timed": launches,

@@ -87,6 +87,10 @@ __device__ __forceinline__ double group_sum(double v, int tpr) {
 template <class T>
 __device__ __forceinline__ T nt_load(const T* p) { return __builtin_nontemporal_load(p); }
 
+// what a row epilogue needs from memory besides the row sum: loaded at the START of the row block so that its
+// latency overlaps the sweep of the block instead of trailing it
+struct RowPre { d2 v; double c; };
+
 template <int NRHS>
 struct Gather;
 template <>
@@ -112,6 +116,8 @@ __device__ __forceinline__ void long_run_rows(const Gather<NRHS>& gat, Epi& epi,
     double a1[NR], a2[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) { a1[i] = 0.0; a2[i] = 0.0; }
+    RowPre pr{};
+    if (lane < NR) pr = epi.pre(row0 + lane);
     constexpr int U = (NR >= 4) ? 2 : (NR == 2 ? 4 : 8);
     int k = lane;
     for (; k + (U - 1) * 64 < cnt; k += U * 64) {
@@ -157,7 +163,7 @@ __device__ __forceinline__ void long_run_rows(const Gather<NRHS>& gat, Epi& epi,
     // lane i finishes row i
 #pragma unroll
     for (int i = 0; i < NR; ++i)
-        if (lane == i) epi.row(row0 + i, a1[i], a2[i]);
+        if (lane == i) epi.row(row0 + i, a1[i], a2[i], pr);
 }
 
 // U lane-major steps of an ELL block starting at step t: all U value (and index) loads are issued before the first
@@ -237,6 +243,8 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
         if (kind == BLK_LONG) {
             // ---------------- long row d.row0
             double a1 = 0.0, a2 = 0.0;
+            RowPre pr{};
+            if (lane == 0 && !d.run()) pr = epi.pre(d.row0);
             const double* __restrict__ val = S.val + d.nnz0;
             const int32_t* __restrict__ col = S.col + d.colpos;
             const int cnt = (int)d.cnt;           // a row of S has < 2^31 entries
@@ -256,7 +264,7 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
             }
             a1 = group_sum(a1, 64);
             if constexpr (NRHS == 2) a2 = group_sum(a2, 64);
-            if (lane == 0) epi.row(d.row0, a1, a2);
+            if (lane == 0) epi.row(d.row0, a1, a2, pr);
         } else if (kind == BLK_ELL) {
             // ---------------- lane-major block: lane (row, lig) owns entries lig, lig + tpr, ... of its row
             const int R = d.nrows(), T = d.steps();
@@ -265,6 +273,9 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
             const int sh = 31 - __clz(tpr);
             const int row = lane >> sh, lig = lane & (tpr - 1);
             const int len = (row < R) ? (int)S.row_rel[d.row0 + row] : 0;
+            const bool owner = row < R && lig == 0;
+            RowPre pr{};
+            if (owner) pr = epi.pre(d.row0 + row);
             const double* __restrict__ val = S.val + d.nnz0 + lane;
             double a1 = 0.0, a2 = 0.0;
             int t = 0;
@@ -283,12 +294,25 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
             }
             a1 = group_sum(a1, tpr);
             if constexpr (NRHS == 2) a2 = group_sum(a2, tpr);
-            if (row < R && lig == 0) epi.row(d.row0 + row, a1, a2);
+            if (owner) epi.row(d.row0 + row, a1, a2, pr);
         } else {
             // ---------------- LDS-staged block: rows row0 .. row0+nrows-1, cnt entries in CSR order
             const int cnt = (int)d.cnt;
             const double* __restrict__ val = S.val + d.nnz0;
             const int32_t* __restrict__ col = S.col + d.colpos;
+            const int R = d.nrows();
+            const int p2 = (R <= 1) ? 1 : (1 << (32 - __clz(R - 1)));
+            const int tpr = 64 / p2;
+            const int sh = 31 - __clz(tpr);
+            const int row = lane >> sh, lig = lane & (tpr - 1);
+            const bool owner = row < R && lig == 0;
+            RowPre pr{};
+            int s0 = 0, e = 0;
+            if (row < R) {
+                s0 = S.row_rel[d.row0 + row];
+                e = (row + 1 < R) ? (int)S.row_rel[d.row0 + row + 1] : cnt;
+            }
+            if (owner) pr = epi.pre(d.row0 + row);
             {
                 double v[WPL]; int c[WPL];
 #pragma unroll
@@ -310,15 +334,8 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int R = d.nrows();
-            const int p2 = (R <= 1) ? 1 : (1 << (32 - __clz(R - 1)));
-            const int tpr = 64 / p2;
-            const int sh = 31 - __clz(tpr);
-            const int row = lane >> sh, lig = lane & (tpr - 1);
             double a1 = 0.0, a2 = 0.0;
             if (row < R) {
-                const int s0 = S.row_rel[d.row0 + row];
-                const int e = (row + 1 < R) ? (int)S.row_rel[d.row0 + row + 1] : cnt;
                 for (int k = s0 + lig; k < e; k += tpr) {
                     if constexpr (NRHS == 2) { const d2 p = reinterpret_cast<const d2*>(prod)[k]; a1 += p.x; a2 += p.y; }
                     else { a1 += prod[k]; }
@@ -326,7 +343,7 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
             }
             a1 = group_sum(a1, tpr);
             if constexpr (NRHS == 2) a2 = group_sum(a2, tpr);
-            if (row < R && lig == 0) epi.row(d.row0 + row, a1, a2);
+            if (owner) epi.row(d.row0 + row, a1, a2, pr);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -342,9 +359,10 @@ struct EpiKkt {
     int n;
     d2 wt;             // (p1_tau, p2_tau)
     double acc[3];     // S1 = sum Ap.p (non-tau rows), T1 = [c;b].p1, T2 = [c;b].p2
-    __device__ __forceinline__ void row(int i, double u1, double u2) {
-        const d2 p = w[i];
-        const double c = cb[i];
+    __device__ __forceinline__ RowPre pre(int i) const { return RowPre{w[i], cb[i]}; }
+    __device__ __forceinline__ void row(int i, double u1, double u2, const RowPre& pr) {
+        const d2 p = pr.v;
+        const double c = pr.c;
         double q1, q2;                                  // (Q p1)_i, (Q p2)_i   HSDEAffine.jl:51-56
         if (i < n) { q1 = u1 + wt.x * c; q2 = u2 + wt.y * c; }
         else { q1 = -(u1 - wt.x * c); q2 = -(u2 - wt.y * c); }
@@ -461,19 +479,21 @@ void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int
 struct EpiQPlain {     // out_plain[i] = sign * (Q v)_i ; acc[0] = [c;b].v
     const double* vcomp; double* out; const double* cb; int n; double vt, sign; double acc[1];
     __device__ __forceinline__ void init(double vtau) { vt = vtau; }
-    __device__ __forceinline__ void row(int i, double u, double) {
-        const double c = cb[i];
+    __device__ __forceinline__ RowPre pre(int i) const { return RowPre{make_double2(vcomp[2 * (int64_t)i], 0.0), cb[i]}; }
+    __device__ __forceinline__ void row(int i, double u, double, const RowPre& pr) {
+        const double c = pr.c;
         const double q = (i < n) ? (u + vt * c) : -(u - vt * c);
         out[i] = sign * q;
-        acc[0] += c * vcomp[2 * (int64_t)i];
+        acc[0] += c * pr.v.x;
     }
 };
 struct EpiQRhs {       // out[i] = (x1_i - (Q x2)_i, 0)      affinepluslinear.jl:94-95 (beta = 1, q = 0, rhs2 = b = 0)
     const d2* x; d2* out; const double* cb; int n; double vt; double acc[1];
     __device__ __forceinline__ void init(double vtau) { vt = vtau; }
-    __device__ __forceinline__ void row(int i, double u, double) {
-        const double c = cb[i];
-        const d2 xi = x[i];
+    __device__ __forceinline__ RowPre pre(int i) const { return RowPre{x[i], cb[i]}; }
+    __device__ __forceinline__ void row(int i, double u, double, const RowPre& pr) {
+        const double c = pr.c;
+        const d2 xi = pr.v;
         const double q = (i < n) ? (u + vt * c) : -(u - vt * c);
         out[i] = make_double2(-q + xi.x, 0.0);          // rhs1 .= beta.*rhs1 .+ x1 .- q with rhs1 = Q'x2 = -(Q x2)
         acc[0] += c * xi.y;
@@ -482,9 +502,10 @@ struct EpiQRhs {       // out[i] = (x1_i - (Q x2)_i, 0)      affinepluslinear.jl
 struct EpiQVfromU {    // out[i] = (y_i.x, (Q y.x)_i)        HSDEAffine.jl:122-124  v = Q u
     const d2* y; d2* out; const double* cb; int n; double vt; double acc[1];
     __device__ __forceinline__ void init(double vtau) { vt = vtau; }
-    __device__ __forceinline__ void row(int i, double u, double) {
-        const double c = cb[i];
-        const d2 yi = y[i];
+    __device__ __forceinline__ RowPre pre(int i) const { return RowPre{y[i], cb[i]}; }
+    __device__ __forceinline__ void row(int i, double u, double, const RowPre& pr) {
+        const double c = pr.c;
+        const d2 yi = pr.v;
         const double q = (i < n) ? (u + vt * c) : -(u - vt * c);
         out[i] = make_double2(yi.x, q);
         acc[0] += c * yi.x;
@@ -493,9 +514,10 @@ struct EpiQVfromU {    // out[i] = (y_i.x, (Q y.x)_i)        HSDEAffine.jl:122-1
 struct EpiQStatus {    // residual sums of checkstatus  HSDEStatus.jl:34-38,59,61  (z = [x;y;tau | r;s;kappa] interleaved)
     const d2* z; const double* cb; int n; double tau; double acc[6];
     __device__ __forceinline__ void init(double vtau) { tau = vtau; }
-    __device__ __forceinline__ void row(int i, double u, double) {
-        const d2 zi = z[i];
-        const double c = cb[i];
+    __device__ __forceinline__ RowPre pre(int i) const { return RowPre{z[i], cb[i]}; }
+    __device__ __forceinline__ void row(int i, double u, double, const RowPre& pr) {
+        const d2 zi = pr.v;
+        const double c = pr.c;
         if (i < n) {                       // u = (A'y)_i, zi = (x_i, r_i), c = c_i
             const double rd = (u / tau + c) - zi.y / tau;
             acc[ST_RD2] += rd * rd;
