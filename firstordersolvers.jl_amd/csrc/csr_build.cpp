@@ -114,6 +114,10 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     auto nextpow2 = [](int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; };
     auto align = [](int64_t v) { return (v + NNZ_ALIGN - 1) / NNZ_ALIGN * NNZ_ALIGN; };
     const bool compress = getenv("FOS_NO_INDEX_COMPRESSION") == nullptr;
+    // lane-major (ELL) blocks are accepted while padded <= cnt * (1 + slack) + 32.  Irregular sparse rows are bound by the
+    // latency of their random 16-byte gathers, not by HBM: measured on C5 (sprandn, ~20/row) a 60 %-padded ELL block
+    // beats the LDS-staged path by 27 %, so up to 2x padding is accepted
+    const double ell_slack = getenv("FOS_ELL_SLACK") ? atof(getenv("FOS_ELL_SLACK")) : 1.0;
     int64_t pos = 0, cpos = 0;
     int64_t r = 0;
     while (r < nrows) {
@@ -174,7 +178,7 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
                 }
                 const int64_t tp = 64 / nextpow2(Rc);
                 const int64_t Tc = (ml + tp - 1) / tp;
-                if (64 * Tc <= c2 + c2 / 6 + 32 && 64 * Tc <= ELL_MAX) {
+                if ((double)(64 * Tc) <= (double)c2 * (1.0 + ell_slack) + 32.0 && 64 * Tc <= ELL_MAX) {
                     R = Rc; tpr = tp; T = Tc; padded = 64 * Tc; cnt = c2; rr = r0 + Rc;
                     ell_ok = true;
                     break;
