@@ -176,6 +176,7 @@ void launch_get_plain(const LaunchCtx& c, double* plain_l, const double2* in, in
 // cones (cones.jl:122-142)
 void launch_cones_elementwise(const LaunchCtx& c, double2* out, const double2* in, const uint8_t* ew_op);
 void launch_cones_soc(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones);
+void launch_cones_exp(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones);
 int  launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones,
                       int kmax, double* gscratch, const double* vin, double* vout, int have_prev);
 size_t psd_scratch_bytes(int kmax, int ncones);

@@ -90,6 +90,7 @@ struct fos_solver {
     // cones
     uint8_t* ew_op = nullptr;
     ConeDesc* soc = nullptr; int nsoc = 0;
+    ConeDesc* expc = nullptr; int nexp = 0;
     ConeDesc* psd = nullptr; int npsd = 0; int psd_kmax = 0;
     double* psd_scratch = nullptr;
     double* psd_V[2] = {nullptr, nullptr};     // warm-start eigenvector bases (ping-pong), orders <= 64
@@ -269,6 +270,7 @@ int prox_cones(fos_solver* h, d2* out, const d2* in) {
     LaunchCtx c = h->ctx();
     launch_cones_elementwise(c, out, in, h->ew_op);
     launch_cones_soc(c, out, in, h->soc, h->nsoc);
+    launch_cones_exp(c, out, in, h->expc, h->nexp);
     FOS_TRY(launch_cones_psd(c, out, in, h->psd, h->npsd, h->psd_kmax, h->psd_scratch,
                              h->psd_V[h->psd_cur], h->psd_V[1 - h->psd_cur], h->psd_have_prev));
     if (h->npsd > 0 && h->psd_V[0]) { h->psd_cur = 1 - h->psd_cur; h->psd_have_prev = 1; }
@@ -412,8 +414,8 @@ int validate_cones(const char* which, int64_t total, int64_t nK, const int32_t* 
                 if (psd_order(len[i]) < 0) { set_error("%s cone %lld: SDP length %lld is not k(k+1)/2", which, (long long)i + 1, (long long)len[i]); return FOS_EINVAL; }
                 break;
             case FOS_CONE_EXPPRIMAL: case FOS_CONE_EXPDUAL:
-                set_error("%s cone %lld: exponential cones are not implemented by the HIP path", which, (long long)i + 1);
-                return FOS_EUNSUPPORTED;
+                if (len[i] != 3) { set_error("%s cone %lld: an exponential cone has exactly 3 entries (got %lld)", which, (long long)i + 1, (long long)len[i]); return FOS_EINVAL; }
+                break;
             default:
                 set_error("%s cone %lld: unknown cone code %d", which, (long long)i + 1, (int)type[i]);
                 return FOS_EINVAL;
@@ -424,7 +426,7 @@ int validate_cones(const char* which, int64_t total, int64_t nK, const int32_t* 
 }
 
 void add_cones(int64_t offset, bool is_K1, int64_t nK, const int32_t* type, const int64_t* start, const int64_t* len,
-               std::vector<uint8_t>& ew, std::vector<ConeDesc>& soc, std::vector<ConeDesc>& psd) {
+               std::vector<uint8_t>& ew, std::vector<ConeDesc>& soc, std::vector<ConeDesc>& psd, std::vector<ConeDesc>& expc) {
     // K2 cone on [x | r]: part1 primal, part2 dual.   K1 cone on [y | s]: part1 dual, part2 primal.   cones.jl:136-140
     for (int64_t i = 0; i < nK; ++i) {
         const int64_t s0 = offset + start[i] - 1;
@@ -446,7 +448,9 @@ void add_cones(int64_t offset, bool is_K1, int64_t nK, const int32_t* type, cons
             cd.start = s0; cd.len = (int32_t)len[i]; cd.type = type[i];
             cd.dual_part = is_K1 ? 0 : 1;
             cd.k = type[i] == FOS_CONE_SDP ? psd_order(len[i]) : 0;
-            (type[i] == FOS_CONE_SDP ? psd : soc).push_back(cd);
+            if (type[i] == FOS_CONE_SDP) psd.push_back(cd);
+            else if (type[i] == FOS_CONE_EXPPRIMAL || type[i] == FOS_CONE_EXPDUAL) expc.push_back(cd);
+            else soc.push_back(cd);
         }
     }
 }
@@ -558,9 +562,11 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
 
     // ---- cones
     std::vector<uint8_t> ew(l, 0);
-    std::vector<ConeDesc> soc, psd;
-    add_cones(0, false, nK2, K2type, K2start, K2len, ew, soc, psd);
-    add_cones(n, true, nK1, K1type, K1start, K1len, ew, soc, psd);
+    std::vector<ConeDesc> soc, psd, expc;
+    add_cones(0, false, nK2, K2type, K2start, K2len, ew, soc, psd, expc);
+    add_cones(n, true, nK1, K1type, K1start, K1len, ew, soc, psd, expc);
+    h->nexp = (int)expc.size();
+    FOS_TRY(dev_upload(h, &h->expc, expc));
     ew[l - 1] = (uint8_t)(EW_MAX0 | (EW_MAX0 << 2));            // tau, kappa  cones.jl:138,141
     FOS_TRY(dev_upload(h, &h->ew_op, ew));
     h->nsoc = (int)soc.size();

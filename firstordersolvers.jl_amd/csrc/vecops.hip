@@ -467,6 +467,83 @@ __global__ __launch_bounds__(VEC_THREADS) void cones_soc_kernel(d2* __restrict__
         if (rot) y[1] = make_double2(y01, y11);
     }
 }
+// Exponential cone K = cl{(r,s,t): s > 0, s exp(r/s) <= t}: ProximalOperators' IndExpPrimal (a port of the SCS
+// projection: closed-form cases, else bisection on the dual variable rho with a 1-D Newton solve inside, tolerance
+// 1e-15, 100 iterations each); IndExpDual = Moreau  x + P_K(-x).  One thread per (cone, part).
+constexpr double EXP_TOL = 1e-15;
+constexpr int EXP_MAXIT = 100;
+
+__device__ double exp_newton_onz(double rho, double y_hat, double z_hat, double w) {
+    double t = fmax(fmax(w - z_hat, -z_hat), EXP_TOL);
+    for (int it = 0; it < EXP_MAXIT; ++it) {
+        const double f = (1.0 / (rho * rho)) * t * (t + z_hat) - y_hat / rho + log(t / rho) + 1.0;
+        const double fp = (1.0 / (rho * rho)) * (2.0 * t + z_hat) + 1.0 / t;
+        t = t - f / fp;
+        if (t <= -z_hat) { t = -z_hat; break; }
+        else if (t <= 0) { t = 0.0; break; }
+        else if (fabs(f) < EXP_TOL) break;
+    }
+    return t + z_hat;
+}
+__device__ double exp_calc_grad(const double* v, double rho, double warm2, double* x) {
+    x[2] = exp_newton_onz(rho, v[1], v[2], warm2);
+    x[1] = (1.0 / rho) * (x[2] - v[2]) * x[2];
+    x[0] = v[0] - rho;
+    return (x[1] == 0) ? x[0] : x[0] + x[1] * log(x[1] / x[2]);
+}
+__device__ void exp_project(const double* v, double* y) {
+    const double r = v[0], s = v[1], t = v[2];
+    if ((s > 0 && s * exp(r / s) <= t) || (r <= 0 && s == 0 && t >= 0)) { y[0] = r; y[1] = s; y[2] = t; return; }
+    if ((-r < 0 && r * exp(s / r) <= -2.718281828459045 * t) || (-r == 0 && -s >= 0 && -t >= 0)) { y[0] = y[1] = y[2] = 0.0; return; }
+    if (r < 0 && s < 0) { y[0] = r; y[1] = fmax(s, 0.0); y[2] = fmax(t, 0.0); return; }
+    double z[3], lb = 0.0, rho = 0.125;
+    double g = exp_calc_grad(v, rho, v[1], z);
+    while (g > 0) {                       // getRhoUb
+        lb = rho;
+        rho = rho * 2;
+        g = exp_calc_grad(v, rho, z[1], z);
+    }
+    double ub = rho;
+    for (int it = 0; it < EXP_MAXIT; ++it) {
+        rho = (ub + lb) / 2;
+        g = exp_calc_grad(v, rho, z[1], z);
+        if (g > 0) lb = rho; else ub = rho;
+        if (ub - lb < EXP_TOL) break;
+    }
+    y[0] = z[0]; y[1] = z[1]; y[2] = z[2];
+}
+// prox of the cone named by `type` (IndExpPrimal, or IndExpDual = x + P_K(-x))
+__device__ void exp_prox(int type, const double* x, double* y) {
+    if (type == FOS_CONE_EXPPRIMAL) { exp_project(x, y); return; }
+    double nx[3] = {-x[0], -x[1], -x[2]}, t[3];
+    exp_project(nx, t);
+    y[0] = x[0] + t[0]; y[1] = x[1] + t[1]; y[2] = x[2] + t[2];
+}
+__global__ __launch_bounds__(64) void cones_exp_kernel(d2* __restrict__ out, const d2* __restrict__ in,
+                                                       const ConeDesc* __restrict__ cones, int ncones) {
+    const int job = blockIdx.x * 64 + threadIdx.x;
+    if (job >= 2 * ncones) return;
+    const ConeDesc cd = cones[job >> 1];
+    const int part = job & 1;
+    const double* xin = reinterpret_cast<const double*>(in + cd.start) + part;
+    double* yout = reinterpret_cast<double*>(out + cd.start) + part;
+    const double x[3] = {xin[0], xin[2], xin[4]};
+    double y[3];
+    if (cd.dual_part == part) {           // proxDual: y = x + prox(-x)      cones.jl:80-85
+        const double nx[3] = {-x[0], -x[1], -x[2]};
+        double t[3];
+        exp_prox(cd.type, nx, t);
+        y[0] = x[0] + t[0]; y[1] = x[1] + t[1]; y[2] = x[2] + t[2];
+    } else {
+        exp_prox(cd.type, x, y);
+    }
+    yout[0] = y[0]; yout[2] = y[1]; yout[4] = y[2];
+}
+void launch_cones_exp(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones) {
+    if (ncones <= 0) return;
+    hipLaunchKernelGGL(cones_exp_kernel, dim3((2 * ncones + 63) / 64), dim3(64), 0, c.stream, out, in, cones, ncones);
+}
+
 void launch_cones_soc(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones) {
     if (ncones <= 0) return;
     const int per_block = VEC_THREADS / 64;

@@ -46,8 +46,8 @@ extern "C" {
 #define FOS_CONE_SOC        4   /* :SOC        IndSOC()               */
 #define FOS_CONE_SOCROT     5   /* :SOCRotated IndRotatedSOC()        */
 #define FOS_CONE_SDP        6   /* :SDP        IndPSD(scaling=true)   */
-#define FOS_CONE_EXPPRIMAL  7   /* :ExpPrimal  (not implemented: FOS_EUNSUPPORTED) */
-#define FOS_CONE_EXPDUAL    8   /* :ExpDual    (not implemented: FOS_EUNSUPPORTED) */
+#define FOS_CONE_EXPPRIMAL  7   /* :ExpPrimal  IndExpPrimal()  (3 entries per cone) */
+#define FOS_CONE_EXPDUAL    8   /* :ExpDual    IndExpDual()    (3 entries per cone) */
 
 /* algorithms: src/solvers/{gap,gapa,fista,dykstra}.jl */
 #define FOS_ALG_GAP     0   /* GAP(alpha, alpha1, alpha2); DR = GAP(a,2,2), AP = GAP(a,1,1)  (solvers.jl:10-11) */

@@ -434,6 +434,94 @@ def prox_socrot(y, x):
     y[1] = y2
 
 
+# Exponential cone  K = cl{(r,s,t): s > 0, s exp(r/s) <= t}.  ProximalOperators' IndExpPrimal is a port of the SCS
+# projection (bisection on the dual variable rho with a 1-D Newton solve inside); IndExpDual is
+# PrecomposeDiagonal(Conjugate(IndExpPrimal()), -1), i.e. Moreau's  P_K*(x) = x + P_K(-x).  PARITY UNPINNED: no
+# reference test touches these cones and the package source is not in the checkout.
+EXP_PROJ_TOL = 1e-15
+EXP_PROJ_MAXIT = 100
+
+
+def _exp_newton_onz(rho, y_hat, z_hat, w):
+    t = max(max(w - z_hat, -z_hat), EXP_PROJ_TOL)
+    for _ in range(EXP_PROJ_MAXIT):
+        f = (1.0 / rho ** 2) * t * (t + z_hat) - y_hat / rho + math.log(t / rho) + 1.0
+        fp = (1.0 / rho ** 2) * (2.0 * t + z_hat) + 1.0 / t
+        t = t - f / fp
+        if t <= -z_hat:
+            t = -z_hat
+            break
+        elif t <= 0:
+            t = 0.0
+            break
+        elif abs(f) < EXP_PROJ_TOL:
+            break
+    return t + z_hat
+
+
+def _exp_solve_with_rho(v, rho, w):
+    x3 = _exp_newton_onz(rho, v[1], v[2], w)
+    x2 = (1.0 / rho) * (x3 - v[2]) * x3
+    x1 = v[0] - rho
+    return (x1, x2, x3)
+
+
+def _exp_calc_grad(v, rho, warm):
+    x = _exp_solve_with_rho(v, rho, warm[1])
+    if x[1] == 0:
+        g = x[0]
+    else:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            g = x[0] + x[1] * float(np.log(np.float64(x[1]) / np.float64(x[2])))
+    return g, x
+
+
+def _exp_rho_ub(v):
+    lb = 0.0
+    rho = 2.0 ** -3
+    g, z = _exp_calc_grad(v, rho, v)
+    while g > 0:
+        lb = rho
+        rho = rho * 2
+        g, z = _exp_calc_grad(v, rho, z)
+    return rho, lb
+
+
+def prox_exp_primal(y, x):
+    r, s, t = float(x[0]), float(x[1]), float(x[2])
+    with np.errstate(over="ignore", divide="ignore", invalid="ignore"):
+        in_cone = (s > 0 and np.float64(s) * np.exp(np.float64(r) / np.float64(s)) <= t) or (r <= 0 and s == 0 and t >= 0)
+        in_polar = (-r < 0 and np.float64(r) * np.exp(np.float64(s) / np.float64(r)) <= -math.e * t) or (-r == 0 and -s >= 0 and -t >= 0)
+    if in_cone:
+        y[:] = x
+    elif in_polar:
+        y[:] = 0.0
+    elif r < 0 and s < 0:
+        y[0] = r
+        y[1] = max(s, 0.0)
+        y[2] = max(t, 0.0)
+    else:
+        v = (r, s, t)
+        ub, lb = _exp_rho_ub(v)
+        z = v
+        for _ in range(EXP_PROJ_MAXIT):
+            rho = (ub + lb) / 2
+            g, z = _exp_calc_grad(v, rho, z)
+            if g > 0:
+                lb = rho
+            else:
+                ub = rho
+            if ub - lb < EXP_PROJ_TOL:
+                break
+        y[:] = z
+
+
+def prox_exp_dual(y, x):
+    tmp = np.empty(3)
+    prox_exp_primal(tmp, -np.asarray(x, dtype=np.float64))
+    y[:] = x + tmp
+
+
 def psd_dim(length):
     """Matrix order k with k(k+1)/2 == length."""
     k = int(round(math.sqrt(0.25 + 2.0 * length) - 0.5))
@@ -490,6 +578,7 @@ def prox_psd_matrix(Y):
 _PROX = {
     CONE_FREE: prox_free, CONE_ZERO: prox_zero, CONE_NONNEG: prox_nonneg, CONE_NONPOS: prox_nonpos,
     CONE_SOC: prox_soc, CONE_SOCROT: prox_socrot, CONE_SDP: prox_psd_scaled,
+    CONE_EXPP: prox_exp_primal, CONE_EXPD: prox_exp_dual,
 }
 
 

@@ -483,8 +483,8 @@ def test_bad_inputs_fail_loudly(pkg):
         pkg.HipHSDE(A, np.zeros(3), np.zeros(3), [("Zero", 2)], [("Free", 3)])
     with pytest.raises(pkg.lib.FosError):          # SDP length not triangular
         pkg.HipHSDE(sp.csc_matrix(np.eye(4)), np.zeros(4), np.zeros(4), [("SDP", 4)], [("Free", 4)])
-    with pytest.raises(pkg.lib.FosError):          # exponential cones: unsupported, not silently ignored
-        pkg.HipHSDE(A, np.zeros(3), np.zeros(3), [("ExpPrimal", 3)], [("Free", 3)])
+    with pytest.raises(pkg.lib.FosError):          # an exponential cone has exactly 3 entries
+        pkg.HipHSDE(sp.csc_matrix(np.eye(4)), np.zeros(4), np.zeros(4), [("ExpPrimal", 4)], [("Free", 4)])
     with pytest.raises(ValueError):
         pkg.HipHSDE(A, np.zeros(3), np.zeros(3), [("Zero", [1, 3, 2])], [("Free", 3)])
 
@@ -506,3 +506,28 @@ def test_rccl_reduction_path_single_rank(pkg):
         d.close()
     assert np.array_equal(outs[0][0], outs[1][0])
     assert outs[0][1:] == outs[1][1:]
+
+
+def test_exponential_cones(pkg, dev_ops):
+    """IndExpPrimal / IndExpDual (conemap :ExpPrimal, :ExpDual; cones.jl:12-13) on both sides of the product, primal and
+    Moreau-dual copies.  PARITY UNPINNED upstream (no reference test); checked against the oracle's restatement of the
+    SCS-derived algorithm to 1e-9 (the bisection/Newton iteration counts may differ by rounding) and through
+    cone membership + Moreau orthogonality."""
+    rng = np.random.default_rng(21)
+    K1 = [("ExpPrimal", 3), ("ExpDual", 3), ("ExpPrimal", 3), ("NonNeg", 2), ("ExpDual", 3)]
+    K2 = [("ExpDual", 3), ("ExpPrimal", 3)]
+    m, n = 14, 6
+    A = sp.random(m, n, density=0.4, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    d, _, _ = dev_ops(A, None, None, K1, K2)
+    S2 = orc.DualConeProduct(orc.ConeProduct.from_lengths(_codes(K1)), orc.ConeProduct.from_lengths(_codes(K2)))
+    for trial in range(40):
+        z = rng.standard_normal(d.N) * 10.0 ** rng.uniform(-1.5, 1.5)
+        ref = np.empty(d.N)
+        S2.prox(ref, z)
+        out = d.prox_cones(z)
+        assert np.linalg.norm(out - ref) <= 1e-9 * max(1.0, np.linalg.norm(z)), trial
+    # closed-form cases: a point inside the cone is fixed, a point in the polar cone maps to 0
+    z = np.zeros(d.N)
+    z[d.l + n:d.l + n + 3] = [0.5, 1.0, 3.0]          # s part of the first K1 cone (ExpPrimal): 1*exp(0.5) <= 3
+    out = d.prox_cones(z)
+    assert np.array_equal(out[d.l + n:d.l + n + 3], [0.5, 1.0, 3.0])

@@ -393,3 +393,25 @@ def test_dual_cone_product_layout():
     assert np.array_equal(out, np.array(expect, dtype=float))
     with pytest.raises(AssertionError):
         orc.ConeProduct([(orc.CONE_ZERO, 0, 2), (orc.CONE_ZERO, 3, 2)])      # gap -> cones.jl:69 assertion
+
+
+def test_exponential_cone_properties():
+    """IndExpPrimal/IndExpDual restatement (parity unpinned upstream): Moreau decomposition x = P_K(x) - P_K*(-x)
+    with P_K(x) orthogonal to P_K*(-x), membership, closed-form cases."""
+    rng = np.random.default_rng(3)
+    for trial in range(200):
+        x = rng.standard_normal(3) * 10.0 ** rng.uniform(-2, 2)
+        y, yd = np.empty(3), np.empty(3)
+        orc.prox_exp_primal(y, x)
+        orc.prox_exp_dual(yd, -x)
+        assert np.linalg.norm(y - yd - x) <= 1e-12 * max(1.0, np.linalg.norm(x))
+        assert abs(y @ yd) <= 1e-6 * max(1.0, np.linalg.norm(x) ** 2)      # accuracy of the SCS-style bisection in extreme cases
+        r, s, t = y
+        assert (s > 0 and s * math.exp(r / s) <= t * (1 + 1e-7) + 1e-9) or (r <= 1e-9 and abs(s) <= 1e-9 and t >= -1e-9)
+    y = np.empty(3)
+    orc.prox_exp_primal(y, np.array([0.5, 1.0, 3.0]))
+    assert np.array_equal(y, [0.5, 1.0, 3.0])
+    orc.prox_exp_primal(y, np.array([1.0, -1.0, -5.0]))          # in the polar cone
+    assert np.array_equal(y, np.zeros(3))
+    orc.prox_exp_primal(y, np.array([-1.0, -2.0, 3.0]))          # r < 0, s < 0: analytical
+    assert np.array_equal(y, [-1.0, 0.0, 3.0])
