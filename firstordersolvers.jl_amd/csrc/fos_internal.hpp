@@ -155,6 +155,8 @@ void launch_cg_update_finalize(const LaunchCtx& c, const double2* r, int from_re
 void launch_cg_pupdate(const LaunchCtx& c, double2* p, const double2* r);
 // cg_update_finalize + cg_pupdate in one launch (iteration number j known at enqueue time)
 void launch_cg_finalize_pupdate(const LaunchCtx& c, double2* p, const double2* r, int from_reduced, int j);
+// kkt_finalize(mode 1) + cg_update in one launch; its r.r partials are written at partials + 3*16392
+void launch_cg_alpha_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, double2* Ap, int from_reduced, int j);
 void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate);   // partials[count x nacc] -> reduced[nacc]
 
 // outer-loop vector kernels (gap.jl:48,58,78; gapa.jl:67,77,96-103; fista.jl:31-46; dykstra.jl)

@@ -217,10 +217,25 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     int next_j = 1;                          // iteration number of the next enqueued launch group (if CG still runs)
     auto enqueue = [&](int count) -> int {
         for (int q = 0; q < count; ++q, ++next_j) {
-            FOS_TRY(kkt_apply_full(h, c, h->P, h->AP, 1, 1, next_j));  // :38-39
-            launch_cg_update(c, x, h->R, h->P, h->AP);                 // :40-41
+            // 3 launches per CG iteration: KKT sweep | alpha + x,r update | stop test + beta + p update
+            const bool rec = h->prof && h->ev_used + 2 <= fos_solver::EV_CAP;
+            if (rec) {
+                while (h->ev.size() < h->ev_used + 2) { hipEvent_t e; FOS_HIP(hipEventCreate(&e)); h->ev.push_back(e); }
+                FOS_HIP(hipEventRecord(h->ev[h->ev_used], h->stream));
+            }
+            launch_kkt2(c, h->P, h->AP, 1);                            // :38   Ap = M p (+ partial sums)
+            if (rec) { FOS_HIP(hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
+            int f1 = 0;
+            FOS_TRY(finish_reduce(h, c, c.S.nwg, 3, 1, &f1));
+            launch_cg_alpha_update(c, x, h->R, h->P, h->AP, f1, next_j);   // :39-41,46
             int f2 = 0;
-            FOS_TRY(finish_reduce(h, c, c.vec_blocks, 1, 1, &f2));
+            if (h->comm) {                                             // sharded: reduce the r.r partials, all-reduce
+                LaunchCtx c2 = c;
+                c2.partials = c.partials + 3 * (size_t)16392;
+                launch_reduce1(c2, c.vec_blocks, 1, 1);
+                FOS_TRY(allreduce(h, 1));
+                f2 = 1;
+            }
             launch_cg_finalize_pupdate(c, h->P, h->R, f2, next_j);     // :42-51 (stop test, beta, p update)
         }
         return FOS_OK;

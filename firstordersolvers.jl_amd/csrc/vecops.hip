@@ -115,6 +115,48 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
     block_reduce_store<1>(acc, partials + blockIdx.x);
 }
 
+// kkt_finalize(mode 1) + cg_update fused: EVERY workgroup reduces the 3 x nwg KKT partials in the same fixed order, finishes
+// the tau rows of Ap = M p and alpha = rn / (Ap.p) itself (so no workgroup waits for another), then updates its slice:
+// x += alpha p ; r -= alpha Ap ; partial r.r.  Workgroup 0 stores Ap[tau], pAp and alpha.     conjugategradients.jl:39-41,46
+__global__ __launch_bounds__(VEC_THREADS) void cg_alpha_update_kernel(int64_t l, d2* __restrict__ x, d2* __restrict__ r,
+                                                                      const d2* __restrict__ p, d2* __restrict__ Ap,
+                                                                      DevState* st, const double* __restrict__ kkt_partials, int nkkt,
+                                                                      const double* __restrict__ reduced, int from_reduced, int j,
+                                                                      double* __restrict__ partials) {
+    if (st->done) return;
+    __shared__ double sums[3];
+    if (from_reduced) { if (threadIdx.x < 3) sums[threadIdx.x] = reduced[threadIdx.x]; __syncthreads(); }
+    else reduce_partials<3>(kkt_partials, nkkt, sums);
+    const d2 pt = p[l - 1];
+    const double S1 = sums[0], T1 = sums[1], T2 = sums[2];
+    const double at1 = pt.x + T2;            // p1_tau - (Q p2)_tau ,  (Q v)_tau = -[c;b].v        HSDEAffine.jl:57
+    const double at2 = -T1 - pt.y;           // (Q p1)_tau - p2_tau
+    const double pAp = S1 + (at1 * pt.x + at2 * pt.y);
+    const double alpha = st->rn2[j & 1] / pAp;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        Ap[l - 1] = make_double2(at1, at2);
+        st->pAp = pAp;
+        st->alpha = alpha;
+    }
+    double acc[1] = {0.0};
+    for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
+        const d2 pi = p[i];
+        const d2 ai = (i == l - 1) ? make_double2(at1, at2) : Ap[i];
+        d2 xi = x[i], ri = r[i];
+        xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+        ri.x -= alpha * ai.x; ri.y -= alpha * ai.y;
+        x[i] = xi;
+        r[i] = ri;
+        if (i != l - 1) acc[0] += ri.x * ri.x + ri.y * ri.y;
+    }
+    block_reduce_store<1>(acc, partials + blockIdx.x);
+}
+void launch_cg_alpha_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, double2* Ap, int from_reduced, int j) {
+    // r.r partials go behind the 3 x nwg KKT partials (both live in c.partials)
+    hipLaunchKernelGGL(cg_alpha_update_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, r, p, Ap, c.st,
+                       c.partials, c.S.nwg, c.reduced, from_reduced, j, c.partials + 3 * (size_t)16392);
+}
+
 // norm(r) <= tol || iter >= max_iters -> done ; else rnold = rn, rn = r.r, beta = rn/rnold, iter += 1    :42-51
 __global__ __launch_bounds__(FIN_THREADS) void cg_update_finalize_kernel(const double* __restrict__ partials, int count,
                                                                          const double* __restrict__ reduced, int from_reduced,
@@ -196,7 +238,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_finalize_pupdate_kernel(int64_
 }
 void launch_cg_finalize_pupdate(const LaunchCtx& c, double2* p, const double2* r, int from_reduced, int j) {
     hipLaunchKernelGGL(cg_finalize_pupdate_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p, r, c.st,
-                       c.partials, c.vec_blocks, c.reduced, from_reduced, j);
+                       c.partials + 3 * (size_t)16392, c.vec_blocks, c.reduced, from_reduced, j);
 }
 
 void launch_cg_init(const LaunchCtx& c, const double2* rhs, const double2* Ap, double2* r, double2* p) {
