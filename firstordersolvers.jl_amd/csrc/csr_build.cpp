@@ -63,7 +63,7 @@ void partition_workgroups(HostBlkCsr* S, int nwg_target) {
 }
 
 int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
-                      int nwg_target, HostBlkCsr* out) {
+                      int nwg_target, HostBlkCsr* out, int resident_waves) {
     if (m < 0 || n < 0) { set_error("negative dimension"); return FOS_EINVAL; }
     if (n + m + 1 > (int64_t)INT32_MAX / 2) { set_error("n+m too large for int32 column indices"); return FOS_EUNSUPPORTED; }
     if (colptr[0] != 1) { set_error("colptr must be 1-based (colptr[1] == 1)"); return FOS_EINVAL; }
@@ -118,6 +118,15 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     // latency of their random 16-byte gathers, not by HBM: measured on C5 (sprandn, ~20/row) a 60 %-padded ELL block
     // beats the LDS-staged path by 27 %, so up to 2x padding is accepted
     const double ell_slack = getenv("FOS_ELL_SLACK") ? atof(getenv("FOS_ELL_SLACK")) : 1.0;
+    // Block size adapts to the operator: a wavefront walks its blocks serially (2 dependent memory round trips per 8
+    // lane-major steps), so a SMALL operator wants many small blocks (latency: every resident wavefront gets ~2 of them),
+    // a large one the full ELL_MAX (fewer descriptors, more rows per lane sweep).
+    int64_t ell_cap = ELL_MAX;
+    if (resident_waves > 0) {
+        ell_cap = (2 * nnz / (2 * (int64_t)resident_waves) + 63) / 64 * 64;
+        ell_cap = std::max<int64_t>(256, std::min<int64_t>(ELL_MAX, ell_cap));
+    }
+    if (getenv("FOS_ELL_CAP")) ell_cap = std::max(64, atoi(getenv("FOS_ELL_CAP")) / 64 * 64);
     int64_t pos = 0, cpos = 0;
     int64_t r = 0;
     while (r < nrows) {
@@ -155,12 +164,12 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             int64_t cnt = 0, maxlen = 0, rr = r;
             while (rr < r_lim) {
                 const int64_t len = rp[rr + 1] - rp[rr];
-                if (cnt + len > ELL_MAX) break;
+                if (rr > r0 && cnt + len > ell_cap) break;
                 const int64_t R1 = rr - r0 + 1;
                 const int64_t tpr1 = 64 / nextpow2(R1);
                 const int64_t ml = std::max(maxlen, len);
                 const int64_t T1 = (ml + tpr1 - 1) / tpr1;
-                if (64 * T1 > ELL_MAX) break;
+                if (rr > r0 && 64 * T1 > std::max<int64_t>(ell_cap, 64 * ((len0 + 63) / 64))) break;
                 cnt += len;
                 maxlen = ml;
                 rr += 1;

@@ -87,7 +87,7 @@ struct DevBlkCsr {
 
 // Builds S = [[0, A'],[A, 0]] from Julia CSC (1-based).  Returns FOS_EINVAL on malformed input.
 int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
-                      int nwg_target, HostBlkCsr* out);
+                      int nwg_target, HostBlkCsr* out, int resident_waves = 0);
 void partition_workgroups(HostBlkCsr* S, int nwg_target);
 
 // ---------------------------------------------------------------------------------- device scalar state

@@ -91,6 +91,12 @@ __device__ __forceinline__ T nt_load(const T* p) { return __builtin_nontemporal_
 // latency overlaps the sweep of the block instead of trailing it
 struct RowPre { d2 v; double c; };
 
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// Gathered vector element(s).  operator(): plain load through the per-CU L1.  nt(): non-temporal (L1-bypassing) variant,
+// kept for experiments only: measured on random gathers (C5, sprandn) it is 1.6x SLOWER than the cached load, although
+// each L1 fill brings a 128-byte line for 16 useful bytes -- the sweep of a random-sparse operator runs at the L2->L1
+// line rate (~125 G lines/s chip wide), which is what bounds C3/C5.
 template <int NRHS>
 struct Gather;
 template <>
@@ -100,11 +106,16 @@ struct Gather<2> {
         d2 x = w[c];
         return make_double2(v * x.x, v * x.y);
     }
+    __device__ __forceinline__ d2 nt(double v, int c) const {
+        const v2d x = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(w) + c);
+        return make_double2(v * x.x, v * x.y);
+    }
 };
 template <>
 struct Gather<1> {
     const double* w;   // points at the chosen component of an interleaved vector: element c at w[2c]
     __device__ __forceinline__ double operator()(double v, int c) const { return v * w[2 * (int64_t)c]; }
+    __device__ __forceinline__ double nt(double v, int c) const { return v * __builtin_nontemporal_load(w + 2 * (int64_t)c); }
 };
 
 constexpr int WPL = WNNZ / 64;      // stream entries per lane

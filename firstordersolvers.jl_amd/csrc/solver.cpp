@@ -530,10 +530,10 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
 
     // ---- operator
     HostBlkCsr& hs = h->hostS;
-    FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, h->nwg_target, &hs));
+    FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, h->nwg_target, &hs, cus * 28));
     if (!getenv("FOS_SPMV_WG") && hs.nblk / SPMV_WAVES < h->nwg_target) {
         // small operators: one or two row blocks per wavefront is the latency floor; more workgroups only add partials
-        h->nwg_target = std::max(cus, hs.nblk / (2 * SPMV_WAVES));
+        h->nwg_target = std::max(cus, (hs.nblk + SPMV_WAVES - 1) / SPMV_WAVES);
         partition_workgroups(&hs, h->nwg_target);
     }
     double* dval; int32_t* dcol; BlkDesc* dblk; uint16_t* drr; int32_t* dwv;
