@@ -134,9 +134,8 @@ struct LaunchCtx {
 
 // KKT apply, 2 RHS interleaved:  out = [I Q'; Q -I] * w   (rows 0..n+m-1; the tau row is written by kkt_finalize)
 void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate);
-// mode 0: finish tau rows only (CG init / test entry); mode 1: also pAp and alpha = rn/pAp (CG iteration)
-void launch_kkt_reduce(const LaunchCtx& c, int gate);     // partials -> reduced[0..2]   (sharded path)
-void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int mode, int gate, int from_reduced, int j = 1);
+// finishes the tau rows of out = M w from the sweep's partial sums (CG init / test entry)
+void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int gate, int from_reduced);
 
 // single right-hand side Q apply on component `comp` of an interleaved vector
 //   Q_PLAIN : out_plain[i] = sign * (Q v)_i            (rows 0..n+m-1; tau row by q1_finalize)
@@ -144,18 +143,14 @@ void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int
 //   Q_STATUS: residual sums of checkstatus             (HSDEStatus.jl:34-38,59,61)
 enum QMode { Q_PLAIN = 0, Q_RHS = 1, Q_STATUS = 2, Q_VFROMU = 3 };
 void launch_q1(const LaunchCtx& c, QMode mode, const double2* v, int comp, double sign, void* out);
-void launch_q1_reduce(const LaunchCtx& c, QMode mode);
 void launch_q1_finalize(const LaunchCtx& c, QMode mode, const double2* v, int comp, double sign, void* out, int from_reduced);
 
 // CG vector kernels
 void launch_cg_init(const LaunchCtx& c, const double2* rhs, const double2* Ap, double2* r, double2* p);
 void launch_cg_init_finalize(const LaunchCtx& c, const double2* r, double tol, int maxit, int from_reduced);
-void launch_cg_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, const double2* Ap);
-void launch_cg_update_finalize(const LaunchCtx& c, const double2* r, int from_reduced);
-void launch_cg_pupdate(const LaunchCtx& c, double2* p, const double2* r);
-// cg_update_finalize + cg_pupdate in one launch (iteration number j known at enqueue time)
+// stop test + beta + p update in one launch (iteration number j known at enqueue time)
 void launch_cg_finalize_pupdate(const LaunchCtx& c, double2* p, const double2* r, int from_reduced, int j);
-// kkt_finalize(mode 1) + cg_update in one launch; its r.r partials are written at partials + 3*16392
+// tau rows of Ap, alpha = rn/(Ap.p), x += alpha p, r -= alpha Ap in one launch; its r.r partials go to partials + 3*16392
 void launch_cg_alpha_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, double2* Ap, int from_reduced, int j);
 void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate);   // partials[count x nacc] -> reduced[nacc]
 

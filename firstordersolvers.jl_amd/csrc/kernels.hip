@@ -443,11 +443,11 @@ __global__ __launch_bounds__(FIN_THREADS) void reduce_kernel(const double* __res
     if ((int)threadIdx.x < nacc) reduced[threadIdx.x] = sums[threadIdx.x];
 }
 
-// mode 0: tau rows only.  mode 1: tau rows + pAp + alpha = rn / pAp   (conjugategradients.jl:39)
+// tau rows of out = M w from the sweep's partials (the CG iteration does this inside cg_alpha_update_kernel)
 __global__ __launch_bounds__(FIN_THREADS) void kkt_finalize_kernel(const double* __restrict__ partials, int count,
                                                                    const double* __restrict__ reduced, int from_reduced,
                                                                    const d2* __restrict__ w, d2* __restrict__ out, int nm,
-                                                                   DevState* st, int mode, int gate, int j) {
+                                                                   const DevState* st, int gate) {
     if (gate && st->done) return;
     __shared__ double sums[3];
     __shared__ double smem[16 * 3];
@@ -459,16 +459,9 @@ __global__ __launch_bounds__(FIN_THREADS) void kkt_finalize_kernel(const double*
     }
     if (threadIdx.x == 0) {
         const d2 pt = w[nm];
-        const double S1 = sums[0], T1 = sums[1], T2 = sums[2];
+        const double T1 = sums[1], T2 = sums[2];
         // (Q v)_tau = -c'v_x - b'v_y = -T(v)                          HSDEAffine.jl:57
-        const double a1 = pt.x + T2;        // p1_tau - (Q p2)_tau
-        const double a2 = -T1 - pt.y;       // (Q p1)_tau - p2_tau
-        out[nm] = make_double2(a1, a2);
-        if (mode == 1) {
-            const double pAp = S1 + (a1 * pt.x + a2 * pt.y);
-            st->pAp = pAp;
-            st->alpha = st->rn2[j & 1] / pAp;
-        }
+        out[nm] = make_double2(pt.x + T2, -T1 - pt.y);      // p1_tau - (Q p2)_tau ; (Q p1)_tau - p2_tau
     }
 }
 
@@ -479,10 +472,9 @@ void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
 void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate) {
     hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, count, nacc, c.reduced, c.st, gate);
 }
-void launch_kkt_reduce(const LaunchCtx& c, int gate) { launch_reduce1(c, c.S.nwg, 3, gate); }
-void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int mode, int gate, int from_reduced, int j) {
+void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int gate, int from_reduced) {
     hipLaunchKernelGGL(kkt_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.nwg, c.reduced,
-                       from_reduced, w, out, (int)(c.n + c.m), c.st, mode, gate, j);
+                       from_reduced, w, out, (int)(c.n + c.m), c.st, gate);
 }
 
 // ------------------------------------------------------------------------------------------------ single RHS Q apply
@@ -610,7 +602,6 @@ void launch_q1(const LaunchCtx& c, QMode mode, const double2* v, int comp, doubl
         hipLaunchKernelGGL((q1_kernel<EpiQStatus, 6>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
     }
 }
-void launch_q1_reduce(const LaunchCtx& c, QMode mode) { launch_reduce1(c, c.S.nwg, mode == Q_STATUS ? 6 : 1, 0); }
 void launch_q1_finalize(const LaunchCtx& c, QMode mode, const double2* v, int comp, double sign, void* out, int from_reduced) {
     (void)comp;
     hipLaunchKernelGGL(q1_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.nwg, c.reduced,

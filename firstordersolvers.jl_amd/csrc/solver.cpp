@@ -185,24 +185,12 @@ int poll_state(fos_solver* h) {
     return FOS_OK;
 }
 
-int kkt_apply_full(fos_solver* h, const LaunchCtx& c, const d2* w, d2* out, int mode, int gate, int j = 1) {
-    bool rec = h->prof && mode == 1 && h->ev_used + 2 <= fos_solver::EV_CAP;
-    if (rec) {
-        while (h->ev.size() < h->ev_used + 2) {
-            hipEvent_t e;
-            FOS_HIP(hipEventCreate(&e));
-            h->ev.push_back(e);
-        }
-        FOS_HIP(hipEventRecord(h->ev[h->ev_used], h->stream));
-    }
-    launch_kkt2(c, w, out, gate);
-    if (rec) {
-        FOS_HIP(hipEventRecord(h->ev[h->ev_used + 1], h->stream));
-        h->ev_used += 2;
-    }
+// out = [I Q'; Q -I] w, all l rows (sweep + tau-row finalize)
+int kkt_apply_full(fos_solver* h, const LaunchCtx& c, const d2* w, d2* out) {
+    launch_kkt2(c, w, out, 0);
     int fr = 0;
-    FOS_TRY(finish_reduce(h, c, c.S.nwg, 3, gate, &fr));
-    launch_kkt_finalize(c, w, out, mode, gate, fr, j);
+    FOS_TRY(finish_reduce(h, c, c.S.nwg, 3, 0, &fr));
+    launch_kkt_finalize(c, w, out, 0, fr);
     return FOS_OK;
 }
 
@@ -210,7 +198,7 @@ int kkt_apply_full(fos_solver* h, const LaunchCtx& c, const d2* w, d2* out, int 
 int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t* iters) {
     LaunchCtx c = h->ctx();
     int fr = 0;
-    FOS_TRY(kkt_apply_full(h, c, x, h->AP, 0, 0));                     // :32  mul!(Ap, A, x)
+    FOS_TRY(kkt_apply_full(h, c, x, h->AP));                           // :32  mul!(Ap, A, x)
     launch_cg_init(c, rhs, h->AP, h->R, h->P);                         // :33-34
     FOS_TRY(finish_reduce(h, c, c.vec_blocks, 1, 0, &fr));
     launch_cg_init_finalize(c, h->R, tol, maxit, fr);                  // :35-36
@@ -820,7 +808,7 @@ int fos_kkt_apply(fos_handle h, double* y, const double* x) {
     FOS_HIP(hipSetDevice(h->device));
     LaunchCtx c = h->ctx();
     FOS_TRY(upload_plain(h, h->W, x));
-    FOS_TRY(kkt_apply_full(h, c, h->W, h->AP, 0, 0));
+    FOS_TRY(kkt_apply_full(h, c, h->W, h->AP));
     return download_plain(h, y, h->AP);
 }
 

@@ -96,26 +96,7 @@ __global__ __launch_bounds__(FIN_THREADS) void cg_init_finalize_kernel(const dou
     }
 }
 
-// x += alpha p ; r -= alpha Ap ; partial r.r                          conjugategradients.jl:40-41,46
-__global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* __restrict__ x, d2* __restrict__ r,
-                                                                const d2* __restrict__ p, const d2* __restrict__ Ap,
-                                                                const DevState* st, double* __restrict__ partials) {
-    if (st->done) return;
-    const double alpha = st->alpha;
-    double acc[1] = {0.0};
-    for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
-        const d2 pi = p[i], ai = Ap[i];
-        d2 xi = x[i], ri = r[i];
-        xi.x += alpha * pi.x; xi.y += alpha * pi.y;
-        ri.x -= alpha * ai.x; ri.y -= alpha * ai.y;
-        x[i] = xi;
-        r[i] = ri;
-        if (i != l - 1) acc[0] += ri.x * ri.x + ri.y * ri.y;
-    }
-    block_reduce_store<1>(acc, partials + blockIdx.x);
-}
-
-// kkt_finalize(mode 1) + cg_update fused: EVERY workgroup reduces the 3 x nwg KKT partials in the same fixed order, finishes
+// alpha + x,r update in one launch: EVERY workgroup reduces the 3 x nwg KKT partials in the same fixed order, finishes
 // the tau rows of Ap = M p and alpha = rn / (Ap.p) itself (so no workgroup waits for another), then updates its slice:
 // x += alpha p ; r -= alpha Ap ; partial r.r.  Workgroup 0 stores Ap[tau], pAp and alpha.     conjugategradients.jl:39-41,46
 __global__ __launch_bounds__(VEC_THREADS) void cg_alpha_update_kernel(int64_t l, d2* __restrict__ x, d2* __restrict__ r,
@@ -157,46 +138,7 @@ void launch_cg_alpha_update(const LaunchCtx& c, double2* x, double2* r, const do
                        c.partials, c.S.nwg, c.reduced, from_reduced, j, c.partials + 3 * (size_t)16392);
 }
 
-// norm(r) <= tol || iter >= max_iters -> done ; else rnold = rn, rn = r.r, beta = rn/rnold, iter += 1    :42-51
-__global__ __launch_bounds__(FIN_THREADS) void cg_update_finalize_kernel(const double* __restrict__ partials, int count,
-                                                                         const double* __restrict__ reduced, int from_reduced,
-                                                                         const d2* __restrict__ r, int64_t l, DevState* st) {
-    if (st->done) return;
-    __shared__ double sums[1];
-    if (from_reduced) { if (threadIdx.x == 0) sums[0] = reduced[0]; __syncthreads(); }
-    else reduce_partials<1>(partials, count, sums);
-    if (threadIdx.x == 0) {
-        const d2 rt = r[l - 1];
-        const double rr = sums[0] + (rt.x * rt.x + rt.y * rt.y);
-        st->rr = rr;
-        const int iter = st->iter;
-        if (sqrt(rr) <= st->tol || iter >= st->maxit) {
-            st->done = 1;
-            st->hit_max = (iter == st->maxit) ? 1 : 0;      // :53
-        } else {
-            const double rnold = st->rn;
-            st->rn_old = rnold;
-            st->rn = rr;
-            st->beta = rr / rnold;
-            st->iter = iter + 1;
-        }
-    }
-}
-
-// p .*= beta ; p .+= r                                                conjugategradients.jl:49-50
-__global__ __launch_bounds__(VEC_THREADS) void cg_pupdate_kernel(int64_t l, d2* __restrict__ p, const d2* __restrict__ r, const DevState* st) {
-    if (st->done) return;
-    const double beta = st->beta;
-    for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
-        d2 pi = p[i];
-        const d2 ri = r[i];
-        pi.x = pi.x * beta + ri.x;
-        pi.y = pi.y * beta + ri.y;
-        p[i] = pi;
-    }
-}
-
-// cg_update_finalize + cg_pupdate fused: EVERY workgroup reduces the <= 1024 r.r partials in the same fixed order (so all
+// stop test + beta + p update in one launch: EVERY workgroup reduces the <= 1024 r.r partials in the same fixed order (so all
 // derive the same stop decision and beta), workgroup 0 stores the scalars.  `j` = the iteration this launch belongs
 // to if CG is still running (known at enqueue time).  A workgroup that starts after workgroup 0 has set `done` simply
 // exits: p is not needed once CG has stopped.                       conjugategradients.jl:42-51
@@ -247,16 +189,6 @@ void launch_cg_init(const LaunchCtx& c, const double2* rhs, const double2* Ap, d
 void launch_cg_init_finalize(const LaunchCtx& c, const double2* r, double tol, int maxit, int from_reduced) {
     hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.vec_blocks, c.reduced,
                        from_reduced, r, c.l, c.st, tol, maxit);
-}
-void launch_cg_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, const double2* Ap) {
-    hipLaunchKernelGGL(cg_update_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, r, p, Ap, c.st, c.partials);
-}
-void launch_cg_update_finalize(const LaunchCtx& c, const double2* r, int from_reduced) {
-    hipLaunchKernelGGL(cg_update_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.vec_blocks, c.reduced,
-                       from_reduced, r, c.l, c.st);
-}
-void launch_cg_pupdate(const LaunchCtx& c, double2* p, const double2* r) {
-    hipLaunchKernelGGL(cg_pupdate_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p, r, c.st);
 }
 
 // ------------------------------------------------------------------------------------------------ outer-loop passes
