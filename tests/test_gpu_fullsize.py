@@ -1,0 +1,113 @@
+"""
+Parity at BASELINE.json's FULL sizes through size-independent properties (the oracle needs minutes per iteration
+at these sizes): linearity / symmetry / skew-symmetry of the operators, idempotence and orthogonality of the
+projections, feasibility of the affine projection, and convergence of whole solves to the KNOWN optimum of the
+complementary-pair construction (workloads.py).  fp64; tolerances stated per check.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _operator_properties(d, rng, tol=1e-11):
+    l, N = d.l, d.N
+    x, y = rng.standard_normal(N), rng.standard_normal(N)
+    a, b = 0.7, -1.3
+    Mx, My = d.kkt_apply(x), d.kkt_apply(y)
+    # linearity of [I Q'; Q -I]
+    assert np.linalg.norm(d.kkt_apply(a * x + b * y) - (a * Mx + b * My)) <= tol * (np.linalg.norm(Mx) + np.linalg.norm(My))
+    # symmetry: x'My == y'Mx   (affinepluslinear.jl:52: transpose == self)
+    assert abs(x @ My - y @ Mx) <= tol * np.linalg.norm(x) * np.linalg.norm(My)
+    # Q is skew symmetric: u'Qu = 0 and Q' = -Q   (HSDEAffine.jl:61-65)
+    u = rng.standard_normal(l)
+    Qu = d.q_apply(u)
+    assert abs(u @ Qu) <= tol * np.linalg.norm(u) * np.linalg.norm(Qu)
+    assert np.array_equal(d.q_apply(u, transpose=True), -Qu)
+    # KKT apply is consistent with Q apply:  M [x1;x2] = [x1 - Q x2 ; Q x1 - x2]
+    x1, x2 = x[:l], x[l:]
+    ref = np.concatenate([x1 - d.q_apply(x2), d.q_apply(x1) - x2])
+    assert np.linalg.norm(Mx - ref) <= tol * np.linalg.norm(ref)
+
+
+def _projection_properties(d, rng):
+    z = rng.standard_normal(d.N)
+    p = d.prox_cones(z)
+    pp = d.prox_cones(p)
+    assert np.linalg.norm(pp - p) <= 1e-11 * np.linalg.norm(p)             # idempotent
+    assert abs((z - p) @ p) <= 1e-10 * np.linalg.norm(z) ** 2               # residual orthogonal to the projection (cone)
+    # affine projection: y = [u;v] with Qu = v (to the CG tolerance of the call) and z - y orthogonal to the subspace
+    tol = 0.2                                                               # first call of a fresh handle: 0.2^sqrt(1)
+    y = d.prox_affine(z)
+    u, v = y[:d.l], y[d.l:]
+    assert np.linalg.norm(d.q_apply(u) - v) <= 2 * tol
+    d.reset_affine()
+
+
+@pytest.fixture(scope="module")
+def c4(pkg):
+    prob = pkg.workloads.c4_block_sdp()
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    yield prob, d
+    d.close()
+
+
+def test_c4_operators_and_projections_full_size(pkg, c4):
+    prob, d = c4
+    assert (prob.m, prob.n, prob.nnz) == (1064960, 16384, 34078720)
+    rng = np.random.default_rng(0)
+    _operator_properties(d, rng)
+    _projection_properties(d, rng)
+
+
+def test_c4_dr_reaches_known_optimum(pkg, c4):
+    """512 x PSD(64) block SDP, DR(eps=1e-4): Optimal; objective and x against the known complementary optimum."""
+    prob, _ = c4
+    model = pkg.solve(prob, pkg.DR(eps=1e-4, max_iters=4000, verbose=0, checki=250))
+    assert model.status() == "Optimal"
+    opt = float(prob.c @ prob.x0)
+    assert model.getobjval() == pytest.approx(opt, rel=5e-3)
+    assert np.max(np.abs(model.getsolution() - prob.x0)) < 1e-3
+    last = model.status_obj.last
+    assert last.p <= 1e-4 * (1 + last.norm_b) and last.d <= 1e-4 * (1 + last.norm_c)
+    # primal feasibility of the returned point, checked on the host: b - A x in K1 (PSD blocks) up to the residual
+    s = prob.b - prob.A @ model.getsolution()
+    k = 64
+    dlen = k * (k + 1) // 2
+    blk = s[:dlen].copy()
+    M = np.zeros((k, k))
+    idx = 0
+    for j in range(k):
+        M[j:, j] = blk[idx:idx + k - j]
+        M[j + 1:, j] /= np.sqrt(2)
+        idx += k - j
+    M = np.tril(M) + np.tril(M, -1).T
+    assert np.linalg.eigvalsh(M).min() > -1e-3
+
+
+def test_c2_full_size_operators_and_progress(pkg):
+    """Dense 5000 x 10000 LP (all long run-rows): operator properties at full size; DR residuals decrease."""
+    prob = pkg.workloads.c2_lp()
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    assert prob.nnz == 5000 * 10000
+    rng = np.random.default_rng(1)
+    _operator_properties(d, rng)
+    _projection_properties(d, rng)
+    d.set_alg(pkg.DR())
+    d.set_iterate(None)
+    _, _, r1 = d.step(1, 100, 100, 1e-8)
+    _, _, r2 = d.step(101, 300, 400, 1e-8)
+    assert r2.p < r1.p and r2.d < r1.d and np.isfinite(r2.g)
+    d.close()
+
+
+def test_c3_full_size_gapa(pkg):
+    """Sparse SOCP (1000 x SOC(50), nnz ~ 1e6), GAPA: operator properties; reaches Optimal at eps=1e-4 near the known optimum."""
+    prob = pkg.workloads.c3_socp()
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    _operator_properties(d, np.random.default_rng(2))
+    _projection_properties(d, np.random.default_rng(3))
+    d.close()
+    model = pkg.solve(prob, pkg.GAPA(eps=1e-4, max_iters=6000, verbose=0, checki=250))
+    assert model.status() == "Optimal"
+    assert model.getobjval() == pytest.approx(float(prob.c @ prob.x0), rel=2e-2, abs=1e-3)
