@@ -38,7 +38,7 @@ __host__ __device__ inline int psd_ld(int k) {
     return ld;
 }
 
-__host__ inline size_t psd_lds_bytes(int k) { return (size_t)(16 + k * psd_ld(k) + 2 * k + 16) * sizeof(double); }
+__host__ inline size_t psd_lds_bytes(int k) { return (size_t)(32 + k * psd_ld(k) + 2 * k + 16) * sizeof(double); }
 
 __device__ __forceinline__ void idx_to_ij(int idx, int k, int& i, int& j) {
     // packed lower triangle, column-major: column j starts at S(j) = j k - j (j-1)/2
@@ -67,6 +67,16 @@ __device__ __forceinline__ double group8_sum(double v) {
     v += dpp_f64<0xB1>(v);         // quad_perm [1,0,3,2]
     return v;
 }
+__device__ __forceinline__ double group16_sum(double v) {
+    v = group8_sum(v);
+    v += dpp_f64<0x140>(v);        // row_mirror: the other half of the 16-lane row
+    return v;
+}
+__device__ __forceinline__ double group32_sum(double v) {
+    v = group16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    return v;
+}
 __device__ __forceinline__ double group_sum(double v, int tpp) {
     for (int off = tpp >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
@@ -84,8 +94,8 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 // ended with at the previous outer iteration (read from vin, the new basis is written to vout).  The iterates of the
 // solver change slowly, so V_prev nearly diagonalises the new matrix and 3-5 sweeps replace 9-10 (the convergence
 // test -- a full sweep without a rotation -- is unchanged, so accuracy does not depend on the start).  Orders <= 64.
-template <bool USE_LDS, bool WARM>
-__global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, const d2* __restrict__ in,
+template <bool USE_LDS, bool WARM, int THREADS>
+__global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, const d2* __restrict__ in,
                                                           const ConeDesc* __restrict__ cones,
                                                           double* __restrict__ gscratch, size_t scratch_stride,
                                                           const double* __restrict__ vin, double* __restrict__ vout,
@@ -101,15 +111,15 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
     double* __restrict__ y = reinterpret_cast<double*>(out + cd.start) + part;
 
     // all LDS comes from the one dynamic array (no static __shared__ in front of it: keeps its base 16-byte aligned)
-    double* red = smem;                          // [0..3] wave partials, [4] sigma
+    double* red = smem;                          // [0..15] wave partials, [16] sigma
     double* G;                                   // address space known at compile time: ds_* vs global_* accesses
-    if constexpr (USE_LDS) G = smem + 16;
+    if constexpr (USE_LDS) G = smem + 32;
     else G = gscratch + (size_t)blockIdx.x * scratch_stride;
     double* wgt = G + (size_t)k * ld;           // k eigen-weights
 
     // ---- load: M = smat(sgn x) with the diagonal scaled by sqrt(2)
     double fro = 0.0;
-    for (int idx = tid; idx < len; idx += PSD_THREADS) {
+    for (int idx = tid; idx < len; idx += THREADS) {
         int i, j;
         idx_to_ij(idx, k, i, j);
         double v = sgn * x[2 * (int64_t)idx];
@@ -122,26 +132,31 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
     if ((tid & 63) == 0) red[tid >> 6] = fro;
     __syncthreads();
     // WARM needs every shifted eigenvalue strictly positive (well defined column directions): sigma > |lambda_min|
-    if (tid == 0) red[4] = (WARM ? 1.001 : 0.505) * sqrt((red[0] + red[1]) + (red[2] + red[3]));
+    if (tid == 0) {
+        double f2 = 0.0;
+        for (int w = 0; w < THREADS / 64; ++w) f2 += red[w];
+        red[16] = (WARM ? 1.001 : 0.505) * sqrt(f2);
+    }
     __syncthreads();
-    const double sigma = red[4];
-    for (int i = tid; i < k; i += PSD_THREADS) G[i + (size_t)i * ld] += sigma;
+    const double sigma = red[16];
+    for (int i = tid; i < k; i += THREADS) G[i + (size_t)i * ld] += sigma;
     __syncthreads();
 
     if constexpr (WARM) {
         if (have_prev && sigma > 0.0) {
             // G0 = M' V_prev : thread (row i = lane, columns j = wave + 4 jj); M' rows from LDS, V_prev (wave-uniform) from L2
             const double* __restrict__ Vp = vin + (size_t)blockIdx.x * vstride;
+            constexpr int NW = THREADS / 64, NJ = 64 / NW;
             const int i = tid & 63, w = tid >> 6;
-            double acc[16];
+            double acc[NJ];
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) acc[jj] = 0.0;
+            for (int jj = 0; jj < NJ; ++jj) acc[jj] = 0.0;
             if (i < k) {
                 for (int t = 0; t < k; ++t) {
                     const double mv = G[i + (size_t)t * ld];
 #pragma unroll
-                    for (int jj = 0; jj < 16; ++jj) {
-                        const int j = w + 4 * jj;
+                    for (int jj = 0; jj < NJ; ++jj) {
+                        const int j = w + NW * jj;
                         if (j < k) acc[jj] += mv * Vp[t + (size_t)j * k];
                     }
                 }
@@ -149,8 +164,8 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
             __syncthreads();
             if (i < k) {
 #pragma unroll
-                for (int jj = 0; jj < 16; ++jj) {
-                    const int j = w + 4 * jj;
+                for (int jj = 0; jj < NJ; ++jj) {
+                    const int j = w + NW * jj;
                     if (j < k) G[i + (size_t)j * ld] = acc[jj];
                 }
             }
@@ -162,9 +177,9 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
     const int K = (k + 1) & ~1;               // even number of players (one bye when k is odd)
     const int npair = K >> 1;
     int tpp = 64;
-    while (tpp > 1 && npair * tpp > PSD_THREADS) tpp >>= 1;
+    while (tpp > 1 && npair * tpp > THREADS) tpp >>= 1;
     const int sh = 31 - __clz(tpp);
-    const int slot = tid >> sh, lig = tid & (tpp - 1), nslot = PSD_THREADS >> sh;
+    const int slot = tid >> sh, lig = tid & (tpp - 1), nslot = THREADS >> sh;
     const double tol = (double)k * 2.220446049250313e-16;
     const double tol2 = tol * tol;
 
@@ -185,6 +200,8 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
                         a += u * u; b += v * v; g += u * v;
                     }
                     if (tpp == 8) { a = group8_sum(a); b = group8_sum(b); g = group8_sum(g); }
+                    else if (tpp == 16) { a = group16_sum(a); b = group16_sum(b); g = group16_sum(g); }
+                    else if (tpp == 32) { a = group32_sum(a); b = group32_sum(b); g = group32_sum(g); }
                     else { a = group_sum(a, tpp); b = group_sum(b, tpp); g = group_sum(g, tpp); }
                     if (g * g <= tol2 * (a * b)) continue;
                     rotated = 1;
@@ -210,7 +227,7 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
 
     // ---- weights: kept columns have ||g_j|| > sigma ; P = sum_j wgt_j g_j g_j', wgt_j = (||g_j|| - sigma) / ||g_j||^2
     double* inv = wgt + k;                      // 1/||g_j|| (WARM: to store the new basis)
-    for (int j = tid; j < k; j += PSD_THREADS) {
+    for (int j = tid; j < k; j += THREADS) {
         double s = 0.0;
         const double* gj = G + (size_t)j * ld;
         for (int i = 0; i < k; ++i) s += gj[i] * gj[i];
@@ -222,7 +239,7 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
     if constexpr (WARM) {
         // new basis: v_j = g_j / ||g_j|| (identity column if the matrix was all zero)
         double* __restrict__ Vn = vout + (size_t)blockIdx.x * vstride;
-        for (int e = tid; e < k * k; e += PSD_THREADS) {
+        for (int e = tid; e < k * k; e += THREADS) {
             const int i = e % k, j = e / k;
             const double s = inv[j];
             Vn[e] = (sigma > 0.0 && s > 0.0) ? G[i + (size_t)j * ld] * s : (i == j ? 1.0 : 0.0);
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(PSD_THREADS) void psd_kernel(d2* __restrict__ out, 
     }
 
     // ---- rebuild the lower triangle, repack, unscale the diagonal; dual: y = x + P(-x)
-    for (int idx = tid; idx < len; idx += PSD_THREADS) {
+    for (int idx = tid; idx < len; idx += THREADS) {
         int i, j;
         idx_to_ij(idx, k, i, j);
         double s = 0.0;
@@ -258,21 +275,29 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     const size_t lds = psd_lds_bytes(kmax);
     const bool use_lds = lds <= 160 * 1024 - 256;
     const bool warm = vin && vout && kmax <= 64 && use_lds;
+    // few matrices (a shard of a multi-GPU run, a small problem): 1024 threads per matrix cut the latency of one
+    // projection; many matrices: 256 threads (4 per CU) maximise throughput
+    static int cus = 0;
+    if (!cus) { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; if (cus <= 0) cus = 256; }
+    const bool wide = warm && (2 * ncones <= 2 * cus) && !getenv("FOS_PSD_NARROW");
     static bool attr_set = false;
     if (use_lds && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, false, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(psd_kernel): %s", hipGetErrorString(e)); return FOS_EHIP; }
         attr_set = true;
     }
     const size_t stride = (size_t)(kmax * psd_ld(kmax) + 2 * kmax + 16);
     const size_t vstride = (size_t)kmax * kmax;
-    if (warm)
-        hipLaunchKernelGGL((psd_kernel<true, true>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev);
+    if (warm && wide)
+        hipLaunchKernelGGL((psd_kernel<true, true, 1024>), dim3(2 * ncones), dim3(1024), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev);
+    else if (warm)
+        hipLaunchKernelGGL((psd_kernel<true, true, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev);
     else if (use_lds)
-        hipLaunchKernelGGL((psd_kernel<true, false>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, nullptr, nullptr, vstride, 0);
+        hipLaunchKernelGGL((psd_kernel<true, false, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, nullptr, nullptr, vstride, 0);
     else
-        hipLaunchKernelGGL((psd_kernel<false, false>), dim3(2 * ncones), dim3(PSD_THREADS), 16 * sizeof(double), c.stream, out, in, cones, gscratch, stride, nullptr, nullptr, vstride, 0);
+        hipLaunchKernelGGL((psd_kernel<false, false, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), 32 * sizeof(double), c.stream, out, in, cones, gscratch, stride, nullptr, nullptr, vstride, 0);
     return FOS_OK;
 }
 
