@@ -159,7 +159,7 @@ void launch_axpby(const LaunchCtx& c, double2* out, double a, const double2* x, 
 void launch_relax_a12(const LaunchCtx& c, double2* out, const double2* y, const double2* x);                          // out = a12 y + (1-a12) x, a12 from state
 void launch_gap_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha, double alpha2);   // x = alpha(alpha2 t2+(1-alpha2)t1) + (1-alpha) x
 void launch_gapa_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha);           // + normedScalar partials
-void launch_gapa_finalize(const LaunchCtx& c, double beta, const double2* x_old_tau_unused, int from_reduced);
+void launch_gapa_finalize(const LaunchCtx& c, double beta, int from_reduced);
 void launch_fista_extrap(const LaunchCtx& c, double2* y, const double2* x, const double2* xold, double coef);         // y = x + coef (x - xold)
 void launch_add(const LaunchCtx& c, double2* out, const double2* a, const double2* b);                                // out = a + b
 void launch_dykstra_corr(const LaunchCtx& c, double2* p, const double2* x, const double2* y);                         // p = x + p - y

@@ -371,7 +371,7 @@ int step_finish(fos_solver* h) {
             launch_gapa_final(c, h->X, h->T2, h->T1, h->alpha);                    // gapa.jl:77,96,103
             int fr = 0;
             FOS_TRY(finish_reduce(h, c, c.vec_blocks, 3, 0, &fr));
-            launch_gapa_finalize(c, h->beta, nullptr, fr);                         // gapa.jl:96-101
+            launch_gapa_finalize(c, h->beta, fr);                                  // gapa.jl:96-101
             return FOS_OK;
         }
         case FOS_ALG_FISTA: {

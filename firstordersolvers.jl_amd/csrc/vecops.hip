@@ -298,7 +298,7 @@ void launch_gap_final(const LaunchCtx& c, double2* x, const double2* t2, const d
 void launch_gapa_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha) {
     hipLaunchKernelGGL(gapa_final_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, t2, t1, alpha, c.st, c.partials, c.reduced);
 }
-void launch_gapa_finalize(const LaunchCtx& c, double beta, const double2*, int from_reduced) {
+void launch_gapa_finalize(const LaunchCtx& c, double beta, int from_reduced) {
     hipLaunchKernelGGL(gapa_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.vec_blocks, c.reduced, from_reduced, beta, c.st);
 }
 void launch_fista_extrap(const LaunchCtx& c, double2* y, const double2* x, const double2* xold, double coef) {
