@@ -430,9 +430,8 @@ class FOSMathProgModel:
         debug = opts.get("debug", 1)
         eps = opts.get("eps", 1e-5)
         checki = opts.get("checki", 100)
-        dev = self.data
-        dev.set_alg(self.alg)                                      # a fresh *Data struct per solve (model.data persists S1)
-        dev.set_iterate(opts.get("initx", None))                   # :10
+        dev = self.data                                            # model.data persists across optimize! calls, as in the
+        dev.set_iterate(opts.get("initx", None))                   # reference (alpha12 / t / y / S1 counters carry over); :10
         status = HSDEStatus(self, checki, eps, verbose, debug, out=self.out)
         self.status_obj = status
         t1 = time.time()
