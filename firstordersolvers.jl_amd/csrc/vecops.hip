@@ -344,8 +344,9 @@ __device__ __forceinline__ double ew_apply(int op, double v) {
     switch (op) {
         case EW_COPY: return v;               // IndFree / dual of IndZero           cones.jl:98
         case EW_ZERO: return 0.0;             // IndZero / dual of IndFree (IndPoint) cones.jl:100
-        case EW_MAX0: return fmax(v, 0.0);    // IndNonnegative (self dual)           cones.jl:101 ; tau, kappa :138,141
-        default:      return fmin(v, 0.0);    // IndNonpositive                       cones.jl:102
+        // comparisons, not fmax/fmin: a NaN must stay a NaN as it does in the reference (Julia's max(NaN,0) is NaN)
+        case EW_MAX0: return v < 0.0 ? 0.0 : v;   // IndNonnegative (self dual)       cones.jl:101 ; tau, kappa :138,141
+        default:      return v > 0.0 ? 0.0 : v;   // IndNonpositive                   cones.jl:102
     }
 }
 // every index whose cone is Free/Zero/NonNeg/NonPos, plus the (tau,kappa) element; op byte: part1 | part2 << 2

@@ -1,0 +1,118 @@
+"""Edge cases through the C ABI: tiny and degenerate shapes, many small cones, one huge cone, zero operator,
+re-use of a handle across algorithms, checkpoint/resume of the affine state."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import fos_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _codes(cones):
+    return [(orc.CONE_CODES[k], l) for k, l in cones]
+
+
+def _cone_ref(K1, K2, z):
+    S2 = orc.DualConeProduct(orc.ConeProduct.from_lengths(_codes(K1)), orc.ConeProduct.from_lengths(_codes(K2)))
+    ref = np.empty_like(z)
+    S2.prox(ref, z)
+    return ref
+
+
+def test_one_by_one_and_zero_operator(pkg):
+    A = sp.csc_matrix(np.array([[2.0]]))
+    d = pkg.HipHSDE(A, np.array([1.0]), np.array([-1.0]), [("NonNeg", 1)], [("NonNeg", 1)])
+    z = np.arange(1.0, 7.0)
+    Q = orc.HSDEMatrixQ(A, np.array([1.0]), np.array([-1.0]))
+    ref = np.empty(6)
+    orc.KKTMatrix(Q).mul(ref, z)
+    assert np.allclose(d.kkt_apply(z), ref, rtol=1e-14)
+    d.close()
+    Z = sp.csc_matrix((5, 7))                       # no stored entries at all
+    d = pkg.HipHSDE(Z, np.ones(5), np.ones(7), [("Zero", 5)], [("Free", 7)])
+    x = np.random.default_rng(0).standard_normal(d.l)
+    Q = orc.HSDEMatrixQ(Z, np.ones(5), np.ones(7))
+    ref = np.empty(d.l)
+    Q.mul(ref, x)
+    assert np.allclose(d.q_apply(x), ref, rtol=1e-14, atol=1e-15)
+    d.close()
+
+
+def test_many_tiny_cones_and_one_huge_cone(pkg):
+    rng = np.random.default_rng(1)
+    # 3000 cones of 1..3 entries of every kind on the row side
+    kinds = ["Zero", "Free", "NonNeg", "NonPos", "SOC", "SDP", "SOCRotated", "ExpPrimal"]
+    K1 = []
+    for i in range(3000):
+        k = kinds[i % len(kinds)]
+        ln = {"SDP": [1, 3][i % 2], "SOCRotated": 2 + i % 2, "ExpPrimal": 3}.get(k, 1 + i % 3)
+        K1.append((k, ln))
+    m = sum(l for _, l in K1)
+    n = 40
+    A = sp.random(m, n, density=0.02, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    d = pkg.HipHSDE(A, rng.standard_normal(m), rng.standard_normal(n), K1, [("Free", n)])
+    z = rng.standard_normal(d.N)
+    assert np.linalg.norm(d.prox_cones(z) - _cone_ref(K1, [("Free", n)], z)) <= 1e-9 * np.linalg.norm(z)
+    d.close()
+    # one SOC with 300 000 entries (a single wavefront walks it) + a PSD cone of order 1
+    K1 = [("SOC", 300000), ("SDP", 1)]
+    m = 300001
+    A = sp.random(m, 3, density=1e-4, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    d = pkg.HipHSDE(A, np.zeros(m), np.zeros(3), K1, [("NonNeg", 3)])
+    z = rng.standard_normal(d.N)
+    assert np.linalg.norm(d.prox_cones(z) - _cone_ref(K1, [("NonNeg", 3)], z)) <= 1e-12 * np.linalg.norm(z)
+    d.close()
+
+
+def test_handle_reuse_across_algorithms_and_resume(pkg):
+    """A handle keeps S1's state (call counter, CG warm start) across solves like the reference's model does
+    (affinepluslinear.jl:66,114); fos_get/set_affine_state + fos_set_iterate resume a run bit for bit."""
+    prob = pkg.workloads.small_mixed()
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d.set_alg(pkg.DR())
+    d.set_iterate(None)
+    d.step(1, 40, 10 ** 9, 1e-8)
+    assert d.prox_count() == 41
+    z40 = d.get_iterate()
+    xinit, i, fr = d.get_affine_state()
+    assert i == 41 and not fr
+    d.step(41, 20, 10 ** 9, 1e-8)
+    z60 = d.get_iterate()
+    # resume from the checkpoint on a FRESH handle
+    e = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    e.set_alg(pkg.DR())
+    e.set_iterate(z40)
+    e.set_affine_state(xinit, i)
+    e.step(41, 20, 10 ** 9, 1e-8)
+    # identical up to the PSD warm-start basis (a fresh handle starts its Jacobi from the identity: ~1e-14 different
+    # projections, amplified by 20 iterations of the chaotic inexact-CG recurrence -- see test_gpu_parity.py)
+    assert np.linalg.norm(e.get_iterate() - z60) <= 1e-7 * np.linalg.norm(z60)
+    # switching the algorithm on a live handle keeps S1's counter
+    d.set_alg(pkg.GAPA(0.8, 0.5))
+    d.step(61, 5, 10 ** 9, 1e-8)
+    assert d.prox_count() == 66 and d.alpha12() != 2.0
+    d.set_alg(pkg.FISTA())
+    d.set_iterate(None)
+    done, checked, res = d.step(1, 10, 10, 1e-8)
+    assert done == 10 and checked and np.isfinite(res.p)
+    d.close()
+    e.close()
+
+
+def test_nan_input_propagates_like_the_reference(pkg):
+    """The reference never guards NaN: a NaN iterate stays NaN, CG runs to its 1000-iteration cap
+    (conjugategradients.jl:42: norm(NaN) <= tol is false) and the shim is told to warn."""
+    prob = pkg.workloads.small_lp()
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d.set_alg(pkg.DR())
+    z = np.zeros(d.N)
+    z[0] = np.nan
+    z[d.l - 1] = z[-1] = 1.0
+    d.set_iterate(z)
+    done, checked, res = d.step(1, 1, 1, 1e-8)
+    assert done == 1 and checked
+    assert d.cgiter() == 1000 and res.cg_maxiter_hit == 1
+    assert np.isnan(d.get_iterate()).any()
+    assert pkg.lib.STATUS_NAMES[res.status] == "Continue"
+    d.close()
