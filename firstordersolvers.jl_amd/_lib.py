@@ -71,6 +71,7 @@ PROTOTYPES = {
     "fos_profile_read": (C.c_int, [_h, _i64p, _dp, _dp]),
     "fos_bench_kkt": (C.c_int, [_h, C.c_int32, _dp]),
     "fos_sync": (C.c_int, [_h]),
+    "fos_host_stacked_spmv": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, C.c_int32, C.c_int32, _i64p]),
     "fos_set_tuning": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32]),
 }
 

@@ -284,4 +284,67 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     return FOS_OK;
 }
 
+// Host emulation of the device traversal (same block kinds, same lane/step mapping, same masking): out = S * v for the
+// stacked vector v = [vx(n); vy(m)].  Used by the CPU tests to validate the format construction without a GPU.
+int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::string* why) {
+    std::vector<int> seen(S.nrows, 0);
+    auto fail = [&](const char* msg, long long a) { if (why) *why = std::string(msg) + " " + std::to_string(a); return FOS_EINVAL; };
+    if ((int)S.wave_blk0.size() != S.nwaves + 1 || S.wave_blk0.front() != 0 || S.wave_blk0.back() != S.nblk) return fail("bad wave partition", S.nwaves);
+    for (int w = 0; w < S.nwaves; ++w) if (S.wave_blk0[w] > S.wave_blk0[w + 1]) return fail("wave partition not monotone at", w);
+    for (int b = 0; b < S.nblk; ++b) {
+        const BlkDesc& d = S.blk[b];
+        if (d.nnz0 % NNZ_ALIGN) return fail("block not aligned", b);
+        const int R = d.nrows();
+        if (d.kind() == BLK_LONG) {
+            const int64_t stride = (d.cnt + NNZ_ALIGN - 1) / NNZ_ALIGN * NNZ_ALIGN;
+            for (int i = 0; i < R; ++i) {
+                double acc = 0.0;
+                for (int64_t k = 0; k < d.cnt; ++k) {
+                    const int64_t c = d.run() ? (int64_t)S.col[d.colpos] + k : S.col[d.colpos + k];
+                    if (c < 0 || c >= S.nrows) return fail("column out of range in block", b);
+                    acc += S.val[d.nnz0 + i * stride + k] * v[c];
+                }
+                out[d.row0 + i] = acc;
+                seen[d.row0 + i]++;
+            }
+        } else if (d.kind() == BLK_ELL) {
+            int p2 = 1; while (p2 < R) p2 <<= 1;
+            const int tpr = 64 / p2, T = d.steps();
+            if (d.cnt != 64 * (int64_t)T) return fail("ELL count mismatch in block", b);
+            for (int i = 0; i < R; ++i) {
+                const int len = S.row_rel[d.row0 + i];
+                double acc = 0.0;
+                for (int lig = 0; lig < tpr; ++lig) {            // the lane sums, then the butterfly (any order on the host)
+                    for (int t = 0; t < T; ++t) {
+                        const int e = t * tpr + lig;
+                        if (e >= len) continue;
+                        const int64_t pos = (int64_t)t * 64 + i * tpr + lig;
+                        const int64_t c = d.run() ? (int64_t)S.col[d.colpos + i] + e : S.col[d.colpos + pos];
+                        if (c < 0 || c >= S.nrows) return fail("column out of range in block", b);
+                        acc += S.val[d.nnz0 + pos] * v[c];
+                    }
+                }
+                out[d.row0 + i] = acc;
+                seen[d.row0 + i]++;
+            }
+        } else {
+            if (d.cnt > WNNZ) return fail("LDS block too large", b);
+            for (int i = 0; i < R; ++i) {
+                const int s0 = S.row_rel[d.row0 + i];
+                const int e0 = (i + 1 < R) ? (int)S.row_rel[d.row0 + i + 1] : (int)d.cnt;
+                double acc = 0.0;
+                for (int k = s0; k < e0; ++k) {
+                    const int64_t c = S.col[d.colpos + k];
+                    if (c < 0 || c >= S.nrows) return fail("column out of range in block", b);
+                    acc += S.val[d.nnz0 + k] * v[c];
+                }
+                out[d.row0 + i] = acc;
+                seen[d.row0 + i]++;
+            }
+        }
+    }
+    for (int64_t r = 0; r < S.nrows; ++r) if (seen[r] != 1) return fail("row not covered exactly once:", r);
+    return FOS_OK;
+}
+
 }  // namespace fos

@@ -89,6 +89,7 @@ struct DevBlkCsr {
 int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
                       int nwg_target, HostBlkCsr* out, int resident_waves = 0);
 void partition_workgroups(HostBlkCsr* S, int nwg_target);
+int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::string* why);
 
 // ---------------------------------------------------------------------------------- device scalar state
 // One struct in device memory; kernels read/write it, the host polls a pinned copy.
@@ -130,6 +131,7 @@ struct LaunchCtx {
     double* partials;      // scratch for per-workgroup partial sums
     double* reduced;       // small buffer of locally reduced sums (all-reduced in place when sharded)
     int32_t vec_blocks;    // grid of the vector kernels
+    int32_t cg_blocks;     // grid of the two fused CG kernels (every workgroup re-reduces the partials: fewer, fatter groups)
 };
 
 // KKT apply, 2 RHS interleaved:  out = [I Q'; Q -I] * w   (rows 0..n+m-1; the tau row is written by kkt_finalize)

@@ -102,6 +102,7 @@ struct fos_solver {
     double* partials = nullptr;
     double* reduced = nullptr;                 // 16 doubles
     int vec_blocks = 0;
+    int cg_blocks = 0;
 
     // algorithm (gap.jl:6-21, gapa.jl:9-25, fista.jl:6-18, dykstra.jl:5-17)
     int alg = FOS_ALG_GAP;
@@ -132,7 +133,7 @@ struct fos_solver {
     LaunchCtx ctx() const {
         LaunchCtx c;
         c.stream = stream; c.S = S; c.cb = cb; c.n = n; c.m = m; c.l = l; c.st = st;
-        c.partials = partials; c.reduced = reduced; c.vec_blocks = vec_blocks;
+        c.partials = partials; c.reduced = reduced; c.vec_blocks = vec_blocks; c.cg_blocks = cg_blocks;
         return c;
     }
 };
@@ -220,7 +221,7 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
             if (h->comm) {                                             // sharded: reduce the r.r partials, all-reduce
                 LaunchCtx c2 = c;
                 c2.partials = c.partials + 3 * (size_t)16392;
-                launch_reduce1(c2, c.vec_blocks, 1, 1);
+                launch_reduce1(c2, c.cg_blocks, 1, 1);
                 FOS_TRY(allreduce(h, 1));
                 f2 = 1;
             }
@@ -562,6 +563,7 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
     }
     FOS_TRY(dev_alloc(h, &h->plain, 2 * l));
     h->vec_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((h->l + 255) / 256, 1024));
+    h->cg_blocks = std::min(h->vec_blocks, getenv("FOS_CG_BLOCKS") ? std::max(1, atoi(getenv("FOS_CG_BLOCKS"))) : 2 * cus);
 
     // ---- cones
     std::vector<uint8_t> ew(l, 0);
@@ -921,6 +923,26 @@ int fos_bench_kkt(fos_handle h, int32_t reps, double* total_ms) {
     if (total_ms) *total_ms = ms;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    return FOS_OK;
+}
+
+int fos_host_stacked_spmv(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                          const double* v, double* out, int32_t spmv_workgroups, int32_t resident_waves, int64_t* stats) {
+    if (!colptr || !v || !out || m < 0 || n < 0) { set_error("bad argument"); return FOS_EINVAL; }
+    HostBlkCsr S;
+    FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, spmv_workgroups > 0 ? spmv_workgroups : 1024, &S, resident_waves));
+    std::string why;
+    int rc = host_stacked_spmv(S, v, out, &why);
+    if (rc != FOS_OK) { set_error("operator format check failed: %s", why.c_str()); return rc; }
+    if (stats) {
+        int64_t nell = 0, nlds = 0, nlong = 0, nrun = 0;
+        for (const BlkDesc& d : S.blk) {
+            if (d.kind() == BLK_ELL) ++nell; else if (d.kind() == BLK_LDS) ++nlds; else ++nlong;
+            if (d.run()) ++nrun;
+        }
+        stats[0] = S.nblk; stats[1] = nell; stats[2] = nlds; stats[3] = nlong; stats[4] = nrun;
+        stats[5] = S.nnz_padded; stats[6] = S.ncol_stored; stats[7] = S.nwaves;
+    }
     return FOS_OK;
 }
 

@@ -182,6 +182,13 @@ int fos_profile_read(fos_handle h, int64_t* launches, double* total_ms, double* 
 int fos_bench_kkt(fos_handle h, int32_t reps, double* total_ms);
 int fos_sync(fos_handle h);
 
+/* Host-only self check of the device operator format (no GPU needed): builds the block format of
+ * S = [[0,A'],[A,0]] exactly as fos_create does and multiplies out = S * v on the HOST by walking the blocks the way the
+ * kernel does.  stats (8 x int64, may be NULL): blocks, ELL, LDS, LONG, run-compressed blocks, stored values, stored
+ * column indices, wavefronts.  Used by the CPU test-suite. */
+int fos_host_stacked_spmv(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                          const double* v, double* out, int32_t spmv_workgroups, int32_t resident_waves, int64_t* stats);
+
 /* tuning knobs (0 keeps the default): workgroups of the SpMV grid, CG iterations enqueued per host poll */
 int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int32_t use_graph);
 

@@ -1,0 +1,94 @@
+"""CPU test of the host logic that builds the device operator format (csr_build.cpp): the library's host emulation
+walks the row blocks exactly like the kernel (ELL lane-major / LDS / LONG, run-compressed or indexed) and must
+reproduce [A'vy; A vx]; every row must be covered exactly once.  No GPU needed."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+
+def host_spmv(pkg, A, v, wg=0, waves=0):
+    lib = pkg.lib.load()
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    m, n = A.shape
+    colptr = np.ascontiguousarray(A.indptr, dtype=np.int64) + 1
+    rowval = np.ascontiguousarray(A.indices, dtype=np.int64) + 1
+    nz = np.ascontiguousarray(A.data, dtype=np.float64)
+    out = np.empty(n + m)
+    stats = np.zeros(8, dtype=np.int64)
+    i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    pkg.lib.check(lib.fos_host_stacked_spmv(m, n, i64(colptr), i64(rowval), pkg.lib.dptr(nz), pkg.lib.dptr(v), pkg.lib.dptr(out),
+                                            wg, waves, i64(stats)))
+    return out, dict(zip(("blocks", "ell", "lds", "long", "run", "vals", "cols", "waves"), stats.tolist()))
+
+
+def reference(A, v):
+    A = sp.csc_matrix(A)
+    m, n = A.shape
+    return np.concatenate([A.T @ v[n:], A @ v[:n]])
+
+
+CASES = {
+    "dense-long-rows": lambda rng: sp.csc_matrix(rng.standard_normal((7, 5000))),
+    "dense-tall": lambda rng: sp.csc_matrix(rng.standard_normal((3000, 9))),
+    "block-diag-dense": lambda rng: sp.block_diag([rng.standard_normal((40, 6)) for _ in range(30)], format="csc"),
+    "sparse-random": lambda rng: sp.random(700, 900, density=0.01, format="csc", random_state=rng, data_rvs=rng.standard_normal),
+    "power-law-rows": lambda rng: sp.vstack([sp.random(1, 3000, density=d, format="csr", random_state=rng, data_rvs=rng.standard_normal)
+                                             for d in np.minimum(1.0, 1.0 / np.arange(1, 120))]).tocsc(),
+    "identity": lambda rng: sp.identity(777, format="csc"),
+    "banded": lambda rng: sp.diags([rng.standard_normal(500 - abs(k)) for k in (-2, -1, 0, 1, 2)], (-2, -1, 0, 1, 2), format="csc"),
+    "empty": lambda rng: sp.csc_matrix((13, 17)),
+    "one-entry": lambda rng: sp.csc_matrix(([3.5], ([4], [2])), shape=(9, 6)),
+    "mixed-run-and-indexed": lambda rng: sp.vstack([sp.csc_matrix(rng.standard_normal((20, 300))),
+                                                    sp.random(200, 300, density=0.05, format="csc", random_state=rng,
+                                                              data_rvs=rng.standard_normal)]).tocsc(),
+    "row-of-2048+": lambda rng: sp.csc_matrix(rng.standard_normal((2, 2049))),
+    "row-of-exactly-2048": lambda rng: sp.csc_matrix(rng.standard_normal((3, 2048))),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("waves", [0, 7168])
+def test_block_format_reproduces_spmv(pkg, name, waves):
+    rng = np.random.default_rng(sum(map(ord, name)))
+    A = CASES[name](rng)
+    m, n = A.shape
+    v = rng.standard_normal(n + m)
+    out, st = host_spmv(pkg, A, v, waves=waves)
+    ref = reference(A, v)
+    assert np.allclose(out, ref, rtol=1e-13, atol=1e-13), (name, st)
+    assert st["ell"] + st["lds"] + st["long"] == st["blocks"]
+    if name in ("dense-long-rows", "dense-tall", "block-diag-dense", "identity", "banded", "row-of-2048+"):
+        assert st["run"] == st["blocks"] - st["lds"], st   # consecutive columns everywhere -> index-compressed (LDS blocks never are)
+    if name in ("dense-long-rows", "dense-tall", "block-diag-dense"):
+        assert st["cols"] < max(64, st["vals"] // 4), st   # one first-column per row instead of one index per entry
+    if name == "sparse-random":
+        assert st["run"] < st["blocks"]
+
+
+def test_partition_sizes(pkg):
+    rng = np.random.default_rng(0)
+    A = sp.random(5000, 3000, density=0.004, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    v = rng.standard_normal(8000)
+    for wg in (1, 8, 64, 1024, 4096):
+        out, st = host_spmv(pkg, A, v, wg=wg)
+        assert np.allclose(out, reference(A, v), rtol=1e-13, atol=1e-13)
+        assert st["waves"] % 4 == 0 and st["waves"] >= 4
+
+
+def test_malformed_csc_is_rejected(pkg):
+    lib = pkg.lib.load()
+    i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    v = np.zeros(5)
+    out = np.zeros(5)
+    nz = np.array([1.0, 2.0])
+    bad = [
+        (np.array([0, 1, 2], dtype=np.int64), np.array([1, 2], dtype=np.int64)),      # 0-based colptr
+        (np.array([1, 3, 2], dtype=np.int64), np.array([1, 2], dtype=np.int64)),      # not monotone
+        (np.array([1, 2, 3], dtype=np.int64), np.array([1, 9], dtype=np.int64)),      # row index out of range
+    ]
+    for colptr, rowval in bad:
+        rc = lib.fos_host_stacked_spmv(3, 2, i64(colptr), i64(rowval), pkg.lib.dptr(nz), pkg.lib.dptr(v), pkg.lib.dptr(out), 0, 0, None)
+        assert rc == -1
