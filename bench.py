@@ -97,6 +97,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
+    reduction = "in-stream RCCL all-reduce"
     force_dist = os.environ.get("FOS_FORCE_DIST") == "1"      # exercise the distributed path with one rank (testing)
     if world > 1 or force_dist:
         import torch.distributed as dist
@@ -117,6 +118,27 @@ def main():
             idt.copy_(torch.frombuffer(bytearray(pkg.HipHSDE.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
         dev.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
+        # scalar sums: peer mailboxes (one xGMI write latency per exchange) when every rank's self test passes,
+        # otherwise the in-stream RCCL all-reduce set up above.  FOS_REDUCTION=rccl|peer|auto (default auto).
+        want = os.environ.get("FOS_REDUCTION", "auto")
+        if want != "rccl":
+            try:
+                handles = [None] * world
+                dist.all_gather_object(handles, dev.peer_export())
+                dev.peer_open(world, rank, handles, timeout_s=20.0)
+                dev.sync()
+                dist.barrier()
+                ok = dev.peer_selftest(64)
+            except Exception as exc:                      # IPC not available between these devices
+                print("rank %d: peer mailboxes unavailable (%s)" % (rank, exc), file=sys.stderr, flush=True)
+                ok = False
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                dev.peer_enable(True)
+                reduction = "peer mailboxes over xGMI (HIP IPC)"
+            elif want == "peer":
+                raise SystemExit("FOS_REDUCTION=peer but the mailbox self test failed")
     if args.spmv_wg:
         dev.set_tuning(spmv_workgroups=args.spmv_wg)
     dev.set_alg(alg)
@@ -190,7 +212,7 @@ def main():
             "solver": type(alg).__name__,
             "local_m": int(prob.m), "local_n": int(prob.n), "local_nnz": int(prob.nnz),
             "cg_iters_per_step": round(launches / max(1, args.steps), 2),
-            "parallelism": "cone-sharded x%d (scalar RCCL all-reduce)" % world if world > 1 else "single GPU",
+            "parallelism": "cone-sharded x%d (scalar sums: %s)" % (world, reduction) if dist is not None else "single GPU",
             "residuals_after_run": {"p": chk.p, "d": chk.d, "g": chk.g, "iteration": it},
             "setup_s": round(t_setup, 2), "generate_s": round(t_gen, 2),
         },
@@ -252,6 +274,11 @@ def main():
                 "gpu_cg_iters_same_step": dev.cgiter(),
             }
             out["cpu_baseline"] = cpu
+    if dist is not None:
+        # librccl prints its version banner through C stdio, which a pipe buffers until exit: flush it now so the
+        # JSON line below is the last thing on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
     if rank == 0:
         print(json.dumps(out), flush=True)
     dev.close()

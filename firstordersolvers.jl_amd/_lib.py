@@ -48,6 +48,10 @@ PROTOTYPES = {
     "fos_sizes": (C.c_int, [_h, _i64p, _i64p, _i64p, _i64p]),
     "fos_comm_get_unique_id": (C.c_int, [C.c_void_p]),
     "fos_comm_init": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
+    "fos_peer_export": (C.c_int, [_h, C.c_void_p]),
+    "fos_peer_open": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p, C.c_double]),
+    "fos_peer_selftest": (C.c_int, [_h, C.c_int, C.POINTER(C.c_int32)]),
+    "fos_peer_enable": (C.c_int, [_h, C.c_int32]),
     "fos_set_alg": (C.c_int, [_h, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
     "fos_reset_affine": (C.c_int, [_h]),
     "fos_set_iterate": (C.c_int, [_h, _dp]),

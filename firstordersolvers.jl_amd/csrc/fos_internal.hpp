@@ -99,6 +99,8 @@ struct DevState {
     double rn2[2];         // r.r ping-pong: CG iteration j reads rn2[j&1] and writes rn2[(j+1)&1] (lets every workgroup of the
                            // fused finalize+p-update kernel derive beta itself without racing the one that stores it)
     int32_t iter, done, maxit, hit_max;
+    int32_t xchg_failed;   // a peer-mailbox exchange timed out (PeerBox below); every later exchange is skipped
+    int32_t pad0;
     // algorithm scalars
     double alpha12;        // GAPAData.alpha12 (gapa.jl:29,101)
     double gapa_scl;       // last normedScalar value (diagnostic)
@@ -121,6 +123,24 @@ struct ConeDesc {          // a SOC / rotated SOC / PSD cone in stacked index sp
     int32_t type;          // FOS_CONE_*
 };
 
+// ---------------------------------------------------------------------------------- peer mailboxes (sharded scalar sums)
+// All-reduce of <= PEER_MAX_VALS doubles over <= PEER_MAX_RANKS GPUs without a collective library: every rank owns a
+// mailbox in UNCACHED device memory that its peers map through HIP IPC.  An exchange (inside reduce_kernel) stores the
+// rank's local sums into every peer's mailbox and polls its own until all ranks' words of this exchange have arrived,
+// then adds them in rank order -- bitwise the same result on every rank.  Every 64-bit word carries its own validity:
+//   word = (sequence number << 32) | 32 payload bits         (two words per double; 8-byte stores are single-copy atomic)
+// so no fence or separate flag is needed.  Layout: [parity 2][source rank][value][half]; the parity of the sequence
+// number selects the half a given exchange uses (a rank can be at most one exchange ahead of a peer).
+constexpr int PEER_MAX_RANKS = 16;
+constexpr int PEER_MAX_VALS = 8;
+constexpr size_t PEER_BOX_WORDS = (size_t)2 * PEER_MAX_RANKS * PEER_MAX_VALS * 2;
+struct PeerBox {
+    unsigned long long* const* box;   // device table [nranks]: box[r] = mailbox of rank r (own entry: the local allocation)
+    uint32_t* seq;                    // device counter of EXECUTED exchanges (gated no-op launches do not count)
+    int32_t nranks, rank;
+    int64_t timeout_ticks;            // wall_clock64() ticks (100 MHz) an exchange may wait for its peers
+};
+
 // ---------------------------------------------------------------------------------- kernel launchers (kernels.hip / psd.hip)
 struct LaunchCtx {
     hipStream_t stream;
@@ -132,6 +152,7 @@ struct LaunchCtx {
     double* reduced;       // small buffer of locally reduced sums (all-reduced in place when sharded)
     int32_t vec_blocks;    // grid of the vector kernels
     int32_t cg_blocks;     // grid of the two fused CG kernels (every workgroup re-reduces the partials: fewer, fatter groups)
+    const PeerBox* peer;   // non-null: launch_reduce1 also exchanges the sums with the peer ranks (no RCCL call follows)
 };
 
 // KKT apply, 2 RHS interleaved:  out = [I Q'; Q -I] * w   (rows 0..n+m-1; the tau row is written by kkt_finalize)
@@ -154,7 +175,7 @@ void launch_cg_init_finalize(const LaunchCtx& c, const double2* r, double tol, i
 void launch_cg_finalize_pupdate(const LaunchCtx& c, double2* p, const double2* r, int from_reduced, int j);
 // tau rows of Ap, alpha = rn/(Ap.p), x += alpha p, r -= alpha Ap in one launch; its r.r partials go to partials + 3*16392
 void launch_cg_alpha_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, double2* Ap, int from_reduced, int j);
-void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate);   // partials[count x nacc] -> reduced[nacc]
+void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate);   // partials[count x nacc] -> reduced[nacc] (+ peer exchange)
 
 // outer-loop vector kernels (gap.jl:48,58,78; gapa.jl:67,77,96-103; fista.jl:31-46; dykstra.jl)
 void launch_axpby(const LaunchCtx& c, double2* out, double a, const double2* x, double b, const double2* y);          // out = a x + b y

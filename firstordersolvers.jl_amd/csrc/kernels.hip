@@ -427,10 +427,13 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
 
 constexpr int FIN_THREADS = 1024;
 
-// generic: partials[count][nacc] -> reduced[nacc]   (sharded path: the all-reduce runs on `reduced`)
+// generic: partials[count][nacc] -> reduced[nacc]; sharded path: the all-reduce then runs on `reduced` (RCCL), or --
+// PEER -- this kernel itself exchanges the sums with the peer ranks through their mailboxes (fos_internal.hpp, PeerBox)
+template <bool PEER>
 __global__ __launch_bounds__(FIN_THREADS) void reduce_kernel(const double* __restrict__ partials, int count, int nacc,
-                                                             double* __restrict__ reduced, const DevState* st, int gate) {
+                                                             double* __restrict__ reduced, DevState* st, int gate, PeerBox pb) {
     if (gate && st->done) return;
+    if (PEER && st->xchg_failed) return;
     __shared__ double sums[8];
     __shared__ double smem[16 * 8];
     // nacc <= 8; instantiate by value
@@ -440,7 +443,48 @@ __global__ __launch_bounds__(FIN_THREADS) void reduce_kernel(const double* __res
         case 6: reduce_partials<6>(partials, count, sums, smem); break;
         default: return;
     }
-    if ((int)threadIdx.x < nacc) reduced[threadIdx.x] = sums[threadIdx.x];
+    if constexpr (!PEER) {
+        if ((int)threadIdx.x < nacc) reduced[threadIdx.x] = sums[threadIdx.x];
+    } else {
+        __shared__ uint32_t halves[PEER_MAX_RANKS * PEER_MAX_VALS * 2];
+        __shared__ int failed;
+        const int t = threadIdx.x;
+        if (t == 0) failed = 0;
+        __syncthreads();
+        const uint32_t seq = *pb.seq + 1u;                 // this exchange (same number on every rank)
+        const size_t par = (size_t)(seq & 1u) * PEER_MAX_RANKS;
+        if (t < pb.nranks * nacc * 2) {                    // thread = (peer rank r, value v, half hh)
+            const int hh = t & 1, v = (t >> 1) % nacc, r = (t >> 1) / nacc;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(sums[v]);
+            const unsigned long long word = ((unsigned long long)seq << 32) | (hh ? (bits >> 32) : (bits & 0xFFFFFFFFull));
+            unsigned long long* dst = pb.box[r] + ((par + pb.rank) * PEER_MAX_VALS + v) * 2 + hh;
+            __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long* src = pb.box[pb.rank] + ((par + r) * PEER_MAX_VALS + v) * 2 + hh;
+            const long long t0 = wall_clock64();
+            unsigned long long w;
+            bool ok;
+            do {
+                w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ok = (uint32_t)(w >> 32) == seq;
+            } while (!ok && (wall_clock64() - t0) < pb.timeout_ticks);
+            if (!ok) failed = 1;
+            halves[(r * PEER_MAX_VALS + v) * 2 + hh] = (uint32_t)w;
+        }
+        __syncthreads();
+        if (failed) {                                      // a peer never arrived: stop the solve, the host reports it
+            if (t == 0) { st->xchg_failed = 1; st->done = 1; }
+            return;
+        }
+        if (t < nacc) {
+            double s = 0.0;
+            for (int r = 0; r < pb.nranks; ++r) {          // rank order: every rank computes the same bits
+                const unsigned long long lo = halves[(r * PEER_MAX_VALS + t) * 2], hi = halves[(r * PEER_MAX_VALS + t) * 2 + 1];
+                s += __longlong_as_double((long long)((hi << 32) | lo));
+            }
+            reduced[t] = s;
+        }
+        if (t == 0) *pb.seq = seq;
+    }
 }
 
 // tau rows of out = M w from the sweep's partials (the CG iteration does this inside cg_alpha_update_kernel)
@@ -470,7 +514,10 @@ void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
                        (int)(c.n + c.m), c.partials, c.st, gate);
 }
 void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate) {
-    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, count, nacc, c.reduced, c.st, gate);
+    if (c.peer)
+        hipLaunchKernelGGL(reduce_kernel<true>, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, count, nacc, c.reduced, c.st, gate, *c.peer);
+    else
+        hipLaunchKernelGGL(reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, count, nacc, c.reduced, c.st, gate, PeerBox{});
 }
 void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int gate, int from_reduced) {
     hipLaunchKernelGGL(kkt_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.nwg, c.reduced,

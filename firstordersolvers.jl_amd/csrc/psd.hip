@@ -90,6 +90,67 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return y;
 }
 
+template <int TPP>
+__device__ __forceinline__ double groupc_sum(double v) {
+    if constexpr (TPP == 8) return group8_sum(v);
+    else if constexpr (TPP == 16) return group16_sum(v);
+    else return group32_sum(v);
+}
+
+// A sweep whose largest rotated pair had cos^2(angle between the columns) <= JACOBI_SMALL2 leaves, by the quadratic
+// convergence of the cyclic method, every pair below the rotation threshold: the sweep that would only confirm it
+// (no rotation, but all the dot products) is skipped.  The resulting error in the projection is O(cos^2 |l_i - l_j|),
+// below the O(k eps ||M||) of the rotation threshold itself.
+constexpr double JACOBI_SMALL2 = 1e-16;
+
+// One-sided Jacobi on a 64 x 64 array: THREADS / TPP == 32 pair slots, one pair per slot and step; the 64 / TPP
+// elements a lane owns of the two columns stay in registers between the dot products and the rotation, and the
+// round-robin partner indices advance by one (mod 63) per step -- no division, no LDS re-read.
+template <int THREADS, int TPP>
+__device__ __forceinline__ void jacobi64(double* __restrict__ G, const int ld, const int tid, const double tol2) {
+    static_assert(THREADS / TPP == 32, "one column pair per slot");
+    constexpr int EPL = 64 / TPP;
+    const int pr = tid / TPP, lig = tid % TPP;
+    int p = pr, q = 63 - pr;                      // step 0: pr = 0 plays (0, 63); pr >= 1 plays (pr, 63 - pr)
+    for (int sweep = 0; sweep < PSD_MAX_SWEEPS; ++sweep) {
+        int rotated = 0, big = 0;
+        for (int step = 0; step < 63; ++step) {
+            double* gp = G + (size_t)p * ld + lig;
+            double* gq = G + (size_t)q * ld + lig;
+            double u[EPL], v[EPL];
+            double a = 0.0, b = 0.0, g = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                u[e] = gp[e * TPP]; v[e] = gq[e * TPP];
+                a += u[e] * u[e]; b += v[e] * v[e]; g += u[e] * v[e];
+            }
+            a = groupc_sum<TPP>(a); b = groupc_sum<TPP>(b); g = groupc_sum<TPP>(g);
+            const double gg = g * g, ab = a * b;
+            if (gg > tol2 * ab) {
+                rotated = 1;
+                if (gg > JACOBI_SMALL2 * ab) big = 1;
+                const double d = b - a;
+                const double rh = fast_rsqrt(d * d + 4.0 * gg);
+                const double c2 = 0.5 + 0.5 * fabs(d) * rh;
+                const double rc = fast_rsqrt(c2);
+                const double cs = c2 * rc;
+                const double sn = copysign(g * rh * rc, d * g);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    gp[e * TPP] = cs * u[e] - sn * v[e];
+                    gq[e * TPP] = sn * u[e] + cs * v[e];
+                }
+            }
+            // next step of the tournament: player 63 stays, the others move one seat
+            p = (p + 1 == 63) ? 0 : p + 1;
+            if (pr != 0) q = (q + 1 == 63) ? 0 : q + 1;
+            __syncthreads();
+        }
+        if (!__syncthreads_or(rotated)) break;
+        if (!__syncthreads_or(big)) break;
+    }
+}
+
 // WARM: start the Jacobi iteration from G0 = (M + sigma I) V_prev, V_prev = the eigenvector basis this (cone, copy)
 // ended with at the previous outer iteration (read from vin, the new basis is written to vout).  The iterates of the
 // solver change slowly, so V_prev nearly diagonalises the new matrix and 3-5 sweeps replace 9-10 (the convergence
@@ -147,7 +208,7 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
             // G0 = M' V_prev : thread (row i = lane, columns j = wave + 4 jj); M' rows from LDS, V_prev (wave-uniform) from L2
             const double* __restrict__ Vp = vin + (size_t)blockIdx.x * vstride;
             constexpr int NW = THREADS / 64, NJ = 64 / NW;
-            const int i = tid & 63, w = tid >> 6;
+            const int i = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: V_prev by scalar loads
             double acc[NJ];
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) acc[jj] = 0.0;
@@ -183,14 +244,16 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
     const double tol = (double)k * 2.220446049250313e-16;
     const double tol2 = tol * tol;
 
-    if (k > 1 && sigma > 0.0) {
+    if (k == 64 && sigma > 0.0) {
+        jacobi64<THREADS, THREADS / 32>(G, ld, tid, tol2);
+    } else if (k > 1 && sigma > 0.0) {
         for (int sweep = 0; sweep < PSD_MAX_SWEEPS; ++sweep) {
-            int rotated = 0;
+            int rotated = 0, big = 0;
             for (int step = 0; step < K - 1; ++step) {
                 for (int pr = slot; pr < npair; pr += nslot) {
                     int p, q;
-                    if (pr == 0) { p = step % (K - 1); q = K - 1; }
-                    else { p = (step + pr) % (K - 1); q = (step + (K - 1) - pr) % (K - 1); }
+                    if (pr == 0) { p = step; q = K - 1; }           // step < K-1 ; the sums below are < 2 (K-1)
+                    else { p = step + pr; if (p >= K - 1) p -= K - 1; q = step + (K - 1) - pr; if (q >= K - 1) q -= K - 1; }
                     if (p >= k || q >= k) continue;       // bye (uniform within the lane group)
                     double* gp = G + (size_t)p * ld;
                     double* gq = G + (size_t)q * ld;
@@ -205,6 +268,7 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
                     else { a = group_sum(a, tpp); b = group_sum(b, tpp); g = group_sum(g, tpp); }
                     if (g * g <= tol2 * (a * b)) continue;
                     rotated = 1;
+                    if (g * g > JACOBI_SMALL2 * (a * b)) big = 1;
                     // rotation that makes the two columns orthogonal: tan(2 theta) = 2g / (b - a), |theta| <= pi/4
                     //   h = sqrt(d^2 + 4 g^2), cos^2 = (1 + |d|/h)/2, sin = sign(d) g / (h cos)
                     const double d = b - a;
@@ -222,6 +286,7 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
                 __syncthreads();
             }
             if (!__syncthreads_or(rotated)) break;
+            if (!__syncthreads_or(big)) break;
         }
     }
 
@@ -284,13 +349,17 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     if (use_lds && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, false, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(psd_kernel): %s", hipGetErrorString(e)); return FOS_EHIP; }
         attr_set = true;
     }
     const size_t stride = (size_t)(kmax * psd_ld(kmax) + 2 * kmax + 16);
     const size_t vstride = (size_t)kmax * kmax;
-    if (warm && wide)
+    static const int wide_threads = getenv("FOS_PSD_THREADS") ? atoi(getenv("FOS_PSD_THREADS")) : 1024;
+    if (warm && wide && wide_threads == 512)
+        hipLaunchKernelGGL((psd_kernel<true, true, 512>), dim3(2 * ncones), dim3(512), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev);
+    else if (warm && wide && wide_threads == 1024)
         hipLaunchKernelGGL((psd_kernel<true, true, 1024>), dim3(2 * ncones), dim3(1024), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev);
     else if (warm)
         hipLaunchKernelGGL((psd_kernel<true, true, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev);

@@ -78,6 +78,7 @@ struct fos_solver {
     std::vector<void*> owned;                  // every hipMalloc'd pointer
     double* cb = nullptr;
     double nb = 0.0, nc = 0.0;                 // ||b||, ||c|| (global)
+    double nb_local = 0.0, nc_local = 0.0;     // this shard's ||b||, ||c||
 
     // vectors: l double2 each
     d2 *X = nullptr, *T1 = nullptr, *T2 = nullptr;          // iterate, tmp1, tmp2
@@ -118,9 +119,14 @@ struct fos_solver {
     int last_cg_pred = 0;
     const d2* last_checked = nullptr;          // vector the last checkstatus was evaluated on
 
-    // sharding
+    // sharding: scalar sums cross GPUs either by an in-stream RCCL all-reduce (comm) or through peer mailboxes (peer_on)
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
+    unsigned long long* peer_mbox = nullptr;   // own mailbox (uncached device memory, exported through HIP IPC)
+    std::vector<void*> peer_opened;            // IPC mappings of the peers' mailboxes
+    PeerBox peer{};
+    bool peer_on = false;
+    bool sharded() const { return comm != nullptr || peer_on; }
 
     // tuning / measurement
     int cg_chunk = 8;
@@ -134,6 +140,7 @@ struct fos_solver {
         LaunchCtx c;
         c.stream = stream; c.S = S; c.cb = cb; c.n = n; c.m = m; c.l = l; c.st = st;
         c.partials = partials; c.reduced = reduced; c.vec_blocks = vec_blocks; c.cg_blocks = cg_blocks;
+        c.peer = peer_on ? &peer : nullptr;
         return c;
     }
 };
@@ -166,14 +173,14 @@ int psd_order(int64_t len) {
 
 // all-reduce of `count` doubles in h->reduced (in place, in stream) when sharded
 int allreduce(fos_solver* h, int count) {
-    if (!h->comm) return FOS_OK;
+    if (h->peer_on || !h->comm) return FOS_OK;                 // peer mailboxes: launch_reduce1 already exchanged
     FOS_NCCL(g_rccl.AllReduce(h->reduced, h->reduced, (size_t)count, ncclDouble, ncclSum, h->comm, h->stream));
     return FOS_OK;
 }
 
 // partials[count][nacc] --(sharded: local reduce + all-reduce)--> returns from_reduced flag for the finalize kernel
 int finish_reduce(fos_solver* h, const LaunchCtx& c, int count, int nacc, int gate, int* from_reduced) {
-    if (!h->comm) { *from_reduced = 0; return FOS_OK; }
+    if (!h->sharded()) { *from_reduced = 0; return FOS_OK; }
     launch_reduce1(c, count, nacc, gate);
     FOS_TRY(allreduce(h, nacc));
     *from_reduced = 1;
@@ -183,6 +190,25 @@ int finish_reduce(fos_solver* h, const LaunchCtx& c, int count, int nacc, int ga
 int poll_state(fos_solver* h) {
     FOS_HIP(hipMemcpyAsync(h->st_host, h->st, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
     FOS_HIP(hipStreamSynchronize(h->stream));
+    if (h->st_host->xchg_failed) {
+        set_error("rank %d: a peer-mailbox exchange timed out (a peer rank stopped or is not running the same call sequence)", h->rank);
+        return FOS_ECOMM;
+    }
+    return FOS_OK;
+}
+
+// sharded set-up: global problem size and norms (tolerance floor, status normalisation) from the shards'
+int global_setup(fos_solver* h) {
+    LaunchCtx c = h->ctx();
+    double loc[3] = {(double)(h->n + h->m), h->nb_local * h->nb_local, h->nc_local * h->nc_local};
+    FOS_HIP(hipMemcpyAsync(h->partials, loc, sizeof(loc), hipMemcpyHostToDevice, h->stream));
+    launch_reduce1(c, 1, 3, 0);
+    FOS_TRY(allreduce(h, 3));
+    FOS_HIP(hipMemcpyAsync(loc, h->reduced, sizeof(loc), hipMemcpyDeviceToHost, h->stream));
+    FOS_TRY(poll_state(h));
+    h->l_global = (int64_t)std::llround(loc[0]) + 1;
+    h->nb = std::sqrt(loc[1]);
+    h->nc = std::sqrt(loc[2]);
     return FOS_OK;
 }
 
@@ -218,7 +244,7 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
             FOS_TRY(finish_reduce(h, c, c.S.nwg, 3, 1, &f1));
             launch_cg_alpha_update(c, x, h->R, h->P, h->AP, f1, next_j);   // :39-41,46
             int f2 = 0;
-            if (h->comm) {                                             // sharded: reduce the r.r partials, all-reduce
+            if (h->sharded()) {                                        // sharded: reduce the r.r partials, all-reduce
                 LaunchCtx c2 = c;
                 c2.partials = c.partials + 3 * (size_t)16392;
                 launch_reduce1(c2, c.cg_blocks, 1, 1);
@@ -552,6 +578,7 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
     for (int64_t j = 0; j < n; ++j) nc2 += c[j] * c[j];
     for (int64_t i = 0; i < m; ++i) nb2 += b[i] * b[i];
     h->nb = std::sqrt(nb2); h->nc = std::sqrt(nc2);
+    h->nb_local = h->nb; h->nc_local = h->nc;
     FOS_TRY(dev_upload(h, &h->cb, cbv));
 
     // ---- vectors
@@ -609,6 +636,7 @@ int fos_destroy(fos_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    for (void* q : h->peer_opened) (void)hipIpcCloseMemHandle(q);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (void* p : h->owned) (void)hipFree(p);
     if (h->st_host) (void)hipHostFree(h->st_host);
@@ -643,15 +671,113 @@ int fos_comm_init(fos_handle h, int nranks, int rank, const void* id128) {
     memcpy(&id, id128, sizeof(id));
     FOS_NCCL(g_rccl.CommInitRank(&h->comm, nranks, id, rank));
     h->nranks = nranks; h->rank = rank;
-    // global size and norms: all-reduce [n+m, ||b||^2, ||c||^2]
-    double loc[3] = {(double)(h->n + h->m), h->nb * h->nb, h->nc * h->nc};
-    FOS_HIP(hipMemcpyAsync(h->reduced, loc, sizeof(loc), hipMemcpyHostToDevice, h->stream));
-    FOS_TRY(allreduce(h, 3));
-    FOS_HIP(hipMemcpyAsync(loc, h->reduced, sizeof(loc), hipMemcpyDeviceToHost, h->stream));
+    return global_setup(h);            // all-reduce [n+m, ||b||^2, ||c||^2]
+}
+
+// ---- peer mailboxes: the sharded scalar sums without a collective library (fos_internal.hpp, PeerBox)
+int fos_peer_export(fos_handle h, void* handle64) {
+    if (!h || !handle64) { set_error("NULL argument"); return FOS_EINVAL; }
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    FOS_HIP(hipSetDevice(h->device));
+    if (!h->peer_mbox) {
+        void* q = nullptr;
+        const size_t bytes = PEER_BOX_WORDS * sizeof(unsigned long long);
+        hipError_t e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained); }
+        if (e != hipSuccess) { set_error("hipExtMallocWithFlags(mailbox): %s", hipGetErrorString(e)); return FOS_ENOMEM; }
+        h->owned.push_back(q);
+        FOS_HIP(hipMemset(q, 0, bytes));                         // sequence number 0 is never sent
+        h->peer_mbox = reinterpret_cast<unsigned long long*>(q);
+    }
+    hipIpcMemHandle_t ipc;
+    FOS_HIP(hipIpcGetMemHandle(&ipc, h->peer_mbox));
+    memcpy(handle64, &ipc, sizeof(ipc));
+    return FOS_OK;
+}
+
+int fos_peer_open(fos_handle h, int nranks, int rank, const void* handles, double timeout_s) {
+    if (!h || !handles || nranks < 1 || nranks > PEER_MAX_RANKS || rank < 0 || rank >= nranks) {
+        set_error("bad peer arguments (1 <= nranks <= %d)", PEER_MAX_RANKS); return FOS_EINVAL;
+    }
+    if (!h->peer_mbox) { set_error("fos_peer_open before fos_peer_export"); return FOS_EINVAL; }
+    if (!h->peer_opened.empty() || h->peer.box) { set_error("peer mailboxes are already open"); return FOS_EINVAL; }
+    if (h->comm && (h->nranks != nranks || h->rank != rank)) { set_error("peer ranks differ from the RCCL communicator's"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    std::vector<unsigned long long*> tab((size_t)nranks, nullptr);
+    for (int r = 0; r < nranks; ++r) {
+        if (r == rank) { tab[r] = h->peer_mbox; continue; }
+        hipIpcMemHandle_t ipc;
+        memcpy(&ipc, (const char*)handles + (size_t)r * sizeof(ipc), sizeof(ipc));
+        void* q = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&q, ipc, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            for (void* o : h->peer_opened) (void)hipIpcCloseMemHandle(o);
+            h->peer_opened.clear();
+            set_error("hipIpcOpenMemHandle(mailbox of rank %d): %s", r, hipGetErrorString(e));
+            return FOS_ECOMM;
+        }
+        h->peer_opened.push_back(q);
+        tab[r] = reinterpret_cast<unsigned long long*>(q);
+    }
+    unsigned long long** dtab = nullptr;
+    FOS_TRY(dev_upload(h, &dtab, tab));
+    uint32_t* seq = nullptr;
+    FOS_TRY(dev_alloc(h, &seq, 1));
+    FOS_HIP(hipMemset(seq, 0, sizeof(uint32_t)));
+    h->peer.box = dtab; h->peer.seq = seq; h->peer.nranks = nranks; h->peer.rank = rank;
+    h->peer.timeout_ticks = (int64_t)((timeout_s > 0 ? timeout_s : 20.0) * 1e8);
+    h->nranks = nranks; h->rank = rank;
+    return FOS_OK;
+}
+
+// `rounds` exchanges of known values, checked exactly; *ok = 0 on a mismatch or a time-out (the handle then keeps
+// whatever reduction it had: RCCL if fos_comm_init was called).  Collective: every rank calls it with the same rounds.
+int fos_peer_selftest(fos_handle h, int rounds, int32_t* ok) {
+    if (!h || !ok) { set_error("NULL argument"); return FOS_EINVAL; }
+    if (!h->peer.box) { set_error("fos_peer_selftest before fos_peer_open"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    const bool was_on = h->peer_on;
+    h->peer_on = true;
+    LaunchCtx c = h->ctx();
+    h->peer_on = was_on;
+    *ok = 1;
+    auto val = [](int r, int k, int a) { return (a == 0) ? (double)(r + 1) * (k + 1) : (a == 1 ? 0.1 * (r + 1) + 1e-3 * k : -1.0 / (r + 1 + k)); };
+    for (int k = 0; k < rounds && *ok; ++k) {
+        const int nacc = (k % 3 == 0) ? 3 : (k % 3 == 1 ? 1 : 6);
+        double loc[6], got[6];
+        for (int a = 0; a < nacc; ++a) loc[a] = val(h->peer.rank, k, a % 3) + a;
+        FOS_HIP(hipMemcpyAsync(h->partials, loc, sizeof(double) * nacc, hipMemcpyHostToDevice, h->stream));
+        launch_reduce1(c, 1, nacc, 0);
+        FOS_HIP(hipMemcpyAsync(got, h->reduced, sizeof(double) * nacc, hipMemcpyDeviceToHost, h->stream));
+        FOS_HIP(hipMemcpyAsync(h->st_host, h->st, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
+        FOS_HIP(hipStreamSynchronize(h->stream));
+        if (h->st_host->xchg_failed) { *ok = 0; break; }
+        for (int a = 0; a < nacc; ++a) {
+            double s = 0.0;
+            for (int r = 0; r < h->peer.nranks; ++r) s += val(r, k, a % 3) + a;
+            if (s != got[a]) *ok = 0;
+        }
+    }
+    if (h->st_host->xchg_failed) {              // leave the handle usable with its previous reduction
+        DevState z;
+        FOS_HIP(hipMemcpy(&z, h->st, sizeof(DevState), hipMemcpyDeviceToHost));
+        z.xchg_failed = 0; z.done = 0;
+        FOS_HIP(hipMemcpy(h->st, &z, sizeof(DevState), hipMemcpyHostToDevice));
+        h->st_host->xchg_failed = 0;
+    }
+    return FOS_OK;
+}
+
+// switch the sharded sums to the peer mailboxes (collective: all ranks make the same choice after the self test)
+int fos_peer_enable(fos_handle h, int32_t on) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    if (on && !h->peer.box) { set_error("fos_peer_enable before fos_peer_open"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
     FOS_HIP(hipStreamSynchronize(h->stream));
-    h->l_global = (int64_t)std::llround(loc[0]) + 1;
-    h->nb = std::sqrt(loc[1]);
-    h->nc = std::sqrt(loc[2]);
+    h->peer_on = on != 0;
+    if (h->sharded()) return global_setup(h);
+    h->l_global = h->l; h->nb = h->nb_local; h->nc = h->nc_local;
     return FOS_OK;
 }
 

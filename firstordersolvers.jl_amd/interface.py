@@ -292,6 +292,27 @@ class HipHSDE:
         buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
         _lib.check(self._lib.fos_comm_init(self._h, nranks, rank, buf))
 
+    # -- peer mailboxes: the sharded sums without a collective call (include/foship.h, fos_peer_*)
+    def peer_export(self) -> bytes:
+        buf = (C.c_ubyte * 64)()
+        _lib.check(self._lib.fos_peer_export(self._h, buf))
+        return bytes(buf)
+
+    def peer_open(self, nranks, rank, handles, timeout_s=0.0):
+        """handles: the peer_export() bytes of every rank, in rank order."""
+        blob = b"".join(handles)
+        assert len(blob) == 64 * nranks
+        buf = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
+        _lib.check(self._lib.fos_peer_open(self._h, nranks, rank, buf, float(timeout_s)))
+
+    def peer_selftest(self, rounds=32) -> bool:
+        ok = C.c_int32(0)
+        _lib.check(self._lib.fos_peer_selftest(self._h, rounds, C.byref(ok)))
+        return bool(ok.value)
+
+    def peer_enable(self, on=True):
+        _lib.check(self._lib.fos_peer_enable(self._h, 1 if on else 0))
+
 
 # ---------------------------------------------------------------------------------------------- status
 

@@ -113,6 +113,24 @@ int fos_sizes(fos_handle h, int64_t* m, int64_t* n, int64_t* N, int64_t* nnz);
 int fos_comm_get_unique_id(void* id128);
 int fos_comm_init(fos_handle h, int nranks, int rank, const void* id128);
 
+/* Peer mailboxes: the same scalar sums WITHOUT a collective call in the stream.  Every rank owns a mailbox in
+ * uncached device memory that its peers map through HIP IPC; the kernel that reduces a rank's partial sums stores
+ * them into every peer's mailbox, waits for the peers' words (each 8-byte word carries its sequence number) and
+ * adds them in rank order -- the same bits on every rank, ~one xGMI write latency instead of a library
+ * all-reduce per CG inner product (conjugategradients.jl:39,46).  Ranks may be processes on different GPUs of one
+ * node (or, for tests, on the same GPU).  Protocol (all collective, the host moves the 64-byte handles):
+ *   fos_peer_export(h, handle64)                     -> allocate the mailbox, get its hipIpcMemHandle_t
+ *   fos_peer_open(h, nranks, rank, handles, timeout) -> handles = nranks x 64 bytes in rank order (own entry ignored);
+ *                                                       timeout_s <= 0: 20 s; nranks <= 16
+ *   fos_peer_selftest(h, rounds, &ok)                -> exchanges of known values checked exactly; ok = 0 on mismatch/time-out
+ *   fos_peer_enable(h, on)                           -> use the mailboxes (on = 0: back to RCCL if fos_comm_init was
+ *                                                       called, else single GPU); recomputes the global size / norms
+ * An exchange that waits longer than the time-out stops the solve with FOS_ECOMM (never a hang). */
+int fos_peer_export(fos_handle h, void* handle64);
+int fos_peer_open(fos_handle h, int nranks, int rank, const void* handles, double timeout_s);
+int fos_peer_selftest(fos_handle h, int rounds, int32_t* ok);
+int fos_peer_enable(fos_handle h, int32_t on);
+
 /* ---- algorithm state: replaces init_algorithm!(alg, model) data structs ---------------------------
  * fos_set_alg: GAP/GAPA/FISTA/Dykstra constructor arguments (gap.jl:13, gapa.jl:15, fista.jl:11) and a
  *   fresh *Data struct (gap.jl:23-28, gapa.jl:27-32: alpha12 = 2.0, fista.jl:20-25: t = 1, y = xold = 0,
