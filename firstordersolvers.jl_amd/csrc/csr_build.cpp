@@ -46,7 +46,7 @@ void partition_workgroups(HostBlkCsr* S, int nwg_target) {
     // cost of a block: its non-zeros plus a per-row term for the epilogue and a fixed per-block term
     std::vector<double> cost(nblk + 1, 0.0);
     for (int b = 0; b < nblk; ++b)
-        cost[b + 1] = cost[b] + double(S->blk[b].cnt) * (S->blk[b].kind() == BLK_LONG ? S->blk[b].nrows() : 1) + 4.0 * double(S->blk[b].nrows()) + 32.0;
+        cost[b + 1] = cost[b] + double(S->blk[b].cnt) * (S->blk[b].kind() == BLK_LONG ? S->blk[b].nrows() : (S->blk[b].kind() == BLK_TILE ? 1.5 : 1.0)) + 4.0 * double(S->blk[b].nrows()) + 32.0;
     const double total = cost[nblk];
     S->wave_blk0.assign(nwaves + 1, 0);
     int b = 0;
@@ -74,46 +74,100 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         if (rowval[k] < 1 || rowval[k] > m) { set_error("rowval[%lld] = %lld out of 1..m", (long long)k + 1, (long long)rowval[k]); return FOS_EINVAL; }
 
     const int64_t nrows = n + m;
-    // ---- plain CSR of S: row pointers
-    std::vector<int64_t> rp(nrows + 1, 0);
-    for (int64_t j = 0; j < n; ++j) rp[j + 1] = colptr[j + 1] - colptr[j];          // A' rows = A columns
-    for (int64_t k = 0; k < nnz; ++k) rp[n + rowval[k]] += 1;                       // A rows (rowval 1-based -> n + (r-1) + 1)
-    for (int64_t r = 0; r < nrows; ++r) rp[r + 1] += rp[r];
-    if (rp[nrows] != 2 * nnz) { set_error("internal: stacked nnz mismatch"); return FOS_EINVAL; }
+    const bool compress = getenv("FOS_NO_INDEX_COMPRESSION") == nullptr;
+    const bool tiles_on = compress && getenv("FOS_NO_TILES") == nullptr;
 
-    // ---- which rows have consecutive column indices ("runs": dense blocks, banded rows) -> index compression
+    // ---- rows of A: length, first column, and whether the columns are consecutive ("run": dense blocks, banded rows)
     std::vector<uint8_t> is_run(nrows, 1);
     std::vector<int32_t> first_col(nrows, 0);
-    for (int64_t j = 0; j < n; ++j) {                       // A' rows: the row indices of column j of A
-        const int64_t k0 = colptr[j] - 1, k1 = colptr[j + 1] - 1;
-        if (k1 > k0) first_col[j] = (int32_t)(n + rowval[k0] - 1);
-        for (int64_t k = k0 + 1; k < k1; ++k)
-            if (rowval[k] != rowval[k - 1] + 1) { is_run[j] = 0; break; }
-    }
+    std::vector<int64_t> alen(m, 0);
     {
         std::vector<int64_t> last(m, -1);
-        for (int64_t j = 0; j < n; ++j) {                   // A rows: columns arrive in ascending order
+        for (int64_t j = 0; j < n; ++j) {                   // columns arrive in ascending order
             for (int64_t k = colptr[j] - 1; k < colptr[j + 1] - 1; ++k) {
                 const int64_t i = rowval[k] - 1;
                 if (last[i] < 0) first_col[n + i] = (int32_t)j;
                 else if (last[i] != j - 1) is_run[n + i] = 0;
                 last[i] = j;
+                alen[i] += 1;
             }
         }
     }
 
-    // ---- row blocks
+    // ---- dual tiles: groups of <= 64 consecutive rows of A that are the same run of columns (fos_internal.hpp, BLK_TILE)
+    struct Group { int64_t i0; int R; int32_t c0; int64_t C; int nchunk; int64_t first_tile; };
+    std::vector<Group> groups;
+    std::vector<int32_t> tile_of(m, -1);
+    if (tiles_on) {
+        int64_t i = 0;
+        while (i < m) {
+            if (!is_run[n + i] || alen[i] < TILE_MIN_COLS) { ++i; continue; }
+            int64_t j = i + 1;
+            while (j < m && j - i < WROWS && is_run[n + j] && alen[j] == alen[i] && first_col[n + j] == first_col[n + i]) ++j;
+            // worth it only if the lane-major tile (64 lanes x padded steps) stores no more than the two copies it replaces
+            const int64_t nch = (alen[i] + TILE_TC_MAX - 1) / TILE_TC_MAX;
+            const int64_t steps = (alen[i] - (nch - 1) * TILE_TC_MAX + TILE_GROUP - 1) / TILE_GROUP * TILE_GROUP + (nch - 1) * TILE_TC_MAX;
+            if (j - i >= TILE_MIN_ROWS && 64 * steps <= 2 * (j - i) * alen[i]) {
+                Group g;
+                g.i0 = i; g.R = (int)(j - i); g.c0 = first_col[n + i]; g.C = alen[i];
+                g.nchunk = (int)((g.C + TILE_TC_MAX - 1) / TILE_TC_MAX);
+                g.first_tile = 0;
+                for (int64_t q = i; q < j; ++q) tile_of[q] = (int32_t)groups.size();
+                groups.push_back(g);
+            }
+            i = j;
+        }
+    }
+    const bool have_tiles = !groups.empty();
+
+    // ---- plain CSR of what the sweep still stores: rows of A' lose the entries that tiles cover, tile rows of A vanish
+    std::vector<int64_t> rp(nrows + 1, 0);
+    for (int64_t j = 0; j < n; ++j) {                       // A' rows = A columns: first column / run-ness of what remains
+        int64_t cnt = 0, prev = -1;
+        for (int64_t k = colptr[j] - 1; k < colptr[j + 1] - 1; ++k) {
+            const int64_t i = rowval[k] - 1;
+            if (tile_of[i] >= 0) continue;
+            if (cnt == 0) first_col[j] = (int32_t)(n + i);
+            else if (i != prev + 1) is_run[j] = 0;
+            prev = i;
+            ++cnt;
+        }
+        rp[j + 1] = cnt;
+    }
+    for (int64_t i = 0; i < m; ++i) rp[n + i + 1] = tile_of[i] >= 0 ? 0 : alen[i];
+    for (int64_t r = 0; r < nrows; ++r) rp[r + 1] += rp[r];
+
+    // ---- deferred rows: columns of A that tiles cover, rows of A whose tiles are split into column chunks
     HostBlkCsr& S = *out;
     S = HostBlkCsr();
     S.nrows = nrows;
     S.nnz = 2 * nnz;
+    std::vector<int32_t> ndef_slots;                        // per row: slots it will sum (0: not deferred)
+    std::vector<uint8_t> skip(nrows, 0);                    // rows the ordinary row blocks do not contain
+    if (have_tiles) {
+        S.row_defer.assign(nrows, -1);
+        ndef_slots.assign(nrows, 0);
+        for (const Group& g : groups) {
+            for (int64_t c = g.c0; c < g.c0 + g.C; ++c) ndef_slots[c] += 1;
+            for (int q = 0; q < g.R; ++q) {
+                skip[n + g.i0 + q] = 1;
+                if (g.nchunk > 1) { ndef_slots[n + g.i0 + q] = g.nchunk; S.row_defer[n + g.i0 + q] = -2; }
+            }
+        }
+        for (int64_t j = 0; j < n; ++j) {
+            if (ndef_slots[j] == 0) continue;
+            if (rp[j + 1] == rp[j]) { S.row_defer[j] = -2; skip[j] = 1; }
+            else { S.row_defer[j] = 0; ndef_slots[j] += 1; }      // slot number assigned below
+        }
+    }
+
+    // ---- row blocks
     S.row_rel.assign(nrows, 0);
     // where the e-th entry of row r goes: ELL rows (tpr > 0): base + (e / tpr) * 64 + lane0 + e % tpr ; else base + e
     std::vector<int64_t> row_base(nrows, 0), row_cbase(nrows, -1);      // value position / column position (-1: run block)
     std::vector<uint8_t> row_tpr(nrows, 0), row_lane0(nrows, 0);
     auto nextpow2 = [](int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; };
     auto align = [](int64_t v) { return (v + NNZ_ALIGN - 1) / NNZ_ALIGN * NNZ_ALIGN; };
-    const bool compress = getenv("FOS_NO_INDEX_COMPRESSION") == nullptr;
     // lane-major (ELL) blocks are accepted while padded <= cnt * (1 + slack) + 32.  Irregular sparse rows are bound by the
     // latency of their random 16-byte gathers, not by HBM: measured on C5 (sprandn, ~20/row) a 60 %-padded ELL block
     // beats the LDS-staged path by 27 %, so up to 2x padding is accepted
@@ -127,16 +181,46 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         ell_cap = std::max<int64_t>(256, std::min<int64_t>(ELL_MAX, ell_cap));
     }
     if (getenv("FOS_ELL_CAP")) ell_cap = std::max(64, atoi(getenv("FOS_ELL_CAP")) / 64 * 64);
+    struct TileRec { int32_t blk; int32_t group; int32_t chunk; int32_t tpad; int32_t cslot, rslot; };
+    std::vector<TileRec> tiles;
     int64_t pos = 0, cpos = 0;
     int64_t r = 0;
     while (r < nrows) {
+        if (r >= n && tile_of[r - n] >= 0) {
+            // ---- the tile blocks of this group of rows, one per chunk of TILE_TC_MAX columns
+            Group& g = groups[tile_of[r - n]];
+            g.first_tile = (int64_t)tiles.size();
+            for (int k = 0; k < g.nchunk; ++k) {
+                const int64_t tc = std::min<int64_t>(TILE_TC_MAX, g.C - (int64_t)k * TILE_TC_MAX);
+                const int64_t tpad = (tc + TILE_GROUP - 1) / TILE_GROUP * TILE_GROUP;
+                BlkDesc d;
+                d.nnz0 = align(pos);
+                d.colpos = align(cpos);
+                d.cnt = 64 * tpad;
+                d.row0 = (int32_t)r;
+                d.info = (int32_t)g.R | (BLK_TILE << 8) | (1 << 10) | ((int32_t)tpad << 16);
+                TileRec t;
+                t.blk = (int32_t)S.blk.size(); t.group = tile_of[r - n]; t.chunk = k; t.tpad = (int32_t)tpad;
+                t.cslot = (int32_t)S.nslots; S.nslots += tpad;
+                t.rslot = -1;
+                if (g.nchunk > 1) { t.rslot = (int32_t)S.nslots; S.nslots += g.R; }
+                tiles.push_back(t);
+                S.blk.push_back(d);
+                pos = d.nnz0 + d.cnt;
+                cpos = d.colpos + 4;                // first column, column-slot base, row-slot base, real columns
+                S.tile_values += (int64_t)g.R * tc;
+            }
+            r += g.R;
+            continue;
+        }
+        if (skip[r]) { ++r; continue; }
         const int64_t r0 = r;
         const int64_t len0 = rp[r + 1] - rp[r];
         const int64_t blk_start = align(pos), col_start = align(cpos);
         const bool run0 = compress && is_run[r];
-        // a block is homogeneous in run-ness; its rows end where the flag flips
+        // a block is homogeneous in run-ness; its rows end where the flag flips (or at a row the sweep does not contain)
         int64_t r_lim = r;
-        while (r_lim < nrows && (r_lim - r0) < WROWS && (compress && is_run[r_lim]) == run0) ++r_lim;
+        while (r_lim < nrows && (r_lim - r0) < WROWS && !skip[r_lim] && (compress && is_run[r_lim]) == run0) ++r_lim;
         BlkDesc d;
         d.nnz0 = blk_start;
         d.colpos = col_start;
@@ -244,58 +328,137 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         cpos = col_start + ncol_used;
     }
     S.nblk = (int32_t)S.blk.size();
+    S.ntiles = (int64_t)tiles.size();
     S.nnz_padded = std::max<int64_t>(align(pos), NNZ_ALIGN);
     S.ncol_stored = std::max<int64_t>(align(cpos), NNZ_ALIGN);
 
     S.val.assign(S.nnz_padded, 0.0);
     S.col.assign(S.ncol_stored, 0);
-    // run blocks: one first-column per row
+    // run blocks: one first-column per row; tile blocks: first column of the chunk and the slot bases
     for (const BlkDesc& d : S.blk) {
-        if (!d.run()) continue;
+        if (!d.run() || d.kind() == BLK_TILE) continue;
         for (int i = 0; i < d.nrows(); ++i) S.col[d.colpos + i] = first_col[d.row0 + i];
+    }
+    for (const TileRec& t : tiles) {
+        const BlkDesc& d = S.blk[t.blk];
+        S.col[d.colpos] = groups[t.group].c0 + t.chunk * TILE_TC_MAX;
+        S.col[d.colpos + 1] = t.cslot;
+        S.col[d.colpos + 2] = t.rslot;
+        S.col[d.colpos + 3] = (int32_t)std::min<int64_t>(TILE_TC_MAX, groups[t.group].C - (int64_t)t.chunk * TILE_TC_MAX);
     }
     auto place = [&](int64_t row, int64_t e) -> int64_t {        // offset of entry e of `row` relative to its block base
         const int64_t tpr = row_tpr[row];
         if (tpr == 0) return e;
         return (e / tpr) * 64 + row_lane0[row] + (e % tpr);
     };
-    // ---- fill A' rows (row j of S = column j of A, entries already sorted by row index)
+    // ---- fill A' rows (row j of S = column j of A, entries already sorted by row index), minus what tiles cover
     for (int64_t j = 0; j < n; ++j) {
         int64_t e = 0;
-        for (int64_t k = colptr[j] - 1; k < colptr[j + 1] - 1; ++k, ++e) {
+        for (int64_t k = colptr[j] - 1; k < colptr[j + 1] - 1; ++k) {
+            if (tile_of[rowval[k] - 1] >= 0) continue;
             const int64_t off = place(j, e);
             S.val[row_base[j] + off] = nzval[k];
             if (row_cbase[j] >= 0) S.col[row_cbase[j] + off] = (int32_t)(n + rowval[k] - 1);
+            ++e;
         }
     }
-    // ---- fill A rows by a counting transpose (column order inside each row = ascending column index)
+    // ---- fill A rows by a counting transpose (column order inside each row = ascending column index); tile rows go
+    //      lane-major into their tile: value (row i0 + lane, column c0 + chunk * TILE_TC_MAX + t) at nnz0 + 64 t + lane
     {
         std::vector<int64_t> fill(m, 0);
         for (int64_t j = 0; j < n; ++j) {
             for (int64_t k = colptr[j] - 1; k < colptr[j + 1] - 1; ++k) {
                 const int64_t i = rowval[k] - 1;
+                if (tile_of[i] >= 0) {
+                    const Group& g = groups[tile_of[i]];
+                    const int64_t cc = j - g.c0;
+                    const TileRec& t = tiles[g.first_tile + cc / TILE_TC_MAX];
+                    S.val[S.blk[t.blk].nnz0 + (cc % TILE_TC_MAX) * 64 + (i - g.i0)] = nzval[k];
+                    continue;
+                }
                 const int64_t off = place(n + i, fill[i]++);
                 S.val[row_base[n + i] + off] = nzval[k];
                 if (row_cbase[n + i] >= 0) S.col[row_cbase[n + i] + off] = (int32_t)j;
             }
         }
     }
+    // ---- slot lists of the deferred rows: [own partial from the sweep] + tile partials in block order
+    if (have_tiles) {
+        for (int64_t j = 0; j < n; ++j)
+            if (S.row_defer[j] == 0) S.row_defer[j] = (int32_t)S.nslots++;
+        if (S.nslots > (int64_t)INT32_MAX / 4) { set_error("too many partial slots"); return FOS_EUNSUPPORTED; }
+        std::vector<int64_t> lp(nrows + 1, 0);
+        for (int64_t q = 0; q < nrows; ++q) lp[q + 1] = lp[q] + ndef_slots[q];
+        std::vector<int32_t> idx(lp[nrows], 0);
+        std::vector<int64_t> cur(lp.begin(), lp.end() - 1);
+        for (int64_t j = 0; j < n; ++j)
+            if (S.row_defer[j] >= 0) idx[cur[j]++] = S.row_defer[j];
+        for (const TileRec& t : tiles) {
+            const Group& g = groups[t.group];
+            const int64_t cc0 = g.c0 + (int64_t)t.chunk * TILE_TC_MAX;
+            const int64_t tc = std::min<int64_t>(TILE_TC_MAX, g.C - (int64_t)t.chunk * TILE_TC_MAX);
+            for (int64_t c = 0; c < tc; ++c) idx[cur[cc0 + c]++] = t.cslot + (int32_t)c;
+            if (t.rslot >= 0)
+                for (int q = 0; q < g.R; ++q) idx[cur[n + g.i0 + q]++] = t.rslot + q;
+        }
+        S.def_ptr.push_back(0);
+        for (int64_t q = 0; q < nrows; ++q) {
+            if (ndef_slots[q] == 0) continue;
+            if (cur[q] != lp[q + 1]) { set_error("internal: slot list of row %lld incomplete", (long long)q); return FOS_EINVAL; }
+            S.def_rows.push_back((int32_t)q);
+            S.def_idx.insert(S.def_idx.end(), idx.begin() + lp[q], idx.begin() + lp[q + 1]);
+            S.def_ptr.push_back((int32_t)S.def_idx.size());
+        }
+    }
     partition_workgroups(&S, nwg_target);
     return FOS_OK;
 }
 
-// Host emulation of the device traversal (same block kinds, same lane/step mapping, same masking): out = S * v for the
-// stacked vector v = [vx(n); vy(m)].  Used by the CPU tests to validate the format construction without a GPU.
+// Host emulation of the device traversal (same block kinds, same lane/step mapping, same masking, same slot lists):
+// out = S * v for the stacked vector v = [vx(n); vy(m)].  Used by the CPU tests to validate the format construction
+// without a GPU.
 int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::string* why) {
-    std::vector<int> seen(S.nrows, 0);
+    std::vector<int> seen(S.nrows, 0), swept(S.nrows, 0);
+    std::vector<double> slots((size_t)std::max<int64_t>(S.nslots, 1), 0.0);
+    std::vector<int> slot_written((size_t)std::max<int64_t>(S.nslots, 1), 0);
+    const bool defer = !S.row_defer.empty();
     auto fail = [&](const char* msg, long long a) { if (why) *why = std::string(msg) + " " + std::to_string(a); return FOS_EINVAL; };
     if ((int)S.wave_blk0.size() != S.nwaves + 1 || S.wave_blk0.front() != 0 || S.wave_blk0.back() != S.nblk) return fail("bad wave partition", S.nwaves);
     for (int w = 0; w < S.nwaves; ++w) if (S.wave_blk0[w] > S.wave_blk0[w + 1]) return fail("wave partition not monotone at", w);
+    // a row finished by the sweep: straight to `out`, or -- deferred rows -- its own partial slot
+    auto finish = [&](int64_t row, double acc) {
+        swept[row]++;
+        if (defer && S.row_defer[row] >= 0) { slots[S.row_defer[row]] = acc; slot_written[S.row_defer[row]]++; }
+        else if (defer && S.row_defer[row] == -2) { seen[row] += 100; }          // must never be in an ordinary block
+        else { out[row] = acc; seen[row]++; }
+    };
     for (int b = 0; b < S.nblk; ++b) {
         const BlkDesc& d = S.blk[b];
         if (d.nnz0 % NNZ_ALIGN) return fail("block not aligned", b);
         const int R = d.nrows();
-        if (d.kind() == BLK_LONG) {
+        if (d.kind() == BLK_TILE) {
+            const int T = d.steps();
+            if (d.cnt != 64 * (int64_t)T || T % TILE_GROUP || R > 64) return fail("bad tile block", b);
+            const int64_t c0 = S.col[d.colpos], cslot = S.col[d.colpos + 1], rslot = S.col[d.colpos + 2], tc = S.col[d.colpos + 3];
+            if (c0 < 0 || tc < 1 || tc > T || T - tc >= TILE_GROUP || c0 + tc > S.nrows) return fail("tile columns out of range in block", b);
+            if (cslot < 0 || cslot + T > S.nslots || (rslot >= 0 && rslot + R > S.nslots)) return fail("tile slots out of range in block", b);
+            for (int t = 0; t < T; ++t) {                                        // column sums: over the lanes
+                double acc = 0.0;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const double a = S.val[d.nnz0 + (int64_t)t * 64 + lane];
+                    if (lane >= R || t >= tc) { if (a != 0.0) return fail("tile padding not zero in block", b); continue; }
+                    acc += a * v[d.row0 + lane];
+                }
+                slots[cslot + t] = acc;
+                slot_written[cslot + t]++;
+            }
+            for (int lane = 0; lane < R; ++lane) {                                // row sums: over the steps
+                double acc = 0.0;
+                for (int t = 0; t < tc; ++t) acc += S.val[d.nnz0 + (int64_t)t * 64 + lane] * v[c0 + t];
+                if (rslot >= 0) { slots[rslot + lane] = acc; slot_written[rslot + lane]++; }
+                else { out[d.row0 + lane] = acc; seen[d.row0 + lane]++; }
+            }
+        } else if (d.kind() == BLK_LONG) {
             const int64_t stride = (d.cnt + NNZ_ALIGN - 1) / NNZ_ALIGN * NNZ_ALIGN;
             for (int i = 0; i < R; ++i) {
                 double acc = 0.0;
@@ -304,8 +467,7 @@ int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::st
                     if (c < 0 || c >= S.nrows) return fail("column out of range in block", b);
                     acc += S.val[d.nnz0 + i * stride + k] * v[c];
                 }
-                out[d.row0 + i] = acc;
-                seen[d.row0 + i]++;
+                finish(d.row0 + i, acc);
             }
         } else if (d.kind() == BLK_ELL) {
             int p2 = 1; while (p2 < R) p2 <<= 1;
@@ -324,8 +486,7 @@ int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::st
                         acc += S.val[d.nnz0 + pos] * v[c];
                     }
                 }
-                out[d.row0 + i] = acc;
-                seen[d.row0 + i]++;
+                finish(d.row0 + i, acc);
             }
         } else {
             if (d.cnt > WNNZ) return fail("LDS block too large", b);
@@ -338,12 +499,30 @@ int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::st
                     if (c < 0 || c >= S.nrows) return fail("column out of range in block", b);
                     acc += S.val[d.nnz0 + k] * v[c];
                 }
-                out[d.row0 + i] = acc;
-                seen[d.row0 + i]++;
+                finish(d.row0 + i, acc);
             }
         }
     }
+    // deferred rows: the second kernel adds their slots in list order
+    if (S.def_ptr.size() != S.def_rows.size() + 1 && !(S.def_rows.empty() && S.def_ptr.empty())) return fail("bad deferred-row lists", (long long)S.def_rows.size());
+    for (size_t q = 0; q < S.def_rows.size(); ++q) {
+        const int64_t row = S.def_rows[q];
+        if (row < 0 || row >= S.nrows || !defer || S.row_defer[row] == -1) return fail("deferred row without a flag:", row);
+        if (q > 0 && S.def_rows[q - 1] >= row) return fail("deferred rows not ascending at", (long long)q);
+        double acc = 0.0;
+        for (int32_t k = S.def_ptr[q]; k < S.def_ptr[q + 1]; ++k) {
+            const int32_t sl = S.def_idx[k];
+            if (sl < 0 || sl >= S.nslots) return fail("slot out of range for row", row);
+            if (slot_written[sl] != 1) return fail("slot not written exactly once, row", row);
+            acc += slots[sl];
+        }
+        out[row] = acc;
+        seen[row]++;
+    }
     for (int64_t r = 0; r < S.nrows; ++r) if (seen[r] != 1) return fail("row not covered exactly once:", r);
+    if (defer)
+        for (int64_t r = 0; r < S.nrows; ++r)
+            if (S.row_defer[r] >= 0 && swept[r] != 1) return fail("deferred row with entries not swept exactly once:", r);
     return FOS_OK;
 }
 

@@ -49,7 +49,19 @@ constexpr int WROWS = 64;           // max rows per row block (>= 1 epilogue lan
 constexpr int LONG_ROWS = 4;        // long run-rows over one column range handled together by a wavefront
 constexpr int NNZ_ALIGN = 4;        // every row block starts at a multiple of 4 entries (16/32-byte aligned)
 
-enum BlkKind : int32_t { BLK_LDS = 0, BLK_ELL = 1, BLK_LONG = 2 };
+enum BlkKind : int32_t { BLK_LDS = 0, BLK_ELL = 1, BLK_LONG = 2, BLK_TILE = 3 };
+
+// Dual tiles (BLK_TILE).  A dense rectangle of A -- R <= 64 consecutive rows whose non-zeros are the SAME run of
+// consecutive columns -- is stored ONCE, lane-major (lane = row, step = column), and serves both products of the
+// stacked operator in one pass: the row sums (A x) stay in the lanes, the column sums (A'y) are formed by an
+// in-register butterfly over 8 steps at a time and written as PARTIALS to a slot array; the A' entries the tile
+// covers are not stored at all.  Rows of S whose sum is spread over several tiles (columns of A covered by tiles;
+// rows of A wider than TILE_TC_MAX columns) are DEFERRED: a second small kernel adds their partial slots in a fixed
+// order and runs the row epilogue.  Halves the matrix bytes of dense operators (C2, C4).
+constexpr int TILE_MIN_ROWS = 16;   // fewer rows: not worth a 64-lane wavefront
+constexpr int TILE_MIN_COLS = 8;
+constexpr int TILE_TC_MAX = 128;    // columns (steps) per tile: 64 KB of values per wavefront work unit
+constexpr int TILE_GROUP = 8;       // steps per butterfly; stored steps are padded to a multiple
 
 struct BlkDesc {                    // one row block = the unit of work of ONE wavefront (32 bytes)
     int64_t nnz0;                   // first value in `val` (multiple of NNZ_ALIGN)
@@ -73,6 +85,14 @@ struct HostBlkCsr {
     std::vector<uint16_t> row_rel;     // [nrows]  row start relative to its block's nnz0 (stream blocks)
     std::vector<int32_t> wave_blk0;    // [nwaves+1]  row blocks owned by each wavefront of the grid
     int32_t nblk = 0, nwg = 0, nwaves = 0;
+    // dual tiles / deferred rows (empty when the operator has no tile)
+    int64_t nslots = 0;                // partial-sum slots (2 doubles each)
+    int64_t ntiles = 0, tile_values = 0;
+    std::vector<int32_t> row_defer;    // [nrows] -1: epilogue in the sweep; >= 0: the sweep stores the row's own partial in that
+                                       // slot; -2: deferred, no entries outside tiles (the sweep never sees the row)
+    std::vector<int32_t> def_rows;     // [ndef]   deferred rows, ascending
+    std::vector<int32_t> def_ptr;      // [ndef+1] their slot lists
+    std::vector<int32_t> def_idx;      // slot indices, in summation order
 };
 
 struct DevBlkCsr {
@@ -83,6 +103,15 @@ struct DevBlkCsr {
     const uint16_t* row_rel;
     const int32_t* wave_blk0;
     int32_t nblk, nwg, nwaves;
+    // dual tiles / deferred rows (ndef == 0: none)
+    double* slots;                     // [nslots][2]
+    const int32_t* row_defer;          // nullptr when ndef == 0
+    const int32_t* def_rows;
+    const int32_t* def_ptr;
+    const int32_t* def_idx;
+    int32_t ndef, nwg_def;             // deferred rows, workgroups of the deferred-row kernel
+    int32_t def_lpr;                   // lanes per deferred row (power of two <= 64)
+    int32_t npart;                     // per-workgroup partial-sum records a sweep produces = nwg + nwg_def
 };
 
 // Builds S = [[0, A'],[A, 0]] from Julia CSC (1-based).  Returns FOS_EINVAL on malformed input.
@@ -90,6 +119,9 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
                       int nwg_target, HostBlkCsr* out, int resident_waves = 0);
 void partition_workgroups(HostBlkCsr* S, int nwg_target);
 int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::string* why);
+constexpr int DEF_THREADS = 256;    // deferred-row kernel: one thread per deferred row
+constexpr int DEF_MAX_WG = 1024;    // its grid (grid-stride beyond)
+constexpr int PART_CAP = 16384 + DEF_MAX_WG + 8;   // per-workgroup partial-sum records a kernel may produce (sweep + deferred rows)
 
 // ---------------------------------------------------------------------------------- device scalar state
 // One struct in device memory; kernels read/write it, the host polls a pinned copy.

@@ -110,19 +110,75 @@ struct Gather<2> {
         const v2d x = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(w) + c);
         return make_double2(v * x.x, v * x.y);
     }
+    __device__ __forceinline__ d2 load(int c) const { return w[c]; }
 };
 template <>
 struct Gather<1> {
     const double* w;   // points at the chosen component of an interleaved vector: element c at w[2c]
     __device__ __forceinline__ double operator()(double v, int c) const { return v * w[2 * (int64_t)c]; }
     __device__ __forceinline__ double nt(double v, int c) const { return v * __builtin_nontemporal_load(w + 2 * (int64_t)c); }
+    __device__ __forceinline__ d2 load(int c) const { return make_double2(w[2 * (int64_t)c], 0.0); }
 };
 
 constexpr int WPL = WNNZ / 64;      // stream entries per lane
 
+// A row the sweep has summed: run its epilogue, or -- a DEFERRED row (dual tiles hold the rest of it) -- park the sum in
+// the row's own partial slot for the deferred-row kernel.
+template <bool DEFER, class Epi>
+__device__ __forceinline__ void finish_row(const DevBlkCsr& S, Epi& epi, int row, double a1, double a2, const RowPre& pr) {
+    if constexpr (DEFER) {
+        const int ds = S.row_defer[row];
+        if (ds >= 0) { reinterpret_cast<d2*>(S.slots)[ds] = make_double2(a1, a2); return; }
+    }
+    epi.row(row, a1, a2, pr);
+}
+
+// v + (v of the lane 16 / 32 away), every lane, without the LDS crossbar: gfx950's v_permlane{16,32}_swap exchanges the odd
+// 16-lane rows (the upper 32 lanes) of one register with the even rows (the lower 32 lanes) of another; fed the same value
+// twice it leaves [r0 r0 r2 r2] / [r1 r1 r3 r3] (resp. [lo lo] / [hi hi]), whose sum is the pairwise total in every lane.
+template <int W>
+__device__ __forceinline__ double swap_sum(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    if constexpr (W == 16) {
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    } else {
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+}
+
+// Column sums of a dual tile.  Every lane holds p[u] = (its row's value in column u) x (its row's vector element) for 8
+// consecutive columns; returns, in EVERY lane, the sum over all 64 lanes for column (lane & 7).  Three halving stages
+// inside each group of 8 lanes (a lane keeps half of its values and trades the other half with a partner that keeps
+// the complementary half: i <-> 7-i, i <-> i^2, i <-> i^1), then three full additions (i^8, i^16, i^32): 7 + 3 adds
+// instead of 8 x 6, and a fixed summation order.
+__device__ __forceinline__ double tile_colsum8(const double (&p)[8], int lane) {
+    const bool b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+    double q[4], r[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double keep = b2 ? p[4 + j] : p[j], send = b2 ? p[j] : p[4 + j];
+        q[j] = keep + dpp_f64<0x141>(send);            // row_half_mirror: columns 4 b2 + j
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double keep = b1 ? q[2 + j] : q[j], send = b1 ? q[j] : q[2 + j];
+        r[j] = keep + dpp_f64<0x4E>(send);             // quad_perm [2,3,0,1]: columns 4 b2 + 2 b1 + j
+    }
+    const double keep = b0 ? r[1] : r[0], send = b0 ? r[0] : r[1];
+    double s = keep + dpp_f64<0xB1>(send);             // quad_perm [1,0,3,2]: column lane & 7
+    s += dpp_f64<0x128>(s);                            // row_ror:8  (lane ^ 8)
+    s = swap_sum<16>(s);                               // + the neighbouring row of 16 lanes
+    s = swap_sum<32>(s);                               // + the other half of the wavefront
+    return s;
+}
+
 // NR long run-rows over the same column range [c00, c00+cnt): each gathered element feeds NR matrix values
-template <int NR, int NRHS, class Epi>
-__device__ __forceinline__ void long_run_rows(const Gather<NRHS>& gat, Epi& epi, const double* __restrict__ val, int64_t stride,
+template <int NR, int NRHS, bool DEFER, class Epi>
+__device__ __forceinline__ void long_run_rows(const DevBlkCsr& S, const Gather<NRHS>& gat, Epi& epi, const double* __restrict__ val, int64_t stride,
                                               int cnt, int c00, int row0, int lane) {
     double a1[NR], a2[NR];
 #pragma unroll
@@ -174,7 +230,7 @@ __device__ __forceinline__ void long_run_rows(const Gather<NRHS>& gat, Epi& epi,
     // lane i finishes row i
 #pragma unroll
     for (int i = 0; i < NR; ++i)
-        if (lane == i) epi.row(row0 + i, a1[i], a2[i], pr);
+        if (lane == i) finish_row<DEFER>(S, epi, row0 + i, a1[i], a2[i], pr);
 }
 
 // U lane-major steps of an ELL block starting at step t: all U value (and index) loads are issued before the first
@@ -240,7 +296,7 @@ __device__ __forceinline__ void long_steps(const Gather<NRHS>& gat, const double
     }
 }
 
-template <int NRHS, class Epi>
+template <int NRHS, bool DEFER, class Epi>
 __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>& gat, Epi& epi, double* prod_all) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -264,9 +320,9 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
                 const int c00 = S.col[d.colpos];  // consecutive columns: col(e) = c00 + e
                 const int nr = d.nrows();
                 const int64_t stride = (d.cnt + NNZ_ALIGN - 1) / NNZ_ALIGN * NNZ_ALIGN;
-                if (nr == 4) long_run_rows<4, NRHS>(gat, epi, val, stride, cnt, c00, d.row0, lane);
-                else if (nr == 2) long_run_rows<2, NRHS>(gat, epi, val, stride, cnt, c00, d.row0, lane);
-                else long_run_rows<1, NRHS>(gat, epi, val, stride, cnt, c00, d.row0, lane);
+                if (nr == 4) long_run_rows<4, NRHS, DEFER>(S, gat, epi, val, stride, cnt, c00, d.row0, lane);
+                else if (nr == 2) long_run_rows<2, NRHS, DEFER>(S, gat, epi, val, stride, cnt, c00, d.row0, lane);
+                else long_run_rows<1, NRHS, DEFER>(S, gat, epi, val, stride, cnt, c00, d.row0, lane);
                 continue;
             } else {
                 for (; k + 7 * 64 < cnt; k += 8 * 64) long_steps<8, NRHS, false>(gat, val, col, k, 0, a1, a2);
@@ -275,7 +331,54 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
             }
             a1 = group_sum(a1, 64);
             if constexpr (NRHS == 2) a2 = group_sum(a2, 64);
-            if (lane == 0) epi.row(d.row0, a1, a2, pr);
+            if (lane == 0) finish_row<DEFER>(S, epi, d.row0, a1, a2, pr);
+        } else if (kind == BLK_TILE) {
+            // ---------------- dual tile: lane = row, step = column; row sums stay in the lanes, column sums go to slots
+            if constexpr (DEFER) {
+                const int R = d.nrows(), T = d.steps();
+                const int c0 = __builtin_amdgcn_readfirstlane(S.col[d.colpos]);
+                const int cslot = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 1]);
+                const int rslot = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 2]);
+                const int tc = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 3]);      // real columns (steps beyond: padding)
+                const bool valid = lane < R;
+                const int row = d.row0 + lane;
+                RowPre pr{};
+                if (valid && rslot < 0) pr = epi.pre(row);
+                const d2 wr = valid ? gat.load(row) : make_double2(0.0, 0.0);
+                const double* __restrict__ val = S.val + d.nnz0 + lane;
+                d2* __restrict__ slots = reinterpret_cast<d2*>(S.slots);
+                double r1 = 0.0, r2 = 0.0;
+                double vn[TILE_GROUP];                 // the next group's values are in flight while this group is reduced
+#pragma unroll
+                for (int u = 0; u < TILE_GROUP; ++u) vn[u] = nt_load(val + 64 * u);
+                for (int t = 0; t < T; t += TILE_GROUP) {
+                    double v[TILE_GROUP];
+                    d2 x[TILE_GROUP];
+#pragma unroll
+                    for (int u = 0; u < TILE_GROUP; ++u) v[u] = vn[u];
+                    if (t + TILE_GROUP < T) {
+#pragma unroll
+                        for (int u = 0; u < TILE_GROUP; ++u) vn[u] = nt_load(val + 64 * (t + TILE_GROUP + u));
+                    }
+#pragma unroll
+                    for (int u = 0; u < TILE_GROUP; ++u) x[u] = (t + u < tc) ? gat.load(c0 + t + u) : make_double2(0.0, 0.0);
+                    double p1[TILE_GROUP], p2[TILE_GROUP];
+#pragma unroll
+                    for (int u = 0; u < TILE_GROUP; ++u) {
+                        r1 += v[u] * x[u].x;
+                        p1[u] = v[u] * wr.x;
+                        if constexpr (NRHS == 2) { r2 += v[u] * x[u].y; p2[u] = v[u] * wr.y; }
+                    }
+                    const double s1 = tile_colsum8(p1, lane);
+                    double s2 = 0.0;
+                    if constexpr (NRHS == 2) s2 = tile_colsum8(p2, lane);
+                    if (lane < TILE_GROUP) slots[cslot + t + lane] = make_double2(s1, s2);
+                }
+                if (valid) {
+                    if (rslot < 0) epi.row(row, r1, r2, pr);
+                    else slots[rslot + lane] = make_double2(r1, r2);
+                }
+            }
         } else if (kind == BLK_ELL) {
             // ---------------- lane-major block: lane (row, lig) owns entries lig, lig + tpr, ... of its row
             const int R = d.nrows(), T = d.steps();
@@ -305,7 +408,7 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
             }
             a1 = group_sum(a1, tpr);
             if constexpr (NRHS == 2) a2 = group_sum(a2, tpr);
-            if (owner) epi.row(d.row0 + row, a1, a2, pr);
+            if (owner) finish_row<DEFER>(S, epi, d.row0 + row, a1, a2, pr);
         } else {
             // ---------------- LDS-staged block: rows row0 .. row0+nrows-1, cnt entries in CSR order
             const int cnt = (int)d.cnt;
@@ -354,7 +457,7 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
             }
             a1 = group_sum(a1, tpr);
             if constexpr (NRHS == 2) a2 = group_sum(a2, tpr);
-            if (owner) epi.row(d.row0 + row, a1, a2, pr);
+            if (owner) finish_row<DEFER>(S, epi, d.row0 + row, a1, a2, pr);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -386,6 +489,7 @@ struct EpiKkt {
     }
 };
 
+template <bool DEFER>
 __global__ __launch_bounds__(SPMV_THREADS) void kkt2_kernel(DevBlkCsr S, const d2* __restrict__ w, d2* __restrict__ out,
                                                             const double* __restrict__ cb, int n, int nm,
                                                             double* __restrict__ partials, const DevState* st, int gate) {
@@ -396,8 +500,50 @@ __global__ __launch_bounds__(SPMV_THREADS) void kkt2_kernel(DevBlkCsr S, const d
     epi.w = w; epi.out = out; epi.cb = cb; epi.n = n; epi.wt = w[nm];
     epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
     Gather<2> gat{w};
-    spmv_walk<2>(S, gat, epi, prod);
+    spmv_walk<2, DEFER>(S, gat, epi, prod);
     block_reduce_store<3, SPMV_THREADS>(epi.acc, red, partials + 3 * (int64_t)blockIdx.x);
+}
+
+// Deferred rows (dual tiles): one thread per row adds the row's partial slots in list order and runs the epilogue the
+// sweep could not; its workgroups append their partial sums behind the sweep's (records nwg .. nwg + nwg_def - 1).
+// `lpr` lanes (a power of two <= 64, S.def_lpr) share a row: lane-strided partial sums, then the fixed DPP butterfly --
+// long slot lists (a dense LP: one partial per 64-row tile) are latency bound with one thread per row.
+template <class Epi>
+__device__ __forceinline__ void deferred_rows(const DevBlkCsr& S, Epi& epi) {
+    const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots);
+    const int lpr = S.def_lpr, sh = 31 - __clz(lpr);
+    const int rows_per_pass = (gridDim.x * DEF_THREADS) >> sh;
+    const int lig = threadIdx.x & (lpr - 1);
+    const int npass = (S.ndef + rows_per_pass - 1) / rows_per_pass;           // uniform trip count: the DPP sums need full waves
+    int q = (blockIdx.x * DEF_THREADS + threadIdx.x) >> sh;
+    for (int pass = 0; pass < npass; ++pass, q += rows_per_pass) {
+        const bool ok = q < S.ndef;
+        const int row = ok ? S.def_rows[q] : 0;
+        RowPre pr{};
+        if (ok && lig == 0) pr = epi.pre(row);
+        double u1 = 0.0, u2 = 0.0;
+        if (ok) {
+            const int k1 = S.def_ptr[q + 1];
+            for (int k = S.def_ptr[q] + lig; k < k1; k += lpr) {
+                const d2 p = slots[S.def_idx[k]];
+                u1 += p.x; u2 += p.y;
+            }
+        }
+        u1 = group_sum(u1, lpr);
+        u2 = group_sum(u2, lpr);
+        if (ok && lig == 0) epi.row(row, u1, u2, pr);
+    }
+}
+__global__ __launch_bounds__(DEF_THREADS) void kkt2_deferred_kernel(DevBlkCsr S, const d2* __restrict__ w, d2* __restrict__ out,
+                                                                    const double* __restrict__ cb, int n, int nm,
+                                                                    double* __restrict__ partials, const DevState* st, int gate) {
+    if (gate && st->done) return;
+    __shared__ double red[16];
+    EpiKkt epi;
+    epi.w = w; epi.out = out; epi.cb = cb; epi.n = n; epi.wt = w[nm];
+    epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
+    deferred_rows(S, epi);
+    block_reduce_store<3, DEF_THREADS>(epi.acc, red, partials + 3 * (int64_t)(S.nwg + blockIdx.x));
 }
 
 // sums partials[count][NACC] -> sums[NACC] in a fixed order (1024 threads, one block)
@@ -510,8 +656,15 @@ __global__ __launch_bounds__(FIN_THREADS) void kkt_finalize_kernel(const double*
 }
 
 void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
-    hipLaunchKernelGGL(kkt2_kernel, dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, w, out, c.cb, (int)c.n,
-                       (int)(c.n + c.m), c.partials, c.st, gate);
+    if (c.S.ndef > 0) {
+        hipLaunchKernelGGL(kkt2_kernel<true>, dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, w, out, c.cb, (int)c.n,
+                           (int)(c.n + c.m), c.partials, c.st, gate);
+        hipLaunchKernelGGL(kkt2_deferred_kernel, dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, w, out, c.cb, (int)c.n,
+                           (int)(c.n + c.m), c.partials, c.st, gate);
+    } else {
+        hipLaunchKernelGGL(kkt2_kernel<false>, dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, w, out, c.cb, (int)c.n,
+                           (int)(c.n + c.m), c.partials, c.st, gate);
+    }
 }
 void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate) {
     if (c.peer)
@@ -520,7 +673,7 @@ void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate) {
         hipLaunchKernelGGL(reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, count, nacc, c.reduced, c.st, gate, PeerBox{});
 }
 void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int gate, int from_reduced) {
-    hipLaunchKernelGGL(kkt_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.nwg, c.reduced,
+    hipLaunchKernelGGL(kkt_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.npart, c.reduced,
                        from_reduced, w, out, (int)(c.n + c.m), c.st, gate);
 }
 
@@ -583,7 +736,7 @@ struct EpiQStatus {    // residual sums of checkstatus  HSDEStatus.jl:34-38,59,6
     }
 };
 
-template <class Epi, int NACC>
+template <class Epi, int NACC, bool DEFER>
 __global__ __launch_bounds__(SPMV_THREADS) void q1_kernel(DevBlkCsr S, const double* __restrict__ vcomp, Epi epi, int nm,
                                                           double* __restrict__ partials) {
     __shared__ __attribute__((aligned(16))) double prod[SPMV_WAVES * WNNZ];
@@ -592,8 +745,28 @@ __global__ __launch_bounds__(SPMV_THREADS) void q1_kernel(DevBlkCsr S, const dou
     for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
     epi.init(vcomp[2 * (int64_t)nm]);      // the tau entry of the gathered component
     Gather<1> gat{vcomp};
-    spmv_walk<1>(S, gat, epi, prod);
+    spmv_walk<1, DEFER>(S, gat, epi, prod);
     block_reduce_store<NACC, SPMV_THREADS>(epi.acc, red, partials + NACC * (int64_t)blockIdx.x);
+}
+template <class Epi, int NACC>
+__global__ __launch_bounds__(DEF_THREADS) void q1_deferred_kernel(DevBlkCsr S, const double* __restrict__ vcomp, Epi epi, int nm,
+                                                                  double* __restrict__ partials) {
+    __shared__ double red[8 * NACC > 16 ? 8 * NACC : 16];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
+    epi.init(vcomp[2 * (int64_t)nm]);
+    deferred_rows(S, epi);
+    block_reduce_store<NACC, DEF_THREADS>(epi.acc, red, partials + NACC * (int64_t)(S.nwg + blockIdx.x));
+}
+template <class Epi, int NACC>
+static void launch_q1_kernels(const LaunchCtx& c, const double* vcomp, const Epi& e, int nm) {
+    dim3 grid(c.S.nwg), block(SPMV_THREADS);
+    if (c.S.ndef > 0) {
+        hipLaunchKernelGGL((q1_kernel<Epi, NACC, true>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
+        hipLaunchKernelGGL((q1_deferred_kernel<Epi, NACC>), dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, vcomp, e, nm, c.partials);
+    } else {
+        hipLaunchKernelGGL((q1_kernel<Epi, NACC, false>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
+    }
 }
 
 __global__ __launch_bounds__(FIN_THREADS) void q1_finalize_kernel(const double* __restrict__ partials, int count,
@@ -634,28 +807,27 @@ __global__ __launch_bounds__(FIN_THREADS) void status_finalize_kernel(const doub
 void launch_q1(const LaunchCtx& c, QMode mode, const double2* v, int comp, double sign, void* out) {
     const double* vcomp = reinterpret_cast<const double*>(v) + comp;
     const int nm = (int)(c.n + c.m);
-    dim3 grid(c.S.nwg), block(SPMV_THREADS);
     if (mode == Q_PLAIN) {
         EpiQPlain e; e.vcomp = vcomp; e.out = (double*)out; e.cb = c.cb; e.n = (int)c.n; e.vt = 0; e.sign = sign;
-        hipLaunchKernelGGL((q1_kernel<EpiQPlain, 1>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
+        launch_q1_kernels<EpiQPlain, 1>(c, vcomp, e, nm);
     } else if (mode == Q_RHS) {
         EpiQRhs e; e.x = v; e.out = (d2*)out; e.cb = c.cb; e.n = (int)c.n; e.vt = 0;
-        hipLaunchKernelGGL((q1_kernel<EpiQRhs, 1>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
+        launch_q1_kernels<EpiQRhs, 1>(c, vcomp, e, nm);
     } else if (mode == Q_VFROMU) {
         EpiQVfromU e; e.y = v; e.out = (d2*)out; e.cb = c.cb; e.n = (int)c.n; e.vt = 0;
-        hipLaunchKernelGGL((q1_kernel<EpiQVfromU, 1>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
+        launch_q1_kernels<EpiQVfromU, 1>(c, vcomp, e, nm);
     } else {
         EpiQStatus e; e.z = v; e.cb = c.cb; e.n = (int)c.n; e.tau = 0;
-        hipLaunchKernelGGL((q1_kernel<EpiQStatus, 6>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
+        launch_q1_kernels<EpiQStatus, 6>(c, vcomp, e, nm);
     }
 }
 void launch_q1_finalize(const LaunchCtx& c, QMode mode, const double2* v, int comp, double sign, void* out, int from_reduced) {
     (void)comp;
-    hipLaunchKernelGGL(q1_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.nwg, c.reduced,
+    hipLaunchKernelGGL(q1_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.npart, c.reduced,
                        from_reduced, (int)mode, v, sign, out, (int)(c.n + c.m));
 }
 void launch_status_finalize(const LaunchCtx& c, const double2* z, int from_reduced) {
-    hipLaunchKernelGGL(status_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.nwg, c.reduced,
+    hipLaunchKernelGGL(status_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.npart, c.reduced,
                        from_reduced, z, (int)(c.n + c.m), c.st);
 }
 

@@ -344,7 +344,7 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     // projection; many matrices: 256 threads (4 per CU) maximise throughput
     static int cus = 0;
     if (!cus) { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; if (cus <= 0) cus = 256; }
-    const bool wide = warm && (2 * ncones <= 2 * cus) && !getenv("FOS_PSD_NARROW");
+    const bool wide = (warm && (2 * ncones <= 2 * cus) && !getenv("FOS_PSD_NARROW")) || (warm && getenv("FOS_PSD_WIDE"));
     static bool attr_set = false;
     if (use_lds && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, false, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
@@ -356,7 +356,7 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     }
     const size_t stride = (size_t)(kmax * psd_ld(kmax) + 2 * kmax + 16);
     const size_t vstride = (size_t)kmax * kmax;
-    static const int wide_threads = getenv("FOS_PSD_THREADS") ? atoi(getenv("FOS_PSD_THREADS")) : 1024;
+    static const int wide_threads = getenv("FOS_PSD_THREADS") ? atoi(getenv("FOS_PSD_THREADS")) : 512;
     if (warm && wide && wide_threads == 512)
         hipLaunchKernelGGL((psd_kernel<true, true, 512>), dim3(2 * ncones), dim3(512), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev);
     else if (warm && wide && wide_threads == 1024)

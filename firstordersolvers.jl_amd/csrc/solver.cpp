@@ -216,7 +216,7 @@ int global_setup(fos_solver* h) {
 int kkt_apply_full(fos_solver* h, const LaunchCtx& c, const d2* w, d2* out) {
     launch_kkt2(c, w, out, 0);
     int fr = 0;
-    FOS_TRY(finish_reduce(h, c, c.S.nwg, 3, 0, &fr));
+    FOS_TRY(finish_reduce(h, c, c.S.npart, 3, 0, &fr));
     launch_kkt_finalize(c, w, out, 0, fr);
     return FOS_OK;
 }
@@ -241,12 +241,12 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
             launch_kkt2(c, h->P, h->AP, 1);                            // :38   Ap = M p (+ partial sums)
             if (rec) { FOS_HIP(hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
             int f1 = 0;
-            FOS_TRY(finish_reduce(h, c, c.S.nwg, 3, 1, &f1));
+            FOS_TRY(finish_reduce(h, c, c.S.npart, 3, 1, &f1));
             launch_cg_alpha_update(c, x, h->R, h->P, h->AP, f1, next_j);   // :39-41,46
             int f2 = 0;
             if (h->sharded()) {                                        // sharded: reduce the r.r partials, all-reduce
                 LaunchCtx c2 = c;
-                c2.partials = c.partials + 3 * (size_t)16392;
+                c2.partials = c.partials + 3 * (size_t)PART_CAP;
                 launch_reduce1(c2, c.cg_blocks, 1, 1);
                 FOS_TRY(allreduce(h, 1));
                 f2 = 1;
@@ -279,7 +279,7 @@ int prox_affine(fos_solver* h, const d2* x) {
     LaunchCtx c = h->ctx();
     int fr = 0;
     launch_q1(c, Q_RHS, x, 1, 1.0, h->RHS);                            // :94-95
-    FOS_TRY(finish_reduce(h, c, c.S.nwg, 1, 0, &fr));
+    FOS_TRY(finish_reduce(h, c, c.S.npart, 1, 0, &fr));
     launch_q1_finalize(c, Q_RHS, x, 1, 1.0, h->RHS, fr);
     if (h->firstrun) {                                                  // :101-104
         FOS_HIP(hipMemcpyAsync(h->SOL, x, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));
@@ -312,7 +312,7 @@ int status_check(fos_solver* h, const d2* z, double eps, fos_check_result* res) 
     LaunchCtx c = h->ctx();
     int fr = 0;
     launch_q1(c, Q_STATUS, z, 0, 1.0, nullptr);
-    FOS_TRY(finish_reduce(h, c, c.S.nwg, 6, 0, &fr));
+    FOS_TRY(finish_reduce(h, c, c.S.npart, 6, 0, &fr));
     launch_status_finalize(c, z, fr);
     FOS_TRY(poll_state(h));
     const double* s = h->st_host->stat;
@@ -565,6 +565,32 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
     h->S.nrows = hs.nrows; h->S.nnz = hs.nnz; h->S.nnz_padded = hs.nnz_padded;
     h->S.val = dval; h->S.col = dcol; h->S.blk = dblk;
     h->S.row_rel = drr; h->S.wave_blk0 = dwv; h->S.nblk = hs.nblk; h->S.nwg = hs.nwg; h->S.nwaves = hs.nwaves;
+    // dual tiles: partial-sum slots and the deferred rows' slot lists
+    h->S.slots = nullptr; h->S.row_defer = nullptr; h->S.def_rows = nullptr; h->S.def_ptr = nullptr; h->S.def_idx = nullptr;
+    h->S.ndef = (int32_t)hs.def_rows.size();
+    h->S.nwg_def = 0; h->S.def_lpr = 1;
+    if (h->S.ndef > 0) {
+        int32_t *drd, *ddr, *ddp, *ddi;
+        double* dsl;
+        FOS_TRY(dev_upload(h, &drd, hs.row_defer));
+        FOS_TRY(dev_upload(h, &ddr, hs.def_rows));
+        FOS_TRY(dev_upload(h, &ddp, hs.def_ptr));
+        FOS_TRY(dev_upload(h, &ddi, hs.def_idx));
+        FOS_TRY(dev_alloc(h, &dsl, (size_t)2 * hs.nslots));
+        FOS_HIP(hipMemset(dsl, 0, sizeof(double) * 2 * hs.nslots));
+        h->S.slots = dsl; h->S.row_defer = drd; h->S.def_rows = ddr; h->S.def_ptr = ddp; h->S.def_idx = ddi;
+        // lanes per deferred row: about a quarter of the average slot-list length (C4: 33 slots -> 8 lanes, dense LP: 80 -> 16)
+        const double avg_list = (double)hs.def_ptr.back() / (double)h->S.ndef;
+        int lpr = 1;
+        while (lpr < 64 && 4.0 * lpr < avg_list) lpr <<= 1;
+        if (getenv("FOS_DEF_LPR")) lpr = std::max(1, std::min(64, atoi(getenv("FOS_DEF_LPR"))));
+        while (lpr & (lpr - 1)) lpr &= lpr - 1;
+        h->S.def_lpr = lpr;
+        h->S.nwg_def = (int32_t)std::min<int64_t>(DEF_MAX_WG, ((int64_t)h->S.ndef * lpr + DEF_THREADS - 1) / DEF_THREADS);
+        std::vector<int32_t>().swap(hs.row_defer);
+        std::vector<int32_t>().swap(hs.def_idx);
+    }
+    h->S.npart = h->S.nwg + h->S.nwg_def;
     // free the big host arrays (keep block table for re-partitioning)
     std::vector<double>().swap(hs.val);
     std::vector<int32_t>().swap(hs.col);
@@ -618,7 +644,7 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
     FOS_HIP(hipMemset(h->st, 0, sizeof(DevState)));
     FOS_HIP(hipHostMalloc((void**)&h->st_host, sizeof(DevState), hipHostMallocDefault));
     memset(h->st_host, 0, sizeof(DevState));
-    FOS_TRY(dev_alloc(h, &h->partials, (size_t)6 * 16392));
+    FOS_TRY(dev_alloc(h, &h->partials, (size_t)6 * PART_CAP));
     FOS_TRY(dev_alloc(h, &h->reduced, 16));
     FOS_HIP(hipMemset(h->reduced, 0, sizeof(double) * 16));
     if (const char* e = getenv("FOS_CG_CHUNK")) h->cg_chunk = std::max(1, atoi(e));
@@ -924,7 +950,7 @@ int fos_q_apply(fos_handle h, double* y, const double* x, int32_t transpose) {
     const double sign = transpose ? -1.0 : 1.0;           // HSDEAffine.jl:61-65
     int fr = 0;
     launch_q1(c, Q_PLAIN, h->W, 0, sign, h->plain + l);
-    FOS_TRY(finish_reduce(h, c, c.S.nwg, 1, 0, &fr));
+    FOS_TRY(finish_reduce(h, c, c.S.npart, 1, 0, &fr));
     launch_q1_finalize(c, Q_PLAIN, h->W, 0, sign, h->plain + l, fr);
     FOS_HIP(hipMemcpyAsync(y, h->plain + l, sizeof(double) * l, hipMemcpyDeviceToHost, h->stream));
     FOS_HIP(hipStreamSynchronize(h->stream));
@@ -982,7 +1008,7 @@ int fos_hsdematrix_prox(fos_handle h, double* y, const double* x) {
     // v = Q*u                                                          :122-124
     int fr = 0;
     launch_q1(c, Q_VFROMU, h->SOL2, 0, 1.0, h->W);
-    FOS_TRY(finish_reduce(h, c, c.S.nwg, 1, 0, &fr));
+    FOS_TRY(finish_reduce(h, c, c.S.npart, 1, 0, &fr));
     launch_q1_finalize(c, Q_VFROMU, h->SOL2, 0, 1.0, h->W, fr);
     return download_plain(h, y, h->W);
 }
@@ -1063,11 +1089,12 @@ int fos_host_stacked_spmv(int64_t m, int64_t n, const int64_t* colptr, const int
     if (stats) {
         int64_t nell = 0, nlds = 0, nlong = 0, nrun = 0;
         for (const BlkDesc& d : S.blk) {
-            if (d.kind() == BLK_ELL) ++nell; else if (d.kind() == BLK_LDS) ++nlds; else ++nlong;
+            if (d.kind() == BLK_ELL) ++nell; else if (d.kind() == BLK_LDS) ++nlds; else if (d.kind() == BLK_LONG) ++nlong;
             if (d.run()) ++nrun;
         }
         stats[0] = S.nblk; stats[1] = nell; stats[2] = nlds; stats[3] = nlong; stats[4] = nrun;
         stats[5] = S.nnz_padded; stats[6] = S.ncol_stored; stats[7] = S.nwaves;
+        stats[8] = S.ntiles; stats[9] = S.nslots; stats[10] = (int64_t)S.def_rows.size(); stats[11] = S.tile_values;
     }
     return FOS_OK;
 }
@@ -1091,6 +1118,7 @@ int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int3
         FOS_HIP(hipMemcpy(const_cast<int32_t*>(h->S.wave_blk0), h->hostS.wave_blk0.data(),
                           h->hostS.wave_blk0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         h->S.nwg = h->hostS.nwg;
+        h->S.npart = h->S.nwg + h->S.nwg_def;
         h->S.nwaves = h->hostS.nwaves;
         h->nwg_target = spmv_workgroups;
     }

@@ -202,8 +202,9 @@ int fos_sync(fos_handle h);
 
 /* Host-only self check of the device operator format (no GPU needed): builds the block format of
  * S = [[0,A'],[A,0]] exactly as fos_create does and multiplies out = S * v on the HOST by walking the blocks the way the
- * kernel does.  stats (8 x int64, may be NULL): blocks, ELL, LDS, LONG, run-compressed blocks, stored values, stored
- * column indices, wavefronts.  Used by the CPU test-suite. */
+ * kernel does (dual tiles and the deferred-row pass included).  stats (12 x int64, may be NULL): blocks, ELL, LDS, LONG,
+ * run-compressed blocks, stored values, stored column indices, wavefronts, dual tiles, partial-sum slots, deferred rows,
+ * matrix entries held in tiles.  Used by the CPU test-suite. */
 int fos_host_stacked_spmv(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
                           const double* v, double* out, int32_t spmv_workgroups, int32_t resident_waves, int64_t* stats);
 

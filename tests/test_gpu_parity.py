@@ -50,6 +50,13 @@ def shapes(pkg):
     out.append(("mixed-lengths", sp.vstack([sp.csc_matrix(rng.standard_normal((2, 1300))),
                                             sp.random(600, 1300, density=0.01, format="csc", random_state=rng,
                                                       data_rvs=rng.standard_normal)]).tocsc()))
+    # dual tiles (dense rectangles stored once, column sums by the in-register butterfly, deferred rows)
+    out.append(("tile-1chunk", sp.csc_matrix(rng.standard_normal((100, 40)))))
+    out.append(("tile-chunks", sp.csc_matrix(rng.standard_normal((70, 300)))))
+    out.append(("tile-blockdiag", sp.block_diag([rng.standard_normal((80, 12)) for _ in range(6)], format="csc")))
+    out.append(("tile-mixed", sp.vstack([sp.csc_matrix(rng.standard_normal((48, 150))),
+                                         sp.random(120, 150, density=0.05, format="csc", random_state=rng, data_rvs=rng.standard_normal),
+                                         sp.csc_matrix(rng.standard_normal((20, 150)))]).tocsc()))
     out.append(("all-zero", sp.csc_matrix((6, 9))))
     return out
 

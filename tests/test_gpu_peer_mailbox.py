@@ -1,0 +1,199 @@
+"""
+GPU tests of the peer-mailbox scalar exchange (include/foship.h fos_peer_*; SURVEY.md 8(e) exchange step): TWO ranks
+-- two processes, both on cuda:0, each holding its cone shard -- exchange the CG / tau-row / GAPA / status sums
+through mailboxes mapped with HIP IPC, with no collective library involved.  (The GPU boxes of the test pool have
+one device; ranks on different devices use the same code, the mapping then goes over xGMI.)
+
+Checked: the self test (exact sums), that both ranks compute bit-identical scalars (same CG counts, same tau/kappa),
+that the gathered iterate equals the unsharded single-handle run to rounding while the CG counts agree, the status
+sums against the oracle on the gathered point, and that a missing peer ends in FOS_ECOMM instead of a hang.
+"""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+ITERS = 12
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem(pkg, kind):
+    w = pkg.workloads
+    if kind == "sdp":
+        return w.c4_block_sdp(nblocks=8, k=16, p=6)
+    return w.c5_mixed(nblocks=4, nb_cols=40, nonneg=12, nsoc=3, socdim=5, npsd=2, k=6, density=0.2)
+
+
+def _alg(pkg, name):
+    return {"DR": pkg.DR, "GAPA": pkg.GAPA, "FISTA": pkg.FISTA}[name]()
+
+
+def _worker(rank, world, port, kind, algname, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # host-side handle exchange only
+    try:
+        prob = _problem(pkg, kind)
+        lp = pkg.sharding.shard_problem(prob, world, rank).problem
+        dev = pkg.HipHSDE(lp.A, lp.b, lp.c, lp.K1, lp.K2)
+        handles = [None] * world
+        dist.all_gather_object(handles, dev.peer_export())
+        dev.peer_open(world, rank, handles, timeout_s=10.0)
+        dist.barrier()
+        ok = dev.peer_selftest(48)
+        oks = [None] * world
+        dist.all_gather_object(oks, ok)
+        if not all(oks):
+            q.put((rank, "selftest failed: %s" % oks))
+            return
+        dev.peer_enable(True)
+        dev.set_alg(_alg(pkg, algname))
+        dev.set_iterate(None)
+        cg, a12 = [], []
+        for i in range(1, ITERS + 1):
+            dev.step(i, 1, 10 ** 9, 1e-9)
+            cg.append(dev.cgiter())
+            a12.append(dev.alpha12())
+            if i == 1:
+                z2 = dev.get_iterate()
+        z = dev.get_iterate()
+        zs, res = dev.getsol(force_check=True, eps=1e-6)
+        q.put((rank, dict(z=z, z2=z2, cg=cg, a12=a12, zs=zs,
+                          res={k: getattr(res, k) for k in ("p", "d", "g", "ctx", "bty", "kappa", "tau", "norm_b", "norm_c")})))
+        dist.barrier()
+        dev.close()
+    except Exception as exc:  # noqa: BLE001
+        q.put((rank, "error: %r" % (exc,)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(kind, algname):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, algname, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, payload = q.get(timeout=240)
+        got[r] = payload
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        assert isinstance(got[r], dict), got[r]
+    return got
+
+
+@pytest.mark.parametrize("kind,algname", [("sdp", "DR"), ("mixed", "GAPA"), ("mixed", "FISTA")])
+def test_two_ranks_one_gpu_match_unsharded(pkg, oracle, kind, algname):
+    orc = oracle
+    got = _run(kind, algname)
+    prob = _problem(pkg, kind)
+    shards = [pkg.sharding.shard_problem(prob, 2, r) for r in range(2)]
+    # both ranks saw the same scalars: identical CG counts, alpha12 history, tau/kappa entries, status values
+    assert got[0]["cg"] == got[1]["cg"]
+    assert got[0]["a12"] == got[1]["a12"]
+    l0 = shards[0].problem.m + shards[0].problem.n + 1
+    l1 = shards[1].problem.m + shards[1].problem.n + 1
+    assert got[0]["z"][l0 - 1] == got[1]["z"][l1 - 1] and got[0]["z"][-1] == got[1]["z"][-1]
+    assert got[0]["res"] == got[1]["res"]
+    # unsharded run on one handle
+    dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    dev.set_alg(_alg(pkg, algname))
+    dev.set_iterate(None)
+    cg = []
+    for i in range(1, ITERS + 1):
+        dev.step(i, 1, 10 ** 9, 1e-9)
+        cg.append(dev.cgiter())
+        if i == 1:
+            x2 = dev.get_iterate()
+    x = dev.get_iterate()
+    xs, res = dev.getsol(force_check=True, eps=1e-6)
+    dev.close()
+    z = pkg.sharding.local_to_global([got[r]["z"] for r in range(2)], shards)
+    assert got[0]["cg"][:4] == cg[:4]
+    # after the first outer iteration only the summation order differs (measured ~5e-10: that CG call already amplifies
+    # rounding); later the loose early CG tolerances amplify the difference further
+    # difference (plain CG on the indefinite KKT system, see tests/test_gpu_parity.py), so the end point is compared
+    # inside the envelope those tolerances allow
+    z2 = pkg.sharding.local_to_global([got[r]["z2"] for r in range(2)], shards)
+    assert np.linalg.norm(z2 - x2) <= 1e-7 * max(1.0, np.linalg.norm(x2))
+    assert np.linalg.norm(z - x) <= 0.05 * max(1.0, np.linalg.norm(x))
+    # global norms and the status sums of the sharded check vs the unsharded one / the oracle on the gathered point
+    assert got[0]["res"]["norm_b"] == pytest.approx(res.norm_b, rel=1e-13)
+    assert got[0]["res"]["norm_c"] == pytest.approx(res.norm_c, rel=1e-13)
+    zs = pkg.sharding.local_to_global([got[r]["zs"] for r in range(2)], shards)
+    codes = lambda cs: [(orc.CONE_CODES[k], l) for k, l in cs]
+    mo = orc.Model(prob.A, prob.b, prob.c, codes(prob.K1), codes(prob.K2))
+    st = orc.HSDEStatus(mo, 10, 1e-6, 0, 1)
+    st.i = 1
+    st.checkstatus(zs, override=True)
+    for key in ("p", "d", "g", "ctx", "bty"):
+        assert got[0]["res"][key] == pytest.approx(st.last[key], rel=1e-9, abs=1e-12), key
+
+
+def test_selftest_single_rank_and_fallback(pkg):
+    """nranks = 1: the exchange is a loop-back through the rank's own mailbox; enabling/disabling keeps the results."""
+    prob = pkg.workloads.small_mixed()
+    ref = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    h = dev.peer_export()
+    assert len(h) == 64
+    dev.peer_open(1, 0, [h])
+    assert dev.peer_selftest(40)
+    dev.peer_enable(True)
+    for d in (ref, dev):
+        d.set_alg(pkg.GAPA())
+        d.set_iterate(None)
+        d.step(1, 15, 10 ** 9, 1e-9)
+    assert np.array_equal(ref.get_iterate(), dev.get_iterate())      # one rank: same sums in the same order
+    dev.peer_enable(False)
+    ref.step(16, 5, 10 ** 9, 1e-9)
+    dev.step(16, 5, 10 ** 9, 1e-9)
+    assert np.array_equal(ref.get_iterate(), dev.get_iterate())
+    ref.close()
+    dev.close()
+
+
+def test_missing_peer_times_out_with_error(pkg):
+    """Rank 0 of a 2-rank layout whose peer never shows up: the exchange gives up after the time-out, the self test
+    reports failure, and a solve attempted anyway returns FOS_ECOMM -- no hang."""
+    prob = pkg.workloads.small_mixed()
+    dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    ghost = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)    # second mailbox in this process: never written by a peer kernel
+    import time
+    try:
+        h0 = dev.peer_export()
+        try:
+            dev.peer_open(2, 0, [h0, ghost.peer_export()], timeout_s=0.3)
+        except pkg.lib.FosError:
+            return                      # this runtime refuses to IPC-open a handle of the same process: clean error, done
+        t0 = time.time()
+        assert dev.peer_selftest(4) is False
+        assert time.time() - t0 < 10.0
+        with pytest.raises(pkg.lib.FosError):
+            dev.peer_enable(True)       # the global-size exchange times out as well
+    finally:
+        dev.close()
+        ghost.close()

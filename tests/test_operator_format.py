@@ -17,11 +17,11 @@ def host_spmv(pkg, A, v, wg=0, waves=0):
     rowval = np.ascontiguousarray(A.indices, dtype=np.int64) + 1
     nz = np.ascontiguousarray(A.data, dtype=np.float64)
     out = np.empty(n + m)
-    stats = np.zeros(8, dtype=np.int64)
+    stats = np.zeros(12, dtype=np.int64)
     i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
     pkg.lib.check(lib.fos_host_stacked_spmv(m, n, i64(colptr), i64(rowval), pkg.lib.dptr(nz), pkg.lib.dptr(v), pkg.lib.dptr(out),
                                             wg, waves, i64(stats)))
-    return out, dict(zip(("blocks", "ell", "lds", "long", "run", "vals", "cols", "waves"), stats.tolist()))
+    return out, dict(zip(("blocks", "ell", "lds", "long", "run", "vals", "cols", "waves", "tiles", "slots", "deferred", "tile_vals"), stats.tolist()))
 
 
 def reference(A, v):
@@ -44,6 +44,19 @@ CASES = {
     "mixed-run-and-indexed": lambda rng: sp.vstack([sp.csc_matrix(rng.standard_normal((20, 300))),
                                                     sp.random(200, 300, density=0.05, format="csc", random_state=rng,
                                                               data_rvs=rng.standard_normal)]).tocsc(),
+    # dual tiles (dense rectangles stored once): one chunk, several chunks (C > 128), ragged tails, sparse neighbours that
+    # leave columns partially covered (deferred rows with an own partial), rectangles next to each other
+    "tile-single-chunk": lambda rng: sp.csc_matrix(rng.standard_normal((100, 40))),
+    "tile-multi-chunk": lambda rng: sp.csc_matrix(rng.standard_normal((70, 300))),
+    "tile-block-diag": lambda rng: sp.block_diag([rng.standard_normal((80, 12)) for _ in range(6)], format="csc"),
+    "tile-plus-sparse-rows": lambda rng: sp.vstack([sp.csc_matrix(rng.standard_normal((48, 150))),
+                                                    sp.random(120, 150, density=0.05, format="csc", random_state=rng,
+                                                              data_rvs=rng.standard_normal),
+                                                    sp.csc_matrix(rng.standard_normal((20, 150)))]).tocsc(),
+    "tile-offset-runs": lambda rng: sp.bmat([[sp.csc_matrix(rng.standard_normal((33, 17))), None],
+                                             [None, sp.csc_matrix(rng.standard_normal((64, 9)))],
+                                             [sp.csc_matrix(rng.standard_normal((16, 17))), sp.csc_matrix(rng.standard_normal((16, 9)))]],
+                                            format="csc"),
     "row-of-2048+": lambda rng: sp.csc_matrix(rng.standard_normal((2, 2049))),
     "row-of-exactly-2048": lambda rng: sp.csc_matrix(rng.standard_normal((3, 2048))),
 }
@@ -59,7 +72,14 @@ def test_block_format_reproduces_spmv(pkg, name, waves):
     out, st = host_spmv(pkg, A, v, waves=waves)
     ref = reference(A, v)
     assert np.allclose(out, ref, rtol=1e-13, atol=1e-13), (name, st)
-    assert st["ell"] + st["lds"] + st["long"] == st["blocks"]
+    assert st["ell"] + st["lds"] + st["long"] + st["tiles"] == st["blocks"]
+    if name.startswith("tile-"):
+        assert st["tiles"] > 0 and st["deferred"] > 0 and st["tile_vals"] > 0, st
+        if name in ("tile-single-chunk", "tile-multi-chunk"):
+            # (nearly) every entry lives in a tile, once: the stored values are about nnz, not 2 nnz
+            assert st["tile_vals"] >= 0.6 * A.nnz and st["vals"] < 1.7 * A.nnz, st
+    if name in ("sparse-random", "identity", "banded", "empty", "one-entry", "power-law-rows", "block-diag-dense", "dense-long-rows"):
+        assert st["tiles"] == 0 and st["deferred"] == 0 and st["slots"] == 0, st     # nothing rectangular enough
     if name in ("dense-long-rows", "dense-tall", "block-diag-dense", "identity", "banded", "row-of-2048+"):
         assert st["run"] == st["blocks"] - st["lds"], st   # consecutive columns everywhere -> index-compressed (LDS blocks never are)
     if name in ("dense-long-rows", "dense-tall", "block-diag-dense"):
