@@ -95,6 +95,10 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     }
 
     // ---- dual tiles: groups of <= 64 consecutive rows of A that are the same run of columns (fos_internal.hpp, BLK_TILE)
+    // columns per tile.  Measured on the dense LP (C2, rows of 10 000 entries): 32: 112 us, 64: 100 us, 128: 110 us per KKT
+    // apply -- narrower tiles shorten a wavefront's serial chain, but every chunk adds a row-partial slot per row
+    int64_t tcmax = TILE_TC_MAX;
+    if (getenv("FOS_TILE_TC")) tcmax = std::max(TILE_GROUP, atoi(getenv("FOS_TILE_TC")) / TILE_GROUP * TILE_GROUP);
     struct Group { int64_t i0; int R; int32_t c0; int64_t C; int nchunk; int64_t first_tile; };
     std::vector<Group> groups;
     std::vector<int32_t> tile_of(m, -1);
@@ -105,12 +109,12 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             int64_t j = i + 1;
             while (j < m && j - i < WROWS && is_run[n + j] && alen[j] == alen[i] && first_col[n + j] == first_col[n + i]) ++j;
             // worth it only if the lane-major tile (64 lanes x padded steps) stores no more than the two copies it replaces
-            const int64_t nch = (alen[i] + TILE_TC_MAX - 1) / TILE_TC_MAX;
-            const int64_t steps = (alen[i] - (nch - 1) * TILE_TC_MAX + TILE_GROUP - 1) / TILE_GROUP * TILE_GROUP + (nch - 1) * TILE_TC_MAX;
+            const int64_t nch = (alen[i] + tcmax - 1) / tcmax;
+            const int64_t steps = (alen[i] - (nch - 1) * tcmax + TILE_GROUP - 1) / TILE_GROUP * TILE_GROUP + (nch - 1) * tcmax;
             if (j - i >= TILE_MIN_ROWS && 64 * steps <= 2 * (j - i) * alen[i]) {
                 Group g;
                 g.i0 = i; g.R = (int)(j - i); g.c0 = first_col[n + i]; g.C = alen[i];
-                g.nchunk = (int)((g.C + TILE_TC_MAX - 1) / TILE_TC_MAX);
+                g.nchunk = (int)((g.C + tcmax - 1) / tcmax);
                 g.first_tile = 0;
                 for (int64_t q = i; q < j; ++q) tile_of[q] = (int32_t)groups.size();
                 groups.push_back(g);
@@ -187,11 +191,11 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     int64_t r = 0;
     while (r < nrows) {
         if (r >= n && tile_of[r - n] >= 0) {
-            // ---- the tile blocks of this group of rows, one per chunk of TILE_TC_MAX columns
+            // ---- the tile blocks of this group of rows, one per chunk of tcmax columns
             Group& g = groups[tile_of[r - n]];
             g.first_tile = (int64_t)tiles.size();
             for (int k = 0; k < g.nchunk; ++k) {
-                const int64_t tc = std::min<int64_t>(TILE_TC_MAX, g.C - (int64_t)k * TILE_TC_MAX);
+                const int64_t tc = std::min<int64_t>(tcmax, g.C - (int64_t)k * tcmax);
                 const int64_t tpad = (tc + TILE_GROUP - 1) / TILE_GROUP * TILE_GROUP;
                 BlkDesc d;
                 d.nnz0 = align(pos);
@@ -232,7 +236,9 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             // LONG_ROWS at a time: the gathered vector element is loaded once per LONG_ROWS matrix values
             int64_t nr = 1;
             if (run0) {
-                while (nr < LONG_ROWS && r + nr < r_lim && (rp[r + nr + 1] - rp[r + nr]) == len0 &&
+                // (at most 16384 entries per block: a wavefront walks its block serially, and a few very long rows
+                // left over next to dual tiles must not become the tail of the whole sweep)
+                while (nr < LONG_ROWS && (nr + 1) * len0 <= 16384 && r + nr < r_lim && (rp[r + nr + 1] - rp[r + nr]) == len0 &&
                        first_col[r + nr] == first_col[r]) ++nr;
                 if (nr == 3) nr = 2;
             }
@@ -341,10 +347,10 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     }
     for (const TileRec& t : tiles) {
         const BlkDesc& d = S.blk[t.blk];
-        S.col[d.colpos] = groups[t.group].c0 + t.chunk * TILE_TC_MAX;
+        S.col[d.colpos] = groups[t.group].c0 + t.chunk * tcmax;
         S.col[d.colpos + 1] = t.cslot;
         S.col[d.colpos + 2] = t.rslot;
-        S.col[d.colpos + 3] = (int32_t)std::min<int64_t>(TILE_TC_MAX, groups[t.group].C - (int64_t)t.chunk * TILE_TC_MAX);
+        S.col[d.colpos + 3] = (int32_t)std::min<int64_t>(tcmax, groups[t.group].C - (int64_t)t.chunk * tcmax);
     }
     auto place = [&](int64_t row, int64_t e) -> int64_t {        // offset of entry e of `row` relative to its block base
         const int64_t tpr = row_tpr[row];
@@ -363,7 +369,7 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         }
     }
     // ---- fill A rows by a counting transpose (column order inside each row = ascending column index); tile rows go
-    //      lane-major into their tile: value (row i0 + lane, column c0 + chunk * TILE_TC_MAX + t) at nnz0 + 64 t + lane
+    //      lane-major into their tile: value (row i0 + lane, column c0 + chunk * tcmax + t) at nnz0 + 64 t + lane
     {
         std::vector<int64_t> fill(m, 0);
         for (int64_t j = 0; j < n; ++j) {
@@ -372,8 +378,8 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
                 if (tile_of[i] >= 0) {
                     const Group& g = groups[tile_of[i]];
                     const int64_t cc = j - g.c0;
-                    const TileRec& t = tiles[g.first_tile + cc / TILE_TC_MAX];
-                    S.val[S.blk[t.blk].nnz0 + (cc % TILE_TC_MAX) * 64 + (i - g.i0)] = nzval[k];
+                    const TileRec& t = tiles[g.first_tile + cc / tcmax];
+                    S.val[S.blk[t.blk].nnz0 + (cc % tcmax) * 64 + (i - g.i0)] = nzval[k];
                     continue;
                 }
                 const int64_t off = place(n + i, fill[i]++);
@@ -395,8 +401,8 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             if (S.row_defer[j] >= 0) idx[cur[j]++] = S.row_defer[j];
         for (const TileRec& t : tiles) {
             const Group& g = groups[t.group];
-            const int64_t cc0 = g.c0 + (int64_t)t.chunk * TILE_TC_MAX;
-            const int64_t tc = std::min<int64_t>(TILE_TC_MAX, g.C - (int64_t)t.chunk * TILE_TC_MAX);
+            const int64_t cc0 = g.c0 + (int64_t)t.chunk * tcmax;
+            const int64_t tc = std::min<int64_t>(tcmax, g.C - (int64_t)t.chunk * tcmax);
             for (int64_t c = 0; c < tc; ++c) idx[cur[cc0 + c]++] = t.cslot + (int32_t)c;
             if (t.rslot >= 0)
                 for (int q = 0; q < g.R; ++q) idx[cur[n + g.i0 + q]++] = t.rslot + q;

@@ -60,7 +60,7 @@ enum BlkKind : int32_t { BLK_LDS = 0, BLK_ELL = 1, BLK_LONG = 2, BLK_TILE = 3 };
 // order and runs the row epilogue.  Halves the matrix bytes of dense operators (C2, C4).
 constexpr int TILE_MIN_ROWS = 16;   // fewer rows: not worth a 64-lane wavefront
 constexpr int TILE_MIN_COLS = 8;
-constexpr int TILE_TC_MAX = 128;    // columns (steps) per tile: 64 KB of values per wavefront work unit
+constexpr int TILE_TC_MAX = 64;     // columns (steps) per tile: 32 KB of values per wavefront work unit (measured best on C2: 32..128 tried)
 constexpr int TILE_GROUP = 8;       // steps per butterfly; stored steps are padded to a multiple
 
 struct BlkDesc {                    // one row block = the unit of work of ONE wavefront (32 bytes)

@@ -8,8 +8,6 @@ Checked: the self test (exact sums), that both ranks compute bit-identical scala
 that the gathered iterate equals the unsharded single-handle run to rounding while the CG counts agree, the status
 sums against the oracle on the gathered point, and that a missing peer ends in FOS_ECOMM instead of a hang.
 """
-import os
-import socket
 import sys
 from pathlib import Path
 
@@ -20,14 +18,6 @@ pytestmark = pytest.mark.gpu
 
 ROOT = Path(__file__).resolve().parent.parent
 ITERS = 12
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def _problem(pkg, kind):
@@ -41,27 +31,23 @@ def _alg(pkg, name):
     return {"DR": pkg.DR, "GAPA": pkg.GAPA, "FISTA": pkg.FISTA}[name]()
 
 
-def _worker(rank, world, port, kind, algname, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+def _worker(rank, world, kind, algname, q_out, q_in):
+    """One rank.  The parent relays the 64-byte handles and acts as the barrier (plain multiprocessing queues: no
+    torch.distributed, no sockets)."""
     sys.path.insert(0, str(ROOT))
-    import torch.distributed as dist
     import __graft_entry__ as ge
     pkg = ge.load_package()
-    dist.init_process_group("gloo", rank=rank, world_size=world)      # host-side handle exchange only
     try:
         prob = _problem(pkg, kind)
         lp = pkg.sharding.shard_problem(prob, world, rank).problem
         dev = pkg.HipHSDE(lp.A, lp.b, lp.c, lp.K1, lp.K2)
-        handles = [None] * world
-        dist.all_gather_object(handles, dev.peer_export())
+        q_out.put((rank, "handle", dev.peer_export()))
+        handles = q_in.get(timeout=120)
         dev.peer_open(world, rank, handles, timeout_s=10.0)
-        dist.barrier()
-        ok = dev.peer_selftest(48)
-        oks = [None] * world
-        dist.all_gather_object(oks, ok)
-        if not all(oks):
-            q.put((rank, "selftest failed: %s" % oks))
+        q_out.put((rank, "opened", None))
+        q_in.get(timeout=120)                                   # barrier: every rank has mapped every mailbox
+        q_out.put((rank, "selftest", dev.peer_selftest(48)))
+        if not q_in.get(timeout=120):
             return
         dev.peer_enable(True)
         dev.set_alg(_alg(pkg, algname))
@@ -75,34 +61,55 @@ def _worker(rank, world, port, kind, algname, q):
                 z2 = dev.get_iterate()
         z = dev.get_iterate()
         zs, res = dev.getsol(force_check=True, eps=1e-6)
-        q.put((rank, dict(z=z, z2=z2, cg=cg, a12=a12, zs=zs,
-                          res={k: getattr(res, k) for k in ("p", "d", "g", "ctx", "bty", "kappa", "tau", "norm_b", "norm_c")})))
-        dist.barrier()
+        q_out.put((rank, "result", dict(z=z, z2=z2, cg=cg, a12=a12, zs=zs,
+                                        res={k: getattr(res, k) for k in ("p", "d", "g", "ctx", "bty", "kappa", "tau", "norm_b", "norm_c")})))
+        q_in.get(timeout=120)                                   # keep the mailbox alive until the peer is done too
         dev.close()
     except Exception as exc:  # noqa: BLE001
-        q.put((rank, "error: %r" % (exc,)))
-    finally:
-        dist.destroy_process_group()
+        q_out.put((rank, "error", repr(exc)))
 
 
 def _run(kind, algname):
-    import torch.multiprocessing as mp
+    import multiprocessing as mp
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
     world = 2
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, algname, q)) for r in range(world)]
+    q_out = ctx.Queue()
+    q_in = [ctx.Queue() for _ in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, kind, algname, q_out, q_in[r])) for r in range(world)]
     for p in procs:
         p.start()
-    got = {}
-    for _ in range(world):
-        r, payload = q.get(timeout=240)
-        got[r] = payload
-    for p in procs:
-        p.join(timeout=60)
-    for r in range(world):
-        assert isinstance(got[r], dict), got[r]
-    return got
+
+    def collect(tag):
+        got = {}
+        for _ in range(world):
+            r, t, payload = q_out.get(timeout=180)
+            assert t == tag, (r, t, payload)
+            got[r] = payload
+        return got
+
+    try:
+        handles = collect("handle")
+        for q in q_in:
+            q.put([handles[r] for r in range(world)])
+        collect("opened")
+        for q in q_in:
+            q.put(True)
+        oks = collect("selftest")
+        ok = all(oks.values())
+        for q in q_in:
+            q.put(ok)
+        assert ok, "mailbox self test failed: %s" % oks
+        got = collect("result")
+        for q in q_in:
+            q.put(True)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0, p.exitcode
+        return got
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
 
 
 @pytest.mark.parametrize("kind,algname", [("sdp", "DR"), ("mixed", "GAPA"), ("mixed", "FISTA")])
