@@ -194,6 +194,12 @@ def main():
     value = args.steps / elapsed
     avg_kernel_ms = kms / max(1, launches)
     achieved = kbytes / (avg_kernel_ms * 1e-3) / 1e9 if launches else 0.0
+    # what the device format actually streams per KKT apply (model, not a counter): stored values + stored column indices +
+    # block descriptors + partial-sum slots (written by the sweep, read by the deferred-row kernel) + vectors in/out + [c;b]
+    ost = dev.operator_stats()
+    stored_bytes = (8.0 * ost["vals"] + 4.0 * ost["cols"] + 32.0 * ost["blocks"] + 2 * 16.0 * ost["slots"]
+                    + 2 * 16.0 * (prob.m + prob.n) + 8.0 * (prob.m + prob.n))
+    stored_gbs = stored_bytes / (avg_kernel_ms * 1e-3) / 1e9 if launches else 0.0
     out = {
         "metric": "GAP/DR outer iterations/sec (+ achieved HBM GB/s of the CG SpMV in `roofline`)",
         "value": round(value, 4),
@@ -218,7 +224,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "kkt2_kernel (fused dual-RHS KKT SpMV)",
+            "kernel": "kkt2_kernel (fused dual-RHS KKT SpMV)" + (" + kkt2_deferred_kernel (rows spread over dual tiles)" if ost["tiles"] else ""),
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -227,6 +233,13 @@ def main():
             "traffic": traffic,
             "traffic_note": "bytes per launch from rocprofv3 PMC passes committed under profiles/ (not collected in this run)" if traffic else None,
             "algorithmic_bytes_per_launch": kbytes,
+            "stored_bytes_per_launch_model": stored_bytes,
+            "stored_gbs": round(stored_gbs, 1),
+            "frac_stored": round(stored_gbs / HBM_PEAK_GBS, 4),
+            "note": ("algorithmic bytes follow SURVEY 8(d) (A and A' each streamed once per dual-RHS apply); dual tiles store dense "
+                     "rectangles of A once for both products, so the sweep moves fewer bytes than that and `frac` can exceed 1; "
+                     "`frac_stored` prices the bytes the format really streams") if ost["tiles"] else None,
+            "operator_format": ost,
             "avg_kernel_ms": round(avg_kernel_ms, 5),
             "launches_timed": launches,
             "kernel_share_of_step": round(kms / (1e3 * elapsed), 4) if elapsed > 0 else None,

@@ -275,6 +275,13 @@ class HipHSDE:
         _lib.check(self._lib.fos_bench_kkt(self._h, reps, C.byref(ms)))
         return ms.value
 
+    def operator_stats(self):
+        """Format statistics of the device operator (fos_operator_stats)."""
+        st = (C.c_int64 * 12)()
+        _lib.check(self._lib.fos_operator_stats(self._h, st))
+        keys = ("blocks", "ell", "lds", "long", "run", "vals", "cols", "waves", "tiles", "slots", "deferred", "tile_vals")
+        return dict(zip(keys, list(st)))
+
     def sync(self):
         _lib.check(self._lib.fos_sync(self._h))
 

@@ -195,6 +195,10 @@ int fos_check(fos_handle h, const double* z, double eps, fos_check_result* res);
  * fos_profile_read: synchronises and returns launches, summed kernel milliseconds, and the ALGORITHMIC
  *   bytes of one launch (B_kkt,min = 24 nnz + 4(m+n+2) + 32(m+n)); resets the counters.
  * fos_bench_kkt: `reps` back-to-back KKT-apply launches on device-resident vectors; total ms by HIP events. */
+/* fos_operator_stats: the 12 format statistics of fos_host_stacked_spmv (below) for the operator this handle holds on the
+ * device -- what the sweep actually streams: 8 B per stored value, 4 B per stored column index, 32 B per block, 16 B per
+ * partial-sum slot written and read again. */
+int fos_operator_stats(fos_handle h, int64_t* stats12);
 int fos_profile(fos_handle h, int32_t enable);
 int fos_profile_read(fos_handle h, int64_t* launches, double* total_ms, double* bytes_per_launch);
 int fos_bench_kkt(fos_handle h, int32_t reps, double* total_ms);

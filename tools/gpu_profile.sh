@@ -9,6 +9,7 @@ mkdir -p $OUT
 python bench.py                      2>&1 | tail -1 > $OUT/bench_c4.json
 python bench.py --workload C2        2>&1 | tail -1 > $OUT/bench_c2.json
 python bench.py --workload C3 --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_c3.json
+python bench.py --workload C5 --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_c5.json
 # kernel trace + stats of the SAME command as the default bench (fewer steps, no CPU leg)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c4 -- python bench.py --steps 20 --no-cpu-baseline > $OUT/trace_c4.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c2 -- python bench.py --workload C2 --steps 20 --no-cpu-baseline > $OUT/trace_c2.log 2>&1

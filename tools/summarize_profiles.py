@@ -32,9 +32,12 @@ for tag in ("trace_c4", "trace_c2"):
     # steady-state average of the dominant kernel (last 20 x cg launches) from the trace
     tf = sorted(glob.glob(os.path.join(src, tag, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     if tf:
-        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(tf[-1])) if "kkt2_kernel" in r["Kernel_Name"]]
+        trows = list(csv.DictReader(open(tf[-1])))
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in trows if "kkt2_kernel" in r["Kernel_Name"]]
+        ddef = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in trows if "kkt2_deferred_kernel" in r["Kernel_Name"]]
         real = [d for d in durs if d > 0.25 * max(durs)]      # launches enqueued past CG convergence exit at once (gated no-ops, ~3 us)
         tail = real[len(real) // 2:]
+        dreal = [d for d in ddef if d > 0.5 * max(ddef)] if ddef else []
         bj = os.path.join(src, "bench_%s.json" % tag.split("_")[1])
         ev = None
         if os.path.exists(bj):
@@ -43,13 +46,16 @@ for tag in ("trace_c4", "trace_c2"):
             except Exception:
                 ev = None
         with open(os.path.join(dst, "%s_%s_kernel_stats.md" % (rnd, tag)), "a") as f:
-            f.write("\nkkt2_kernel: %d launches, %d of them gated no-ops (enqueued past CG convergence, ~3 us each); "
+            f.write("\nkkt2_kernel (the sweep): %d launches, %d of them gated no-ops (enqueued past CG convergence, ~3 us each); "
                     "average of the real launches = %.2f us, over the second half of the run (steady state) = %.2f us\n"
                     % (len(durs), len(durs) - len(real), sum(real) / len(real) / 1e3, sum(tail) / len(tail) / 1e3))
+            if dreal:
+                f.write("kkt2_deferred_kernel (rows spread over dual tiles; second kernel of every KKT apply): average of the real "
+                        "launches = %.2f us; one KKT apply = sweep + deferred rows = %.2f us\n"
+                        % (sum(dreal) / len(dreal) / 1e3, (sum(tail) / len(tail) + sum(dreal) / len(dreal)) / 1e3))
             if ev:
-                f.write("bench.py on the same box, un-profiled, HIP events around the same launches: %.2f us "
-                        "(kernel-trace instrumentation slows the C4 sweep by up to ~10 %%: its 17 MB gathered vector is "
-                        "colder in L2 between instrumented dispatches; C2, whose vector is 0.24 MB, agrees within 2 %%)\n" % ev)
+                f.write("bench.py on the same box, un-profiled, HIP events around the same launches (both kernels of an apply): "
+                        "%.2f us\n" % ev)
 
 for tag, counter in (("pmc_fetch_c4", "FETCH_SIZE"), ("pmc_write_c4", "WRITE_SIZE")):
     files = sorted(glob.glob(os.path.join(src, tag, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
@@ -77,9 +83,13 @@ for wl in ("c4",):
         files = sorted(glob.glob(os.path.join(src, tag, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
         if not files:
             continue
-        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[-1])) if r.get("Counter_Name") == counter and "kkt2" in r["Kernel_Name"]]
-        v = [x for x in v if x > 0.25 * max(v)]
-        vals[counter] = sum(v) / len(v) * 1024.0
+        tot = 0.0
+        for kname in ("kkt2_kernel", "kkt2_deferred_kernel"):      # one KKT apply = sweep + deferred-row kernel
+            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[-1])) if r.get("Counter_Name") == counter and kname in r["Kernel_Name"]]
+            v = [x for x in v if x > 0.25 * max(v)] if v else []
+            if v:
+                tot += sum(v) / len(v) * 1024.0
+        vals[counter] = tot
     if len(vals) == 2:
         traffic[wl.upper()] = {"fetch_size_bytes_reported": vals["FETCH_SIZE"], "write_size_bytes_reported": vals["WRITE_SIZE"],
                                "traffic_bytes": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
@@ -88,7 +98,7 @@ for wl in ("c4",):
 if traffic:
     json.dump(traffic, open(os.path.join(dst, "%s_kkt_traffic.json" % rnd), "w"), indent=1)
 
-for b in ("bench_c4", "bench_c2", "bench_c3"):
+for b in ("bench_c4", "bench_c2", "bench_c3", "bench_c5"):
     p = os.path.join(src, b + ".json")
     if os.path.exists(p):
         txt = open(p).read().strip()
