@@ -24,6 +24,8 @@ def _problem(pkg, kind):
     w = pkg.workloads
     if kind == "sdp":
         return w.c4_block_sdp(nblocks=8, k=16, p=6)
+    if kind == "sdp-tiles":          # 36 x 8 dense blocks: stored as dual tiles, so the sharded sums include deferred-row records
+        return w.c4_block_sdp(nblocks=6, k=8, p=8)
     return w.c5_mixed(nblocks=4, nb_cols=40, nonneg=12, nsoc=3, socdim=5, npsd=2, k=6, density=0.2)
 
 
@@ -112,7 +114,7 @@ def _run(kind, algname):
                 p.kill()
 
 
-@pytest.mark.parametrize("kind,algname", [("sdp", "DR"), ("mixed", "GAPA"), ("mixed", "FISTA")])
+@pytest.mark.parametrize("kind,algname", [("sdp", "DR"), ("sdp-tiles", "DR"), ("mixed", "GAPA"), ("mixed", "FISTA")])
 def test_two_ranks_one_gpu_match_unsharded(pkg, oracle, kind, algname):
     orc = oracle
     got = _run(kind, algname)
@@ -127,6 +129,8 @@ def test_two_ranks_one_gpu_match_unsharded(pkg, oracle, kind, algname):
     assert got[0]["res"] == got[1]["res"]
     # unsharded run on one handle
     dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    if kind == "sdp-tiles":
+        assert dev.operator_stats()["tiles"] > 0
     dev.set_alg(_alg(pkg, algname))
     dev.set_iterate(None)
     cg = []
