@@ -122,23 +122,38 @@ def main():
         # otherwise the in-stream RCCL all-reduce set up above.  FOS_REDUCTION=rccl|peer|auto (default auto).
         want = os.environ.get("FOS_REDUCTION", "auto")
         if want != "rccl":
+            # every collective below is executed by every rank in the same order, whatever fails locally
+            def agree(ok):
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return int(flag.item()) == 1
             try:
-                handles = [None] * world
-                dist.all_gather_object(handles, dev.peer_export())
-                dev.peer_open(world, rank, handles, timeout_s=20.0)
-                dev.sync()
+                mine = dev.peer_export()
+            except Exception as exc:                      # no uncached allocation / IPC export on this device
+                print("rank %d: peer mailbox export failed (%s)" % (rank, exc), file=sys.stderr, flush=True)
+                mine = None
+            handles = [None] * world
+            dist.all_gather_object(handles, mine)
+            ok = all(h is not None for h in handles)
+            if ok:
+                try:
+                    dev.peer_open(world, rank, handles, timeout_s=20.0)
+                    dev.sync()
+                except Exception as exc:                  # IPC mapping not available between these devices
+                    print("rank %d: peer mailboxes unavailable (%s)" % (rank, exc), file=sys.stderr, flush=True)
+                    ok = False
+            if agree(ok):
                 dist.barrier()
-                ok = dev.peer_selftest(64)
-            except Exception as exc:                      # IPC not available between these devices
-                print("rank %d: peer mailboxes unavailable (%s)" % (rank, exc), file=sys.stderr, flush=True)
-                ok = False
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                dev.peer_enable(True)
-                reduction = "peer mailboxes over xGMI (HIP IPC)"
-            elif want == "peer":
-                raise SystemExit("FOS_REDUCTION=peer but the mailbox self test failed")
+                try:
+                    ok = dev.peer_selftest(64)
+                except Exception as exc:
+                    print("rank %d: peer mailbox self test raised (%s)" % (rank, exc), file=sys.stderr, flush=True)
+                    ok = False
+                if agree(ok):
+                    dev.peer_enable(True)
+                    reduction = "peer mailboxes over xGMI (HIP IPC)"
+            if want == "peer" and not reduction.startswith("peer"):
+                raise SystemExit("FOS_REDUCTION=peer but the peer mailboxes are not usable")
     if args.spmv_wg:
         dev.set_tuning(spmv_workgroups=args.spmv_wg)
     dev.set_alg(alg)

@@ -22,11 +22,13 @@ What it restates (paths under /root/reference; every function cites the lines it
 Third-party arithmetic NOT under /root/reference: the per-cone projections are calls into
 ProximalOperators.jl (Project.toml:10, version UNPINNED, no Manifest).  They are restated
 here from that package's published algorithm (IndFree/IndZero/IndPoint/IndNonnegative/
-IndNonpositive/IndSOC/IndRotatedSOC/IndPSD(scaling=true)).  Pinning status:
+IndNonpositive/IndSOC/IndRotatedSOC/IndPSD(scaling=true)/IndExpPrimal/IndExpDual).  Pinning status:
   * IndPSD: pinned by the reference's RNG-free known answer test/testPSD.jl:3-4,14-25.
   * IndNonnegative / Zero / Free: pinned through the DR/GAPA solves of test/testDRandGAPA.jl
     (problem shape; Julia's RNG stream is unavailable, optimum checked with scipy nnls).
-  * IndSOC / IndRotatedSOC: PARITY UNPINNED -- no reference test touches them.
+  * IndSOC / IndRotatedSOC / IndExpPrimal / IndExpDual: PARITY UNPINNED -- no reference test touches them
+    (the exponential cone follows the SCS-style bisection + Newton projection; checked here only through the
+    projection's optimality conditions).
 The Julia reference itself cannot be executed in the build container (no julia binary), so
 the oracle is pinned against the reference's own tests restated in tests/test_oracle_*.py
 (identities vs dense linear algebra, CG property test, PSD known answer, print formats).
