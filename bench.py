@@ -261,7 +261,7 @@ def main():
         },
     }
 
-    # ---- CPU baseline (rank 0, N = 1): the oracle restatement, one core, ONE steady-state outer iteration
+    # ---- CPU baseline (rank 0, N = 1): the C port of the oracle restatement on one core (+ all cores), bounded sample
     if world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, str(ROOT / "oracle"))
         import fos_oracle as orc
@@ -288,16 +288,59 @@ def main():
         if isinstance(oalg, orc.FISTA):
             cpu = None          # FISTA's y/xold/t live on the device only; skip the hand-off
         else:
+            # (1) parity cross-check: ONE outer iteration of the numpy oracle and of the GPU from the same state
             tc = time.perf_counter()
             oalg.step(xo, it + 1, ost)
-            tcpu = time.perf_counter() - tc
+            t_np = time.perf_counter() - tc
+            cg_cpu = oalg.S1.getcgiter()
+            # (2) the timed baseline: the plain-C port (oracle/fos_cport.c, checked against the oracle in tests/test_cport.py)
+            #     from the same state, a bounded sample of >= ~10 s (at most 8 iterations); one thread like the
+            #     single-threaded reference, then all host cores (OpenMP: rows/columns of A, vector passes, cones)
+            import fos_cport as cport
+            codes = lambda cs: [(orc.CONE_CODES[k], l) for k, l in cs]
+
+            def time_cport(threads, budget_s):
+                cp = cport.CPort(prob.A, prob.b, prob.c, codes(prob.K1), codes(prob.K2), threads=threads)
+                cp.set_affine_state(xinit, pi)
+                xc = np.ascontiguousarray(z, dtype=np.float64).copy()
+                a12 = dev.alpha12() if isinstance(oalg, orc.GAPA) else 2.0
+                n_it, t0c, cgs = 0, time.perf_counter(), []
+                while n_it < 8 and (n_it == 0 or time.perf_counter() - t0c < budget_s):
+                    if isinstance(oalg, orc.GAPA):
+                        a12 = cp.gapa_step(xc, alg.alpha, alg.beta, a12)
+                    else:
+                        cp.gap_step(xc, alg.alpha, alg.alpha1, alg.alpha2)
+                    cgs.append(cp.cgiter())
+                    n_it += 1
+                dt = time.perf_counter() - t0c
+                cp.close()
+                return n_it / dt, n_it, dt, cgs
+
+            v1, n1, dt1, cgs1 = time_cport(1, 10.0)
+            try:                                  # (threadpool_limits(1) above also caps OpenMP's default team size; the C
+                ncores = len(os.sched_getaffinity(0))   # port passes num_threads explicitly, so ask the OS for the core count)
+            except Exception:
+                ncores = os.cpu_count() or 1
+            try:                                  # a container's CPU quota, when there is one
+                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if quota != "max":
+                    ncores = max(1, min(ncores, int(float(quota) / float(period) + 0.5)))
+            except Exception:
+                pass
+            ncores = min(ncores, 32)              # beyond ~32 threads the fork/join of every vector pass dominates (measured:
+                                                  # 256 threads are 20x slower than one)
+            vall = time_cport(ncores, 5.0) if ncores > 1 else None
             dev.step(it + 1, 1, BIG, 1e-8)
             zg = dev.get_iterate()
             cpu = {
-                "value": round(1.0 / tcpu, 5), "unit": "iterations/s", "cores": 1, "kind": "port",
-                "sample": "1 steady-state outer iteration (i=%d, %d CG iterations) of oracle/fos_oracle.py (numpy/scipy, "
-                          "CSC SpMV as the reference: 4 sweeps per KKT apply) from the GPU's state" % (it + 1, oalg.S1.getcgiter()),
-                "seconds": round(tcpu, 3),
+                "value": round(v1, 5), "unit": "iterations/s", "cores": 1, "kind": "port",
+                "sample": "%d steady-state outer iterations (from i=%d, %s CG iterations each) of oracle/fos_cport.c -- plain C, "
+                          "CSC scatter/gather SpMV and 4 sweeps per KKT apply as the reference, one thread -- from the GPU's state, "
+                          "%.1f s" % (n1, it + 1, "/".join(map(str, cgs1[:4])), dt1),
+                "seconds": round(dt1, 3),
+                "multi_core": ({"value": round(vall[0], 5), "cores": ncores, "iterations": vall[1], "seconds": round(vall[2], 3),
+                               "how": "same C port, OpenMP over rows/columns of A, vector passes and cones"} if vall else None),
+                "numpy_oracle_same_step": {"value": round(1.0 / t_np, 5), "seconds": round(t_np, 3), "cg_iters": cg_cpu},
                 "gpu_vs_cpu_same_step_rel_dev": float(np.linalg.norm(zg - xo) / max(1.0, np.linalg.norm(xo))),
                 "gpu_cg_iters_same_step": dev.cgiter(),
             }
