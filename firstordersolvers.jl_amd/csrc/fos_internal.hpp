@@ -111,7 +111,9 @@ struct DevBlkCsr {
     const int32_t* def_idx;
     int32_t ndef, nwg_def;             // deferred rows, workgroups of the deferred-row kernel
     int32_t def_lpr;                   // lanes per deferred row (power of two <= 64)
-    int32_t npart;                     // per-workgroup partial-sum records a sweep produces = nwg + nwg_def
+    int32_t npart, part_off;           // the partial-sum records a sweep leaves for its consumers: `npart` records starting at
+                                       // record `part_off` (no tiles: the sweep's nwg; tiles: the deferred-row kernel folds the
+                                       // sweep's records into its own nwg_def, stored behind them)
 };
 
 // Builds S = [[0, A'],[A, 0]] from Julia CSC (1-based).  Returns FOS_EINVAL on malformed input.
@@ -207,7 +209,7 @@ void launch_cg_init_finalize(const LaunchCtx& c, const double2* r, double tol, i
 void launch_cg_finalize_pupdate(const LaunchCtx& c, double2* p, const double2* r, int from_reduced, int j);
 // tau rows of Ap, alpha = rn/(Ap.p), x += alpha p, r -= alpha Ap in one launch; its r.r partials go to partials + 3*16392
 void launch_cg_alpha_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, double2* Ap, int from_reduced, int j);
-void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate);   // partials[count x nacc] -> reduced[nacc] (+ peer exchange)
+void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate, int off = 0);   // partials[off.. +count][nacc] -> reduced[nacc] (+ peer exchange)
 
 // outer-loop vector kernels (gap.jl:48,58,78; gapa.jl:67,77,96-103; fista.jl:31-46; dykstra.jl)
 void launch_axpby(const LaunchCtx& c, double2* out, double a, const double2* x, double b, const double2* y);          // out = a x + b y

@@ -534,6 +534,16 @@ __device__ __forceinline__ void deferred_rows(const DevBlkCsr& S, Epi& epi) {
         if (ok && lig == 0) epi.row(row, u1, u2, pr);
     }
 }
+// The sweep left nwg partial-sum records; the deferred-row kernel runs after it anyway, so each of its nwg_def workgroups
+// also folds a slice of them into its own record: the consumers (every workgroup of cg_alpha_update re-reduces the
+// records) then read nwg_def instead of nwg + nwg_def of them.  Thread t of workgroup b takes records b, b + nwg_def, ...
+template <int NACC>
+__device__ __forceinline__ void fold_sweep_records(const DevBlkCsr& S, const double* __restrict__ partials, double (&acc)[NACC]) {
+    for (int rec = blockIdx.x + gridDim.x * (int)threadIdx.x; rec < S.nwg; rec += gridDim.x * DEF_THREADS) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] += partials[(int64_t)rec * NACC + a];
+    }
+}
 __global__ __launch_bounds__(DEF_THREADS) void kkt2_deferred_kernel(DevBlkCsr S, const d2* __restrict__ w, d2* __restrict__ out,
                                                                     const double* __restrict__ cb, int n, int nm,
                                                                     double* __restrict__ partials, const DevState* st, int gate) {
@@ -543,6 +553,7 @@ __global__ __launch_bounds__(DEF_THREADS) void kkt2_deferred_kernel(DevBlkCsr S,
     epi.w = w; epi.out = out; epi.cb = cb; epi.n = n; epi.wt = w[nm];
     epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
     deferred_rows(S, epi);
+    fold_sweep_records<3>(S, partials, epi.acc);
     block_reduce_store<3, DEF_THREADS>(epi.acc, red, partials + 3 * (int64_t)(S.nwg + blockIdx.x));
 }
 
@@ -666,14 +677,15 @@ void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
                            (int)(c.n + c.m), c.partials, c.st, gate);
     }
 }
-void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate) {
+void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate, int off) {
+    const double* part = c.partials + (size_t)nacc * off;
     if (c.peer)
-        hipLaunchKernelGGL(reduce_kernel<true>, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, count, nacc, c.reduced, c.st, gate, *c.peer);
+        hipLaunchKernelGGL(reduce_kernel<true>, dim3(1), dim3(FIN_THREADS), 0, c.stream, part, count, nacc, c.reduced, c.st, gate, *c.peer);
     else
-        hipLaunchKernelGGL(reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, count, nacc, c.reduced, c.st, gate, PeerBox{});
+        hipLaunchKernelGGL(reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, c.stream, part, count, nacc, c.reduced, c.st, gate, PeerBox{});
 }
 void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int gate, int from_reduced) {
-    hipLaunchKernelGGL(kkt_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.npart, c.reduced,
+    hipLaunchKernelGGL(kkt_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials + 3 * (size_t)c.S.part_off, c.S.npart, c.reduced,
                        from_reduced, w, out, (int)(c.n + c.m), c.st, gate);
 }
 
@@ -756,6 +768,7 @@ __global__ __launch_bounds__(DEF_THREADS) void q1_deferred_kernel(DevBlkCsr S, c
     for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
     epi.init(vcomp[2 * (int64_t)nm]);
     deferred_rows(S, epi);
+    fold_sweep_records<NACC>(S, partials, epi.acc);
     block_reduce_store<NACC, DEF_THREADS>(epi.acc, red, partials + NACC * (int64_t)(S.nwg + blockIdx.x));
 }
 template <class Epi, int NACC>
@@ -823,11 +836,11 @@ void launch_q1(const LaunchCtx& c, QMode mode, const double2* v, int comp, doubl
 }
 void launch_q1_finalize(const LaunchCtx& c, QMode mode, const double2* v, int comp, double sign, void* out, int from_reduced) {
     (void)comp;
-    hipLaunchKernelGGL(q1_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.npart, c.reduced,
+    hipLaunchKernelGGL(q1_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials + (size_t)c.S.part_off, c.S.npart, c.reduced,
                        from_reduced, (int)mode, v, sign, out, (int)(c.n + c.m));
 }
 void launch_status_finalize(const LaunchCtx& c, const double2* z, int from_reduced) {
-    hipLaunchKernelGGL(status_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.S.npart, c.reduced,
+    hipLaunchKernelGGL(status_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials + 6 * (size_t)c.S.part_off, c.S.npart, c.reduced,
                        from_reduced, z, (int)(c.n + c.m), c.st);
 }
 

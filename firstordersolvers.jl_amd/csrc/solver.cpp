@@ -179,9 +179,9 @@ int allreduce(fos_solver* h, int count) {
 }
 
 // partials[count][nacc] --(sharded: local reduce + all-reduce)--> returns from_reduced flag for the finalize kernel
-int finish_reduce(fos_solver* h, const LaunchCtx& c, int count, int nacc, int gate, int* from_reduced) {
+int finish_reduce(fos_solver* h, const LaunchCtx& c, int count, int nacc, int gate, int* from_reduced, int off = 0) {
     if (!h->sharded()) { *from_reduced = 0; return FOS_OK; }
-    launch_reduce1(c, count, nacc, gate);
+    launch_reduce1(c, count, nacc, gate, off);
     FOS_TRY(allreduce(h, nacc));
     *from_reduced = 1;
     return FOS_OK;
@@ -216,7 +216,7 @@ int global_setup(fos_solver* h) {
 int kkt_apply_full(fos_solver* h, const LaunchCtx& c, const d2* w, d2* out) {
     launch_kkt2(c, w, out, 0);
     int fr = 0;
-    FOS_TRY(finish_reduce(h, c, c.S.npart, 3, 0, &fr));
+    FOS_TRY(finish_reduce(h, c, c.S.npart, 3, 0, &fr, c.S.part_off));
     launch_kkt_finalize(c, w, out, 0, fr);
     return FOS_OK;
 }
@@ -241,7 +241,7 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
             launch_kkt2(c, h->P, h->AP, 1);                            // :38   Ap = M p (+ partial sums)
             if (rec) { FOS_HIP(hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
             int f1 = 0;
-            FOS_TRY(finish_reduce(h, c, c.S.npart, 3, 1, &f1));
+            FOS_TRY(finish_reduce(h, c, c.S.npart, 3, 1, &f1, c.S.part_off));
             launch_cg_alpha_update(c, x, h->R, h->P, h->AP, f1, next_j);   // :39-41,46
             int f2 = 0;
             if (h->sharded()) {                                        // sharded: reduce the r.r partials, all-reduce
@@ -279,7 +279,7 @@ int prox_affine(fos_solver* h, const d2* x) {
     LaunchCtx c = h->ctx();
     int fr = 0;
     launch_q1(c, Q_RHS, x, 1, 1.0, h->RHS);                            // :94-95
-    FOS_TRY(finish_reduce(h, c, c.S.npart, 1, 0, &fr));
+    FOS_TRY(finish_reduce(h, c, c.S.npart, 1, 0, &fr, c.S.part_off));
     launch_q1_finalize(c, Q_RHS, x, 1, 1.0, h->RHS, fr);
     if (h->firstrun) {                                                  // :101-104
         FOS_HIP(hipMemcpyAsync(h->SOL, x, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));
@@ -312,7 +312,7 @@ int status_check(fos_solver* h, const d2* z, double eps, fos_check_result* res) 
     LaunchCtx c = h->ctx();
     int fr = 0;
     launch_q1(c, Q_STATUS, z, 0, 1.0, nullptr);
-    FOS_TRY(finish_reduce(h, c, c.S.npart, 6, 0, &fr));
+    FOS_TRY(finish_reduce(h, c, c.S.npart, 6, 0, &fr, c.S.part_off));
     launch_status_finalize(c, z, fr);
     FOS_TRY(poll_state(h));
     const double* s = h->st_host->stat;
@@ -598,7 +598,8 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
         std::vector<int32_t>().swap(hs.row_defer);
         std::vector<int32_t>().swap(hs.def_idx);
     }
-    h->S.npart = h->S.nwg + h->S.nwg_def;
+    h->S.npart = h->S.nwg_def > 0 ? h->S.nwg_def : h->S.nwg;
+    h->S.part_off = h->S.nwg_def > 0 ? h->S.nwg : 0;
     // free the big host arrays (keep block table for re-partitioning)
     std::vector<double>().swap(hs.val);
     std::vector<int32_t>().swap(hs.col);
@@ -958,7 +959,7 @@ int fos_q_apply(fos_handle h, double* y, const double* x, int32_t transpose) {
     const double sign = transpose ? -1.0 : 1.0;           // HSDEAffine.jl:61-65
     int fr = 0;
     launch_q1(c, Q_PLAIN, h->W, 0, sign, h->plain + l);
-    FOS_TRY(finish_reduce(h, c, c.S.npart, 1, 0, &fr));
+    FOS_TRY(finish_reduce(h, c, c.S.npart, 1, 0, &fr, c.S.part_off));
     launch_q1_finalize(c, Q_PLAIN, h->W, 0, sign, h->plain + l, fr);
     FOS_HIP(hipMemcpyAsync(y, h->plain + l, sizeof(double) * l, hipMemcpyDeviceToHost, h->stream));
     FOS_HIP(hipStreamSynchronize(h->stream));
@@ -1016,7 +1017,7 @@ int fos_hsdematrix_prox(fos_handle h, double* y, const double* x) {
     // v = Q*u                                                          :122-124
     int fr = 0;
     launch_q1(c, Q_VFROMU, h->SOL2, 0, 1.0, h->W);
-    FOS_TRY(finish_reduce(h, c, c.S.npart, 1, 0, &fr));
+    FOS_TRY(finish_reduce(h, c, c.S.npart, 1, 0, &fr, c.S.part_off));
     launch_q1_finalize(c, Q_VFROMU, h->SOL2, 0, 1.0, h->W, fr);
     return download_plain(h, y, h->W);
 }
@@ -1140,7 +1141,8 @@ int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int3
         FOS_HIP(hipMemcpy(const_cast<int32_t*>(h->S.wave_blk0), h->hostS.wave_blk0.data(),
                           h->hostS.wave_blk0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         h->S.nwg = h->hostS.nwg;
-        h->S.npart = h->S.nwg + h->S.nwg_def;
+        h->S.npart = h->S.nwg_def > 0 ? h->S.nwg_def : h->S.nwg;
+    h->S.part_off = h->S.nwg_def > 0 ? h->S.nwg : 0;
         h->S.nwaves = h->hostS.nwaves;
         h->nwg_target = spmv_workgroups;
     }

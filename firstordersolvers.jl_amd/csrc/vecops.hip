@@ -135,7 +135,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_alpha_update_kernel(int64_t l,
 void launch_cg_alpha_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, double2* Ap, int from_reduced, int j) {
     // r.r partials go behind the 3 x nwg KKT partials (both live in c.partials)
     hipLaunchKernelGGL(cg_alpha_update_kernel, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, r, p, Ap, c.st,
-                       c.partials, c.S.npart, c.reduced, from_reduced, j, c.partials + 3 * (size_t)PART_CAP);
+                       c.partials + 3 * (size_t)c.S.part_off, c.S.npart, c.reduced, from_reduced, j, c.partials + 3 * (size_t)PART_CAP);
 }
 
 // stop test + beta + p update in one launch: EVERY workgroup reduces the <= 1024 r.r partials in the same fixed order (so all
