@@ -55,6 +55,11 @@ def c4(pkg):
 def test_c4_operators_and_projections_full_size(pkg, c4):
     prob, d = c4
     assert (prob.m, prob.n, prob.nnz) == (1064960, 16384, 34078720)
+    # the dense 2080 x 32 blocks are held as dual tiles: every entry once (plus the padding lanes of the 32-row tail tiles),
+    # all 16384 columns of A finished by the deferred-row kernel
+    st = d.operator_stats()
+    assert st["tiles"] == 512 * 33 and st["tile_vals"] == prob.nnz and st["deferred"] == prob.n
+    assert prob.nnz <= st["vals"] <= 1.05 * prob.nnz and st["cols"] < 0.01 * prob.nnz, st
     rng = np.random.default_rng(0)
     _operator_properties(d, rng)
     _projection_properties(d, rng)
