@@ -95,14 +95,23 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # FOS_BENCH_BACKEND=gloo (testing only): host-side coordination over gloo, scalar sums through the peer mailboxes only, ranks
+    # mapped round-robin onto the visible GPUs -- lets the whole N > 1 path run with several ranks on ONE GPU, which RCCL refuses
+    host_gloo = os.environ.get("FOS_BENCH_BACKEND") == "gloo"
+    if host_gloo:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
+    tdev = "cpu" if host_gloo else "cuda"
     dist = None
     reduction = "in-stream RCCL all-reduce"
     force_dist = os.environ.get("FOS_FORCE_DIST") == "1"      # exercise the distributed path with one rank (testing)
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if host_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as ge
     pkg = ge.load_package()
@@ -113,18 +122,19 @@ def main():
     t0 = time.time()
     dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2, device=local_rank)
     if dist is not None:
-        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(pkg.HipHSDE.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
-        dev.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
+        if not host_gloo:
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(pkg.HipHSDE.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            dev.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
         # scalar sums: peer mailboxes (one xGMI write latency per exchange) when every rank's self test passes,
         # otherwise the in-stream RCCL all-reduce set up above.  FOS_REDUCTION=rccl|peer|auto (default auto).
-        want = os.environ.get("FOS_REDUCTION", "auto")
+        want = "peer" if host_gloo else os.environ.get("FOS_REDUCTION", "auto")
         if want != "rccl":
             # every collective below is executed by every rank in the same order, whatever fails locally
             def agree(ok):
-                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=tdev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 return int(flag.item()) == 1
             try:
@@ -186,7 +196,7 @@ def main():
     it += done
     elapsed = t2 - t1
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     launches, kms, kbytes = dev.profile_read()
