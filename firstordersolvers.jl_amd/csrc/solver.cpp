@@ -256,7 +256,8 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
         return FOS_OK;
     };
     const size_t ev_start = h->ev_used;      // profiling: only the launches of REAL iterations are kept (below)
-    int first = h->last_cg_pred > 0 ? h->last_cg_pred + 2 : h->cg_chunk;
+    static const int pred_slack = getenv("FOS_CG_SLACK") ? atoi(getenv("FOS_CG_SLACK")) : 1;   // iterations enqueued beyond the last solve's count (each costs ~15-25 us when not needed; too few costs a poll)
+    int first = h->last_cg_pred > 0 ? h->last_cg_pred + pred_slack : h->cg_chunk;
     first = std::max(1, std::min(first, maxit));
     FOS_TRY(enqueue(first));
     FOS_TRY(poll_state(h));
