@@ -57,6 +57,10 @@ def shapes(pkg):
     out.append(("tile-mixed", sp.vstack([sp.csc_matrix(rng.standard_normal((48, 150))),
                                          sp.random(120, 150, density=0.05, format="csc", random_state=rng, data_rvs=rng.standard_normal),
                                          sp.csc_matrix(rng.standard_normal((20, 150)))]).tocsc()))
+    # random mixes of dense rectangles (some tiled, some too small), sparse noise, empty rows / columns
+    from test_operator_format import _random_structured
+    for seed in (3, 11, 19, 27, 35):
+        out.append(("random-structured-%d" % seed, _random_structured(np.random.default_rng(1000 + seed))))
     out.append(("all-zero", sp.csc_matrix((6, 9))))
     return out
 

@@ -112,3 +112,39 @@ def test_malformed_csc_is_rejected(pkg):
     for colptr, rowval in bad:
         rc = lib.fos_host_stacked_spmv(3, 2, i64(colptr), i64(rowval), pkg.lib.dptr(nz), pkg.lib.dptr(v), pkg.lib.dptr(out), 0, 0, None)
         assert rc == -1
+
+
+def _random_structured(rng):
+    """Random mix of what the builder distinguishes: dense rectangles (tile candidates: >= 16 equal rows; and smaller ones that
+    must NOT become tiles), long dense rows, sparse noise, empty rows and columns."""
+    m, n = int(rng.integers(20, 400)), int(rng.integers(10, 300))
+    A = sp.lil_matrix((m, n))
+    for _ in range(int(rng.integers(0, 5))):                        # rectangles
+        r0, c0 = int(rng.integers(0, m)), int(rng.integers(0, n))
+        h, w = int(rng.integers(1, 120)), int(rng.integers(1, 200))
+        r1, c1 = min(m, r0 + h), min(n, c0 + w)
+        A[r0:r1, c0:c1] = rng.standard_normal((r1 - r0, c1 - c0))
+    if rng.random() < 0.6:                                          # sparse noise (breaks some runs, leaves partial columns)
+        A = A + sp.random(m, n, density=float(rng.uniform(0.001, 0.03)), format="lil", random_state=rng, data_rvs=rng.standard_normal)
+        A = A.tolil()
+    if rng.random() < 0.5:
+        A[int(rng.integers(0, m)), :] = 0
+    if rng.random() < 0.5:
+        A[:, int(rng.integers(0, n))] = 0
+    A = A.tocsc()
+    A.eliminate_zeros()
+    return A
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_structures(pkg, seed):
+    rng = np.random.default_rng(1000 + seed)
+    A = _random_structured(rng)
+    m, n = A.shape
+    v = rng.standard_normal(n + m)
+    for waves in (0, 7168):
+        out, st = host_spmv(pkg, A, v, waves=waves)
+        ref = reference(A, v)
+        assert np.allclose(out, ref, rtol=1e-12, atol=1e-12), (seed, st)
+        assert st["ell"] + st["lds"] + st["long"] + st["tiles"] == st["blocks"]
+        assert st["tile_vals"] <= A.nnz
