@@ -116,3 +116,31 @@ def test_c3_full_size_gapa(pkg):
     model = pkg.solve(prob, pkg.GAPA(eps=1e-4, max_iters=6000, verbose=0, checki=250))
     assert model.status() == "Optimal"
     assert model.getobjval() == pytest.approx(float(prob.c @ prob.x0), rel=2e-2, abs=1e-3)
+
+
+def test_c5_full_size_fista_residuals_vs_oracle(pkg, oracle):
+    """Mixed-cone HSDE, l ~ 1e6 (NonNeg + SOC + PSD, 8 blocks), FISTA: operator / projection properties at full size, and the
+    residuals p, d, g, c'x, b'y the device reports at a check against the oracle's residual formulas (HSDEStatus.jl:27-71) on
+    the SAME point -- relative 1e-9 (the BASELINE tolerance is 1e-8)."""
+    orc = oracle
+    prob = pkg.workloads.c5_mixed()
+    assert 9.9e5 < prob.m + prob.n + 1 < 1.01e6
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    _operator_properties(d, np.random.default_rng(4))
+    _projection_properties(d, np.random.default_rng(5))
+    d.set_alg(pkg.FISTA())
+    d.set_iterate(None)
+    done, checked, res = d.step(1, 40, 40, 1e-8)
+    assert done == 40 and checked
+    z = d.get_checked()                                   # the cone-feasible point the check was evaluated on
+    om = orc.Model(prob.A, prob.b, prob.c, [(orc.CONE_CODES[k], l) for k, l in prob.K1],
+                   [(orc.CONE_CODES[k], l) for k, l in prob.K2])
+    st = orc.HSDEStatus(om, 40, 1e-8, 0, 1)
+    st.i = 40
+    st.checkstatus(z, override=True)
+    for key in ("p", "d", "g", "ctx", "bty"):
+        assert getattr(res, key) == pytest.approx(st.last[key], rel=1e-9, abs=1e-13), key
+    assert res.status == {"Continue": 0, "Optimal": 1, "Unbounded": 2, "Infeasible": 3}[st.status]
+    _, _, res2 = d.step(41, 160, 200, 1e-8)
+    assert res2.p < res.p and res2.d < res.d             # and FISTA makes progress at this size
+    d.close()
