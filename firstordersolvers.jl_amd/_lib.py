@@ -46,6 +46,7 @@ PROTOTYPES = {
                              C.c_int64, _i32p, _i64p, _i64p, C.c_int64, _i32p, _i64p, _i64p, C.c_int, C.POINTER(_h)]),
     "fos_destroy": (C.c_int, [_h]),
     "fos_sizes": (C.c_int, [_h, _i64p, _i64p, _i64p, _i64p]),
+    "fos_get_cg_total": (C.c_int, [_h, _i64p]),
     "fos_operator_stats": (C.c_int, [_h, _i64p]),
     "fos_comm_get_unique_id": (C.c_int, [C.c_void_p]),
     "fos_comm_init": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),

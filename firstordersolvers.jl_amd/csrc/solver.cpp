@@ -132,6 +132,8 @@ struct fos_solver {
     int cg_chunk = 8;
     int nwg_target = 2048;
     bool prof = false;
+    int prof_period = 1;                       // every prof_period-th KKT launch is bracketed by events (1: all)
+    int64_t cg_total = 0;                      // CG iterations since fos_create
     std::vector<hipEvent_t> ev;                // pairs
     size_t ev_used = 0;
     static constexpr size_t EV_CAP = 2 * 16384;
@@ -233,7 +235,7 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     auto enqueue = [&](int count) -> int {
         for (int q = 0; q < count; ++q, ++next_j) {
             // 3 launches per CG iteration: KKT sweep | alpha + x,r update | stop test + beta + p update
-            const bool rec = h->prof && h->ev_used + 2 <= fos_solver::EV_CAP;
+            const bool rec = h->prof && (next_j - 1) % h->prof_period == 0 && h->ev_used + 2 <= fos_solver::EV_CAP;
             if (rec) {
                 while (h->ev.size() < h->ev_used + 2) { hipEvent_t e; FOS_HIP(hipEventCreate(&e)); h->ev.push_back(e); }
                 FOS_HIP(hipEventRecord(h->ev[h->ev_used], h->stream));
@@ -267,10 +269,12 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     }
     *iters = h->st_host->iter;
     {   // iterations 1..iter each did exactly one gated KKT launch; launches enqueued past convergence were no-ops
-        const size_t real = std::min<size_t>((size_t)h->st_host->iter, (h->ev_used - ev_start) / 2);
+        const size_t sampled = h->st_host->iter >= 1 ? (size_t)((h->st_host->iter - 1) / h->prof_period + 1) : 0;
+        const size_t real = std::min<size_t>(sampled, (h->ev_used - ev_start) / 2);
         h->ev_used = ev_start + 2 * real;
     }
     h->last_cg_pred = h->st_host->iter;
+    h->cg_total += h->st_host->iter;
     if (h->st_host->hit_max) h->hit_max_accum = 1;
     return FOS_OK;
 }
@@ -1043,12 +1047,19 @@ int fos_check(fos_handle h, const double* z, double eps, fos_check_result* res) 
 int fos_profile(fos_handle h, int32_t enable) {
     if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
     h->prof = enable != 0;
+    h->prof_period = enable > 1 ? enable : 1;
     return FOS_OK;
 }
 
 static double kkt_bytes(const fos_solver* h) {
     // B_kkt,min = 24 nnz + 4(m+n+2) + 32(m+n)
     return 24.0 * (double)h->nnz + 4.0 * (double)(h->m + h->n + 2) + 32.0 * (double)(h->m + h->n);
+}
+
+int fos_get_cg_total(fos_handle h, int64_t* total) {
+    if (!h || !total) { set_error("NULL argument"); return FOS_EINVAL; }
+    *total = h->cg_total;
+    return FOS_OK;
 }
 
 int fos_profile_read(fos_handle h, int64_t* launches, double* total_ms, double* bytes_per_launch) {

@@ -261,7 +261,8 @@ class HipHSDE:
 
     # -- measurement
     def profile(self, enable):
-        _lib.check(self._lib.fos_profile(self._h, 1 if enable else 0))
+        """False/0: off; True/1: events around every KKT launch; N > 1: around every N-th (sampling)."""
+        _lib.check(self._lib.fos_profile(self._h, int(enable)))
 
     def profile_read(self):
         n = C.c_int64(0)
@@ -274,6 +275,11 @@ class HipHSDE:
         ms = C.c_double(0)
         _lib.check(self._lib.fos_bench_kkt(self._h, reps, C.byref(ms)))
         return ms.value
+
+    def cg_total(self):
+        v = C.c_int64(0)
+        _lib.check(self._lib.fos_get_cg_total(self._h, C.byref(v)))
+        return v.value
 
     def operator_stats(self):
         """Format statistics of the device operator (fos_operator_stats)."""

@@ -199,7 +199,9 @@ int fos_check(fos_handle h, const double* z, double eps, fos_check_result* res);
  * device -- what the sweep actually streams: 8 B per stored value, 4 B per stored column index, 32 B per block, 16 B per
  * partial-sum slot written and read again. */
 int fos_operator_stats(fos_handle h, int64_t* stats12);
-int fos_profile(fos_handle h, int32_t enable);
+int fos_profile(fos_handle h, int32_t enable);      /* 0: off; 1: every launch; N > 1: every N-th launch (sampling: an event
+                                                        pair per launch costs ~5 % of a C4 step) */
+int fos_get_cg_total(fos_handle h, int64_t* total);  /* CG iterations run since fos_create (getcgiter summed) */
 int fos_profile_read(fos_handle h, int64_t* launches, double* total_ms, double* bytes_per_launch);
 int fos_bench_kkt(fos_handle h, int32_t reps, double* total_ms);
 int fos_sync(fos_handle h);

@@ -116,3 +116,28 @@ def test_nan_input_propagates_like_the_reference(pkg):
     assert np.isnan(d.get_iterate()).any()
     assert pkg.lib.STATUS_NAMES[res.status] == "Continue"
     d.close()
+
+
+def test_profile_event_sampling_counts(pkg):
+    """fos_profile(1) brackets every KKT launch of the CG iterations with events, fos_profile(N) every N-th (iterations 1, 1+N,
+    ... of each solve); launches enqueued past convergence (gated no-ops) never count; fos_get_cg_total sums getcgiter."""
+    prob = pkg.workloads.small_mixed()
+    dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    dev.set_alg(pkg.DR())
+    dev.set_iterate(None)
+    dev.step(1, 30, 10 ** 9, 1e-9)
+    for period in (1, 3):
+        dev.profile(period)
+        dev.profile_read()
+        c0 = dev.cg_total()
+        expect, total = 0, 0
+        for i in range(31, 41):
+            dev.step(i, 1, 10 ** 9, 1e-9)
+            k = dev.cgiter()
+            total += k
+            expect += (k - 1) // period + 1
+        launches, ms, nbytes = dev.profile_read()
+        assert dev.cg_total() - c0 == total
+        assert launches == expect and ms > 0.0 and nbytes > 0.0
+        dev.profile(0)
+    dev.close()

@@ -35,9 +35,10 @@ for tag in ("trace_c4", "trace_c2"):
         trows = list(csv.DictReader(open(tf[-1])))
         durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in trows if "kkt2_kernel" in r["Kernel_Name"]]
         ddef = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in trows if "kkt2_deferred_kernel" in r["Kernel_Name"]]
-        real = [d for d in durs if d > 0.25 * max(durs)]      # launches enqueued past CG convergence exit at once (gated no-ops, ~3 us)
+        med = lambda v: sorted(v)[len(v) // 2]
+        real = [d for d in durs if d > 0.25 * med(durs)]      # launches enqueued past CG convergence exit at once (gated no-ops, ~3 us)
         tail = real[len(real) // 2:]
-        dreal = [d for d in ddef if d > 0.5 * max(ddef)] if ddef else []
+        dreal = [d for d in ddef if d > 0.4 * med(ddef)] if ddef else []   # (most launches are real, so the median is a real one)
         bj = os.path.join(src, "bench_%s.json" % tag.split("_")[1])
         ev = None
         if os.path.exists(bj):
