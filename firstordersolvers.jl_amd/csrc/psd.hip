@@ -97,10 +97,11 @@ __device__ __forceinline__ double groupc_sum(double v) {
     else return group32_sum(v);
 }
 
-// A sweep whose largest rotated pair had cos^2(angle between the columns) <= JACOBI_SMALL2 leaves, by the quadratic
-// convergence of the cyclic method, every pair below the rotation threshold: the sweep that would only confirm it
-// (no rotation, but all the dot products) is skipped.  The resulting error in the projection is O(cos^2 |l_i - l_j|),
-// below the O(k eps ||M||) of the rotation threshold itself.
+// A sweep in which every rotation was TINY -- both the cosine between the two columns and the sine of the rotation angle
+// below 1e-8 -- leaves, by the quadratic convergence of the cyclic method, every pair below the rotation threshold: the
+// sweep that would only confirm it (no rotation, but all the dot products) is skipped.  The angle matters, not only the
+// cosine: inside a cluster of (nearly) equal eigenvalues two almost orthogonal columns are still turned by a LARGE angle,
+// which disturbs their products with all other columns to first order -- such a sweep is never the last one.
 constexpr double JACOBI_SMALL2 = 1e-16;
 
 // One-sided Jacobi on a 64 x 64 array: THREADS / TPP == 32 pair slots, one pair per slot and step; the 64 / TPP
@@ -128,13 +129,13 @@ __device__ __forceinline__ void jacobi64(double* __restrict__ G, const int ld, c
             const double gg = g * g, ab = a * b;
             if (gg > tol2 * ab) {
                 rotated = 1;
-                if (gg > JACOBI_SMALL2 * ab) big = 1;
                 const double d = b - a;
                 const double rh = fast_rsqrt(d * d + 4.0 * gg);
                 const double c2 = 0.5 + 0.5 * fabs(d) * rh;
                 const double rc = fast_rsqrt(c2);
                 const double cs = c2 * rc;
                 const double sn = copysign(g * rh * rc, d * g);
+                if (gg > JACOBI_SMALL2 * ab || sn * sn > JACOBI_SMALL2) big = 1;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
                     gp[e * TPP] = cs * u[e] - sn * v[e];
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
                     else { a = group_sum(a, tpp); b = group_sum(b, tpp); g = group_sum(g, tpp); }
                     if (g * g <= tol2 * (a * b)) continue;
                     rotated = 1;
-                    if (g * g > JACOBI_SMALL2 * (a * b)) big = 1;
+
                     // rotation that makes the two columns orthogonal: tan(2 theta) = 2g / (b - a), |theta| <= pi/4
                     //   h = sqrt(d^2 + 4 g^2), cos^2 = (1 + |d|/h)/2, sin = sign(d) g / (h cos)
                     const double d = b - a;
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
                     const double rc = fast_rsqrt(c2);
                     const double cs = c2 * rc;
                     const double sn = copysign(g * rh * rc, d * g);
+                    if (g * g > JACOBI_SMALL2 * (a * b) || sn * sn > JACOBI_SMALL2) big = 1;
                     for (int i = lig; i < k; i += tpp) {
                         const double u = gp[i], v = gq[i];
                         gp[i] = cs * u - sn * v;

@@ -298,6 +298,38 @@ def test_psd_known_answer_and_sizes(pkg, dev_ops):
             assert np.linalg.norm(out - ref) <= 5e-13 * max(1.0, np.linalg.norm(z)), k
 
 
+def test_psd_warm_start_drift_and_clustered_spectra(pkg, dev_ops):
+    """The warm-started Jacobi (previous eigenvector basis, confirming sweep skipped when a sweep's rotations were all tiny):
+    slowly drifting matrices as in the solver's steady state, clustered / repeated eigenvalues, eigenvalues straddling zero by
+    1e-9, wide dynamic range -- order 64 (register fast path) and 16 (generic path); every call against LAPACK (oracle)."""
+    rng = np.random.default_rng(5)
+    for k in (64, 16):
+        ln = k * (k + 1) // 2
+        d, _, _ = dev_ops(sp.random(ln, 3, density=0.1, format="csc", random_state=rng), None, None, [("SDP", ln)], [("Free", 3)])
+        S2 = orc.DualConeProduct(orc.ConeProduct.from_lengths([(orc.CONE_SDP, ln)]), orc.ConeProduct.from_lengths([(orc.CONE_FREE, 3)]))
+        Q, _ = np.linalg.qr(rng.standard_normal((k, k)))
+        sym = lambda B: (B + B.T) / 2
+        M0, E = sym(rng.standard_normal((k, k))), sym(rng.standard_normal((k, k)))
+        mats = [M0 + t * 1e-4 * E for t in range(6)]                                         # drift
+        mats += [M0 + 1e-9 * t * E for t in range(3)]                                        # almost no change: tiny rotations only
+        half = k // 2
+        mats.append(Q @ np.diag([1.0] * half + [-1.0] * (k - half)) @ Q.T)                    # two clusters
+        mats.append(Q @ np.diag(np.concatenate([1 + 1e-9 * rng.standard_normal(half), -1 + 1e-9 * rng.standard_normal(k - half)])) @ Q.T)
+        mats.append(Q @ np.diag(1e-9 * rng.standard_normal(k)) @ Q.T + 0.0)                  # everything next to zero
+        mats.append(Q @ np.diag(np.concatenate([np.logspace(-8, 8, half), -np.logspace(-8, 8, k - half)])) @ Q.T)
+        mats.append(np.eye(k))
+        mats.append(-np.eye(k))
+        for it, M in enumerate(mats):
+            sv = pkg.workloads._svec(sym(M))
+            z = np.zeros(d.N)
+            z[3:3 + ln] = sv                     # y part (dual copy)
+            z[d.l + 3:d.l + 3 + ln] = sv         # s part (primal copy)
+            ref = np.empty(d.N)
+            S2.prox(ref, z)
+            out = d.prox_cones(z)
+            assert np.linalg.norm(out - ref) <= 1e-12 * max(1e-300, np.linalg.norm(z)), (k, it)
+
+
 # ---------------------------------------------------------------------------------------------- status
 
 
