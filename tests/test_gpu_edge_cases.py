@@ -141,3 +141,40 @@ def test_profile_event_sampling_counts(pkg):
         assert launches == expect and ms > 0.0 and nbytes > 0.0
         dev.profile(0)
     dev.close()
+
+
+def test_nan_and_inf_through_dual_tiles_and_repartition(pkg, oracle):
+    """A NaN / Inf entry of the input vector must reach exactly the outputs it reaches in the reference's four SpMV sweeps,
+    also when the operator is stored as dual tiles (padding lanes and padded steps must not leak or swallow it); and
+    re-partitioning the sweep (fos_set_tuning) must not change a single bit of any row sum."""
+    import scipy.sparse as sp
+    orc = oracle
+    rng = np.random.default_rng(9)
+    A = sp.vstack([sp.csc_matrix(rng.standard_normal((70, 45))),                                   # tiles: 64 + (6 rows left over)
+                   sp.random(40, 45, density=0.1, format="csc", random_state=rng, data_rvs=rng.standard_normal)]).tocsc()
+    m, n = A.shape
+    prob = pkg.workloads.from_complementary_pair("tiles-nan", A, [("Zero", m)], [("NonNeg", n)], rng)
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    assert d.operator_stats()["tiles"] > 0
+    M = orc.KKTMatrix(orc.HSDEMatrixQ(prob.A, prob.b, prob.c))
+    base = rng.standard_normal(d.N)
+    for idx, bad in ((3, np.nan), (n + 10, np.nan), (n + 69, np.inf), (d.l + 7, np.nan), (d.l + n + 64, -np.inf), (n + 100, np.nan)):
+        z = base.copy()
+        z[idx] = bad
+        ref = np.empty(d.N)
+        with np.errstate(invalid="ignore"):
+            M.mul(ref, z)
+        out = d.kkt_apply(z)
+        assert np.array_equal(np.isnan(out), np.isnan(ref)), idx
+        assert np.array_equal(np.isinf(out), np.isinf(ref)), idx
+        ok = np.isfinite(ref)
+        assert np.allclose(out[ok], ref[ok], rtol=1e-12, atol=1e-12), idx
+    ref_bits = d.kkt_apply(base)
+    for wg in (8, 64, 1000):
+        d.set_tuning(spmv_workgroups=wg)
+        out = d.kkt_apply(base)
+        rows = np.ones(d.N, dtype=bool)
+        rows[[d.l - 1, d.N - 1]] = False            # the tau rows are sums of per-workgroup partial sums: grouping may change the last bit
+        assert np.array_equal(out[rows], ref_bits[rows]), wg
+        assert np.allclose(out[~rows], ref_bits[~rows], rtol=1e-13, atol=0), wg
+    d.close()
