@@ -488,6 +488,29 @@ def test_mixed_cone_solve_matches_oracle(pkg, algname):
             assert getattr(last, key) == pytest.approx(olast[key], rel=0.5)
 
 
+@pytest.mark.parametrize("algname", ["DR", "GAPA"])
+def test_tile_stored_lp_solve_matches_oracle(pkg, algname):
+    """Whole solves on a dense LP whose operator is partly stored as dual tiles (96 x 180: the first 64 rows as three 64-column
+    chunks, the other 32 rows in ordinary blocks, so every column of A is a deferred row WITH an own partial and the 64 tile
+    rows are deferred across chunks): status, iteration count, solution and residuals against the oracle."""
+    prob = pkg.workloads.small_lp(seed=21, m=96, n=180)
+    dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    st = dev.operator_stats()
+    dev.close()
+    assert st["tiles"] == 3 and st["deferred"] == 64 + 180, st
+    mk = {"DR": lambda M, **o: M.DR(**o), "GAPA": lambda M, **o: M.GAPA(0.8, 0.5, **o)}[algname]
+    # (this LP converges slowly: both runs stop at max_iters with the reference's :Continue -> :Indeterminate; what is compared
+    # is the whole 1500-iteration trajectory's end point)
+    model, sol, _ = solve_both(pkg, prob, mk, eps=1e-6, verbose=0, max_iters=1500, checki=50)
+    assert model.status() == sol.status
+    assert model.iterations == sol.iterations
+    assert np.max(np.abs(model.getsolution() - sol.x)) <= 1e-4 * max(1.0, np.max(np.abs(sol.x)))
+    assert model.getobjval() == pytest.approx(sol.obj_val, rel=1e-4, abs=1e-6)
+    last, olast = model.status_obj.last, sol.status_obj.last
+    for key in ("p", "d", "g"):
+        assert getattr(last, key) == pytest.approx(olast[key], rel=1e-3)
+
+
 def test_max_iters_forced_check_and_history(pkg):
     """solverwrapper.jl:31-34: forced check on the guess when the last iteration was not a check iteration."""
     prob = pkg.workloads.c1_readme_nnls(seed=2)
