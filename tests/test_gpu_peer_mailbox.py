@@ -187,6 +187,78 @@ def test_selftest_single_rank_and_fallback(pkg):
     dev.close()
 
 
+def _timeout_worker(rank, q_out, q_in):
+    """Rank 0 exchanges; rank 1 maps the mailboxes and then never shows up at an exchange."""
+    import time
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    try:
+        prob = pkg.workloads.small_mixed()
+        dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+        q_out.put((rank, "handle", dev.peer_export()))
+        dev.peer_open(2, rank, q_in.get(timeout=120), timeout_s=0.5)
+        q_out.put((rank, "opened", None))
+        q_in.get(timeout=120)
+        if rank == 0:
+            t0 = time.time()
+            ok = dev.peer_selftest(8)
+            dt = time.time() - t0
+            try:
+                dev.peer_enable(True)
+                err = None
+            except pkg.lib.FosError as exc:
+                err = str(exc)
+            q_out.put((rank, "result", (ok, dt, err)))
+        else:
+            q_out.put((rank, "result", None))
+        q_in.get(timeout=120)                                   # rank 1 keeps its mailbox alive until rank 0 has given up
+        dev.close()
+    except Exception as exc:  # noqa: BLE001
+        q_out.put((rank, "error", repr(exc)))
+
+
+def test_absent_peer_times_out_instead_of_hanging():
+    """Two processes map each other's mailboxes; only rank 0 ever exchanges.  Its self test must come back False after the
+    0.5 s time-out (not hang), and switching to the mailboxes anyway must raise FOS_ECOMM."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    q_in = [ctx.Queue(), ctx.Queue()]
+    procs = [ctx.Process(target=_timeout_worker, args=(r, q_out, q_in[r])) for r in range(2)]
+    for p in procs:
+        p.start()
+
+    def collect(tag):
+        got = {}
+        for _ in range(2):
+            r, t, payload = q_out.get(timeout=180)
+            assert t == tag, (r, t, payload)
+            got[r] = payload
+        return got
+
+    try:
+        handles = collect("handle")
+        for q in q_in:
+            q.put([handles[0], handles[1]])
+        collect("opened")
+        for q in q_in:
+            q.put(True)
+        res = collect("result")
+        for q in q_in:
+            q.put(True)
+        ok, dt, err = res[0]
+        assert ok is False and dt < 15.0, (ok, dt)
+        assert err is not None and "timed out" in err, err
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0, p.exitcode
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+
+
 def test_missing_peer_times_out_with_error(pkg):
     """Rank 0 of a 2-rank layout whose peer never shows up: the exchange gives up after the time-out, the self test
     reports failure, and a solve attempted anyway returns FOS_ECOMM -- no hang."""
