@@ -16,4 +16,6 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c
 # HBM traffic of the dominant kernel: separate passes for FETCH_SIZE and WRITE_SIZE (TCC slots), counters only
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c4 -- python bench.py --steps 3 --warmup 20 --no-cpu-baseline > $OUT/pmc_fetch_c4.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c4 -- python bench.py --steps 3 --warmup 20 --no-cpu-baseline > $OUT/pmc_write_c4.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c2 -- python bench.py --workload C2 --steps 3 --warmup 20 --no-cpu-baseline > $OUT/pmc_fetch_c2.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c2 -- python bench.py --workload C2 --steps 3 --warmup 20 --no-cpu-baseline > $OUT/pmc_write_c2.log 2>&1
 ls -R $OUT | head -50

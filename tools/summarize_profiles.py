@@ -58,7 +58,7 @@ for tag in ("trace_c4", "trace_c2"):
                 f.write("bench.py on the same box, un-profiled, HIP events around the same launches (both kernels of an apply): "
                         "%.2f us\n" % ev)
 
-for tag, counter in (("pmc_fetch_c4", "FETCH_SIZE"), ("pmc_write_c4", "WRITE_SIZE")):
+for tag, counter in (("pmc_fetch_c4", "FETCH_SIZE"), ("pmc_write_c4", "WRITE_SIZE"), ("pmc_fetch_c2", "FETCH_SIZE"), ("pmc_write_c2", "WRITE_SIZE")):
     files = sorted(glob.glob(os.path.join(src, tag, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     if not files:
         continue
@@ -67,7 +67,7 @@ for tag, counter in (("pmc_fetch_c4", "FETCH_SIZE"), ("pmc_write_c4", "WRITE_SIZ
         if r.get("Counter_Name") == counter:
             acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     with open(os.path.join(dst, "%s_%s.md" % (rnd, tag)), "w") as f:
-        f.write("# rocprofv3 --pmc %s (own pass) : `python bench.py --steps 3 --warmup 20 --no-cpu-baseline`\n\n" % counter)
+        f.write("# rocprofv3 --pmc %s (own pass) : `python bench.py%s --steps 3 --warmup 20 --no-cpu-baseline`\n\n" % (counter, " --workload C2" if tag.endswith("c2") else ""))
         f.write("| kernel | dispatches | mean %s per dispatch (counter units: KB) | as MB |\n|---|---|---|---|\n" % counter)
         for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
             if "kkt2" in k or "cg_" in k:      # drop gated no-op dispatches (counter ~0)
@@ -78,7 +78,7 @@ for tag, counter in (("pmc_fetch_c4", "FETCH_SIZE"), ("pmc_write_c4", "WRITE_SIZ
 # measured HBM traffic of the dominant kernel per launch, for bench.py's roofline.traffic (2 x FETCH_SIZE: the gfx950
 # under-count for coalesced streams, MI355X_MICROARCH.md "HBM"; + WRITE_SIZE), keyed by workload
 traffic = {}
-for wl in ("c4",):
+for wl in ("c4", "c2"):
     vals = {}
     for tag, counter in (("pmc_fetch_" + wl, "FETCH_SIZE"), ("pmc_write_" + wl, "WRITE_SIZE")):
         files = sorted(glob.glob(os.path.join(src, tag, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
