@@ -168,6 +168,10 @@ struct ConeDesc {          // a SOC / rotated SOC / PSD cone in stacked index sp
 constexpr int PEER_MAX_RANKS = 16;
 constexpr int PEER_MAX_VALS = 8;
 constexpr size_t PEER_BOX_WORDS = (size_t)2 * PEER_MAX_RANKS * PEER_MAX_VALS * 2;
+// A mailbox has TWO such regions: region 0 for the exchanges of the single-workgroup reduce kernel (sequence = a device
+// counter of executed exchanges), region 1 for the two exchanges of a CG iteration that are FOLDED into the CG vector kernels
+// (every workgroup reduces the local records itself, workgroup 0 also writes them to the peers, every workgroup polls; the
+// sequence number is (CG solve number, iteration, phase), known at launch, its parity = the phase).
 struct PeerBox {
     unsigned long long* const* box;   // device table [nranks]: box[r] = mailbox of rank r (own entry: the local allocation)
     uint32_t* seq;                    // device counter of EXECUTED exchanges (gated no-op launches do not count)
@@ -206,9 +210,11 @@ void launch_q1_finalize(const LaunchCtx& c, QMode mode, const double2* v, int co
 void launch_cg_init(const LaunchCtx& c, const double2* rhs, const double2* Ap, double2* r, double2* p);
 void launch_cg_init_finalize(const LaunchCtx& c, const double2* r, double tol, int maxit, int from_reduced);
 // stop test + beta + p update in one launch (iteration number j known at enqueue time)
-void launch_cg_finalize_pupdate(const LaunchCtx& c, double2* p, const double2* r, int from_reduced, int j);
+void launch_cg_finalize_pupdate(const LaunchCtx& c, double2* p, const double2* r, int from_reduced, int j,
+                                const PeerBox* fold = nullptr, uint32_t seq_base = 0);
 // tau rows of Ap, alpha = rn/(Ap.p), x += alpha p, r -= alpha Ap in one launch; its r.r partials go to partials + 3*16392
-void launch_cg_alpha_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, double2* Ap, int from_reduced, int j);
+void launch_cg_alpha_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, double2* Ap, int from_reduced, int j,
+                            const PeerBox* fold = nullptr, uint32_t seq_base = 0);
 void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate, int off = 0);   // partials[off.. +count][nacc] -> reduced[nacc] (+ peer exchange)
 
 // outer-loop vector kernels (gap.jl:48,58,78; gapa.jl:67,77,96-103; fista.jl:31-46; dykstra.jl)

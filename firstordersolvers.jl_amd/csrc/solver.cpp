@@ -126,6 +126,7 @@ struct fos_solver {
     std::vector<void*> peer_opened;            // IPC mappings of the peers' mailboxes
     PeerBox peer{};
     bool peer_on = false;
+    uint32_t cg_epoch = 0;                     // CG solves so far: the sequence space of the folded exchanges
     bool sharded() const { return comm != nullptr || peer_on; }
 
     // tuning / measurement
@@ -232,6 +233,10 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     FOS_TRY(finish_reduce(h, c, c.vec_blocks, 1, 0, &fr));
     launch_cg_init_finalize(c, h->R, tol, maxit, fr);                  // :35-36
     int next_j = 1;                          // iteration number of the next enqueued launch group (if CG still runs)
+    static const bool fold_env = !(getenv("FOS_PEER_FOLD") && atoi(getenv("FOS_PEER_FOLD")) == 0);
+    const bool fold = h->peer_on && fold_env;
+    h->cg_epoch += 1;                        // the same on every rank: all ranks make the same calls
+    const uint32_t seq_base = (uint32_t)(h->cg_epoch * 2048u);          // + 2 j + phase  (j <= 1000)
     auto enqueue = [&](int count) -> int {
         for (int q = 0; q < count; ++q, ++next_j) {
             // 3 launches per CG iteration: KKT sweep | alpha + x,r update | stop test + beta + p update
@@ -242,6 +247,11 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
             }
             launch_kkt2(c, h->P, h->AP, 1);                            // :38   Ap = M p (+ partial sums)
             if (rec) { FOS_HIP(hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
+            if (fold) {       // peer mailboxes: both exchanges of the iteration happen inside the two CG vector kernels
+                launch_cg_alpha_update(c, x, h->R, h->P, h->AP, 0, next_j, &h->peer, seq_base);
+                launch_cg_finalize_pupdate(c, h->P, h->R, 0, next_j, &h->peer, seq_base);
+                continue;
+            }
             int f1 = 0;
             FOS_TRY(finish_reduce(h, c, c.S.npart, 3, 1, &f1, c.S.part_off));
             launch_cg_alpha_update(c, x, h->R, h->P, h->AP, f1, next_j);   // :39-41,46
@@ -721,7 +731,7 @@ int fos_peer_export(fos_handle h, void* handle64) {
     FOS_HIP(hipSetDevice(h->device));
     if (!h->peer_mbox) {
         void* q = nullptr;
-        const size_t bytes = PEER_BOX_WORDS * sizeof(unsigned long long);
+        const size_t bytes = 2 * PEER_BOX_WORDS * sizeof(unsigned long long);      // region 0 + region 1
         hipError_t e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached);
         if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained); }
         if (e != hipSuccess) { set_error("hipExtMallocWithFlags(mailbox): %s", hipGetErrorString(e)); return FOS_ENOMEM; }

@@ -96,18 +96,74 @@ __global__ __launch_bounds__(FIN_THREADS) void cg_init_finalize_kernel(const dou
     }
 }
 
+// Folded peer exchange (fos_internal.hpp, region 1 of the mailboxes): called by EVERY workgroup of a CG vector kernel with the
+// same local sums; workgroup 0 also stores them into the peers' mailboxes; all poll their own mailbox for the peers' words of
+// sequence number `seq` and add in rank order.  Returns false (and stops the solve) when a peer does not answer in time.
+template <int NACC>
+__device__ __forceinline__ bool peer_fold_sum(const PeerBox& pb, uint32_t seq, double* sums /* shared: in local, out total */, DevState* st) {
+    __shared__ uint32_t halves[PEER_MAX_RANKS * NACC * 2];
+    __shared__ int failed;
+    const int t = threadIdx.x;
+    if (t == 0) failed = 0;
+    __syncthreads();
+    const size_t par = (size_t)(seq & 1u) * PEER_MAX_RANKS;
+    if (t < pb.nranks * NACC * 2) {
+        const int hh = t & 1, v = (t >> 1) % NACC, r = (t >> 1) / NACC;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(sums[v]);
+        const uint32_t mine = hh ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+        if (r == pb.rank) {
+            halves[(r * NACC + v) * 2 + hh] = mine;
+        } else {
+            if (blockIdx.x == 0) {
+                unsigned long long* dst = pb.box[r] + PEER_BOX_WORDS + ((par + pb.rank) * PEER_MAX_VALS + v) * 2 + hh;
+                __hip_atomic_store(dst, ((unsigned long long)seq << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            const unsigned long long* src = pb.box[pb.rank] + PEER_BOX_WORDS + ((par + r) * PEER_MAX_VALS + v) * 2 + hh;
+            const long long t0 = wall_clock64();
+            unsigned long long w;
+            bool ok;
+            do {
+                w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ok = (uint32_t)(w >> 32) == seq;
+            } while (!ok && (wall_clock64() - t0) < pb.timeout_ticks);
+            if (!ok) failed = 1;
+            halves[(r * NACC + v) * 2 + hh] = (uint32_t)w;
+        }
+    }
+    __syncthreads();
+    if (failed) {
+        if (blockIdx.x == 0 && t == 0) { st->xchg_failed = 1; st->done = 1; }
+        return false;
+    }
+    if (t < NACC) {
+        double s = 0.0;
+        for (int r = 0; r < pb.nranks; ++r) {
+            const unsigned long long lo = halves[(r * NACC + t) * 2], hi = halves[(r * NACC + t) * 2 + 1];
+            s += __longlong_as_double((long long)((hi << 32) | lo));
+        }
+        sums[t] = s;
+    }
+    __syncthreads();
+    return true;
+}
+
 // alpha + x,r update in one launch: EVERY workgroup reduces the 3 x nwg KKT partials in the same fixed order, finishes
 // the tau rows of Ap = M p and alpha = rn / (Ap.p) itself (so no workgroup waits for another), then updates its slice:
 // x += alpha p ; r -= alpha Ap ; partial r.r.  Workgroup 0 stores Ap[tau], pAp and alpha.     conjugategradients.jl:39-41,46
+template <bool FOLD>
 __global__ __launch_bounds__(VEC_THREADS) void cg_alpha_update_kernel(int64_t l, d2* __restrict__ x, d2* __restrict__ r,
                                                                       const d2* __restrict__ p, d2* __restrict__ Ap,
                                                                       DevState* st, const double* __restrict__ kkt_partials, int nkkt,
                                                                       const double* __restrict__ reduced, int from_reduced, int j,
-                                                                      double* __restrict__ partials) {
+                                                                      double* __restrict__ partials, PeerBox pb, uint32_t seq_base) {
     if (st->done) return;
+    if (FOLD && st->xchg_failed) return;
     __shared__ double sums[3];
     if (from_reduced) { if (threadIdx.x < 3) sums[threadIdx.x] = reduced[threadIdx.x]; __syncthreads(); }
     else reduce_partials<3>(kkt_partials, nkkt, sums);
+    if constexpr (FOLD) {
+        if (!peer_fold_sum<3>(pb, seq_base + 2u * (uint32_t)j, sums, st)) return;
+    }
     const d2 pt = p[l - 1];
     const double S1 = sums[0], T1 = sums[1], T2 = sums[2];
     const double at1 = pt.x + T2;            // p1_tau - (Q p2)_tau ,  (Q v)_tau = -[c;b].v        HSDEAffine.jl:57
@@ -132,23 +188,35 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_alpha_update_kernel(int64_t l,
     }
     block_reduce_store<1>(acc, partials + blockIdx.x);
 }
-void launch_cg_alpha_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, double2* Ap, int from_reduced, int j) {
+void launch_cg_alpha_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, double2* Ap, int from_reduced, int j,
+                            const PeerBox* fold, uint32_t seq_base) {
     // r.r partials go behind the 3 x nwg KKT partials (both live in c.partials)
-    hipLaunchKernelGGL(cg_alpha_update_kernel, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, r, p, Ap, c.st,
-                       c.partials + 3 * (size_t)c.S.part_off, c.S.npart, c.reduced, from_reduced, j, c.partials + 3 * (size_t)PART_CAP);
+    if (fold)
+        hipLaunchKernelGGL(cg_alpha_update_kernel<true>, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, r, p, Ap, c.st,
+                           c.partials + 3 * (size_t)c.S.part_off, c.S.npart, c.reduced, 0, j, c.partials + 3 * (size_t)PART_CAP, *fold, seq_base);
+    else
+        hipLaunchKernelGGL(cg_alpha_update_kernel<false>, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, r, p, Ap, c.st,
+                           c.partials + 3 * (size_t)c.S.part_off, c.S.npart, c.reduced, from_reduced, j, c.partials + 3 * (size_t)PART_CAP,
+                           PeerBox{}, 0u);
 }
 
 // stop test + beta + p update in one launch: EVERY workgroup reduces the <= 1024 r.r partials in the same fixed order (so all
 // derive the same stop decision and beta), workgroup 0 stores the scalars.  `j` = the iteration this launch belongs
 // to if CG is still running (known at enqueue time).  A workgroup that starts after workgroup 0 has set `done` simply
 // exits: p is not needed once CG has stopped.                       conjugategradients.jl:42-51
+template <bool FOLD>
 __global__ __launch_bounds__(VEC_THREADS) void cg_finalize_pupdate_kernel(int64_t l, d2* __restrict__ p, const d2* __restrict__ r,
                                                                           DevState* st, const double* __restrict__ partials, int count,
-                                                                          const double* __restrict__ reduced, int from_reduced, int j) {
+                                                                          const double* __restrict__ reduced, int from_reduced, int j,
+                                                                          PeerBox pb, uint32_t seq_base) {
     if (st->done) return;
+    if (FOLD && st->xchg_failed) return;
     __shared__ double sums[1];
     if (from_reduced) { if (threadIdx.x == 0) sums[0] = reduced[0]; __syncthreads(); }
     else reduce_partials<1>(partials, count, sums);
+    if constexpr (FOLD) {
+        if (!peer_fold_sum<1>(pb, seq_base + 2u * (uint32_t)j + 1u, sums, st)) return;
+    }
     const d2 rt = r[l - 1];
     const double rr = sums[0] + (rt.x * rt.x + rt.y * rt.y);
     const double rnold = st->rn2[j & 1];
@@ -178,9 +246,13 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_finalize_pupdate_kernel(int64_
         p[i] = pi;
     }
 }
-void launch_cg_finalize_pupdate(const LaunchCtx& c, double2* p, const double2* r, int from_reduced, int j) {
-    hipLaunchKernelGGL(cg_finalize_pupdate_kernel, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p, r, c.st,
-                       c.partials + 3 * (size_t)PART_CAP, c.cg_blocks, c.reduced, from_reduced, j);
+void launch_cg_finalize_pupdate(const LaunchCtx& c, double2* p, const double2* r, int from_reduced, int j, const PeerBox* fold, uint32_t seq_base) {
+    if (fold)
+        hipLaunchKernelGGL(cg_finalize_pupdate_kernel<true>, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p, r, c.st,
+                           c.partials + 3 * (size_t)PART_CAP, c.cg_blocks, c.reduced, 0, j, *fold, seq_base);
+    else
+        hipLaunchKernelGGL(cg_finalize_pupdate_kernel<false>, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p, r, c.st,
+                           c.partials + 3 * (size_t)PART_CAP, c.cg_blocks, c.reduced, from_reduced, j, PeerBox{}, 0u);
 }
 
 void launch_cg_init(const LaunchCtx& c, const double2* rhs, const double2* Ap, double2* r, double2* p) {
