@@ -125,6 +125,8 @@ int fos_comm_init(fos_handle h, int nranks, int rank, const void* id128);
  *   fos_peer_selftest(h, rounds, &ok)                -> exchanges of known values checked exactly; ok = 0 on mismatch/time-out
  *   fos_peer_enable(h, on)                           -> use the mailboxes (on = 0: back to RCCL if fos_comm_init was
  *                                                       called, else single GPU); recomputes the global size / norms
+ * The two exchanges of every CG iteration are folded into the CG vector kernels (every workgroup polls, workgroup 0 also
+ * writes), so a sharded CG iteration needs no more launches than an unsharded one.
  * An exchange that waits longer than the time-out stops the solve with FOS_ECOMM (never a hang). */
 int fos_peer_export(fos_handle h, void* handle64);
 int fos_peer_open(fos_handle h, int nranks, int rank, const void* handles, double timeout_s);
