@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes on the KKT sweep alone (scratch/kkt_only.py): wave-time breakdown and cache behaviour.
+# PMC passes on the KKT sweep alone (tools/kkt_only.py): wave-time breakdown and cache behaviour.
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
@@ -15,7 +15,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_sum TCC_BUSY_sum" \
            "GRBM_GUI_ACTIVE GRBM_TA_BUSY"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python scratch/kkt_only.py $WL $WG 20 > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python tools/kkt_only.py $WL $WG 20 > $OUT/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections
