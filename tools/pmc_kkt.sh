@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC passes on the KKT sweep alone (tools/kkt_only.py): wave-time breakdown and cache behaviour.
+# (No TA_* counters: that pass aborted and hung a box of this pool; every pass runs under its own time-out.)
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
@@ -11,11 +12,10 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INST_LEVEL_VMEM SQ_INST_CYCLES_VMEM_RD SQ_LEVEL_WAVES" \
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum" \
            "TCP_TCC_READ_REQ_sum TCP_TA_TCP_STATE_READ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum" \
-           "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum" \
            "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_sum TCC_BUSY_sum" \
-           "GRBM_GUI_ACTIVE GRBM_TA_BUSY"; do
+           "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python tools/kkt_only.py $WL $WG 20 > $OUT/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python tools/kkt_only.py $WL $WG 20 > $OUT/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections
