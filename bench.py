@@ -228,6 +228,14 @@ def main():
     stored_bytes = (8.0 * ost["vals"] + 4.0 * ost["cols"] + 32.0 * ost["blocks"] + 2 * 16.0 * ost["slots"]
                     + 2 * 16.0 * (prob.m + prob.n) + 8.0 * (prob.m + prob.n))
     stored_gbs = stored_bytes / (avg_kernel_ms * 1e-3) / 1e9 if launches else 0.0
+    # N > 1: every rank sweeps its own shard at the same time; the job's SpMV rate is the sum over ranks
+    agg = None
+    if dist is not None:
+        tt = torch.tensor([achieved, stored_gbs], dtype=torch.float64, device=tdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        agg = {"achieved_all_ranks": round(float(tt[0]), 1), "stored_gbs_all_ranks": round(float(tt[1]), 1),
+               "frac_of_n_gpus_peak": round(float(tt[0]) / (HBM_PEAK_GBS * world), 4),
+               "note": "this rank's KKT apply on its shard is what `achieved` prices; the sum over the ranks is the job's rate"}
     out = {
         "metric": "GAP/DR outer iterations/sec (+ achieved HBM GB/s of the CG SpMV in `roofline`)",
         "value": round(value, 4),
@@ -268,6 +276,7 @@ def main():
                      "rectangles of A once for both products, so the sweep moves fewer bytes than that and `frac` can exceed 1; "
                      "`frac_stored` prices the bytes the format really streams") if ost["tiles"] else None,
             "operator_format": ost,
+            "all_ranks": agg,
             "avg_kernel_ms": round(avg_kernel_ms, 5),
             "launches_timed": launches,
             "launches_in_region": cg_timed,
