@@ -75,6 +75,8 @@ PROTOTYPES = {
     "fos_check": (C.c_int, [_h, _dp, C.c_double, C.POINTER(CheckResult)]),
     "fos_profile": (C.c_int, [_h, C.c_int32]),
     "fos_profile_read": (C.c_int, [_h, _i64p, _dp, _dp]),
+    "fos_profile_read_classes": (C.c_int, [_h, _i64p, _dp]),
+    "fos_bench_cg_chain": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "fos_bench_kkt": (C.c_int, [_h, C.c_int32, _dp]),
     "fos_sync": (C.c_int, [_h]),
     "fos_host_stacked_spmv": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, C.c_int32, C.c_int32, _i64p]),

@@ -1,0 +1,166 @@
+// Device helpers shared by kernels.hip and vecops.hip: wavefront / workgroup reductions in a fixed order, DPP lane-group
+// sums, the folded peer-mailbox exchange, and the scalar bookkeeping that closes a CG iteration.
+#pragma once
+
+#include "fos_internal.hpp"
+
+namespace fos {
+
+typedef double2 d2;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over aligned groups of `tpr` lanes (tpr a power of two, wave-uniform); every lane of a group gets the total
+__device__ __forceinline__ double group_sum(double v, int tpr) {
+    if (tpr >= 2) v += dpp_f64<0xB1>(v);       // quad_perm [1,0,3,2]
+    if (tpr >= 4) v += dpp_f64<0x4E>(v);       // quad_perm [2,3,0,1]
+    if (tpr >= 8) v += dpp_f64<0x141>(v);      // row_half_mirror
+    if (tpr >= 16) v += dpp_f64<0x140>(v);     // row_mirror
+    if (tpr >= 32) v += __shfl_xor(v, 16, 64);
+    if (tpr >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// sums partials[count][NACC] -> sums[NACC] (shared) in a fixed order; any block size that is a multiple of 64, <= 1024
+template <int NACC>
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int count, double* sums) {
+    __shared__ double smem[16 * NACC];
+    double acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] += partials[(int64_t)i * NACC + a];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        double v = wave_sum(acc[a]);
+        if (lane == 0) smem[wave * NACC + a] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += smem[w * NACC + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
+// Folded peer exchange (fos_internal.hpp, region 1 of the mailboxes): called by EVERY workgroup of a CG kernel with the
+// same local sums; workgroup 0 also stores them into the peers' mailboxes; all poll their own mailbox for the peers' words of
+// sequence number `seq` and add in rank order.  Returns false (and stops the solve) when a peer does not answer in time.
+template <int NACC>
+__device__ __forceinline__ bool peer_fold_sum(const PeerBox& pb, uint32_t seq, double* sums /* shared: in local, out total */, DevState* st) {
+    __shared__ uint32_t halves[PEER_MAX_RANKS * NACC * 2];
+    __shared__ int failed;
+    const int t = threadIdx.x;
+    if (t == 0) failed = 0;
+    __syncthreads();
+    const size_t par = (size_t)(seq & 1u) * PEER_MAX_RANKS;
+    if (t < pb.nranks * NACC * 2) {
+        const int hh = t & 1, v = (t >> 1) % NACC, r = (t >> 1) / NACC;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(sums[v]);
+        const uint32_t mine = hh ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+        if (r == pb.rank) {
+            halves[(r * NACC + v) * 2 + hh] = mine;
+        } else {
+            if (blockIdx.x == 0) {
+                unsigned long long* dst = pb.box[r] + PEER_BOX_WORDS + ((par + pb.rank) * PEER_MAX_VALS + v) * 2 + hh;
+                __hip_atomic_store(dst, ((unsigned long long)seq << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            const unsigned long long* src = pb.box[pb.rank] + PEER_BOX_WORDS + ((par + r) * PEER_MAX_VALS + v) * 2 + hh;
+            const long long t0 = wall_clock64();
+            unsigned long long w;
+            bool ok;
+            do {
+                w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ok = (uint32_t)(w >> 32) == seq;
+            } while (!ok && (wall_clock64() - t0) < pb.timeout_ticks);
+            if (!ok) failed = 1;
+            halves[(r * NACC + v) * 2 + hh] = (uint32_t)w;
+        }
+    }
+    __syncthreads();
+    if (failed) {
+        if (blockIdx.x == 0 && t == 0) { st->xchg_failed = 1; st->done = 1; }
+        return false;
+    }
+    if (t < NACC) {
+        double s = 0.0;
+        for (int r = 0; r < pb.nranks; ++r) {
+            const unsigned long long lo = halves[(r * NACC + t) * 2], hi = halves[(r * NACC + t) * 2 + 1];
+            s += __longlong_as_double((long long)((hi << 32) | lo));
+        }
+        sums[t] = s;
+    }
+    __syncthreads();
+    return true;
+}
+
+// What closes CG iteration `jd` (conjugategradients.jl:42-50): r.r from the partial sums the x,r update left, the stop test
+// `norm(r) <= tol || iter >= max_iters`, and -- if CG goes on -- beta = rn / rnold.  EVERY workgroup of the calling kernel
+// evaluates it on the same records in the same order (so all take the same decision); workgroup 0 stores the scalars.
+// r.r ping-pongs: RN[k] = r.r after iteration k (RN[0]: the start) lives in st->rn2[k & 1]; iteration j's alpha reads RN[j-1].
+struct CgClose { double beta; bool stop; bool ok; };
+__device__ __forceinline__ CgClose cg_close_iteration(DevState* st, const double* __restrict__ rr_partials, int count,
+                                                      const double* __restrict__ reduced, int from_reduced,
+                                                      const d2* __restrict__ r, int64_t l, int jd, const PeerBox& pb, uint32_t seq_base) {
+    // Every WAVEFRONT adds the <= 1024 records itself (lane-strided, then the butterfly): no LDS, no workgroup barrier, and
+    // all loads of this prologue are in flight together -- it is latency that every workgroup of a sweep pays before its first tile.
+    const int lane = threadIdx.x & 63;
+    const d2 rt = r[l - 1];
+    const double rnold = st->rn2[(jd - 1) & 1], tol = st->tol;
+    const int maxit = st->maxit;
+    double s = 0.0;
+    if (from_reduced) {
+        s = reduced[0];
+    } else {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = (lane + 64 * k < count) ? rr_partials[lane + 64 * k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += v[k];
+        s = wave_sum(s);
+    }
+    CgClose c{0.0, true, true};
+    if (pb.nranks > 0) {
+        __shared__ double sums[1];
+        if (threadIdx.x == 0) sums[0] = s;
+        __syncthreads();
+        if (!peer_fold_sum<1>(pb, seq_base + 2u * (uint32_t)jd + 1u, sums, st)) { c.ok = false; return c; }
+        s = sums[0];
+    }
+    const double rr = s + (rt.x * rt.x + rt.y * rt.y);
+    c.stop = (sqrt(rr) <= tol) || (jd >= maxit);                  // :42
+    c.beta = rr / rnold;                                          // :46-48
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->rr = rr;
+        if (c.stop) {
+            st->iter = jd;
+            st->hit_max = (jd == maxit) ? 1 : 0;                  // :53
+            __threadfence();
+            st->done = 1;
+        } else {
+            st->rn_old = rnold;
+            st->rn = rr;
+            st->rn2[jd & 1] = rr;
+            st->beta = c.beta;
+            st->iter = jd + 1;                                    // :50
+        }
+    }
+    return c;
+}
+
+}  // namespace fos

@@ -191,12 +191,36 @@ struct LaunchCtx {
     int32_t vec_blocks;    // grid of the vector kernels
     int32_t cg_blocks;     // grid of the two fused CG kernels (every workgroup re-reduces the partials: fewer, fatter groups)
     const PeerBox* peer;   // non-null: launch_reduce1 also exchanges the sums with the peer ranks (no RCCL call follows)
+    const uint32_t* def_mask;   // bit i set: row i of S is finished from partial slots (nullptr: no dual tiles)
 };
 
-// KKT apply, 2 RHS interleaved:  out = [I Q'; Q -I] * w   (rows 0..n+m-1; the tau row is written by kkt_finalize)
+// KKT apply, 2 RHS interleaved:  out = [I Q'; Q -I] * w   (rows 0..n+m-1; the tau row is written by kkt_finalize).
+// Stand-alone form: sweep (+ deferred-row kernel for operators with dual tiles); partial sums: c.S.npart records at c.S.part_off
 void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate);
 // finishes the tau rows of out = M w from the sweep's partial sums (CG init / test entry)
 void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int gate, int from_reduced);
+
+// One CG iteration = TWO dependent launches (conjugategradients.jl:37-51):
+//   launch_kkt2_cg   iteration j >= 2 with fuse_p: closes iteration j-1 (r.r, stop test, beta), then sweeps with
+//                    p_j = r + beta p_{j-1} formed on the fly and stored through the rows' owners; partial sums of Ap.p and
+//                    of the tau rows, including the share of rows spread over dual-tile slots (c.S.nwg records at record 0);
+//   launch_cg_update alpha, tau rows, the slot-spread rows of Ap, x += alpha p, r -= alpha Ap, r.r partials.
+// Without fuse_p (gather-bound sparse operators: forming p on the fly would double the gathers) the p update stays a third
+// launch (launch_cg_pupdate).  p_j lives in buffer j & 1.
+struct CgIter {
+    int j;                     // iteration number, from 1
+    const double2* r;
+    const double2* p_prev;     // p_{j-1}
+    double2* p_cur;            // p_j
+    bool fuse_p;
+    int rr_from_reduced;       // r.r of iteration j-1 was all-reduced into c.reduced (sharded, RCCL)
+    const PeerBox* fold;       // non-null: the two exchanges of the iteration happen inside the two kernels (peer mailboxes)
+    uint32_t seq_base;
+};
+void launch_kkt2_cg(const LaunchCtx& c, const CgIter& it, double2* Ap);
+void launch_cg_stop_check(const LaunchCtx& c, const CgIter& it);      // closes iteration it.j - 1 when no sweep follows in this batch
+void launch_cg_update(const LaunchCtx& c, const CgIter& it, double2* x, double2* r, double2* Ap, int kkt_from_reduced);
+void launch_cg_pupdate(const LaunchCtx& c, const CgIter& it, double2* p_next);   // !fuse_p: closes iteration j, p_{j+1} = r + beta p_j
 
 // single right-hand side Q apply on component `comp` of an interleaved vector
 //   Q_PLAIN : out_plain[i] = sign * (Q v)_i            (rows 0..n+m-1; tau row by q1_finalize)
@@ -209,12 +233,6 @@ void launch_q1_finalize(const LaunchCtx& c, QMode mode, const double2* v, int co
 // CG vector kernels
 void launch_cg_init(const LaunchCtx& c, const double2* rhs, const double2* Ap, double2* r, double2* p);
 void launch_cg_init_finalize(const LaunchCtx& c, const double2* r, double tol, int maxit, int from_reduced);
-// stop test + beta + p update in one launch (iteration number j known at enqueue time)
-void launch_cg_finalize_pupdate(const LaunchCtx& c, double2* p, const double2* r, int from_reduced, int j,
-                                const PeerBox* fold = nullptr, uint32_t seq_base = 0);
-// tau rows of Ap, alpha = rn/(Ap.p), x += alpha p, r -= alpha Ap in one launch; its r.r partials go to partials + 3*16392
-void launch_cg_alpha_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, double2* Ap, int from_reduced, int j,
-                            const PeerBox* fold = nullptr, uint32_t seq_base = 0);
 void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate, int off = 0);   // partials[off.. +count][nacc] -> reduced[nacc] (+ peer exchange)
 
 // outer-loop vector kernels (gap.jl:48,58,78; gapa.jl:67,77,96-103; fista.jl:31-46; dykstra.jl)

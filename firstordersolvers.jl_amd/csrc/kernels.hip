@@ -14,19 +14,13 @@
 //   relaxation / extrapolation passes of gap.jl:48,58,78  gapa.jl:67,77,96-103  fista.jl:31-46.
 //
 // Wavefront = 64 lanes; workgroups of 256 threads (4 waves) unless noted; all arithmetic fp64.
-#include "fos_internal.hpp"
+#include <type_traits>
+
+#include "dev_common.hpp"
 
 namespace fos {
 
-typedef double2 d2;
-
 // ------------------------------------------------------------------------------------------------ helpers
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
 
 // Blocks b and b+8 share an XCD (round-robin dispatch); give every XCD one contiguous slice of the row blocks so
 // its private L2 sees a compact window of the gathered vector.  Speed only, never correctness.
@@ -66,24 +60,6 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
 //   Long row (> WNNZ entries): the wavefront strides the row, 4 loads in flight per lane, and reduces in-register.
 // Summation order is fixed by the storage -> bit-reproducible run to run.
 
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-// sum over aligned groups of `tpr` lanes (tpr a power of two, wave-uniform); every lane of a group gets the total
-__device__ __forceinline__ double group_sum(double v, int tpr) {
-    if (tpr >= 2) v += dpp_f64<0xB1>(v);       // quad_perm [1,0,3,2]
-    if (tpr >= 4) v += dpp_f64<0x4E>(v);       // quad_perm [2,3,0,1]
-    if (tpr >= 8) v += dpp_f64<0x141>(v);      // row_half_mirror
-    if (tpr >= 16) v += dpp_f64<0x140>(v);     // row_mirror
-    if (tpr >= 32) v += __shfl_xor(v, 16, 64);
-    if (tpr >= 64) v += __shfl_xor(v, 32, 64);
-    return v;
-}
-
 template <class T>
 __device__ __forceinline__ T nt_load(const T* p) { return __builtin_nontemporal_load(p); }
 
@@ -93,42 +69,79 @@ struct RowPre { d2 v; double c; };
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-// Gathered vector element(s).  operator(): plain load through the per-CU L1.  nt(): non-temporal (L1-bypassing) variant,
-// kept for experiments only: measured on random gathers (C5, sprandn) it is 1.6x SLOWER than the cached load, although
-// each L1 fill brings a 128-byte line for 16 useful bytes -- the sweep of a random-sparse operator runs at the L2->L1
-// line rate (~125 G lines/s chip wide), which is what bounds C3/C5.
-template <int NRHS>
-struct Gather;
-template <>
-struct Gather<2> {
+// Gathered vector element(s).  load(c): plain load through the per-CU L1.  (An L1-bypassing non-temporal gather was measured
+// 1.6x SLOWER on random gathers (C5, sprandn) although each L1 fill brings a 128-byte line for 16 useful bytes -- the sweep
+// of a random-sparse operator runs at the L2->L1 line rate, DESIGN.md.)
+//   GatherW : element c of an interleaved vector w (both right-hand sides in one 16-byte load).
+//   GatherP : the CG direction formed ON THE FLY, p_new[c] = r[c] + beta p_old[c] (conjugategradients.jl:49: p .*= beta;
+//             p .+= r -- a multiply and an add, no contraction, so that every wavefront that needs element c and the one
+//             that stores it compute the same bits): the p update of iteration j-1 rides on the sweep of iteration j.
+//   Gather1 : one component of an interleaved vector (single right-hand side applies).
+// load_u(c): the same element for a WAVE-UNIFORM index, read through the constant address space so that it becomes a scalar
+// load (s_load_dwordx4: no vector-memory instruction, no VGPRs, no 1 KB of L1 return data for 16 useful bytes).  Valid because
+// no kernel writes a vector it gathers from (p_new goes to the other ping-pong buffer), and a kernel boundary invalidates the
+// scalar cache.
+typedef const __attribute__((address_space(4))) v2d* cptr_v2d;
+__device__ __forceinline__ d2 ld_const(const d2* p) { const v2d t = *(cptr_v2d)(p); return make_double2(t.x, t.y); }
+typedef const __attribute__((address_space(4))) double* cptr_f64;
+struct GatherW {
+    static constexpr int NRHS = 2;
+    static constexpr bool FUSED = false;
     const d2* w;
-    __device__ __forceinline__ d2 operator()(double v, int c) const {
-        d2 x = w[c];
-        return make_double2(v * x.x, v * x.y);
-    }
-    __device__ __forceinline__ d2 nt(double v, int c) const {
-        const v2d x = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(w) + c);
-        return make_double2(v * x.x, v * x.y);
-    }
     __device__ __forceinline__ d2 load(int c) const { return w[c]; }
+    __device__ __forceinline__ d2 load_u(int c) const { return ld_const(w + c); }
 };
-template <>
-struct Gather<1> {
+struct GatherP {
+    static constexpr int NRHS = 2;
+    static constexpr bool FUSED = true;
+    const d2* r;
+    const d2* pold;
+    double beta;
+    __device__ __forceinline__ d2 load(int c) const {
+#pragma clang fp contract(off)
+        const d2 a = r[c], b = pold[c];
+        const double bx = b.x * beta, by = b.y * beta;
+        return make_double2(bx + a.x, by + a.y);
+    }
+    __device__ __forceinline__ d2 load_u(int c) const {
+#pragma clang fp contract(off)
+        const d2 a = ld_const(r + c), b = ld_const(pold + c);
+        const double bx = b.x * beta, by = b.y * beta;
+        return make_double2(bx + a.x, by + a.y);
+    }
+    // the two addends of element c, wave-uniform (scalar loads): a tile forms its row sums as A r + beta (A p_old) so that
+    // the gathered elements stay in scalar registers (32 vector registers less: 4 instead of 3 wavefronts per SIMD)
+    __device__ __forceinline__ d2 r_u(int c) const { return ld_const(r + c); }
+    __device__ __forceinline__ d2 pold_u(int c) const { return ld_const(pold + c); }
+};
+struct Gather1 {
+    static constexpr int NRHS = 1;
+    static constexpr bool FUSED = false;
     const double* w;   // points at the chosen component of an interleaved vector: element c at w[2c]
-    __device__ __forceinline__ double operator()(double v, int c) const { return v * w[2 * (int64_t)c]; }
-    __device__ __forceinline__ double nt(double v, int c) const { return v * __builtin_nontemporal_load(w + 2 * (int64_t)c); }
     __device__ __forceinline__ d2 load(int c) const { return make_double2(w[2 * (int64_t)c], 0.0); }
+    __device__ __forceinline__ d2 load_u(int c) const { return make_double2(*(cptr_f64)(w + 2 * (int64_t)c), 0.0); }
 };
+// value x gathered element
+template <class G>
+__device__ __forceinline__ d2 gprod(const G& g, double v, int c) {
+    const d2 x = g.load(c);
+    if constexpr (G::NRHS == 2) return make_double2(v * x.x, v * x.y);
+    else return make_double2(v * x.x, 0.0);
+}
 
 constexpr int WPL = WNNZ / 64;      // stream entries per lane
 
 // A row the sweep has summed: run its epilogue, or -- a DEFERRED row (dual tiles hold the rest of it) -- park the sum in
-// the row's own partial slot for the deferred-row kernel.
+// the row's own partial slot for whoever adds the slot lists (epi.park: a CG sweep adds the row's share of Ap.p there).
 template <bool DEFER, class Epi>
 __device__ __forceinline__ void finish_row(const DevBlkCsr& S, Epi& epi, int row, double a1, double a2, const RowPre& pr) {
     if constexpr (DEFER) {
         const int ds = S.row_defer[row];
-        if (ds >= 0) { reinterpret_cast<d2*>(S.slots)[ds] = make_double2(a1, a2); return; }
+        if (ds >= 0) {
+            reinterpret_cast<d2*>(S.slots)[ds] = make_double2(a1, a2);
+            epi.park(row, a1, a2, pr.v);
+            return;
+        }
     }
     epi.row(row, a1, a2, pr);
 }
@@ -177,8 +190,8 @@ __device__ __forceinline__ double tile_colsum8(const double (&p)[8], int lane) {
 }
 
 // NR long run-rows over the same column range [c00, c00+cnt): each gathered element feeds NR matrix values
-template <int NR, int NRHS, bool DEFER, class Epi>
-__device__ __forceinline__ void long_run_rows(const DevBlkCsr& S, const Gather<NRHS>& gat, Epi& epi, const double* __restrict__ val, int64_t stride,
+template <int NR, bool DEFER, class G, class Epi>
+__device__ __forceinline__ void long_run_rows(const DevBlkCsr& S, const G& gat, Epi& epi, const double* __restrict__ val, int64_t stride,
                                               int cnt, int c00, int row0, int lane) {
     double a1[NR], a2[NR];
 #pragma unroll
@@ -193,39 +206,30 @@ __device__ __forceinline__ void long_run_rows(const DevBlkCsr& S, const Gather<N
         for (int i = 0; i < NR; ++i)
 #pragma unroll
             for (int u = 0; u < U; ++u) v[i][u] = nt_load(val + i * stride + k + 64 * u);
-        if constexpr (NRHS == 2) {
-            d2 x[U];
+        d2 x[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) x[u] = gat.w[c00 + k + 64 * u];
+        for (int u = 0; u < U; ++u) x[u] = gat.load(c00 + k + 64 * u);
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int i = 0; i < NR; ++i) { a1[i] += v[i][u] * x[u].x; a2[i] += v[i][u] * x[u].y; }
-        } else {
-            double x[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) x[u] = gat.w[2 * (int64_t)(c00 + k + 64 * u)];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int i = 0; i < NR; ++i) a1[i] += v[i][u] * x[u];
-        }
+            for (int i = 0; i < NR; ++i) {
+                a1[i] += v[i][u] * x[u].x;
+                if constexpr (G::NRHS == 2) a2[i] += v[i][u] * x[u].y;
+            }
     }
     for (; k < cnt; k += 64) {
-        if constexpr (NRHS == 2) {
-            const d2 x = gat.w[c00 + k];
+        const d2 x = gat.load(c00 + k);
 #pragma unroll
-            for (int i = 0; i < NR; ++i) { const double v = nt_load(val + i * stride + k); a1[i] += v * x.x; a2[i] += v * x.y; }
-        } else {
-            const double x = gat.w[2 * (int64_t)(c00 + k)];
-#pragma unroll
-            for (int i = 0; i < NR; ++i) a1[i] += nt_load(val + i * stride + k) * x;
+        for (int i = 0; i < NR; ++i) {
+            const double v = nt_load(val + i * stride + k);
+            a1[i] += v * x.x;
+            if constexpr (G::NRHS == 2) a2[i] += v * x.y;
         }
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         a1[i] = group_sum(a1[i], 64);
-        if constexpr (NRHS == 2) a2[i] = group_sum(a2[i], 64);
+        if constexpr (G::NRHS == 2) a2[i] = group_sum(a2[i], 64);
     }
     // lane i finishes row i
 #pragma unroll
@@ -235,8 +239,8 @@ __device__ __forceinline__ void long_run_rows(const DevBlkCsr& S, const Gather<N
 
 // U lane-major steps of an ELL block starting at step t: all U value (and index) loads are issued before the first
 // use, so a wavefront keeps U x 512 B (+ indices, + gathers) in flight.
-template <int U, int NRHS, bool RUN>
-__device__ __forceinline__ void ell_steps(const Gather<NRHS>& gat, const double* __restrict__ val, const int32_t* __restrict__ col,
+template <int U, bool RUN, class G>
+__device__ __forceinline__ void ell_steps(const G& gat, const double* __restrict__ val, const int32_t* __restrict__ col,
                                           int t, int tpr, int lig, int len, int c0, double& a1, double& a2) {
     double v[U];
     int c[U];
@@ -253,51 +257,40 @@ __device__ __forceinline__ void ell_steps(const Gather<NRHS>& gat, const double*
         m[u] = e < len;
         if constexpr (RUN) c[u] = c0 + (m[u] ? e : 0);
     }
-    if constexpr (NRHS == 2) {
-        d2 p[U];
+    d2 p[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) p[u] = gat(v[u], c[u]);
+    for (int u = 0; u < U; ++u) p[u] = gprod(gat, v[u], c[u]);
 #pragma unroll
-        for (int u = 0; u < U; ++u) if (m[u]) { a1 += p[u].x; a2 += p[u].y; }
-    } else {
-        double p[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) p[u] = gat(v[u], c[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) if (m[u]) a1 += p[u];
-    }
+    for (int u = 0; u < U; ++u)
+        if (m[u]) {
+            a1 += p[u].x;
+            if constexpr (G::NRHS == 2) a2 += p[u].y;
+        }
 }
 
 // U strided steps of a long row starting at entry k (lane-consecutive, 64 entries per step)
-template <int U, int NRHS, bool RUN>
-__device__ __forceinline__ void long_steps(const Gather<NRHS>& gat, const double* __restrict__ val, const int32_t* __restrict__ col,
-                                           int k, int c00, double& a1, double& a2) {
+template <int U, class G>
+__device__ __forceinline__ void long_steps(const G& gat, const double* __restrict__ val, const int32_t* __restrict__ col,
+                                           int k, double& a1, double& a2) {
     double v[U];
     int c[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) v[u] = nt_load(val + k + 64 * u);
 #pragma unroll
+    for (int u = 0; u < U; ++u) c[u] = nt_load(col + k + 64 * u);
+    d2 p[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) p[u] = gprod(gat, v[u], c[u]);
+#pragma unroll
     for (int u = 0; u < U; ++u) {
-        if constexpr (RUN) c[u] = c00 + k + 64 * u;
-        else c[u] = nt_load(col + k + 64 * u);
-    }
-    if constexpr (NRHS == 2) {
-        d2 p[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) p[u] = gat(v[u], c[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) { a1 += p[u].x; a2 += p[u].y; }
-    } else {
-        double p[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) p[u] = gat(v[u], c[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) a1 += p[u];
+        a1 += p[u].x;
+        if constexpr (G::NRHS == 2) a2 += p[u].y;
     }
 }
 
-template <int NRHS, bool DEFER, class Epi>
-__device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>& gat, Epi& epi, double* prod_all) {
+template <bool DEFER, class G, class Epi>
+__device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi& epi, double* prod_all) {
+    constexpr int NRHS = G::NRHS;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = xcd_remap(blockIdx.x, S.nwg);
@@ -320,14 +313,14 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
                 const int c00 = S.col[d.colpos];  // consecutive columns: col(e) = c00 + e
                 const int nr = d.nrows();
                 const int64_t stride = (d.cnt + NNZ_ALIGN - 1) / NNZ_ALIGN * NNZ_ALIGN;
-                if (nr == 4) long_run_rows<4, NRHS, DEFER>(S, gat, epi, val, stride, cnt, c00, d.row0, lane);
-                else if (nr == 2) long_run_rows<2, NRHS, DEFER>(S, gat, epi, val, stride, cnt, c00, d.row0, lane);
-                else long_run_rows<1, NRHS, DEFER>(S, gat, epi, val, stride, cnt, c00, d.row0, lane);
+                if (nr == 4) long_run_rows<4, DEFER>(S, gat, epi, val, stride, cnt, c00, d.row0, lane);
+                else if (nr == 2) long_run_rows<2, DEFER>(S, gat, epi, val, stride, cnt, c00, d.row0, lane);
+                else long_run_rows<1, DEFER>(S, gat, epi, val, stride, cnt, c00, d.row0, lane);
                 continue;
             } else {
-                for (; k + 7 * 64 < cnt; k += 8 * 64) long_steps<8, NRHS, false>(gat, val, col, k, 0, a1, a2);
-                for (; k + 1 * 64 < cnt; k += 2 * 64) long_steps<2, NRHS, false>(gat, val, col, k, 0, a1, a2);
-                for (; k < cnt; k += 64) long_steps<1, NRHS, false>(gat, val, col, k, 0, a1, a2);
+                for (; k + 7 * 64 < cnt; k += 8 * 64) long_steps<8>(gat, val, col, k, a1, a2);
+                for (; k + 1 * 64 < cnt; k += 2 * 64) long_steps<2>(gat, val, col, k, a1, a2);
+                for (; k < cnt; k += 64) long_steps<1>(gat, val, col, k, a1, a2);
             }
             a1 = group_sum(a1, 64);
             if constexpr (NRHS == 2) a2 = group_sum(a2, 64);
@@ -349,34 +342,59 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
                 d2* __restrict__ slots = reinterpret_cast<d2*>(S.slots);
                 double r1 = 0.0, r2 = 0.0;
                 double vn[TILE_GROUP];                 // the next group's values are in flight while this group is reduced
+                // the element of this lane's column slot (lanes 0..7), for epi.park: fetched one group AHEAD and BEFORE that
+                // group's values -- vmcnt retires in order, so a load issued behind the value prefetch could only be waited
+                // for together with it, which would serialise the pipeline
+                d2 xln = make_double2(0.0, 0.0);
+                if constexpr (Epi::FOLDDEF) { if (lane < TILE_GROUP && lane < tc) xln = gat.load(c0 + lane); }
 #pragma unroll
                 for (int u = 0; u < TILE_GROUP; ++u) vn[u] = nt_load(val + 64 * u);
                 for (int t = 0; t < T; t += TILE_GROUP) {
                     double v[TILE_GROUP];
                     d2 x[TILE_GROUP];
+                    const d2 xl = xln;
 #pragma unroll
                     for (int u = 0; u < TILE_GROUP; ++u) v[u] = vn[u];
                     if (t + TILE_GROUP < T) {
+                        if constexpr (Epi::FOLDDEF) { if (lane < TILE_GROUP && t + TILE_GROUP + lane < tc) xln = gat.load(c0 + t + TILE_GROUP + lane); }
 #pragma unroll
                         for (int u = 0; u < TILE_GROUP; ++u) vn[u] = nt_load(val + 64 * (t + TILE_GROUP + u));
                     }
-#pragma unroll
-                    for (int u = 0; u < TILE_GROUP; ++u) x[u] = (t + u < tc) ? gat.load(c0 + t + u) : make_double2(0.0, 0.0);
                     double p1[TILE_GROUP], p2[TILE_GROUP];
+                    if constexpr (G::FUSED) {
+                        // row sums of p_new = r + beta p_old as (A r) + beta (A p_old): equal to rounding, operands stay scalar
+                        double ga1 = 0.0, ga2 = 0.0, gb1 = 0.0, gb2 = 0.0;
 #pragma unroll
-                    for (int u = 0; u < TILE_GROUP; ++u) {
-                        r1 += v[u] * x[u].x;
-                        p1[u] = v[u] * wr.x;
-                        if constexpr (NRHS == 2) { r2 += v[u] * x[u].y; p2[u] = v[u] * wr.y; }
+                        for (int u = 0; u < TILE_GROUP; ++u) {
+                            const d2 xa = (t + u < tc) ? gat.r_u(c0 + t + u) : make_double2(0.0, 0.0);
+                            const d2 xb = (t + u < tc) ? gat.pold_u(c0 + t + u) : make_double2(0.0, 0.0);
+                            ga1 += v[u] * xa.x; ga2 += v[u] * xa.y;
+                            gb1 += v[u] * xb.x; gb2 += v[u] * xb.y;
+                            p1[u] = v[u] * wr.x; p2[u] = v[u] * wr.y;
+                        }
+                        r1 += ga1 + gat.beta * gb1;
+                        r2 += ga2 + gat.beta * gb2;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < TILE_GROUP; ++u) x[u] = (t + u < tc) ? gat.load_u(c0 + t + u) : make_double2(0.0, 0.0);
+#pragma unroll
+                        for (int u = 0; u < TILE_GROUP; ++u) {
+                            r1 += v[u] * x[u].x;
+                            p1[u] = v[u] * wr.x;
+                            if constexpr (NRHS == 2) { r2 += v[u] * x[u].y; p2[u] = v[u] * wr.y; }
+                        }
                     }
                     const double s1 = tile_colsum8(p1, lane);
                     double s2 = 0.0;
                     if constexpr (NRHS == 2) s2 = tile_colsum8(p2, lane);
-                    if (lane < TILE_GROUP) slots[cslot + t + lane] = make_double2(s1, s2);
+                    if (lane < TILE_GROUP) {
+                        slots[cslot + t + lane] = make_double2(s1, s2);
+                        epi.park(c0 + t + lane, s1, s2, xl);
+                    }
                 }
                 if (valid) {
                     if (rslot < 0) epi.row(row, r1, r2, pr);
-                    else slots[rslot + lane] = make_double2(r1, r2);
+                    else { slots[rslot + lane] = make_double2(r1, r2); epi.park(row, r1, r2, wr); }
                 }
             }
         } else if (kind == BLK_ELL) {
@@ -397,14 +415,14 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
                 // consecutive columns: entry e = t*tpr + lig of this lane's row sits in column c0 + e; lanes past their
                 // row's length (and padding lanes) read column c0 (valid) and are masked
                 const int c0 = (row < R) ? S.col[d.colpos + row] : 0;
-                for (; t + 8 <= T; t += 8) ell_steps<8, NRHS, true>(gat, val, nullptr, t, tpr, lig, len, c0, a1, a2);
-                for (; t + 2 <= T; t += 2) ell_steps<2, NRHS, true>(gat, val, nullptr, t, tpr, lig, len, c0, a1, a2);
-                for (; t < T; ++t) ell_steps<1, NRHS, true>(gat, val, nullptr, t, tpr, lig, len, c0, a1, a2);
+                for (; t + 8 <= T; t += 8) ell_steps<8, true>(gat, val, nullptr, t, tpr, lig, len, c0, a1, a2);
+                for (; t + 2 <= T; t += 2) ell_steps<2, true>(gat, val, nullptr, t, tpr, lig, len, c0, a1, a2);
+                for (; t < T; ++t) ell_steps<1, true>(gat, val, nullptr, t, tpr, lig, len, c0, a1, a2);
             } else {
                 const int32_t* __restrict__ col = S.col + d.colpos + lane;
-                for (; t + 8 <= T; t += 8) ell_steps<8, NRHS, false>(gat, val, col, t, tpr, lig, len, 0, a1, a2);
-                for (; t + 2 <= T; t += 2) ell_steps<2, NRHS, false>(gat, val, col, t, tpr, lig, len, 0, a1, a2);
-                for (; t < T; ++t) ell_steps<1, NRHS, false>(gat, val, col, t, tpr, lig, len, 0, a1, a2);
+                for (; t + 8 <= T; t += 8) ell_steps<8, false>(gat, val, col, t, tpr, lig, len, 0, a1, a2);
+                for (; t + 2 <= T; t += 2) ell_steps<2, false>(gat, val, col, t, tpr, lig, len, 0, a1, a2);
+                for (; t < T; ++t) ell_steps<1, false>(gat, val, col, t, tpr, lig, len, 0, a1, a2);
             }
             a1 = group_sum(a1, tpr);
             if constexpr (NRHS == 2) a2 = group_sum(a2, tpr);
@@ -440,8 +458,9 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
                 for (int j = 0; j < WPL; ++j) {
                     const int k = lane + j * 64;
                     if (k < cnt) {
-                        if constexpr (NRHS == 2) reinterpret_cast<d2*>(prod)[k] = gat(v[j], c[j]);
-                        else prod[k] = gat(v[j], c[j]);
+                        const d2 pv = gprod(gat, v[j], c[j]);
+                        if constexpr (NRHS == 2) reinterpret_cast<d2*>(prod)[k] = pv;
+                        else prod[k] = pv.x;
                     }
                 }
             }
@@ -466,14 +485,23 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const Gather<NRHS>
 
 // ------------------------------------------------------------------------------------------------ KKT apply, 2 RHS
 
+// Row epilogue of out = [I Q'; Q -I] w for both right-hand sides, plus the three sums CG needs.
+//   FOLD (CG sweeps over an operator with dual tiles): rows whose sum is spread over partial slots are finished by the NEXT
+//   kernel (cg_update_kernel adds the slot lists while it updates x and r), yet alpha = rn / (Ap.p) is needed before that.
+//   Ap.p is bilinear in the partial sums: for a deferred row i with slots s_k, p = p_i, c = [c;b]_i, sg = +1 (i < n), -1 (else)
+//       (Ap)_i . p_i = (p.x^2 - p.y^2) + c (wt.x p.y - wt.y p.x) + sg * sum_k (s_k.x p.y - s_k.y p.x)
+//   so whoever WRITES a slot adds its term (park), and the slot-free part is added once per deferred row by kkt_deferred_local.
+template <class G, bool FOLD>
 struct EpiKkt {
-    const d2* w;
+    static constexpr bool FOLDDEF = FOLD;
+    G gat;
     d2* out;
+    d2* pnew;          // GatherP: where the row's owner stores p_new[i]
     const double* cb;
     int n;
     d2 wt;             // (p1_tau, p2_tau)
     double acc[3];     // S1 = sum Ap.p (non-tau rows), T1 = [c;b].p1, T2 = [c;b].p2
-    __device__ __forceinline__ RowPre pre(int i) const { return RowPre{w[i], cb[i]}; }
+    __device__ __forceinline__ RowPre pre(int i) const { return RowPre{gat.load(i), cb[i]}; }
     __device__ __forceinline__ void row(int i, double u1, double u2, const RowPre& pr) {
         const d2 p = pr.v;
         const double c = pr.c;
@@ -483,31 +511,87 @@ struct EpiKkt {
         const double a1 = p.x - q2;                     // y1 = Q'x2 + x1 = -(Q x2) + x1     affinepluslinear.jl:45-46
         const double a2 = q1 - p.y;                     // y2 = Q x1 - x2                    affinepluslinear.jl:47-48
         out[i] = make_double2(a1, a2);
+        if constexpr (G::FUSED) pnew[i] = p;
         acc[0] += a1 * p.x + a2 * p.y;
+        acc[1] += c * p.x;
+        acc[2] += c * p.y;
+    }
+    // a partial sum (s1, s2) of row i went to a slot; p = the row's vector element
+    __device__ __forceinline__ void park(int i, double s1, double s2, const d2& p) {
+        if constexpr (FOLD) {
+            const double t = s1 * p.y - s2 * p.x;
+            acc[0] += (i < n) ? t : -t;
+        }
+    }
+    // the slot-free part of a deferred row (and its p_new)
+    __device__ __forceinline__ void deferred_local(int i) {
+        const d2 p = gat.load(i);
+        const double c = cb[i];
+        if constexpr (G::FUSED) pnew[i] = p;
+        acc[0] += (p.x * p.x - p.y * p.y) + c * (wt.x * p.y - wt.y * p.x);
         acc[1] += c * p.x;
         acc[2] += c * p.y;
     }
 };
 
-template <bool DEFER>
-__global__ __launch_bounds__(SPMV_THREADS) void kkt2_kernel(DevBlkCsr S, const d2* __restrict__ w, d2* __restrict__ out,
-                                                            const double* __restrict__ cb, int n, int nm,
-                                                            double* __restrict__ partials, const DevState* st, int gate) {
-    if (gate && st->done) return;
+// Fused dual-RHS KKT sweep.  Template switches:
+//   DEFER  the operator has dual tiles (rows spread over partial slots);
+//   FUSEP  CG iteration j >= 2: the kernel first CLOSES iteration j-1 (cg_close_iteration: r.r from the update kernel's
+//          partials, stop test, beta -- every workgroup, same order), then sweeps with p_j = r + beta p_{j-1} formed on the fly
+//          (GatherP) and stores p_j through the rows' owners: conjugategradients.jl:42-50 without a launch of its own;
+//   FOLD   the slot-spread rows' share of Ap.p is added here (EpiKkt), so no deferred-row kernel follows in a CG iteration.
+struct KktArgs {
+    const d2* w;               // !FUSEP: the vector to apply to (p_j);  FUSEP: p_{j-1}
+    const d2* r;               // FUSEP
+    d2* pnew;                  // FUSEP: p_j
+    d2* out;
+    const double* cb;
+    int n, nm;
+    double* partials;          // 3 doubles per workgroup
+    DevState* st;
+    int gate;                  // !FUSEP: skip when st->done
+    const double* rr_partials; // FUSEP: the update kernel's r.r records
+    int rr_count;
+    const double* reduced;     // FUSEP + RCCL: all-reduced r.r
+    int from_reduced;
+    int j;                     // FUSEP: this iteration (>= 2)
+    PeerBox pb;                // FUSEP: nranks > 0 -> the r.r exchange happens here (peer mailboxes)
+    uint32_t seq_base;
+};
+
+template <bool DEFER, bool FUSEP, bool FOLD>
+__global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBlkCsr S, KktArgs a) {
+    static_assert(!FOLD || DEFER, "FOLD is about deferred rows");
+    if ((FUSEP || a.gate) && a.st->done) return;
     __shared__ __attribute__((aligned(16))) double prod[SPMV_WAVES * WNNZ * 2];
     __shared__ double red[16];
-    EpiKkt epi;
-    epi.w = w; epi.out = out; epi.cb = cb; epi.n = n; epi.wt = w[nm];
+    using G = typename std::conditional<FUSEP, GatherP, GatherW>::type;
+    G gat;
+    if constexpr (FUSEP) {
+        if (a.pb.nranks > 0 && a.st->xchg_failed) return;
+        const CgClose cl = cg_close_iteration(a.st, a.rr_partials, a.rr_count, a.reduced, a.from_reduced, a.r, (int64_t)a.nm + 1, a.j - 1, a.pb, a.seq_base);
+        if (!cl.ok || cl.stop) return;
+        gat.r = a.r; gat.pold = a.w; gat.beta = cl.beta;
+    } else {
+        gat.w = a.w;
+    }
+    EpiKkt<G, FOLD> epi;
+    epi.gat = gat; epi.out = a.out; epi.pnew = a.pnew; epi.cb = a.cb; epi.n = a.n; epi.wt = gat.load_u(a.nm);
     epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
-    Gather<2> gat{w};
-    spmv_walk<2, DEFER>(S, gat, epi, prod);
-    block_reduce_store<3, SPMV_THREADS>(epi.acc, red, partials + 3 * (int64_t)blockIdx.x);
+    if constexpr (FUSEP) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.pnew[a.nm] = epi.wt;          // the tau element has no row in S
+    }
+    if constexpr (FOLD) {
+        for (int q = blockIdx.x * SPMV_THREADS + threadIdx.x; q < S.ndef; q += gridDim.x * SPMV_THREADS) epi.deferred_local(S.def_rows[q]);
+    }
+    spmv_walk<DEFER>(S, gat, epi, prod);
+    block_reduce_store<3, SPMV_THREADS>(epi.acc, red, a.partials + 3 * (int64_t)blockIdx.x);
 }
 
-// Deferred rows (dual tiles): one thread per row adds the row's partial slots in list order and runs the epilogue the
-// sweep could not; its workgroups append their partial sums behind the sweep's (records nwg .. nwg + nwg_def - 1).
-// `lpr` lanes (a power of two <= 64, S.def_lpr) share a row: lane-strided partial sums, then the fixed DPP butterfly --
-// long slot lists (a dense LP: one partial per 64-row tile) are latency bound with one thread per row.
+// Deferred rows (dual tiles): `lpr` lanes (a power of two <= 64, S.def_lpr) share a row: lane-strided partial sums of the
+// row's slots in list order, then the fixed DPP butterfly -- long slot lists (a dense LP: one partial per 64-row tile) are
+// latency bound with one thread per row.  Used by the stand-alone applies (CG start, rhs build, status, test entries); inside
+// a CG iteration cg_update_kernel does the same sums itself.
 template <class Epi>
 __device__ __forceinline__ void deferred_rows(const DevBlkCsr& S, Epi& epi) {
     const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots);
@@ -535,8 +619,8 @@ __device__ __forceinline__ void deferred_rows(const DevBlkCsr& S, Epi& epi) {
     }
 }
 // The sweep left nwg partial-sum records; the deferred-row kernel runs after it anyway, so each of its nwg_def workgroups
-// also folds a slice of them into its own record: the consumers (every workgroup of cg_alpha_update re-reduces the
-// records) then read nwg_def instead of nwg + nwg_def of them.  Thread t of workgroup b takes records b, b + nwg_def, ...
+// also folds a slice of them into its own record: the consumers then read nwg_def instead of nwg + nwg_def of them.
+// Thread t of workgroup b takes records b, b + nwg_def, ...
 template <int NACC>
 __device__ __forceinline__ void fold_sweep_records(const DevBlkCsr& S, const double* __restrict__ partials, double (&acc)[NACC]) {
     for (int rec = blockIdx.x + gridDim.x * (int)threadIdx.x; rec < S.nwg; rec += gridDim.x * DEF_THREADS) {
@@ -549,37 +633,12 @@ __global__ __launch_bounds__(DEF_THREADS) void kkt2_deferred_kernel(DevBlkCsr S,
                                                                     double* __restrict__ partials, const DevState* st, int gate) {
     if (gate && st->done) return;
     __shared__ double red[16];
-    EpiKkt epi;
-    epi.w = w; epi.out = out; epi.cb = cb; epi.n = n; epi.wt = w[nm];
+    EpiKkt<GatherW, false> epi;
+    epi.gat.w = w; epi.out = out; epi.pnew = nullptr; epi.cb = cb; epi.n = n; epi.wt = w[nm];
     epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
     deferred_rows(S, epi);
     fold_sweep_records<3>(S, partials, epi.acc);
     block_reduce_store<3, DEF_THREADS>(epi.acc, red, partials + 3 * (int64_t)(S.nwg + blockIdx.x));
-}
-
-// sums partials[count][NACC] -> sums[NACC] in a fixed order (1024 threads, one block)
-template <int NACC>
-__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int count, double* sums /*shared, NACC*/, double* smem /*shared 16*NACC*/) {
-    double acc[NACC];
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
-    for (int i = threadIdx.x; i < count; i += blockDim.x) {
-#pragma unroll
-        for (int a = 0; a < NACC; ++a) acc[a] += partials[(int64_t)i * NACC + a];
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) {
-        double v = wave_sum(acc[a]);
-        if (lane == 0) smem[wave * NACC + a] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < NACC) {
-        double s = 0.0;
-        for (int w = 0; w < nw; ++w) s += smem[w * NACC + threadIdx.x];
-        sums[threadIdx.x] = s;
-    }
-    __syncthreads();
 }
 
 constexpr int FIN_THREADS = 1024;
@@ -592,12 +651,11 @@ __global__ __launch_bounds__(FIN_THREADS) void reduce_kernel(const double* __res
     if (gate && st->done) return;
     if (PEER && st->xchg_failed) return;
     __shared__ double sums[8];
-    __shared__ double smem[16 * 8];
     // nacc <= 8; instantiate by value
     switch (nacc) {
-        case 1: reduce_partials<1>(partials, count, sums, smem); break;
-        case 3: reduce_partials<3>(partials, count, sums, smem); break;
-        case 6: reduce_partials<6>(partials, count, sums, smem); break;
+        case 1: reduce_partials<1>(partials, count, sums); break;
+        case 3: reduce_partials<3>(partials, count, sums); break;
+        case 6: reduce_partials<6>(partials, count, sums); break;
         default: return;
     }
     if constexpr (!PEER) {
@@ -644,19 +702,18 @@ __global__ __launch_bounds__(FIN_THREADS) void reduce_kernel(const double* __res
     }
 }
 
-// tau rows of out = M w from the sweep's partials (the CG iteration does this inside cg_alpha_update_kernel)
+// tau rows of out = M w from the sweep's partials (the CG iteration does this inside cg_update_kernel)
 __global__ __launch_bounds__(FIN_THREADS) void kkt_finalize_kernel(const double* __restrict__ partials, int count,
                                                                    const double* __restrict__ reduced, int from_reduced,
                                                                    const d2* __restrict__ w, d2* __restrict__ out, int nm,
                                                                    const DevState* st, int gate) {
     if (gate && st->done) return;
     __shared__ double sums[3];
-    __shared__ double smem[16 * 3];
     if (from_reduced) {
         if (threadIdx.x < 3) sums[threadIdx.x] = reduced[threadIdx.x];
         __syncthreads();
     } else {
-        reduce_partials<3>(partials, count, sums, smem);
+        reduce_partials<3>(partials, count, sums);
     }
     if (threadIdx.x == 0) {
         const d2 pt = w[nm];
@@ -666,16 +723,58 @@ __global__ __launch_bounds__(FIN_THREADS) void kkt_finalize_kernel(const double*
     }
 }
 
+// closes CG iteration j-1 when no sweep of iteration j follows in the same batch of launches (the host then learns whether CG
+// has stopped from DevState.done); if CG goes on, the next batch's sweep simply repeats the evaluation
+__global__ __launch_bounds__(SPMV_THREADS) void cg_stop_check_kernel(KktArgs a) {
+    if (a.st->done) return;
+    if (a.pb.nranks > 0 && a.st->xchg_failed) return;
+    (void)cg_close_iteration(a.st, a.rr_partials, a.rr_count, a.reduced, a.from_reduced, a.r, (int64_t)a.nm + 1, a.j - 1, a.pb, a.seq_base);
+}
+
+static KktArgs plain_args(const LaunchCtx& c, const double2* w, double2* out, int gate) {
+    KktArgs a{};
+    a.w = w; a.out = out; a.cb = c.cb; a.n = (int)c.n; a.nm = (int)(c.n + c.m); a.partials = c.partials; a.st = c.st; a.gate = gate;
+    return a;
+}
+// stand-alone apply: sweep (+ deferred-row kernel when the operator has dual tiles); leaves c.S.npart records at c.S.part_off
 void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
+    const KktArgs a = plain_args(c, w, out, gate);
     if (c.S.ndef > 0) {
-        hipLaunchKernelGGL(kkt2_kernel<true>, dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, w, out, c.cb, (int)c.n,
-                           (int)(c.n + c.m), c.partials, c.st, gate);
+        hipLaunchKernelGGL((kkt2_kernel<true, false, false>), dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, a);
         hipLaunchKernelGGL(kkt2_deferred_kernel, dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, w, out, c.cb, (int)c.n,
                            (int)(c.n + c.m), c.partials, c.st, gate);
     } else {
-        hipLaunchKernelGGL(kkt2_kernel<false>, dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, w, out, c.cb, (int)c.n,
-                           (int)(c.n + c.m), c.partials, c.st, gate);
+        hipLaunchKernelGGL((kkt2_kernel<false, false, false>), dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, a);
     }
+}
+// the sweep of CG iteration j (gated on DevState.done); leaves c.S.nwg records at record 0.
+//   fuse_p && j >= 2: closes iteration j-1 and forms p_j = r + beta p_{j-1} on the fly (p_prev -> p_cur);
+//   otherwise applies to p_cur as it stands (iteration 1, or the p update ran as its own kernel).
+void launch_kkt2_cg(const LaunchCtx& c, const CgIter& it, double2* Ap) {
+    KktArgs a = plain_args(c, it.p_cur, Ap, 1);
+    const bool fused = it.fuse_p && it.j >= 2;
+    if (fused) {
+        a.w = it.p_prev; a.r = it.r; a.pnew = it.p_cur;
+        a.rr_partials = c.partials + 3 * (size_t)PART_CAP; a.rr_count = c.cg_blocks;
+        a.reduced = c.reduced; a.from_reduced = it.rr_from_reduced; a.j = it.j;
+        if (it.fold) { a.pb = *it.fold; a.seq_base = it.seq_base; }
+    }
+    dim3 grid(c.S.nwg), block(SPMV_THREADS);
+    if (c.S.ndef > 0) {
+        if (fused) hipLaunchKernelGGL((kkt2_kernel<true, true, true>), grid, block, 0, c.stream, c.S, a);
+        else hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
+    } else {
+        if (fused) hipLaunchKernelGGL((kkt2_kernel<false, true, false>), grid, block, 0, c.stream, c.S, a);
+        else hipLaunchKernelGGL((kkt2_kernel<false, false, false>), grid, block, 0, c.stream, c.S, a);
+    }
+}
+void launch_cg_stop_check(const LaunchCtx& c, const CgIter& it) {
+    KktArgs a = plain_args(c, nullptr, nullptr, 1);
+    a.r = it.r;
+    a.rr_partials = c.partials + 3 * (size_t)PART_CAP; a.rr_count = c.cg_blocks;
+    a.reduced = c.reduced; a.from_reduced = it.rr_from_reduced; a.j = it.j;
+    if (it.fold) { a.pb = *it.fold; a.seq_base = it.seq_base; }
+    hipLaunchKernelGGL(cg_stop_check_kernel, dim3(1), dim3(SPMV_THREADS), 0, c.stream, a);
 }
 void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate, int off) {
     const double* part = c.partials + (size_t)nacc * off;
@@ -691,7 +790,9 @@ void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int
 
 // ------------------------------------------------------------------------------------------------ single RHS Q apply
 
-struct EpiQPlain {     // out_plain[i] = sign * (Q v)_i ; acc[0] = [c;b].v
+struct EpiQPlain {
+    static constexpr bool FOLDDEF = false;
+    __device__ __forceinline__ void park(int, double, double, const d2&) {}     // out_plain[i] = sign * (Q v)_i ; acc[0] = [c;b].v
     const double* vcomp; double* out; const double* cb; int n; double vt, sign; double acc[1];
     __device__ __forceinline__ void init(double vtau) { vt = vtau; }
     __device__ __forceinline__ RowPre pre(int i) const { return RowPre{make_double2(vcomp[2 * (int64_t)i], 0.0), cb[i]}; }
@@ -702,7 +803,9 @@ struct EpiQPlain {     // out_plain[i] = sign * (Q v)_i ; acc[0] = [c;b].v
         acc[0] += c * pr.v.x;
     }
 };
-struct EpiQRhs {       // out[i] = (x1_i - (Q x2)_i, 0)      affinepluslinear.jl:94-95 (beta = 1, q = 0, rhs2 = b = 0)
+struct EpiQRhs {
+    static constexpr bool FOLDDEF = false;
+    __device__ __forceinline__ void park(int, double, double, const d2&) {}       // out[i] = (x1_i - (Q x2)_i, 0)      affinepluslinear.jl:94-95 (beta = 1, q = 0, rhs2 = b = 0)
     const d2* x; d2* out; const double* cb; int n; double vt; double acc[1];
     __device__ __forceinline__ void init(double vtau) { vt = vtau; }
     __device__ __forceinline__ RowPre pre(int i) const { return RowPre{x[i], cb[i]}; }
@@ -714,7 +817,9 @@ struct EpiQRhs {       // out[i] = (x1_i - (Q x2)_i, 0)      affinepluslinear.jl
         acc[0] += c * xi.y;
     }
 };
-struct EpiQVfromU {    // out[i] = (y_i.x, (Q y.x)_i)        HSDEAffine.jl:122-124  v = Q u
+struct EpiQVfromU {
+    static constexpr bool FOLDDEF = false;
+    __device__ __forceinline__ void park(int, double, double, const d2&) {}    // out[i] = (y_i.x, (Q y.x)_i)        HSDEAffine.jl:122-124  v = Q u
     const d2* y; d2* out; const double* cb; int n; double vt; double acc[1];
     __device__ __forceinline__ void init(double vtau) { vt = vtau; }
     __device__ __forceinline__ RowPre pre(int i) const { return RowPre{y[i], cb[i]}; }
@@ -726,7 +831,9 @@ struct EpiQVfromU {    // out[i] = (y_i.x, (Q y.x)_i)        HSDEAffine.jl:122-1
         acc[0] += c * yi.x;
     }
 };
-struct EpiQStatus {    // residual sums of checkstatus  HSDEStatus.jl:34-38,59,61  (z = [x;y;tau | r;s;kappa] interleaved)
+struct EpiQStatus {
+    static constexpr bool FOLDDEF = false;
+    __device__ __forceinline__ void park(int, double, double, const d2&) {}    // residual sums of checkstatus  HSDEStatus.jl:34-38,59,61  (z = [x;y;tau | r;s;kappa] interleaved)
     const d2* z; const double* cb; int n; double tau; double acc[6];
     __device__ __forceinline__ void init(double vtau) { tau = vtau; }
     __device__ __forceinline__ RowPre pre(int i) const { return RowPre{z[i], cb[i]}; }
@@ -756,8 +863,8 @@ __global__ __launch_bounds__(SPMV_THREADS) void q1_kernel(DevBlkCsr S, const dou
 #pragma unroll
     for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
     epi.init(vcomp[2 * (int64_t)nm]);      // the tau entry of the gathered component
-    Gather<1> gat{vcomp};
-    spmv_walk<1, DEFER>(S, gat, epi, prod);
+    Gather1 gat{vcomp};
+    spmv_walk<DEFER>(S, gat, epi, prod);
     block_reduce_store<NACC, SPMV_THREADS>(epi.acc, red, partials + NACC * (int64_t)blockIdx.x);
 }
 template <class Epi, int NACC>
@@ -786,12 +893,11 @@ __global__ __launch_bounds__(FIN_THREADS) void q1_finalize_kernel(const double* 
                                                                   const double* __restrict__ reduced, int from_reduced,
                                                                   int mode, const d2* __restrict__ v, double sign, void* out, int nm) {
     __shared__ double sums[1];
-    __shared__ double smem[16];
     if (from_reduced) {
         if (threadIdx.x == 0) sums[0] = reduced[0];
         __syncthreads();
     } else {
-        reduce_partials<1>(partials, count, sums, smem);
+        reduce_partials<1>(partials, count, sums);
     }
     if (threadIdx.x == 0) {
         const double T = sums[0];            // [c;b].v ;  (Q v)_tau = -T
@@ -806,12 +912,11 @@ __global__ __launch_bounds__(FIN_THREADS) void status_finalize_kernel(const doub
                                                                       const double* __restrict__ reduced, int from_reduced,
                                                                       const d2* __restrict__ z, int nm, DevState* st) {
     __shared__ double sums[6];
-    __shared__ double smem[16 * 6];
     if (from_reduced) {
         if (threadIdx.x < 6) sums[threadIdx.x] = reduced[threadIdx.x];
         __syncthreads();
     } else {
-        reduce_partials<6>(partials, count, sums, smem);
+        reduce_partials<6>(partials, count, sums);
     }
     if (threadIdx.x < 6) st->stat[threadIdx.x] = sums[threadIdx.x];
     if (threadIdx.x == 0) { st->stat[ST_TAU] = z[nm].x; st->stat[ST_KAPPA] = z[nm].y; }

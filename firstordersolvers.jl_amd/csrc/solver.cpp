@@ -82,7 +82,8 @@ struct fos_solver {
 
     // vectors: l double2 each
     d2 *X = nullptr, *T1 = nullptr, *T2 = nullptr;          // iterate, tmp1, tmp2
-    d2 *SOL = nullptr, *RHS = nullptr, *R = nullptr, *P = nullptr, *AP = nullptr;   // CG: xinit/y, rhs, r, p, z
+    d2 *SOL = nullptr, *RHS = nullptr, *R = nullptr, *AP = nullptr;                 // CG: xinit/y, rhs, r, z
+    d2 *PB[2] = {nullptr, nullptr};                         // CG direction, ping-pong: p_j lives in PB[j & 1]
     d2 *Y = nullptr, *XOLD = nullptr;                       // FISTA y / xold ; Dykstra p / q
     d2 *W = nullptr;                                        // scratch (Dykstra sums, test entries)
     d2 *SOL2 = nullptr;                                     // HSDEMatrix.cgdata.xinit
@@ -104,6 +105,8 @@ struct fos_solver {
     double* reduced = nullptr;                 // 16 doubles
     int vec_blocks = 0;
     int cg_blocks = 0;
+    uint32_t* def_mask = nullptr;              // bit i: row i of S is finished from partial slots (dual tiles)
+    bool fuse_p = false;                       // the p update of CG rides on the next sweep (2 launches per iteration)
 
     // algorithm (gap.jl:6-21, gapa.jl:9-25, fista.jl:6-18, dykstra.jl:5-17)
     int alg = FOS_ALG_GAP;
@@ -133,17 +136,20 @@ struct fos_solver {
     int cg_chunk = 8;
     int nwg_target = 2048;
     bool prof = false;
-    int prof_period = 1;                       // every prof_period-th KKT launch is bracketed by events (1: all)
+    int prof_period = 1;                       // every prof_period-th launch of a class is bracketed by events (1: all)
     int64_t cg_total = 0;                      // CG iterations since fos_create
-    std::vector<hipEvent_t> ev;                // pairs
-    size_t ev_used = 0;
-    static constexpr size_t EV_CAP = 2 * 16384;
+    struct ProfRec { hipEvent_t a, b; int cls; int j; };
+    std::vector<ProfRec> prof_recs;            // event pairs, reused
+    size_t prof_used = 0;
+    int64_t prof_seen[FOS_PROF_CLASSES] = {0, 0, 0};
+    static constexpr size_t PROF_CAP = 16384;
 
     LaunchCtx ctx() const {
         LaunchCtx c;
         c.stream = stream; c.S = S; c.cb = cb; c.n = n; c.m = m; c.l = l; c.st = st;
         c.partials = partials; c.reduced = reduced; c.vec_blocks = vec_blocks; c.cg_blocks = cg_blocks;
         c.peer = peer_on ? &peer : nullptr;
+        c.def_mask = def_mask;
         return c;
     }
 };
@@ -190,7 +196,34 @@ int finish_reduce(fos_solver* h, const LaunchCtx& c, int count, int nacc, int ga
     return FOS_OK;
 }
 
+// a kernel launch that the runtime rejected (bad configuration, missing attribute) is only reported by hipGetLastError
+int check_launch(const char* where) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("%s: a kernel launch failed: %s", where, hipGetErrorString(e)); return FOS_EHIP; }
+    return FOS_OK;
+}
+
+// profiling: a launch group whose ordinal (CG: the iteration's number counted over all solves since fos_create, so that every
+// position inside a solve gets sampled; PSD: the call's number) is a multiple of prof_period is bracketed by an event pair
+int prof_begin(fos_solver* h, int cls, int j, int64_t ordinal) {
+    if (!h->prof) return -1;
+    if ((ordinal % h->prof_period) != 0 || h->prof_used >= fos_solver::PROF_CAP) return -1;
+    if (h->prof_recs.size() <= h->prof_used) {
+        fos_solver::ProfRec r{};
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+        h->prof_recs.push_back(r);
+    }
+    fos_solver::ProfRec& r = h->prof_recs[h->prof_used];
+    r.cls = cls; r.j = j;
+    if (hipEventRecord(r.a, h->stream) != hipSuccess) return -1;
+    return (int)h->prof_used++;
+}
+void prof_end(fos_solver* h, int idx) {
+    if (idx >= 0) (void)hipEventRecord(h->prof_recs[idx].b, h->stream);
+}
+
 int poll_state(fos_solver* h) {
+    FOS_TRY(check_launch("poll"));
     FOS_HIP(hipMemcpyAsync(h->st_host, h->st, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
     FOS_HIP(hipStreamSynchronize(h->stream));
     if (h->st_host->xchg_failed) {
@@ -225,50 +258,54 @@ int kkt_apply_full(fos_solver* h, const LaunchCtx& c, const d2* w, d2* out) {
 }
 
 // conjugategradient!(x, KKTMatrix(Q), rhs, r, p, Ap; tol, max_iters)      conjugategradients.jl:31-55
+// Device resident: the host enqueues iterations AHEAD (every CG kernel is gated on DevState.done) and polls once per batch.
 int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t* iters) {
     LaunchCtx c = h->ctx();
     int fr = 0;
     FOS_TRY(kkt_apply_full(h, c, x, h->AP));                           // :32  mul!(Ap, A, x)
-    launch_cg_init(c, rhs, h->AP, h->R, h->P);                         // :33-34
+    launch_cg_init(c, rhs, h->AP, h->R, h->PB[1]);                     // :33-34   (p_1 in buffer 1)
     FOS_TRY(finish_reduce(h, c, c.vec_blocks, 1, 0, &fr));
     launch_cg_init_finalize(c, h->R, tol, maxit, fr);                  // :35-36
     int next_j = 1;                          // iteration number of the next enqueued launch group (if CG still runs)
     static const bool fold_env = !(getenv("FOS_PEER_FOLD") && atoi(getenv("FOS_PEER_FOLD")) == 0);
     const bool fold = h->peer_on && fold_env;
+    const bool rccl = h->sharded() && !fold;  // sums cross the ranks between the kernels (reduce kernel + all-reduce, or unfolded mailboxes)
     h->cg_epoch += 1;                        // the same on every rank: all ranks make the same calls
     const uint32_t seq_base = (uint32_t)(h->cg_epoch * 2048u);          // + 2 j + phase  (j <= 1000)
+    auto iter_desc = [&](int j) {
+        CgIter it;
+        it.j = j; it.r = h->R; it.p_prev = h->PB[(j - 1) & 1]; it.p_cur = h->PB[j & 1];
+        it.fuse_p = h->fuse_p; it.rr_from_reduced = rccl ? 1 : 0; it.fold = fold ? &h->peer : nullptr; it.seq_base = seq_base;
+        return it;
+    };
+    const size_t prof_start = h->prof_used;
     auto enqueue = [&](int count) -> int {
-        for (int q = 0; q < count; ++q, ++next_j) {
-            // 3 launches per CG iteration: KKT sweep | alpha + x,r update | stop test + beta + p update
-            const bool rec = h->prof && (next_j - 1) % h->prof_period == 0 && h->ev_used + 2 <= fos_solver::EV_CAP;
-            if (rec) {
-                while (h->ev.size() < h->ev_used + 2) { hipEvent_t e; FOS_HIP(hipEventCreate(&e)); h->ev.push_back(e); }
-                FOS_HIP(hipEventRecord(h->ev[h->ev_used], h->stream));
-            }
-            launch_kkt2(c, h->P, h->AP, 1);                            // :38   Ap = M p (+ partial sums)
-            if (rec) { FOS_HIP(hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
-            if (fold) {       // peer mailboxes: both exchanges of the iteration happen inside the two CG vector kernels
-                launch_cg_alpha_update(c, x, h->R, h->P, h->AP, 0, next_j, &h->peer, seq_base);
-                launch_cg_finalize_pupdate(c, h->P, h->R, 0, next_j, &h->peer, seq_base);
-                continue;
-            }
+        for (int q = 0; q < count && next_j <= maxit; ++q, ++next_j) {
+            const CgIter it = iter_desc(next_j);
+            // launch 1: [close iteration j-1: r.r, stop test, beta; p_j on the fly] KKT sweep Ap = M p_j + partial sums   :38,:42-50
+            int pe = prof_begin(h, FOS_PROF_KKT, next_j, h->cg_total + next_j - 1);
+            launch_kkt2_cg(c, it, h->AP);
+            prof_end(h, pe);
             int f1 = 0;
-            FOS_TRY(finish_reduce(h, c, c.S.npart, 3, 1, &f1, c.S.part_off));
-            launch_cg_alpha_update(c, x, h->R, h->P, h->AP, f1, next_j);   // :39-41,46
-            int f2 = 0;
-            if (h->sharded()) {                                        // sharded: reduce the r.r partials, all-reduce
+            if (rccl) { launch_reduce1(c, c.S.nwg, 3, 1, 0); FOS_TRY(allreduce(h, 3)); f1 = 1; }
+            // launch 2: alpha, tau rows, slot-spread rows, x += alpha p, r -= alpha Ap, r.r partials                       :39-41
+            pe = prof_begin(h, FOS_PROF_CGVEC, next_j, h->cg_total + next_j - 1);
+            launch_cg_update(c, it, x, h->R, h->AP, f1);
+            if (rccl) {
                 LaunchCtx c2 = c;
                 c2.partials = c.partials + 3 * (size_t)PART_CAP;
                 launch_reduce1(c2, c.cg_blocks, 1, 1);
                 FOS_TRY(allreduce(h, 1));
-                f2 = 1;
             }
-            launch_cg_finalize_pupdate(c, h->P, h->R, f2, next_j);     // :42-51 (stop test, beta, p update)
+            // gather-bound operators: closing the iteration and p_{j+1} = r + beta p_j stay a launch of their own           :42-51
+            if (!h->fuse_p) launch_cg_pupdate(c, it, h->PB[(next_j + 1) & 1]);
+            prof_end(h, pe);
         }
+        // the last update of the batch is closed by a one-workgroup launch (a following batch's sweep repeats it, same result)
+        if (h->fuse_p) launch_cg_stop_check(c, iter_desc(next_j));
         return FOS_OK;
     };
-    const size_t ev_start = h->ev_used;      // profiling: only the launches of REAL iterations are kept (below)
-    static const int pred_slack = getenv("FOS_CG_SLACK") ? atoi(getenv("FOS_CG_SLACK")) : 1;   // iterations enqueued beyond the last solve's count (each costs ~15-25 us when not needed; too few costs a poll)
+    static const int pred_slack = getenv("FOS_CG_SLACK") ? atoi(getenv("FOS_CG_SLACK")) : 1;   // iterations enqueued beyond the last solve's count (each costs a few gated no-op launches when not needed; too few costs a poll)
     int first = h->last_cg_pred > 0 ? h->last_cg_pred + pred_slack : h->cg_chunk;
     first = std::max(1, std::min(first, maxit));
     FOS_TRY(enqueue(first));
@@ -278,11 +315,9 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
         FOS_TRY(poll_state(h));
     }
     *iters = h->st_host->iter;
-    {   // iterations 1..iter each did exactly one gated KKT launch; launches enqueued past convergence were no-ops
-        const size_t sampled = h->st_host->iter >= 1 ? (size_t)((h->st_host->iter - 1) / h->prof_period + 1) : 0;
-        const size_t real = std::min<size_t>(sampled, (h->ev_used - ev_start) / 2);
-        h->ev_used = ev_start + 2 * real;
-    }
+    // profiling: launches enqueued past convergence were gated no-ops -- drop their event pairs
+    for (size_t k = prof_start; k < h->prof_used; ++k)
+        if (h->prof_recs[k].j > h->st_host->iter) h->prof_recs[k].cls = -1;
     h->last_cg_pred = h->st_host->iter;
     h->cg_total += h->st_host->iter;
     if (h->st_host->hit_max) h->hit_max_accum = 1;
@@ -316,10 +351,12 @@ int prox_cones(fos_solver* h, d2* out, const d2* in) {
     launch_cones_elementwise(c, out, in, h->ew_op);
     launch_cones_soc(c, out, in, h->soc, h->nsoc);
     launch_cones_exp(c, out, in, h->expc, h->nexp);
+    const int pe = h->npsd > 0 ? prof_begin(h, FOS_PROF_PSD, 0, h->prof_seen[FOS_PROF_PSD]++) : -1;
     FOS_TRY(launch_cones_psd(c, out, in, h->psd, h->npsd, h->psd_kmax, h->psd_scratch,
                              h->psd_V[h->psd_cur], h->psd_V[1 - h->psd_cur], h->psd_have_prev));
+    prof_end(h, pe);
     if (h->npsd > 0 && h->psd_V[0]) { h->psd_cur = 1 - h->psd_cur; h->psd_have_prev = 1; }
-    return FOS_OK;
+    return check_launch("cone projection");
 }
 
 // checkstatus(status, z, override=true) values + decision               HSDEStatus.jl:27-63
@@ -449,6 +486,7 @@ int validate_cones(const char* which, int64_t total, int64_t nK, const int32_t* 
     for (int64_t i = 0; i < nK; ++i) {
         if (start[i] != prev_end + 1) { set_error("%s cone %lld: range starts at %lld, expected %lld (ranges must be contiguous and ordered)", which, (long long)i + 1, (long long)start[i], (long long)prev_end + 1); return FOS_EINVAL; }
         if (len[i] < 1) { set_error("%s cone %lld: empty range", which, (long long)i + 1); return FOS_EINVAL; }
+        if (len[i] > (int64_t)INT32_MAX) { set_error("%s cone %lld: %lld entries exceed the int32 cone descriptor", which, (long long)i + 1, (long long)len[i]); return FOS_EUNSUPPORTED; }
         prev_end = start[i] + len[i] - 1;
         switch (type[i]) {
             case FOS_CONE_FREE: case FOS_CONE_ZERO: case FOS_CONE_NONNEG: case FOS_CONE_NONPOS: case FOS_CONE_SOC: break;
@@ -555,7 +593,7 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
     hipDeviceProp_t prop;
     FOS_HIP(hipGetDeviceProperties(&prop, device));
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char* e = getenv("FOS_SPMV_WG")) h->nwg_target = std::max(1, atoi(e));
+    if (const char* e = getenv("FOS_SPMV_WG")) h->nwg_target = std::max(1, std::min(16384, atoi(e)));
     else h->nwg_target = cus * 12;      // ~1.7x the resident workgroups (7/CU): measured best for the KKT sweep (dynamic balance)
 
     // ---- operator
@@ -610,9 +648,18 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
         while (lpr & (lpr - 1)) lpr &= lpr - 1;
         h->S.def_lpr = lpr;
         h->S.nwg_def = (int32_t)std::min<int64_t>(DEF_MAX_WG, ((int64_t)h->S.ndef * lpr + DEF_THREADS - 1) / DEF_THREADS);
+        // bit mask of the rows finished from partial slots (cg_update_kernel skips them in its streaming pass)
+        std::vector<uint32_t> mask((size_t)(h->l + 31) / 32 + 1, 0u);
+        for (int32_t r : hs.def_rows) mask[(size_t)r >> 5] |= 1u << (r & 31);
+        FOS_TRY(dev_upload(h, &h->def_mask, mask));
         std::vector<int32_t>().swap(hs.row_defer);
         std::vector<int32_t>().swap(hs.def_idx);
     }
+    // The p update of CG can ride on the next sweep (two launches per iteration, launch_kkt2_cg): built and measured -- on
+    // MI355X it is SLOWER than the separate launch at every size tried (C4: sweep 59 -> 86 us against a 10 us p update kernel;
+    // 64-block shard: 13 -> 20 us against 5 us), so it stays an option (fos_set_tuning / FOS_CG_FUSE_P)
+    h->fuse_p = false;
+    if (const char* e = getenv("FOS_CG_FUSE_P")) h->fuse_p = atoi(e) != 0;
     h->S.npart = h->S.nwg_def > 0 ? h->S.nwg_def : h->S.nwg;
     h->S.part_off = h->S.nwg_def > 0 ? h->S.nwg : 0;
     // free the big host arrays (keep block table for re-partitioning)
@@ -633,7 +680,7 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
 
     // ---- vectors
     const size_t l = (size_t)h->l;
-    d2** vecs[] = {&h->X, &h->T1, &h->T2, &h->SOL, &h->RHS, &h->R, &h->P, &h->AP, &h->Y, &h->XOLD, &h->W, &h->SOL2};
+    d2** vecs[] = {&h->X, &h->T1, &h->T2, &h->SOL, &h->RHS, &h->R, &h->PB[0], &h->PB[1], &h->AP, &h->Y, &h->XOLD, &h->W, &h->SOL2};
     for (d2** v : vecs) {
         FOS_TRY(dev_alloc(h, v, l));
         FOS_HIP(hipMemset(*v, 0, sizeof(d2) * l));
@@ -687,7 +734,7 @@ int fos_destroy(fos_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (void* q : h->peer_opened) (void)hipIpcCloseMemHandle(q);
-    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (void* p : h->owned) (void)hipFree(p);
     if (h->st_host) (void)hipHostFree(h->st_host);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -906,6 +953,7 @@ int fos_step(fos_handle h, int64_t i_first, int64_t count, int64_t checki, doubl
         }
     }
     if (iters_done) *iters_done = done;
+    FOS_TRY(check_launch("fos_step"));
     FOS_HIP(hipStreamSynchronize(h->stream));
     return FOS_OK;
 }
@@ -1058,6 +1106,7 @@ int fos_profile(fos_handle h, int32_t enable) {
     if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
     h->prof = enable != 0;
     h->prof_period = enable > 1 ? enable : 1;
+    for (int k = 0; k < FOS_PROF_CLASSES; ++k) h->prof_seen[k] = 0;
     return FOS_OK;
 }
 
@@ -1072,20 +1121,35 @@ int fos_get_cg_total(fos_handle h, int64_t* total) {
     return FOS_OK;
 }
 
-int fos_profile_read(fos_handle h, int64_t* launches, double* total_ms, double* bytes_per_launch) {
+// launches / summed milliseconds per class of the bracketed launch groups since the last read; resets the records
+int fos_profile_read_classes(fos_handle h, int64_t* launches3, double* total_ms3) {
     if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
     FOS_HIP(hipSetDevice(h->device));
     FOS_HIP(hipStreamSynchronize(h->stream));
-    double tot = 0.0;
-    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    int64_t n[FOS_PROF_CLASSES] = {0, 0, 0};
+    double t[FOS_PROF_CLASSES] = {0.0, 0.0, 0.0};
+    for (size_t i = 0; i < h->prof_used; ++i) {
+        const auto& r = h->prof_recs[i];
+        if (r.cls < 0 || r.cls >= FOS_PROF_CLASSES) continue;
         float ms = 0.f;
-        FOS_HIP(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
-        tot += ms;
+        FOS_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        n[r.cls] += 1; t[r.cls] += ms;
     }
-    if (launches) *launches = (int64_t)(h->ev_used / 2);
-    if (total_ms) *total_ms = tot;
+    for (int k = 0; k < FOS_PROF_CLASSES; ++k) {
+        if (launches3) launches3[k] = n[k];
+        if (total_ms3) total_ms3[k] = t[k];
+    }
+    h->prof_used = 0;
+    return FOS_OK;
+}
+
+int fos_profile_read(fos_handle h, int64_t* launches, double* total_ms, double* bytes_per_launch) {
+    int64_t n[FOS_PROF_CLASSES];
+    double t[FOS_PROF_CLASSES];
+    FOS_TRY(fos_profile_read_classes(h, n, t));
+    if (launches) *launches = n[FOS_PROF_KKT];
+    if (total_ms) *total_ms = t[FOS_PROF_KKT];
     if (bytes_per_launch) *bytes_per_launch = kkt_bytes(h);
-    h->ev_used = 0;
     return FOS_OK;
 }
 
@@ -1123,6 +1187,62 @@ int fos_bench_kkt(fos_handle h, int32_t reps, double* total_ms) {
     return FOS_OK;
 }
 
+int fos_bench_cg_chain(fos_handle h, int32_t iters, int32_t reps, int32_t use_graph, double* ms_per_iter) {
+    if (!h || iters < 1 || reps < 1 || !ms_per_iter) { set_error("bad argument"); return FOS_EINVAL; }
+    if (h->sharded()) { set_error("fos_bench_cg_chain: single-GPU handles only"); return FOS_EUNSUPPORTED; }
+    FOS_HIP(hipSetDevice(h->device));
+    LaunchCtx c = h->ctx();
+    // CG on M y = X from y = 0 with a tolerance that is never met: every enqueued iteration really runs
+    FOS_HIP(hipMemcpyAsync(h->RHS, h->X, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));
+    FOS_HIP(hipMemsetAsync(h->W, 0, sizeof(d2) * h->l, h->stream));
+    FOS_TRY(kkt_apply_full(h, c, h->W, h->AP));
+    launch_cg_init(c, h->RHS, h->AP, h->R, h->PB[1]);
+    launch_cg_init_finalize(c, h->R, -1.0, INT32_MAX, 0);
+    auto chain = [&]() {
+        for (int j = 1; j <= iters; ++j) {
+            CgIter it;
+            it.j = j; it.r = h->R; it.p_prev = h->PB[(j - 1) & 1]; it.p_cur = h->PB[j & 1];
+            it.fuse_p = h->fuse_p; it.rr_from_reduced = 0; it.fold = nullptr; it.seq_base = 0;
+            launch_kkt2_cg(c, it, h->AP);
+            launch_cg_update(c, it, h->W, h->R, h->AP, 0);
+            if (!h->fuse_p) launch_cg_pupdate(c, it, h->PB[(j + 1) & 1]);
+        }
+    };
+    hipEvent_t e0, e1;
+    FOS_HIP(hipEventCreate(&e0));
+    FOS_HIP(hipEventCreate(&e1));
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (use_graph) {
+        FOS_HIP(hipStreamSynchronize(h->stream));
+        FOS_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        chain();
+        FOS_HIP(hipStreamEndCapture(h->stream, &graph));
+        FOS_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        FOS_HIP(hipGraphLaunch(exec, h->stream));          // warm
+    } else {
+        chain();                                           // warm
+    }
+    FOS_HIP(hipEventRecord(e0, h->stream));
+    for (int rep = 0; rep < reps; ++rep) {
+        if (use_graph) FOS_HIP(hipGraphLaunch(exec, h->stream));
+        else chain();
+    }
+    FOS_HIP(hipEventRecord(e1, h->stream));
+    FOS_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FOS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_iter = (double)ms / ((double)reps * iters);
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    // leave the handle as fos_reset_affine + a fresh iterate would: the CG state used above is scratch
+    FOS_TRY(check_launch("fos_bench_cg_chain"));
+    FOS_TRY(poll_state(h));
+    return FOS_OK;
+}
+
 int fos_host_stacked_spmv(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
                           const double* v, double* out, int32_t spmv_workgroups, int32_t resident_waves, int64_t* stats) {
     if (!colptr || !v || !out || m < 0 || n < 0) { set_error("bad argument"); return FOS_EINVAL; }
@@ -1151,10 +1271,10 @@ int fos_sync(fos_handle h) {
     return FOS_OK;
 }
 
-int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int32_t use_graph) {
+int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int32_t fuse_p) {
     if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
-    (void)use_graph;
     FOS_HIP(hipSetDevice(h->device));
+    if (fuse_p >= 0) h->fuse_p = fuse_p != 0;
     if (cg_chunk > 0) h->cg_chunk = cg_chunk;
     if (spmv_workgroups > 0) {
         if (spmv_workgroups > 16384) spmv_workgroups = 16384;
@@ -1164,7 +1284,7 @@ int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int3
                           h->hostS.wave_blk0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         h->S.nwg = h->hostS.nwg;
         h->S.npart = h->S.nwg_def > 0 ? h->S.nwg_def : h->S.nwg;
-    h->S.part_off = h->S.nwg_def > 0 ? h->S.nwg : 0;
+        h->S.part_off = h->S.nwg_def > 0 ? h->S.nwg : 0;
         h->S.nwaves = h->hostS.nwaves;
         h->nwg_target = spmv_workgroups;
     }

@@ -5,22 +5,14 @@
 // FP contraction is OFF in this file: the reference evaluates e.g. `y .= a1.*y .+ (1-a1).*x` (gap.jl:48) as
 // two multiplies and an add; keeping that keeps the iterates as close to the reference as the reduction
 // order allows.
-#include "fos_internal.hpp"
+#include "dev_common.hpp"
 
 #pragma clang fp contract(off)
 
 namespace fos {
 
-typedef double2 d2;
-
 constexpr int VEC_THREADS = 256;
 constexpr int FIN_THREADS = 1024;
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
 
 template <int NACC>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* out) {
@@ -33,31 +25,6 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
     }
     __syncthreads();
     if (tid < NACC) out[tid] = (smem[tid] + smem[NACC + tid]) + (smem[2 * NACC + tid] + smem[3 * NACC + tid]);
-}
-
-template <int NACC>
-__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int count, double* sums) {
-    __shared__ double smem[16 * NACC];
-    double acc[NACC];
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
-    for (int i = threadIdx.x; i < count; i += blockDim.x) {
-#pragma unroll
-        for (int a = 0; a < NACC; ++a) acc[a] += partials[(int64_t)i * NACC + a];
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) {
-        double v = wave_sum(acc[a]);
-        if (lane == 0) smem[wave * NACC + a] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < NACC) {
-        double s = 0.0;
-        for (int w = 0; w < nw; ++w) s += smem[w * NACC + threadIdx.x];
-        sums[threadIdx.x] = s;
-    }
-    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------ CG
@@ -85,8 +52,8 @@ __global__ __launch_bounds__(FIN_THREADS) void cg_init_finalize_kernel(const dou
     if (threadIdx.x == 0) {
         const d2 rt = r[l - 1];
         st->rn = sums[0] + (rt.x * rt.x + rt.y * rt.y);     // rn = dot(r,r)      :35
-        st->rn2[1] = st->rn;                                 // iteration 1 reads slot 1
-        st->rn2[0] = 0.0;
+        st->rn2[0] = st->rn;                                 // RN[0]: iteration 1's alpha reads slot 0 (dev_common.hpp)
+        st->rn2[1] = 0.0;
         st->rn_old = 0.0;
         st->iter = 1;                                        // :36
         st->done = 0;
@@ -96,66 +63,27 @@ __global__ __launch_bounds__(FIN_THREADS) void cg_init_finalize_kernel(const dou
     }
 }
 
-// Folded peer exchange (fos_internal.hpp, region 1 of the mailboxes): called by EVERY workgroup of a CG vector kernel with the
-// same local sums; workgroup 0 also stores them into the peers' mailboxes; all poll their own mailbox for the peers' words of
-// sequence number `seq` and add in rank order.  Returns false (and stops the solve) when a peer does not answer in time.
-template <int NACC>
-__device__ __forceinline__ bool peer_fold_sum(const PeerBox& pb, uint32_t seq, double* sums /* shared: in local, out total */, DevState* st) {
-    __shared__ uint32_t halves[PEER_MAX_RANKS * NACC * 2];
-    __shared__ int failed;
-    const int t = threadIdx.x;
-    if (t == 0) failed = 0;
-    __syncthreads();
-    const size_t par = (size_t)(seq & 1u) * PEER_MAX_RANKS;
-    if (t < pb.nranks * NACC * 2) {
-        const int hh = t & 1, v = (t >> 1) % NACC, r = (t >> 1) / NACC;
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(sums[v]);
-        const uint32_t mine = hh ? (uint32_t)(bits >> 32) : (uint32_t)bits;
-        if (r == pb.rank) {
-            halves[(r * NACC + v) * 2 + hh] = mine;
-        } else {
-            if (blockIdx.x == 0) {
-                unsigned long long* dst = pb.box[r] + PEER_BOX_WORDS + ((par + pb.rank) * PEER_MAX_VALS + v) * 2 + hh;
-                __hip_atomic_store(dst, ((unsigned long long)seq << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            const unsigned long long* src = pb.box[pb.rank] + PEER_BOX_WORDS + ((par + r) * PEER_MAX_VALS + v) * 2 + hh;
-            const long long t0 = wall_clock64();
-            unsigned long long w;
-            bool ok;
-            do {
-                w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                ok = (uint32_t)(w >> 32) == seq;
-            } while (!ok && (wall_clock64() - t0) < pb.timeout_ticks);
-            if (!ok) failed = 1;
-            halves[(r * NACC + v) * 2 + hh] = (uint32_t)w;
-        }
-    }
-    __syncthreads();
-    if (failed) {
-        if (blockIdx.x == 0 && t == 0) { st->xchg_failed = 1; st->done = 1; }
-        return false;
-    }
-    if (t < NACC) {
-        double s = 0.0;
-        for (int r = 0; r < pb.nranks; ++r) {
-            const unsigned long long lo = halves[(r * NACC + t) * 2], hi = halves[(r * NACC + t) * 2 + 1];
-            s += __longlong_as_double((long long)((hi << 32) | lo));
-        }
-        sums[t] = s;
-    }
-    __syncthreads();
-    return true;
-}
-
-// alpha + x,r update in one launch: EVERY workgroup reduces the 3 x nwg KKT partials in the same fixed order, finishes
+// Second launch of a CG iteration.  EVERY workgroup reduces the sweep's 3 x nkkt partial sums in the same fixed order, finishes
 // the tau rows of Ap = M p and alpha = rn / (Ap.p) itself (so no workgroup waits for another), then updates its slice:
 // x += alpha p ; r -= alpha Ap ; partial r.r.  Workgroup 0 stores Ap[tau], pAp and alpha.     conjugategradients.jl:39-41,46
-template <bool FOLD>
-__global__ __launch_bounds__(VEC_THREADS) void cg_alpha_update_kernel(int64_t l, d2* __restrict__ x, d2* __restrict__ r,
-                                                                      const d2* __restrict__ p, d2* __restrict__ Ap,
-                                                                      DevState* st, const double* __restrict__ kkt_partials, int nkkt,
-                                                                      const double* __restrict__ reduced, int from_reduced, int j,
-                                                                      double* __restrict__ partials, PeerBox pb, uint32_t seq_base) {
+// DEF (operators with dual tiles): rows of Ap whose sum the sweep left spread over partial slots are finished HERE -- `lpr`
+// lanes add a row's slot list in list order (as kkt2_deferred_kernel does for the stand-alone applies), run the row epilogue
+// of EpiKkt and update x, r of that row at once; their share of Ap.p is already in the sweep's sums (EpiKkt, FOLD).
+template <bool DEF, bool FOLD>
+__global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* __restrict__ x, d2* __restrict__ r,
+                                                                const d2* __restrict__ p, d2* __restrict__ Ap,
+                                                                DevState* st, const double* __restrict__ kkt_partials, int nkkt,
+                                                                const double* __restrict__ reduced, int from_reduced, int j,
+                                                                double* __restrict__ partials, DevBlkCsr S, const double* __restrict__ cb, int n,
+                                                                const uint32_t* __restrict__ def_mask, PeerBox pb, uint32_t seq_base) {
+    // the first element of this thread's slice is requested BEFORE the scalar prologue (two dependent round trips and two
+    // barriers): on small operators the prologue's latency, not bandwidth, is what this kernel costs
+    const int64_t stride = (int64_t)gridDim.x * VEC_THREADS;
+    const int64_t i0 = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x;
+    bool have0 = i0 < l;
+    if constexpr (DEF) { if (have0 && ((def_mask[i0 >> 5] >> (i0 & 31)) & 1u)) have0 = false; }
+    d2 p0 = make_double2(0.0, 0.0), a0 = p0, x0 = p0, r0 = p0;
+    if (have0) { p0 = p[i0]; a0 = Ap[i0]; x0 = x[i0]; r0 = r[i0]; }
     if (st->done) return;
     if (FOLD && st->xchg_failed) return;
     __shared__ double sums[3];
@@ -169,14 +97,60 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_alpha_update_kernel(int64_t l,
     const double at1 = pt.x + T2;            // p1_tau - (Q p2)_tau ,  (Q v)_tau = -[c;b].v        HSDEAffine.jl:57
     const double at2 = -T1 - pt.y;           // (Q p1)_tau - p2_tau
     const double pAp = S1 + (at1 * pt.x + at2 * pt.y);
-    const double alpha = st->rn2[j & 1] / pAp;
+    const double alpha = st->rn2[(j - 1) & 1] / pAp;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         Ap[l - 1] = make_double2(at1, at2);
         st->pAp = pAp;
         st->alpha = alpha;
     }
     double acc[1] = {0.0};
-    for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
+    if constexpr (DEF) {
+        const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots);
+        const int lpr = S.def_lpr, sh = 31 - __clz(lpr);
+        const int rows_per_pass = (gridDim.x * VEC_THREADS) >> sh;
+        const int lig = threadIdx.x & (lpr - 1);
+        const int npass = (S.ndef + rows_per_pass - 1) / rows_per_pass;       // uniform trip count: the DPP sums need full waves
+        int q = (blockIdx.x * VEC_THREADS + threadIdx.x) >> sh;
+        for (int pass = 0; pass < npass; ++pass, q += rows_per_pass) {
+            const bool ok = q < S.ndef;
+            const int row = ok ? S.def_rows[q] : 0;
+            const bool own = ok && lig == 0;
+            d2 pi = make_double2(0.0, 0.0), xi = pi, ri = pi;
+            double c = 0.0;
+            if (own) { pi = p[row]; xi = x[row]; ri = r[row]; c = cb[row]; }
+            double u1 = 0.0, u2 = 0.0;
+            if (ok) {
+                const int k1 = S.def_ptr[q + 1];
+                for (int k = S.def_ptr[q] + lig; k < k1; k += lpr) {
+                    const d2 s = slots[S.def_idx[k]];
+                    u1 += s.x; u2 += s.y;
+                }
+            }
+            u1 = group_sum(u1, lpr);
+            u2 = group_sum(u2, lpr);
+            if (own) {
+                double q1, q2;                                  // EpiKkt::row (kernels.hip)
+                if (row < n) { q1 = u1 + pt.x * c; q2 = u2 + pt.y * c; }
+                else { q1 = -(u1 - pt.x * c); q2 = -(u2 - pt.y * c); }
+                const double a1 = pi.x - q2, a2 = q1 - pi.y;
+                xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+                ri.x -= alpha * a1; ri.y -= alpha * a2;
+                x[row] = xi;
+                r[row] = ri;
+                acc[0] += ri.x * ri.x + ri.y * ri.y;
+            }
+        }
+    }
+    if (have0) {
+        if (i0 == l - 1) a0 = make_double2(at1, at2);
+        x0.x += alpha * p0.x; x0.y += alpha * p0.y;
+        r0.x -= alpha * a0.x; r0.y -= alpha * a0.y;
+        x[i0] = x0;
+        r[i0] = r0;
+        if (i0 != l - 1) acc[0] += r0.x * r0.x + r0.y * r0.y;
+    }
+    for (int64_t i = i0 + stride; i < l; i += stride) {
+        if constexpr (DEF) { if ((def_mask[i >> 5] >> (i & 31)) & 1u) continue; }
         const d2 pi = p[i];
         const d2 ai = (i == l - 1) ? make_double2(at1, at2) : Ap[i];
         d2 xi = x[i], ri = r[i];
@@ -188,71 +162,49 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_alpha_update_kernel(int64_t l,
     }
     block_reduce_store<1>(acc, partials + blockIdx.x);
 }
-void launch_cg_alpha_update(const LaunchCtx& c, double2* x, double2* r, const double2* p, double2* Ap, int from_reduced, int j,
-                            const PeerBox* fold, uint32_t seq_base) {
-    // r.r partials go behind the 3 x nwg KKT partials (both live in c.partials)
-    if (fold)
-        hipLaunchKernelGGL(cg_alpha_update_kernel<true>, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, r, p, Ap, c.st,
-                           c.partials + 3 * (size_t)c.S.part_off, c.S.npart, c.reduced, 0, j, c.partials + 3 * (size_t)PART_CAP, *fold, seq_base);
-    else
-        hipLaunchKernelGGL(cg_alpha_update_kernel<false>, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, r, p, Ap, c.st,
-                           c.partials + 3 * (size_t)c.S.part_off, c.S.npart, c.reduced, from_reduced, j, c.partials + 3 * (size_t)PART_CAP,
-                           PeerBox{}, 0u);
+void launch_cg_update(const LaunchCtx& c, const CgIter& it, double2* x, double2* r, double2* Ap, int kkt_from_reduced) {
+    // r.r partials go behind the KKT partials (both live in c.partials); inside a CG iteration the sweep leaves c.S.nwg records at 0
+    double* rr_out = c.partials + 3 * (size_t)PART_CAP;
+    const PeerBox pb = it.fold ? *it.fold : PeerBox{};
+    dim3 grid(c.cg_blocks), block(VEC_THREADS);
+#define FOS_UPD(DEF, FOLD)                                                                                                   \
+    hipLaunchKernelGGL((cg_update_kernel<DEF, FOLD>), grid, block, 0, c.stream, c.l, x, r, (const d2*)it.p_cur, Ap, c.st, c.partials, \
+                       c.S.nwg, c.reduced, it.fold ? 0 : kkt_from_reduced, it.j, rr_out, c.S, c.cb, (int)c.n, c.def_mask, pb, it.seq_base)
+    if (c.S.ndef > 0) { if (it.fold) FOS_UPD(true, true); else FOS_UPD(true, false); }
+    else { if (it.fold) FOS_UPD(false, true); else FOS_UPD(false, false); }
+#undef FOS_UPD
 }
 
-// stop test + beta + p update in one launch: EVERY workgroup reduces the <= 1024 r.r partials in the same fixed order (so all
-// derive the same stop decision and beta), workgroup 0 stores the scalars.  `j` = the iteration this launch belongs
-// to if CG is still running (known at enqueue time).  A workgroup that starts after workgroup 0 has set `done` simply
-// exits: p is not needed once CG has stopped.                       conjugategradients.jl:42-51
-template <bool FOLD>
-__global__ __launch_bounds__(VEC_THREADS) void cg_finalize_pupdate_kernel(int64_t l, d2* __restrict__ p, const d2* __restrict__ r,
-                                                                          DevState* st, const double* __restrict__ partials, int count,
-                                                                          const double* __restrict__ reduced, int from_reduced, int j,
-                                                                          PeerBox pb, uint32_t seq_base) {
+// Third launch of a CG iteration when the p update is NOT fused into the next sweep: closes iteration j (every workgroup,
+// same order: cg_close_iteration) and forms p_{j+1} = beta p_j + r.  A workgroup that starts after workgroup 0 has set `done`
+// simply exits: p is not needed once CG has stopped.                       conjugategradients.jl:42-51
+__global__ __launch_bounds__(VEC_THREADS) void cg_pupdate_kernel(int64_t l, d2* __restrict__ pnext, const d2* __restrict__ pcur,
+                                                                 const d2* __restrict__ r, DevState* st,
+                                                                 const double* __restrict__ partials, int count,
+                                                                 const double* __restrict__ reduced, int from_reduced, int j,
+                                                                 PeerBox pb, uint32_t seq_base) {
+    const int64_t stride = (int64_t)gridDim.x * VEC_THREADS;
+    const int64_t i0 = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x;
+    d2 p0 = make_double2(0.0, 0.0), r0 = p0;
+    if (i0 < l) { p0 = pcur[i0]; r0 = r[i0]; }          // requested before the scalar prologue (latency)
     if (st->done) return;
-    if (FOLD && st->xchg_failed) return;
-    __shared__ double sums[1];
-    if (from_reduced) { if (threadIdx.x == 0) sums[0] = reduced[0]; __syncthreads(); }
-    else reduce_partials<1>(partials, count, sums);
-    if constexpr (FOLD) {
-        if (!peer_fold_sum<1>(pb, seq_base + 2u * (uint32_t)j + 1u, sums, st)) return;
-    }
-    const d2 rt = r[l - 1];
-    const double rr = sums[0] + (rt.x * rt.x + rt.y * rt.y);
-    const double rnold = st->rn2[j & 1];
-    const bool stop = (sqrt(rr) <= st->tol) || (j >= st->maxit);
-    const double beta = rr / rnold;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        st->rr = rr;
-        if (stop) {
-            st->iter = j;
-            st->hit_max = (j == st->maxit) ? 1 : 0;      // :53
-            __threadfence();
-            st->done = 1;
-        } else {
-            st->rn_old = rnold;
-            st->rn = rr;
-            st->rn2[(j + 1) & 1] = rr;
-            st->beta = beta;
-            st->iter = j + 1;
-        }
-    }
-    if (stop) return;
-    for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
-        d2 pi = p[i];
+    if (pb.nranks > 0 && st->xchg_failed) return;
+    const CgClose cl = cg_close_iteration(st, partials, count, reduced, from_reduced, r, l, j, pb, seq_base);
+    if (!cl.ok || cl.stop) return;
+    const double beta = cl.beta;
+    if (i0 < l) pnext[i0] = make_double2(p0.x * beta + r0.x, p0.y * beta + r0.y);
+    for (int64_t i = i0 + stride; i < l; i += stride) {
+        d2 pi = pcur[i];
         const d2 ri = r[i];
         pi.x = pi.x * beta + ri.x;
         pi.y = pi.y * beta + ri.y;
-        p[i] = pi;
+        pnext[i] = pi;
     }
 }
-void launch_cg_finalize_pupdate(const LaunchCtx& c, double2* p, const double2* r, int from_reduced, int j, const PeerBox* fold, uint32_t seq_base) {
-    if (fold)
-        hipLaunchKernelGGL(cg_finalize_pupdate_kernel<true>, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p, r, c.st,
-                           c.partials + 3 * (size_t)PART_CAP, c.cg_blocks, c.reduced, 0, j, *fold, seq_base);
-    else
-        hipLaunchKernelGGL(cg_finalize_pupdate_kernel<false>, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p, r, c.st,
-                           c.partials + 3 * (size_t)PART_CAP, c.cg_blocks, c.reduced, from_reduced, j, PeerBox{}, 0u);
+void launch_cg_pupdate(const LaunchCtx& c, const CgIter& it, double2* p_next) {
+    hipLaunchKernelGGL(cg_pupdate_kernel, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p_next, (const d2*)it.p_cur, it.r, c.st,
+                       c.partials + 3 * (size_t)PART_CAP, c.cg_blocks, c.reduced, it.rr_from_reduced, it.j,
+                       it.fold ? *it.fold : PeerBox{}, it.seq_base);
 }
 
 void launch_cg_init(const LaunchCtx& c, const double2* rhs, const double2* Ap, double2* r, double2* p) {

@@ -291,8 +291,22 @@ class HipHSDE:
     def sync(self):
         _lib.check(self._lib.fos_sync(self._h))
 
-    def set_tuning(self, spmv_workgroups=0, cg_chunk=0, use_graph=0):
-        _lib.check(self._lib.fos_set_tuning(self._h, spmv_workgroups, cg_chunk, use_graph))
+    def set_tuning(self, spmv_workgroups=0, cg_chunk=0, fuse_p=-1):
+        """fuse_p: -1 keeps the library's choice, 0 / 1 force the three- / two-launch CG iteration."""
+        _lib.check(self._lib.fos_set_tuning(self._h, spmv_workgroups, cg_chunk, fuse_p))
+
+    def profile_read_classes(self):
+        """{'kkt' | 'psd' | 'cgvec': (launch groups, summed ms)} of the bracketed launches since the last read."""
+        n = (C.c_int64 * 3)()
+        ms = (C.c_double * 3)()
+        _lib.check(self._lib.fos_profile_read_classes(self._h, n, ms))
+        return {k: (n[i], ms[i]) for i, k in enumerate(("kkt", "psd", "cgvec"))}
+
+    def bench_cg_chain(self, iters, reps=5, use_graph=False):
+        """ms per CG iteration of a chain that never converges (fos_bench_cg_chain)."""
+        ms = C.c_double(0)
+        _lib.check(self._lib.fos_bench_cg_chain(self._h, iters, reps, 1 if use_graph else 0, C.byref(ms)))
+        return ms.value
 
     # -- sharding (SURVEY.md 8(e)); the host side hands over an ncclUniqueId obtained on rank 0
     @staticmethod

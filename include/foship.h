@@ -205,6 +205,19 @@ int fos_profile(fos_handle h, int32_t enable);      /* 0: off; 1: every launch; 
                                                         pair per launch costs ~5 % of a C4 step) */
 int fos_get_cg_total(fos_handle h, int64_t* total);  /* CG iterations run since fos_create (getcgiter summed) */
 int fos_profile_read(fos_handle h, int64_t* launches, double* total_ms, double* bytes_per_launch);
+/* The same records split by class of launch group (arrays of FOS_PROF_CLASSES entries): the KKT sweep of a CG iteration,
+ * the batched PSD projection of one cone-prox call (cones.jl:89-94 over all PSD cones), the CG vector update(s) of an
+ * iteration.  Resets the records like fos_profile_read. */
+#define FOS_PROF_KKT 0
+#define FOS_PROF_PSD 1
+#define FOS_PROF_CGVEC 2
+#define FOS_PROF_CLASSES 3
+int fos_profile_read_classes(fos_handle h, int64_t* launches3, double* total_ms3);
+/* fos_bench_cg_chain: `iters` CG iterations (conjugategradients.jl:37-51; sweep + update [+ p update]) on the current
+ * iterate as right-hand side with the stop test disabled, enqueued eagerly (use_graph = 0) or captured ONCE into a hipGraph
+ * and replayed `reps` times (use_graph = 1); *ms_per_iter by HIP events.  Measurement only: it answers whether graph replay
+ * shortens the dependent-launch chain of a CG solve. */
+int fos_bench_cg_chain(fos_handle h, int32_t iters, int32_t reps, int32_t use_graph, double* ms_per_iter);
 int fos_bench_kkt(fos_handle h, int32_t reps, double* total_ms);
 int fos_sync(fos_handle h);
 
@@ -216,8 +229,9 @@ int fos_sync(fos_handle h);
 int fos_host_stacked_spmv(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
                           const double* v, double* out, int32_t spmv_workgroups, int32_t resident_waves, int64_t* stats);
 
-/* tuning knobs (0 keeps the default): workgroups of the SpMV grid, CG iterations enqueued per host poll */
-int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int32_t use_graph);
+/* tuning knobs (0 keeps the default): workgroups of the SpMV grid, CG iterations enqueued per host poll;
+ * fuse_p: -1 keeps the choice made at fos_create, 0 / 1 force the three- / two-launch CG iteration (see fos_bench_cg_chain) */
+int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int32_t fuse_p);
 
 #ifdef __cplusplus
 }
