@@ -97,6 +97,12 @@ __device__ __forceinline__ double groupc_sum(double v) {
     else return group32_sum(v);
 }
 
+// ---- the two dense contractions of an order-64 projection on the matrix cores (v_mfma_f64_16x16x4_f64)
+// Operand maps (cdna_hip_programming.md section 3, f64 form): lane l holds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15];
+// the 16 x 16 result has column l & 15 and rows (l >> 4) + 4 r in registers r = 0..3.  A 64 x 64 product is 4 x 4 tiles of
+// 16 k-steps; the wavefronts of the workgroup share the tiles.
+typedef double v4d __attribute__((ext_vector_type(4)));
+
 // A sweep in which every rotation was TINY -- both the cosine between the two columns and the sine of the rotation angle
 // below 1e-8 -- leaves, by the quadratic convergence of the cyclic method, every pair below the rotation threshold: the
 // sweep that would only confirm it (no rotation, but all the dot products) is skipped.  The angle matters, not only the
@@ -108,12 +114,13 @@ constexpr double JACOBI_SMALL2 = 1e-16;
 // elements a lane owns of the two columns stay in registers between the dot products and the rotation, and the
 // round-robin partner indices advance by one (mod 63) per step -- no division, no LDS re-read.
 template <int THREADS, int TPP>
-__device__ __forceinline__ void jacobi64(double* __restrict__ G, const int ld, const int tid, const double tol2) {
+__device__ __forceinline__ int jacobi64(double* __restrict__ G, const int ld, const int tid, const double tol2) {
     static_assert(THREADS / TPP == 32, "one column pair per slot");
     constexpr int EPL = 64 / TPP;
     const int pr = tid / TPP, lig = tid % TPP;
     int p = pr, q = 63 - pr;                      // step 0: pr = 0 plays (0, 63); pr >= 1 plays (pr, 63 - pr)
-    for (int sweep = 0; sweep < PSD_MAX_SWEEPS; ++sweep) {
+    int sweep = 0;
+    for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
         int rotated = 0, big = 0;
         for (int step = 0; step < 63; ++step) {
             double* gp = G + (size_t)p * ld + lig;
@@ -150,6 +157,7 @@ __device__ __forceinline__ void jacobi64(double* __restrict__ G, const int ld, c
         if (!__syncthreads_or(rotated)) break;
         if (!__syncthreads_or(big)) break;
     }
+    return sweep + 1;
 }
 
 // WARM: start the Jacobi iteration from G0 = (M + sigma I) V_prev, V_prev = the eigenvector basis this (cone, copy)
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
                                                           const ConeDesc* __restrict__ cones,
                                                           double* __restrict__ gscratch, size_t scratch_stride,
                                                           const double* __restrict__ vin, double* __restrict__ vout,
-                                                          size_t vstride, int have_prev) {
+                                                          size_t vstride, int have_prev, int* __restrict__ stats, int phase_limit) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
     const int cone = blockIdx.x >> 1, part = blockIdx.x & 1;
@@ -203,39 +211,74 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
     const double sigma = red[16];
     for (int i = tid; i < k; i += THREADS) G[i + (size_t)i * ld] += sigma;
     __syncthreads();
+    if (phase_limit == 1) return;               // diagnostic builds of the phase profile only (tools/psd_phases.py)
 
     if constexpr (WARM) {
         if (have_prev && sigma > 0.0) {
-            // G0 = M' V_prev : thread (row i = lane, columns j = wave + 4 jj); M' rows from LDS, V_prev (wave-uniform) from L2
             const double* __restrict__ Vp = vin + (size_t)blockIdx.x * vstride;
-            constexpr int NW = THREADS / 64, NJ = 64 / NW;
-            const int i = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: V_prev by scalar loads
-            double acc[NJ];
+            constexpr int NW = THREADS / 64;
+            if (k == 64) {
+                // G0 = M' V_prev on the matrix cores.  Tile tt = wave + NW q: column block jb = tt & 3 (the same for all tiles
+                // of a wavefront, whose 16 x 64 slab of V_prev -- 8 KB, contiguous -- is fetched ONCE: 16 loads per lane, each
+                // k-step's B operand), row block ib = tt >> 2; A operands = columns of the symmetric M' read from LDS.
+                constexpr int NT = 16 / NW;                    // tiles per wavefront
+                const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+                const int jb = w & 3, lr = lane & 15, lk = lane >> 4;
+                double bv[16];
 #pragma unroll
-            for (int jj = 0; jj < NJ; ++jj) acc[jj] = 0.0;
-            if (i < k) {
-                for (int t = 0; t < k; ++t) {
-                    const double mv = G[i + (size_t)t * ld];
+                for (int kk = 0; kk < 16; ++kk) bv[kk] = Vp[(size_t)(jb * 16 + lr) * 64 + kk * 4 + lk];
+                v4d acc[NT];
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    const int ib = (w + NW * q) >> 2;
+                    acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+                    const double* __restrict__ ga = G + ib * 16 + lr + (size_t)lk * ld;
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk)
+                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[(size_t)kk * 4 * ld], bv[kk], acc[q], 0, 0, 0);
+                }
+                __syncthreads();                               // every wavefront has read M' before anyone overwrites it
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    const int ib = (w + NW * q) >> 2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) G[ib * 16 + lk + 4 * r + (size_t)(jb * 16 + lr) * ld] = acc[q][r];
+                }
+                __syncthreads();
+            } else {
+                // G0 = M' V_prev : thread (row i = lane, columns j = wave + NW jj); M' rows from LDS, V_prev (wave-uniform) from L2
+                constexpr int NJ = 64 / NW;
+                const int i = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: V_prev by scalar loads
+                double acc[NJ];
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) acc[jj] = 0.0;
+                if (i < k) {
+                    for (int t = 0; t < k; ++t) {
+                        const double mv = G[i + (size_t)t * ld];
+#pragma unroll
+                        for (int jj = 0; jj < NJ; ++jj) {
+                            const int j = w + NW * jj;
+                            if (j < k) acc[jj] += mv * Vp[t + (size_t)j * k];
+                        }
+                    }
+                }
+                __syncthreads();
+                if (i < k) {
 #pragma unroll
                     for (int jj = 0; jj < NJ; ++jj) {
                         const int j = w + NW * jj;
-                        if (j < k) acc[jj] += mv * Vp[t + (size_t)j * k];
+                        if (j < k) G[i + (size_t)j * ld] = acc[jj];
                     }
                 }
+                __syncthreads();
             }
-            __syncthreads();
-            if (i < k) {
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) {
-                    const int j = w + NW * jj;
-                    if (j < k) G[i + (size_t)j * ld] = acc[jj];
-                }
-            }
-            __syncthreads();
         }
     }
 
+    if (phase_limit == 2) return;
+
     // ---- one-sided Jacobi sweeps
+    int nsweeps = 0;
     const int K = (k + 1) & ~1;               // even number of players (one bye when k is odd)
     const int npair = K >> 1;
     int tpp = 64;
@@ -246,10 +289,11 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
     const double tol2 = tol * tol;
 
     if (k == 64 && sigma > 0.0) {
-        jacobi64<THREADS, THREADS / 32>(G, ld, tid, tol2);
+        nsweeps = jacobi64<THREADS, THREADS / 32>(G, ld, tid, tol2);
     } else if (k > 1 && sigma > 0.0) {
         for (int sweep = 0; sweep < PSD_MAX_SWEEPS; ++sweep) {
             int rotated = 0, big = 0;
+            nsweeps = sweep + 1;
             for (int step = 0; step < K - 1; ++step) {
                 for (int pr = slot; pr < npair; pr += nslot) {
                     int p, q;
@@ -292,6 +336,9 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
         }
     }
 
+    if (stats && tid == 0) stats[blockIdx.x] = nsweeps;
+    if (phase_limit == 3) return;
+
     // ---- weights: kept columns have ||g_j|| > sigma ; P = sum_j wgt_j g_j g_j', wgt_j = (||g_j|| - sigma) / ||g_j||^2
     double* inv = wgt + k;                      // 1/||g_j|| (WARM: to store the new basis)
     for (int j = tid; j < k; j += THREADS) {
@@ -313,7 +360,56 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
         }
     }
 
+    if (phase_limit == 4) return;
+
     // ---- rebuild the lower triangle, repack, unscale the diagonal; dual: y = x + P(-x)
+    if (USE_LDS && k == 64 && THREADS <= 1024) {
+        // P = (G diag(wgt)) G' on the matrix cores: the 10 tiles on and below the diagonal, round-robin over the wavefronts;
+        // the tiles replace G in LDS (after a barrier), the pack loop below then reads P[i][j]
+        constexpr int NW = THREADS / 64;
+        constexpr int NT = (10 + NW - 1) / NW;
+        const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int lr = lane & 15, lk = lane >> 4;
+        v4d acc[NT];
+        double wk[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) wk[kk] = wgt[kk * 4 + lk];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int tt = w + NW * q;                      // lower-triangle tile list: (0,0) (1,0) (2,0) (3,0) (1,1) (2,1) (3,1) (2,2) (3,2) (3,3)
+            acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+            if (tt < 10) {
+                const int jb = tt < 4 ? 0 : (tt < 7 ? 1 : (tt < 9 ? 2 : 3));
+                const int ib = tt < 4 ? tt : (tt < 7 ? tt - 3 : (tt < 9 ? tt - 5 : 3));
+                const double* __restrict__ ga = G + ib * 16 + lr + (size_t)lk * ld;
+                const double* __restrict__ gb = G + jb * 16 + lr + (size_t)lk * ld;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk)
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wk[kk] * ga[(size_t)kk * 4 * ld], gb[(size_t)kk * 4 * ld], acc[q], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int tt = w + NW * q;
+            if (tt < 10) {
+                const int jb = tt < 4 ? 0 : (tt < 7 ? 1 : (tt < 9 ? 2 : 3));
+                const int ib = tt < 4 ? tt : (tt < 7 ? tt - 3 : (tt < 9 ? tt - 5 : 3));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) G[ib * 16 + lk + 4 * r + (size_t)(jb * 16 + lr) * ld] = acc[q][r];
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < len; idx += THREADS) {
+            int i, j;
+            idx_to_ij(idx, k, i, j);
+            double s = G[i + (size_t)j * ld];
+            if (i == j) s *= INV_SQRT2;
+            if (dual) s = x[2 * (int64_t)idx] + s;
+            y[2 * (int64_t)idx] = s;
+        }
+        return;
+    }
     for (int idx = tid; idx < len; idx += THREADS) {
         int i, j;
         idx_to_ij(idx, k, i, j);
@@ -337,38 +433,42 @@ size_t psd_basis_doubles(int kmax, int ncones) {       // one warm-start basis b
 }
 
 int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones, int kmax, double* gscratch,
-                     const double* vin, double* vout, int have_prev) {
+                     const double* vin, double* vout, int have_prev, int* stats, int phase_limit) {
     if (ncones <= 0) return FOS_OK;
     const size_t lds = psd_lds_bytes(kmax);
     const bool use_lds = lds <= 160 * 1024 - 256;
     const bool warm = vin && vout && kmax <= 64 && use_lds;
-    // few matrices (a shard of a multi-GPU run, a small problem): 1024 threads per matrix cut the latency of one
-    // projection; many matrices: 256 threads (4 per CU) maximise throughput
-    static int cus = 0;
-    if (!cus) { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; if (cus <= 0) cus = 256; }
+    // few matrices (a shard of a multi-GPU run, a small problem): 512 threads per matrix cut the latency of one
+    // projection; many matrices: 256 threads (4 per CU) maximise throughput.  Per DEVICE: a process may hold handles on several.
+    constexpr int MAXDEV = 64;
+    static int cus_of[MAXDEV] = {0};
+    static bool attr_set[MAXDEV] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) { set_error("hipGetDevice failed or device id >= %d", MAXDEV); return FOS_EHIP; }
+    if (!cus_of[dev]) { hipDeviceProp_t prop; cus_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
+    const int cus = cus_of[dev];
     const bool wide = (warm && (2 * ncones <= 2 * cus) && !getenv("FOS_PSD_NARROW")) || (warm && getenv("FOS_PSD_WIDE"));
-    static bool attr_set = false;
-    if (use_lds && !attr_set) {
+    if (use_lds && !attr_set[dev]) {          // hipFuncSetAttribute acts on the CURRENT device
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, false, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(psd_kernel): %s", hipGetErrorString(e)); return FOS_EHIP; }
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const size_t stride = (size_t)(kmax * psd_ld(kmax) + 2 * kmax + 16);
     const size_t vstride = (size_t)kmax * kmax;
     static const int wide_threads = getenv("FOS_PSD_THREADS") ? atoi(getenv("FOS_PSD_THREADS")) : 512;
     if (warm && wide && wide_threads == 512)
-        hipLaunchKernelGGL((psd_kernel<true, true, 512>), dim3(2 * ncones), dim3(512), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev);
+        hipLaunchKernelGGL((psd_kernel<true, true, 512>), dim3(2 * ncones), dim3(512), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev, stats, phase_limit);
     else if (warm && wide && wide_threads == 1024)
-        hipLaunchKernelGGL((psd_kernel<true, true, 1024>), dim3(2 * ncones), dim3(1024), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev);
+        hipLaunchKernelGGL((psd_kernel<true, true, 1024>), dim3(2 * ncones), dim3(1024), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev, stats, phase_limit);
     else if (warm)
-        hipLaunchKernelGGL((psd_kernel<true, true, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev);
+        hipLaunchKernelGGL((psd_kernel<true, true, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev, stats, phase_limit);
     else if (use_lds)
-        hipLaunchKernelGGL((psd_kernel<true, false, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, nullptr, nullptr, vstride, 0);
+        hipLaunchKernelGGL((psd_kernel<true, false, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, nullptr, nullptr, vstride, 0, stats, phase_limit);
     else
-        hipLaunchKernelGGL((psd_kernel<false, false, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), 32 * sizeof(double), c.stream, out, in, cones, gscratch, stride, nullptr, nullptr, vstride, 0);
+        hipLaunchKernelGGL((psd_kernel<false, false, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), 32 * sizeof(double), c.stream, out, in, cones, gscratch, stride, nullptr, nullptr, vstride, 0, stats, phase_limit);
     return FOS_OK;
 }
 

@@ -97,6 +97,8 @@ struct fos_solver {
     double* psd_scratch = nullptr;
     double* psd_V[2] = {nullptr, nullptr};     // warm-start eigenvector bases (ping-pong), orders <= 64
     int psd_cur = 0, psd_have_prev = 0;
+    int* psd_stats = nullptr;                  // Jacobi sweeps of the last projection, per (cone, copy)  (fos_psd_debug)
+    int psd_phase_limit = 0;                   // diagnostic: stop the PSD kernel after a phase (wrong results!)
 
     // scalars
     DevState* st = nullptr;
@@ -353,9 +355,10 @@ int prox_cones(fos_solver* h, d2* out, const d2* in) {
     launch_cones_exp(c, out, in, h->expc, h->nexp);
     const int pe = h->npsd > 0 ? prof_begin(h, FOS_PROF_PSD, 0, h->prof_seen[FOS_PROF_PSD]++) : -1;
     FOS_TRY(launch_cones_psd(c, out, in, h->psd, h->npsd, h->psd_kmax, h->psd_scratch,
-                             h->psd_V[h->psd_cur], h->psd_V[1 - h->psd_cur], h->psd_have_prev));
+                             h->psd_V[h->psd_cur], h->psd_V[1 - h->psd_cur], h->psd_have_prev, h->psd_stats, h->psd_phase_limit));
     prof_end(h, pe);
-    if (h->npsd > 0 && h->psd_V[0]) { h->psd_cur = 1 - h->psd_cur; h->psd_have_prev = 1; }
+    // (a diagnostic launch truncated before the basis store leaves the previous basis current)
+    if (h->npsd > 0 && h->psd_V[0] && (h->psd_phase_limit == 0 || h->psd_phase_limit >= 4)) { h->psd_cur = 1 - h->psd_cur; h->psd_have_prev = 1; }
     return check_launch("cone projection");
 }
 
@@ -1184,6 +1187,28 @@ int fos_bench_kkt(fos_handle h, int32_t reps, double* total_ms) {
     if (total_ms) *total_ms = ms;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    return FOS_OK;
+}
+
+int fos_psd_debug(fos_handle h, int32_t collect_stats, int32_t phase_limit) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    if (collect_stats && !h->psd_stats && h->npsd > 0) {
+        FOS_TRY(dev_alloc(h, &h->psd_stats, (size_t)2 * h->npsd));
+        FOS_HIP(hipMemset(h->psd_stats, 0, sizeof(int) * 2 * h->npsd));
+    }
+    h->psd_phase_limit = phase_limit;
+    return FOS_OK;
+}
+
+int fos_psd_stats(fos_handle h, int32_t* sweeps, int64_t cap, int64_t* count) {
+    if (!h || !count) { set_error("NULL argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    *count = h->psd_stats ? 2 * (int64_t)h->npsd : 0;
+    if (sweeps && h->psd_stats) {
+        FOS_HIP(hipStreamSynchronize(h->stream));
+        FOS_HIP(hipMemcpy(sweeps, h->psd_stats, sizeof(int32_t) * (size_t)std::min<int64_t>(cap, *count), hipMemcpyDeviceToHost));
+    }
     return FOS_OK;
 }
 

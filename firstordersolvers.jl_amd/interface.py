@@ -302,6 +302,17 @@ class HipHSDE:
         _lib.check(self._lib.fos_profile_read_classes(self._h, n, ms))
         return {k: (n[i], ms[i]) for i, k in enumerate(("kkt", "psd", "cgvec"))}
 
+    def psd_debug(self, collect_stats=True, phase_limit=0):
+        _lib.check(self._lib.fos_psd_debug(self._h, 1 if collect_stats else 0, int(phase_limit)))
+
+    def psd_sweeps(self):
+        """Jacobi sweeps of the last PSD projection per (cone, copy) matrix (after psd_debug(True))."""
+        n = C.c_int64(0)
+        _lib.check(self._lib.fos_psd_stats(self._h, None, 0, C.byref(n)))
+        out = np.zeros(max(1, n.value), dtype=np.int32)
+        _lib.check(self._lib.fos_psd_stats(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), n.value, C.byref(n)))
+        return out[:n.value]
+
     def bench_cg_chain(self, iters, reps=5, use_graph=False):
         """ms per CG iteration of a chain that never converges (fos_bench_cg_chain)."""
         ms = C.c_double(0)

@@ -219,6 +219,11 @@ int fos_profile_read_classes(fos_handle h, int64_t* launches3, double* total_ms3
  * shortens the dependent-launch chain of a CG solve. */
 int fos_bench_cg_chain(fos_handle h, int32_t iters, int32_t reps, int32_t use_graph, double* ms_per_iter);
 int fos_bench_kkt(fos_handle h, int32_t reps, double* total_ms);
+/* PSD kernel diagnostics (cones.jl:89-94 -> IndPSD): collect_stats != 0 makes every projection record the number of Jacobi
+ * sweeps each (cone, copy) matrix took (fos_psd_stats: 2 x #PSD cones entries, order (cone, part)); phase_limit 1..4 ends
+ * the kernel after load+shift / warm-start product / sweeps / weights+basis -- results are then WRONG, timing use only. */
+int fos_psd_debug(fos_handle h, int32_t collect_stats, int32_t phase_limit);
+int fos_psd_stats(fos_handle h, int32_t* sweeps, int64_t cap, int64_t* count);
 int fos_sync(fos_handle h);
 
 /* Host-only self check of the device operator format (no GPU needed): builds the block format of
