@@ -5,19 +5,24 @@ bench.py -- GAP/DR outer iterations per second + achieved HBM GB/s of the CG SpM
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C4|C2|C3|C5|...]
 
 A "step" is ONE outer iteration of the solver (solverwrapper.jl:23-29: affine projection by warm-started CG over
-the KKT operator -> cone projection -> relaxations) on a synthetic problem already resident in HBM.  Warm-up
-defaults to 200 iterations so that the CG tolerance schedule max(0.2^sqrt(i), l*eps) has reached its floor
-(steady state, ~all of the per-iteration work).  The timed region excludes set-up and the every-`checki` status.
+the KKT operator -> cone projection -> relaxations) on a synthetic problem already resident in HBM.  The metric is
+defined on the STEADY STATE: past the outer iteration at which the CG tolerance schedule
+max(0.2^sqrt(i), l*eps) (affinepluslinear.jl:108-112) reaches its floor -- i = 190 for C4.  Whatever --warmup says, the
+untimed warm-up therefore runs at least to that iteration (`warmup_effective` in the output; `warmup` echoes the flag);
+exactly --steps iterations are then timed.  The timed region excludes set-up and the every-`checki` status.
 
 Default workload (all N): C4, BASELINE.json configs[3] "Block-diagonal SDP, 512 PSD blocks of size 64x64, DR,
 cone-sharded across 1/2/4/8 MI355X via RCCL" -- the configuration the metric ("... at 1/2/4/8 GPUs") and the
 north-star targets (1e6-variable problem, >=3.5x at 8 GPUs on the block-PSD workload) are quoted on; it fits one
-GPU.  N > 1 is STRONG scaling of that one problem: rank g owns blocks [512 g/N, 512 (g+1)/N) and only scalars
-cross GPUs (RCCL all-reduce, in stream).  `--workload C2` runs configs[1] (dense 5000x10000 LP) on one GPU.
+GPU.  N > 1 is STRONG scaling of that one problem by default: rank g owns blocks [512 g/N, 512 (g+1)/N) and only scalars
+cross GPUs (peer mailboxes over xGMI, or an in-stream RCCL all-reduce); `--scaling weak` gives every rank 512 blocks of a
+512 N-block problem instead, and an N > 1 run in the default mode also times that weak-scaling problem and reports it under
+`weak_scaling` in the same line.  `--workload C2` runs configs[1] (dense 5000x10000 LP) on one GPU.
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = fused dual-RHS KKT SpMV,
-HIP events on the solver's stream around every launch in the timed region) and, at N = 1, `cpu_baseline`
-(the oracle restatement timed on one host core for ONE steady-state outer iteration from the GPU's state).
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` for the kernel with the largest measured share of the
+step (HIP events on the solver's stream around sampled launches of the KKT sweep, the batched PSD projection and the CG
+vector updates), `roofline_psd`, `time_shares` and, at N = 1, `cpu_baseline` (the C port of the oracle restatement timed on
+one host core and on all of them, for a bounded sample of steady-state outer iterations from the GPU's state).
 """
 from __future__ import annotations
 
@@ -34,12 +39,26 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+FP64_PEAK_TFLOPS = 78.6        # MI355X fp64 vector = matrix peak (AMD data sheet; the micro-architecture guide lists no fp64 MFMA rate)
+EPS = 2.220446049250313e-16
 
 
-def build_problem(pkg, workload, nranks, rank, small):
+def tolerance_floor_iteration(l_global):
+    """First outer iteration whose CG tolerance max(0.2^sqrt(i), l*eps) is the floor l*eps (affinepluslinear.jl:108-112)."""
+    import math
+    i = max(1, int(math.ceil((math.log(l_global * EPS) / math.log(0.2)) ** 2)))
+    while 0.2 ** math.sqrt(i) > l_global * EPS:
+        i += 1
+    return i
+
+
+
+def build_problem(pkg, workload, nranks, rank, small, weak=False):
     w = pkg.workloads
     if workload == "C4":
         nb = 64 if small else 512
+        if weak:
+            nb *= nranks                                  # every rank owns 512 blocks of a 512 N-block problem
         lo, hi = (nb * rank) // nranks, (nb * (rank + 1)) // nranks
         prob = w.c4_block_sdp(nblocks=nb, block_range=(lo, hi))
         desc = "C4 block-diagonal SDP, %d PSD(64) blocks, 32 free vars/block, DR" % nb
@@ -83,6 +102,10 @@ def main():
     ap.add_argument("--small", action="store_true", help="reduced sizes (smoke / CI); not a valid benchmark number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spmv-wg", type=int, default=0)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1, C4: strong = the 512-block problem split over the ranks (default, the metric's definition); "
+                         "weak = 512 blocks per rank")
+    ap.add_argument("--no-weak-extra", action="store_true", help="N > 1: skip the additional weak-scaling measurement")
     args = ap.parse_args()
 
     import torch
@@ -115,175 +138,253 @@ def main():
 
     import __graft_entry__ as ge
     pkg = ge.load_package()
-
-    t0 = time.time()
-    prob, alg, desc, glob = build_problem(pkg, args.workload, world, rank, args.small)
-    t_gen = time.time() - t0
-    t0 = time.time()
-    dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2, device=local_rank)
-    if dist is not None:
-        if not host_gloo:
-            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(pkg.HipHSDE.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, 0)
-            dev.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
-        # scalar sums: peer mailboxes (one xGMI write latency per exchange) when every rank's self test passes,
-        # otherwise the in-stream RCCL all-reduce set up above.  FOS_REDUCTION=rccl|peer|auto (default auto).
-        want = "peer" if host_gloo else os.environ.get("FOS_REDUCTION", "auto")
-        if want != "rccl":
-            # every collective below is executed by every rank in the same order, whatever fails locally
-            def agree(ok):
-                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=tdev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                return int(flag.item()) == 1
-            try:
-                mine = dev.peer_export()
-            except Exception as exc:                      # no uncached allocation / IPC export on this device
-                print("rank %d: peer mailbox export failed (%s)" % (rank, exc), file=sys.stderr, flush=True)
-                mine = None
-            handles = [None] * world
-            dist.all_gather_object(handles, mine)
-            ok = all(h is not None for h in handles)
-            if ok:
-                try:
-                    dev.peer_open(world, rank, handles, timeout_s=20.0)
-                    dev.sync()
-                except Exception as exc:                  # IPC mapping not available between these devices
-                    print("rank %d: peer mailboxes unavailable (%s)" % (rank, exc), file=sys.stderr, flush=True)
-                    ok = False
-            if agree(ok):
-                dist.barrier()
-                try:
-                    ok = dev.peer_selftest(64)
-                except Exception as exc:
-                    print("rank %d: peer mailbox self test raised (%s)" % (rank, exc), file=sys.stderr, flush=True)
-                    ok = False
-                if agree(ok):
-                    dev.peer_enable(True)
-                    reduction = "peer mailboxes over xGMI (HIP IPC)"
-            if want == "peer" and not reduction.startswith("peer"):
-                raise SystemExit("FOS_REDUCTION=peer but the peer mailboxes are not usable")
-    if args.spmv_wg:
-        dev.set_tuning(spmv_workgroups=args.spmv_wg)
-    dev.set_alg(alg)
-    dev.set_iterate(None)
-    t_setup = time.time() - t0
-
     BIG = 10 ** 12
 
-    def barrier():
+    def agree(ok):
+        """every collective here is executed by every rank in the same order, whatever fails locally"""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def run_case(weak):
+        """Build the (shard of the) problem, warm up to the steady state, time exactly --steps outer iterations."""
+        reduction = "in-stream RCCL all-reduce"
+        t0 = time.time()
+        prob, alg, desc, glob = build_problem(pkg, args.workload, world, rank, args.small, weak=weak)
+        t_gen = time.time() - t0
+        t0 = time.time()
+        dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2, device=local_rank)
+        if dist is not None:
+            if not host_gloo:
+                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(pkg.HipHSDE.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, 0)
+                dev.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
+            # scalar sums: peer mailboxes (one xGMI write latency per exchange) when every rank's self test passes,
+            # otherwise the in-stream RCCL all-reduce set up above.  FOS_REDUCTION=rccl|peer|auto (default auto).
+            want = "peer" if host_gloo else os.environ.get("FOS_REDUCTION", "auto")
+            if want != "rccl":
+                try:
+                    mine = dev.peer_export()
+                except Exception as exc:                      # no uncached allocation / IPC export on this device
+                    print("rank %d: peer mailbox export failed (%s)" % (rank, exc), file=sys.stderr, flush=True)
+                    mine = None
+                handles = [None] * world
+                dist.all_gather_object(handles, mine)
+                ok = all(h is not None for h in handles)
+                if ok:
+                    try:
+                        dev.peer_open(world, rank, handles, timeout_s=20.0)
+                        dev.sync()
+                    except Exception as exc:                  # IPC mapping not available between these devices
+                        print("rank %d: peer mailboxes unavailable (%s)" % (rank, exc), file=sys.stderr, flush=True)
+                        ok = False
+                if agree(ok):
+                    dist.barrier()
+                    try:
+                        ok = dev.peer_selftest(64)
+                    except Exception as exc:
+                        print("rank %d: peer mailbox self test raised (%s)" % (rank, exc), file=sys.stderr, flush=True)
+                        ok = False
+                    if agree(ok):
+                        dev.peer_enable(True)
+                        reduction = "peer mailboxes over xGMI (HIP IPC)"
+                if want == "peer" and not reduction.startswith("peer"):
+                    raise SystemExit("FOS_REDUCTION=peer but the peer mailboxes are not usable")
+        if args.spmv_wg:
+            dev.set_tuning(spmv_workgroups=args.spmv_wg)
+        dev.set_alg(alg)
+        dev.set_iterate(None)
+        t_setup = time.time() - t0
+
+        def barrier():
+            dev.sync()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+
+        # ---- warm-up (untimed): at least to the iteration where the CG tolerance reaches its floor l*eps
+        nm = torch.tensor([float(prob.m + prob.n)], dtype=torch.float64, device=tdev)
+        if dist is not None:
+            dist.all_reduce(nm, op=dist.ReduceOp.SUM)
+        l_global = int(nm.item()) + 1
+        i_floor = tolerance_floor_iteration(l_global)
+        warm = max(args.warmup, i_floor)
+        it = 0
+        if warm > 0:
+            done, _, _ = dev.step(1, warm, BIG, 1e-8)
+            it += done
+        # ---- timed: exactly K outer iterations
+        PROF_PERIOD = 4        # HIP events around every 4th launch group of each class (an event pair per launch costs ~5 % of a C4 step)
+        dev.psd_debug(True, 0)
+        dev.profile(PROF_PERIOD)
+        dev.profile_read_classes()
+        cg0 = dev.cg_total()
+        barrier()
+        t1 = time.perf_counter()
+        done, _, _ = dev.step(it + 1, args.steps, BIG, 1e-8)
         dev.sync()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    # ---- warm-up (untimed): W outer iterations
-    it = 0
-    cg_hist = []
-    if args.warmup > 0:
-        done, _, _ = dev.step(1, args.warmup, BIG, 1e-8)
+        t2 = time.perf_counter()
         it += done
-    # ---- timed: exactly K outer iterations
-    PROF_PERIOD = 4            # HIP events around every 4th KKT launch of the timed region (an event pair per launch costs ~5 % of a step)
-    dev.profile(PROF_PERIOD)
-    dev.profile_read()
-    cg0 = dev.cg_total()
-    barrier()
-    t1 = time.perf_counter()
-    done, _, _ = dev.step(it + 1, args.steps, BIG, 1e-8)
-    dev.sync()
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    it += done
-    elapsed = t2 - t1
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    launches, kms, kbytes = dev.profile_read()
-    cg_timed = dev.cg_total() - cg0
-    dev.profile(False)
-    barrier()
+        elapsed = t2 - t1
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        cls = dev.profile_read_classes()
+        cg_timed = dev.cg_total() - cg0
+        sweeps = dev.psd_sweeps()
+        dev.profile(False)
+        barrier()
 
-    # one check on the current point (not timed): residuals for the record
-    _, _, chk = dev.step(it + 1, 1, 1, 1e-8)
-    it += 1
+        # one check on the current point (not timed): residuals for the record
+        _, _, chk = dev.step(it + 1, 1, 1, 1e-8)
+        it += 1
 
-    # HBM traffic of the dominant kernel measured offline with PMC counters on this workload (profiles/, per launch)
-    traffic = None
-    try:
-        cands = sorted(Path(ROOT / "profiles").glob("r*_kkt_traffic.json"))
-        if cands and not args.small and world == 1:
-            traffic = json.load(open(cands[-1])).get(args.workload, {}).get("traffic_bytes")
-    except Exception:
-        traffic = None
-    ms_per_step = 1e3 * elapsed / max(1, args.steps)
-    value = args.steps / elapsed
-    avg_kernel_ms = kms / max(1, launches)
-    achieved = kbytes / (avg_kernel_ms * 1e-3) / 1e9 if launches else 0.0
-    # what the device format actually streams per KKT apply (model, not a counter): stored values + stored column indices +
-    # block descriptors + partial-sum slots (written by the sweep, read by the deferred-row kernel) + vectors in/out + [c;b]
-    ost = dev.operator_stats()
-    stored_bytes = (8.0 * ost["vals"] + 4.0 * ost["cols"] + 32.0 * ost["blocks"] + 2 * 16.0 * ost["slots"]
-                    + 2 * 16.0 * (prob.m + prob.n) + 8.0 * (prob.m + prob.n))
-    stored_gbs = stored_bytes / (avg_kernel_ms * 1e-3) / 1e9 if launches else 0.0
-    # N > 1: every rank sweeps its own shard at the same time; the job's SpMV rate is the sum over ranks
-    agg = None
-    if dist is not None:
-        tt = torch.tensor([achieved, stored_gbs], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        agg = {"achieved_all_ranks": round(float(tt[0]), 1), "stored_gbs_all_ranks": round(float(tt[1]), 1),
-               "frac_of_n_gpus_peak": round(float(tt[0]) / (HBM_PEAK_GBS * world), 4),
-               "note": "this rank's KKT apply on its shard is what `achieved` prices; the sum over the ranks is the job's rate"}
-    out = {
-        "metric": "GAP/DR outer iterations/sec (+ achieved HBM GB/s of the CG SpMV in `roofline`)",
-        "value": round(value, 4),
-        "unit": "iterations/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic (numpy default_rng, seeds in firstordersolvers.jl_amd/workloads.py)",
-        "config": {
-            "workload": desc + (" [SMALL]" if args.small else ""),
-            "solver": type(alg).__name__,
-            "local_m": int(prob.m), "local_n": int(prob.n), "local_nnz": int(prob.nnz),
-            "cg_iters_per_step": round(cg_timed / max(1, args.steps), 2),
-            "parallelism": "cone-sharded x%d (scalar sums: %s)" % (world, reduction) if dist is not None else "single GPU",
-            "residuals_after_run": {"p": chk.p, "d": chk.d, "g": chk.g, "iteration": it},
-            "setup_s": round(t_setup, 2), "generate_s": round(t_gen, 2),
-        },
-        "roofline": {
+        ms_per_step = 1e3 * elapsed / max(1, args.steps)
+        value = args.steps / elapsed
+        launches, kms = cls["kkt"]
+        avg_kernel_ms = kms / max(1, launches)
+        # ---- bytes of ONE KKT sweep launch
+        # (1) what the device format really streams (model, checked against the PMC counters within 1 %, DESIGN.md 5): stored
+        #     values + stored column indices + block descriptors + partial-sum slots written + the vector's rows read + [c;b]
+        #     read + the result written; the gathered columns of the vector are served from L2.
+        ost = dev.operator_stats()
+        nmr = prob.m + prob.n
+        stored_bytes = (8.0 * ost["vals"] + 4.0 * ost["cols"] + 32.0 * ost["blocks"] + 16.0 * ost["slots"]
+                        + 16.0 * nmr + 8.0 * nmr + 16.0 * nmr)
+        # (2) the same from rocprofv3 PMC passes of THIS round's kernels (tools/gpu_profile_r02.sh -> profiles/), when committed
+        traffic, traffic_src = None, None
+        try:
+            cands = sorted(Path(ROOT / "profiles").glob("r02_kkt_traffic.json"))
+            if cands and not args.small and world == 1:
+                ent = json.load(open(cands[-1])).get(args.workload, {})
+                traffic, traffic_src = ent.get("traffic_bytes"), ent.get("source")
+        except Exception:
+            traffic = None
+        # (3) SURVEY 8(d)'s model of a fused dual-RHS apply on a CSR operator (A and A' each streamed once)
+        survey_bytes = 24.0 * prob.nnz + 4.0 * (nmr + 2) + 32.0 * nmr
+        moved = traffic if traffic else stored_bytes
+        achieved = moved / (avg_kernel_ms * 1e-3) / 1e9 if launches else 0.0
+        survey_gbs = survey_bytes / (avg_kernel_ms * 1e-3) / 1e9 if launches else 0.0
+        # ---- PSD projection: flops of the algorithm as run (sweeps counted by the kernel)
+        npsd_mats = int(sweeps.size)
+        psd_n, psd_ms = cls["psd"]
+        avg_psd_ms = psd_ms / max(1, psd_n)
+        mean_sweeps = float(sweeps.mean()) if npsd_mats else 0.0
+        kk = 64
+        flop_sweep = (kk - 1) * (kk // 2) * (3 * 2 * kk + 2 * kk * 3)          # per pair: 3 dot products + the rotation of 2 columns
+        flop_fixed = 2 * kk ** 3 + 10 * 16 * 16 * kk * 2 + 2 * kk * kk         # warm-start product, rebuild (10 tiles), weights
+        psd_flops = npsd_mats * (mean_sweeps * flop_sweep + flop_fixed)
+        psd_tflops = psd_flops / (avg_psd_ms * 1e-3) / 1e12 if psd_n and avg_psd_ms > 0 else 0.0
+        vec_n, vec_ms = cls["cgvec"]
+        avg_vec_ms = vec_ms / max(1, vec_n)
+        shares = {
+            "kkt_sweep": round(avg_kernel_ms * cg_timed / (1e3 * elapsed), 4) if elapsed > 0 else None,
+            "cg_vector_updates": round(avg_vec_ms * cg_timed / (1e3 * elapsed), 4) if elapsed > 0 else None,
+            "psd_projection": round(avg_psd_ms * args.steps / (1e3 * elapsed), 4) if elapsed > 0 and psd_n else 0.0,
+        }
+        shares["other (rhs build, CG start, relaxations, elementwise/SOC cones, launch gaps, host poll)"] = round(
+            max(0.0, 1.0 - sum(v for v in shares.values() if v)), 4)
+        dominant = max((k for k in ("kkt_sweep", "cg_vector_updates", "psd_projection")), key=lambda k: shares[k] or 0.0)
+        # N > 1: every rank sweeps its own shard at the same time; the job's SpMV rate is the sum over ranks (SURVEY 8(e))
+        agg = None
+        if dist is not None:
+            tt = torch.tensor([achieved], dtype=torch.float64, device=tdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            agg = {"achieved_all_ranks": round(float(tt[0]), 1),
+                   "frac_of_n_gpus_peak": round(float(tt[0]) / (HBM_PEAK_GBS * world), 4),
+                   "note": "this rank's KKT sweep on its shard is what `achieved` prices; the sum over the ranks is the job's rate"}
+        roof_kkt = {
             "bound": "hbm",
-            "kernel": "kkt2_kernel (fused dual-RHS KKT SpMV)" + (" + kkt2_deferred_kernel (rows spread over dual tiles)" if ost["tiles"] else ""),
+            "kernel": "kkt2_kernel: fused dual-RHS KKT sweep of a CG iteration (4 reference SpMV sweeps + epilogue + 3 reductions)",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "frac_of_measured_copy_6290": round(achieved / 6290.0, 4),
+            "bytes_per_launch": moved,
+            "bytes_basis": ("HBM-side bytes per launch from rocprofv3 PMC passes of this round's kernels (%s)" % traffic_src) if traffic
+                           else "bytes the stored format streams per launch (model; agrees with the PMC counters to 1 % on C4/C2, DESIGN.md 5)",
             "traffic": traffic,
-            "traffic_note": "bytes per launch from rocprofv3 PMC passes committed under profiles/ (not collected in this run)" if traffic else None,
-            "algorithmic_bytes_per_launch": kbytes,
             "stored_bytes_per_launch_model": stored_bytes,
-            "stored_gbs": round(stored_gbs, 1),
-            "frac_stored": round(stored_gbs / HBM_PEAK_GBS, 4),
-            "note": ("algorithmic bytes follow SURVEY 8(d) (A and A' each streamed once per dual-RHS apply); dual tiles store dense "
-                     "rectangles of A once for both products, so the sweep moves fewer bytes than that and `frac` can exceed 1; "
-                     "`frac_stored` prices the bytes the format really streams") if ost["tiles"] else None,
+            "survey_model_bytes_per_launch": survey_bytes,
+            "frac_vs_survey_model": round(survey_gbs / HBM_PEAK_GBS, 4),
+            "survey_model_note": "SURVEY 8(d) counts A and A' as two CSR streams (24 B per non-zero of A per dual-RHS apply); dual tiles "
+                                 "store a dense rectangle of A once for both products (8 B), so this ratio can exceed 1 -- it is NOT a "
+                                 "roofline fraction, `frac` is" if ost["tiles"] else None,
             "operator_format": ost,
             "all_ranks": agg,
             "avg_kernel_ms": round(avg_kernel_ms, 5),
             "launches_timed": launches,
             "launches_in_region": cg_timed,
-            "event_sampling": "every %d-th KKT launch of the timed region" % PROF_PERIOD,
-            "kernel_share_of_step": round(avg_kernel_ms * cg_timed / (1e3 * elapsed), 4) if elapsed > 0 else None,
-        },
-    }
+            "event_sampling": "KKT sweeps whose iteration number (counted over all CG solves) is a multiple of %d" % PROF_PERIOD,
+            "kernel_share_of_step": shares["kkt_sweep"],
+        }
+        roof_psd = None
+        if psd_n:
+            roof_psd = {
+                "bound": "mfma",
+                "kernel": "psd_kernel: batched order-64 PSD projection, one-sided Jacobi with warm start; warm-start product and rebuild on v_mfma_f64_16x16x4",
+                "achieved": round(psd_tflops, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(psd_tflops / FP64_PEAK_TFLOPS, 4),
+                "flops_per_launch": psd_flops,
+                "flops_model": "matrices x (sweeps x 63 x 32 pairs x 768 + 2 x 64^3 + 10 x 16 x 16 x 64 x 2 + 2 x 64^2); sweeps counted by the kernel",
+                "matrices_per_launch": npsd_mats, "mean_jacobi_sweeps": round(mean_sweeps, 3),
+                "sweeps_histogram_last_launch": {int(k): int(v) for k, v in zip(*np.unique(sweeps, return_counts=True))},
+                "avg_kernel_ms": round(avg_psd_ms, 5), "launches_timed": psd_n,
+                "note": "latency / issue bound inside LDS (63 dependent rotation steps per sweep), not an MFMA-bound kernel; the two dense "
+                        "contractions are 8 % of its time after moving to MFMA (profiles/r02_psd_phases_*.json)",
+                "kernel_share_of_step": shares["psd_projection"],
+            }
+        out = {
+            "metric": "GAP/DR outer iterations/sec (+ achieved HBM GB/s of the CG SpMV in `roofline`)",
+            "value": round(value, 4),
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "warmup_effective": warm,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak" if weak else "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (numpy default_rng, seeds in firstordersolvers.jl_amd/workloads.py)",
+            "config": {
+                "workload": desc + (" [SMALL]" if args.small else ""),
+                "solver": type(alg).__name__,
+                "regime": "steady state: CG tolerance at its floor l*eps = %.3g from outer iteration %d on (affinepluslinear.jl:108-112); "
+                          "timed iterations %d..%d" % (l_global * EPS, i_floor, warm + 1, warm + args.steps),
+                "local_m": int(prob.m), "local_n": int(prob.n), "local_nnz": int(prob.nnz),
+                "cg_iters_per_step": round(cg_timed / max(1, args.steps), 2),
+                "cg_launches_per_iteration": 2 if os.environ.get("FOS_CG_FUSE_P") == "1" else 3,
+                "parallelism": "cone-sharded x%d (scalar sums: %s)" % (world, reduction) if dist is not None else "single GPU",
+                "residuals_after_run": {"p": chk.p, "d": chk.d, "g": chk.g, "iteration": it},
+                "setup_s": round(t_setup, 2), "generate_s": round(t_gen, 2),
+                "instance_note": "data scaled as BASELINE.md 3 records (||b|| = ||c|| = 10, A_j / 32): a well-conditioned instance, 17 CG "
+                                 "iterations per outer iteration at the floor; unscaled data needs ~75" if args.workload == "C4" else None,
+            },
+            "dominant_kernel": dominant,
+            "time_shares": shares,
+            "roofline": roof_kkt if dominant != "psd_projection" or roof_psd is None else roof_psd,
+            "roofline_kkt": roof_kkt if dominant == "psd_projection" and roof_psd is not None else "= roofline",
+            "roofline_psd": roof_psd,
+        }
+        return out, dev, prob, alg, it
+
+    weak_main = args.scaling == "weak"
+    out, dev, prob, alg, it = run_case(weak_main)
+    if world > 1 and not weak_main and not args.no_weak_extra and args.workload == "C4":
+        # the same job once more with 512 blocks PER RANK: weak scaling, reported beside the strong-scaling headline
+        dev.close()
+        wout, dev, prob, alg, it = run_case(True)
+        out["weak_scaling"] = {k: wout[k] for k in ("value", "unit", "ms_per_step", "scaling", "warmup_effective")}
+        out["weak_scaling"]["config"] = {k: wout["config"][k] for k in ("workload", "local_m", "local_n", "local_nnz", "cg_iters_per_step", "parallelism")}
+        rk = wout["roofline_kkt"] if isinstance(wout["roofline_kkt"], dict) else wout["roofline"]
+        out["weak_scaling"]["roofline_kkt"] = {k: rk[k] for k in ("achieved", "frac", "avg_kernel_ms", "all_ranks")}
 
     # ---- CPU baseline (rank 0, N = 1): the C port of the oracle restatement on one core (+ all cores), bounded sample
     if world == 1 and not args.no_cpu_baseline:

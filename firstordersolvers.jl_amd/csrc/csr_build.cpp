@@ -62,8 +62,106 @@ void partition_workgroups(HostBlkCsr* S, int nwg_target) {
     S->nwaves = nwaves;
 }
 
+// Window-panel storage of S (fos_internal.hpp, WinPanel).  Returns true when built; false = "not worth it" (the caller falls
+// back to row blocks): fewer entries inside the panel-window tiles than half the vector elements the tiles stage (the window
+// loads would then cost more than the gathers they replace), or too few panels to fill the GPU.
+static bool build_window_panels(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                                bool force, HostBlkCsr* out) {
+    const int64_t nrows = n + m, nnz = colptr[n] - 1;
+    if (nrows >= (int64_t)1 << 31 || 2 * nnz >= ((int64_t)1 << 40)) return false;
+    // ---- CSR of S: rows 0..n-1 = columns of A (entries at stacked column n + i), rows n.. = rows of A (stacked column j)
+    std::vector<int64_t> rp(nrows + 1, 0);
+    for (int64_t j = 0; j < n; ++j) rp[j + 1] = colptr[j + 1] - colptr[j];
+    for (int64_t k = 0; k < nnz; ++k) rp[n + rowval[k]] += 1;          // rowval is 1-based: row i -> index n + i + 1 - 1 + 1
+    for (int64_t r = 0; r < nrows; ++r) rp[r + 1] += rp[r];
+    std::vector<int32_t> ci((size_t)2 * nnz);
+    std::vector<double> vv((size_t)2 * nnz);
+    {
+        std::vector<int64_t> fill(rp.begin() + n, rp.end() - 1);
+        for (int64_t j = 0; j < n; ++j) {
+            int64_t q = rp[j];
+            for (int64_t k = colptr[j] - 1; k < colptr[j + 1] - 1; ++k, ++q) {
+                const int64_t i = rowval[k] - 1;
+                ci[q] = (int32_t)(n + i); vv[q] = nzval[k];
+                const int64_t f = fill[i]++;
+                ci[f] = (int32_t)j; vv[f] = nzval[k];
+            }
+        }
+    }
+    for (int64_t r = 0; r < nrows; ++r)                    // the window walk needs ascending columns inside every row
+        for (int64_t q = rp[r] + 1; q < rp[r + 1]; ++q)
+            if (ci[q] <= ci[q - 1]) return false;
+    HostBlkCsr& S = *out;
+    const int64_t npanel = (nrows + WIN_ROWS - 1) / WIN_ROWS;
+    int64_t staged = 0;                                   // vector elements the tiles stage
+    std::vector<int32_t> cnt(WIN_ROWS), order(WIN_ROWS), cursor(WIN_ROWS);
+    int64_t pos = 0;
+    for (int64_t p = 0; p < npanel; ++p) {
+        const int64_t r0 = p * WIN_ROWS, R = std::min<int64_t>(WIN_ROWS, nrows - r0);
+        WinPanel wp;
+        wp.row0 = (int32_t)r0; wp.nrows = (int32_t)R; wp.seg0 = (int32_t)S.wseg.size(); wp.nseg = 0;
+        // the windows this panel touches, ascending: every row's entries are sorted by column, so walk them window by window
+        for (int64_t i = 0; i < R; ++i) cursor[i] = 0;
+        while (true) {
+            int64_t wmin = -1;                            // the smallest window with an unconsumed entry
+            for (int64_t i = 0; i < R; ++i) {
+                const int64_t q = rp[r0 + i] + cursor[i];
+                if (q < rp[r0 + i + 1]) { const int64_t w = ci[q] / WIN_COLS; if (wmin < 0 || w < wmin) wmin = w; }
+            }
+            if (wmin < 0) break;
+            const int64_t c0 = wmin * WIN_COLS, c1 = std::min<int64_t>(c0 + WIN_COLS, nrows);
+            int64_t nact = 0;
+            for (int64_t i = 0; i < R; ++i) {
+                int32_t k = 0;
+                for (int64_t q = rp[r0 + i] + cursor[i]; q < rp[r0 + i + 1] && ci[q] < c1; ++q) ++k;
+                cnt[i] = k;
+                if (k > 0) order[nact++] = (int32_t)i;
+            }
+            std::stable_sort(order.begin(), order.begin() + nact, [&](int32_t a, int32_t b) { return cnt[a] > cnt[b]; });
+            WinSeg sg;
+            sg.col0 = (int32_t)c0; sg.ncols = (int32_t)(c1 - c0); sg.slice0 = (int32_t)S.wslice.size(); sg.nslice = 0;
+            for (int64_t s0 = 0; s0 < nact; s0 += 64) {
+                const int64_t ns = std::min<int64_t>(64, nact - s0);
+                const int32_t T = cnt[order[s0]];
+                WinSlice sl;
+                sl.off = pos; sl.steps = T; sl.pad = 0;
+                S.wval.resize((size_t)(pos + 64 * (int64_t)T), 0.0);
+                S.wcol.resize((size_t)(pos + 64 * (int64_t)T), 0);
+                const size_t rbase = S.wrow.size();
+                S.wrow.resize(rbase + 64, (uint16_t)0xFFFF);
+                for (int64_t l = 0; l < ns; ++l) {
+                    const int32_t i = order[s0 + l];
+                    S.wrow[rbase + l] = (uint16_t)i;
+                    const int64_t q0 = rp[r0 + i] + cursor[i];
+                    for (int32_t t = 0; t < cnt[i]; ++t) {
+                        S.wval[(size_t)(pos + 64 * (int64_t)t + l)] = vv[q0 + t];
+                        S.wcol[(size_t)(pos + 64 * (int64_t)t + l)] = (uint16_t)(ci[q0 + t] - c0);
+                    }
+                }
+                pos += 64 * (int64_t)T;
+                S.wslice.push_back(sl);
+                sg.nslice += 1;
+            }
+            for (int64_t i = 0; i < R; ++i) cursor[i] += cnt[i];
+            S.wseg.push_back(sg);
+            wp.nseg += 1;
+            staged += c1 - c0;
+        }
+        S.wpanel.push_back(wp);
+    }
+    const bool worth = 2 * nnz >= staged / 2 && npanel >= 64;
+    if (!worth && !force) {
+        S.wpanel.clear(); S.wseg.clear(); S.wslice.clear(); S.wval.clear(); S.wcol.clear(); S.wrow.clear();
+        std::vector<double>().swap(S.wval);
+        return false;
+    }
+    S.nnz_padded = pos;
+    S.ncol_stored = pos;
+    return true;
+}
+
 int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
-                      int nwg_target, HostBlkCsr* out, int resident_waves) {
+                      int nwg_target, HostBlkCsr* out, int resident_waves, int window_mode) {
     if (m < 0 || n < 0) { set_error("negative dimension"); return FOS_EINVAL; }
     if (n + m + 1 > (int64_t)INT32_MAX / 2) { set_error("n+m too large for int32 column indices"); return FOS_EUNSUPPORTED; }
     if (colptr[0] != 1) { set_error("colptr must be 1-based (colptr[1] == 1)"); return FOS_EINVAL; }
@@ -123,6 +221,27 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         }
     }
     const bool have_tiles = !groups.empty();
+
+    // ---- gather-bound operators: window panels instead of row blocks (decided from the operator; FOS_WINDOWS=0/1 forces)
+    {
+        int mode = window_mode;
+        if (const char* e = getenv("FOS_WINDOWS")) mode = atoi(e);
+        int64_t nrun = 0;
+        for (int64_t r = 0; r < nrows; ++r) nrun += is_run[r] ? 1 : 0;     // (rows of A only carry a meaningful flag here; A' rows default to 1)
+        int64_t runA = 0;
+        for (int64_t i = 0; i < m; ++i) runA += (is_run[n + i] && alen[i] > 1) ? 1 : 0;
+        const bool candidate = !have_tiles && nnz >= 4 * nrows / 2 && runA < m / 10 && nrows >= 64 * (int64_t)WIN_ROWS;
+        if (mode == 1 || (mode != 0 && candidate)) {
+            *out = HostBlkCsr();
+            out->nrows = nrows;
+            out->nnz = 2 * nnz;
+            if (build_window_panels(m, n, colptr, rowval, nzval, mode == 1, out)) {
+                out->nblk = 0; out->nwg = (int32_t)std::min<size_t>(out->wpanel.size(), 16384); out->nwaves = 0;
+                out->wave_blk0.assign(1, 0);
+                return FOS_OK;
+            }
+        }
+    }
 
     // ---- plain CSR of what the sweep still stores: rows of A' lose the entries that tiles cover, tile rows of A vanish
     std::vector<int64_t> rp(nrows + 1, 0);
@@ -424,6 +543,47 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
 // out = S * v for the stacked vector v = [vx(n); vy(m)].  Used by the CPU tests to validate the format construction
 // without a GPU.
 int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::string* why) {
+    if (!S.wpanel.empty()) {
+        // window panels: per panel the row sums accumulate window by window, inside a window slice by slice, lane by lane
+        auto failw = [&](const char* msg, long long a) { if (why) *why = std::string(msg) + " " + std::to_string(a); return FOS_EINVAL; };
+        std::vector<int> covered(S.nrows, 0);
+        int64_t next_row = 0;
+        for (size_t p = 0; p < S.wpanel.size(); ++p) {
+            const WinPanel& wp = S.wpanel[p];
+            if (wp.row0 != next_row || wp.nrows < 1 || wp.nrows > WIN_ROWS) return failw("bad panel", (long long)p);
+            next_row += wp.nrows;
+            std::vector<double> acc(wp.nrows, 0.0);
+            int32_t prev_col0 = -1;
+            for (int32_t sgi = wp.seg0; sgi < wp.seg0 + wp.nseg; ++sgi) {
+                const WinSeg& sg = S.wseg[sgi];
+                if (sg.col0 <= prev_col0 || sg.col0 % WIN_COLS || sg.ncols < 1 || sg.ncols > WIN_COLS || sg.col0 + sg.ncols > S.nrows) return failw("bad window in panel", (long long)p);
+                prev_col0 = sg.col0;
+                std::vector<int> used(wp.nrows, 0);
+                for (int32_t sl = sg.slice0; sl < sg.slice0 + sg.nslice; ++sl) {
+                    const WinSlice& ws = S.wslice[sl];
+                    if (ws.off % 64 || ws.steps < 1 || ws.off + 64 * (int64_t)ws.steps > (int64_t)S.wval.size()) return failw("bad slice", sl);
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const uint16_t rid = S.wrow[(size_t)sl * 64 + lane];
+                        double a = 0.0;
+                        for (int t = 0; t < ws.steps; ++t) {
+                            const size_t e = (size_t)(ws.off + 64 * (int64_t)t + lane);
+                            const int c = S.wcol[e];
+                            if (c >= sg.ncols) return failw("column outside the window in slice", sl);
+                            if (rid == 0xFFFF && S.wval[e] != 0.0) return failw("padding lane with a value in slice", sl);
+                            a += S.wval[e] * v[sg.col0 + c];
+                        }
+                        if (rid == 0xFFFF) continue;
+                        if (rid >= wp.nrows || used[rid]++) return failw("row listed twice in a window, slice", sl);
+                        acc[rid] += a;
+                    }
+                }
+            }
+            for (int32_t i = 0; i < wp.nrows; ++i) { out[wp.row0 + i] = acc[i]; covered[wp.row0 + i]++; }
+        }
+        if (next_row != S.nrows) return failw("panels do not cover all rows:", next_row);
+        for (int64_t r = 0; r < S.nrows; ++r) if (covered[r] != 1) return failw("row not covered exactly once:", r);
+        return FOS_OK;
+    }
     std::vector<int> seen(S.nrows, 0), swept(S.nrows, 0);
     std::vector<double> slots((size_t)std::max<int64_t>(S.nslots, 1), 0.0);
     std::vector<int> slot_written((size_t)std::max<int64_t>(S.nslots, 1), 0);

@@ -63,6 +63,20 @@ constexpr int TILE_MIN_COLS = 8;
 constexpr int TILE_TC_MAX = 64;     // columns (steps) per tile: 32 KB of values per wavefront work unit (measured best on C2: 32..128 tried)
 constexpr int TILE_GROUP = 8;       // steps per butterfly; stored steps are padded to a multiple
 
+// Window panels (gather-bound random-sparse operators, C5 class).  A PANEL = WIN_ROWS consecutive rows of S, the unit of
+// work of ONE WORKGROUP, which walks the column WINDOWS (WIN_COLS consecutive entries of the stacked vector) its rows touch:
+// the window is staged in LDS by coalesced loads, the panel's non-zeros inside it are multiplied against LDS (no 128-byte L1
+// line fill per 16-byte gather: the bound of the row-block formats on such operators), and the row sums are kept in LDS across
+// the windows.  Inside a (panel, window) SEGMENT the rows that have entries there are sorted by their entry count (SELL-sigma)
+// and cut into SLICES of 64 rows stored lane-major (lane = row, step = entry; padded to the slice's longest row: ~10 %, not the
+// 40-50 % of panel-wide ELL), with 16-bit column offsets inside the window and a 16-bit local row id per lane.
+constexpr int WIN_COLS = 4096;      // window: 64 KB of double2 in LDS
+constexpr int WIN_ROWS = 2048;      // panel: 32 KB of row sums in LDS
+constexpr int WIN_THREADS = 1024;   // 16 wavefronts share the window; one workgroup per CU (96 KB of LDS)
+struct WinPanel { int32_t row0, nrows, seg0, nseg; };
+struct WinSeg { int32_t col0, ncols, slice0, nslice; };
+struct WinSlice { int64_t off; int32_t steps, pad; };       // values/columns at off + 64 t + lane (off a multiple of 64)
+
 struct BlkDesc {                    // one row block = the unit of work of ONE wavefront (32 bytes)
     int64_t nnz0;                   // first value in `val` (multiple of NNZ_ALIGN)
     int64_t colpos;                 // first entry in `col`: per-entry column indices, or -- for a RUN block, whose rows
@@ -93,6 +107,13 @@ struct HostBlkCsr {
     std::vector<int32_t> def_rows;     // [ndef]   deferred rows, ascending
     std::vector<int32_t> def_ptr;      // [ndef+1] their slot lists
     std::vector<int32_t> def_idx;      // slot indices, in summation order
+    // window panels (empty unless the operator is stored that way; then blk is empty and val/col are unused)
+    std::vector<WinPanel> wpanel;
+    std::vector<WinSeg> wseg;
+    std::vector<WinSlice> wslice;
+    std::vector<double> wval;
+    std::vector<uint16_t> wcol;        // column offset inside the window, per stored entry
+    std::vector<uint16_t> wrow;        // [nslice * 64] local row of each lane (0xFFFF: no row)
 };
 
 struct DevBlkCsr {
@@ -114,11 +135,19 @@ struct DevBlkCsr {
     int32_t npart, part_off;           // the partial-sum records a sweep leaves for its consumers: `npart` records starting at
                                        // record `part_off` (no tiles: the sweep's nwg; tiles: the deferred-row kernel folds the
                                        // sweep's records into its own nwg_def, stored behind them)
+    // window panels (npanel == 0: row-block storage)
+    int32_t npanel;
+    const WinPanel* wpanel;
+    const WinSeg* wseg;
+    const WinSlice* wslice;
+    const double* wval;
+    const uint16_t* wcol;
+    const uint16_t* wrow;
 };
 
 // Builds S = [[0, A'],[A, 0]] from Julia CSC (1-based).  Returns FOS_EINVAL on malformed input.
 int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
-                      int nwg_target, HostBlkCsr* out, int resident_waves = 0);
+                      int nwg_target, HostBlkCsr* out, int resident_waves = 0, int window_mode = -1);   // -1: decide from the operator, 0 / 1: force
 void partition_workgroups(HostBlkCsr* S, int nwg_target);
 int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::string* why);
 constexpr int DEF_THREADS = 256;    // deferred-row kernel: one thread per deferred row

@@ -483,6 +483,75 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
     }
 }
 
+// ------------------------------------------------------------------------------------------------ window panels
+// Gather-bound operators (fos_internal.hpp, WinPanel): ONE WORKGROUP per panel of WIN_ROWS rows.  Per column window the panel
+// touches: stage the window of the vector in LDS (coalesced 16-byte loads), then every wavefront takes whole 64-row slices --
+// lane = row, lane-major values and 16-bit window offsets streamed non-temporally, the vector element read from LDS -- and adds
+// its lanes' sums to the panel's row sums in LDS (a row appears once per window: no conflict, fixed order).  The row epilogue
+// runs once per row at the end, over consecutive rows (coalesced).
+constexpr size_t win_lds_bytes(int nrhs) { return (size_t)(WIN_COLS + WIN_ROWS) * 8 * nrhs + 64 * sizeof(double); }
+
+template <class G, class Epi>
+__device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& epi, double* lds) {
+    constexpr int NRHS = G::NRHS;
+    constexpr int NWAVES = WIN_THREADS / 64;
+    using E = typename std::conditional<NRHS == 2, d2, double>::type;
+    E* win = reinterpret_cast<E*>(lds);
+    E* acc = win + WIN_COLS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int p = xcd_remap(blockIdx.x, gridDim.x); p < S.npanel; p += gridDim.x) {
+        const WinPanel wp = S.wpanel[p];
+        for (int i = tid; i < wp.nrows; i += WIN_THREADS) {
+            if constexpr (NRHS == 2) acc[i] = make_double2(0.0, 0.0); else acc[i] = 0.0;
+        }
+        for (int sgi = wp.seg0; sgi < wp.seg0 + wp.nseg; ++sgi) {
+            const WinSeg sg = S.wseg[sgi];
+            __syncthreads();                               // the previous window's readers are done (first pass: acc is zeroed)
+            for (int i = tid; i < sg.ncols; i += WIN_THREADS) {
+                const d2 x = gat.load(sg.col0 + i);
+                if constexpr (NRHS == 2) win[i] = x; else win[i] = x.x;
+            }
+            __syncthreads();
+            for (int sl = sg.slice0 + wv; sl < sg.slice0 + sg.nslice; sl += NWAVES) {
+                const int64_t off = S.wslice[sl].off;
+                const int T = S.wslice[sl].steps;
+                const unsigned rid = S.wrow[(size_t)sl * 64 + lane];
+                const double* __restrict__ val = S.wval + off + lane;
+                const uint16_t* __restrict__ col = S.wcol + off + lane;
+                double a1 = 0.0, a2 = 0.0;
+                int t = 0;
+                for (; t + 4 <= T; t += 4) {
+                    double v[4]; unsigned c[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { v[u] = nt_load(val + 64 * (t + u)); c[u] = nt_load(col + 64 * (t + u)); }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const E x = win[c[u]];
+                        if constexpr (NRHS == 2) { a1 += v[u] * x.x; a2 += v[u] * x.y; } else a1 += v[u] * x;
+                    }
+                }
+                for (; t < T; ++t) {
+                    const double v = nt_load(val + 64 * t);
+                    const E x = win[nt_load(col + 64 * t)];
+                    if constexpr (NRHS == 2) { a1 += v * x.x; a2 += v * x.y; } else a1 += v * x;
+                }
+                if (rid != 0xFFFFu) {
+                    if constexpr (NRHS == 2) { const d2 o = acc[rid]; acc[rid] = make_double2(o.x + a1, o.y + a2); }
+                    else acc[rid] += a1;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < wp.nrows; i += WIN_THREADS) {
+            const int row = wp.row0 + i;
+            const RowPre pr = epi.pre(row);
+            if constexpr (NRHS == 2) { const d2 a = acc[i]; epi.row(row, a.x, a.y, pr); }
+            else epi.row(row, acc[i], 0.0, pr);
+        }
+        __syncthreads();                                   // before the next panel zeroes acc
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ KKT apply, 2 RHS
 
 // Row epilogue of out = [I Q'; Q -I] w for both right-hand sides, plus the three sums CG needs.
@@ -586,6 +655,30 @@ __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBl
     }
     spmv_walk<DEFER>(S, gat, epi, prod);
     block_reduce_store<3, SPMV_THREADS>(epi.acc, red, a.partials + 3 * (int64_t)blockIdx.x);
+}
+
+// window-panel form of the sweep (stand-alone applies and CG iterations alike: no dual tiles, the p update is a kernel of its own)
+__global__ __launch_bounds__(WIN_THREADS) void kkt2_win_kernel(DevBlkCsr S, KktArgs a) {
+    if (a.gate && a.st->done) return;
+    extern __shared__ __attribute__((aligned(16))) double wlds[];
+    GatherW gat;
+    gat.w = a.w;
+    EpiKkt<GatherW, false> epi;
+    epi.gat = gat; epi.out = a.out; epi.pnew = nullptr; epi.cb = a.cb; epi.n = a.n; epi.wt = gat.load_u(a.nm);
+    epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
+    win_walk(S, gat, epi, wlds);
+    block_reduce_store<3, WIN_THREADS>(epi.acc, wlds + (size_t)(WIN_COLS + WIN_ROWS) * 2, a.partials + 3 * (int64_t)blockIdx.x);
+}
+// dynamic LDS above 64 KB needs an opt-in per kernel and device
+template <class K>
+static bool win_lds_optin(K kernel, size_t bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(window kernel, %zu bytes of LDS): %s", bytes, hipGetErrorString(e)); return false; }
+    return true;
+}
+static void launch_kkt2_win(const LaunchCtx& c, const KktArgs& a) {
+    (void)win_lds_optin(kkt2_win_kernel, win_lds_bytes(2));       // cheap (a table update); a failure surfaces through check_launch
+    hipLaunchKernelGGL(kkt2_win_kernel, dim3(c.S.nwg), dim3(WIN_THREADS), win_lds_bytes(2), c.stream, c.S, a);
 }
 
 // Deferred rows (dual tiles): `lpr` lanes (a power of two <= 64, S.def_lpr) share a row: lane-strided partial sums of the
@@ -739,6 +832,7 @@ static KktArgs plain_args(const LaunchCtx& c, const double2* w, double2* out, in
 // stand-alone apply: sweep (+ deferred-row kernel when the operator has dual tiles); leaves c.S.npart records at c.S.part_off
 void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
     const KktArgs a = plain_args(c, w, out, gate);
+    if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
     if (c.S.ndef > 0) {
         hipLaunchKernelGGL((kkt2_kernel<true, false, false>), dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, a);
         hipLaunchKernelGGL(kkt2_deferred_kernel, dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, w, out, c.cb, (int)c.n,
@@ -752,6 +846,7 @@ void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
 //   otherwise applies to p_cur as it stands (iteration 1, or the p update ran as its own kernel).
 void launch_kkt2_cg(const LaunchCtx& c, const CgIter& it, double2* Ap) {
     KktArgs a = plain_args(c, it.p_cur, Ap, 1);
+    if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }       // (fuse_p is never set for window-panel operators)
     const bool fused = it.fuse_p && it.j >= 2;
     if (fused) {
         a.w = it.p_prev; a.r = it.r; a.pnew = it.p_cur;
@@ -879,8 +974,25 @@ __global__ __launch_bounds__(DEF_THREADS) void q1_deferred_kernel(DevBlkCsr S, c
     block_reduce_store<NACC, DEF_THREADS>(epi.acc, red, partials + NACC * (int64_t)(S.nwg + blockIdx.x));
 }
 template <class Epi, int NACC>
+__global__ __launch_bounds__(WIN_THREADS) void q1_win_kernel(DevBlkCsr S, const double* __restrict__ vcomp, Epi epi, int nm,
+                                                             double* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) double wlds[];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
+    epi.init(vcomp[2 * (int64_t)nm]);
+    Gather1 gat{vcomp};
+    win_walk(S, gat, epi, wlds);
+    block_reduce_store<NACC, WIN_THREADS>(epi.acc, wlds + (size_t)(WIN_COLS + WIN_ROWS), partials + NACC * (int64_t)blockIdx.x);
+}
+template <class Epi, int NACC>
 static void launch_q1_kernels(const LaunchCtx& c, const double* vcomp, const Epi& e, int nm) {
     dim3 grid(c.S.nwg), block(SPMV_THREADS);
+    if (c.S.npanel > 0) {
+        const size_t lds = win_lds_bytes(1) + 16 * NACC * sizeof(double);
+        (void)win_lds_optin(q1_win_kernel<Epi, NACC>, lds);
+        hipLaunchKernelGGL((q1_win_kernel<Epi, NACC>), grid, dim3(WIN_THREADS), lds, c.stream, c.S, vcomp, e, nm, c.partials);
+        return;
+    }
     if (c.S.ndef > 0) {
         hipLaunchKernelGGL((q1_kernel<Epi, NACC, true>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
         hipLaunchKernelGGL((q1_deferred_kernel<Epi, NACC>), dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, vcomp, e, nm, c.partials);

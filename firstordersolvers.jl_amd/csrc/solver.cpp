@@ -29,6 +29,39 @@ struct Rccl {
 };
 static Rccl g_rccl;
 
+// ------------------------------------------------------------------------------------------------ roctx ranges
+// Named ranges around the phases of an outer iteration (affine projection / cone projection / status check) for
+// `rocprofv3 --marker-trace`.  Resolved by dlopen at first use and only when FOS_ROCTX=1: no link-time dependency, no cost
+// otherwise (one predictable branch per phase).
+struct Roctx {
+    int state = 0;                         // 0: not tried, 1: on, -1: off
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+static Roctx g_roctx;
+static bool roctx_on() {
+    if (g_roctx.state == 0) {
+        g_roctx.state = -1;
+        const char* e = getenv("FOS_ROCTX");
+        if (e && atoi(e) != 0) {
+            const char* names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"};
+            for (const char* nm : names) {
+                void* lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+                if (!lib) continue;
+                g_roctx.push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+                g_roctx.pop = (int (*)())dlsym(lib, "roctxRangePop");
+                if (g_roctx.push && g_roctx.pop) { g_roctx.state = 1; break; }
+            }
+        }
+    }
+    return g_roctx.state == 1;
+}
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* name) : on(roctx_on()) { if (on) g_roctx.push(name); }
+    ~RoctxRange() { if (on) g_roctx.pop(); }
+};
+
 static int rccl_load() {
     if (g_rccl.lib) return FOS_OK;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -328,6 +361,7 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
 
 // prox!(y, S1::AffinePlusLinear, x) with the result left in h->SOL       affinepluslinear.jl:83-126
 int prox_affine(fos_solver* h, const d2* x) {
+    RoctxRange range("fos:prox_affine (rhs build + warm-started CG over the KKT operator)");
     LaunchCtx c = h->ctx();
     int fr = 0;
     launch_q1(c, Q_RHS, x, 1, 1.0, h->RHS);                            // :94-95
@@ -349,6 +383,7 @@ int prox_affine(fos_solver* h, const d2* x) {
 
 // prox!(y, S2::DualConeProduct, x)                                        cones.jl:122-142
 int prox_cones(fos_solver* h, d2* out, const d2* in) {
+    RoctxRange range("fos:prox_cones (elementwise + SOC + Exp + batched PSD)");
     LaunchCtx c = h->ctx();
     launch_cones_elementwise(c, out, in, h->ew_op);
     launch_cones_soc(c, out, in, h->soc, h->nsoc);
@@ -364,6 +399,7 @@ int prox_cones(fos_solver* h, d2* out, const d2* in) {
 
 // checkstatus(status, z, override=true) values + decision               HSDEStatus.jl:27-63
 int status_check(fos_solver* h, const d2* z, double eps, fos_check_result* res) {
+    RoctxRange range("fos:checkstatus");
     LaunchCtx c = h->ctx();
     int fr = 0;
     launch_q1(c, Q_STATUS, z, 0, 1.0, nullptr);

@@ -19,7 +19,7 @@ module FOSHip
 using ..FirstOrderSolvers
 import ..FirstOrderSolvers: FOSAlgorithm, FOSSolverData, FOSMathProgModel, HSDEStatus, GAP, GAPA, FISTA, Dykstra,
                             init_algorithm!, getsol, getcgiter, iterate, printstatusheader, printstatusiter,
-                            savedata, get_sets_and_status, ConeProduct
+                            savedata, ConeProduct
 import ProximalOperators
 using SparseArrays, Printf
 
@@ -103,8 +103,12 @@ for T in (:GAP, :GAPA, :FISTA, :Dykstra)
     @eval function init_algorithm!(alg::$T, model::FOSMathProgModel)
         if usegpu(model)
             alg.direct && error("direct=true is not available on the HIP path")     # HSDE.jl:12-15 is CPU only
-            # status_generator is the reference's closure [HSDE.jl:26-27]; sets S1/S2 are not built on the host
-            _, _, _, status_generator = get_sets_and_status(alg, model)
+            # the reference's closure [HSDE.jl:24-27], built directly: get_sets_and_status would also construct the host-side
+            # AffinePlusLinear (5 N-vectors of CG state) and DualConeProduct, which the device path never touches.
+            # m, n as DualConeProduct's constructor takes them [cones.jl:121]
+            sm, sn = model.K1.ranges[end][end], model.K2.ranges[end][end]
+            status_generator = (mo, checki, eps, verbose, debug) ->
+                HSDEStatus(sm, sn, 0, mo, :Continue, checki, eps, verbose, false, false, time_ns(), model.init_duration, debug)
             data = HipData(model, get(model.options, :device, 0))
             set_alg!(data, alg)
             return data, status_generator
@@ -176,9 +180,13 @@ function iterate(alg::FOSAlgorithm, data::HipData, status::HSDEStatus, x, max_it
     return guess
 end
 
-# ---- single-step entry points, so wrappers written against step/getsol keep working (one ccall per iteration) -----
+# ---- single-step entry points for callers written against step/getsol (one upload, one ccall, one download per
+#      iteration: correct but PCIe bound -- `iterate` above is the path to use).  The host vector is uploaded on EVERY call, so
+#      a caller that edits x between steps is honoured.  LineSearchWrapper / LongstepWrapper are NOT supported with gpu=true:
+#      they call prox! on S1/S2 themselves [wrappers/linesearch.jl:36-75], which the device path does not build.
 function Base.step(alg::FOSAlgorithm, data::HipData, x, i, status::HSDEStatus, longstep = nothing)
-    i == 1 && check(ccall((:fos_set_iterate, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, x))
+    longstep === nothing || error("longstep/linesearch wrappers are not available with gpu=true")
+    check(ccall((:fos_set_iterate, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, x))
     done, checked, res = Ref{Int64}(0), Ref{Int32}(0), Ref{CheckResult}()
     check(ccall((:fos_step, libfoship), Cint,
                 (Ptr{Cvoid}, Int64, Int64, Int64, Cdouble, Ref{Int64}, Ref{Int32}, Ref{CheckResult}),

@@ -342,3 +342,10 @@ CONFIGS = {
     "C4": c4_block_sdp,
     "C5": c5_mixed,
 }
+
+
+def mid_mixed(seed=14):
+    """l ~ 1e4 mixed-cone problem (NonNeg + SOC(50) + PSD(16), 2 blocks, ~20 non-zeros per row): large enough for the device
+    paths of the full-size configurations (ELL blocks, batched SOC/PSD kernels, warm-started PSD), small enough for the numpy
+    oracle to run whole solves in seconds -- the mid-size whole-solve parity case."""
+    return c5_mixed(seed=seed, nblocks=2, nb_cols=2500, nonneg=1200, nsoc=12, socdim=50, npsd=2, k=16, density=8e-3)

@@ -1,0 +1,58 @@
+"""
+The complete `bench.py --gpus N` flow on ONE GPU (the driver launches it on 2/4/8 GPUs at round end; it must not rot):
+two ranks started by torch.distributed.run share the device, host-side coordination over gloo (`FOS_BENCH_BACKEND=gloo`:
+RCCL refuses several ranks per device), scalar sums through the peer mailboxes -- per-rank shard generation, mailbox export /
+open / self test, barrier + max-over-ranks timing, the strong-scaling headline plus the weak-scaling extra, ONE JSON line.
+The same problem run by one rank must report the same residuals.
+"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _last_json(text):
+    for line in reversed(text.strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            return json.loads(line)
+    raise AssertionError("no JSON line in:\n" + text[-2000:])
+
+
+def test_bench_two_ranks_on_one_gpu_matches_single_rank():
+    env = dict(os.environ, FOS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", "29541", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--small"]
+    r2 = subprocess.run(cmd2, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stdout[-3000:] + r2.stderr[-3000:]
+    out2 = _last_json(r2.stdout)
+    cmd1 = [sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "3", "--small", "--no-cpu-baseline"]
+    r1 = subprocess.run(cmd1, cwd=str(ROOT), env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stdout[-3000:] + r1.stderr[-3000:]
+    out1 = _last_json(r1.stdout)
+
+    # contract fields of the N = 2 line
+    assert out2["n_gpus"] == 2 and out2["steps"] == 6 and out2["warmup"] == 3 and out2["scaling"] == "strong"
+    assert out2["unit"] == "iterations/s" and out2["value"] > 0 and out2["higher_is_better"] is True and out2["dtype"] == "f64"
+    assert out2["warmup_effective"] >= out2["warmup"] and out2["warmup_effective"] == out1["warmup_effective"]   # same global l
+    assert "peer mailboxes" in out2["config"]["parallelism"]
+    assert out2["roofline"]["all_ranks"]["achieved_all_ranks"] >= out2["roofline"]["achieved"]
+    assert "cpu_baseline" not in out2                       # N = 1 only
+    # each rank holds half of the blocks
+    assert 2 * out2["config"]["local_m"] == out1["config"]["local_m"] and 2 * out2["config"]["local_nnz"] == out1["config"]["local_nnz"]
+    # the weak-scaling extra: twice the blocks in total, the single-rank shard size per rank
+    w = out2["weak_scaling"]
+    assert w["scaling"] == "weak" and w["value"] > 0 and w["config"]["local_m"] == out1["config"]["local_m"]
+    # same problem, same iteration count, same residuals (sums cross the ranks in a different order: rounding only, then the
+    # CG-chaos envelope of DESIGN.md 4 over a few hundred iterations)
+    ra, rb = out1["config"]["residuals_after_run"], out2["config"]["residuals_after_run"]
+    assert ra["iteration"] == rb["iteration"]
+    for k in ("p", "d", "g"):
+        assert rb[k] == pytest.approx(ra[k], rel=1e-4), k
+    assert out2["config"]["cg_iters_per_step"] == pytest.approx(out1["config"]["cg_iters_per_step"], abs=1.5)
