@@ -82,6 +82,8 @@ PROTOTYPES = {
     "fos_psd_stats": (C.c_int, [_h, _i32p, C.c_int64, _i64p]),
     "fos_sync": (C.c_int, [_h]),
     "fos_host_stacked_spmv": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, C.c_int32, C.c_int32, _i64p]),
+    "fos_host_stacked_spmv_mode": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, C.c_int32, _i64p]),
+    "fos_window_stats": (C.c_int, [_h, _i64p]),
     "fos_set_tuning": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32]),
 }
 

@@ -77,6 +77,7 @@ struct WinPanel { int32_t row0, nrows, seg0, nseg; };
 struct WinSeg { int32_t col0, ncols, slice0, nslice; };
 struct WinSlice { int64_t off; int32_t steps, pad; };       // values/columns at off + 64 t + lane (off a multiple of 64)
 
+
 struct BlkDesc {                    // one row block = the unit of work of ONE wavefront (32 bytes)
     int64_t nnz0;                   // first value in `val` (multiple of NNZ_ALIGN)
     int64_t colpos;                 // first entry in `col`: per-entry column indices, or -- for a RUN block, whose rows

@@ -333,6 +333,8 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
                 const int cslot = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 1]);
                 const int rslot = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 2]);
                 const int tc = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 3]);      // real columns (steps beyond: padding)
+                const int cstride = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 4]);  // slot numbering: a deferred row's list is
+                const int rstride = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 5]);  // contiguous, so a tile writes at a stride
                 const bool valid = lane < R;
                 const int row = d.row0 + lane;
                 RowPre pr{};
@@ -387,14 +389,14 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
                     const double s1 = tile_colsum8(p1, lane);
                     double s2 = 0.0;
                     if constexpr (NRHS == 2) s2 = tile_colsum8(p2, lane);
-                    if (lane < TILE_GROUP) {
-                        slots[cslot + t + lane] = make_double2(s1, s2);
+                    if (lane < TILE_GROUP && t + lane < tc) {
+                        slots[cslot + (t + lane) * cstride] = make_double2(s1, s2);
                         epi.park(c0 + t + lane, s1, s2, xl);
                     }
                 }
                 if (valid) {
                     if (rslot < 0) epi.row(row, r1, r2, pr);
-                    else { slots[rslot + lane] = make_double2(r1, r2); epi.park(row, r1, r2, wr); }
+                    else { slots[rslot + lane * rstride] = make_double2(r1, r2); epi.park(row, r1, r2, wr); }
                 }
             }
         } else if (kind == BLK_ELL) {
@@ -491,11 +493,76 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
 // runs once per row at the end, over consecutive rows (coalesced).
 constexpr size_t win_lds_bytes(int nrhs) { return (size_t)(WIN_COLS + WIN_ROWS) * 8 * nrhs + 64 * sizeof(double); }
 
+// What a wavefront holds of one 64-row slice while the window is being staged: the first WIN_PRE steps of its lane's values
+// and window offsets, requested BEFORE the barriers of the segment so that one memory latency covers the window and the matrix.
+constexpr int WIN_PRE = 8;
+struct WinSliceRegs {
+    double v[WIN_PRE];
+    unsigned c[WIN_PRE];
+    unsigned rid;          // local row of this lane, 0xFFFF: none
+    int T;                 // steps of the slice, wave-uniform (0: no slice)
+    int64_t off;
+};
+__device__ __forceinline__ void win_slice_desc(const DevBlkCsr& S, int sl, bool have, WinSliceRegs& r) {
+    // wave-uniform descriptor through the constant address space (scalar loads)
+    typedef const __attribute__((address_space(4))) WinSlice* cptr_slice;
+    r.T = 0; r.off = 0;
+    if (have) { const cptr_slice d = (cptr_slice)(S.wslice + sl); r.off = d->off; r.T = d->steps; }
+}
+// The value / offset loads depend only on the (scalar) slice descriptor, NOT on the per-lane row word (a second dependent
+// memory round trip per segment costs more than the padding it would avoid reading: per-lane-count predication measured
+// 210-260 us per C5 sweep).  Steps beyond a lane's count hold value 0 / offset 0.
+__device__ __forceinline__ void win_slice_issue(const DevBlkCsr& S, int sl, int lane, WinSliceRegs& r) {
+    r.rid = 0xFFFFu;
+#pragma unroll
+    for (int t = 0; t < WIN_PRE; ++t) { r.v[t] = 0.0; r.c[t] = 0u; }
+    if (r.T > 0) {
+        r.rid = S.wrow[(size_t)sl * 64 + lane];
+        const double* __restrict__ val = S.wval + r.off + lane;
+        const uint16_t* __restrict__ col = S.wcol + r.off + lane;
+#pragma unroll
+        for (int t = 0; t < WIN_PRE; ++t)
+            if (t < r.T) { r.v[t] = nt_load(val + 64 * t); r.c[t] = nt_load(col + 64 * t); }
+    }
+}
+template <int NRHS, class E>
+__device__ __forceinline__ void win_slice_compute(const DevBlkCsr& S, const WinSliceRegs& r, const E* __restrict__ win, E* __restrict__ acc, int lane) {
+    if (r.T <= 0) return;
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int t = 0; t < WIN_PRE; ++t) {                    // (steps beyond T hold value 0, offset 0)
+        const E x = win[r.c[t]];
+        if constexpr (NRHS == 2) { a1 += r.v[t] * x.x; a2 += r.v[t] * x.y; } else a1 += r.v[t] * x;
+    }
+    if (r.T > WIN_PRE) {                                   // a row with many entries inside one window: the rest is streamed here
+        const double* __restrict__ val = S.wval + r.off + lane;
+        const uint16_t* __restrict__ col = S.wcol + r.off + lane;
+        for (int t = WIN_PRE; t < r.T; ++t) {
+            const double v = nt_load(val + 64 * t);
+            const E x = win[nt_load(col + 64 * t)];
+            if constexpr (NRHS == 2) { a1 += v * x.x; a2 += v * x.y; } else a1 += v * x;
+        }
+    }
+    if (r.rid != 0xFFFFu) {
+        if constexpr (NRHS == 2) { const d2 o = acc[r.rid]; acc[r.rid] = make_double2(o.x + a1, o.y + a2); }
+        else acc[r.rid] += a1;
+    }
+}
+
+// One segment = one (panel, window) tile.  EVERYTHING the segment needs from memory -- the window's vector elements and the
+// first WIN_PRE steps of two slices per wavefront -- is requested before the first barrier, so a segment costs one memory
+// latency, two barriers and the LDS work.  What bounds the walk is the NUMBER of segments a CU runs one after the other
+// (nrows x ncols / (WIN_ROWS x WIN_COLS x CUs)) times the latency of one, which grows once a wavefront has more slices than it
+// holds in registers.  Measured per C5 sweep (MI355X): row blocks 155 us; 2048 x 4096 tiles 116 us (kept); 4096 x 4096 tiles
+// 160 us (3 slices per wavefront and segment); 2048 x 2048 tiles with a register-double-buffered software pipeline across
+// segments 136-145 us (twice the barriers; the overlap does not pay for them); per-lane-count predicated loads 210-260 us.
 template <class G, class Epi>
 __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& epi, double* lds) {
     constexpr int NRHS = G::NRHS;
     constexpr int NWAVES = WIN_THREADS / 64;
+    constexpr int WPT = WIN_COLS / WIN_THREADS;            // window elements per thread
     using E = typename std::conditional<NRHS == 2, d2, double>::type;
+    typedef const __attribute__((address_space(4))) WinSeg* cptr_seg;
     E* win = reinterpret_cast<E*>(lds);
     E* acc = win + WIN_COLS;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -505,40 +572,34 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
             if constexpr (NRHS == 2) acc[i] = make_double2(0.0, 0.0); else acc[i] = 0.0;
         }
         for (int sgi = wp.seg0; sgi < wp.seg0 + wp.nseg; ++sgi) {
-            const WinSeg sg = S.wseg[sgi];
+            const cptr_seg sgp = (cptr_seg)(S.wseg + sgi);
+            const int col0 = sgp->col0, ncols = sgp->ncols, slice0 = sgp->slice0, nslice = sgp->nslice;
+            // ---- everything this segment needs from memory is requested here, in one go
+            WinSliceRegs r0, r1;
+            win_slice_desc(S, slice0 + wv, wv < nslice, r0);
+            win_slice_desc(S, slice0 + wv + NWAVES, wv + NWAVES < nslice, r1);
+            d2 wreg[WPT];
+#pragma unroll
+            for (int q = 0; q < WPT; ++q) {
+                const int i = tid + q * WIN_THREADS;
+                wreg[q] = (i < ncols) ? gat.load(col0 + i) : make_double2(0.0, 0.0);
+            }
+            win_slice_issue(S, slice0 + wv, lane, r0);
+            win_slice_issue(S, slice0 + wv + NWAVES, lane, r1);
             __syncthreads();                               // the previous window's readers are done (first pass: acc is zeroed)
-            for (int i = tid; i < sg.ncols; i += WIN_THREADS) {
-                const d2 x = gat.load(sg.col0 + i);
-                if constexpr (NRHS == 2) win[i] = x; else win[i] = x.x;
+#pragma unroll
+            for (int q = 0; q < WPT; ++q) {
+                const int i = tid + q * WIN_THREADS;
+                if (i < ncols) { if constexpr (NRHS == 2) win[i] = wreg[q]; else win[i] = wreg[q].x; }
             }
             __syncthreads();
-            for (int sl = sg.slice0 + wv; sl < sg.slice0 + sg.nslice; sl += NWAVES) {
-                const int64_t off = S.wslice[sl].off;
-                const int T = S.wslice[sl].steps;
-                const unsigned rid = S.wrow[(size_t)sl * 64 + lane];
-                const double* __restrict__ val = S.wval + off + lane;
-                const uint16_t* __restrict__ col = S.wcol + off + lane;
-                double a1 = 0.0, a2 = 0.0;
-                int t = 0;
-                for (; t + 4 <= T; t += 4) {
-                    double v[4]; unsigned c[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { v[u] = nt_load(val + 64 * (t + u)); c[u] = nt_load(col + 64 * (t + u)); }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const E x = win[c[u]];
-                        if constexpr (NRHS == 2) { a1 += v[u] * x.x; a2 += v[u] * x.y; } else a1 += v[u] * x;
-                    }
-                }
-                for (; t < T; ++t) {
-                    const double v = nt_load(val + 64 * t);
-                    const E x = win[nt_load(col + 64 * t)];
-                    if constexpr (NRHS == 2) { a1 += v * x.x; a2 += v * x.y; } else a1 += v * x;
-                }
-                if (rid != 0xFFFFu) {
-                    if constexpr (NRHS == 2) { const d2 o = acc[rid]; acc[rid] = make_double2(o.x + a1, o.y + a2); }
-                    else acc[rid] += a1;
-                }
+            win_slice_compute<NRHS>(S, r0, win, acc, lane);
+            win_slice_compute<NRHS>(S, r1, win, acc, lane);
+            for (int sl = slice0 + wv + 2 * NWAVES; sl < slice0 + nslice; sl += NWAVES) {      // (more than 2 x 16 slices: never at WIN_ROWS = 2048)
+                WinSliceRegs r;
+                win_slice_desc(S, sl, true, r);
+                win_slice_issue(S, sl, lane, r);
+                win_slice_compute<NRHS>(S, r, win, acc, lane);
             }
         }
         __syncthreads();

@@ -107,6 +107,7 @@ struct fos_solver {
 
     // operator
     HostBlkCsr hostS;                          // kept only for re-partitioning (indices freed after upload)
+    int64_t win_stats[4] = {0, 0, 0, 0};       // window panels: panels, (panel, window) segments, 64-row slices, stored entries
     DevBlkCsr S{};
     std::vector<void*> owned;                  // every hipMalloc'd pointer
     double* cb = nullptr;
@@ -638,12 +639,13 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
     // ---- operator
     HostBlkCsr& hs = h->hostS;
     FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, h->nwg_target, &hs, cus * 28));
-    if (!getenv("FOS_SPMV_WG") && hs.nblk / SPMV_WAVES < h->nwg_target) {
+    const bool windowed = !hs.wpanel.empty();
+    if (!windowed && !getenv("FOS_SPMV_WG") && hs.nblk / SPMV_WAVES < h->nwg_target) {
         // small operators: one or two row blocks per wavefront is the latency floor; more workgroups only add partials
         h->nwg_target = std::max(cus, (hs.nblk + SPMV_WAVES - 1) / SPMV_WAVES);
         partition_workgroups(&hs, h->nwg_target);
     }
-    if (!getenv("FOS_SPMV_WG") && hs.ntiles > hs.nblk / 2 && hs.nblk / SPMV_WAVES >= h->nwg_target) {
+    if (!windowed && !getenv("FOS_SPMV_WG") && hs.ntiles > hs.nblk / 2 && hs.nblk / SPMV_WAVES >= h->nwg_target) {
         // tile-dominated operator: the blocks are equal work units, so give every wavefront the SAME whole number of them
         // (C4: 16896 tiles over 12288 wavefronts leaves 3/8 of them with twice the work: 77 us; 4224 workgroups: 71 us)
         const int64_t waves_target = (int64_t)h->nwg_target * SPMV_WAVES;
@@ -661,6 +663,31 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
         std::vector<int32_t> wv(std::max<size_t>(hs.wave_blk0.size(), (size_t)SPMV_WAVES * 16384 + 16), 0);
         std::copy(hs.wave_blk0.begin(), hs.wave_blk0.end(), wv.begin());
         FOS_TRY(dev_upload(h, &dwv, wv));
+    }
+    if (windowed) {
+        // window panels: persistent workgroups, one per CU (96 KB of LDS each), walking the panels (measured on C5: 116 us per
+        // sweep with 256 workgroups, 122 us with one workgroup per panel)
+        int nwg = std::min<int>((int)hs.wpanel.size(), cus);
+        if (const char* e = getenv("FOS_SPMV_WG")) nwg = std::max(1, std::min<int>(atoi(e), (int)hs.wpanel.size()));
+        if (nwg >= 8) nwg -= nwg % 8;
+        hs.nwg = nwg;
+    }
+    h->S.npanel = (int32_t)hs.wpanel.size();
+    h->S.wpanel = nullptr; h->S.wseg = nullptr; h->S.wslice = nullptr; h->S.wval = nullptr; h->S.wcol = nullptr; h->S.wrow = nullptr;
+    if (h->S.npanel > 0) {
+        WinPanel* dp; WinSeg* dsg; WinSlice* dsl; double* dwv2; uint16_t *dwc, *dwr;
+        FOS_TRY(dev_upload(h, &dp, hs.wpanel));
+        FOS_TRY(dev_upload(h, &dsg, hs.wseg));
+        FOS_TRY(dev_upload(h, &dsl, hs.wslice));
+        FOS_TRY(dev_upload(h, &dwv2, hs.wval));
+        FOS_TRY(dev_upload(h, &dwc, hs.wcol));
+        FOS_TRY(dev_upload(h, &dwr, hs.wrow));
+        h->S.wpanel = dp; h->S.wseg = dsg; h->S.wslice = dsl; h->S.wval = dwv2; h->S.wcol = dwc; h->S.wrow = dwr;
+        h->win_stats[0] = (int64_t)hs.wpanel.size(); h->win_stats[1] = (int64_t)hs.wseg.size(); h->win_stats[2] = (int64_t)hs.wslice.size();
+        h->win_stats[3] = (int64_t)hs.wval.size();
+        std::vector<double>().swap(hs.wval);
+        std::vector<uint16_t>().swap(hs.wcol);
+        std::vector<uint16_t>().swap(hs.wrow);
     }
     h->S.nrows = hs.nrows; h->S.nnz = hs.nnz; h->S.nnz_padded = hs.nnz_padded;
     h->S.val = dval; h->S.col = dcol; h->S.blk = dblk;
@@ -1206,6 +1233,12 @@ int fos_operator_stats(fos_handle h, int64_t* stats) {
     return FOS_OK;
 }
 
+int fos_window_stats(fos_handle h, int64_t* stats4) {
+    if (!h || !stats4) { set_error("NULL argument"); return FOS_EINVAL; }
+    for (int k = 0; k < 4; ++k) stats4[k] = h->win_stats[k];
+    return FOS_OK;
+}
+
 int fos_bench_kkt(fos_handle h, int32_t reps, double* total_ms) {
     if (!h || reps < 1) { set_error("bad argument"); return FOS_EINVAL; }
     FOS_HIP(hipSetDevice(h->device));
@@ -1325,6 +1358,22 @@ int fos_host_stacked_spmv(int64_t m, int64_t n, const int64_t* colptr, const int
     return FOS_OK;
 }
 
+int fos_host_stacked_spmv_mode(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                               const double* v, double* out, int32_t window_mode, int64_t* stats16) {
+    if (!colptr || !v || !out || m < 0 || n < 0) { set_error("bad argument"); return FOS_EINVAL; }
+    HostBlkCsr S;
+    FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, 1024, &S, 0, window_mode));
+    std::string why;
+    int rc = host_stacked_spmv(S, v, out, &why);
+    if (rc != FOS_OK) { set_error("operator format check failed: %s", why.c_str()); return rc; }
+    if (stats16) {
+        for (int k = 0; k < 16; ++k) stats16[k] = 0;
+        stats16[0] = S.nblk; stats16[5] = S.nnz_padded; stats16[6] = S.ncol_stored; stats16[8] = S.ntiles; stats16[9] = S.nslots;
+        stats16[12] = (int64_t)S.wpanel.size(); stats16[13] = (int64_t)S.wseg.size(); stats16[14] = (int64_t)S.wslice.size(); stats16[15] = (int64_t)S.wval.size();
+    }
+    return FOS_OK;
+}
+
 int fos_sync(fos_handle h) {
     if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
     FOS_HIP(hipSetDevice(h->device));
@@ -1337,7 +1386,11 @@ int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int3
     FOS_HIP(hipSetDevice(h->device));
     if (fuse_p >= 0) h->fuse_p = fuse_p != 0;
     if (cg_chunk > 0) h->cg_chunk = cg_chunk;
-    if (spmv_workgroups > 0) {
+    if (spmv_workgroups > 0 && h->S.npanel > 0) {
+        // window panels: the grid is a number of persistent workgroups walking the panels
+        h->S.nwg = std::max(1, std::min<int32_t>(std::min(spmv_workgroups, 16384), h->S.npanel));
+        h->S.npart = h->S.nwg; h->S.part_off = 0;
+    } else if (spmv_workgroups > 0) {
         if (spmv_workgroups > 16384) spmv_workgroups = 16384;
         FOS_HIP(hipStreamSynchronize(h->stream));
         partition_workgroups(&h->hostS, spmv_workgroups);

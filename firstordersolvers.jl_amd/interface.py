@@ -286,7 +286,11 @@ class HipHSDE:
         st = (C.c_int64 * 12)()
         _lib.check(self._lib.fos_operator_stats(self._h, st))
         keys = ("blocks", "ell", "lds", "long", "run", "vals", "cols", "waves", "tiles", "slots", "deferred", "tile_vals")
-        return dict(zip(keys, list(st)))
+        out = dict(zip(keys, list(st)))
+        ws = (C.c_int64 * 4)()
+        _lib.check(self._lib.fos_window_stats(self._h, ws))
+        out.update(zip(("win_panels", "win_segments", "win_slices", "win_vals"), list(ws)))
+        return out
 
     def sync(self):
         _lib.check(self._lib.fos_sync(self._h))

@@ -201,6 +201,10 @@ int fos_check(fos_handle h, const double* z, double eps, fos_check_result* res);
  * device -- what the sweep actually streams: 8 B per stored value, 4 B per stored column index, 32 B per block, 16 B per
  * partial-sum slot written and read again. */
 int fos_operator_stats(fos_handle h, int64_t* stats12);
+/* Window-panel storage (gather-bound random-sparse operators; csrc/fos_internal.hpp WinPanel): panels, (panel, window)
+ * segments, 64-row slices, stored entries (8 B value + 2 B window offset each; 2 B row id per slice lane).  All zero when the
+ * operator is held in row blocks / dual tiles (then fos_operator_stats describes it). */
+int fos_window_stats(fos_handle h, int64_t* stats4);
 int fos_profile(fos_handle h, int32_t enable);      /* 0: off; 1: every launch; N > 1: every N-th launch (sampling: an event
                                                         pair per launch costs ~5 % of a C4 step) */
 int fos_get_cg_total(fos_handle h, int64_t* total);  /* CG iterations run since fos_create (getcgiter summed) */
@@ -233,6 +237,10 @@ int fos_sync(fos_handle h);
  * matrix entries held in tiles.  Used by the CPU test-suite. */
 int fos_host_stacked_spmv(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
                           const double* v, double* out, int32_t spmv_workgroups, int32_t resident_waves, int64_t* stats);
+/* the same with the storage choice forced: window_mode 0 = row blocks / dual tiles, 1 = window panels (any size), -1 = as
+ * fos_create decides; stats16 (may be NULL) = the 12 statistics above followed by the 4 of fos_window_stats */
+int fos_host_stacked_spmv_mode(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                               const double* v, double* out, int32_t window_mode, int64_t* stats16);
 
 /* tuning knobs (0 keeps the default): workgroups of the SpMV grid, CG iterations enqueued per host poll;
  * fuse_p: -1 keeps the choice made at fos_create, 0 / 1 force the three- / two-launch CG iteration (see fos_bench_cg_chain) */

@@ -148,3 +148,64 @@ def test_random_structures(pkg, seed):
         assert np.allclose(out, ref, rtol=1e-12, atol=1e-12), (seed, st)
         assert st["ell"] + st["lds"] + st["long"] + st["tiles"] == st["blocks"]
         assert st["tile_vals"] <= A.nnz
+
+
+# ------------------------------------------------------------------------------------------------ window panels
+def _host_spmv_mode(pkg, A, v, mode):
+    import ctypes as C
+    lib = pkg.lib.load()
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    m, n = A.shape
+    colptr = (A.indptr.astype(np.int64) + 1)
+    rowval = (A.indices.astype(np.int64) + 1)
+    nz = np.ascontiguousarray(A.data, dtype=np.float64)
+    out = np.zeros(n + m)
+    stats = (C.c_int64 * 16)()
+    i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    pkg.lib.check(lib.fos_host_stacked_spmv_mode(m, n, i64(colptr), i64(rowval), pkg.lib.dptr(nz), pkg.lib.dptr(np.ascontiguousarray(v)),
+                                                 pkg.lib.dptr(out), mode, stats))
+    return out, list(stats)
+
+
+@pytest.mark.parametrize("shape,density,seed", [((300, 260), 0.05, 1), ((5000, 4100), 0.004, 2), ((9000, 200), 0.03, 3), ((70, 9000), 0.02, 4),
+                                                 ((4097, 4096), 0.002, 5), ((1, 1), 1.0, 6), ((3000, 2500), 0.0, 7)])
+def test_window_panels_host_emulation(pkg, shape, density, seed):
+    """Forced window-panel storage (fos_internal.hpp, WinPanel): the host walk of the panels / windows / slices -- the traversal
+    the kernel performs -- reproduces S v = [A'vy; A vx]; rows without entries, empty operators, windows cut at the end of the
+    vector, panels with fewer than 64 rows and rows longer than a window are all covered."""
+    rng = np.random.default_rng(seed)
+    m, n = shape
+    A = sp.random(m, n, density=density, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    if density > 0 and m > 100:                            # a few rows much longer than the rest, one dense column
+        A = A.tolil()
+        A[3, :] = rng.standard_normal(n) * (rng.random(n) < 0.5)
+        A[:, 1] = rng.standard_normal((m, 1))
+        A = A.tocsc()
+    v = rng.standard_normal(n + m)
+    out, st = _host_spmv_mode(pkg, A, v, 1)
+    ref = np.concatenate([A.T @ v[n:], A @ v[:n]])
+    assert np.allclose(out, ref, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(ref).max()))
+    assert st[12] == -(-(n + m) // 2048) and st[0] == 0            # panels of 2048 rows, no row blocks
+    assert st[15] >= 2 * A.nnz                                      # stored entries (padding included)
+    out0, st0 = _host_spmv_mode(pkg, A, v, 0)                       # the same operator in row blocks / tiles
+    assert np.allclose(out0, ref, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(ref).max())) and st0[12] == 0
+
+
+def test_window_panels_chosen_for_large_random_sparse_only(pkg):
+    """fos_create's choice (window_mode -1): a C5-like random-sparse operator with >= 64 panels goes to window panels with little
+    padding; a small one, a dense LP (dual tiles) and a banded (run-compressed) one keep their row-block formats."""
+    rng = np.random.default_rng(11)
+    m = n = 70000                                                   # 140 000 stacked rows = 69 panels
+    A = sp.random(m, n, density=20.0 / n, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    v = rng.standard_normal(n + m)
+    out, st = _host_spmv_mode(pkg, A, v, -1)
+    ref = np.concatenate([A.T @ v[n:], A @ v[:n]])
+    assert np.allclose(out, ref, rtol=1e-12, atol=1e-11)
+    assert st[12] == 69 and st[0] == 0
+    assert st[15] <= 1.25 * 2 * A.nnz, (st[15], 2 * A.nnz)          # SELL-sigma slices: padding well under the 40-50 % of panel-wide ELL
+    small = sp.random(3000, 2500, density=0.01, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    assert _host_spmv_mode(pkg, small, rng.standard_normal(5500), -1)[1][12] == 0
+    dense = sp.csc_matrix(rng.standard_normal((128, 96)))
+    st = _host_spmv_mode(pkg, dense, rng.standard_normal(224), -1)[1]
+    assert st[12] == 0 and st[8] > 0
