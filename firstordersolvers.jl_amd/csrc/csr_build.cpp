@@ -332,7 +332,7 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
                 tiles.push_back(t);
                 S.blk.push_back(d);
                 pos = d.nnz0 + d.cnt;
-                cpos = d.colpos + 6;                // first column, column-slot base, row-slot base, real columns, column-slot stride, row-slot stride
+                cpos = d.colpos + 4;                // first column, column-slot base, row-slot base, real columns
                 S.tile_values += (int64_t)g.R * tc;
             }
             r += g.R;
@@ -472,8 +472,6 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         S.col[d.colpos + 1] = t.cslot;
         S.col[d.colpos + 2] = t.rslot;
         S.col[d.colpos + 3] = (int32_t)std::min<int64_t>(tcmax, groups[t.group].C - (int64_t)t.chunk * tcmax);
-        S.col[d.colpos + 4] = 1;
-        S.col[d.colpos + 5] = 1;
     }
     auto place = [&](int64_t row, int64_t e) -> int64_t {        // offset of entry e of `row` relative to its block base
         const int64_t tpr = row_tpr[row];
@@ -537,43 +535,6 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             S.def_rows.push_back((int32_t)q);
             S.def_idx.insert(S.def_idx.end(), idx.begin() + lp[q], idx.begin() + lp[q + 1]);
             S.def_ptr.push_back((int32_t)S.def_idx.size());
-        }
-        // ---- renumber the slots so that every deferred row's list is CONTIGUOUS in memory: whoever adds a list (the CG update
-        // kernel, the deferred-row kernels) then reads consecutive 16-byte slots instead of one 128-byte line per slot; a tile
-        // writes its column sums at a stride instead (writes are not on anybody's critical path).  Possible when, per tile, the
-        // new numbers are affine in the column (dense blocks over a common column range: C4, C2); otherwise nothing changes.
-        if (!getenv("FOS_NO_SLOT_RENUMBER")) {
-            std::vector<int32_t> newid((size_t)S.nslots, -1);
-            int32_t next = 0;
-            for (int32_t sl : S.def_idx) newid[sl] = next++;
-            bool affine = true;
-            struct Aff { int32_t cb, cs, rb, rs; };
-            std::vector<Aff> aff(tiles.size());
-            for (size_t ti = 0; ti < tiles.size() && affine; ++ti) {
-                const TileRec& t = tiles[ti];
-                const Group& g = groups[t.group];
-                const int64_t tc = std::min<int64_t>(tcmax, g.C - (int64_t)t.chunk * tcmax);
-                Aff a{newid[t.cslot], 1, -1, 1};
-                if (tc > 1) a.cs = newid[t.cslot + 1] - a.cb;
-                for (int64_t c = 0; c < tc; ++c) if (newid[t.cslot + c] != a.cb + (int32_t)c * a.cs) affine = false;
-                if (t.rslot >= 0) {
-                    a.rb = newid[t.rslot];
-                    if (g.R > 1) a.rs = newid[t.rslot + 1] - a.rb;
-                    for (int q = 0; q < g.R; ++q) if (newid[t.rslot + q] != a.rb + q * a.rs) affine = false;
-                }
-                if (a.cs < 1 || a.rs < 1) affine = false;
-                aff[ti] = a;
-            }
-            if (affine) {
-                for (int32_t& sl : S.def_idx) sl = newid[sl];
-                for (int64_t j = 0; j < n; ++j) if (S.row_defer[j] >= 0) S.row_defer[j] = newid[S.row_defer[j]];
-                for (size_t ti = 0; ti < tiles.size(); ++ti) {
-                    const BlkDesc& d = S.blk[tiles[ti].blk];
-                    S.col[d.colpos + 1] = aff[ti].cb; S.col[d.colpos + 2] = aff[ti].rb;
-                    S.col[d.colpos + 4] = aff[ti].cs; S.col[d.colpos + 5] = aff[ti].rs;
-                }
-                S.nslots = next;                         // (the padded steps of a tile no longer own a slot: they are not written)
-            }
         }
     }
     partition_workgroups(&S, nwg_target);
@@ -647,9 +608,8 @@ int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::st
             const int T = d.steps();
             if (d.cnt != 64 * (int64_t)T || T % TILE_GROUP || R > 64) return fail("bad tile block", b);
             const int64_t c0 = S.col[d.colpos], cslot = S.col[d.colpos + 1], rslot = S.col[d.colpos + 2], tc = S.col[d.colpos + 3];
-            const int64_t cstride = S.col[d.colpos + 4], rstride = S.col[d.colpos + 5];
             if (c0 < 0 || tc < 1 || tc > T || T - tc >= TILE_GROUP || c0 + tc > S.nrows) return fail("tile columns out of range in block", b);
-            if (cstride < 1 || rstride < 1 || cslot < 0 || cslot + (tc - 1) * cstride >= S.nslots || (rslot >= 0 && rslot + (R - 1) * rstride >= S.nslots)) return fail("tile slots out of range in block", b);
+            if (cslot < 0 || cslot + T > S.nslots || (rslot >= 0 && rslot + R > S.nslots)) return fail("tile slots out of range in block", b);
             for (int t = 0; t < T; ++t) {                                        // column sums: over the lanes
                 double acc = 0.0;
                 for (int lane = 0; lane < 64; ++lane) {
@@ -657,14 +617,13 @@ int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::st
                     if (lane >= R || t >= tc) { if (a != 0.0) return fail("tile padding not zero in block", b); continue; }
                     acc += a * v[d.row0 + lane];
                 }
-                if (t >= tc) continue;                                           // padded steps own no slot
-                slots[cslot + t * cstride] = acc;
-                slot_written[cslot + t * cstride]++;
+                slots[cslot + t] = acc;
+                slot_written[cslot + t]++;
             }
             for (int lane = 0; lane < R; ++lane) {                                // row sums: over the steps
                 double acc = 0.0;
                 for (int t = 0; t < tc; ++t) acc += S.val[d.nnz0 + (int64_t)t * 64 + lane] * v[c0 + t];
-                if (rslot >= 0) { slots[rslot + lane * rstride] = acc; slot_written[rslot + lane * rstride]++; }
+                if (rslot >= 0) { slots[rslot + lane] = acc; slot_written[rslot + lane]++; }
                 else { out[d.row0 + lane] = acc; seen[d.row0 + lane]++; }
             }
         } else if (d.kind() == BLK_LONG) {

@@ -333,8 +333,6 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
                 const int cslot = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 1]);
                 const int rslot = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 2]);
                 const int tc = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 3]);      // real columns (steps beyond: padding)
-                const int cstride = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 4]);  // slot numbering: a deferred row's list is
-                const int rstride = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 5]);  // contiguous, so a tile writes at a stride
                 const bool valid = lane < R;
                 const int row = d.row0 + lane;
                 RowPre pr{};
@@ -389,14 +387,14 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
                     const double s1 = tile_colsum8(p1, lane);
                     double s2 = 0.0;
                     if constexpr (NRHS == 2) s2 = tile_colsum8(p2, lane);
-                    if (lane < TILE_GROUP && t + lane < tc) {
-                        slots[cslot + (t + lane) * cstride] = make_double2(s1, s2);
+                    if (lane < TILE_GROUP) {
+                        slots[cslot + t + lane] = make_double2(s1, s2);
                         epi.park(c0 + t + lane, s1, s2, xl);
                     }
                 }
                 if (valid) {
                     if (rslot < 0) epi.row(row, r1, r2, pr);
-                    else { slots[rslot + lane * rstride] = make_double2(r1, r2); epi.park(row, r1, r2, wr); }
+                    else { slots[rslot + lane] = make_double2(r1, r2); epi.park(row, r1, r2, wr); }
                 }
             }
         } else if (kind == BLK_ELL) {

@@ -754,6 +754,12 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
     FOS_TRY(dev_alloc(h, &h->plain, 2 * l));
     h->vec_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((h->l + 255) / 256, 1024));
     h->cg_blocks = std::min(h->vec_blocks, getenv("FOS_CG_BLOCKS") ? std::max(1, atoi(getenv("FOS_CG_BLOCKS"))) : 2 * cus);
+    // the x,r update kernel also adds the slot lists of the rows spread over dual tiles (`def_lpr` lanes per row): its grid must
+    // cover them in ONE pass even when the vectors are short (dense LP C2: 15 000 such rows x 16 lanes against l = 15 001 --
+    // sized by l alone the kernel took 105 us instead of 17)
+    if (h->S.ndef > 0)
+        h->cg_blocks = std::max<int>(h->cg_blocks, (int)std::min<int64_t>(1024, ((int64_t)h->S.ndef * h->S.def_lpr + 255) / 256));
+    h->cg_blocks = std::min(h->cg_blocks, 1024);         // (cg_close_iteration adds at most 1024 r.r records per wavefront)
 
     // ---- cones
     std::vector<uint8_t> ew(l, 0);
