@@ -250,7 +250,7 @@ struct CgIter {
 void launch_kkt2_cg(const LaunchCtx& c, const CgIter& it, double2* Ap);
 void launch_cg_stop_check(const LaunchCtx& c, const CgIter& it);      // closes iteration it.j - 1 when no sweep follows in this batch
 void launch_cg_update(const LaunchCtx& c, const CgIter& it, double2* x, double2* r, double2* Ap, int kkt_from_reduced);
-void launch_cg_pupdate(const LaunchCtx& c, const CgIter& it, double2* p_next);   // !fuse_p: closes iteration j, p_{j+1} = r + beta p_j
+void launch_cg_pupdate(const LaunchCtx& c, const CgIter& it, double2* x, double2* p_next);   // !fuse_p: x += alpha p_j, closes iteration j, p_{j+1} = r + beta p_j
 
 // single right-hand side Q apply on component `comp` of an interleaved vector
 //   Q_PLAIN : out_plain[i] = sign * (Q v)_i            (rows 0..n+m-1; tau row by q1_finalize)

@@ -334,7 +334,7 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
                 FOS_TRY(allreduce(h, 1));
             }
             // gather-bound operators: closing the iteration and p_{j+1} = r + beta p_j stay a launch of their own           :42-51
-            if (!h->fuse_p) launch_cg_pupdate(c, it, h->PB[(next_j + 1) & 1]);
+            if (!h->fuse_p) launch_cg_pupdate(c, it, x, h->PB[(next_j + 1) & 1]);
             prof_end(h, pe);
         }
         // the last update of the batch is closed by a one-workgroup launch (a following batch's sweep repeats it, same result)
@@ -1305,7 +1305,7 @@ int fos_bench_cg_chain(fos_handle h, int32_t iters, int32_t reps, int32_t use_gr
             it.fuse_p = h->fuse_p; it.rr_from_reduced = 0; it.fold = nullptr; it.seq_base = 0;
             launch_kkt2_cg(c, it, h->AP);
             launch_cg_update(c, it, h->W, h->R, h->AP, 0);
-            if (!h->fuse_p) launch_cg_pupdate(c, it, h->PB[(j + 1) & 1]);
+            if (!h->fuse_p) launch_cg_pupdate(c, it, h->W, h->PB[(j + 1) & 1]);
         }
     };
     hipEvent_t e0, e1;

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(FIN_THREADS) void cg_init_finalize_kernel(const dou
 // DEF (operators with dual tiles): rows of Ap whose sum the sweep left spread over partial slots are finished HERE -- `lpr`
 // lanes add a row's slot list in list order (as kkt2_deferred_kernel does for the stand-alone applies), run the row epilogue
 // of EpiKkt and update x, r of that row at once; their share of Ap.p is already in the sweep's sums (EpiKkt, FOLD).
-template <bool DEF, bool FOLD>
+// XUPD = false (the p update is a launch of its own): x += alpha p moves into that launch, which reads p anyway -- this kernel
+// then touches Ap, r (+ p, x only for the slot-spread rows): 48 instead of 96 bytes per element.
+template <bool DEF, bool FOLD, bool XUPD>
 __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* __restrict__ x, d2* __restrict__ r,
                                                                 const d2* __restrict__ p, d2* __restrict__ Ap,
                                                                 DevState* st, const double* __restrict__ kkt_partials, int nkkt,
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
     bool have0 = i0 < l;
     if constexpr (DEF) { if (have0 && ((def_mask[i0 >> 5] >> (i0 & 31)) & 1u)) have0 = false; }
     d2 p0 = make_double2(0.0, 0.0), a0 = p0, x0 = p0, r0 = p0;
-    if (have0) { p0 = p[i0]; a0 = Ap[i0]; x0 = x[i0]; r0 = r[i0]; }
+    if (have0) { a0 = Ap[i0]; r0 = r[i0]; if constexpr (XUPD) { p0 = p[i0]; x0 = x[i0]; } }
     if (st->done) return;
     if (FOLD && st->xchg_failed) return;
     __shared__ double sums[3];
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
             const bool own = ok && lig == 0;
             d2 pi = make_double2(0.0, 0.0), xi = pi, ri = pi;
             double c = 0.0;
-            if (own) { pi = p[row]; xi = x[row]; ri = r[row]; c = cb[row]; }
+            if (own) { pi = p[row]; ri = r[row]; c = cb[row]; if constexpr (XUPD) xi = x[row]; }
             double u1 = 0.0, u2 = 0.0;
             if (ok) {
                 const int k1 = S.def_ptr[q + 1];
@@ -133,9 +135,8 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
                 if (row < n) { q1 = u1 + pt.x * c; q2 = u2 + pt.y * c; }
                 else { q1 = -(u1 - pt.x * c); q2 = -(u2 - pt.y * c); }
                 const double a1 = pi.x - q2, a2 = q1 - pi.y;
-                xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+                if constexpr (XUPD) { xi.x += alpha * pi.x; xi.y += alpha * pi.y; x[row] = xi; }
                 ri.x -= alpha * a1; ri.y -= alpha * a2;
-                x[row] = xi;
                 r[row] = ri;
                 acc[0] += ri.x * ri.x + ri.y * ri.y;
             }
@@ -143,20 +144,22 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
     }
     if (have0) {
         if (i0 == l - 1) a0 = make_double2(at1, at2);
-        x0.x += alpha * p0.x; x0.y += alpha * p0.y;
+        if constexpr (XUPD) { x0.x += alpha * p0.x; x0.y += alpha * p0.y; x[i0] = x0; }
         r0.x -= alpha * a0.x; r0.y -= alpha * a0.y;
-        x[i0] = x0;
         r[i0] = r0;
         if (i0 != l - 1) acc[0] += r0.x * r0.x + r0.y * r0.y;
     }
     for (int64_t i = i0 + stride; i < l; i += stride) {
         if constexpr (DEF) { if ((def_mask[i >> 5] >> (i & 31)) & 1u) continue; }
-        const d2 pi = p[i];
         const d2 ai = (i == l - 1) ? make_double2(at1, at2) : Ap[i];
-        d2 xi = x[i], ri = r[i];
-        xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+        d2 ri = r[i];
+        if constexpr (XUPD) {
+            const d2 pi = p[i];
+            d2 xi = x[i];
+            xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+            x[i] = xi;
+        }
         ri.x -= alpha * ai.x; ri.y -= alpha * ai.y;
-        x[i] = xi;
         r[i] = ri;
         if (i != l - 1) acc[0] += ri.x * ri.x + ri.y * ri.y;
     }
@@ -167,42 +170,56 @@ void launch_cg_update(const LaunchCtx& c, const CgIter& it, double2* x, double2*
     double* rr_out = c.partials + 3 * (size_t)PART_CAP;
     const PeerBox pb = it.fold ? *it.fold : PeerBox{};
     dim3 grid(c.cg_blocks), block(VEC_THREADS);
-#define FOS_UPD(DEF, FOLD)                                                                                                   \
-    hipLaunchKernelGGL((cg_update_kernel<DEF, FOLD>), grid, block, 0, c.stream, c.l, x, r, (const d2*)it.p_cur, Ap, c.st, c.partials, \
+#define FOS_UPD(DEF, FOLD, XUPD)                                                                                             \
+    hipLaunchKernelGGL((cg_update_kernel<DEF, FOLD, XUPD>), grid, block, 0, c.stream, c.l, x, r, (const d2*)it.p_cur, Ap, c.st, c.partials, \
                        c.S.nwg, c.reduced, it.fold ? 0 : kkt_from_reduced, it.j, rr_out, c.S, c.cb, (int)c.n, c.def_mask, pb, it.seq_base)
-    if (c.S.ndef > 0) { if (it.fold) FOS_UPD(true, true); else FOS_UPD(true, false); }
-    else { if (it.fold) FOS_UPD(false, true); else FOS_UPD(false, false); }
+#define FOS_UPD2(DEF, FOLD) do { if (it.fuse_p) FOS_UPD(DEF, FOLD, true); else FOS_UPD(DEF, FOLD, false); } while (0)
+    if (c.S.ndef > 0) { if (it.fold) FOS_UPD2(true, true); else FOS_UPD2(true, false); }
+    else { if (it.fold) FOS_UPD2(false, true); else FOS_UPD2(false, false); }
+#undef FOS_UPD2
 #undef FOS_UPD
 }
 
 // Third launch of a CG iteration when the p update is NOT fused into the next sweep: closes iteration j (every workgroup,
 // same order: cg_close_iteration) and forms p_{j+1} = beta p_j + r.  A workgroup that starts after workgroup 0 has set `done`
 // simply exits: p is not needed once CG has stopped.                       conjugategradients.jl:42-51
+// It also carries x += alpha p_j (conjugategradients.jl:40) of the iteration it closes -- p_j is read here anyway -- and does so
+// whether or not CG stops at this iteration (alpha = DevState.alpha, stored by the update kernel before this launch).
 __global__ __launch_bounds__(VEC_THREADS) void cg_pupdate_kernel(int64_t l, d2* __restrict__ pnext, const d2* __restrict__ pcur,
-                                                                 const d2* __restrict__ r, DevState* st,
+                                                                 d2* __restrict__ x, const d2* __restrict__ r, DevState* st,
                                                                  const double* __restrict__ partials, int count,
                                                                  const double* __restrict__ reduced, int from_reduced, int j,
                                                                  PeerBox pb, uint32_t seq_base) {
     const int64_t stride = (int64_t)gridDim.x * VEC_THREADS;
     const int64_t i0 = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x;
-    d2 p0 = make_double2(0.0, 0.0), r0 = p0;
-    if (i0 < l) { p0 = pcur[i0]; r0 = r[i0]; }          // requested before the scalar prologue (latency)
+    d2 p0 = make_double2(0.0, 0.0), r0 = p0, x0 = p0;
+    if (i0 < l) { p0 = pcur[i0]; r0 = r[i0]; x0 = x[i0]; }     // requested before the scalar prologue (latency)
     if (st->done) return;
     if (pb.nranks > 0 && st->xchg_failed) return;
+    const double alpha = st->alpha;
     const CgClose cl = cg_close_iteration(st, partials, count, reduced, from_reduced, r, l, j, pb, seq_base);
-    if (!cl.ok || cl.stop) return;
+    if (!cl.ok) return;
     const double beta = cl.beta;
-    if (i0 < l) pnext[i0] = make_double2(p0.x * beta + r0.x, p0.y * beta + r0.y);
+    const bool go_on = !cl.stop;
+    if (i0 < l) {
+        x[i0] = make_double2(x0.x + alpha * p0.x, x0.y + alpha * p0.y);
+        if (go_on) pnext[i0] = make_double2(p0.x * beta + r0.x, p0.y * beta + r0.y);
+    }
     for (int64_t i = i0 + stride; i < l; i += stride) {
         d2 pi = pcur[i];
-        const d2 ri = r[i];
-        pi.x = pi.x * beta + ri.x;
-        pi.y = pi.y * beta + ri.y;
-        pnext[i] = pi;
+        d2 xi = x[i];
+        xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+        x[i] = xi;
+        if (go_on) {
+            const d2 ri = r[i];
+            pi.x = pi.x * beta + ri.x;
+            pi.y = pi.y * beta + ri.y;
+            pnext[i] = pi;
+        }
     }
 }
-void launch_cg_pupdate(const LaunchCtx& c, const CgIter& it, double2* p_next) {
-    hipLaunchKernelGGL(cg_pupdate_kernel, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p_next, (const d2*)it.p_cur, it.r, c.st,
+void launch_cg_pupdate(const LaunchCtx& c, const CgIter& it, double2* x, double2* p_next) {
+    hipLaunchKernelGGL(cg_pupdate_kernel, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p_next, (const d2*)it.p_cur, x, it.r, c.st,
                        c.partials + 3 * (size_t)PART_CAP, c.cg_blocks, c.reduced, it.rr_from_reduced, it.j,
                        it.fold ? *it.fold : PeerBox{}, it.seq_base);
 }
