@@ -63,7 +63,7 @@ for w in ("c4", "c2", "c3", "c5"):
                 fm, wm = sum(fe_r) / len(fe_r), sum(wr_r) / len(wr_r)
                 mb = (2 * fm + wm) * 1024 / 1e6
                 f.write("| %s | %d | %.1f | %.1f | %.2f |\n" % (k, len(fe_r), fm, wm, mb))
-                if k.startswith("kkt2_kernel") and len(fe_r) > 20:
+                if (k.startswith("kkt2_kernel") or k.startswith("kkt2_win_kernel")) and len(fe_r) > 20:
                     t = traffic.setdefault(w.upper(), {"traffic_bytes": 0.0, "kernels": {}, "source": "profiles/%s_pmc_%s.md" % (rnd, w)})
                     t["kernels"][k] = {"launches": len(fe_r), "fetch_kib": fm, "write_kib": wm, "bytes": mb * 1e6}
 for w, t in traffic.items():
