@@ -56,6 +56,8 @@ PROTOTYPES = {
     "fos_peer_enable": (C.c_int, [_h, C.c_int32]),
     "fos_set_alg": (C.c_int, [_h, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
     "fos_reset_affine": (C.c_int, [_h]),
+    "fos_enable_direct": (C.c_int, [_h, _i64p, _i64p, _dp]),
+    "fos_disable_direct": (C.c_int, [_h]),
     "fos_set_iterate": (C.c_int, [_h, _dp]),
     "fos_get_iterate": (C.c_int, [_h, _dp]),
     "fos_get_checked": (C.c_int, [_h, _dp]),

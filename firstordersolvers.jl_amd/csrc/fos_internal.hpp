@@ -275,6 +275,15 @@ void launch_fista_extrap(const LaunchCtx& c, double2* y, const double2* x, const
 void launch_add(const LaunchCtx& c, double2* out, const double2* a, const double2* b);                                // out = a + b
 void launch_dykstra_corr(const LaunchCtx& c, double2* p, const double2* x, const double2* y);                         // p = x + p - y
 
+// direct = true (HSDE.jl:12-15): dense set-up helpers and the per-projection kernels
+void launch_dense_q_fill(const LaunchCtx& c, const int64_t* colptr, const int64_t* rowval, const double* nzval, double* Q, int64_t ld);
+void launch_dense_gemm(const LaunchCtx& c, int L, double alpha, const double* A, const double* B, double gamma, const double* D, double* Cm);
+void launch_dense_resid(const LaunchCtx& c, int64_t L, const double* Y, double* partials, int nblocks);
+void launch_dense_scale_identity(const LaunchCtx& c, int64_t L, double* X, double s);
+void launch_dense_symv(const LaunchCtx& c, int64_t ld, const double* G, const double* t, double* w);
+void launch_direct_rhs(const LaunchCtx& c, const double2* W, const double2* x, double* t);
+void launch_direct_finish(const LaunchCtx& c, const double2* x, const double2* W, double2* out);
+
 // layout conversion at the ABI boundary
 void launch_interleave(const LaunchCtx& c, double2* out, const double* plain);    // plain [part1(l); part2(l)] -> interleaved
 void launch_deinterleave(const LaunchCtx& c, double* plain, const double2* in);

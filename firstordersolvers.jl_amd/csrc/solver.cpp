@@ -149,6 +149,13 @@ struct fos_solver {
     double alpha = 0.8, alpha1 = 1.8, alpha2 = 1.8, beta = 0.0;
     double fista_t = 1.0;
 
+    // direct = true (HSDE.jl:12-15): S1 = IndAffine([Q -I], 0), an exact projection through a one-time dense factorisation
+    bool direct = false;
+    double* Ginv = nullptr;                    // (I + Q Q')^-1, symmetric, column-major, leading dimension Gld (l padded to 64)
+    int64_t Gld = 0;
+    int direct_iters = 0;                      // Newton-Schulz iterations the set-up took
+    double* dvec[2] = {nullptr, nullptr};      // two plain l-vectors
+
     // S1 = AffinePlusLinear state (affinepluslinear.jl:58-69)
     int64_t prox_i = 1;
     bool firstrun = true;
@@ -360,8 +367,29 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     return FOS_OK;
 }
 
+// prox!(y, S1::IndAffine([Q -I], 0), x) with the result left in h->SOL        HSDE.jl:12-15 (direct = true)
+int prox_affine_direct(fos_solver* h, const d2* x) {
+    RoctxRange range("fos:prox_affine_direct (2 Q sweeps + dense symmetric matvec)");
+    LaunchCtx c = h->ctx();
+    int fr = 0;
+    // (scratch: the CG vectors R, AP -- the input may be X, Y or W)
+    launch_q1(c, Q_VFROMU, x, 0, 1.0, h->R);                           // R = (u, Q u)
+    FOS_TRY(finish_reduce(h, c, c.S.npart, 1, 0, &fr, c.S.part_off));
+    launch_q1_finalize(c, Q_VFROMU, x, 0, 1.0, h->R, fr);
+    launch_direct_rhs(c, h->R, x, h->dvec[0]);                         // t = Q u - v
+    launch_dense_symv(c, h->Gld, h->Ginv, h->dvec[0], h->dvec[1]);     // w = (I + Q Q')^-1 t
+    launch_set_comp(c, h->AP, h->dvec[1], 0);                          // (w, 0)
+    launch_q1(c, Q_VFROMU, h->AP, 0, 1.0, h->R);                       // R = (w, Q w)
+    FOS_TRY(finish_reduce(h, c, c.S.npart, 1, 0, &fr, c.S.part_off));
+    launch_q1_finalize(c, Q_VFROMU, h->AP, 0, 1.0, h->R, fr);
+    launch_direct_finish(c, x, h->R, h->SOL);                          // (u + Q w, v + w)
+    h->cgiter = 0;
+    return check_launch("direct affine projection");
+}
+
 // prox!(y, S1::AffinePlusLinear, x) with the result left in h->SOL       affinepluslinear.jl:83-126
 int prox_affine(fos_solver* h, const d2* x) {
+    if (h->direct) return prox_affine_direct(h, x);
     RoctxRange range("fos:prox_affine (rhs build + warm-started CG over the KKT operator)");
     LaunchCtx c = h->ctx();
     int fr = 0;
@@ -966,6 +994,106 @@ int fos_set_alg(fos_handle h, int alg, double alpha, double alpha1, double alpha
     FOS_HIP(hipMemsetAsync(h->Y, 0, sizeof(d2) * h->l, h->stream));
     FOS_HIP(hipMemsetAsync(h->XOLD, 0, sizeof(d2) * h->l, h->stream));
     FOS_HIP(hipStreamSynchronize(h->stream));
+    return FOS_OK;
+}
+
+// direct = true: build (I + Q Q')^-1 once.  A is handed over again (the handle keeps only its device format).
+// G = I + Q Q' = I - Q Q is symmetric positive definite with lambda_min >= 1; its inverse is formed by the Newton-Schulz iteration
+//     X_0 = I / (1.25 lambda~),   X_{k+1} = 2 X_k - X_k (G X_k),        lambda~ = a power-iteration estimate of lambda_max(G),
+// whose residual I - G X_k squares every step: ceil(log2 lambda~) + 7 steps reach rounding level (verified at the end: the
+// entries of G X - I).  Only matrix products are needed: the hand-written fp64 MFMA GEMM of vecops.hip.
+int fos_enable_direct(fos_handle h, const int64_t* colptr, const int64_t* rowval, const double* nzval) {
+    if (!h || !colptr || (!rowval && colptr[h->n] > 1)) { set_error("NULL argument"); return FOS_EINVAL; }
+    if (h->sharded()) { set_error("direct=true is a single-GPU mode"); return FOS_EUNSUPPORTED; }
+    if (h->Ginv) { h->direct = true; return FOS_OK; }
+    const int64_t l = h->l, nnz = colptr[h->n] - 1;
+    if (l > 46000) { set_error("direct=true holds dense %lld x %lld matrices: supported up to l = 46000", (long long)l, (long long)l); return FOS_EUNSUPPORTED; }
+    if (nnz != h->nnz) { set_error("fos_enable_direct: A has %lld non-zeros, the handle was created with %lld", (long long)nnz, (long long)h->nnz); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    LaunchCtx c = h->ctx();
+    const int64_t L = (l + 63) / 64 * 64;
+    const size_t L2 = (size_t)L * (size_t)L;
+    int64_t *dcp = nullptr, *drv = nullptr;
+    double *dnz = nullptr, *B0 = nullptr, *B1 = nullptr, *B2 = nullptr;       // B0: Q, later Y = G X;  B1, B2: X ping-pong
+    auto cleanup = [&]() { (void)hipFree(dcp); (void)hipFree(drv); (void)hipFree(dnz); (void)hipFree(B0); (void)hipFree(B1); (void)hipFree(B2); };
+    hipError_t e = hipMalloc((void**)&dcp, sizeof(int64_t) * (h->n + 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&drv, sizeof(int64_t) * std::max<int64_t>(nnz, 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&dnz, sizeof(double) * std::max<int64_t>(nnz, 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&B0, sizeof(double) * L2);
+    if (e == hipSuccess) e = hipMalloc((void**)&B1, sizeof(double) * L2);
+    if (e == hipSuccess) e = hipMalloc((void**)&B2, sizeof(double) * L2);
+    if (e != hipSuccess) { cleanup(); set_error("direct=true: hipMalloc of the dense set-up buffers (4 x %zu bytes) failed: %s", L2 * 8, hipGetErrorString(e)); return FOS_ENOMEM; }
+    double* G = nullptr;
+    int rc = dev_alloc(h, &G, L2);
+    if (rc == FOS_OK && !h->dvec[0]) rc = dev_alloc(h, &h->dvec[0], (size_t)L);
+    if (rc == FOS_OK && !h->dvec[1]) rc = dev_alloc(h, &h->dvec[1], (size_t)L);
+    if (rc != FOS_OK) { cleanup(); return rc; }
+    auto fail = [&](int code) { cleanup(); return code; };
+#define DIRECT_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("direct=true set-up: %s -> %s", #expr, hipGetErrorString(_e)); return fail(FOS_EHIP); } } while (0)
+    DIRECT_HIP(hipMemcpyAsync(dcp, colptr, sizeof(int64_t) * (h->n + 1), hipMemcpyHostToDevice, h->stream));
+    if (nnz) DIRECT_HIP(hipMemcpyAsync(drv, rowval, sizeof(int64_t) * nnz, hipMemcpyHostToDevice, h->stream));
+    if (nnz) DIRECT_HIP(hipMemcpyAsync(dnz, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
+    DIRECT_HIP(hipMemsetAsync(B0, 0, sizeof(double) * L2, h->stream));
+    DIRECT_HIP(hipMemsetAsync(B1, 0, sizeof(double) * L2, h->stream));
+    launch_dense_q_fill(c, dcp, drv, dnz, B0, L);                           // B0 = Q (zero padded to L x L)
+    launch_dense_scale_identity(c, L, B1, 1.0);                             // B1 = I
+    launch_dense_gemm(c, (int)L, -1.0, B0, B0, 1.0, B1, G);                 // G = I - Q Q  (padding rows/columns: identity)
+    // ---- power iteration for lambda_max(G) (Rayleigh quotients from below; host-side norms of an l-vector)
+    std::vector<double> v((size_t)L, 0.0), w((size_t)L, 0.0);
+    for (int64_t i = 0; i < l; ++i) v[i] = 1.0 + 0.37 * std::sin(1.7 * (double)i);
+    double lam = 1.0;
+    for (int it = 0; it < 20; ++it) {
+        double nv = 0.0;
+        for (int64_t i = 0; i < l; ++i) nv += v[i] * v[i];
+        nv = std::sqrt(nv);
+        for (int64_t i = 0; i < l; ++i) v[i] /= nv;
+        DIRECT_HIP(hipMemcpyAsync(h->dvec[0], v.data(), sizeof(double) * l, hipMemcpyHostToDevice, h->stream));
+        launch_dense_symv(c, L, G, h->dvec[0], h->dvec[1]);
+        DIRECT_HIP(hipMemcpyAsync(w.data(), h->dvec[1], sizeof(double) * l, hipMemcpyDeviceToHost, h->stream));
+        DIRECT_HIP(hipStreamSynchronize(h->stream));
+        double nw = 0.0;
+        for (int64_t i = 0; i < l; ++i) nw += w[i] * w[i];
+        nw = std::sqrt(nw);
+        if (!(nw == nw) || nw > 1e300) { set_error("direct=true: the operator has non-finite entries"); return fail(FOS_EINVAL); }
+        lam = std::max(lam, nw);
+        v.swap(w);
+    }
+    // ---- Newton-Schulz
+    const double x0 = 1.0 / (1.25 * lam);
+    launch_dense_scale_identity(c, L, B1, x0);                              // X_0 = x0 I  (B1 was I: only its diagonal is non-zero)
+    double *X = B1, *Xn = B2;
+    const int planned = (int)std::ceil(std::log2(std::max(1.0, lam))) + 7;
+    double resid = 1.0;
+    int it = 0;
+    std::vector<double> part(256);
+    for (; it < planned + 6; ++it) {
+        launch_dense_gemm(c, (int)L, 1.0, G, X, 0.0, nullptr, B0);          // Y = G X
+        if (it >= planned) {                                                // converged?  max |Y - I|
+            launch_dense_resid(c, L, B0, h->partials, 256);
+            DIRECT_HIP(hipMemcpyAsync(part.data(), h->partials, sizeof(double) * 256, hipMemcpyDeviceToHost, h->stream));
+            DIRECT_HIP(hipStreamSynchronize(h->stream));
+            resid = 0.0;
+            for (double r : part) resid = (r > resid || r != r) ? r : resid;
+            if (resid <= 1e-12) break;
+        }
+        launch_dense_gemm(c, (int)L, -1.0, X, B0, 2.0, X, Xn);              // X <- 2 X - X Y
+        std::swap(X, Xn);
+    }
+    if (!(resid <= 1e-12)) { set_error("direct=true: the inverse of I + Q Q' did not converge (max |G X - I| = %.3e after %d steps, lambda_max ~ %.3e)", resid, it, lam); return fail(FOS_EINVAL); }
+    DIRECT_HIP(hipMemcpyAsync(G, X, sizeof(double) * L2, hipMemcpyDeviceToDevice, h->stream));     // keep the inverse in the handle's buffer
+    DIRECT_HIP(hipStreamSynchronize(h->stream));
+#undef DIRECT_HIP
+    rc = check_launch("direct=true set-up");
+    cleanup();
+    if (rc != FOS_OK) return rc;
+    h->Ginv = G; h->Gld = L; h->direct_iters = it;
+    h->direct = true;
+    return FOS_OK;
+}
+
+int fos_disable_direct(fos_handle h) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    h->direct = false;
     return FOS_OK;
 }
 

@@ -352,6 +352,158 @@ void launch_dykstra_corr(const LaunchCtx& c, double2* p, const double2* x, const
     hipLaunchKernelGGL(dykstra_corr_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p, x, y);
 }
 
+// ------------------------------------------------------------------------------------------------ direct = true (HSDE.jl:12-15)
+// S1 = IndAffine([Q -I], 0): the exact projection of [u; v] onto {Q u = v},
+//     w = (I + Q Q')^-1 (Q u - v),   u+ = u - Q'w = u + Q w,   v+ = v + w        (Q' = -Q, HSDEAffine.jl:61-65)
+// with G^-1 = (I + Q Q')^-1 = (I - Q Q)^-1 formed ONCE as a dense matrix by the Newton-Schulz iteration X <- 2X - X (G X) on a
+// hand-written fp64 MFMA GEMM (quadratically convergent for the symmetric positive definite G, lambda_min(G) >= 1; needs only
+// matrix products -- the vendor's dense solver library alone takes minutes to load on a fresh box); per projection two Q sweeps,
+// one dense symmetric matrix-vector product (HBM bound: 8 l^2 bytes) and two elementwise passes.
+
+// dense Q (column-major, l x l) from the CSC of A: column j < n holds -A(:,j) in rows n.., -c_j in the last row; column n+i holds
+// A(i,:)' in rows 0..n-1 and -b_i in the last row; the last column is [c; b; 0]
+__global__ __launch_bounds__(VEC_THREADS) void dense_q_fill_kernel(int64_t m, int64_t n, const int64_t* __restrict__ colptr,
+                                                                   const int64_t* __restrict__ rowval, const double* __restrict__ nzval,
+                                                                   const double* __restrict__ cb, double* __restrict__ Q, int64_t ld) {
+    const int64_t l = ld, lm1 = n + m;              // leading dimension (l padded to a multiple of 64); index of the tau row
+    for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
+        for (int64_t k = colptr[j] - 1 + threadIdx.x; k < colptr[j + 1] - 1; k += VEC_THREADS) {
+            const int64_t i = rowval[k] - 1;
+            const double a = nzval[k];
+            Q[(n + i) + j * l] = -a;                 // -A
+            Q[j + (n + i) * l] = a;                  //  A'
+        }
+    }
+    for (int64_t q = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; q < n + m; q += (int64_t)gridDim.x * VEC_THREADS) {
+        Q[q + lm1 * l] = cb[q];                      // last column: [c; b]
+        Q[lm1 + q * l] = -cb[q];                     // last row: [-c', -b']
+    }
+}
+// w = G t for a symmetric column-major G: one wavefront per column (= row), 16-byte loads, fixed summation order
+__global__ __launch_bounds__(VEC_THREADS) void dense_symv_kernel(int64_t l, int64_t ld, const double* __restrict__ G, const double* __restrict__ t,
+                                                                 double* __restrict__ w) {
+    const int lane = threadIdx.x & 63;
+    const int64_t col = blockIdx.x * (int64_t)(VEC_THREADS / 64) + (threadIdx.x >> 6);
+    if (col >= l) return;
+    const double* __restrict__ g = G + col * ld;     // (ld is a multiple of 64: every column starts 16-byte aligned)
+    double acc = 0.0;
+    const int64_t i0 = 0;
+    const int64_t npair = (l - i0) / 2;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d* __restrict__ g2 = reinterpret_cast<const v2d*>(g + i0);
+    for (int64_t q = lane; q < npair; q += 64) {
+        const v2d a = __builtin_nontemporal_load(g2 + q);
+        acc += a.x * t[i0 + 2 * q] + a.y * t[i0 + 2 * q + 1];
+    }
+    if (lane == 0 && i0 + 2 * npair < l) acc += g[l - 1] * t[l - 1];
+    acc = wave_sum(acc);
+    if (lane == 0) w[col] = acc;
+}
+// t = (Q u) - v from W = (u, Q u) and x = (u, v)
+__global__ __launch_bounds__(VEC_THREADS) void direct_rhs_kernel(int64_t l, const d2* __restrict__ W, const d2* __restrict__ x, double* __restrict__ t) {
+    GRID_STRIDE(i, l) t[i] = W[i].y - x[i].y;
+}
+// out = (u + Q w, v + w) from x = (u, v) and W = (w, Q w)
+__global__ __launch_bounds__(VEC_THREADS) void direct_finish_kernel(int64_t l, const d2* __restrict__ x, const d2* __restrict__ W, d2* __restrict__ out) {
+    GRID_STRIDE(i, l) { const d2 xi = x[i], wi = W[i]; out[i] = make_double2(xi.x + wi.y, xi.y + wi.x); }
+}
+// C = alpha A B + gamma D  for dense column-major L x L matrices (L a multiple of 64) on v_mfma_f64_16x16x4_f64: one 64 x 64 tile
+// of C per workgroup, each of the 4 wavefronts a 32 x 32 quadrant (2 x 2 MFMA tiles), K in chunks of 16 staged through LDS.
+// Set-up code (the Newton-Schulz iteration below runs it ~30 times per handle), not a per-iteration kernel.
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(VEC_THREADS) void dense_gemm_kernel(int L, double alpha, const double* __restrict__ A, const double* __restrict__ B,
+                                                                 double gamma, const double* __restrict__ D, double* __restrict__ Cm) {
+    __shared__ double As[16][64 + 2];            // As[k][i]
+    __shared__ double Bs[16][64 + 2];            // Bs[k][j]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
+    const int lr = lane & 15, lk = lane >> 4;
+    v4d_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = v4d_t{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < L; k0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid & 63, kk = (tid >> 6) + 4 * q;
+            As[kk][i] = A[(size_t)(i0 + i) + (size_t)(k0 + kk) * L];
+            const int k = tid & 15, j = (tid >> 4) + 16 * q;
+            Bs[k][j] = B[(size_t)(k0 + k) + (size_t)(j0 + j) * L];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 4) {
+            double av[2], bv[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[a] = As[ks + lk][wr + 16 * a + lr];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bv[b] = Bs[ks + lk][wc + 16 * b + lr];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // result map of the f64 MFMA: column lane & 15, rows (lane >> 4) + 4 r
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t idx = (size_t)(i0 + wr + 16 * a + lk + 4 * r) + (size_t)(j0 + wc + 16 * b + lr) * L;
+                double v = alpha * acc[a][b][r];
+                if (gamma != 0.0) v += gamma * D[idx];
+                Cm[idx] = v;
+            }
+}
+// max |G X - I| over all entries (Y = G X given): one partial per workgroup
+__global__ __launch_bounds__(VEC_THREADS) void dense_resid_kernel(int64_t L, const double* __restrict__ Y, double* __restrict__ partials) {
+    double mx = 0.0;
+    for (int64_t e = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; e < L * L; e += (int64_t)gridDim.x * VEC_THREADS) {
+        const int64_t i = e % L, j = e / L;
+        const double d = fabs(Y[e] - (i == j ? 1.0 : 0.0));
+        mx = (d > mx || d != d) ? d : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(mx, off, 64); mx = (o > mx || o != o) ? o : mx; }
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = sm[0];
+        for (int w = 1; w < 4; ++w) m = (sm[w] > m || sm[w] != sm[w]) ? sm[w] : m;
+        partials[blockIdx.x] = m;
+    }
+}
+__global__ __launch_bounds__(VEC_THREADS) void dense_scale_identity_kernel(int64_t L, double* __restrict__ X, double s) {
+    for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < L; i += (int64_t)gridDim.x * VEC_THREADS) X[i + i * L] = s;
+}
+void launch_dense_gemm(const LaunchCtx& c, int L, double alpha, const double* A, const double* B, double gamma, const double* D, double* Cm) {
+    hipLaunchKernelGGL(dense_gemm_kernel, dim3(L / 64, L / 64), dim3(VEC_THREADS), 0, c.stream, L, alpha, A, B, gamma, D, Cm);
+}
+void launch_dense_resid(const LaunchCtx& c, int64_t L, const double* Y, double* partials, int nblocks) {
+    hipLaunchKernelGGL(dense_resid_kernel, dim3(nblocks), dim3(VEC_THREADS), 0, c.stream, L, Y, partials);
+}
+void launch_dense_scale_identity(const LaunchCtx& c, int64_t L, double* X, double s) {
+    hipLaunchKernelGGL(dense_scale_identity_kernel, dim3(64), dim3(VEC_THREADS), 0, c.stream, L, X, s);
+}
+
+void launch_dense_q_fill(const LaunchCtx& c, const int64_t* colptr, const int64_t* rowval, const double* nzval, double* Q, int64_t ld) {
+    hipLaunchKernelGGL(dense_q_fill_kernel, dim3(1024), dim3(VEC_THREADS), 0, c.stream, c.m, c.n, colptr, rowval, nzval, c.cb, Q, ld);
+}
+void launch_dense_symv(const LaunchCtx& c, int64_t ld, const double* G, const double* t, double* w) {
+    hipLaunchKernelGGL(dense_symv_kernel, dim3((unsigned)((c.l + 3) / 4)), dim3(VEC_THREADS), 0, c.stream, c.l, ld, G, t, w);
+}
+void launch_direct_rhs(const LaunchCtx& c, const double2* W, const double2* x, double* t) {
+    hipLaunchKernelGGL(direct_rhs_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, W, x, t);
+}
+void launch_direct_finish(const LaunchCtx& c, const double2* x, const double2* W, double2* out) {
+    hipLaunchKernelGGL(direct_finish_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, W, out);
+}
+
 // ------------------------------------------------------------------------------------------------ layout conversion
 
 __global__ __launch_bounds__(VEC_THREADS) void interleave_kernel(int64_t l, d2* __restrict__ out, const double* __restrict__ plain) {

@@ -295,6 +295,19 @@ class HipHSDE:
     def sync(self):
         _lib.check(self._lib.fos_sync(self._h))
 
+    def enable_direct(self, A):
+        """direct = true (HSDE.jl:12-15): exact affine projection through a one-time dense factorisation (fos_enable_direct)."""
+        A = sp.csc_matrix(A)
+        A.sort_indices()
+        colptr = (A.indptr.astype(np.int64) + 1)
+        rowval = (A.indices.astype(np.int64) + 1)
+        nz = np.ascontiguousarray(A.data, dtype=np.float64)
+        i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+        _lib.check(self._lib.fos_enable_direct(self._h, i64(colptr), i64(rowval), _lib.dptr(nz)))
+
+    def disable_direct(self):
+        _lib.check(self._lib.fos_disable_direct(self._h))
+
     def set_tuning(self, spmv_workgroups=0, cg_chunk=0, fuse_p=-1):
         """fuse_p: -1 keeps the library's choice, 0 / 1 force the three- / two-launch CG iteration."""
         _lib.check(self._lib.fos_set_tuning(self._h, spmv_workgroups, cg_chunk, fuse_p))
@@ -399,10 +412,13 @@ class HSDEStatus:
                 h.setdefault("x", []).append((i, z[0:n].copy()))
                 h.setdefault("y", []).append((i, z[n:n + m].copy()))
                 h.setdefault("s", []).append((i, z[nu + n:nu + n + m].copy()))
-        if self.verbose > 0:                                       # :43-51
+        if self.verbose > 0 and not self.direct:                   # :43-47
             h.setdefault("cgiter", []).append((i, int(res.cgiter)))
             self._println("%6d|% 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 4d % .1es" %
                           (i, res.p, res.d, res.g, res.ctx, -res.bty, res.kappa / res.tau, res.cgiter, t / 1e9))
+        elif self.verbose > 0:                                     # :48-50 (direct: no cg column, no :cgiter history)
+            self._println("%6d|% 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % .1es" %
+                          (i, res.p, res.d, res.g, res.ctx, -res.bty, res.kappa / res.tau, t / 1e9))
         if res.cg_maxiter_hit:
             import warnings
             warnings.warn("CG reached max iterations, result may be inaccurate")     # conjugategradients.jl:53
@@ -442,8 +458,6 @@ class FOSMathProgModel:
 
     # loadproblem!(model, c, A, b, constr_cones, var_cones)        FOSSolverInterface.jl:27-64
     def loadproblem(self, c, A, b, constr_cones, var_cones):
-        if self.alg.direct:
-            raise NotImplementedError("direct=true (sparse factorisation, HSDE.jl:12-15) is out of the HIP path's scope")
         t1 = time.perf_counter_ns()
         A = sp.csc_matrix(A)
         self.input_numconstr, self.input_numvar = A.shape
@@ -454,6 +468,8 @@ class FOSMathProgModel:
             self.data.close()
         self.data = HipHSDE(A, self.b, self.c, self.K1, self.K2, device=self.device)     # init_algorithm!  :58
         self.data.set_alg(self.alg)
+        if self.alg.direct:                                        # HSDE(model, direct=alg.direct)   HSDE.jl:12-15
+            self.data.enable_direct(A)
         self.init_duration = time.perf_counter_ns() - t1
         return self
 
@@ -496,6 +512,7 @@ class FOSMathProgModel:
         dev = self.data                                            # model.data persists across optimize! calls, as in the
         dev.set_iterate(opts.get("initx", None))                   # reference (alpha12 / t / y / S1 counters carry over); :10
         status = HSDEStatus(self, checki, eps, verbose, debug, out=self.out)
+        status.direct = bool(self.alg.direct)                      # HSDE.jl:27
         self.status_obj = status
         t1 = time.time()
         status.printstatusheader()

@@ -102,15 +102,19 @@ usegpu(model::FOSMathProgModel) = get(model.options, :gpu, false) === true
 for T in (:GAP, :GAPA, :FISTA, :Dykstra)
     @eval function init_algorithm!(alg::$T, model::FOSMathProgModel)
         if usegpu(model)
-            alg.direct && error("direct=true is not available on the HIP path")     # HSDE.jl:12-15 is CPU only
             # the reference's closure [HSDE.jl:24-27], built directly: get_sets_and_status would also construct the host-side
             # AffinePlusLinear (5 N-vectors of CG state) and DualConeProduct, which the device path never touches.
             # m, n as DualConeProduct's constructor takes them [cones.jl:121]
             sm, sn = model.K1.ranges[end][end], model.K2.ranges[end][end]
             status_generator = (mo, checki, eps, verbose, debug) ->
-                HSDEStatus(sm, sn, 0, mo, :Continue, checki, eps, verbose, false, false, time_ns(), model.init_duration, debug)
+                HSDEStatus(sm, sn, 0, mo, :Continue, checki, eps, verbose, false, alg.direct, time_ns(), model.init_duration, debug)
             data = HipData(model, get(model.options, :device, 0))
             set_alg!(data, alg)
+            if alg.direct            # HSDE.jl:12-15: S1 = IndAffine([Q -I], 0) -> exact projection, (I + Q Q')^-1 formed once on the device
+                A = model.A
+                GC.@preserve A check(ccall((:fos_enable_direct, libfoship), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}),
+                                           data.handle, A.colptr, A.rowval, A.nzval))
+            end
             return data, status_generator
         end
         return invoke(init_algorithm!, Tuple{$T,FirstOrderSolvers.AbstractFOSModel}, alg, model)
@@ -134,9 +138,11 @@ function record!(stat::HSDEStatus, data::HipData, r::CheckResult)
         end
         savedata(i, r.p, r.d, r.g, r.ctx, r.bty, r.kappa, r.tau, x, y, s, t, model, stat.debug)
     end
-    if stat.verbose > 0
+    if stat.verbose > 0 && !stat.direct                                        # HSDEStatus.jl:43-47
         push!(model.history, :cgiter, i, r.cgiter)
         printstatusiter(i, r.p, r.d, r.g, r.ctx, r.bty, r.kappa / r.tau, r.cgiter, t)
+    elseif stat.verbose > 0                                                    # :48-50
+        printstatusiter(i, r.p, r.d, r.g, r.ctx, r.bty, r.kappa / r.tau, t)
     end
     r.cg_maxiter_hit != 0 && @warn "CG reached max iterations, result may be inaccurate"   # conjugategradients.jl:53
     stat.status = STATUS_SYMBOLS[r.status+1]

@@ -142,6 +142,17 @@ int fos_peer_enable(fos_handle h, int32_t on);
 int fos_set_alg(fos_handle h, int alg, double alpha, double alpha1, double alpha2, double beta);
 int fos_reset_affine(fos_handle h);
 
+/* direct = true (the `direct` field of GAP/GAPA/FISTA/Dykstra; HSDE.jl:12-15): S1 becomes IndAffine([Q -I], 0), the EXACT
+ * projection onto {Q u = v} through a factorisation formed once, instead of AffinePlusLinear's warm-started CG.  The
+ * reference factorises the sparse [Q -I] on the CPU (ProximalOperators.IndAffine); here (I + Q Q')^-1 is formed once as a
+ * dense matrix on the device (Newton-Schulz iteration on a hand-written fp64 MFMA GEMM: l <= 46000, 8 l^2 bytes of HBM kept,
+ * four times that during set-up, ~(2 log2(lambda_max) + 14) l x l x l products) and a projection is two Q sweeps and one
+ * dense symmetric matrix-vector product.  A (the arrays fos_create was given) is passed
+ * again: the handle keeps only its device format.  No CG runs: fos_check_result.cgiter stays 0 and the host prints the table
+ * without the cg column (HSDEStatus.jl:44-50,79).  Single-GPU handles only.  fos_disable_direct returns to CG. */
+int fos_enable_direct(fos_handle h, const int64_t* colptr, const int64_t* rowval, const double* nzval);
+int fos_disable_direct(fos_handle h);
+
 /* getinitialvalue / option initx (solverwrapper.jl:10, HSDE.jl:40-47): z = 0, tau = kappa = 1 when z == NULL */
 int fos_set_iterate(fos_handle h, const double* z);
 int fos_get_iterate(fos_handle h, double* z);              /* the current x of `iterate` */

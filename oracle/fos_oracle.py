@@ -676,11 +676,37 @@ class Model:
         self.init_duration = 0
 
 
-def hsde_sets(model):
+class IndAffineDirect:
+    """IndAffine([sparse(Q) -I], zeros(l)) of HSDE.jl:12-15 (direct = true): the exact projection onto {[u; v]: Q u - v = 0}.
+    ProximalOperators factorises the sparse matrix (source not in the checkout); the projection itself is unique:
+        w = (I + Q Q')^-1 (Q u - v),  u+ = u - Q'w,  v+ = v + w.
+    Restated with a dense Cholesky factor (scipy) -- small problems only, as the reference's own direct tests are."""
+
+    def __init__(self, Q):
+        import scipy.linalg
+        self.A = Q
+        self.Qd = Q.todense()
+        self.l = self.Qd.shape[0]
+        self.chol = scipy.linalg.cho_factor(np.eye(self.l) + self.Qd @ self.Qd.T)
+
+    def prox(self, y, x):
+        import scipy.linalg
+        l = self.l
+        u, v = x[:l], x[l:]
+        w = scipy.linalg.cho_solve(self.chol, self.Qd @ u - v)
+        y[:l] = u - self.Qd.T @ w
+        y[l:] = v + w
+        return 0.0
+
+
+def hsde_sets(model, direct=False):
     """HSDE(model; direct=false)   HSDE.jl:7-29  ->  (S1, S2, N)."""
     Q = HSDEMatrixQ(model.A, model.b, model.c, space=model.space)           # :17
     l = Q.shape[0]
-    S1 = AffinePlusLinear(Q, np.zeros(l), np.zeros(l), 1, decreasing_accuracy=True)   # :22
+    if direct:
+        S1 = IndAffineDirect(Q)                                             # :12-15
+    else:
+        S1 = AffinePlusLinear(Q, np.zeros(l), np.zeros(l), 1, decreasing_accuracy=True)   # :22
     S2 = DualConeProduct(model.K1, model.K2)                                # :24
     return S1, S2, 2 * l                                                    # :28
 
@@ -818,8 +844,11 @@ class HSDEStatus:
                     h.setdefault("y", []).append((i, z[n:n + m].copy()))
                     h.setdefault("s", []).append((i, z[nu + n:nu + n + m].copy()))
             if self.verbose > 0:                           # :43-51
-                cgiter = self.S1.getcgiter() if self.S1 is not None else 0
-                model.history.setdefault("cgiter", []).append((i, cgiter))
+                if not self.direct:
+                    cgiter = self.S1.getcgiter() if self.S1 is not None else 0
+                    model.history.setdefault("cgiter", []).append((i, cgiter))
+                else:
+                    cgiter = None                          # :48-50: no cg column, no :cgiter history
                 self._println(format_status_iter(i, res["p"], res["d"], res["g"], res["ctx"], res["bty"],
                                                  res["kappa"] / res["tau"], cgiter, t))
             status = decide_status(res, self.eps)
@@ -842,10 +871,11 @@ class GAP:
 
     def __init__(self, alpha=0.8, alpha1=1.8, alpha2=1.8, **options):
         self.alpha, self.alpha1, self.alpha2 = alpha, alpha1, alpha2
+        self.direct = bool(options.pop("direct", False))    # the positional `direct` field of gap.jl:10
         self.options = options
 
     def init(self, model):                                  # gap.jl:23-28
-        self.S1, self.S2, n = hsde_sets(model)
+        self.S1, self.S2, n = hsde_sets(model, self.direct)
         self.tmp1 = np.empty(n)
         self.tmp2 = np.empty(n)
 
@@ -893,10 +923,11 @@ class GAPA:
 
     def __init__(self, alpha=1.0, beta=0.0, **options):
         self.alpha, self.beta = alpha, beta
+        self.direct = bool(options.pop("direct", False))
         self.options = options
 
     def init(self, model):                                  # gapa.jl:27-32
-        self.S1, self.S2, n = hsde_sets(model)
+        self.S1, self.S2, n = hsde_sets(model, self.direct)
         self.alpha12 = 2.0
         self.tmp1 = np.empty(n)
         self.tmp2 = np.empty(n)
@@ -908,7 +939,7 @@ class GAPA:
         self.S2.prox(self.tmp2, self.tmp1)                  # S2!  :72-78
         status.checkstatus(self.tmp2)
         self.tmp2[:] = a12 * self.tmp2 + (1 - a12) * self.tmp1
-        scl = normed_scalar(self.tmp2, self.tmp1, self.tmp1, x, getattr(self.S1.A, "space", LOCAL))     # :96
+        scl = normed_scalar(self.tmp2, self.tmp1, self.tmp1, x, getattr(getattr(self.S1, "A", None), "space", LOCAL))     # :96
         scl = 0.0 if math.isnan(scl) else min(max(scl, 0.0), 1.0)   # :96-97 (clamp then NaN -> 0)
         s = math.sqrt(1 - scl ** 2)                         # :98
         aopt = 2 / (1 + s)                                  # :100
@@ -926,10 +957,11 @@ class FISTA:
 
     def __init__(self, alpha=1.0, **options):
         self.alpha = alpha
+        self.direct = bool(options.pop("direct", False))
         self.options = options
 
     def init(self, model):                                  # fista.jl:20-25
-        self.S1, self.S2, n = hsde_sets(model)
+        self.S1, self.S2, n = hsde_sets(model, self.direct)
         self.t = 1.0
         self.y = np.zeros(n)
         self.xold = np.zeros(n)
@@ -958,10 +990,11 @@ class Dykstra:
     """Dykstra()   dykstra.jl:5-9."""
 
     def __init__(self, **options):
+        self.direct = bool(options.pop("direct", False))
         self.options = options
 
     def init(self, model):                                  # dykstra.jl:19-23
-        self.S1, self.S2, n = hsde_sets(model)
+        self.S1, self.S2, n = hsde_sets(model, self.direct)
         self.p = np.zeros(n)
         self.q = np.zeros(n)
         self.y = np.empty(n)
@@ -1021,6 +1054,7 @@ def solve(model, alg, out=None):
     x = opts["initx"] if "initx" in opts else hsde_initialvalue(model)
     model.history = {}                                       # optimize! :10
     status = HSDEStatus(model, checki, eps, verbose, debug, S1=alg.S1, out=out)
+    status.direct = bool(getattr(alg, "direct", False))      # HSDE.jl:27
     guess = iterate(alg, status, x, max_iters)
     xs, ys, ss, st = hsde_populatesolution(model, guess, status)
     sol = Solution(xs, ys, ss, st)

@@ -42,9 +42,7 @@ def test_constructor_signatures_mirror_reference(pkg):
     m = pkg.FOSMathProgModel(pkg.GAP(0.5, 2.0, 2.0, max_iters=2000))
     assert m.options == dict(max_iters=2000) and m.status() == "NotSolved"
     assert "SDP" in m.supportedcones()
-    with pytest.raises(NotImplementedError):
-        pkg.FOSMathProgModel(pkg.GAPA(direct=True)).loadproblem(np.zeros(1), sp.csc_matrix(np.eye(1)), np.zeros(1),
-                                                               [("Zero", 1)], [("Free", 1)])
+    assert pkg.GAPA(direct=True).direct is True and pkg.DR(0.5, direct=True).direct is True     # gap.jl:10 (device: tests/test_gpu_direct.py)
 
 
 def test_cone_normalisation(pkg):

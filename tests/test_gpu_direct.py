@@ -1,0 +1,95 @@
+"""
+direct = true on the HIP path (HSDE.jl:12-15, used by the reference's test/testDRandGAPA.jl:37-43 and
+test/testprint.jl:49-61): S1 = IndAffine([Q -I], 0) as an exact projection through (I + Q Q')^-1 formed once on the device.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import fos_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _omodel(prob):
+    codes = lambda cs: [(orc.CONE_CODES[k], l) for k, l in cs]
+    return orc.Model(prob.A, prob.b, prob.c, codes(prob.K1), codes(prob.K2))
+
+
+@pytest.mark.parametrize("which", ["small_mixed", "small_lp", "tile_lp"])
+def test_direct_projection_matches_oracle_and_is_exact(pkg, which):
+    """fos_prox_affine in direct mode vs the oracle's IndAffineDirect (1e-12), feasibility Q u = v and orthogonality of the
+    displacement to rounding; on a row-block operator, one with odd l, and one stored as dual tiles."""
+    prob = {"small_mixed": pkg.workloads.small_mixed, "small_lp": lambda: pkg.workloads.small_lp(seed=3, m=31, n=61),
+            "tile_lp": lambda: pkg.workloads.small_lp(seed=21, m=96, n=180)}[which]()
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d.enable_direct(prob.A)
+    S1 = orc.IndAffineDirect(orc.HSDEMatrixQ(prob.A, prob.b, prob.c))
+    rng = np.random.default_rng(9)
+    l = d.l
+    for scale in (1.0, 1e3):
+        x = scale * rng.standard_normal(d.N)
+        y = d.prox_affine(x)
+        ref = np.empty(d.N)
+        S1.prox(ref, x)
+        assert np.linalg.norm(y - ref) <= 1e-12 * np.linalg.norm(ref) * max(1.0, np.linalg.cond(np.eye(l) + S1.Qd @ S1.Qd.T) / 1e3)
+        assert np.linalg.norm(d.q_apply(y[:l]) - y[l:]) <= 1e-12 * np.linalg.norm(y)
+        u = rng.standard_normal(l)
+        t = np.concatenate([u, d.q_apply(u)])
+        assert abs((x - y) @ t) <= 1e-11 * np.linalg.norm(t) * np.linalg.norm(x)
+    # the CG path of the same handle gives the same projection (to its tolerance floor) once direct is switched off
+    d.disable_direct()
+    d.reset_affine()
+    x = rng.standard_normal(d.N)
+    ycg = None
+    for _ in range(400):                                  # advance the tolerance schedule to its floor
+        ycg = d.prox_affine(x)
+    ref = np.empty(d.N)
+    S1.prox(ref, x)
+    assert np.linalg.norm(ycg - ref) <= 1e-9 * np.linalg.norm(ref)
+    d.close()
+
+
+@pytest.mark.parametrize("algname", ["DR", "GAPA", "FISTA"])
+def test_direct_whole_solve_matches_oracle(pkg, algname):
+    """Whole solves with direct=true against the oracle's direct mode: there is no inexact CG in the loop, so the iterates do not
+    diverge chaotically -- same status, SAME iteration count, residuals and solution to 1e-9; printed table without the cg
+    column and history without :cgiter (HSDEStatus.jl:44-50,79; test/testprint.jl:16,56)."""
+    prob = pkg.workloads.small_mixed()
+    mk = {"DR": lambda M, **o: M.DR(**o), "GAPA": lambda M, **o: M.GAPA(0.8, 0.5, **o), "FISTA": lambda M, **o: M.FISTA(**o)}[algname]
+    opts = dict(eps=1e-6, verbose=1, max_iters=3000 if algname != "FISTA" else 300, checki=50, direct=True)
+    out = []
+    model = pkg.solve(prob, mk(pkg, **opts), out=out)
+    oout = []
+    sol = orc.solve(_omodel(prob), mk(orc, **opts), out=oout)
+    assert out[2] == " Iter | pri res | dua res | rel gap | pri obj | dua obj | kap/tau | time" == oout[2]
+    assert "cgiter" not in model.history
+    assert model.status() == sol.status and model.iterations == sol.iterations
+    last, olast = model.status_obj.last, sol.status_obj.last
+    for key in ("p", "d", "g"):
+        assert getattr(last, key) == pytest.approx(olast[key], rel=1e-6, abs=1e-12)
+    assert np.max(np.abs(model.getsolution() - sol.x)) <= 1e-9 * max(1.0, np.max(np.abs(sol.x)))
+    # rows of the table agree in every printed digit except the time column
+    rows = [ln for ln in out if ln[:6].strip().isdigit()]
+    orows = [ln for ln in oout if ln[:6].strip().isdigit()]
+    assert len(rows) == len(orows) and all(a.rsplit(" ", 1)[0] == b.rsplit(" ", 1)[0] for a, b in zip(rows[:3], orows[:3]))
+
+
+def test_direct_on_dense_lp_is_faster_than_cg_and_reaches_the_optimum(pkg):
+    """A 300 x 600 dense LP (dual tiles): direct=true and the CG path reach the same optimum; the direct iteration needs no CG."""
+    prob = pkg.workloads.c2_lp(m=300, n=600, scale=25.0)
+    opts = dict(eps=1e-6, verbose=0, max_iters=6000, checki=100)
+    md = pkg.solve(prob, pkg.DR(direct=True, **opts))
+    mi = pkg.solve(prob, pkg.DR(**opts))
+    assert md.status() == mi.status()
+    assert md.getobjval() == pytest.approx(mi.getobjval(), rel=1e-4, abs=1e-6)
+    assert md.getobjval() == pytest.approx(float(prob.c @ prob.x0), rel=1e-2, abs=1e-4)
+
+
+def test_direct_refuses_what_it_cannot_hold(pkg):
+    prob = pkg.workloads.c3_socp()                        # l = 70 001: a dense 39 GB matrix is past the stated limit
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    with pytest.raises(pkg.lib.FosError) as e:
+        d.enable_direct(prob.A)
+    assert "46000" in str(e.value)
+    d.close()

@@ -415,3 +415,56 @@ def test_exponential_cone_properties():
     assert np.array_equal(y, np.zeros(3))
     orc.prox_exp_primal(y, np.array([-1.0, -2.0, 3.0]))          # r < 0, s < 0: analytical
     assert np.array_equal(y, [-1.0, 0.0, 3.0])
+
+
+# ------------------------------------------------------------------------------------------------ direct = true
+def test_direct_affine_projection_is_the_exact_projection():
+    """HSDE.jl:12-15 (direct=true): S1 = IndAffine([Q -I], 0).  Its prox is the orthogonal projection onto {Q u = v}: the result
+    is feasible to rounding, the displacement is orthogonal to the subspace, and AffinePlusLinear's CG (the direct=false S1)
+    run to its floor reaches the same point -- the two S1 of the reference are the same operator (test/testDRandGAPA.jl:28-43
+    solves the same problem both ways)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(23)
+    m, n = 17, 11
+    A = sp.random(m, n, density=0.4, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    b, c = rng.standard_normal(m), rng.standard_normal(n)
+    Q = orc.HSDEMatrixQ(A, b, c)
+    l = n + m + 1
+    S1d = orc.IndAffineDirect(Q)
+    x = rng.standard_normal(2 * l)
+    y = np.empty(2 * l)
+    S1d.prox(y, x)
+    Qd = Q.todense()
+    assert np.linalg.norm(Qd @ y[:l] - y[l:]) < 1e-12 * np.linalg.norm(y)
+    # x - y is orthogonal to every [u; Q u]
+    for _ in range(5):
+        u = rng.standard_normal(l)
+        t = np.concatenate([u, Qd @ u])
+        assert abs((x - y) @ t) < 1e-11 * np.linalg.norm(t) * np.linalg.norm(x)
+    S1 = orc.AffinePlusLinear(Q, np.zeros(l), np.zeros(l), 1, decreasing_accuracy=False)
+    y2 = np.empty(2 * l)
+    S1.prox(y2, x)
+    assert np.linalg.norm(y2 - y) < 1e-9 * np.linalg.norm(y)
+
+
+def test_direct_solve_prints_without_cg_column_and_matches_indirect():
+    """test/testprint.jl:15-16,49-61 and testDRandGAPA.jl:28-43: with direct=true the header has no cg column, rows carry no cg
+    count, history has no :cgiter, and the solve reaches the same optimum as the CG path."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    m, n = 30, 20
+    A = sp.random(m, n, density=0.3, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    x0 = np.maximum(rng.standard_normal(n), 0.0)
+    r0 = np.where(x0 > 0, 0.0, rng.random(n))
+    y0 = rng.standard_normal(m)
+    b, c = A @ x0, r0 - A.T @ y0                    # equality-constrained LP: K1 = Zero, K2 = NonNeg
+    om = orc.Model(A, b, c, [(orc.CONE_CODES["Zero"], m)], [(orc.CONE_CODES["NonNeg"], n)])
+    out_d, out_i = [], []
+    sd = orc.solve(om, orc.GAPA(0.8, 0.9, direct=True, verbose=2, debug=1, eps=1e-8, checki=100, max_iters=20000), out=out_d)
+    si = orc.solve(om, orc.GAPA(0.8, 0.9, verbose=2, debug=1, eps=1e-8, checki=100, max_iters=20000), out=out_i)
+    assert out_d[2] == " Iter | pri res | dua res | rel gap | pri obj | dua obj | kap/tau | time"      # o12
+    assert out_i[2] == " Iter | pri res | dua res | rel gap | pri obj | dua obj | kap/tau | cg  | time"  # o11
+    assert out_d[4].startswith("   100|") and len(out_d[4].split()) == len(out_i[4].split()) - 1
+    assert sd.status == "Optimal" == si.status
+    assert sd.obj_val == pytest.approx(si.obj_val, abs=1e-6)
+    assert float(c @ sd.x) == pytest.approx(float(c @ x0), abs=1e-6)
