@@ -44,12 +44,15 @@ PROTOTYPES = {
     "fos_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "fos_create": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp,
                              C.c_int64, _i32p, _i64p, _i64p, C.c_int64, _i32p, _i64p, _i64p, C.c_int, C.POINTER(_h)]),
+    "fos_create2": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp,
+                              C.c_int64, _i32p, _i64p, _i64p, C.c_int64, _i32p, _i64p, _i64p, C.c_int, C.c_int32, C.POINTER(_h)]),
     "fos_destroy": (C.c_int, [_h]),
     "fos_sizes": (C.c_int, [_h, _i64p, _i64p, _i64p, _i64p]),
     "fos_get_cg_total": (C.c_int, [_h, _i64p]),
     "fos_operator_stats": (C.c_int, [_h, _i64p]),
     "fos_comm_get_unique_id": (C.c_int, [C.c_void_p]),
     "fos_comm_init": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
+    "fos_comm_init_host": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "fos_peer_export": (C.c_int, [_h, C.c_void_p]),
     "fos_peer_open": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p, C.c_double]),
     "fos_peer_selftest": (C.c_int, [_h, C.c_int, C.POINTER(C.c_int32)]),
@@ -109,6 +112,9 @@ def load(check_symbols=False):
         raise FosError(-101, "ABI version mismatch")
     _lib = lib
     return lib
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)     # fos_allreduce_fn
 
 
 def header_symbols():

@@ -165,7 +165,7 @@ static bool build_window_panels(int64_t m, int64_t n, const int64_t* colptr, con
 }
 
 int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
-                      int nwg_target, HostBlkCsr* out, int resident_waves, int window_mode) {
+                      int nwg_target, HostBlkCsr* out, int resident_waves, int window_mode, bool row_sharded) {
     if (m < 0 || n < 0) { set_error("negative dimension"); return FOS_EINVAL; }
     if (n + m + 1 > (int64_t)INT32_MAX / 2) { set_error("n+m too large for int32 column indices"); return FOS_EUNSUPPORTED; }
     if (colptr[0] != 1) { set_error("colptr must be 1-based (colptr[1] == 1)"); return FOS_EINVAL; }
@@ -177,7 +177,10 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
 
     const int64_t nrows = n + m;
     const bool compress = getenv("FOS_NO_INDEX_COMPRESSION") == nullptr;
-    const bool tiles_on = compress && getenv("FOS_NO_TILES") == nullptr;
+    // row-sharded operators (fos_internal.hpp): every row of A' is finished from ONE partial slot that is summed over the ranks
+    // first, so those rows use the deferred-row machinery; no dual tiles, no window panels
+    const bool tiles_on = compress && getenv("FOS_NO_TILES") == nullptr && !row_sharded;
+    if (row_sharded) window_mode = 0;
 
     // ---- rows of A: length, first column, and whether the columns are consecutive ("run": dense blocks, banded rows)
     std::vector<uint8_t> is_run(nrows, 1);
@@ -269,6 +272,17 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     S.nnz = 2 * nnz;
     std::vector<int32_t> ndef_slots;                        // per row: slots it will sum (0: not deferred)
     std::vector<uint8_t> skip(nrows, 0);                    // rows the ordinary row blocks do not contain
+    S.row_sharded = row_sharded;
+    if (row_sharded) {
+        S.row_defer.assign(nrows, -1);
+        ndef_slots.assign(nrows, 0);
+        for (int64_t j = 0; j < n; ++j) {
+            ndef_slots[j] = 1;                                   // its own partial, slot j (the all-reduce buffer is indexed by column)
+            if (rp[j + 1] == rp[j]) { S.row_defer[j] = -2; skip[j] = 1; }       // no local entries: the slot keeps its zero
+            else S.row_defer[j] = (int32_t)j;
+        }
+        S.nslots = n;
+    }
     if (have_tiles) {
         S.row_defer.assign(nrows, -1);
         ndef_slots.assign(nrows, 0);
@@ -509,6 +523,14 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             }
         }
     }
+    if (row_sharded) {
+        S.def_ptr.push_back(0);
+        for (int64_t j = 0; j < n; ++j) {
+            S.def_rows.push_back((int32_t)j);
+            S.def_idx.push_back((int32_t)j);
+            S.def_ptr.push_back((int32_t)S.def_idx.size());
+        }
+    }
     // ---- slot lists of the deferred rows: [own partial from the sweep] + tile partials in block order
     if (have_tiles) {
         for (int64_t j = 0; j < n; ++j)
@@ -681,7 +703,7 @@ int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::st
         for (int32_t k = S.def_ptr[q]; k < S.def_ptr[q + 1]; ++k) {
             const int32_t sl = S.def_idx[k];
             if (sl < 0 || sl >= S.nslots) return fail("slot out of range for row", row);
-            if (slot_written[sl] != 1) return fail("slot not written exactly once, row", row);
+            if (slot_written[sl] != 1 && !(S.row_sharded && S.row_defer[row] == -2 && slot_written[sl] == 0)) return fail("slot not written exactly once, row", row);
             acc += slots[sl];
         }
         out[row] = acc;

@@ -108,6 +108,7 @@ struct HostBlkCsr {
     std::vector<int32_t> def_rows;     // [ndef]   deferred rows, ascending
     std::vector<int32_t> def_ptr;      // [ndef+1] their slot lists
     std::vector<int32_t> def_idx;      // slot indices, in summation order
+    bool row_sharded = false;          // every row of A' is deferred with the single slot `row` (summed over the ranks before use)
     // window panels (empty unless the operator is stored that way; then blk is empty and val/col are unused)
     std::vector<WinPanel> wpanel;
     std::vector<WinSeg> wseg;
@@ -126,7 +127,8 @@ struct DevBlkCsr {
     const int32_t* wave_blk0;
     int32_t nblk, nwg, nwaves;
     // dual tiles / deferred rows (ndef == 0: none)
-    double* slots;                     // [nslots][2]
+    double* slots;                     // [nslots][2]   written by the sweeps
+    const double* slots_rd;            // what the slot-list sums read: == slots, or -- row-sharded operators -- the all-reduced copy
     const int32_t* row_defer;          // nullptr when ndef == 0
     const int32_t* def_rows;
     const int32_t* def_ptr;
@@ -148,7 +150,8 @@ struct DevBlkCsr {
 
 // Builds S = [[0, A'],[A, 0]] from Julia CSC (1-based).  Returns FOS_EINVAL on malformed input.
 int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
-                      int nwg_target, HostBlkCsr* out, int resident_waves = 0, int window_mode = -1);   // -1: decide from the operator, 0 / 1: force
+                      int nwg_target, HostBlkCsr* out, int resident_waves = 0, int window_mode = -1,   // -1: decide from the operator, 0 / 1: force
+                      bool row_sharded = false);
 void partition_workgroups(HostBlkCsr* S, int nwg_target);
 int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::string* why);
 constexpr int DEF_THREADS = 256;    // deferred-row kernel: one thread per deferred row
@@ -222,6 +225,13 @@ struct LaunchCtx {
     int32_t cg_blocks;     // grid of the two fused CG kernels (every workgroup re-reduces the partials: fewer, fatter groups)
     const PeerBox* peer;   // non-null: launch_reduce1 also exchanges the sums with the peer ranks (no RCCL call follows)
     const uint32_t* def_mask;   // bit i set: row i of S is finished from partial slots (nullptr: no dual tiles)
+    // row-sharded operators (rank g owns rows of A, the column space is replicated): the slots the sweep filled are
+    // summed over the ranks between the sweep and whatever adds the slot lists (`between`, called by the launchers); sums over
+    // replicated entries (indices < n_repl) are counted by ONE rank only (count_repl).
+    int (*between)(void*);
+    void* between_arg;
+    int32_t count_repl;         // 1: this rank counts the replicated entries in scalar sums (always 1 when not row-sharded)
+    int64_t n_repl;             // replicated leading entries of every vector (0 when not row-sharded)
 };
 
 // KKT apply, 2 RHS interleaved:  out = [I Q'; Q -I] * w   (rows 0..n+m-1; the tau row is written by kkt_finalize).

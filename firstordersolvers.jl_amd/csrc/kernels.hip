@@ -685,6 +685,7 @@ struct KktArgs {
     int j;                     // FUSEP: this iteration (>= 2)
     PeerBox pb;                // FUSEP: nranks > 0 -> the r.r exchange happens here (peer mailboxes)
     uint32_t seq_base;
+    int count_repl;            // FOLD: 0 = the slot-free part of the slot-spread rows is counted by another rank (row-sharded)
 };
 
 template <bool DEFER, bool FUSEP, bool FOLD>
@@ -710,7 +711,11 @@ __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBl
         if (blockIdx.x == 0 && threadIdx.x == 0) a.pnew[a.nm] = epi.wt;          // the tau element has no row in S
     }
     if constexpr (FOLD) {
-        for (int q = blockIdx.x * SPMV_THREADS + threadIdx.x; q < S.ndef; q += gridDim.x * SPMV_THREADS) epi.deferred_local(S.def_rows[q]);
+        if (a.count_repl) {
+            for (int q = blockIdx.x * SPMV_THREADS + threadIdx.x; q < S.ndef; q += gridDim.x * SPMV_THREADS) epi.deferred_local(S.def_rows[q]);
+        } else if constexpr (FUSEP) {            // (p_new of those rows must still be stored)
+            for (int q = blockIdx.x * SPMV_THREADS + threadIdx.x; q < S.ndef; q += gridDim.x * SPMV_THREADS) { const int i = S.def_rows[q]; a.pnew[i] = gat.load(i); }
+        }
     }
     spmv_walk<DEFER>(S, gat, epi, prod);
     block_reduce_store<3, SPMV_THREADS>(epi.acc, red, a.partials + 3 * (int64_t)blockIdx.x);
@@ -746,7 +751,7 @@ static void launch_kkt2_win(const LaunchCtx& c, const KktArgs& a) {
 // a CG iteration cg_update_kernel does the same sums itself.
 template <class Epi>
 __device__ __forceinline__ void deferred_rows(const DevBlkCsr& S, Epi& epi) {
-    const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots);
+    const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots_rd);
     const int lpr = S.def_lpr, sh = 31 - __clz(lpr);
     const int rows_per_pass = (gridDim.x * DEF_THREADS) >> sh;
     const int lig = threadIdx.x & (lpr - 1);
@@ -782,13 +787,14 @@ __device__ __forceinline__ void fold_sweep_records(const DevBlkCsr& S, const dou
 }
 __global__ __launch_bounds__(DEF_THREADS) void kkt2_deferred_kernel(DevBlkCsr S, const d2* __restrict__ w, d2* __restrict__ out,
                                                                     const double* __restrict__ cb, int n, int nm,
-                                                                    double* __restrict__ partials, const DevState* st, int gate) {
+                                                                    double* __restrict__ partials, const DevState* st, int gate, int count) {
     if (gate && st->done) return;
     __shared__ double red[16];
     EpiKkt<GatherW, false> epi;
     epi.gat.w = w; epi.out = out; epi.pnew = nullptr; epi.cb = cb; epi.n = n; epi.wt = w[nm];
     epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
     deferred_rows(S, epi);
+    if (!count) epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;      // row-sharded: these rows are replicated, another rank counts them
     fold_sweep_records<3>(S, partials, epi.acc);
     block_reduce_store<3, DEF_THREADS>(epi.acc, red, partials + 3 * (int64_t)(S.nwg + blockIdx.x));
 }
@@ -886,6 +892,7 @@ __global__ __launch_bounds__(SPMV_THREADS) void cg_stop_check_kernel(KktArgs a) 
 static KktArgs plain_args(const LaunchCtx& c, const double2* w, double2* out, int gate) {
     KktArgs a{};
     a.w = w; a.out = out; a.cb = c.cb; a.n = (int)c.n; a.nm = (int)(c.n + c.m); a.partials = c.partials; a.st = c.st; a.gate = gate;
+    a.count_repl = c.count_repl;
     return a;
 }
 // stand-alone apply: sweep (+ deferred-row kernel when the operator has dual tiles); leaves c.S.npart records at c.S.part_off
@@ -894,8 +901,9 @@ void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
     if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
     if (c.S.ndef > 0) {
         hipLaunchKernelGGL((kkt2_kernel<true, false, false>), dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, a);
+        if (c.between) (void)c.between(c.between_arg);        // row-sharded: the slots are summed over the ranks here
         hipLaunchKernelGGL(kkt2_deferred_kernel, dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, w, out, c.cb, (int)c.n,
-                           (int)(c.n + c.m), c.partials, c.st, gate);
+                           (int)(c.n + c.m), c.partials, c.st, gate, (int)c.count_repl);
     } else {
         hipLaunchKernelGGL((kkt2_kernel<false, false, false>), dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, a);
     }
@@ -1023,12 +1031,16 @@ __global__ __launch_bounds__(SPMV_THREADS) void q1_kernel(DevBlkCsr S, const dou
 }
 template <class Epi, int NACC>
 __global__ __launch_bounds__(DEF_THREADS) void q1_deferred_kernel(DevBlkCsr S, const double* __restrict__ vcomp, Epi epi, int nm,
-                                                                  double* __restrict__ partials) {
+                                                                  double* __restrict__ partials, int count) {
     __shared__ double red[8 * NACC > 16 ? 8 * NACC : 16];
 #pragma unroll
     for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
     epi.init(vcomp[2 * (int64_t)nm]);
     deferred_rows(S, epi);
+    if (!count) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
+    }
     fold_sweep_records<NACC>(S, partials, epi.acc);
     block_reduce_store<NACC, DEF_THREADS>(epi.acc, red, partials + NACC * (int64_t)(S.nwg + blockIdx.x));
 }
@@ -1054,7 +1066,8 @@ static void launch_q1_kernels(const LaunchCtx& c, const double* vcomp, const Epi
     }
     if (c.S.ndef > 0) {
         hipLaunchKernelGGL((q1_kernel<Epi, NACC, true>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
-        hipLaunchKernelGGL((q1_deferred_kernel<Epi, NACC>), dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, vcomp, e, nm, c.partials);
+        if (c.between) (void)c.between(c.between_arg);
+        hipLaunchKernelGGL((q1_deferred_kernel<Epi, NACC>), dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, vcomp, e, nm, c.partials, (int)c.count_repl);
     } else {
         hipLaunchKernelGGL((q1_kernel<Epi, NACC, false>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
     }

@@ -173,7 +173,15 @@ struct fos_solver {
     PeerBox peer{};
     bool peer_on = false;
     uint32_t cg_epoch = 0;                     // CG solves so far: the sequence space of the folded exchanges
-    bool sharded() const { return comm != nullptr || peer_on; }
+    // ... or through the caller's own collective on host buffers (fos_comm_init_host: MPI.jl, gloo, ...)
+    fos_allreduce_fn host_fn = nullptr;
+    void* host_user = nullptr;
+    double* host_buf = nullptr;                // pinned, max(2n, 16) doubles
+    bool sharded() const { return comm != nullptr || peer_on || host_fn != nullptr; }
+    // row sharding of a non-block-diagonal A: the first n entries (and tau, kappa) of every vector are replicated,
+    // the slots of the rows of A' are summed over the ranks (RCCL all-reduce of 2n doubles) between a sweep and its slot-list sums
+    bool row_sharded = false;
+    double* slots_rd = nullptr;
 
     // tuning / measurement
     int cg_chunk = 8;
@@ -187,15 +195,40 @@ struct fos_solver {
     int64_t prof_seen[FOS_PROF_CLASSES] = {0, 0, 0};
     static constexpr size_t PROF_CAP = 16384;
 
+    static int sum_slots_over_ranks(void* self);      // defined below (needs the RCCL table)
+
     LaunchCtx ctx() const {
         LaunchCtx c;
         c.stream = stream; c.S = S; c.cb = cb; c.n = n; c.m = m; c.l = l; c.st = st;
         c.partials = partials; c.reduced = reduced; c.vec_blocks = vec_blocks; c.cg_blocks = cg_blocks;
         c.peer = peer_on ? &peer : nullptr;
         c.def_mask = def_mask;
+        c.between = nullptr; c.between_arg = nullptr;
+        c.count_repl = (!row_sharded || rank == 0) ? 1 : 0;
+        c.n_repl = row_sharded ? n : 0;
+        if (row_sharded) { c.between = &fos_solver::sum_slots_over_ranks; c.between_arg = const_cast<fos_solver*>(this); }
         return c;
     }
 };
+
+// row-sharded operators: slots (this rank's partial sums of A'y, 2n doubles) -> slots_rd (their sum over the ranks), in stream
+// the caller's collective: stage `count` doubles through the pinned host buffer (synchronises the stream; a slow path by design)
+static int host_allreduce(fos_solver* h, const double* src, double* dst, size_t count) {
+    if (hipMemcpyAsync(h->host_buf, src, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return FOS_EHIP;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return FOS_EHIP;
+    if (h->host_fn(h->host_user, h->host_buf, (int64_t)count) != 0) { set_error("the caller's all-reduce callback failed"); return FOS_ECOMM; }
+    if (hipMemcpyAsync(dst, h->host_buf, sizeof(double) * count, hipMemcpyHostToDevice, h->stream) != hipSuccess) return FOS_EHIP;
+    return hipStreamSynchronize(h->stream) == hipSuccess ? FOS_OK : FOS_EHIP;          // the buffer is reused by the next call
+}
+
+int fos_solver::sum_slots_over_ranks(void* self) {
+    fos_solver* h = static_cast<fos_solver*>(self);
+    if (h->host_fn) return host_allreduce(h, h->S.slots, h->slots_rd, (size_t)2 * (size_t)h->n);
+    if (!h->comm) {            // no communicator yet (set-up calls before fos_comm_init, or a single process): the sum is the copy
+        return hipMemcpyAsync(h->slots_rd, h->S.slots, sizeof(double) * 2 * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream) == hipSuccess ? FOS_OK : FOS_EHIP;
+    }
+    return g_rccl.AllReduce(h->S.slots, h->slots_rd, (size_t)2 * (size_t)h->n, ncclDouble, ncclSum, h->comm, h->stream) == ncclSuccess ? FOS_OK : FOS_ECOMM;
+}
 
 namespace {
 
@@ -225,7 +258,9 @@ int psd_order(int64_t len) {
 
 // all-reduce of `count` doubles in h->reduced (in place, in stream) when sharded
 int allreduce(fos_solver* h, int count) {
-    if (h->peer_on || !h->comm) return FOS_OK;                 // peer mailboxes: launch_reduce1 already exchanged
+    if (h->peer_on) return FOS_OK;                             // peer mailboxes: launch_reduce1 already exchanged
+    if (h->host_fn) return host_allreduce(h, h->reduced, h->reduced, (size_t)count);
+    if (!h->comm) return FOS_OK;
     FOS_NCCL(g_rccl.AllReduce(h->reduced, h->reduced, (size_t)count, ncclDouble, ncclSum, h->comm, h->stream));
     return FOS_OK;
 }
@@ -279,7 +314,8 @@ int poll_state(fos_solver* h) {
 // sharded set-up: global problem size and norms (tolerance floor, status normalisation) from the shards'
 int global_setup(fos_solver* h) {
     LaunchCtx c = h->ctx();
-    double loc[3] = {(double)(h->n + h->m), h->nb_local * h->nb_local, h->nc_local * h->nc_local};
+    const bool cnt = !h->row_sharded || h->rank == 0;     // row-sharded: the n columns and c are replicated, counted by rank 0
+    double loc[3] = {(double)(h->m + (cnt ? h->n : 0)), h->nb_local * h->nb_local, cnt ? h->nc_local * h->nc_local : 0.0};
     FOS_HIP(hipMemcpyAsync(h->partials, loc, sizeof(loc), hipMemcpyHostToDevice, h->stream));
     launch_reduce1(c, 1, 3, 0);
     FOS_TRY(allreduce(h, 3));
@@ -330,9 +366,10 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
             launch_kkt2_cg(c, it, h->AP);
             prof_end(h, pe);
             int f1 = 0;
+            if (c.between) FOS_TRY(c.between(c.between_arg));         // row-sharded: A'y partial sums over the ranks (n-vector)
             if (rccl) { launch_reduce1(c, c.S.nwg, 3, 1, 0); FOS_TRY(allreduce(h, 3)); f1 = 1; }
             // launch 2: alpha, tau rows, slot-spread rows, x += alpha p, r -= alpha Ap, r.r partials                       :39-41
-            pe = prof_begin(h, FOS_PROF_CGVEC, next_j, h->cg_total + next_j - 1);
+            pe = prof_begin(h, FOS_PROF_CGVEC, next_j, (h->cg_total + next_j - 1) % 4 == 1 ? (h->cg_total + next_j - 1) / 4 : 1);   // a quarter of the sweeps' rate, other iterations
             launch_cg_update(c, it, x, h->R, h->AP, f1);
             if (rccl) {
                 LaunchCtx c2 = c;
@@ -638,6 +675,14 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
                int64_t nK1, const int32_t* K1type, const int64_t* K1start, const int64_t* K1len,
                int64_t nK2, const int32_t* K2type, const int64_t* K2start, const int64_t* K2len,
                int device, fos_handle* out) {
+    return fos_create2(m, n, colptr, rowval, nzval, b, c, nK1, K1type, K1start, K1len, nK2, K2type, K2start, K2len, device, 0, out);
+}
+
+int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                const double* b, const double* c,
+                int64_t nK1, const int32_t* K1type, const int64_t* K1start, const int64_t* K1len,
+                int64_t nK2, const int32_t* K2type, const int64_t* K2start, const int64_t* K2len,
+                int device, int32_t flags, fos_handle* out) {
     if (!out) { set_error("out handle is NULL"); return FOS_EINVAL; }
     *out = nullptr;
     if (m < 0 || n < 0 || !colptr || (!rowval && colptr[n] > 1) || (!b && m) || (!c && n)) { set_error("NULL or negative argument"); return FOS_EINVAL; }
@@ -666,7 +711,8 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
 
     // ---- operator
     HostBlkCsr& hs = h->hostS;
-    FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, h->nwg_target, &hs, cus * 28));
+    h->row_sharded = (flags & FOS_CREATE_ROW_SHARDED) != 0;
+    FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, h->nwg_target, &hs, cus * 28, -1, h->row_sharded));
     const bool windowed = !hs.wpanel.empty();
     if (!windowed && !getenv("FOS_SPMV_WG") && hs.nblk / SPMV_WAVES < h->nwg_target) {
         // small operators: one or two row blocks per wavefront is the latency floor; more workgroups only add partials
@@ -721,7 +767,7 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
     h->S.val = dval; h->S.col = dcol; h->S.blk = dblk;
     h->S.row_rel = drr; h->S.wave_blk0 = dwv; h->S.nblk = hs.nblk; h->S.nwg = hs.nwg; h->S.nwaves = hs.nwaves;
     // dual tiles: partial-sum slots and the deferred rows' slot lists
-    h->S.slots = nullptr; h->S.row_defer = nullptr; h->S.def_rows = nullptr; h->S.def_ptr = nullptr; h->S.def_idx = nullptr;
+    h->S.slots = nullptr; h->S.slots_rd = nullptr; h->S.row_defer = nullptr; h->S.def_rows = nullptr; h->S.def_ptr = nullptr; h->S.def_idx = nullptr;
     h->S.ndef = (int32_t)hs.def_rows.size();
     h->S.nwg_def = 0; h->S.def_lpr = 1;
     if (h->S.ndef > 0) {
@@ -733,7 +779,12 @@ int fos_create(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowva
         FOS_TRY(dev_upload(h, &ddi, hs.def_idx));
         FOS_TRY(dev_alloc(h, &dsl, (size_t)2 * hs.nslots));
         FOS_HIP(hipMemset(dsl, 0, sizeof(double) * 2 * hs.nslots));
-        h->S.slots = dsl; h->S.row_defer = drd; h->S.def_rows = ddr; h->S.def_ptr = ddp; h->S.def_idx = ddi;
+        h->S.slots = dsl; h->S.slots_rd = dsl; h->S.row_defer = drd; h->S.def_rows = ddr; h->S.def_ptr = ddp; h->S.def_idx = ddi;
+        if (h->row_sharded) {                      // the all-reduced copy the slot-list sums read
+            FOS_TRY(dev_alloc(h, &h->slots_rd, (size_t)2 * hs.nslots));
+            FOS_HIP(hipMemset(h->slots_rd, 0, sizeof(double) * 2 * hs.nslots));
+            h->S.slots_rd = h->slots_rd;
+        }
         // lanes per deferred row: about a quarter of the average slot-list length (C4: 33 slots -> 8 lanes, dense LP: 80 -> 16)
         const double avg_list = (double)hs.def_ptr.back() / (double)h->S.ndef;
         int lpr = 1;
@@ -833,6 +884,7 @@ int fos_destroy(fos_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    if (h->host_buf) (void)hipHostFree(h->host_buf);
     for (void* q : h->peer_opened) (void)hipIpcCloseMemHandle(q);
     for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (void* p : h->owned) (void)hipFree(p);
@@ -871,9 +923,28 @@ int fos_comm_init(fos_handle h, int nranks, int rank, const void* id128) {
     return global_setup(h);            // all-reduce [n+m, ||b||^2, ||c||^2]
 }
 
+// Sharding with the CALLER's collective (MPI.jl's Allreduce!, torch.distributed on any backend, ...): every cross-rank sum is
+// staged through a pinned host buffer and handed to `fn` (in place, blocking).  Correct for both shardings, slow (one stream
+// synchronisation per sum): the path for a host that owns no RCCL communicator, and the one a single-GPU box can run with two
+// processes (tests/test_gpu_peer_mailbox.py::test_row_sharded_two_processes_host_exchange).
+int fos_comm_init_host(fos_handle h, int nranks, int rank, fos_allreduce_fn fn, void* user) {
+    if (!h || !fn || nranks < 1 || rank < 0 || rank >= nranks) { set_error("bad comm arguments"); return FOS_EINVAL; }
+    if (h->comm || h->peer_on) { set_error("this handle already has a communicator"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    if (!h->host_buf) {
+        void* q = nullptr;
+        FOS_HIP(hipHostMalloc(&q, sizeof(double) * std::max<size_t>((size_t)2 * (size_t)h->n, 16), hipHostMallocDefault));
+        h->host_buf = static_cast<double*>(q);
+    }
+    h->host_fn = fn; h->host_user = user;
+    h->nranks = nranks; h->rank = rank;
+    return global_setup(h);
+}
+
 // ---- peer mailboxes: the sharded scalar sums without a collective library (fos_internal.hpp, PeerBox)
 int fos_peer_export(fos_handle h, void* handle64) {
     if (!h || !handle64) { set_error("NULL argument"); return FOS_EINVAL; }
+    if (h->row_sharded) { set_error("row-sharded handles exchange an n-vector per Q apply: RCCL (fos_comm_init) only, no peer mailboxes"); return FOS_EUNSUPPORTED; }
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
     FOS_HIP(hipSetDevice(h->device));
     if (!h->peer_mbox) {

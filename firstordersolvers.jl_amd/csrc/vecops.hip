@@ -31,14 +31,15 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
 
 // r = rhs - Ap ; p = r ; partial r.r over the non-tau rows          conjugategradients.jl:33-35
 __global__ __launch_bounds__(VEC_THREADS) void cg_init_kernel(int64_t l, const d2* __restrict__ rhs, const d2* __restrict__ Ap,
-                                                              d2* __restrict__ r, d2* __restrict__ p, double* __restrict__ partials) {
+                                                              d2* __restrict__ r, d2* __restrict__ p, double* __restrict__ partials,
+                                                              int64_t acc_from) {
     double acc[1] = {0.0};
     for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
         const d2 b = rhs[i], a = Ap[i];
         const d2 ri = make_double2(b.x - a.x, b.y - a.y);
         r[i] = ri;
         p[i] = ri;
-        if (i != l - 1) acc[0] += ri.x * ri.x + ri.y * ri.y;
+        if (i != l - 1 && i >= acc_from) acc[0] += ri.x * ri.x + ri.y * ri.y;       // (acc_from > 0: replicated entries counted elsewhere)
     }
     block_reduce_store<1>(acc, partials + blockIdx.x);
 }
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
                                                                 DevState* st, const double* __restrict__ kkt_partials, int nkkt,
                                                                 const double* __restrict__ reduced, int from_reduced, int j,
                                                                 double* __restrict__ partials, DevBlkCsr S, const double* __restrict__ cb, int n,
-                                                                const uint32_t* __restrict__ def_mask, PeerBox pb, uint32_t seq_base) {
+                                                                const uint32_t* __restrict__ def_mask, PeerBox pb, uint32_t seq_base, int count_repl) {
     // the first element of this thread's slice is requested BEFORE the scalar prologue (two dependent round trips and two
     // barriers): on small operators the prologue's latency, not bandwidth, is what this kernel costs
     const int64_t stride = (int64_t)gridDim.x * VEC_THREADS;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
     }
     double acc[1] = {0.0};
     if constexpr (DEF) {
-        const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots);
+        const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots_rd);
         const int lpr = S.def_lpr, sh = 31 - __clz(lpr);
         const int rows_per_pass = (gridDim.x * VEC_THREADS) >> sh;
         const int lig = threadIdx.x & (lpr - 1);
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
                 if constexpr (XUPD) { xi.x += alpha * pi.x; xi.y += alpha * pi.y; x[row] = xi; }
                 ri.x -= alpha * a1; ri.y -= alpha * a2;
                 r[row] = ri;
-                acc[0] += ri.x * ri.x + ri.y * ri.y;
+                if (count_repl) acc[0] += ri.x * ri.x + ri.y * ri.y;       // (row-sharded: replicated rows are counted by one rank)
             }
         }
     }
@@ -172,7 +173,7 @@ void launch_cg_update(const LaunchCtx& c, const CgIter& it, double2* x, double2*
     dim3 grid(c.cg_blocks), block(VEC_THREADS);
 #define FOS_UPD(DEF, FOLD, XUPD)                                                                                             \
     hipLaunchKernelGGL((cg_update_kernel<DEF, FOLD, XUPD>), grid, block, 0, c.stream, c.l, x, r, (const d2*)it.p_cur, Ap, c.st, c.partials, \
-                       c.S.nwg, c.reduced, it.fold ? 0 : kkt_from_reduced, it.j, rr_out, c.S, c.cb, (int)c.n, c.def_mask, pb, it.seq_base)
+                       c.S.nwg, c.reduced, it.fold ? 0 : kkt_from_reduced, it.j, rr_out, c.S, c.cb, (int)c.n, c.def_mask, pb, it.seq_base, (int)c.count_repl)
 #define FOS_UPD2(DEF, FOLD) do { if (it.fuse_p) FOS_UPD(DEF, FOLD, true); else FOS_UPD(DEF, FOLD, false); } while (0)
     if (c.S.ndef > 0) { if (it.fold) FOS_UPD2(true, true); else FOS_UPD2(true, false); }
     else { if (it.fold) FOS_UPD2(false, true); else FOS_UPD2(false, false); }
@@ -225,7 +226,8 @@ void launch_cg_pupdate(const LaunchCtx& c, const CgIter& it, double2* x, double2
 }
 
 void launch_cg_init(const LaunchCtx& c, const double2* rhs, const double2* Ap, double2* r, double2* p) {
-    hipLaunchKernelGGL(cg_init_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, rhs, Ap, r, p, c.partials);
+    hipLaunchKernelGGL(cg_init_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, rhs, Ap, r, p, c.partials,
+                       c.count_repl ? (int64_t)0 : c.n_repl);
 }
 void launch_cg_init_finalize(const LaunchCtx& c, const double2* r, double tol, int maxit, int from_reduced) {
     hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.vec_blocks, c.reduced,
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(VEC_THREADS) void gap_final_kernel(int64_t l, d2* _
 // tau-row contributions go to reduced[8..10] (replicated across shards, added after the all-reduce).
 __global__ __launch_bounds__(VEC_THREADS) void gapa_final_kernel(int64_t l, d2* __restrict__ x, const d2* __restrict__ t2,
                                                                  const d2* __restrict__ t1, double alpha, const DevState* st,
-                                                                 double* __restrict__ partials, double* __restrict__ reduced) {
+                                                                 double* __restrict__ partials, double* __restrict__ reduced, int64_t acc_from) {
     const double a12 = st->alpha12, b12 = 1 - a12, b = 1 - alpha;
     double acc[3] = {0.0, 0.0, 0.0};
     GRID_STRIDE(i, l) {
@@ -280,8 +282,8 @@ __global__ __launch_bounds__(VEC_THREADS) void gapa_final_kernel(int64_t l, d2* 
         const double d1x = rx - v.x, d1y = ry - v.y;      // tmp2 - tmp1
         const double d2x = v.x - xi.x, d2y = v.y - xi.y;  // tmp1 - x
         const double s = d1x * d2x + d1y * d2y, n1 = d1x * d1x + d1y * d1y, n2 = d2x * d2x + d2y * d2y;
-        if (i != l - 1) { acc[0] += s; acc[1] += n1; acc[2] += n2; }
-        else { reduced[8] = s; reduced[9] = n1; reduced[10] = n2; }
+        if (i == l - 1) { reduced[8] = s; reduced[9] = n1; reduced[10] = n2; }
+        else if (i >= acc_from) { acc[0] += s; acc[1] += n1; acc[2] += n2; }
         xi.x = alpha * rx + b * xi.x;
         xi.y = alpha * ry + b * xi.y;
         x[i] = xi;
@@ -337,7 +339,8 @@ void launch_gap_final(const LaunchCtx& c, double2* x, const double2* t2, const d
     hipLaunchKernelGGL(gap_final_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, t2, t1, alpha, alpha2);
 }
 void launch_gapa_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha) {
-    hipLaunchKernelGGL(gapa_final_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, t2, t1, alpha, c.st, c.partials, c.reduced);
+    hipLaunchKernelGGL(gapa_final_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, t2, t1, alpha, c.st, c.partials, c.reduced,
+                       c.count_repl ? (int64_t)0 : c.n_repl);
 }
 void launch_gapa_finalize(const LaunchCtx& c, double beta, int from_reduced) {
     hipLaunchKernelGGL(gapa_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.vec_blocks, c.reduced, from_reduced, beta, c.st);

@@ -117,7 +117,9 @@ class HipHSDE:
     """Owns one fos_handle: the device-resident S1 (AffinePlusLinear over HSDEMatrixQ), S2 (DualConeProduct),
     iterate and algorithm data.  == what init_algorithm!/get_sets_and_status build (FOSSolverInterface.jl:76-79)."""
 
-    def __init__(self, A, b, c, K1, K2, device=0):
+    def __init__(self, A, b, c, K1, K2, device=0, row_sharded=False):
+        """row_sharded (SURVEY 8(f2)): this rank holds the rows of A of its K1 cones and all columns (sharding.shard_rows);
+        follow with comm_init on every rank."""
         self._lib = _lib.load()
         A = sp.csc_matrix(A)                       # loadproblem! sparsifies dense input, FOSSolverInterface.jl:27-29
         A.sort_indices()
@@ -134,9 +136,9 @@ class HipHSDE:
         h = C.c_void_p()
         i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
         i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
-        _lib.check(self._lib.fos_create(m, n, i64(colptr), i64(rowval), _lib.dptr(nzval), _lib.dptr(b), _lib.dptr(c),
-                                        len(k1t), i32(k1t), i64(k1s), i64(k1l),
-                                        len(k2t), i32(k2t), i64(k2s), i64(k2l), device, C.byref(h)))
+        _lib.check(self._lib.fos_create2(m, n, i64(colptr), i64(rowval), _lib.dptr(nzval), _lib.dptr(b), _lib.dptr(c),
+                                         len(k1t), i32(k1t), i64(k1s), i64(k1l),
+                                         len(k2t), i32(k2t), i64(k2s), i64(k2l), device, 1 if row_sharded else 0, C.byref(h)))
         self._h = h
 
     def close(self):
@@ -346,6 +348,21 @@ class HipHSDE:
     def comm_init(self, nranks, rank, unique_id: bytes):
         buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
         _lib.check(self._lib.fos_comm_init(self._h, nranks, rank, buf))
+
+    def comm_init_host(self, nranks, rank, allreduce_sum):
+        """Sharding over the caller's own collective (fos_comm_init_host): `allreduce_sum(a)` must replace the float64 numpy
+        array `a` by its sum over the ranks, in place, blocking -- e.g. torch.distributed.all_reduce(torch.from_numpy(a)) on
+        any backend, or MPI's Allreduce."""
+        def _cb(user, buf, count):
+            try:
+                allreduce_sum(np.ctypeslib.as_array(buf, shape=(count,)))
+                return 0
+            except Exception:           # noqa: BLE001 -- reported through the ABI's error code
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._host_cb = _lib.ALLREDUCE_FN(_cb)          # keep the trampoline alive as long as the handle
+        _lib.check(self._lib.fos_comm_init_host(self._h, nranks, rank, C.cast(self._host_cb, C.c_void_p), None))
 
     # -- peer mailboxes: the sharded sums without a collective call (include/foship.h, fos_peer_*)
     def peer_export(self) -> bytes:

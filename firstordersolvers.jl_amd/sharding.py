@@ -137,6 +137,69 @@ def shard_problem(problem: ConicProblem, nranks: int, rank: int) -> Shard:
     return Shard(loc, (r0, r1), (c0, c1), problem.m, problem.n)
 
 
+@dataclass
+class RowShard:
+    problem: ConicProblem          # local problem: the rows of A (and b, K1 cones) this rank owns, ALL columns (c, K2 whole)
+    rows: tuple                    # (r0, r1) global row range
+    m_global: int
+    n: int
+
+
+def plan_rows(problem: ConicProblem, nranks: int):
+    """Contiguous split of the K1 cones into nranks runs of near-equal work (non-zeros + rows); any A qualifies."""
+    A = problem.A.tocsr()
+    kb = _cone_bounds(problem.K1)
+    if len(problem.K1) < nranks:
+        raise ValueError("only %d K1 cones for %d ranks" % (len(problem.K1), nranks))
+    nnz_per_row = np.diff(A.indptr)
+    w = [float(nnz_per_row[kb[i]:kb[i + 1]].sum()) + 4.0 * (kb[i + 1] - kb[i]) for i in range(len(problem.K1))]
+    ccuts = balanced_cone_split(w, nranks)
+    return ccuts, [int(kb[c]) for c in ccuts]
+
+
+def shard_rows(problem: ConicProblem, nranks: int, rank: int) -> RowShard:
+    """Row sharding for a NON block-diagonal A: rank g keeps the rows of its K1 cones and every column; x, r, c,
+    tau, kappa are replicated, y, s, b are local.  Per Q apply the n-vector A'y = sum_g A_g'y_g is all-reduced
+    (HSDEAffine.jl:51); the scalar sums count the replicated entries once."""
+    ccuts, row_cuts = plan_rows(problem, nranks)
+    r0, r1 = row_cuts[rank], row_cuts[rank + 1]
+    A = problem.A.tocsr()[r0:r1].tocsc()
+    A.sort_indices()
+    loc = ConicProblem("%s[rows %d/%d]" % (problem.name, rank, nranks), A, problem.b[r0:r1].copy(), problem.c.copy(),
+                       list(problem.K1[ccuts[rank]:ccuts[rank + 1]]), list(problem.K2),
+                       x0=None if problem.x0 is None else problem.x0.copy(),
+                       y0=None if problem.y0 is None else problem.y0[r0:r1].copy(),
+                       s0=None if problem.s0 is None else problem.s0[r0:r1].copy(), meta=dict(problem.meta))
+    return RowShard(loc, (r0, r1), problem.m, problem.n)
+
+
+def rows_local_to_global(shards_z, shards):
+    """Global iterate from row-sharded local iterates (x, r, tau, kappa from rank 0: they are replicated)."""
+    mg, n = shards[0].m_global, shards[0].n
+    lg = mg + n + 1
+    z = np.zeros(2 * lg)
+    z0 = shards_z[0]
+    l0 = shards[0].problem.m + n + 1
+    z[:n] = z0[:n]
+    z[lg:lg + n] = z0[l0:l0 + n]
+    z[lg - 1] = z0[l0 - 1]
+    z[2 * lg - 1] = z0[2 * l0 - 1]
+    for zl, sh in zip(shards_z, shards):
+        r0, r1 = sh.rows
+        ml = r1 - r0
+        ll = ml + n + 1
+        z[n + r0:n + r1] = zl[n:n + ml]
+        z[lg + n + r0:lg + n + r1] = zl[ll + n:ll + n + ml]
+    return z
+
+
+def rows_global_to_local(z, shard: RowShard):
+    mg, n = shard.m_global, shard.n
+    lg = mg + n + 1
+    r0, r1 = shard.rows
+    return np.concatenate([z[:n], z[n + r0:n + r1], [z[lg - 1]], z[lg:lg + n], z[lg + n + r0:lg + n + r1], [z[2 * lg - 1]]])
+
+
 def local_to_global(shards_z, shards):
     """Assemble the global iterate z = [x; y; tau; r; s; kappa] from per-rank local iterates (tau, kappa from rank 0)."""
     mg, ng = shards[0].m_global, shards[0].n_global

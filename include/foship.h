@@ -102,6 +102,18 @@ int fos_create(int64_t m, int64_t n,
                int64_t nK1, const int32_t* K1type, const int64_t* K1start, const int64_t* K1len,
                int64_t nK2, const int32_t* K2type, const int64_t* K2start, const int64_t* K2len,
                int device, fos_handle* out);
+
+/* fos_create with flags.  FOS_CREATE_ROW_SHARDED (multi-GPU for an A that is NOT block diagonal): this rank
+ * holds the ROWS of A that belong to its K1 cones (m = local rows, b local, K1 local) and ALL n columns (c, K2 whole).  x, r,
+ * tau, kappa are replicated on every rank, y and s are local.  Per Q apply the n-vector A'y = sum over ranks of A_g'y_g is
+ * all-reduced in stream (RCCL; HSDEAffine.jl:51), every scalar sum counts the replicated entries once (rank 0).  Follow with
+ * fos_comm_init on every rank; without a communicator the handle behaves as the only rank.  No peer mailboxes, no dual tiles. */
+#define FOS_CREATE_ROW_SHARDED 1
+int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                const double* b, const double* c,
+                int64_t nK1, const int32_t* K1type, const int64_t* K1start, const int64_t* K1len,
+                int64_t nK2, const int32_t* K2type, const int64_t* K2start, const int64_t* K2len,
+                int device, int32_t flags, fos_handle* out);
 int fos_destroy(fos_handle h);                             /* Julia finalizer */
 int fos_sizes(fos_handle h, int64_t* m, int64_t* n, int64_t* N, int64_t* nnz);
 
@@ -112,6 +124,12 @@ int fos_sizes(fos_handle h, int64_t* m, int64_t* n, int64_t* N, int64_t* nnz);
  * fos_comm_init: collective over all ranks.  Without it the handle is a single-GPU solver. */
 int fos_comm_get_unique_id(void* id128);
 int fos_comm_init(fos_handle h, int nranks, int rank, const void* id128);
+/* The same with the CALLER's collective instead of RCCL (a Julia host with MPI.jl, a test harness with gloo): every cross-rank
+ * sum -- scalars, and the n-vector of a row-sharded handle -- is staged through a pinned host buffer and handed to
+ * `fn(user, buf, count)`, which must replace buf[0..count) by its sum over the ranks (blocking, the same call sequence on
+ * every rank) and return 0.  Slow by design (one stream synchronisation per sum); excludes fos_comm_init / peer mailboxes. */
+typedef int (*fos_allreduce_fn)(void* user, double* buf, int64_t count);
+int fos_comm_init_host(fos_handle h, int nranks, int rank, fos_allreduce_fn fn, void* user);
 
 /* Peer mailboxes: the same scalar sums WITHOUT a collective call in the stream.  Every rank owns a mailbox in
  * uncached device memory that its peers map through HIP IPC; the kernel that reduces a rank's partial sums stores

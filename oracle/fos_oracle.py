@@ -71,6 +71,19 @@ class LocalSpace:
         """dot of two vectors without replicated entries (x-, y-, r-, s-like)."""
         return np.float64(np.dot(a, b))
 
+    # part-aware forms (the row-sharded space below treats column-space and row-space vectors differently)
+    def dotX(self, a, b):
+        """dot of two column-space (x-, r-, c-like) vectors."""
+        return self.dotL(a, b)
+
+    def dotY(self, a, b):
+        """dot of two row-space (y-, s-, b-like) vectors."""
+        return self.dotL(a, b)
+
+    def sumX(self, v):
+        """a column-space vector that every rank holds a partial sum of (A'y) -> its sum over ranks."""
+        return v
+
 
 class ShardedSpace(LocalSpace):
     """allreduce: callable mapping a float64 ndarray to its sum over ranks."""
@@ -92,6 +105,42 @@ class ShardedSpace(LocalSpace):
 
     def dotL(self, a, b):
         return self.allsum(np.dot(a, b))
+
+
+class RowShardedSpace(LocalSpace):
+    """Row sharding of a NON block-diagonal A: rank g owns the rows of A of its K1 cones (y, s, b local), every
+    rank holds all n columns (x, r, c and tau, kappa replicated).  What crosses ranks: the n-vector A'y = sum_g A_g'y_g (one
+    all-reduce per Q apply, HSDEAffine.jl:51) and the scalar sums, in which the replicated entries are counted once.
+    allreduce: callable mapping a float64 ndarray to its sum over ranks; n = number of (replicated) columns."""
+
+    def __init__(self, allreduce, l_global, n):
+        self._ar = allreduce
+        self.l_global = l_global
+        self.n = n
+
+    def allsum(self, v):
+        return np.float64(self._ar(np.array([v], dtype=np.float64))[0])
+
+    def global_l(self, l_local):
+        return self.l_global
+
+    def dotN(self, a, b):
+        l, n = a.shape[0] // 2, self.n
+        rep = (np.dot(a[:n], b[:n]) + a[l - 1] * b[l - 1] + np.dot(a[l:l + n], b[l:l + n]) + a[2 * l - 1] * b[2 * l - 1])
+        loc = np.dot(a[n:l - 1], b[n:l - 1]) + np.dot(a[l + n:2 * l - 1], b[l + n:2 * l - 1])
+        return self.allsum(loc) + np.float64(rep)
+
+    def dotL(self, a, b):
+        raise TypeError("RowShardedSpace: use dotX (replicated column space) or dotY (sharded row space)")
+
+    def dotX(self, a, b):
+        return np.float64(np.dot(a, b))
+
+    def dotY(self, a, b):
+        return self.allsum(np.dot(a, b))
+
+    def sumX(self, v):
+        return np.asarray(self._ar(np.array(v, dtype=np.float64)), dtype=np.float64)
 
 
 LOCAL = LocalSpace()
@@ -131,12 +180,12 @@ class HSDEMatrixQ:
         b1 = B[:n]
         b2 = B[n:n + m]
         b3 = B[n + m]
-        y1 = self.At @ b2                       # :51  mul!(y1, transpose(A), b2)
+        y1 = self.space.sumX(self.At @ b2)      # :51  mul!(y1, transpose(A), b2)   (row-sharded A: summed over the ranks)
         y2 = self.A @ b1                        # :52  mul!(y2, A, b1)
         y1 = y1 + b3 * self.c                   # :54  y1 .+= b3.*c
         y2 = y2 - b3 * self.b                   # :55  y2 .-= b3.*b
         y2 = -y2                                # :56  y2 .= .-y2
-        last = -self.space.dotL(self.c, b1) - self.space.dotL(self.b, b2)   # :57 (computed before Y is written: B may not alias Y)
+        last = -self.space.dotX(self.c, b1) - self.space.dotY(self.b, b2)   # :57 (computed before Y is written: B may not alias Y)
         Y[:n] = y1
         Y[n:n + m] = y2
         Y[n + m] = last
@@ -767,19 +816,20 @@ def residuals(model, z):
     kappa = z[2 * nu - 1]
     A, b, c = model.A, model.b, model.c
     sp_ = getattr(model, "space", LOCAL)
-    norm = lambda v: float(np.sqrt(sp_.dotL(v, v)))          # norm over the (possibly sharded) vector
-    nb = norm(b)
-    nc = norm(c)
+    normx = lambda v: float(np.sqrt(sp_.dotX(v, v)))         # norms over the (possibly sharded) column / row space
+    normy = lambda v: float(np.sqrt(sp_.dotY(v, v)))
+    nb = normy(b)
+    nc = normx(c)
     Ax = A @ x
-    ATy = A.T @ y
+    ATy = sp_.sumX(A.T @ y)
     with np.errstate(divide="ignore", invalid="ignore"):      # Julia: x/0.0 -> Inf/NaN silently
-        p = norm(Ax / tau + s / tau - b) / abs(1 + nb)                            # :34
-        d = norm(ATy / tau + c - r / tau) / abs(1 + nc)                           # :35
-        ctx = float(sp_.dotL(c, x))                                               # :36
-        bty = float(sp_.dotL(b, y))                                               # :37
+        p = normy(Ax / tau + s / tau - b) / abs(1 + nb)                           # :34
+        d = normx(ATy / tau + c - r / tau) / abs(1 + nc)                          # :35
+        ctx = float(sp_.dotX(c, x))                                               # :36
+        bty = float(sp_.dotY(b, y))                                               # :37
         g = abs(ctx / tau + bty / tau) / (1 + abs(ctx / tau) + abs(bty / tau))    # :38
     return dict(p=p, d=d, g=g, ctx=ctx, bty=bty, kappa=float(kappa), tau=float(tau),
-                nAxs=norm(Ax + s), nATy=norm(ATy), nb=nb, nc=nc)
+                nAxs=normy(Ax + s), nATy=normx(ATy), nb=nb, nc=nc)
 
 
 def decide_status(res, eps):

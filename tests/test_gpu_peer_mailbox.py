@@ -280,3 +280,169 @@ def test_missing_peer_times_out_with_error(pkg):
     finally:
         dev.close()
         ghost.close()
+
+
+def test_row_sharded_single_rank_matches_unsharded(pkg, oracle):
+    """SURVEY 8(f2) plumbing on ONE rank (what a one-GPU box can run): a row-sharded handle -- every row of A' finished from a
+    partial slot that passes through the all-reduce buffer, replicated-entry counting, RCCL communicator of size 1 -- must
+    reproduce the ordinary handle: operators to rounding, whole solves to the same status / iteration count / solution.
+    (The multi-rank sums are checked at the oracle level by tests/test_sharding_gloo.py::test_row_sharded_oracle_matches_unsharded;
+    the row-sharded HIP path has never run on two GPUs.)"""
+    import torch
+    prob = pkg.workloads.small_mixed()
+    d0 = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d1 = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2, row_sharded=True)
+    st = d1.operator_stats()
+    assert st["deferred"] == prob.n and st["tiles"] == 0
+    rng = np.random.default_rng(3)
+    z = rng.standard_normal(d0.N)
+    for stage in ("no communicator", "1-rank RCCL communicator"):
+        if stage.startswith("1-rank"):
+            d1.comm_init(1, 0, pkg.HipHSDE.comm_unique_id())
+        assert np.allclose(d1.kkt_apply(z), d0.kkt_apply(z), rtol=1e-13, atol=1e-13), stage
+        u = rng.standard_normal(d0.l)
+        assert np.allclose(d1.q_apply(u), d0.q_apply(u), rtol=1e-13, atol=1e-13), stage
+        r0, r1 = d0.check(z, 1e-6), d1.check(z, 1e-6)
+        for key in ("p", "d", "g", "ctx", "bty"):
+            assert getattr(r1, key) == pytest.approx(getattr(r0, key), rel=1e-12), (stage, key)
+    for alg in (pkg.DR(), pkg.GAPA(0.8, 0.5)):
+        # one outer iteration = one CG solve from the same start: same CG iteration count, iterate equal to rounding;
+        # 60 iterations: the inexact projections amplify the rounding differences of the two summation orders (the
+        # unsharded oracle against the sharded one differs by as much, tests/test_sharding_gloo.py) -- status to 1e-3
+        for iters, tol in ((1, 1e-10), (60, 1e-3)):
+            outs = []
+            for d in (d0, d1):
+                d.set_alg(alg)
+                d.set_iterate(None)
+                d.reset_affine()
+                done, checked, res = d.step(1, iters, iters, 1e-6)
+                outs.append((d.get_iterate(), res, d.cgiter()))
+            if iters == 1:
+                assert outs[0][2] == outs[1][2]
+            assert np.linalg.norm(outs[0][0] - outs[1][0]) <= tol * max(1.0, np.linalg.norm(outs[0][0])), (iters,)
+            for key in ("p", "d", "g"):
+                assert getattr(outs[1][1], key) == pytest.approx(getattr(outs[0][1], key), rel=100 * tol, abs=1e-12, nan_ok=True)
+    d0.close()
+    d1.close()
+
+
+def _worker_rows(rank, world, port, algname, iters, q):
+    """One rank of a row-sharded solve; both processes share cuda:0, the cross-rank sums go through gloo (fos_comm_init_host)."""
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, str(ROOT))
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        prob = pkg.workloads.small_mixed()
+        sh = pkg.sharding.shard_rows(prob, world, rank)
+        lp = sh.problem
+        dev = pkg.HipHSDE(lp.A, lp.b, lp.c, lp.K1, lp.K2, row_sharded=True)
+        calls = [0]
+
+        def allreduce_sum(a):
+            calls[0] += 1
+            dist.all_reduce(torch.from_numpy(a))
+        dev.comm_init_host(world, rank, allreduce_sum)
+        rng = np.random.default_rng(5)
+        zg = rng.standard_normal(2 * (prob.n + prob.m + 1))          # a global vector, restricted to this rank's rows
+        zl = pkg.sharding.rows_global_to_local(zg, sh)
+        kk = dev.kkt_apply(zl)
+        chk = dev.check(zl, 1e-6)
+        dev.set_alg({"DR": pkg.DR, "GAPA": lambda: pkg.GAPA(0.8, 0.5)}[algname]())
+        dev.set_iterate(None)
+        cg = []
+        for i in range(1, iters + 1):
+            dev.step(i, 1, 10 ** 9, 1e-9)
+            cg.append(dev.cgiter())
+            if i == 1:
+                z1 = dev.get_iterate()
+        z = dev.get_iterate()
+        zs, res = dev.getsol(force_check=True, eps=1e-6)
+        q.put((rank, dict(kk=kk, chk={k: getattr(chk, k) for k in ("p", "d", "g", "ctx", "bty")}, z1=z1, z=z, cg=cg, calls=calls[0],
+                          res={k: getattr(res, k) for k in ("p", "d", "g", "ctx", "bty", "norm_b", "norm_c")})))
+        dist.barrier()
+        dev.close()
+        dist.destroy_process_group()
+    except Exception as exc:  # noqa: BLE001
+        import traceback
+        q.put((rank, "error: " + repr(exc) + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("algname", ["DR", "GAPA"])
+def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname):
+    """SURVEY 8(f2) with TWO ranks on the one GPU of the test box: each process holds the rows of half of the K1 cones of a
+    problem whose A couples everything (workloads.small_mixed), the n-vector A'y and every scalar sum cross the processes
+    through the caller's collective (fos_comm_init_host, here gloo).  Replicated parts bitwise identical on both ranks; the
+    KKT operator and the status sums on a common vector equal the unsharded handle's to rounding; the first outer iteration
+    (one CG solve) reproduces the unsharded handle with the same CG count; ten iterations follow it to 1e-3 (as the oracle's
+    own sharded-vs-unsharded comparison, tests/test_sharding_gloo.py)."""
+    import socket
+    import torch.multiprocessing as mp
+    iters, world = 10, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_rows, args=(r, world, port, algname, iters, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            r, payload = q.get(timeout=300)
+            assert not isinstance(payload, str), payload
+            got[r] = payload
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    prob = pkg.workloads.small_mixed()
+    shards = [pkg.sharding.shard_rows(prob, world, r) for r in range(world)]
+    n = prob.n
+    ls = [sh.problem.m + n + 1 for sh in shards]
+    g0, g1 = got[0], got[1]
+    assert g0["calls"] == g1["calls"] > 0
+    for key in ("z", "z1", "kk"):
+        a, b = g0[key], g1[key]
+        assert np.array_equal(a[:n], b[:n]) and np.array_equal(a[ls[0]:ls[0] + n], b[ls[1]:ls[1] + n]), key
+        assert a[ls[0] - 1] == b[ls[1] - 1] and a[-1] == b[-1], key
+    assert g0["cg"] == g1["cg"]
+    for key in g0["res"]:
+        assert g0["res"][key] == g1["res"][key], key               # all-reduced sums: the same bits on both ranks
+    # against the ordinary single handle
+    d0 = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    rng = np.random.default_rng(5)
+    zg = rng.standard_normal(d0.N)
+    kk = pkg.sharding.rows_local_to_global([g0["kk"], g1["kk"]], shards)
+    assert np.allclose(kk, d0.kkt_apply(zg), rtol=1e-12, atol=1e-12)
+    chk = d0.check(zg, 1e-6)
+    for key in ("p", "d", "g", "ctx", "bty"):
+        assert g0["chk"][key] == pytest.approx(getattr(chk, key), rel=1e-11), key
+    d0.set_alg({"DR": pkg.DR, "GAPA": lambda: pkg.GAPA(0.8, 0.5)}[algname]())
+    d0.set_iterate(None)
+    cg = []
+    for i in range(1, iters + 1):
+        d0.step(i, 1, 10 ** 9, 1e-9)
+        cg.append(d0.cgiter())
+        if i == 1:
+            z1 = d0.get_iterate()
+    z = d0.get_iterate()
+    _, res = d0.getsol(force_check=True, eps=1e-6)
+    assert g0["cg"][0] == cg[0]
+    zz1 = pkg.sharding.rows_local_to_global([g0["z1"], g1["z1"]], shards)
+    assert np.linalg.norm(zz1 - z1) <= 1e-7 * max(1.0, np.linalg.norm(z1))
+    zz = pkg.sharding.rows_local_to_global([g0["z"], g1["z"]], shards)
+    tol = 1e-3 if g0["cg"] == cg else 0.2
+    assert np.linalg.norm(zz - z) <= tol * max(1.0, np.linalg.norm(z))
+    assert g0["res"]["norm_b"] == pytest.approx(res.norm_b, rel=1e-12) and g0["res"]["norm_c"] == pytest.approx(res.norm_c, rel=1e-12)
+    d0.close()

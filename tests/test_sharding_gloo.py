@@ -24,6 +24,95 @@ def _free_port():
     return p
 
 
+def _worker_rows(rank, world, port, algname, iters, q):
+    """Row sharding of a NON block-diagonal problem: x replicated, A'y all-reduced as an n-vector."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    import fos_oracle as orc
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    prob = pkg.workloads.small_mixed()
+    shard = pkg.sharding.shard_rows(prob, world, rank)
+
+    def allreduce(v):
+        t = torch.from_numpy(np.array(v, dtype=np.float64))
+        dist.all_reduce(t)
+        return t.numpy()
+    space = orc.RowShardedSpace(allreduce, prob.m + prob.n + 1, prob.n)
+    lp = shard.problem
+    codes = lambda cs: [(orc.CONE_CODES[k], l) for k, l in cs]
+    mo = orc.Model(lp.A, lp.b, lp.c, codes(lp.K1), codes(lp.K2), space=space)
+    alg = {"DR": orc.DR, "GAPA": lambda: orc.GAPA(0.8, 0.5), "FISTA": orc.FISTA}[algname]()
+    alg.init(mo)
+    x = orc.hsde_initialvalue(mo)
+    st = orc.HSDEStatus(mo, iters, 1e-6, 0, 1, S1=alg.S1)
+    cg = []
+    for i in range(1, iters + 1):
+        st.i = i
+        alg.step(x, i, st)
+        cg.append(alg.S1.getcgiter())
+    q.put((rank, x.copy(), cg, dict(st.last), getattr(alg, "alpha12", None)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algname", ["DR", "GAPA"])
+def test_row_sharded_oracle_matches_unsharded(pkg, oracle, algname):
+    """Two gloo ranks, each with the rows of half of the K1 cones of a problem whose A couples everything: the replicated
+    parts (x, r, tau, kappa) stay bitwise identical on both ranks, the gathered iterate follows the unsharded oracle, the
+    status sums agree."""
+    import torch.multiprocessing as mp
+    orc = oracle
+    iters, world = 10, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rows, args=(r, world, port, algname, iters, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, x, cg, last, a12 = q.get(timeout=240)
+        got[r] = (x, cg, last, a12)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    prob = pkg.workloads.small_mixed()
+    codes = lambda cs: [(orc.CONE_CODES[k], l) for k, l in cs]
+    mo = orc.Model(prob.A, prob.b, prob.c, codes(prob.K1), codes(prob.K2))
+    alg = {"DR": orc.DR, "GAPA": lambda: orc.GAPA(0.8, 0.5)}[algname]()
+    alg.init(mo)
+    x = orc.hsde_initialvalue(mo)
+    st = orc.HSDEStatus(mo, iters, 1e-6, 0, 1, S1=alg.S1)
+    cg = []
+    for i in range(1, iters + 1):
+        st.i = i
+        alg.step(x, i, st)
+        cg.append(alg.S1.getcgiter())
+    shards = [pkg.sharding.shard_rows(prob, world, r) for r in range(world)]
+    n = prob.n
+    l0, l1 = shards[0].problem.m + n + 1, shards[1].problem.m + n + 1
+    z0, z1 = got[0][0], got[1][0]
+    # replicated parts: bitwise the same on both ranks
+    assert np.array_equal(z0[:n], z1[:n]) and np.array_equal(z0[l0:l0 + n], z1[l1:l1 + n])
+    assert z0[l0 - 1] == z1[l1 - 1] and z0[-1] == z1[-1]
+    assert got[0][1] == got[1][1] and got[0][1][:3] == cg[:3]
+    z = pkg.sharding.rows_local_to_global([z0, z1], shards)
+    if got[0][1] == cg:          # (same CG stop iterations: what is left is rounding amplified by plain CG on the indefinite system)
+        assert np.linalg.norm(z - x) <= 1e-3 * max(1.0, np.linalg.norm(x))
+    else:
+        assert np.linalg.norm(z - x) <= 0.2 * max(1.0, np.linalg.norm(x))
+    for key in ("p", "d", "g", "ctx", "bty", "nb", "nc"):
+        assert got[0][2][key] == pytest.approx(got[1][2][key], rel=1e-12, abs=1e-300)
+    assert got[0][2]["nb"] == pytest.approx(st.last["nb"], rel=1e-12) and got[0][2]["nc"] == pytest.approx(st.last["nc"], rel=1e-12)
+
+
 def _worker(rank, world, port, algname, iters, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
