@@ -275,7 +275,9 @@ def main():
         avg_psd_ms = psd_ms / max(1, psd_n)
         mean_sweeps = float(sweeps.mean()) if npsd_mats else 0.0
         kk = 64
-        flop_sweep = (kk - 1) * (kk // 2) * (3 * 2 * kk + 2 * kk * 3)          # per pair: 3 dot products + the rotation of 2 columns
+        # per sweep: 64 steps x 32 pairs x (one dot product + the rotation of 2 columns); the wave kernel carries the column norms
+        # along instead of recomputing them, so this is fewer flops per sweep than the 3-dot-product workgroup kernel did
+        flop_sweep = kk * (kk // 2) * (2 * kk + 2 * kk * 3)
         flop_fixed = 2 * kk ** 3 + 10 * 16 * 16 * kk * 2 + 2 * kk * kk         # warm-start product, rebuild (10 tiles), weights
         psd_flops = npsd_mats * (mean_sweeps * flop_sweep + flop_fixed)
         psd_tflops = psd_flops / (avg_psd_ms * 1e-3) / 1e12 if psd_n and avg_psd_ms > 0 else 0.0
@@ -327,16 +329,17 @@ def main():
         if psd_n:
             roof_psd = {
                 "bound": "mfma",
-                "kernel": "psd_kernel: batched order-64 PSD projection, one-sided Jacobi with warm start; warm-start product and rebuild on v_mfma_f64_16x16x4",
+                "kernel": "psd64_wave_kernel: batched order-64 PSD projection, one wavefront per matrix, one-sided Jacobi (odd-even ordering) in registers with warm start; warm-start product and rebuild on v_mfma_f64_16x16x4",
                 "achieved": round(psd_tflops, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(psd_tflops / FP64_PEAK_TFLOPS, 4),
                 "flops_per_launch": psd_flops,
-                "flops_model": "matrices x (sweeps x 63 x 32 pairs x 768 + 2 x 64^3 + 10 x 16 x 16 x 64 x 2 + 2 x 64^2); sweeps counted by the kernel",
+                "flops_model": "matrices x (sweeps x 64 steps x 32 pairs x 512 + 2 x 64^3 + 10 x 16 x 16 x 64 x 2 + 2 x 64^2); sweeps counted by the kernel",
                 "matrices_per_launch": npsd_mats, "mean_jacobi_sweeps": round(mean_sweeps, 3),
                 "sweeps_histogram_last_launch": {int(k): int(v) for k, v in zip(*np.unique(sweeps, return_counts=True))},
                 "avg_kernel_ms": round(avg_psd_ms, 5), "launches_timed": psd_n,
-                "note": "latency / issue bound inside LDS (63 dependent rotation steps per sweep), not an MFMA-bound kernel; the two dense "
-                        "contractions are 8 % of its time after moving to MFMA (profiles/r02_psd_phases_*.json)",
+                "note": "issue bound: one wavefront per SIMD issues an fp64 VALU op every 7.5 cycles and a DPP move every 9 (measured; "
+                        "4 waves per SIMD reach ~5), and 1024 matrices are one wavefront per SIMD; the two dense contractions are "
+                        "12 % of its time (profiles/r02_psd_phases_wave.json)",
                 "kernel_share_of_step": shares["psd_projection"],
             }
         out = {

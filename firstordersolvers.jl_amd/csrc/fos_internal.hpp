@@ -305,7 +305,7 @@ void launch_cones_elementwise(const LaunchCtx& c, double2* out, const double2* i
 void launch_cones_soc(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones);
 void launch_cones_exp(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones);
 int  launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones,
-                      int kmax, double* gscratch, const double* vin, double* vout, int have_prev, int* stats, int phase_limit);
+                      int kmin, int kmax, double* gscratch, const double* vin, double* vout, int have_prev, int* stats, int phase_limit);
 size_t psd_scratch_bytes(int kmax, int ncones);
 size_t psd_basis_doubles(int kmax, int ncones);
 

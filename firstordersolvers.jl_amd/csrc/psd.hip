@@ -421,6 +421,320 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Order 64, ONE WAVEFRONT per matrix, the Jacobi iteration in REGISTERS.
+//
+// The workgroup kernel above spends its sweeps on LDS traffic (every step re-reads and re-writes the 32 KB array) and on a
+// barrier per step; its rotation angles and dot-product reductions are replicated over the 8 lanes of a pair.  Here lane
+// (s, h) = (lane & 31, lane >> 5) owns rows 32 h .. 32 h + 31 of the two columns of seat pair s (64 doubles in registers), the
+// three dot products of a pair are one add across the two halves (v_permlane32_swap), and the pairs follow the ODD-EVEN
+// TRANSPOSITION ordering: 64 seats in a line, even steps rotate seats (2s, 2s+1) -- both columns in the same lane, no data
+// movement at all -- odd steps rotate seats (2s+1, 2s+2): lane s fetches the partner column from lane s+1 and sends its own
+// rotated column back (DPP wave shifts, 64 + 64 dword moves); after every rotation the two columns swap seats, so that in 64
+// steps every pair of columns has met exactly once.  No LDS and no barrier inside a sweep; 1024 matrices are one wavefront
+// on each of the 1024 SIMDs.  LDS (one 64 x 66 array per wavefront) only stages the packed input, the two matrix-core
+// products (G0 = M' V_prev, P = G diag(w) G') and the packed output.  Same rotation formulas, thresholds, shift and weights as
+// the workgroup kernel; the basis buffers are interchangeable.
+constexpr int P64_LD = 66;
+constexpr int P64_LEN = 64 * 65 / 2;
+// (row, column) of every entry of the packed lower triangle of an order-64 matrix: i | j << 8
+struct Psd64Index {
+    unsigned short ij[P64_LEN + 32];
+    constexpr Psd64Index() : ij() {
+        int idx = 0;
+        for (int j = 0; j < 64; ++j)
+            for (int i = j; i < 64; ++i) ij[idx++] = (unsigned short)(i | (j << 8));
+        for (; idx < P64_LEN + 32; ++idx) ij[idx] = 0;
+    }
+};
+__device__ const Psd64Index psd64_index = Psd64Index();
+__host__ inline size_t psd64w_lds_bytes() { return (size_t)(64 * P64_LD + 64 + 64 + 8) * sizeof(double); }
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_shift_f64(double old, double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(old), lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(old), hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_WAVE_SHL1 = 0x130;   // lane i reads lane i + 1 (lane 63 keeps `old`)
+constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i reads lane i - 1 (lane 0 keeps `old`)
+
+// v[lane] + v[lane ^ 32] in every lane, the same bits in both
+__device__ __forceinline__ double half_sum(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+// the rotation that makes two columns with squared norms a, b and product g orthogonal (same formulas as jacobi64)
+__device__ __forceinline__ void jacobi_angle(double a, double b, double g, double gg, double ab, double& cs, double& sn, int& big) {
+    const double d = b - a;
+    const double rh = fast_rsqrt(d * d + 4.0 * gg);
+    const double c2 = 0.5 + 0.5 * fabs(d) * rh;
+    const double rc = fast_rsqrt(c2);
+    cs = c2 * rc;
+    sn = copysign(g * rh * rc, d * g);
+    if (gg > JACOBI_SMALL2 * ab || sn * sn > JACOBI_SMALL2) big = 1;
+}
+
+// g = U . V over the 64 rows (the squared norms a, b are NOT recomputed per step: they travel with the columns and are
+// updated by the rotation -- a' = a - t g, b' = b + t g, t = tan(theta) -- and refreshed from the columns at every sweep start)
+__device__ __forceinline__ double dot32(const double (&U)[32], const double (&V)[32]) {
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 32; r += 4) {
+        g0 += U[r] * V[r]; g1 += U[r + 1] * V[r + 1]; g2 += U[r + 2] * V[r + 2]; g3 += U[r + 3] * V[r + 3];
+    }
+    return half_sum((g0 + g1) + (g2 + g3));
+}
+__device__ __forceinline__ double norm32(const double (&U)[32]) { return dot32(U, U); }
+
+// even step: the two columns of the lane's own seat pair
+__device__ __forceinline__ void jstep_even(double (&U)[32], double (&V)[32], double& a, double& b, double tol2, int& rotated, int& big) {
+    const double g = dot32(U, V);
+    const double gg = g * g, ab = a * b;
+    const bool need = gg > tol2 * ab;
+    if (__ballot(need) == 0) return;
+    double cs = 1.0, sn = 0.0;
+    if (need) {
+        rotated = 1;
+        jacobi_angle(a, b, g, gg, ab, cs, sn, big);
+        const double tg = sn / cs * g;
+        a = fmax(a - tg, 0.0); b = b + tg;
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const double u = U[r], v = V[r];
+        U[r] = cs * u - sn * v;
+        V[r] = sn * u + cs * v;
+    }
+}
+
+// odd step: the lane's column U (seat 2s+1, squared norm a) meets column W of lane s+1 (seat 2s+2, squared norm bw); afterwards
+// the rotated partner takes the lane's seat and the rotated own column moves up into W of lane s+1.  Seat pair 31 has no upper
+// neighbour: its U stays, and what it sends "up" -- into lane (0, h=1), which has no lower neighbour -- is that lane's own W,
+// which it has just fetched.
+__device__ __forceinline__ void jstep_odd(double (&U)[32], double (&W)[32], double& a, double& bw, bool last, double tol2, int& rotated, int& big) {
+    double X[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) X[r] = dpp_shift_f64<DPP_WAVE_SHL1>(0.0, W[r]);
+    double b = dpp_shift_f64<DPP_WAVE_SHL1>(0.0, bw);
+    const double g = dot32(U, X);
+    const double gg = g * g, ab = a * b;
+    const bool need = !last && gg > tol2 * ab;
+    double cs = 1.0, sn = 0.0, an = a;
+    if (need) {
+        rotated = 1;
+        jacobi_angle(a, b, g, gg, ab, cs, sn, big);
+        const double tg = sn / cs * g;
+        an = fmax(a - tg, 0.0); b = b + tg;
+    }
+    // new own seat = c1 U + c2 X ; sent up = c3 U + c4 X      (rotation + seat swap; identity for the last seat pair)
+    const double c1 = last ? 1.0 : sn, c2 = last ? 0.0 : cs, c3 = last ? 0.0 : cs, c4 = last ? 1.0 : -sn;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const double u = U[r], x = X[r];
+        const double up = c3 * u + c4 * x;
+        U[r] = c1 * u + c2 * x;
+        W[r] = dpp_shift_f64<DPP_WAVE_SHR1>(W[r], up);
+    }
+    // the squared norms travel with their columns
+    a = last ? a : b;
+    bw = dpp_shift_f64<DPP_WAVE_SHR1>(bw, last ? b : an);
+}
+
+template <bool WARM>
+__global__ __launch_bounds__(64) void psd64_wave_kernel(d2* __restrict__ out, const d2* __restrict__ in, const ConeDesc* __restrict__ cones,
+                                                        const double* __restrict__ vin, double* __restrict__ vout, size_t vstride,
+                                                        int have_prev, int* __restrict__ stats, int phase_limit) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int LD = P64_LD;
+    const int lane = threadIdx.x;
+    const int cone = blockIdx.x >> 1, part = blockIdx.x & 1;
+    const ConeDesc cd = cones[cone];
+    const bool dual = (cd.dual_part == part);
+    const double sgn = dual ? -1.0 : 1.0;
+    const double* __restrict__ x = reinterpret_cast<const double*>(in + cd.start) + part;
+    double* __restrict__ y = reinterpret_cast<double*>(out + cd.start) + part;
+    double* G = smem;                            // [64][LD], column-major
+    double* wgt = G + 64 * LD;                   // [64]
+    double* inv = wgt + 64;                      // [64]
+
+    // ---- load: M = smat(sgn x), diagonal scaled by sqrt(2): 33 coalesced loads per lane, all in flight together
+    double fro = 0.0;
+    {
+        double v[33];
+        unsigned short ij[33];
+#pragma unroll
+        for (int q = 0; q < 33; ++q) {
+            const int idx = q * 64 + lane;
+            ij[q] = psd64_index.ij[idx];
+            v[q] = idx < P64_LEN ? x[2 * (int64_t)idx] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 33; ++q) {
+            const int i = ij[q] & 0xFF, j = ij[q] >> 8;
+            double w = sgn * v[q];
+            if (i == j) { w *= SQRT2; fro += w * w; }
+            else fro += 2.0 * w * w;
+            if (q * 64 + lane < P64_LEN) {
+                G[i + j * LD] = w;
+                G[j + i * LD] = w;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
+    const double sigma = (WARM ? 1.001 : 0.505) * sqrt(fro);
+    __syncthreads();
+    G[lane + lane * LD] += sigma;
+    __syncthreads();
+    if (phase_limit == 1) return;
+
+    const int lr = lane & 15, lk = lane >> 4;
+    if constexpr (WARM) {
+        if (have_prev && sigma > 0.0) {
+            // G0 = M' V_prev : 16 tiles of 16 k-steps on the matrix cores, operands as in psd_kernel
+            const double* __restrict__ Vp = vin + (size_t)blockIdx.x * vstride;
+            double bv[4][16];
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) bv[jb][kk] = Vp[(size_t)(jb * 16 + lr) * 64 + kk * 4 + lk];
+            v4d acc[4][4];
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                double ga[16];
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) ga[kk] = G[ib * 16 + lr + (kk * 4 + lk) * LD];
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    acc[ib][jb] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) acc[ib][jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[kk], bv[jb][kk], acc[ib][jb], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) G[ib * 16 + lk + 4 * r + (jb * 16 + lr) * LD] = acc[ib][jb][r];
+            __syncthreads();
+        }
+    }
+    if (phase_limit == 2) return;
+
+    // ---- one-sided Jacobi, odd-even ordering, in registers
+    const int s = lane & 31, h = lane >> 5;
+    double A[32], B[32];
+    {
+        const double* ga = G + 32 * h + (2 * s) * LD;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) { A[r] = ga[r]; B[r] = ga[r + LD]; }
+    }
+    int nsweeps = 0;
+    if (sigma > 0.0) {
+        const double tol = 64.0 * 2.220446049250313e-16;
+        const double tol2 = tol * tol;
+        const bool last = s == 31;
+        for (int sweep = 0; sweep < PSD_MAX_SWEEPS; ++sweep) {
+            int rotated = 0, big = 0;
+            nsweeps = sweep + 1;
+            double na = norm32(A), nb = norm32(B);
+            for (int q = 0; q < 16; ++q) {
+                jstep_even(A, B, na, nb, tol2, rotated, big);          // seats (2s, 2s+1) = (A, B); afterwards seat 2s+1 holds A
+                jstep_odd(A, B, na, nb, last, tol2, rotated, big);     // seat 2s+1 (A) with seat 2s+2 (B of lane s+1)
+                jstep_even(A, B, na, nb, tol2, rotated, big);          // afterwards seat 2s+1 holds B
+                jstep_odd(B, A, nb, na, last, tol2, rotated, big);     // seat 2s+1 (B) with seat 2s+2 (A of lane s+1)
+            }
+            if (__ballot(rotated) == 0) break;
+            if (__ballot(big) == 0) break;
+        }
+    }
+    if (stats && lane == 0) stats[blockIdx.x] = nsweeps;
+    if (phase_limit == 3) return;
+
+    // ---- weights, new basis
+    {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) { sa += A[r] * A[r]; sb += B[r] * B[r]; }
+        sa = half_sum(sa); sb = half_sum(sb);
+        __syncthreads();
+        double* ga = G + 32 * h + (2 * s) * LD;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) { ga[r] = A[r]; ga[r + LD] = B[r]; }
+        if (h == 0) {
+            const double na = sqrt(sa), nb = sqrt(sb);
+            wgt[2 * s] = na > sigma ? (na - sigma) / sa : 0.0;
+            wgt[2 * s + 1] = nb > sigma ? (nb - sigma) / sb : 0.0;
+            inv[2 * s] = na > 0.0 ? 1.0 / na : 0.0;
+            inv[2 * s + 1] = nb > 0.0 ? 1.0 / nb : 0.0;
+        }
+        __syncthreads();
+    }
+    if constexpr (WARM) {
+        double* __restrict__ Vn = vout + (size_t)blockIdx.x * vstride;
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) {
+            const double sc = inv[j];
+            Vn[j * 64 + lane] = (sigma > 0.0 && sc > 0.0) ? G[lane + j * LD] * sc : (lane == j ? 1.0 : 0.0);
+        }
+    }
+    if (phase_limit == 4) return;
+
+    // ---- P = (G diag(wgt)) G' : the 10 tiles on and below the diagonal, written over G, then packed
+    {
+        double fr[4][16], wk[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) wk[kk] = wgt[kk * 4 + lk];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) fr[ib][kk] = G[ib * 16 + lr + (kk * 4 + lk) * LD];
+        v4d acc[10];
+        int t = 0;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int ib = jb; ib < 4; ++ib, ++t) {
+                acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wk[kk] * fr[ib][kk], fr[jb][kk], acc[t], 0, 0, 0);
+            }
+        __syncthreads();
+        t = 0;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int ib = jb; ib < 4; ++ib, ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) G[ib * 16 + lk + 4 * r + (jb * 16 + lr) * LD] = acc[t][r];
+        __syncthreads();
+    }
+    {
+        double xv[33];
+        unsigned short ij[33];
+#pragma unroll
+        for (int q = 0; q < 33; ++q) {
+            const int idx = q * 64 + lane;
+            ij[q] = psd64_index.ij[idx];
+            xv[q] = (dual && idx < P64_LEN) ? x[2 * (int64_t)idx] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 33; ++q) {
+            const int idx = q * 64 + lane;
+            const int i = ij[q] & 0xFF, j = ij[q] >> 8;
+            double v = G[i + j * LD];
+            if (i == j) v *= INV_SQRT2;
+            if (idx < P64_LEN) y[2 * (int64_t)idx] = xv[q] + v;
+        }
+    }
+}
+
 size_t psd_scratch_bytes(int kmax, int ncones) {
     if (ncones <= 0) return 0;
     if (psd_lds_bytes(kmax) <= 160 * 1024 - 256) return 0;
@@ -432,9 +746,20 @@ size_t psd_basis_doubles(int kmax, int ncones) {       // one warm-start basis b
     return (size_t)2 * ncones * (size_t)kmax * kmax;
 }
 
-int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones, int kmax, double* gscratch,
+int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones, int kmin, int kmax, double* gscratch,
                      const double* vin, double* vout, int have_prev, int* stats, int phase_limit) {
     if (ncones <= 0) return FOS_OK;
+    // every cone of order 64: one wavefront per matrix, sweeps in registers (FOS_PSD_WAVE=0: the workgroup kernel)
+    static const bool wave_env = !(getenv("FOS_PSD_WAVE") && atoi(getenv("FOS_PSD_WAVE")) == 0);
+    if (kmin == 64 && kmax == 64 && wave_env) {
+        const size_t wl = psd64w_lds_bytes();
+        const size_t vs = (size_t)64 * 64;
+        if (vin && vout)
+            hipLaunchKernelGGL((psd64_wave_kernel<true>), dim3(2 * ncones), dim3(64), wl, c.stream, out, in, cones, vin, vout, vs, have_prev, stats, phase_limit);
+        else
+            hipLaunchKernelGGL((psd64_wave_kernel<false>), dim3(2 * ncones), dim3(64), wl, c.stream, out, in, cones, nullptr, nullptr, vs, 0, stats, phase_limit);
+        return FOS_OK;
+    }
     const size_t lds = psd_lds_bytes(kmax);
     const bool use_lds = lds <= 160 * 1024 - 256;
     const bool warm = vin && vout && kmax <= 64 && use_lds;

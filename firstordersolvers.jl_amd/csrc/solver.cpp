@@ -64,12 +64,16 @@ struct RoctxRange {
 
 static int rccl_load() {
     if (g_rccl.lib) return FOS_OK;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // ONE copy of RCCL per process: a host that already carries one (PyTorch ships its own librccl.so) must be joined, not
+    // doubled -- two copies interpose each other's globals and the process dies in their destructors at exit.  So: the copy that
+    // is already loaded, if any; otherwise a private one (local scope, own symbols first) that a later-loaded copy cannot touch.
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
     void* lib = nullptr;
     for (const char* nm : names) {
-        lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
         if (lib) break;
     }
+    for (int k = 0; !lib && k < 3; ++k) lib = dlopen(names[k], RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
     if (!lib) { set_error("cannot dlopen librccl.so: %s", dlerror()); return FOS_ECOMM; }
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
@@ -127,7 +131,7 @@ struct fos_solver {
     uint8_t* ew_op = nullptr;
     ConeDesc* soc = nullptr; int nsoc = 0;
     ConeDesc* expc = nullptr; int nexp = 0;
-    ConeDesc* psd = nullptr; int npsd = 0; int psd_kmax = 0;
+    ConeDesc* psd = nullptr; int npsd = 0; int psd_kmax = 0, psd_kmin = 0;
     double* psd_scratch = nullptr;
     double* psd_V[2] = {nullptr, nullptr};     // warm-start eigenvector bases (ping-pong), orders <= 64
     int psd_cur = 0, psd_have_prev = 0;
@@ -455,7 +459,7 @@ int prox_cones(fos_solver* h, d2* out, const d2* in) {
     launch_cones_soc(c, out, in, h->soc, h->nsoc);
     launch_cones_exp(c, out, in, h->expc, h->nexp);
     const int pe = h->npsd > 0 ? prof_begin(h, FOS_PROF_PSD, 0, h->prof_seen[FOS_PROF_PSD]++) : -1;
-    FOS_TRY(launch_cones_psd(c, out, in, h->psd, h->npsd, h->psd_kmax, h->psd_scratch,
+    FOS_TRY(launch_cones_psd(c, out, in, h->psd, h->npsd, h->psd_kmin, h->psd_kmax, h->psd_scratch,
                              h->psd_V[h->psd_cur], h->psd_V[1 - h->psd_cur], h->psd_have_prev, h->psd_stats, h->psd_phase_limit));
     prof_end(h, pe);
     // (a diagnostic launch truncated before the basis store leaves the previous basis current)
@@ -853,6 +857,8 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     h->npsd = (int)psd.size();
     FOS_TRY(dev_upload(h, &h->soc, soc));
     for (auto& cd : psd) h->psd_kmax = std::max(h->psd_kmax, cd.k);
+    h->psd_kmin = h->psd_kmax;
+    for (auto& cd : psd) h->psd_kmin = std::min(h->psd_kmin, cd.k);
     FOS_TRY(dev_upload(h, &h->psd, psd));
     size_t sb = psd_scratch_bytes(h->psd_kmax, h->npsd);
     if (sb) FOS_TRY(dev_alloc(h, &h->psd_scratch, sb / sizeof(double)));

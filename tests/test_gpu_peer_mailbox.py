@@ -288,7 +288,6 @@ def test_row_sharded_single_rank_matches_unsharded(pkg, oracle):
     reproduce the ordinary handle: operators to rounding, whole solves to the same status / iteration count / solution.
     (The multi-rank sums are checked at the oracle level by tests/test_sharding_gloo.py::test_row_sharded_oracle_matches_unsharded;
     the row-sharded HIP path has never run on two GPUs.)"""
-    import torch
     prob = pkg.workloads.small_mixed()
     d0 = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     d1 = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2, row_sharded=True)
@@ -381,8 +380,8 @@ def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname):
     KKT operator and the status sums on a common vector equal the unsharded handle's to rounding; the first outer iteration
     (one CG solve) reproduces the unsharded handle with the same CG count; ten iterations follow it to 1e-3 (as the oracle's
     own sharded-vs-unsharded comparison, tests/test_sharding_gloo.py)."""
+    import multiprocessing as mp
     import socket
-    import torch.multiprocessing as mp
     iters, world = 10, 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
