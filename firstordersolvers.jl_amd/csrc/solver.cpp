@@ -342,10 +342,12 @@ int kkt_apply_full(fos_solver* h, const LaunchCtx& c, const d2* w, d2* out) {
 
 // conjugategradient!(x, KKTMatrix(Q), rhs, r, p, Ap; tol, max_iters)      conjugategradients.jl:31-55
 // Device resident: the host enqueues iterations AHEAD (every CG kernel is gated on DevState.done) and polls once per batch.
-int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t* iters) {
+// `apply_on` (default: x): the vector the start residual's operator product is taken of -- prox_affine passes x - (0, in.y)
+// together with rhs = in, which is rhs - M x without ever forming rhs (see there).
+int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t* iters, const d2* apply_on = nullptr) {
     LaunchCtx c = h->ctx();
     int fr = 0;
-    FOS_TRY(kkt_apply_full(h, c, x, h->AP));                           // :32  mul!(Ap, A, x)
+    FOS_TRY(kkt_apply_full(h, c, apply_on ? apply_on : x, h->AP));    // :32  mul!(Ap, A, x)
     launch_cg_init(c, rhs, h->AP, h->R, h->PB[1]);                     // :33-34   (p_1 in buffer 1)
     FOS_TRY(finish_reduce(h, c, c.vec_blocks, 1, 0, &fr));
     launch_cg_init_finalize(c, h->R, tol, maxit, fr);                  // :35-36
@@ -433,20 +435,28 @@ int prox_affine(fos_solver* h, const d2* x) {
     if (h->direct) return prox_affine_direct(h, x);
     RoctxRange range("fos:prox_affine (rhs build + warm-started CG over the KKT operator)");
     LaunchCtx c = h->ctx();
-    int fr = 0;
-    launch_q1(c, Q_RHS, x, 1, 1.0, h->RHS);                            // :94-95
-    FOS_TRY(finish_reduce(h, c, c.S.npart, 1, 0, &fr, c.S.part_off));
-    launch_q1_finalize(c, Q_RHS, x, 1, 1.0, h->RHS, fr);
+    // The right-hand side [x1 - Q x2; 0] (:94-95) costs a sweep over A, and CG starts with another one for rhs - M y (:32-33).
+    // Since M [0; x2] = [-Q x2; -x2], rhs = x + M [0; x2] and the start residual is  x - M (y - [0; x2]) : ONE sweep, applied
+    // to the warm start shifted by the input's second part, and rhs is never formed (FOS_FUSED_RHS=0: the two sweeps).
+    static const bool fused_rhs = !(getenv("FOS_FUSED_RHS") && atoi(getenv("FOS_FUSED_RHS")) == 0);
+    if (!fused_rhs) {
+        int fr = 0;
+        launch_q1(c, Q_RHS, x, 1, 1.0, h->RHS);                        // :94-95
+        FOS_TRY(finish_reduce(h, c, c.S.npart, 1, 0, &fr, c.S.part_off));
+        launch_q1_finalize(c, Q_RHS, x, 1, 1.0, h->RHS, fr);
+    }
     if (h->firstrun) {                                                  // :101-104
         FOS_HIP(hipMemcpyAsync(h->SOL, x, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));
         h->firstrun = false;
     }
+    if (fused_rhs) launch_shift_part2(c, h->RHS, h->SOL, x);           // RHS buffer := y - [0; x2]
     // :108-112   tol = max(0.2^sqrt(i), size(A,2)*eps())
     const double eps = 2.220446049250313e-16;
     double tol = std::max(std::pow(0.2, std::sqrt((double)h->prox_i)), (double)h->l_global * eps);
     h->prox_i += 1;                                                     // :114
     int64_t it = 0;
-    FOS_TRY(cg_solve(h, h->SOL, h->RHS, tol, 1000, &it));               // :115-117 ; y aliases xinit (:106,:122)
+    if (fused_rhs) FOS_TRY(cg_solve(h, h->SOL, x, tol, 1000, &it, h->RHS));
+    else FOS_TRY(cg_solve(h, h->SOL, h->RHS, tol, 1000, &it));          // :115-117 ; y aliases xinit (:106,:122)
     h->cgiter = it;                                                     // :121
     return FOS_OK;                                                      // :124 y2 .*= beta with beta = 1
 }

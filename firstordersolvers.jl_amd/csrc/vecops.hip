@@ -329,6 +329,16 @@ __global__ __launch_bounds__(VEC_THREADS) void dykstra_corr_kernel(int64_t l, d2
     }
 }
 
+// out = y - [0; x2] in the interleaved layout: (y.x, y.y - x.y)        (prox_affine: the vector the CG start residual applies M to)
+__global__ __launch_bounds__(VEC_THREADS) void shift_part2_kernel(int64_t l, d2* __restrict__ out, const d2* __restrict__ y, const d2* __restrict__ x) {
+    for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
+        const d2 yi = y[i];
+        out[i] = make_double2(yi.x, yi.y - x[i].y);
+    }
+}
+void launch_shift_part2(const LaunchCtx& c, double2* out, const double2* y, const double2* x) {
+    hipLaunchKernelGGL(shift_part2_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, y, x);
+}
 void launch_axpby(const LaunchCtx& c, double2* out, double a, const double2* x, double b, const double2* y) {
     hipLaunchKernelGGL(axpby_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, a, x, b, y);
 }
