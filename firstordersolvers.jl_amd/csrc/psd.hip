@@ -749,9 +749,19 @@ size_t psd_basis_doubles(int kmax, int ncones) {       // one warm-start basis b
 int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones, int kmin, int kmax, double* gscratch,
                      const double* vin, double* vout, int have_prev, int* stats, int phase_limit) {
     if (ncones <= 0) return FOS_OK;
-    // every cone of order 64: one wavefront per matrix, sweeps in registers (FOS_PSD_WAVE=0: the workgroup kernel)
-    static const bool wave_env = !(getenv("FOS_PSD_WAVE") && atoi(getenv("FOS_PSD_WAVE")) == 0);
-    if (kmin == 64 && kmax == 64 && wave_env) {
+    constexpr int MAXDEV = 64;
+    static int cus_of[MAXDEV] = {0};
+    static bool attr_set[MAXDEV] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) { set_error("hipGetDevice failed or device id >= %d", MAXDEV); return FOS_EHIP; }
+    if (!cus_of[dev]) { hipDeviceProp_t prop; cus_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
+    const int cus = cus_of[dev];
+    // every cone of order 64: one wavefront per matrix, sweeps in registers (FOS_PSD_WAVE=0: the workgroup kernel; =1: always).
+    // With fewer matrices than half the CUs (a shard of a multi-GPU run) most SIMDs would idle next to one busy wavefront: the
+    // 512-thread workgroup kernel is then as fast or faster (128 matrices: 166 vs 173 us).
+    const char* wave_str = getenv("FOS_PSD_WAVE");          // (read per call: the tests switch it)
+    const int wave_env = wave_str ? atoi(wave_str) : -1;
+    if (kmin == 64 && kmax == 64 && wave_env != 0 && (wave_env == 1 || 4 * ncones > cus)) {
         const size_t wl = psd64w_lds_bytes();
         const size_t vs = (size_t)64 * 64;
         if (vin && vout)
@@ -765,13 +775,6 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     const bool warm = vin && vout && kmax <= 64 && use_lds;
     // few matrices (a shard of a multi-GPU run, a small problem): 512 threads per matrix cut the latency of one
     // projection; many matrices: 256 threads (4 per CU) maximise throughput.  Per DEVICE: a process may hold handles on several.
-    constexpr int MAXDEV = 64;
-    static int cus_of[MAXDEV] = {0};
-    static bool attr_set[MAXDEV] = {false};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) { set_error("hipGetDevice failed or device id >= %d", MAXDEV); return FOS_EHIP; }
-    if (!cus_of[dev]) { hipDeviceProp_t prop; cus_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
-    const int cus = cus_of[dev];
     const bool wide = (warm && (2 * ncones <= 2 * cus) && !getenv("FOS_PSD_NARROW")) || (warm && getenv("FOS_PSD_WIDE"));
     if (use_lds && !attr_set[dev]) {          // hipFuncSetAttribute acts on the CURRENT device
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, false, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);

@@ -1,6 +1,13 @@
 """Golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py from the oracle).
 CPU: the oracle still reproduces them (guards against silent edits of the checker).
-GPU: the HIP path reproduces them through the C ABI, WITHOUT importing the oracle."""
+GPU: the HIP path reproduces them through the C ABI, WITHOUT importing the oracle.
+
+What these fixtures can and cannot show: they come from THIS repository's numpy oracle (Julia is not available to run the
+reference itself), so they catch drift of either side from the oracle -- not a mistake the oracle shares with nobody.  The
+oracle's agreement with the reference rests on tests/test_oracle_reference.py (the reference's own known answers: the README
+NNLS problem, test/testPSD.jl's 2x2 projection, test/testprint.jl's formats, the CG / AffinePlusLinear / HSDEMatrix identities
+against dense linear algebra) and, for the cones whose arithmetic lives in ProximalOperators.jl, on the oracle-free projection
+certificates (tests/cone_certificates.py)."""
 from pathlib import Path
 
 import numpy as np

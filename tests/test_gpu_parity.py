@@ -256,7 +256,15 @@ PSD_KNOWN = np.array([[0.03909044662082823, -0.00823811392936668],
                       [-0.00823811392936668, 0.00173614084718757]])
 
 
-def test_psd_known_answer_and_sizes(pkg, dev_ops):
+@pytest.fixture(params=["wave", "workgroup"])
+def psd64_kernel(request, monkeypatch):
+    """Order-64 cones have two kernels (one wavefront per matrix / one workgroup per matrix; the library picks by batch size):
+    the PSD tests run both."""
+    monkeypatch.setenv("FOS_PSD_WAVE", "1" if request.param == "wave" else "0")
+    return request.param
+
+
+def test_psd_known_answer_and_sizes(pkg, dev_ops, psd64_kernel):
     """test/testPSD.jl:14-19 known answer through the GPU PSD kernel; random orders 1..120 (LDS path) and 150
     (global-scratch path); degenerate spectra (+-lambda pairs, zero matrix, rank one)."""
     r2 = math.sqrt(2)
@@ -298,7 +306,7 @@ def test_psd_known_answer_and_sizes(pkg, dev_ops):
             assert np.linalg.norm(out - ref) <= 5e-13 * max(1.0, np.linalg.norm(z)), k
 
 
-def test_psd_warm_start_drift_and_clustered_spectra(pkg, dev_ops):
+def test_psd_warm_start_drift_and_clustered_spectra(pkg, dev_ops, psd64_kernel):
     """The warm-started Jacobi (previous eigenvector basis, confirming sweep skipped when a sweep's rotations were all tiny):
     slowly drifting matrices as in the solver's steady state, clustered / repeated eigenvalues, eigenvalues straddling zero by
     1e-9, wide dynamic range -- order 64 (register fast path) and 16 (generic path); every call against LAPACK (oracle)."""
