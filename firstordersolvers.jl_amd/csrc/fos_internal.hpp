@@ -64,15 +64,17 @@ constexpr int TILE_TC_MAX = 64;     // columns (steps) per tile: 32 KB of values
 constexpr int TILE_GROUP = 8;       // steps per butterfly; stored steps are padded to a multiple
 
 // Window panels (gather-bound random-sparse operators, C5 class).  A PANEL = WIN_ROWS consecutive rows of S, the unit of
-// work of ONE WORKGROUP, which walks the column WINDOWS (WIN_COLS consecutive entries of the stacked vector) its rows touch:
+// work of ONE WORKGROUP (two of them share a CU), which walks the column WINDOWS (WIN_COLS consecutive entries of the stacked vector) its rows touch:
 // the window is staged in LDS by coalesced loads, the panel's non-zeros inside it are multiplied against LDS (no 128-byte L1
 // line fill per 16-byte gather: the bound of the row-block formats on such operators), and the row sums are kept in LDS across
 // the windows.  Inside a (panel, window) SEGMENT the rows that have entries there are sorted by their entry count (SELL-sigma)
 // and cut into SLICES of 64 rows stored lane-major (lane = row, step = entry; padded to the slice's longest row: ~10 %, not the
 // 40-50 % of panel-wide ELL), with 16-bit column offsets inside the window and a 16-bit local row id per lane.
-constexpr int WIN_COLS = 4096;      // window: 64 KB of double2 in LDS
-constexpr int WIN_ROWS = 2048;      // panel: 32 KB of row sums in LDS
-constexpr int WIN_THREADS = 1024;   // 16 wavefronts share the window; one workgroup per CU (96 KB of LDS)
+constexpr int WIN_COLS = 3072;      // window: 48 KB of double2 in LDS
+constexpr int WIN_ROWS = 2016;      // panel: 31.5 KB of row sums in LDS
+constexpr int WIN_NSL = 3;          // slices per wavefront and segment whose first WIN_PRE steps are requested with the window
+constexpr int WIN_WG_PER_CU = 2;    // two workgroups per CU (2 x 80 KB of LDS): each hides the other's memory latency
+constexpr int WIN_THREADS = 512;    // 8 wavefronts share the window
 struct WinPanel { int32_t row0, nrows, seg0, nseg; };
 struct WinSeg { int32_t col0, ncols, slice0, nslice; };
 struct WinSlice { int64_t off; int32_t steps, pad; };       // values/columns at off + 64 t + lane (off a multiple of 64)

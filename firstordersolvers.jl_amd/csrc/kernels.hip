@@ -548,12 +548,18 @@ __device__ __forceinline__ void win_slice_compute(const DevBlkCsr& S, const WinS
 }
 
 // One segment = one (panel, window) tile.  EVERYTHING the segment needs from memory -- the window's vector elements and the
-// first WIN_PRE steps of two slices per wavefront -- is requested before the first barrier, so a segment costs one memory
-// latency, two barriers and the LDS work.  What bounds the walk is the NUMBER of segments a CU runs one after the other
-// (nrows x ncols / (WIN_ROWS x WIN_COLS x CUs)) times the latency of one, which grows once a wavefront has more slices than it
-// holds in registers.  Measured per C5 sweep (MI355X): row blocks 155 us; 2048 x 4096 tiles 116 us (kept); 4096 x 4096 tiles
-// 160 us (3 slices per wavefront and segment); 2048 x 2048 tiles with a register-double-buffered software pipeline across
-// segments 136-145 us (twice the barriers; the overlap does not pay for them); per-lane-count predicated loads 210-260 us.
+// first WIN_PRE steps of WIN_NSL slices per wavefront -- is requested before the first barrier, so a segment costs one memory
+// latency, two barriers and the LDS work.  The walk is LATENCY bound: its time is (segments a workgroup slot runs one after the
+// other) x (latency of one); with the sweep's parts switched off in turn, of 112 us per C5 sweep 63 were that skeleton, 20
+// the window gathers, 30 the slice loads and the multiply.  So what pays is more workgroup slots without proportionally more
+// segments: TWO workgroups of 512 threads per CU (2 x 80 KB of LDS: 3072-column windows, 2016-row panels, three slices per
+// wavefront in registers) run 20.7 segments per slot where one workgroup of 1024 threads (4096 x 2048, 96 KB) ran 32.
+// Measured per C5 sweep (MI355X): row blocks 155 us; 1 x 1024 threads, 2048 x 4096 tiles 112-116 us; 2 x 512 threads,
+// 2016 x 3072 tiles 93 us (kept).  Slower: 4096 x 4096 tiles with 1024 threads 139-160 us (a third / fourth slice per wavefront
+// falls into the dependent-load path); 2048 x 2048 tiles with a register-double-buffered software pipeline across segments
+// 136-145 us (twice the barriers); per-lane-count predicated loads 210-260 us; next segment's descriptors requested one segment
+// ahead by scalar loads 111.6 us (they share the LDS counter, so the LDS accesses wait for them anyway), by vector loads from a
+// flat per-(segment, wavefront) table 127 us.
 template <class G, class Epi>
 __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& epi, double* lds) {
     constexpr int NRHS = G::NRHS;
@@ -573,17 +579,17 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
             const cptr_seg sgp = (cptr_seg)(S.wseg + sgi);
             const int col0 = sgp->col0, ncols = sgp->ncols, slice0 = sgp->slice0, nslice = sgp->nslice;
             // ---- everything this segment needs from memory is requested here, in one go
-            WinSliceRegs r0, r1;
-            win_slice_desc(S, slice0 + wv, wv < nslice, r0);
-            win_slice_desc(S, slice0 + wv + NWAVES, wv + NWAVES < nslice, r1);
+            WinSliceRegs r[WIN_NSL];
+#pragma unroll
+            for (int u = 0; u < WIN_NSL; ++u) win_slice_desc(S, slice0 + wv + u * NWAVES, wv + u * NWAVES < nslice, r[u]);
             d2 wreg[WPT];
 #pragma unroll
             for (int q = 0; q < WPT; ++q) {
                 const int i = tid + q * WIN_THREADS;
                 wreg[q] = (i < ncols) ? gat.load(col0 + i) : make_double2(0.0, 0.0);
             }
-            win_slice_issue(S, slice0 + wv, lane, r0);
-            win_slice_issue(S, slice0 + wv + NWAVES, lane, r1);
+#pragma unroll
+            for (int u = 0; u < WIN_NSL; ++u) win_slice_issue(S, slice0 + wv + u * NWAVES, lane, r[u]);
             __syncthreads();                               // the previous window's readers are done (first pass: acc is zeroed)
 #pragma unroll
             for (int q = 0; q < WPT; ++q) {
@@ -591,13 +597,13 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
                 if (i < ncols) { if constexpr (NRHS == 2) win[i] = wreg[q]; else win[i] = wreg[q].x; }
             }
             __syncthreads();
-            win_slice_compute<NRHS>(S, r0, win, acc, lane);
-            win_slice_compute<NRHS>(S, r1, win, acc, lane);
-            for (int sl = slice0 + wv + 2 * NWAVES; sl < slice0 + nslice; sl += NWAVES) {      // (more than 2 x 16 slices: never at WIN_ROWS = 2048)
-                WinSliceRegs r;
-                win_slice_desc(S, sl, true, r);
-                win_slice_issue(S, sl, lane, r);
-                win_slice_compute<NRHS>(S, r, win, acc, lane);
+#pragma unroll
+            for (int u = 0; u < WIN_NSL; ++u) win_slice_compute<NRHS>(S, r[u], win, acc, lane);
+            for (int sl = slice0 + wv + WIN_NSL * NWAVES; sl < slice0 + nslice; sl += NWAVES) {      // (more slices than the registers hold: rare)
+                WinSliceRegs t;
+                win_slice_desc(S, sl, true, t);
+                win_slice_issue(S, sl, lane, t);
+                win_slice_compute<NRHS>(S, t, win, acc, lane);
             }
         }
         __syncthreads();
@@ -722,7 +728,7 @@ __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBl
 }
 
 // window-panel form of the sweep (stand-alone applies and CG iterations alike: no dual tiles, the p update is a kernel of its own)
-__global__ __launch_bounds__(WIN_THREADS) void kkt2_win_kernel(DevBlkCsr S, KktArgs a) {
+__global__ __launch_bounds__(WIN_THREADS, 4) void kkt2_win_kernel(DevBlkCsr S, KktArgs a) {
     if (a.gate && a.st->done) return;
     extern __shared__ __attribute__((aligned(16))) double wlds[];
     GatherW gat;
@@ -1045,7 +1051,7 @@ __global__ __launch_bounds__(DEF_THREADS) void q1_deferred_kernel(DevBlkCsr S, c
     block_reduce_store<NACC, DEF_THREADS>(epi.acc, red, partials + NACC * (int64_t)(S.nwg + blockIdx.x));
 }
 template <class Epi, int NACC>
-__global__ __launch_bounds__(WIN_THREADS) void q1_win_kernel(DevBlkCsr S, const double* __restrict__ vcomp, Epi epi, int nm,
+__global__ __launch_bounds__(WIN_THREADS, 4) void q1_win_kernel(DevBlkCsr S, const double* __restrict__ vcomp, Epi epi, int nm,
                                                              double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) double wlds[];
 #pragma unroll

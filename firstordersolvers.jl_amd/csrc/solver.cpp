@@ -757,7 +757,7 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     if (windowed) {
         // window panels: persistent workgroups, one per CU (96 KB of LDS each), walking the panels (measured on C5: 116 us per
         // sweep with 256 workgroups, 122 us with one workgroup per panel)
-        int nwg = std::min<int>((int)hs.wpanel.size(), cus);
+        int nwg = std::min<int>((int)hs.wpanel.size(), cus * WIN_WG_PER_CU);
         if (const char* e = getenv("FOS_SPMV_WG")) nwg = std::max(1, std::min<int>(atoi(e), (int)hs.wpanel.size()));
         if (nwg >= 8) nwg -= nwg % 8;
         hs.nwg = nwg;

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
+WIN_ROWS = 2016          # rows per window panel (csrc/fos_internal.hpp)
+
 
 def host_spmv(pkg, A, v, wg=0, waves=0):
     lib = pkg.lib.load()
@@ -186,7 +188,7 @@ def test_window_panels_host_emulation(pkg, shape, density, seed):
     out, st = _host_spmv_mode(pkg, A, v, 1)
     ref = np.concatenate([A.T @ v[n:], A @ v[:n]])
     assert np.allclose(out, ref, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(ref).max()))
-    assert st[12] == -(-(n + m) // 2048) and st[0] == 0            # panels of 2048 rows, no row blocks
+    assert st[12] == -(-(n + m) // WIN_ROWS) and st[0] == 0        # panels of WIN_ROWS rows, no row blocks
     assert st[15] >= 2 * A.nnz                                      # stored entries (padding included)
     out0, st0 = _host_spmv_mode(pkg, A, v, 0)                       # the same operator in row blocks / tiles
     assert np.allclose(out0, ref, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(ref).max())) and st0[12] == 0
@@ -196,13 +198,13 @@ def test_window_panels_chosen_for_large_random_sparse_only(pkg):
     """fos_create's choice (window_mode -1): a C5-like random-sparse operator with >= 64 panels goes to window panels with little
     padding; a small one, a dense LP (dual tiles) and a banded (run-compressed) one keep their row-block formats."""
     rng = np.random.default_rng(11)
-    m = n = 70000                                                   # 140 000 stacked rows = 69 panels
+    m = n = 70000                                                   # 140 000 stacked rows = 70 panels
     A = sp.random(m, n, density=20.0 / n, format="csc", random_state=rng, data_rvs=rng.standard_normal)
     v = rng.standard_normal(n + m)
     out, st = _host_spmv_mode(pkg, A, v, -1)
     ref = np.concatenate([A.T @ v[n:], A @ v[:n]])
     assert np.allclose(out, ref, rtol=1e-12, atol=1e-11)
-    assert st[12] == 69 and st[0] == 0
+    assert st[12] == -(-(n + m) // WIN_ROWS) and st[0] == 0
     assert st[15] <= 1.25 * 2 * A.nnz, (st[15], 2 * A.nnz)          # SELL-sigma slices: padding well under the 40-50 % of panel-wide ELL
     small = sp.random(3000, 2500, density=0.01, format="csc", random_state=rng, data_rvs=rng.standard_normal)
     assert _host_spmv_mode(pkg, small, rng.standard_normal(5500), -1)[1][12] == 0
