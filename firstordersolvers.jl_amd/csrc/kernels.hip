@@ -493,7 +493,7 @@ constexpr size_t win_lds_bytes(int nrhs) { return (size_t)(WIN_COLS + WIN_ROWS) 
 
 // What a wavefront holds of one 64-row slice while the window is being staged: the first WIN_PRE steps of its lane's values
 // and window offsets, requested BEFORE the barriers of the segment so that one memory latency covers the window and the matrix.
-constexpr int WIN_PRE = 8;
+constexpr int WIN_PRE = 6;
 struct WinSliceRegs {
     double v[WIN_PRE];
     unsigned c[WIN_PRE];
@@ -564,7 +564,7 @@ template <class G, class Epi>
 __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& epi, double* lds) {
     constexpr int NRHS = G::NRHS;
     constexpr int NWAVES = WIN_THREADS / 64;
-    constexpr int WPT = WIN_COLS / WIN_THREADS;            // window elements per thread
+    constexpr int WPT = (WIN_COLS + WIN_THREADS - 1) / WIN_THREADS;      // window elements per thread
     using E = typename std::conditional<NRHS == 2, d2, double>::type;
     typedef const __attribute__((address_space(4))) WinSeg* cptr_seg;
     E* win = reinterpret_cast<E*>(lds);
