@@ -167,6 +167,7 @@ struct fos_solver {
     int hit_max_accum = 0;
     bool firstrun2 = true;                     // HSDEMatrix.cgdata.firstrun
     int last_cg_pred = 0;
+    int cg_same_run = 0;                       // consecutive solves that took exactly last_cg_pred iterations
     const d2* last_checked = nullptr;          // vector the last checkstatus was evaluated on
 
     // sharding: scalar sums cross GPUs either by an in-stream RCCL all-reduce (comm) or through peer mailboxes (peer_on)
@@ -392,7 +393,10 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
         return FOS_OK;
     };
     static const int pred_slack = getenv("FOS_CG_SLACK") ? atoi(getenv("FOS_CG_SLACK")) : 1;   // iterations enqueued beyond the last solve's count (each costs a few gated no-op launches when not needed; too few costs a poll)
-    int first = h->last_cg_pred > 0 ? h->last_cg_pred + pred_slack : h->cg_chunk;
+    // (the slack iteration is dropped once three solves in a row took the same number of iterations: steady state of a
+    // well-conditioned problem -- C4: 17, 17, 17, ... -- where it would be three gated no-op launches per solve)
+    const int slack = (pred_slack == 1 && h->cg_same_run >= 3) ? 0 : pred_slack;
+    int first = h->last_cg_pred > 0 ? h->last_cg_pred + slack : h->cg_chunk;
     first = std::max(1, std::min(first, maxit));
     FOS_TRY(enqueue(first));
     FOS_TRY(poll_state(h));
@@ -404,6 +408,7 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     // profiling: launches enqueued past convergence were gated no-ops -- drop their event pairs
     for (size_t k = prof_start; k < h->prof_used; ++k)
         if (h->prof_recs[k].j > h->st_host->iter) h->prof_recs[k].cls = -1;
+    h->cg_same_run = (h->st_host->iter == h->last_cg_pred) ? h->cg_same_run + 1 : 0;
     h->last_cg_pred = h->st_host->iter;
     h->cg_total += h->st_host->iter;
     if (h->st_host->hit_max) h->hit_max_accum = 1;
