@@ -9,5 +9,5 @@ fallback: every compute call goes through the library and fails loudly if it is 
 from . import _lib as lib          # noqa: F401
 from . import workloads            # noqa: F401
 from .interface import (AP, DR, FISTA, GAP, GAPA, Dykstra, FOSAlgorithm, FOSMathProgModel, HipHSDE, HSDEStatus,  # noqa: F401
-                        Solution, solve, HEADER_CG, HEADER_DIRECT)
+                        LineSearchWrapper, Solution, solve, HEADER_CG, HEADER_DIRECT)
 from . import sharding             # noqa: F401

@@ -278,6 +278,7 @@ void launch_cg_init_finalize(const LaunchCtx& c, const double2* r, double tol, i
 void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate, int off = 0);   // partials[off.. +count][nacc] -> reduced[nacc] (+ peer exchange)
 
 // outer-loop vector kernels (gap.jl:48,58,78; gapa.jl:67,77,96-103; fista.jl:31-46; dykstra.jl)
+void launch_normdiff(const LaunchCtx& c, const double2* x, const double2* y);   // c.partials[0 .. vec_blocks) = partial sums of |x - y|^2
 void launch_shift_part2(const LaunchCtx& c, double2* out, const double2* y, const double2* x);   // out = (y.x, y.y - x.y)
 void launch_axpby(const LaunchCtx& c, double2* out, double a, const double2* x, double b, const double2* y);          // out = a x + b y
 void launch_relax_a12(const LaunchCtx& c, double2* out, const double2* y, const double2* x);                          // out = a12 y + (1-a12) x, a12 from state

@@ -167,6 +167,10 @@ struct fos_solver {
     int hit_max_accum = 0;
     bool firstrun2 = true;                     // HSDEMatrix.cgdata.firstrun
     int last_cg_pred = 0;
+    // LineSearchWrapper (wrappers/linesearch.jl): every ls_interval-th iteration is a 31-point step-length search
+    int64_t ls_interval = 0;
+    bool ls_now = false;                       // the iteration in flight is a line-search iteration (between step_once and step_finish)
+    double ls_log[34] = {0};                   // last search: ||res||, the 31 test residuals, the chosen alpha, the iteration
     int cg_same_run = 0;                       // consecutive solves that took exactly last_cg_pred iterations
     const d2* last_checked = nullptr;          // vector the last checkstatus was evaluated on
 
@@ -522,9 +526,62 @@ int status_check(fos_solver* h, const d2* z, double eps, fos_check_result* res) 
     return FOS_OK;
 }
 
+// ---- LineSearchWrapper(GAP / GAPA)                                   wrappers/linesearch.jl:36-75
+// S1!(y, x) = a1 prox_S1(x) + (1 - a1) x ,  S2!(y, x) = a2 prox_S2(x) + (1 - a2) x   (gap.jl:42-59; GAPA: a1 = a2 = alpha12, gapa.jl:61-79)
+// scratch: Y = tmp1 (the iterate the search starts from), XOLD = res, W = tmp3 -- unused by these two algorithms
+void ls_relax(fos_solver* h, const LaunchCtx& c, d2* out, const d2* y, const d2* x, int which) {
+    if (h->alg == FOS_ALG_GAPA) { launch_relax_a12(c, out, y, x); return; }
+    const double a = which == 1 ? h->alpha1 : h->alpha2;
+    launch_axpby(c, out, a, y, 1 - a, x);
+}
+int ls_normdiff(fos_solver* h, const LaunchCtx& c, const d2* x, const d2* y, double* out) {
+    launch_normdiff(c, x, y);
+    std::vector<double> part((size_t)c.vec_blocks);
+    FOS_HIP(hipMemcpyAsync(part.data(), c.partials, sizeof(double) * part.size(), hipMemcpyDeviceToHost, h->stream));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    double s = 0.0;
+    for (double v : part) s += v;
+    *out = std::sqrt(s);
+    return FOS_OK;
+}
+int ls_begin(fos_solver* h, const d2** check_on) {
+    LaunchCtx c = h->ctx();
+    FOS_HIP(hipMemcpyAsync(h->Y, h->X, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));     // tmp1 .= x            :41
+    FOS_TRY(prox_affine(h, h->X));                                                                  // S1!(tmp2, x)         :45
+    ls_relax(h, c, h->T1, h->SOL, h->X, 1);
+    FOS_TRY(prox_cones(h, h->T2, h->T1));                                                           // S2!(x, tmp2): prox + checkstatus :46
+    *check_on = h->T2;
+    return FOS_OK;
+}
+int ls_finish(fos_solver* h, int64_t i) {
+    LaunchCtx c = h->ctx();
+    ls_relax(h, c, h->X, h->T2, h->T1, 2);                                                          //   ... and its relaxation
+    launch_axpby(c, h->XOLD, 1.0, h->X, -1.0, h->Y);                                                // res .= x .- tmp1     :49
+    FOS_TRY(ls_normdiff(h, c, h->X, h->Y, &h->ls_log[0]));                                          // normres = norm(res)  :50
+    double best = INFINITY, abest = 1.0, a = 0.1;                                                   // :53-55
+    for (int k = 0; k <= 30; ++k) {                                                                 // :56
+        a = a * 1.8;                                                                                // :57
+        launch_axpby(c, h->X, 1.0, h->Y, a, h->XOLD);                                               // x .= tmp1 .+ a.*res  :58
+        FOS_TRY(prox_affine(h, h->X));                                                              // S1!(tmp2, x, nostatus) :60
+        ls_relax(h, c, h->T1, h->SOL, h->X, 1);
+        FOS_TRY(prox_cones(h, h->T2, h->T1));                                                       // S2!(tmp3, tmp2, nostatus) :61
+        ls_relax(h, c, h->W, h->T2, h->T1, 2);
+        double tr = 0.0;
+        FOS_TRY(ls_normdiff(h, c, h->X, h->W, &tr));                                                // testres = normdiff(x, tmp3) :62
+        h->ls_log[1 + k] = tr;
+        if (tr < best) { best = tr; abest = a; }                                                    // :64-67
+    }
+    launch_axpby(c, h->X, 1.0, h->Y, abest, h->XOLD);                                               // x .= tmp1 .+ abest.*res :70
+    h->ls_log[32] = abest;
+    h->ls_log[33] = (double)i;
+    return FOS_OK;
+}
+
 // one outer iteration; *check_on receives the vector checkstatus is evaluated on (the cone-feasible point)
 int step_once(fos_solver* h, int64_t i, const d2** check_on) {
     LaunchCtx c = h->ctx();
+    h->ls_now = h->ls_interval > 0 && (i % h->ls_interval) == 0;                                    // linesearch.jl:39
+    if (h->ls_now) return ls_begin(h, check_on);
     switch (h->alg) {
         case FOS_ALG_GAP: {                                              // gap.jl:61-80
             FOS_TRY(prox_affine(h, h->X));                               // S1!: prox!(y,S1,x)          :45
@@ -564,8 +621,9 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on) {
 }
 
 // the part of the step after checkstatus
-int step_finish(fos_solver* h) {
+int step_finish(fos_solver* h, int64_t i) {
     LaunchCtx c = h->ctx();
+    if (h->ls_now) { h->ls_now = false; return ls_finish(h, i); }
     switch (h->alg) {
         case FOS_ALG_GAP:
             launch_gap_final(c, h->X, h->T2, h->T1, h->alpha, h->alpha2);          // gap.jl:58,78
@@ -1077,6 +1135,7 @@ int fos_set_alg(fos_handle h, int alg, double alpha, double alpha1, double alpha
     if (alg < FOS_ALG_GAP || alg > FOS_ALG_DYKSTRA) { set_error("unknown algorithm %d", alg); return FOS_EINVAL; }
     FOS_HIP(hipSetDevice(h->device));
     h->alg = alg; h->alpha = alpha; h->alpha1 = alpha1; h->alpha2 = alpha2; h->beta = beta;
+    h->ls_interval = 0; h->ls_now = false;                              // a fresh algorithm is unwrapped (fos_set_linesearch follows)
     h->fista_t = 1.0;                                                   // fista.jl:24
     // fresh *Data: alpha12 = 2.0 (gapa.jl:29); y = xold = 0 (fista.jl:24); p = q = 0 (dykstra.jl:21)
     DevState z;
@@ -1238,7 +1297,7 @@ int fos_step(fos_handle h, int64_t i_first, int64_t count, int64_t checki, doubl
             FOS_TRY(status_check(h, check_on, eps, &r));
             h->last_checked = check_on;
         }
-        FOS_TRY(step_finish(h));
+        FOS_TRY(step_finish(h, i));
         ++done;
         if (do_check) {
             if (res) *res = r;
@@ -1249,6 +1308,23 @@ int fos_step(fos_handle h, int64_t i_first, int64_t count, int64_t checki, doubl
     if (iters_done) *iters_done = done;
     FOS_TRY(check_launch("fos_step"));
     FOS_HIP(hipStreamSynchronize(h->stream));
+    return FOS_OK;
+}
+
+// LineSearchWrapper(alg; lsinterval) around GAP (AP, DR) or GAPA: iterations i with i % lsinterval == 0 become a 31-point search of
+// the step length along S2(S1(x)) - x; 0 switches it off.  fos_linesearch_log: what the reference prints during the last search.
+int fos_set_linesearch(fos_handle h, int64_t lsinterval) {
+    if (!h || lsinterval < 0) { set_error("bad argument"); return FOS_EINVAL; }
+    if (lsinterval > 0 && h->alg != FOS_ALG_GAP && h->alg != FOS_ALG_GAPA) {
+        set_error("this algorithm does not support line search (support_linesearch: GAP and GAPA only, solvers/defaults.jl:22)");
+        return FOS_EUNSUPPORTED;
+    }
+    h->ls_interval = lsinterval;
+    return FOS_OK;
+}
+int fos_linesearch_log(fos_handle h, double* out34) {
+    if (!h || !out34) { set_error("NULL argument"); return FOS_EINVAL; }
+    memcpy(out34, h->ls_log, sizeof(h->ls_log));
     return FOS_OK;
 }
 

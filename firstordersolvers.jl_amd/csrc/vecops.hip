@@ -339,6 +339,19 @@ __global__ __launch_bounds__(VEC_THREADS) void shift_part2_kernel(int64_t l, d2*
 void launch_shift_part2(const LaunchCtx& c, double2* out, const double2* y, const double2* x) {
     hipLaunchKernelGGL(shift_part2_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, y, x);
 }
+// partial sums of |x - y|^2 over both parts (normdiff of wrappers/linesearch.jl:77-85), one record per workgroup
+__global__ __launch_bounds__(VEC_THREADS) void normdiff_kernel(int64_t l, const d2* __restrict__ x, const d2* __restrict__ y, double* __restrict__ partials) {
+    double acc[1] = {0.0};
+    for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
+        const d2 a = x[i], b = y[i];
+        const double dx = a.x - b.x, dy = a.y - b.y;
+        acc[0] += dx * dx + dy * dy;
+    }
+    block_reduce_store<1>(acc, partials + blockIdx.x);
+}
+void launch_normdiff(const LaunchCtx& c, const double2* x, const double2* y) {
+    hipLaunchKernelGGL(normdiff_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, y, c.partials);
+}
 void launch_axpby(const LaunchCtx& c, double2* out, double a, const double2* x, double b, const double2* y) {
     hipLaunchKernelGGL(axpby_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, a, x, b, y);
 }

@@ -19,6 +19,8 @@ from __future__ import annotations
 import ctypes as C
 import time
 
+import math
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -91,6 +93,50 @@ class Dykstra(FOSAlgorithm):
 
 # ---------------------------------------------------------------------------------------------- device handle
 
+def _ieee_div(a, b):
+    """a / b as Julia evaluates it (Inf / NaN instead of an exception when tau is still 0 at an early check)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return float(np.float64(a) / np.float64(b))
+
+
+def _julia_specials(s):
+    """@printf shows Inf / NaN where Python's % formatting writes inf / nan."""
+    return s.replace("inf", "Inf").replace("nan", "NaN")
+
+
+def julia_float(x):
+    """How Julia's println shows a Float64 (shortest round-trip digits; exponent form outside 1e-4 <= |x| < 1e6)."""
+    x = float(x)
+    if math.isnan(x):
+        return "NaN"
+    if math.isinf(x):
+        return "Inf" if x > 0 else "-Inf"
+    if x == 0.0:
+        return "-0.0" if math.copysign(1.0, x) < 0 else "0.0"
+    mant, ex = np.format_float_scientific(x, unique=True, trim="0").split("e")
+    ex = int(ex)
+    if -4 <= ex < 6:
+        return np.format_float_positional(x, unique=True, trim="0")
+    return "%se%d" % (mant + "0" if mant.endswith(".") else mant, ex)
+
+
+class LineSearchWrapper(FOSAlgorithm):
+    """LineSearchWrapper(alg; lsinterval=100, kwargs...)   wrappers/linesearch.jl:3-24 -- around GAP (AP, DR) or GAPA, the
+    algorithms with support_linesearch == Val{:Fast}.  Every lsinterval-th iteration is a 31-point search of the step length
+    along S2!(S1!(x)) - x, run on the device (fos_set_linesearch); the reference's println output of a search is reproduced
+    from fos_linesearch_log."""
+
+    def __init__(self, alg, lsinterval=100, **kwargs):
+        if not isinstance(alg, (GAP, GAPA)):                 # linesearch.jl:20-22 (an @error in the reference)
+            raise ValueError("Algorithm %s does not support line search" % type(alg).__name__)
+        self.alg, self.lsinterval = alg, int(lsinterval)
+        self.options = {**alg.options, **kwargs}            # merge(alg.options, kwargs)
+        self.direct = alg.direct
+
+    def _alg_args(self):
+        return self.alg._alg_args()
+
+
 def _normalize_cones(cones, total, what):
     """(name, length) or (name, 1-based index range/list) tuples -> (types int32, starts int64 1-based, lens int64).
     Index lists must be contiguous: toRanges, src/cones.jl:44-56."""
@@ -156,6 +202,18 @@ class HipHSDE:
     def set_alg(self, alg: FOSAlgorithm):
         code, a, a1, a2, beta = alg._alg_args()
         _lib.check(self._lib.fos_set_alg(self._h, code, a, a1, a2, beta))
+        if isinstance(alg, LineSearchWrapper):
+            self.set_linesearch(alg.lsinterval)
+
+    def set_linesearch(self, lsinterval):
+        """LineSearchWrapper around the current algorithm (0: off); fos_set_linesearch."""
+        _lib.check(self._lib.fos_set_linesearch(self._h, int(lsinterval)))
+
+    def linesearch_log(self):
+        """(iteration, ||res||, [31 test residuals], alpha_best) of the last search."""
+        out = np.zeros(34)
+        _lib.check(self._lib.fos_linesearch_log(self._h, _lib.dptr(out)))
+        return int(out[33]), float(out[0]), out[1:32].copy(), float(out[32])
 
     def reset_affine(self):
         _lib.check(self._lib.fos_reset_affine(self._h))
@@ -431,11 +489,11 @@ class HSDEStatus:
                 h.setdefault("s", []).append((i, z[nu + n:nu + n + m].copy()))
         if self.verbose > 0 and not self.direct:                   # :43-47
             h.setdefault("cgiter", []).append((i, int(res.cgiter)))
-            self._println("%6d|% 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 4d % .1es" %
-                          (i, res.p, res.d, res.g, res.ctx, -res.bty, res.kappa / res.tau, res.cgiter, t / 1e9))
+            self._println(_julia_specials("%6d|% 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 4d % .1es" %
+                          (i, res.p, res.d, res.g, res.ctx, -res.bty, _ieee_div(res.kappa, res.tau), res.cgiter, t / 1e9)))
         elif self.verbose > 0:                                     # :48-50 (direct: no cg column, no :cgiter history)
-            self._println("%6d|% 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % .1es" %
-                          (i, res.p, res.d, res.g, res.ctx, -res.bty, res.kappa / res.tau, t / 1e9))
+            self._println(_julia_specials("%6d|% 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % .1es" %
+                          (i, res.p, res.d, res.g, res.ctx, -res.bty, _ieee_div(res.kappa, res.tau), t / 1e9)))
         if res.cg_maxiter_hit:
             import warnings
             warnings.warn("CG reached max iterations, result may be inaccurate")     # conjugategradients.jl:53
@@ -534,11 +592,22 @@ class FOSMathProgModel:
         t1 = time.time()
         status.printstatusheader()
         i = 0
+        ls = self.alg.lsinterval if isinstance(self.alg, LineSearchWrapper) else 0
         while i < max_iters:                                       # for i = 1:max_iters   :23
             count = min(max_iters - i, checki - (i % checki))
+            if ls > 0:
+                count = min(count, ls - (i % ls))                  # stop at every line-search iteration: its output is printed
             done, checked, res = dev.step(i + 1, count, checki, eps)
             i += done
             status.i = i
+            if ls > 0 and i % ls == 0:                             # what linesearch.jl:51,63,69 print
+                _, normres, tests, abest = dev.linesearch_log()
+                status._println("test, %s" % julia_float(normres))
+                a = 0.1
+                for tr in tests:
+                    a = a * 1.8
+                    status._println("\u03b1: %s, %s" % (julia_float(a), julia_float(tr)))
+                status._println("\u03b1: %s" % julia_float(abest))
             if checked:
                 z = dev.get_checked() if debug > 1 else None      # debug=2 stores x,y,s of the checked point
                 status.record(res, z)

@@ -66,6 +66,7 @@ mutable struct HipData <: FOSSolverData
     m::Int
     n::Int
     cgiter::Int64
+    lsinterval::Int64                     # > 0: LineSearchWrapper around the algorithm [wrappers/linesearch.jl]
     function HipData(model::FOSMathProgModel, device::Integer)
         A = model.A                       # SparseMatrixCSC{Float64,Int}: colptr/rowval are Int64 and 1-based, as the ABI wants
         m, n = size(A)
@@ -82,7 +83,7 @@ mutable struct HipData <: FOSSolverData
                         m, n, A.colptr, A.rowval, A.nzval, b, c,
                         length(t1), t1, s1, l1, length(t2), t2, s2, l2, Cint(device), h))
         end
-        d = new(h[], m, n, 0)
+        d = new(h[], m, n, 0, 0)
         finalizer(x -> (x.handle != C_NULL && ccall((:fos_destroy, libfoship), Cint, (Ptr{Cvoid},), x.handle); x.handle = C_NULL), d)
         return d
     end
@@ -119,6 +120,31 @@ for T in (:GAP, :GAPA, :FISTA, :Dykstra)
         end
         return invoke(init_algorithm!, Tuple{$T,FirstOrderSolvers.AbstractFOSModel}, alg, model)
     end
+end
+
+# ---- LineSearchWrapper(GAP / GAPA) [wrappers/linesearch.jl]: the wrapped algorithm's handle with the search switched on; the
+#      search itself (tmp1 = x; x = S2!(S1!(x)); 31 trial step lengths; x = tmp1 + alpha_best res) runs on the device.
+function init_algorithm!(ls::LineSearchWrapper, model::FOSMathProgModel)
+    if usegpu(model)
+        data, status_generator = init_algorithm!(ls.alg, model)          # errors for algorithms other than GAP / GAPA below
+        check(ccall((:fos_set_linesearch, libfoship), Cint, (Ptr{Cvoid}, Int64), data.handle, ls.lsinterval))
+        data.lsinterval = ls.lsinterval
+        return data, status_generator
+    end
+    return invoke(init_algorithm!, Tuple{LineSearchWrapper,FirstOrderSolvers.AbstractFOSModel}, ls, model)
+end
+
+# what linesearch.jl:51,63,69 print during a search, from the device's record of the last one
+function print_linesearch(data::HipData)
+    log = Vector{Float64}(undef, 34)
+    check(ccall((:fos_linesearch_log, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, log))
+    println("test, $(log[1])")
+    α = 0.1
+    for k = 0:30
+        α = α * 1.8
+        println("α: $α, $(log[2+k])")
+    end
+    println("α: $(log[33])")
 end
 
 getcgiter(d::HipData) = d.cgiter                                              # defaults.jl:25-30
@@ -162,11 +188,14 @@ function iterate(alg::FOSAlgorithm, data::HipData, status::HSDEStatus, x, max_it
     done, checked, res = Ref{Int64}(0), Ref{Int32}(0), Ref{CheckResult}()
     while i < max_iters
         count = min(max_iters - i, status.checki - (i % status.checki))
+        ls = data.lsinterval
+        ls > 0 && (count = min(count, ls - (i % ls)))                 # stop at every line-search iteration: its output is printed
         check(ccall((:fos_step, libfoship), Cint,
                     (Ptr{Cvoid}, Int64, Int64, Int64, Cdouble, Ref{Int64}, Ref{Int32}, Ref{CheckResult}),
                     data.handle, i + 1, count, status.checki, status.eps, done, checked, res))
         i += done[]
         status.i = i
+        ls > 0 && i % ls == 0 && print_linesearch(data)
         if checked[] != 0
             record!(status, data, res[])
             status.status != :Continue && break
@@ -188,8 +217,8 @@ end
 
 # ---- single-step entry points for callers written against step/getsol (one upload, one ccall, one download per
 #      iteration: correct but PCIe bound -- `iterate` above is the path to use).  The host vector is uploaded on EVERY call, so
-#      a caller that edits x between steps is honoured.  LineSearchWrapper / LongstepWrapper are NOT supported with gpu=true:
-#      they call prox! on S1/S2 themselves [wrappers/linesearch.jl:36-75], which the device path does not build.
+#      a caller that edits x between steps is honoured.  LineSearchWrapper runs on the device through `iterate` (above);
+#      LongstepWrapper is NOT supported with gpu=true (it collects half-planes on the host and solves a BigFloat QP).
 function Base.step(alg::FOSAlgorithm, data::HipData, x, i, status::HSDEStatus, longstep = nothing)
     longstep === nothing || error("longstep/linesearch wrappers are not available with gpu=true")
     check(ccall((:fos_set_iterate, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, x))

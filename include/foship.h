@@ -186,6 +186,17 @@ int fos_get_checked(fos_handle h, double* z);              /* the vector the las
 int fos_step(fos_handle h, int64_t i_first, int64_t count, int64_t checki, double eps,
              int64_t* iters_done, int32_t* checked, fos_check_result* res);
 
+/* LineSearchWrapper(alg; lsinterval) of src/wrappers/linesearch.jl:36-75 around GAP (AP, DR) or GAPA -- the algorithms with
+ * support_linesearch == Val{:Fast} (gap.jl:89, gapa.jl:117).  After fos_set_alg: iterations i with i % lsinterval == 0 are no
+ * longer a plain step but   tmp1 = x;  x = S2!(S1!(x)) (checkstatus inside S2! as usual);  res = x - tmp1;
+ * for k = 0:30  alpha = 0.1 * 1.8^(k+1);  testres_k = || (tmp1 + alpha res) - S2!(S1!(tmp1 + alpha res)) ||;
+ * x = tmp1 + alpha_best res  -- all on the device, every S1! a warm-started CG solve that advances the tolerance counter as in
+ * the reference.  lsinterval = 0 switches the wrapper off; any other algorithm is refused (FOS_EUNSUPPORTED).
+ * fos_linesearch_log: out34 = [ ||res||, testres_0..30, alpha_best, iteration ] of the last search -- what the reference
+ * prints with its println calls (linesearch.jl:51,63,69). */
+int fos_set_linesearch(fos_handle h, int64_t lsinterval);
+int fos_linesearch_log(fos_handle h, double* out34);
+
 /* getsol(alg, data, x): one more S1 prox + S2 prox (gap.jl:82-87, gapa.jl:107-112, fista.jl:50-56); advances
  * the CG call counter like the reference.  z_out (N doubles) receives `guess`.  If force_check != 0 the
  * override check of solverwrapper.jl:31-34 is evaluated on the guess. */

@@ -799,8 +799,10 @@ def _jl_e(v, prec=2, width=9):
 def format_status_iter(i, p, d, g, ctx, bty, kt, cgiter, t_ns):
     """printstatusiter   HSDEStatus.jl:85-91 (prints -bty as the dual objective)."""
     if cgiter is None:
-        return "%6d|% 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % .1es" % (i, p, d, g, ctx, -bty, kt, t_ns / 1e9)
-    return "%6d|% 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 4d % .1es" % (i, p, d, g, ctx, -bty, kt, cgiter, t_ns / 1e9)
+        s = "%6d|% 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % .1es" % (i, p, d, g, ctx, -bty, kt, t_ns / 1e9)
+    else:
+        s = "%6d|% 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 9.2e % 4d % .1es" % (i, p, d, g, ctx, -bty, kt, cgiter, t_ns / 1e9)
+    return s.replace("inf", "Inf").replace("nan", "NaN")           # @printf's spelling
 
 
 def residuals(model, z):
@@ -900,7 +902,7 @@ class HSDEStatus:
                 else:
                     cgiter = None                          # :48-50: no cg column, no :cgiter history
                 self._println(format_status_iter(i, res["p"], res["d"], res["g"], res["ctx"], res["bty"],
-                                                 res["kappa"] / res["tau"], cgiter, t))
+                                                 _ieee_div(res["kappa"], res["tau"]), cgiter, t))
             status = decide_status(res, self.eps)
             if status == "Optimal" and self.verbose > 0:   # :55-57
                 self._println("Found solution i=%d" % i)
@@ -982,13 +984,20 @@ class GAPA:
         self.tmp1 = np.empty(n)
         self.tmp2 = np.empty(n)
 
-    def step(self, x, i, status):                           # gapa.jl:80-105
+    def S1_(self, y, x):                                    # gapa.jl:61-70
         a12 = self.alpha12
-        self.S1.prox(self.tmp1, x)                          # S1!  :61-70
-        self.tmp1[:] = a12 * self.tmp1 + (1 - a12) * x
-        self.S2.prox(self.tmp2, self.tmp1)                  # S2!  :72-78
-        status.checkstatus(self.tmp2)
-        self.tmp2[:] = a12 * self.tmp2 + (1 - a12) * self.tmp1
+        self.S1.prox(y, x)
+        y[:] = a12 * y + (1 - a12) * x
+
+    def S2_(self, y, x, status):                            # gapa.jl:72-78
+        a12 = self.alpha12
+        self.S2.prox(y, x)
+        status.checkstatus(y)
+        y[:] = a12 * y + (1 - a12) * x
+
+    def step(self, x, i, status):                           # gapa.jl:80-105
+        self.S1_(self.tmp1, x)
+        self.S2_(self.tmp2, self.tmp1, status)
         scl = normed_scalar(self.tmp2, self.tmp1, self.tmp1, x, getattr(getattr(self.S1, "A", None), "space", LOCAL))     # :96
         scl = 0.0 if math.isnan(scl) else min(max(scl, 0.0), 1.0)   # :96-97 (clamp then NaN -> 0)
         s = math.sqrt(1 - scl ** 2)                         # :98
@@ -1061,6 +1070,103 @@ class Dykstra:
         self.S1.prox(tmp1, x)
         self.S2.prox(self.y, tmp1)
         return self.y
+
+
+# ----------------------------------------------------------------------------------------
+# LineSearchWrapper      src/wrappers/linesearch.jl ; NoStatus  src/status.jl:3-11
+# ----------------------------------------------------------------------------------------
+
+
+def _ieee_div(a, b):
+    """a / b as Julia evaluates it (Inf / NaN instead of an exception when tau is still 0 at an early check)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return float(np.float64(a) / np.float64(b))
+
+
+class NoStatus:
+    """checkstatus / logextra / printstatusheader are no-ops (status.jl:3-11)."""
+    status = "Continue"
+
+    def checkstatus(self, z, override=False):
+        return False
+
+
+def julia_float(x):
+    """How Julia's println shows a Float64 (shortest round-trip digits; exponent form outside 1e-4 <= |x| < 1e6)."""
+    x = float(x)
+    if math.isnan(x):
+        return "NaN"
+    if math.isinf(x):
+        return "Inf" if x > 0 else "-Inf"
+    if x == 0.0:
+        return "-0.0" if math.copysign(1.0, x) < 0 else "0.0"
+    sci = np.format_float_scientific(x, unique=True, trim="0")       # e.g. 1.234567e+06 / 1.e-05 -> mantissa with .0
+    mant, ex = sci.split("e")
+    ex = int(ex)
+    if -4 <= ex < 6:
+        return np.format_float_positional(x, unique=True, trim="0")
+    if mant.endswith("."):
+        mant += "0"
+    return "%se%d" % (mant, ex)
+
+
+class LineSearchWrapper:
+    """LineSearchWrapper(alg; lsinterval=100, kwargs...)   linesearch.jl:3-24.  Every lsinterval-th iteration: one S2!(S1!(x))
+    evaluation with the real status, then 31 trial step lengths 0.1*1.8^(k+1) along res = S2(S1(x)) - x scored by
+    ||x_trial - S2(S1(x_trial))|| with NoStatus; the best one is taken (linesearch.jl:36-75).  The reference's println calls
+    are reproduced through `out` (default: stdout)."""
+
+    def __init__(self, alg, lsinterval=100, out=None, **options):
+        if not isinstance(alg, (GAP, GAPA)):                 # support_linesearch: gap.jl:89, gapa.jl:117, defaults.jl:22
+            raise ValueError("Algorithm %s does not support line search" % type(alg).__name__)
+        self.alg, self.lsinterval, self.out = alg, lsinterval, out
+        self.options = {**alg.options, **options}           # merge(alg.options, kwargs)   :23
+        self.direct = alg.direct
+        self.log = []                                        # (i, normres, [testres...], alpha_best) per search
+
+    def _println(self, s):                                  # (same sink convention as HSDEStatus: a list, or stdout)
+        if self.out is None:
+            print(s)
+        else:
+            self.out.append(s)
+
+    def init(self, model):                                  # :26-32
+        self.alg.init(model)
+        self.S1, self.S2 = self.alg.S1, self.alg.S2
+        n = self.alg.tmp1.size
+        self.tmp1, self.tmp2, self.tmp3, self.res = np.empty(n), np.empty(n), np.empty(n), np.empty(n)
+
+    def step(self, x, i, status):                           # :36-75
+        if i % self.lsinterval != 0:                        # :39
+            self.alg.step(x, i, status)                     # :73
+            return
+        tmp1, tmp2, tmp3, res = self.tmp1, self.tmp2, self.tmp3, self.res
+        tmp1[:] = x                                         # :41
+        self.alg.S1_(tmp2, x)                               # :45
+        self.alg.S2_(x, tmp2, status)                       # :46
+        nostatus = NoStatus()                               # :48
+        res[:] = x - tmp1                                   # :49
+        normres = float(np.linalg.norm(res))                # :50
+        self._println("test, %s" % julia_float(normres))    # :51
+        best, abest, a = math.inf, 1.0, 0.1                 # :53-55
+        tests = []
+        for k in range(31):                                 # :56
+            a = a * 1.8                                     # :57
+            x[:] = tmp1 + a * res                           # :58
+            self.alg.S1_(tmp2, x)                           # :60
+            self.alg.S2_(tmp3, tmp2, nostatus)              # :61
+            d = x - tmp3                                    # normdiff  :62,77-85
+            testres = math.sqrt(float(np.dot(d, d)))
+            tests.append(testres)
+            self._println("\u03b1: %s, %s" % (julia_float(a), julia_float(testres)))   # :63
+            if testres < best:                              # :64-67
+                best, abest = testres, a
+        self._println("\u03b1: %s" % julia_float(abest))    # :69
+        x[:] = tmp1 + abest * res                           # :70
+        self.log.append((i, normres, tests, abest))
+
+    def getsol(self, x):                                    # :93-95
+        return self.alg.getsol(x)
 
 
 # ----------------------------------------------------------------------------------------

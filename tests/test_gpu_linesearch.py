@@ -1,0 +1,80 @@
+"""
+GPU test of the LineSearchWrapper (src/wrappers/linesearch.jl) on the device -- fos_set_linesearch / fos_linesearch_log through the
+Python mirror -- against the oracle's restatement on the same problem: iterates before, at and after a search, the 31 test
+residuals and the chosen step length, the printed lines, the CG tolerance counter, and whole solves.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _omodel(orc, prob):
+    codes = lambda cs: [(orc.CONE_CODES[k], l) for k, l in cs]
+    return orc.Model(prob.A, prob.b, prob.c, codes(prob.K1), codes(prob.K2))
+
+
+@pytest.mark.parametrize("algname", ["DR", "GAP", "GAPA"])
+def test_linesearch_iterates_match_oracle(pkg, oracle, algname):
+    orc = oracle
+    prob = pkg.workloads.small_mixed()
+    mk = {"DR": lambda M: M.DR(), "GAP": lambda M: M.GAP(0.8, 1.5, 1.6), "GAPA": lambda M: M.GAPA(0.8, 0.5)}[algname]
+    ls = 5
+    # oracle
+    lines = []
+    owrap = orc.LineSearchWrapper(mk(orc), lsinterval=ls, out=lines)
+    mo = _omodel(orc, prob)
+    owrap.init(mo)
+    xo = orc.hsde_initialvalue(mo)
+    # device
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d.set_alg(pkg.LineSearchWrapper(mk(pkg), lsinterval=ls))
+    d.set_iterate(None)
+    st = orc.HSDEStatus(mo, 10 ** 9, 1e-9, 0, 1, S1=owrap.S1)
+    for i in range(1, 2 * ls + 2):                              # two searches (i = 5, 10) and the steps around them
+        st.i = i
+        owrap.step(xo, i, st)
+        d.step(i, 1, 10 ** 9, 1e-9)
+        z = d.get_iterate()
+        scale = max(1.0, np.linalg.norm(xo))
+        # (the first iterations solve S1 to the loose tolerance 0.2^sqrt(i) of affinepluslinear.jl:108-112: the inexact
+        #  solutions depend on rounding at the 1e-5 level, on the device and in the oracle alike)
+        assert np.linalg.norm(z - xo) <= 1e-4 * scale, (algname, i)
+        assert d.prox_count() == owrap.S1.i, (algname, i)       # S.i of affinepluslinear.jl:114: +1 per step, +32 per search
+        if i % ls == 0:
+            it, normres, tests, abest = d.linesearch_log()
+            oi, onormres, otests, oabest = owrap.log[-1]
+            assert it == oi == i
+            assert normres == pytest.approx(onormres, rel=1e-4)
+            assert np.allclose(tests, otests, rtol=2e-3, atol=1e-9), (algname, i)
+            # same step length unless two trial residuals tie to within the CG tolerance
+            k, ko = int(np.argmin(tests)), int(np.argmin(otests))
+            assert abest == oabest or abs(otests[k] - otests[ko]) <= 2e-3 * abs(otests[ko]), (algname, i, abest, oabest)
+    d.close()
+    assert len(lines) == 2 * 33
+
+
+def test_linesearch_solve_prints_and_converges(pkg, oracle):
+    """Whole solve through FOSMathProgModel: the search output is printed in the reference's form after every lsinterval-th
+    iteration, the solve still ends Optimal at the oracle's objective; algorithms without support_linesearch are refused."""
+    orc = oracle
+    prob = pkg.workloads.c1_readme_nnls(seed=2)
+    out = []
+    model = pkg.FOSMathProgModel(pkg.LineSearchWrapper(pkg.DR(eps=1e-6, verbose=1, checki=10), lsinterval=50))
+    model.out = out
+    model.loadproblem(prob.c, prob.A, prob.b, prob.K1, prob.K2)
+    model.optimize()
+    assert model.status() == "Optimal"
+    sol = orc.solve(_omodel(orc, prob), orc.LineSearchWrapper(orc.DR(eps=1e-6, verbose=0, checki=10), lsinterval=50, out=[]))
+    assert sol.status == "Optimal" and model.getobjval() == pytest.approx(sol.obj_val, rel=1e-4)
+    tests = [s for s in out if s.startswith("test, ")]
+    alphas = [s for s in out if s.startswith("α: ")]
+    assert len(tests) == model.iterations // 50 and len(alphas) == 32 * len(tests)
+    assert alphas[0].startswith("α: 0.18000000000000002, ")
+    with pytest.raises(ValueError):
+        pkg.LineSearchWrapper(pkg.FISTA())
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d.set_alg(pkg.FISTA())
+    with pytest.raises(pkg.lib.FosError):
+        d.set_linesearch(10)
+    d.close()

@@ -468,3 +468,48 @@ def test_direct_solve_prints_without_cg_column_and_matches_indirect():
     assert sd.status == "Optimal" == si.status
     assert sd.obj_val == pytest.approx(si.obj_val, abs=1e-6)
     assert float(c @ sd.x) == pytest.approx(float(c @ x0), abs=1e-6)
+
+
+# ------------------------------------------------------------------ src/wrappers/linesearch.jl (test/linesearch.jl configuration)
+
+
+def test_linesearch_wrapper_oracle(nnls):
+    """LineSearchWrapper(GAP(0.5, 1.0, 1.0), lsinterval) as test/linesearch.jl:11 builds it (that script is not part of the
+    reference's runtests and its literal optimum depends on Julia's RNG, so this pins the restatement's own semantics,
+    linesearch.jl:36-75): plain steps between searches; a search evaluates the 31 step lengths 0.1*1.8^(k+1) and takes the
+    argmin (first one on ties) of ||x - S2(S1(x))||; the CG tolerance counter advances by one per S1 evaluation; the printed
+    lines have the reference's form; only GAP and GAPA are accepted."""
+    prob, model, xs, opt = nnls
+    ls = 7
+    lines = []
+    wrap = orc.LineSearchWrapper(orc.GAP(0.5, 1.0, 1.0, eps=1e-8, verbose=0, checki=1, max_iters=3 * ls), lsinterval=ls, out=lines)
+    assert wrap.options == dict(eps=1e-8, verbose=0, checki=1, max_iters=3 * ls)
+    plain = orc.GAP(0.5, 1.0, 1.0)
+    wrap.init(model)
+    plain.init(model)
+    x = orc.hsde_initialvalue(model)
+    xp = x.copy()
+    st = orc.NoStatus()
+    for i in range(1, ls):                                   # iterations 1 .. ls-1: the wrapped algorithm's own steps
+        wrap.step(x, i, st)
+        plain.step(xp, i, st)
+    assert np.array_equal(x, xp)
+    calls_before = wrap.S1.i
+    x0 = x.copy()
+    wrap.step(x, ls, st)                                     # the search
+    assert wrap.S1.i == calls_before + 32                    # one S1 for the base point + 31 trials
+    i_log, normres, tests, abest = wrap.log[-1]
+    assert i_log == ls and len(tests) == 31
+    alphas = [0.1 * 1.8 ** (k + 1) for k in range(31)]
+    assert abest == pytest.approx(alphas[int(np.argmin(tests))], rel=1e-12)
+    assert lines[0] == "test, %s" % orc.julia_float(normres)
+    assert lines[1].startswith("α: 0.18000000000000002, ") and lines[32] == "α: %s" % orc.julia_float(abest) and len(lines) == 33
+    # the new iterate lies on the search line through x0, at the chosen step length (linesearch.jl:41,49,70)
+    assert np.array_equal(wrap.tmp1, x0) and np.array_equal(x, x0 + abest * wrap.res)
+    assert normres == pytest.approx(np.linalg.norm(wrap.res), rel=1e-15)
+    # whole solve through solve(): still converges on the README problem
+    sol = orc.solve(model, orc.LineSearchWrapper(orc.DR(eps=1e-6, verbose=0, checki=10), lsinterval=50, out=[]))
+    assert sol.status == "Optimal" and sol.obj_val == pytest.approx(opt, rel=1e-4)
+    with pytest.raises(ValueError):
+        orc.LineSearchWrapper(orc.FISTA())
+    assert [orc.julia_float(v) for v in (0.18, 1e-5, 0.00012, 1234567.0, 1e6, 100000.0)] == ["0.18", "1.0e-5", "0.00012", "1.234567e6", "1.0e6", "100000.0"]
