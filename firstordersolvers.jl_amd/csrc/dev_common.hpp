@@ -152,6 +152,12 @@ __device__ __forceinline__ CgClose cg_close_iteration(DevState* st, const double
             st->hit_max = (jd == maxit) ? 1 : 0;                  // :53
             __threadfence();
             st->done = 1;
+            if (st->hostmark) {                                   // tell the host directly (it may be spinning on this record)
+                HostMark* m = reinterpret_cast<HostMark*>(st->hostmark);
+                m->iter = jd; m->hit_max = (jd == maxit) ? 1 : 0; m->rr = rr;
+                __threadfence_system();
+                __hip_atomic_store(&m->seq, seq_base >> 11, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         } else {
             st->rn_old = rnold;
             st->rn = rr;

@@ -175,7 +175,12 @@ struct DevState {
     double gapa_scl;       // last normedScalar value (diagnostic)
     // status sums, filled by status_finalize: see StatusIdx
     double stat[12];
+    // host-visible (pinned, mapped) record the kernel that ends a CG solve fills: lets the host see the end of the solve
+    // without a stream synchronisation (HostMark below; 0: none)
+    unsigned long long hostmark;
 };
+struct HostMark { uint32_t seq; int32_t iter; int32_t hit_max; int32_t batch; double rr; };   // seq = the solve's number, written last;
+                                                                                            // batch: id of a batch of iterations that ended WITHOUT convergence
 
 enum StatusIdx { ST_RP2 = 0, ST_RD2, ST_CTX, ST_BTY, ST_AXS2, ST_ATY2, ST_TAU, ST_KAPPA, ST_COUNT };
 
@@ -232,6 +237,7 @@ struct LaunchCtx {
     // replicated entries (indices < n_repl) are counted by ONE rank only (count_repl).
     int (*between)(void*);
     void* between_arg;
+    const int32_t* gate = nullptr;   // non-null: the relaxation / cone kernels run only if *gate != 0 (DevState.done: enqueued behind a CG batch)
     int32_t count_repl;         // 1: this rank counts the replicated entries in scalar sums (always 1 when not row-sharded)
     int64_t n_repl;             // replicated leading entries of every vector (0 when not row-sharded)
 };
@@ -258,6 +264,7 @@ struct CgIter {
     int rr_from_reduced;       // r.r of iteration j-1 was all-reduced into c.reduced (sharded, RCCL)
     const PeerBox* fold;       // non-null: the two exchanges of the iteration happen inside the two kernels (peer mailboxes)
     uint32_t seq_base;
+    int32_t batch_mark = 0;    // != 0: this is the last iteration the host enqueued; if CG goes on after it, the p update tells the host (HostMark.batch)
 };
 void launch_kkt2_cg(const LaunchCtx& c, const CgIter& it, double2* Ap);
 void launch_cg_stop_check(const LaunchCtx& c, const CgIter& it);      // closes iteration it.j - 1 when no sweep follows in this batch

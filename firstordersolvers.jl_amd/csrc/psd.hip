@@ -169,7 +169,8 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
                                                           const ConeDesc* __restrict__ cones,
                                                           double* __restrict__ gscratch, size_t scratch_stride,
                                                           const double* __restrict__ vin, double* __restrict__ vout,
-                                                          size_t vstride, int have_prev, int* __restrict__ stats, int phase_limit) {
+                                                          size_t vstride, int have_prev, int* __restrict__ stats, int phase_limit, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;                  // speculatively enqueued behind a CG batch that did not converge: no-op
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
     const int cone = blockIdx.x >> 1, part = blockIdx.x & 1;
@@ -548,7 +549,8 @@ __device__ __forceinline__ void jstep_odd(double (&U)[32], double (&W)[32], doub
 template <bool WARM>
 __global__ __launch_bounds__(64) void psd64_wave_kernel(d2* __restrict__ out, const d2* __restrict__ in, const ConeDesc* __restrict__ cones,
                                                         const double* __restrict__ vin, double* __restrict__ vout, size_t vstride,
-                                                        int have_prev, int* __restrict__ stats, int phase_limit) {
+                                                        int have_prev, int* __restrict__ stats, int phase_limit, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int LD = P64_LD;
     const int lane = threadIdx.x;
@@ -765,9 +767,9 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
         const size_t wl = psd64w_lds_bytes();
         const size_t vs = (size_t)64 * 64;
         if (vin && vout)
-            hipLaunchKernelGGL((psd64_wave_kernel<true>), dim3(2 * ncones), dim3(64), wl, c.stream, out, in, cones, vin, vout, vs, have_prev, stats, phase_limit);
+            hipLaunchKernelGGL((psd64_wave_kernel<true>), dim3(2 * ncones), dim3(64), wl, c.stream, out, in, cones, vin, vout, vs, have_prev, stats, phase_limit, c.gate);
         else
-            hipLaunchKernelGGL((psd64_wave_kernel<false>), dim3(2 * ncones), dim3(64), wl, c.stream, out, in, cones, nullptr, nullptr, vs, 0, stats, phase_limit);
+            hipLaunchKernelGGL((psd64_wave_kernel<false>), dim3(2 * ncones), dim3(64), wl, c.stream, out, in, cones, nullptr, nullptr, vs, 0, stats, phase_limit, c.gate);
         return FOS_OK;
     }
     const size_t lds = psd_lds_bytes(kmax);
@@ -788,15 +790,15 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     const size_t vstride = (size_t)kmax * kmax;
     static const int wide_threads = getenv("FOS_PSD_THREADS") ? atoi(getenv("FOS_PSD_THREADS")) : 512;
     if (warm && wide && wide_threads == 512)
-        hipLaunchKernelGGL((psd_kernel<true, true, 512>), dim3(2 * ncones), dim3(512), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev, stats, phase_limit);
+        hipLaunchKernelGGL((psd_kernel<true, true, 512>), dim3(2 * ncones), dim3(512), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev, stats, phase_limit, c.gate);
     else if (warm && wide && wide_threads == 1024)
-        hipLaunchKernelGGL((psd_kernel<true, true, 1024>), dim3(2 * ncones), dim3(1024), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev, stats, phase_limit);
+        hipLaunchKernelGGL((psd_kernel<true, true, 1024>), dim3(2 * ncones), dim3(1024), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev, stats, phase_limit, c.gate);
     else if (warm)
-        hipLaunchKernelGGL((psd_kernel<true, true, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev, stats, phase_limit);
+        hipLaunchKernelGGL((psd_kernel<true, true, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev, stats, phase_limit, c.gate);
     else if (use_lds)
-        hipLaunchKernelGGL((psd_kernel<true, false, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, nullptr, nullptr, vstride, 0, stats, phase_limit);
+        hipLaunchKernelGGL((psd_kernel<true, false, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), lds, c.stream, out, in, cones, gscratch, stride, nullptr, nullptr, vstride, 0, stats, phase_limit, c.gate);
     else
-        hipLaunchKernelGGL((psd_kernel<false, false, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), 32 * sizeof(double), c.stream, out, in, cones, gscratch, stride, nullptr, nullptr, vstride, 0, stats, phase_limit);
+        hipLaunchKernelGGL((psd_kernel<false, false, PSD_THREADS>), dim3(2 * ncones), dim3(PSD_THREADS), 32 * sizeof(double), c.stream, out, in, cones, gscratch, stride, nullptr, nullptr, vstride, 0, stats, phase_limit, c.gate);
     return FOS_OK;
 }
 

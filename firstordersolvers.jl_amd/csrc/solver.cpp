@@ -4,6 +4,7 @@
 // scalars per CG poll / convergence check).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <functional>
 
 #include <algorithm>
 #include <cmath>
@@ -141,6 +142,10 @@ struct fos_solver {
     // scalars
     DevState* st = nullptr;
     DevState* st_host = nullptr;               // pinned
+    // speculation past a CG solve: the kernels that follow it are enqueued (gated on DevState.done) BEFORE the host learns the
+    // iteration count, which it then reads from a record the CG kernels write into pinned host memory (wait_cg_mark)
+    HostMark* mark = nullptr;                  // pinned + mapped; DevState.hostmark points at it
+    bool speculate = true;
     double* partials = nullptr;
     double* reduced = nullptr;                 // 16 doubles
     int vec_blocks = 0;
@@ -320,6 +325,27 @@ int poll_state(fos_solver* h) {
     return FOS_OK;
 }
 
+// Has CG solve number `epoch` ended within its first batch of iterations?  No stream synchronisation and nothing in the stream:
+// the kernel that ends a solve writes HostMark.seq in pinned host memory, the marked p update of a batch that runs out before
+// convergence writes HostMark.batch; the host spins on the two (and looks at the stream now and then, in case neither comes).
+int wait_cg_mark(fos_solver* h, uint32_t epoch, int32_t batch_id, bool* ended) {
+    FOS_TRY(check_launch("poll"));
+    volatile HostMark* m = h->mark;
+    for (uint32_t spin = 1;; ++spin) {
+        if (__atomic_load_n(&m->seq, __ATOMIC_ACQUIRE) == epoch) { *ended = true; break; }
+        if (__atomic_load_n(&m->batch, __ATOMIC_ACQUIRE) == batch_id) { *ended = false; break; }
+        if ((spin & 0xFFFFu) == 0 && hipStreamQuery(h->stream) == hipSuccess) {          // everything enqueued has run
+            if (__atomic_load_n(&m->seq, __ATOMIC_ACQUIRE) == epoch) { *ended = true; break; }
+            if (__atomic_load_n(&m->batch, __ATOMIC_ACQUIRE) == batch_id) { *ended = false; break; }
+            set_error("the CG kernels left no completion mark (a kernel of the solve failed)");
+            return FOS_EHIP;
+        }
+    }
+    if (*ended) { h->st_host->done = 1; h->st_host->iter = m->iter; h->st_host->hit_max = m->hit_max; h->st_host->rr = m->rr; }
+    else h->st_host->done = 0;
+    return FOS_OK;
+}
+
 // sharded set-up: global problem size and norms (tolerance floor, status normalisation) from the shards'
 int global_setup(fos_solver* h) {
     LaunchCtx c = h->ctx();
@@ -349,7 +375,14 @@ int kkt_apply_full(fos_solver* h, const LaunchCtx& c, const d2* w, d2* out) {
 // Device resident: the host enqueues iterations AHEAD (every CG kernel is gated on DevState.done) and polls once per batch.
 // `apply_on` (default: x): the vector the start residual's operator product is taken of -- prox_affine passes x - (0, in.y)
 // together with rhs = in, which is rhs - M x without ever forming rhs (see there).
-int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t* iters, const d2* apply_on = nullptr) {
+// `post` (optional): what follows the solve on the stream (relaxation, cone projection, ...), taking a LaunchCtx whose `gate`
+// it must hand to every launch.  It is enqueued right behind the FIRST batch of iterations, gated on DevState.done, and the host
+// then reads the state at the end of the batch on a second stream: when the batch sufficed (the steady state) the GPU has
+// gone straight on while the host was still finding that out, and *post_ran = true.  Otherwise the gated launches were
+// no-ops, CG continues as usual and the caller runs `post` itself.
+typedef std::function<int(const LaunchCtx&)> PostFn;
+int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t* iters, const d2* apply_on = nullptr,
+             const PostFn* post = nullptr, bool* post_ran = nullptr) {
     LaunchCtx c = h->ctx();
     int fr = 0;
     FOS_TRY(kkt_apply_full(h, c, apply_on ? apply_on : x, h->AP));    // :32  mul!(Ap, A, x)
@@ -369,9 +402,13 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
         return it;
     };
     const size_t prof_start = h->prof_used;
+    const bool spec = post && h->speculate && !h->sharded() && !c.between && !h->fuse_p && (seq_base >> 11) != 0u;   // (solve number 0 mod 2^21: the mark's initial value)
+    const int32_t batch_id = (int32_t)(((seq_base >> 11) & 0x7FFFFFu) << 8 | 1u);
+    bool mark_last = spec;                   // the first batch ends with a marked p update
     auto enqueue = [&](int count) -> int {
         for (int q = 0; q < count && next_j <= maxit; ++q, ++next_j) {
-            const CgIter it = iter_desc(next_j);
+            CgIter it = iter_desc(next_j);
+            if (mark_last && (q == count - 1 || next_j == maxit)) it.batch_mark = batch_id;
             // launch 1: [close iteration j-1: r.r, stop test, beta; p_j on the fly] KKT sweep Ap = M p_j + partial sums   :38,:42-50
             int pe = prof_begin(h, FOS_PROF_KKT, next_j, h->cg_total + next_j - 1);
             launch_kkt2_cg(c, it, h->AP);
@@ -403,7 +440,17 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     int first = h->last_cg_pred > 0 ? h->last_cg_pred + slack : h->cg_chunk;
     first = std::max(1, std::min(first, maxit));
     FOS_TRY(enqueue(first));
-    FOS_TRY(poll_state(h));
+    mark_last = false;
+    if (spec) {
+        LaunchCtx cg = c;
+        cg.gate = &h->st->done;
+        FOS_TRY((*post)(cg));
+        bool ended = false;
+        FOS_TRY(wait_cg_mark(h, (uint32_t)(seq_base >> 11), batch_id, &ended));
+        if (post_ran) *post_ran = ended;
+    } else {
+        FOS_TRY(poll_state(h));
+    }
     while (!h->st_host->done) {
         FOS_TRY(enqueue(h->cg_chunk));
         FOS_TRY(poll_state(h));
@@ -440,7 +487,7 @@ int prox_affine_direct(fos_solver* h, const d2* x) {
 }
 
 // prox!(y, S1::AffinePlusLinear, x) with the result left in h->SOL       affinepluslinear.jl:83-126
-int prox_affine(fos_solver* h, const d2* x) {
+int prox_affine(fos_solver* h, const d2* x, const PostFn* post = nullptr, bool* post_ran = nullptr) {
     if (h->direct) return prox_affine_direct(h, x);
     RoctxRange range("fos:prox_affine (rhs build + warm-started CG over the KKT operator)");
     LaunchCtx c = h->ctx();
@@ -464,16 +511,17 @@ int prox_affine(fos_solver* h, const d2* x) {
     double tol = std::max(std::pow(0.2, std::sqrt((double)h->prox_i)), (double)h->l_global * eps);
     h->prox_i += 1;                                                     // :114
     int64_t it = 0;
-    if (fused_rhs) FOS_TRY(cg_solve(h, h->SOL, x, tol, 1000, &it, h->RHS));
-    else FOS_TRY(cg_solve(h, h->SOL, h->RHS, tol, 1000, &it));          // :115-117 ; y aliases xinit (:106,:122)
+    if (fused_rhs) FOS_TRY(cg_solve(h, h->SOL, x, tol, 1000, &it, h->RHS, post, post_ran));
+    else FOS_TRY(cg_solve(h, h->SOL, h->RHS, tol, 1000, &it, nullptr, post, post_ran));          // :115-117 ; y aliases xinit (:106,:122)
     h->cgiter = it;                                                     // :121
     return FOS_OK;                                                      // :124 y2 .*= beta with beta = 1
 }
 
 // prox!(y, S2::DualConeProduct, x)                                        cones.jl:122-142
-int prox_cones(fos_solver* h, d2* out, const d2* in) {
+int prox_cones(fos_solver* h, d2* out, const d2* in, const int32_t* gate = nullptr) {
     RoctxRange range("fos:prox_cones (elementwise + SOC + Exp + batched PSD)");
     LaunchCtx c = h->ctx();
+    c.gate = gate;
     launch_cones_elementwise(c, out, in, h->ew_op);
     launch_cones_soc(c, out, in, h->soc, h->nsoc);
     launch_cones_exp(c, out, in, h->expc, h->nexp);
@@ -578,23 +626,40 @@ int ls_finish(fos_solver* h, int64_t i) {
 }
 
 // one outer iteration; *check_on receives the vector checkstatus is evaluated on (the cone-feasible point)
-int step_once(fos_solver* h, int64_t i, const d2** check_on) {
+int step_finish_launch(fos_solver* h, const LaunchCtx& c);
+int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bool* finish_done) {
     LaunchCtx c = h->ctx();
+    *finish_done = false;
     h->ls_now = h->ls_interval > 0 && (i % h->ls_interval) == 0;                                    // linesearch.jl:39
     if (h->ls_now) return ls_begin(h, check_on);
     switch (h->alg) {
-        case FOS_ALG_GAP: {                                              // gap.jl:61-80
-            FOS_TRY(prox_affine(h, h->X));                               // S1!: prox!(y,S1,x)          :45
-            launch_axpby(c, h->T1, h->alpha1, h->SOL, 1 - h->alpha1, h->X);   //   y = a1 y + (1-a1) x     :48
-            FOS_TRY(prox_cones(h, h->T2, h->T1));                        // S2!: prox!(y,S2,x)          :55
-            *check_on = h->T2;                                           //   checkstatus(status, y)    :56
-            return FOS_OK;
-        }
+        case FOS_ALG_GAP:                                                // gap.jl:61-80
         case FOS_ALG_GAPA: {                                             // gapa.jl:80-105
-            FOS_TRY(prox_affine(h, h->X));
-            launch_relax_a12(c, h->T1, h->SOL, h->X);                    // :67
-            FOS_TRY(prox_cones(h, h->T2, h->T1));
-            *check_on = h->T2;                                           // :75
+            // everything behind the CG solve of S1! -- and, when no status check sits in between, the final relaxation of
+            // the step too -- is handed to the solve as its `post` work (cg_solve): enqueued behind the first CG batch,
+            // gated, so that the GPU does not wait for the host to learn the iteration count
+            const bool gapa = h->alg == FOS_ALG_GAPA;
+            const PostFn post = [h, gapa, will_check](const LaunchCtx& cg) -> int {
+                if (gapa) launch_relax_a12(cg, h->T1, h->SOL, h->X);                          // gapa.jl:67
+                else launch_axpby(cg, h->T1, h->alpha1, h->SOL, 1 - h->alpha1, h->X);          //   y = a1 y + (1-a1) x     :48
+                FOS_TRY(prox_cones(h, h->T2, h->T1, cg.gate));                                // S2!: prox!(y,S2,x)  :55
+                if (!will_check) FOS_TRY(step_finish_launch(h, cg));
+                return FOS_OK;
+            };
+            // host-side state the post work advances (restored if its launches turn out to have been no-ops)
+            const int psd_cur = h->psd_cur, psd_have_prev = h->psd_have_prev;
+            const size_t prof_used = h->prof_used;
+            const int64_t psd_seen = h->prof_seen[FOS_PROF_PSD];
+            bool ran = false;
+            FOS_TRY(prox_affine(h, h->X, &post, &ran));                  // S1!: prox!(y,S1,x)          :45
+            if (!ran) {
+                h->psd_cur = psd_cur; h->psd_have_prev = psd_have_prev; h->prof_seen[FOS_PROF_PSD] = psd_seen;
+                // (event pairs recorded around no-op launches: forget them; the CG records of this solve stay)
+                for (size_t k = prof_used; k < h->prof_used; ++k) if (h->prof_recs[k].cls == FOS_PROF_PSD) h->prof_recs[k].cls = -1;
+                FOS_TRY(post(c));
+            }
+            *check_on = h->T2;                                           //   checkstatus(status, y)    :56
+            *finish_done = !will_check;
             return FOS_OK;
         }
         case FOS_ALG_FISTA: {                                            // fista.jl:28-48
@@ -624,6 +689,9 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on) {
 int step_finish(fos_solver* h, int64_t i) {
     LaunchCtx c = h->ctx();
     if (h->ls_now) { h->ls_now = false; return ls_finish(h, i); }
+    return step_finish_launch(h, c);
+}
+int step_finish_launch(fos_solver* h, const LaunchCtx& c) {
     switch (h->alg) {
         case FOS_ALG_GAP:
             launch_gap_final(c, h->X, h->T2, h->T1, h->alpha, h->alpha2);          // gap.jl:58,78
@@ -779,6 +847,9 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     h->m = m; h->n = n; h->l = n + m + 1; h->l_global = h->l;
     h->nnz = colptr[n] - 1;
     FOS_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    FOS_HIP(hipHostMalloc((void**)&h->mark, sizeof(HostMark), hipHostMallocMapped));
+    memset(h->mark, 0, sizeof(HostMark));
+    h->speculate = !(getenv("FOS_SPECULATE") && atoi(getenv("FOS_SPECULATE")) == 0);
 
     hipDeviceProp_t prop;
     FOS_HIP(hipGetDeviceProperties(&prop, device));
@@ -945,6 +1016,12 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     // ---- scalars
     FOS_TRY(dev_alloc(h, &h->st, 1));
     FOS_HIP(hipMemset(h->st, 0, sizeof(DevState)));
+    {
+        void* dp = nullptr;
+        FOS_HIP(hipHostGetDevicePointer(&dp, h->mark, 0));
+        const unsigned long long addr = (unsigned long long)(uintptr_t)dp;
+        FOS_HIP(hipMemcpy(&h->st->hostmark, &addr, sizeof(addr), hipMemcpyHostToDevice));
+    }
     FOS_HIP(hipHostMalloc((void**)&h->st_host, sizeof(DevState), hipHostMallocDefault));
     memset(h->st_host, 0, sizeof(DevState));
     FOS_TRY(dev_alloc(h, &h->partials, (size_t)6 * PART_CAP));
@@ -970,6 +1047,7 @@ int fos_destroy(fos_handle h) {
     for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (void* p : h->owned) (void)hipFree(p);
     if (h->st_host) (void)hipHostFree(h->st_host);
+    if (h->mark) (void)hipHostFree(h->mark);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return FOS_OK;
@@ -1290,14 +1368,15 @@ int fos_step(fos_handle h, int64_t i_first, int64_t count, int64_t checki, doubl
     int64_t done = 0;
     for (int64_t i = i_first; done < count; ++i) {
         const d2* check_on = nullptr;
-        FOS_TRY(step_once(h, i, &check_on));
         const bool do_check = (i % checki) == 0;                         // HSDEStatus.jl:28
+        bool finish_done = false;
+        FOS_TRY(step_once(h, i, &check_on, do_check, &finish_done));
         fos_check_result r;
         if (do_check) {
             FOS_TRY(status_check(h, check_on, eps, &r));
             h->last_checked = check_on;
         }
-        FOS_TRY(step_finish(h, i));
+        if (!finish_done) FOS_TRY(step_finish(h, i));
         ++done;
         if (do_check) {
             if (res) *res = r;

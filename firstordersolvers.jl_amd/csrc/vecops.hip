@@ -190,7 +190,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_pupdate_kernel(int64_t l, d2* 
                                                                  d2* __restrict__ x, const d2* __restrict__ r, DevState* st,
                                                                  const double* __restrict__ partials, int count,
                                                                  const double* __restrict__ reduced, int from_reduced, int j,
-                                                                 PeerBox pb, uint32_t seq_base) {
+                                                                 PeerBox pb, uint32_t seq_base, int32_t batch_mark) {
     const int64_t stride = (int64_t)gridDim.x * VEC_THREADS;
     const int64_t i0 = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x;
     d2 p0 = make_double2(0.0, 0.0), r0 = p0, x0 = p0;
@@ -202,6 +202,8 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_pupdate_kernel(int64_t l, d2* 
     if (!cl.ok) return;
     const double beta = cl.beta;
     const bool go_on = !cl.stop;
+    if (batch_mark != 0 && go_on && blockIdx.x == 0 && threadIdx.x == 0 && st->hostmark)      // the host's batch is used up, CG is not done
+        __hip_atomic_store(&reinterpret_cast<HostMark*>(st->hostmark)->batch, batch_mark, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (i0 < l) {
         x[i0] = make_double2(x0.x + alpha * p0.x, x0.y + alpha * p0.y);
         if (go_on) pnext[i0] = make_double2(p0.x * beta + r0.x, p0.y * beta + r0.y);
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_pupdate_kernel(int64_t l, d2* 
 void launch_cg_pupdate(const LaunchCtx& c, const CgIter& it, double2* x, double2* p_next) {
     hipLaunchKernelGGL(cg_pupdate_kernel, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p_next, (const d2*)it.p_cur, x, it.r, c.st,
                        c.partials + 3 * (size_t)PART_CAP, c.cg_blocks, c.reduced, it.rr_from_reduced, it.j,
-                       it.fold ? *it.fold : PeerBox{}, it.seq_base);
+                       it.fold ? *it.fold : PeerBox{}, it.seq_base, it.batch_mark);
 }
 
 void launch_cg_init(const LaunchCtx& c, const double2* rhs, const double2* Ap, double2* r, double2* p) {
@@ -240,7 +242,8 @@ void launch_cg_init_finalize(const LaunchCtx& c, const double2* r, double tol, i
 
 // out = a x + b y          (gap.jl:48  y .= a1.*y .+ (1-a1).*x ; fista.jl:37)
 __global__ __launch_bounds__(VEC_THREADS) void axpby_kernel(int64_t l, d2* __restrict__ out, double a, const d2* __restrict__ x,
-                                                            double b, const d2* __restrict__ y) {
+                                                            double b, const d2* __restrict__ y, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;                  // speculatively enqueued behind a CG batch that did not converge: no-op
     GRID_STRIDE(i, l) {
         const d2 xi = x[i], yi = y[i];
         out[i] = make_double2(a * xi.x + b * yi.x, a * xi.y + b * yi.y);
@@ -248,7 +251,8 @@ __global__ __launch_bounds__(VEC_THREADS) void axpby_kernel(int64_t l, d2* __res
 }
 // out = a12 y + (1-a12) x with a12 from the device state          gapa.jl:67
 __global__ __launch_bounds__(VEC_THREADS) void relax_a12_kernel(int64_t l, d2* __restrict__ out, const d2* __restrict__ y,
-                                                                const d2* __restrict__ x, const DevState* st) {
+                                                                const d2* __restrict__ x, const DevState* st, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;                  // speculatively enqueued behind a CG batch that did not converge: no-op
     const double a = st->alpha12, b = 1 - a;
     GRID_STRIDE(i, l) {
         const d2 xi = x[i], yi = y[i];
@@ -257,7 +261,8 @@ __global__ __launch_bounds__(VEC_THREADS) void relax_a12_kernel(int64_t l, d2* _
 }
 // tmp2 = a2 tmp2 + (1-a2) tmp1 ; x = a tmp2 + (1-a) x           gap.jl:58,78
 __global__ __launch_bounds__(VEC_THREADS) void gap_final_kernel(int64_t l, d2* __restrict__ x, const d2* __restrict__ t2,
-                                                                const d2* __restrict__ t1, double alpha, double alpha2) {
+                                                                const d2* __restrict__ t1, double alpha, double alpha2, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;                  // speculatively enqueued behind a CG batch that did not converge: no-op
     const double b2 = 1 - alpha2, b = 1 - alpha;
     GRID_STRIDE(i, l) {
         const d2 u = t2[i], v = t1[i];
@@ -272,7 +277,8 @@ __global__ __launch_bounds__(VEC_THREADS) void gap_final_kernel(int64_t l, d2* _
 // tau-row contributions go to reduced[8..10] (replicated across shards, added after the all-reduce).
 __global__ __launch_bounds__(VEC_THREADS) void gapa_final_kernel(int64_t l, d2* __restrict__ x, const d2* __restrict__ t2,
                                                                  const d2* __restrict__ t1, double alpha, const DevState* st,
-                                                                 double* __restrict__ partials, double* __restrict__ reduced, int64_t acc_from) {
+                                                                 double* __restrict__ partials, double* __restrict__ reduced, int64_t acc_from, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;                  // speculatively enqueued behind a CG batch that did not converge: no-op
     const double a12 = st->alpha12, b12 = 1 - a12, b = 1 - alpha;
     double acc[3] = {0.0, 0.0, 0.0};
     GRID_STRIDE(i, l) {
@@ -292,7 +298,8 @@ __global__ __launch_bounds__(VEC_THREADS) void gapa_final_kernel(int64_t l, d2* 
 }
 // scl = clamp(|sum|/sqrt(n1 n2),0,1), NaN -> 0 ; s = sqrt(1-scl^2) ; a12 = (1-beta) 2/(1+s) + 2 beta     gapa.jl:96-101
 __global__ __launch_bounds__(FIN_THREADS) void gapa_finalize_kernel(const double* __restrict__ partials, int count,
-                                                                    double* __restrict__ reduced, int from_reduced, double beta, DevState* st) {
+                                                                    double* __restrict__ reduced, int from_reduced, double beta, DevState* st, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;                  // speculatively enqueued behind a CG batch that did not converge: no-op
     __shared__ double sums[3];
     if (from_reduced) { if (threadIdx.x < 3) sums[threadIdx.x] = reduced[threadIdx.x]; __syncthreads(); }
     else reduce_partials<3>(partials, count, sums);
@@ -353,20 +360,20 @@ void launch_normdiff(const LaunchCtx& c, const double2* x, const double2* y) {
     hipLaunchKernelGGL(normdiff_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, y, c.partials);
 }
 void launch_axpby(const LaunchCtx& c, double2* out, double a, const double2* x, double b, const double2* y) {
-    hipLaunchKernelGGL(axpby_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, a, x, b, y);
+    hipLaunchKernelGGL(axpby_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, a, x, b, y, c.gate);
 }
 void launch_relax_a12(const LaunchCtx& c, double2* out, const double2* y, const double2* x) {
-    hipLaunchKernelGGL(relax_a12_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, y, x, c.st);
+    hipLaunchKernelGGL(relax_a12_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, y, x, c.st, c.gate);
 }
 void launch_gap_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha, double alpha2) {
-    hipLaunchKernelGGL(gap_final_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, t2, t1, alpha, alpha2);
+    hipLaunchKernelGGL(gap_final_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, t2, t1, alpha, alpha2, c.gate);
 }
 void launch_gapa_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha) {
     hipLaunchKernelGGL(gapa_final_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, t2, t1, alpha, c.st, c.partials, c.reduced,
-                       c.count_repl ? (int64_t)0 : c.n_repl);
+                       c.count_repl ? (int64_t)0 : c.n_repl, c.gate);
 }
 void launch_gapa_finalize(const LaunchCtx& c, double beta, int from_reduced) {
-    hipLaunchKernelGGL(gapa_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.vec_blocks, c.reduced, from_reduced, beta, c.st);
+    hipLaunchKernelGGL(gapa_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.vec_blocks, c.reduced, from_reduced, beta, c.st, c.gate);
 }
 void launch_fista_extrap(const LaunchCtx& c, double2* y, const double2* x, const double2* xold, double coef) {
     hipLaunchKernelGGL(fista_extrap_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, y, x, xold, coef);
@@ -570,7 +577,8 @@ __device__ __forceinline__ double ew_apply(int op, double v) {
 }
 // every index whose cone is Free/Zero/NonNeg/NonPos, plus the (tau,kappa) element; op byte: part1 | part2 << 2
 __global__ __launch_bounds__(VEC_THREADS) void cones_elementwise_kernel(int64_t l, d2* __restrict__ out, const d2* __restrict__ in,
-                                                                        const uint8_t* __restrict__ ew_op) {
+                                                                        const uint8_t* __restrict__ ew_op, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;                  // speculatively enqueued behind a CG batch that did not converge: no-op
     GRID_STRIDE(i, l) {
         const uint8_t op = ew_op[i];
         if (op == EW_SKIP) continue;
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cones_elementwise_kernel(int64_t 
     }
 }
 void launch_cones_elementwise(const LaunchCtx& c, double2* out, const double2* in, const uint8_t* ew_op) {
-    hipLaunchKernelGGL(cones_elementwise_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, in, ew_op);
+    hipLaunchKernelGGL(cones_elementwise_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, in, ew_op, c.gate);
 }
 
 // Second-order cones, one wavefront per cone, both copies (primal on one part, Moreau dual x + P(-x) on the
@@ -599,7 +607,8 @@ __device__ __forceinline__ SocOut soc_decide(double t, double nx) {
 constexpr double S45 = 0.7071067811865475;
 
 __global__ __launch_bounds__(VEC_THREADS) void cones_soc_kernel(d2* __restrict__ out, const d2* __restrict__ in,
-                                                                const ConeDesc* __restrict__ cones, int ncones) {
+                                                                const ConeDesc* __restrict__ cones, int ncones, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;                  // speculatively enqueued behind a CG batch that did not converge: no-op
     const int lane = threadIdx.x & 63;
     const int cone = blockIdx.x * (VEC_THREADS / 64) + (threadIdx.x >> 6);
     if (cone >= ncones) return;
@@ -714,7 +723,8 @@ __device__ void exp_prox(int type, const double* x, double* y) {
     y[0] = x[0] + t[0]; y[1] = x[1] + t[1]; y[2] = x[2] + t[2];
 }
 __global__ __launch_bounds__(64) void cones_exp_kernel(d2* __restrict__ out, const d2* __restrict__ in,
-                                                       const ConeDesc* __restrict__ cones, int ncones) {
+                                                       const ConeDesc* __restrict__ cones, int ncones, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;                  // speculatively enqueued behind a CG batch that did not converge: no-op
     const int job = blockIdx.x * 64 + threadIdx.x;
     if (job >= 2 * ncones) return;
     const ConeDesc cd = cones[job >> 1];
@@ -735,13 +745,13 @@ __global__ __launch_bounds__(64) void cones_exp_kernel(d2* __restrict__ out, con
 }
 void launch_cones_exp(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones) {
     if (ncones <= 0) return;
-    hipLaunchKernelGGL(cones_exp_kernel, dim3((2 * ncones + 63) / 64), dim3(64), 0, c.stream, out, in, cones, ncones);
+    hipLaunchKernelGGL(cones_exp_kernel, dim3((2 * ncones + 63) / 64), dim3(64), 0, c.stream, out, in, cones, ncones, c.gate);
 }
 
 void launch_cones_soc(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones) {
     if (ncones <= 0) return;
     const int per_block = VEC_THREADS / 64;
-    hipLaunchKernelGGL(cones_soc_kernel, dim3((ncones + per_block - 1) / per_block), dim3(VEC_THREADS), 0, c.stream, out, in, cones, ncones);
+    hipLaunchKernelGGL(cones_soc_kernel, dim3((ncones + per_block - 1) / per_block), dim3(VEC_THREADS), 0, c.stream, out, in, cones, ncones, c.gate);
 }
 
 }  // namespace fos
