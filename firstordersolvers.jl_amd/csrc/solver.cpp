@@ -337,8 +337,10 @@ int wait_cg_mark(fos_solver* h, uint32_t epoch, int32_t batch_id, bool* ended) {
         if ((spin & 0xFFFFu) == 0 && hipStreamQuery(h->stream) == hipSuccess) {          // everything enqueued has run
             if (__atomic_load_n(&m->seq, __ATOMIC_ACQUIRE) == epoch) { *ended = true; break; }
             if (__atomic_load_n(&m->batch, __ATOMIC_ACQUIRE) == batch_id) { *ended = false; break; }
-            set_error("the CG kernels left no completion mark (a kernel of the solve failed)");
-            return FOS_EHIP;
+            // no mark: a kernel of the solve gave up (a peer exchange timed out, ...) -- the ordinary state read reports why
+            FOS_TRY(poll_state(h));
+            *ended = h->st_host->done != 0;
+            return FOS_OK;
         }
     }
     if (*ended) { h->st_host->done = 1; h->st_host->iter = m->iter; h->st_host->hit_max = m->hit_max; h->st_host->rr = m->rr; }
@@ -402,7 +404,11 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
         return it;
     };
     const size_t prof_start = h->prof_used;
-    const bool spec = post && h->speculate && !h->sharded() && !c.between && !h->fuse_p && (seq_base >> 11) != 0u;   // (solve number 0 mod 2^21: the mark's initial value)
+    // (sharded: only with the exchanges folded into the CG kernels -- no collective call sits in the stream -- and only for GAP,
+    //  whose post-solve kernels contain no reduction; every rank takes the same decisions, so all mispredict together.
+    //  Solve number 0 mod 2^21 is the mark's initial value.)
+    const bool spec = post && h->speculate && !c.between && !h->fuse_p && (seq_base >> 11) != 0u &&
+                      (!h->sharded() || (fold && h->alg == FOS_ALG_GAP));
     const int32_t batch_id = (int32_t)(((seq_base >> 11) & 0x7FFFFFu) << 8 | 1u);
     bool mark_last = spec;                   // the first batch ends with a marked p update
     auto enqueue = [&](int count) -> int {
