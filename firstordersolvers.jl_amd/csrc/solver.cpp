@@ -334,6 +334,7 @@ int wait_cg_mark(fos_solver* h, uint32_t epoch, int32_t batch_id, bool* ended) {
     for (uint32_t spin = 1;; ++spin) {
         if (__atomic_load_n(&m->seq, __ATOMIC_ACQUIRE) == epoch) { *ended = true; break; }
         if (__atomic_load_n(&m->batch, __ATOMIC_ACQUIRE) == batch_id) { *ended = false; break; }
+        __builtin_ia32_pause();
         if ((spin & 0xFFFFu) == 0 && hipStreamQuery(h->stream) == hipSuccess) {          // everything enqueued has run
             if (__atomic_load_n(&m->seq, __ATOMIC_ACQUIRE) == epoch) { *ended = true; break; }
             if (__atomic_load_n(&m->batch, __ATOMIC_ACQUIRE) == batch_id) { *ended = false; break; }
