@@ -178,3 +178,29 @@ def test_nan_and_inf_through_dual_tiles_and_repartition(pkg, oracle):
         assert np.array_equal(out[rows], ref_bits[rows]), wg
         assert np.allclose(out[~rows], ref_bits[~rows], rtol=1e-13, atol=0), wg
     d.close()
+
+
+@pytest.mark.parametrize("algname", ["DR", "GAPA"])
+def test_speculation_past_cg_is_bitwise_neutral(pkg, monkeypatch, algname):
+    """The kernels behind a CG solve are enqueued, gated, before the host knows the iteration count (speculation past
+    the CG solve); on a misprediction -- the first solves of every run, whose counts grow -- they are no-ops and are enqueued
+    again.  Arithmetic and order are unchanged, so the iterates, the CG counts and the status sums must be BITWISE those of
+    the synchronous path (FOS_SPECULATE=0), on problems with and without PSD cones (the warm-start basis ping-pong is
+    host-side state that a misprediction has to roll back)."""
+    for prob in (pkg.workloads.small_mixed(), pkg.workloads.c4_block_sdp(nblocks=6, k=8, p=8)):
+        runs = []
+        for spec in ("1", "0"):
+            monkeypatch.setenv("FOS_SPECULATE", spec)
+            d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+            d.set_alg(pkg.DR() if algname == "DR" else pkg.GAPA(0.8, 0.5))
+            d.set_iterate(None)
+            cg = []
+            for i in range(1, 41):
+                d.step(i, 1, 10 ** 9, 1e-9)
+                cg.append(d.cgiter())
+            done, checked, res = d.step(41, 4, 4, 1e-9)          # a batch of four ending in a status check (i = 44)
+            runs.append((d.get_iterate(), cg, (res.p, res.d, res.g, res.ctx, res.bty)))
+            d.close()
+        assert runs[0][1] == runs[1][1]
+        assert np.array_equal(runs[0][0], runs[1][0])
+        assert np.array_equal(np.array(runs[0][2]), np.array(runs[1][2]), equal_nan=True)
