@@ -109,6 +109,11 @@ __device__ __forceinline__ bool peer_fold_sum(const PeerBox& pb, uint32_t seq, d
     return true;
 }
 
+// Values that cross workgroups INSIDE a kernel: the L2s of the XCDs are not coherent with each other between kernel boundaries,
+// so such a value is written through to memory and read past the caches (agent-scope accesses).
+__device__ __forceinline__ void st_coh(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_coh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // What closes CG iteration `jd` (conjugategradients.jl:42-50): r.r from the partial sums the x,r update left, the stop test
 // `norm(r) <= tol || iter >= max_iters`, and -- if CG goes on -- beta = rn / rnold.  EVERY workgroup of the calling kernel
 // evaluates it on the same records in the same order (so all take the same decision); workgroup 0 stores the scalars.

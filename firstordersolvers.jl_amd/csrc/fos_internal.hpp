@@ -169,7 +169,7 @@ struct DevState {
                            // fused finalize+p-update kernel derive beta itself without racing the one that stores it)
     int32_t iter, done, maxit, hit_max;
     int32_t xchg_failed;   // a peer-mailbox exchange timed out (PeerBox below); every later exchange is skipped
-    int32_t pad0;
+    int32_t bar_failed;    // a wait between workgroups inside a kernel timed out (cg_update_kernel's producer flags)
     // algorithm scalars
     double alpha12;        // GAPAData.alpha12 (gapa.jl:29,101)
     double gapa_scl;       // last normedScalar value (diagnostic)
@@ -237,6 +237,7 @@ struct LaunchCtx {
     // replicated entries (indices < n_repl) are counted by ONE rank only (count_repl).
     int (*between)(void*);
     void* between_arg;
+    double* pre = nullptr;           // 3 x 16 doubles + 16 flags: the producer workgroups' sums of the sweep records (cg_update_kernel)
     const int32_t* gate = nullptr;   // non-null: the relaxation / cone kernels run only if *gate != 0 (DevState.done: enqueued behind a CG batch)
     int32_t count_repl;         // 1: this rank counts the replicated entries in scalar sums (always 1 when not row-sharded)
     int64_t n_repl;             // replicated leading entries of every vector (0 when not row-sharded)

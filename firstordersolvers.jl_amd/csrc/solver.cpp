@@ -145,6 +145,8 @@ struct fos_solver {
     // speculation past a CG solve: the kernels that follow it are enqueued (gated on DevState.done) BEFORE the host learns the
     // iteration count, which it then reads from a record the CG kernels write into pinned host memory (wait_cg_mark)
     HostMark* mark = nullptr;                  // pinned + mapped; DevState.hostmark points at it
+    double* pre_sums = nullptr;                // LaunchCtx::pre
+    bool pre_on = true;
     bool speculate = true;
     double* partials = nullptr;
     double* reduced = nullptr;                 // 16 doubles
@@ -217,6 +219,7 @@ struct fos_solver {
         c.partials = partials; c.reduced = reduced; c.vec_blocks = vec_blocks; c.cg_blocks = cg_blocks;
         c.peer = peer_on ? &peer : nullptr;
         c.def_mask = def_mask;
+        c.pre = pre_on ? pre_sums : nullptr;
         c.between = nullptr; c.between_arg = nullptr;
         c.count_repl = (!row_sharded || rank == 0) ? 1 : 0;
         c.n_repl = row_sharded ? n : 0;
@@ -321,6 +324,10 @@ int poll_state(fos_solver* h) {
     if (h->st_host->xchg_failed) {
         set_error("rank %d: a peer-mailbox exchange timed out (a peer rank stopped or is not running the same call sequence)", h->rank);
         return FOS_ECOMM;
+    }
+    if (h->st_host->bar_failed) {
+        set_error("cg_update_kernel: the producer workgroups' flags did not arrive within 5 s; set FOS_CG_PRE=0");
+        return FOS_EHIP;
     }
     return FOS_OK;
 }
@@ -1023,6 +1030,9 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     // ---- scalars
     FOS_TRY(dev_alloc(h, &h->st, 1));
     FOS_HIP(hipMemset(h->st, 0, sizeof(DevState)));
+    FOS_TRY(dev_alloc(h, &h->pre_sums, 3 * 16 + 16));
+    FOS_HIP(hipMemset(h->pre_sums, 0, sizeof(double) * (3 * 16 + 16)));
+    h->pre_on = !(getenv("FOS_CG_PRE") && atoi(getenv("FOS_CG_PRE")) == 0);
     {
         void* dp = nullptr;
         FOS_HIP(hipHostGetDevicePointer(&dp, h->mark, 0));

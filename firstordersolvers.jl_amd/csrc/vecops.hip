@@ -12,6 +12,7 @@
 namespace fos {
 
 constexpr int VEC_THREADS = 256;
+constexpr int PRE_NPROD = 16;        // workgroups of cg_update_kernel that add the sweep's records for all the others
 constexpr int FIN_THREADS = 1024;
 
 template <int NACC>
@@ -78,7 +79,8 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
                                                                 DevState* st, const double* __restrict__ kkt_partials, int nkkt,
                                                                 const double* __restrict__ reduced, int from_reduced, int j,
                                                                 double* __restrict__ partials, DevBlkCsr S, const double* __restrict__ cb, int n,
-                                                                const uint32_t* __restrict__ def_mask, PeerBox pb, uint32_t seq_base, int count_repl) {
+                                                                const uint32_t* __restrict__ def_mask, PeerBox pb, uint32_t seq_base, int count_repl,
+                                                                double* __restrict__ pre, uint32_t pre_seq) {
     // the first element of this thread's slice is requested BEFORE the scalar prologue (two dependent round trips and two
     // barriers): on small operators the prologue's latency, not bandwidth, is what this kernel costs
     const int64_t stride = (int64_t)gridDim.x * VEC_THREADS;
@@ -91,6 +93,36 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
     if (FOLD && st->xchg_failed) return;
     __shared__ double sums[3];
     if (from_reduced) { if (threadIdx.x < 3) sums[threadIdx.x] = reduced[threadIdx.x]; __syncthreads(); }
+    else if (pre != nullptr) {
+        // Thousands of sweep records (C4: 4 224): every workgroup adding them all again cost ~6 us of this kernel.  Instead the
+        // first PRE_NPROD workgroups -- always dispatched first, so a waiting workgroup can never keep them from running --
+        // add a slice each, publish the three sums (written through to memory) and raise a flag carrying this launch's
+        // number; everybody waits for the flags (cache-bypassing loads: no atomics, nothing serialises) and adds the
+        // PRE_NPROD partial results in order.  Fixed order, same bits in every workgroup.
+        uint32_t* flags = reinterpret_cast<uint32_t*>(pre + 3 * PRE_NPROD);
+        if (blockIdx.x < PRE_NPROD) {
+            const int per = (nkkt + PRE_NPROD - 1) / PRE_NPROD;
+            const int lo = min((int)blockIdx.x * per, nkkt), cnt = min(per, nkkt - lo);
+            reduce_partials<3>(kkt_partials + 3 * (size_t)lo, cnt, sums);
+            if (threadIdx.x < 3) st_coh(pre + 3 * blockIdx.x + threadIdx.x, sums[threadIdx.x]);
+            __syncthreads();                                     // (the three stores have been acknowledged)
+            if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, pre_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (threadIdx.x < PRE_NPROD) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pre_seq) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 500000000LL) { st->bar_failed = 1; st->done = 1; break; }      // 5 s of the 100 MHz clock: give up, flag the state
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            double sum = 0.0;
+            for (int b = 0; b < PRE_NPROD; ++b) sum += ld_coh(pre + 3 * b + threadIdx.x);
+            sums[threadIdx.x] = sum;
+        }
+        __syncthreads();
+    }
     else reduce_partials<3>(kkt_partials, nkkt, sums);
     if constexpr (FOLD) {
         if (!peer_fold_sum<3>(pb, seq_base + 2u * (uint32_t)j, sums, st)) return;
@@ -171,9 +203,12 @@ void launch_cg_update(const LaunchCtx& c, const CgIter& it, double2* x, double2*
     double* rr_out = c.partials + 3 * (size_t)PART_CAP;
     const PeerBox pb = it.fold ? *it.fold : PeerBox{};
     dim3 grid(c.cg_blocks), block(VEC_THREADS);
+    // many sweep records and enough workgroups: the first PRE_NPROD of them add the records for all (cg_update_kernel)
+    double* pre = (c.pre && !it.fold && !kkt_from_reduced && c.S.nwg >= 2048 && c.cg_blocks >= 4 * PRE_NPROD) ? c.pre : nullptr;
 #define FOS_UPD(DEF, FOLD, XUPD)                                                                                             \
     hipLaunchKernelGGL((cg_update_kernel<DEF, FOLD, XUPD>), grid, block, 0, c.stream, c.l, x, r, (const d2*)it.p_cur, Ap, c.st, c.partials, \
-                       c.S.nwg, c.reduced, it.fold ? 0 : kkt_from_reduced, it.j, rr_out, c.S, c.cb, (int)c.n, c.def_mask, pb, it.seq_base, (int)c.count_repl)
+                       c.S.nwg, c.reduced, it.fold ? 0 : kkt_from_reduced, it.j, rr_out, c.S, c.cb, (int)c.n, c.def_mask, pb, it.seq_base, (int)c.count_repl, \
+                       pre, (uint32_t)(it.seq_base + 2u * (uint32_t)it.j + 1u))
 #define FOS_UPD2(DEF, FOLD) do { if (it.fuse_p) FOS_UPD(DEF, FOLD, true); else FOS_UPD(DEF, FOLD, false); } while (0)
     if (c.S.ndef > 0) { if (it.fold) FOS_UPD2(true, true); else FOS_UPD2(true, false); }
     else { if (it.fold) FOS_UPD2(false, true); else FOS_UPD2(false, false); }
