@@ -38,7 +38,8 @@ __host__ __device__ inline int psd_ld(int k) {
     return ld;
 }
 
-__host__ inline size_t psd_lds_bytes(int k) { return (size_t)(32 + k * psd_ld(k) + 2 * k + 16) * sizeof(double); }
+constexpr int PSD_RED_SCRATCH = 256;      // doubles of LDS behind wgt / inv: the reducer of jacobi64_regs (order 64 only)
+__host__ inline size_t psd_lds_bytes(int k) { return (size_t)(32 + k * psd_ld(k) + 2 * k + 16 + (k == 64 ? PSD_RED_SCRATCH : 0)) * sizeof(double); }
 
 __device__ __forceinline__ void idx_to_ij(int idx, int k, int& i, int& j) {
     // packed lower triangle, column-major: column j starts at S(j) = j k - j (j-1)/2
@@ -164,6 +165,8 @@ __device__ __forceinline__ int jacobi64(double* __restrict__ G, const int ld, co
 // ended with at the previous outer iteration (read from vin, the new basis is written to vout).  The iterates of the
 // solver change slowly, so V_prev nearly diagonalises the new matrix and 3-5 sweeps replace 9-10 (the convergence
 // test -- a full sweep without a rotation -- is unchanged, so accuracy does not depend on the start).  Orders <= 64.
+__device__ __forceinline__ int jacobi64_regs(double* __restrict__ G, const int ld, const int tid, const double tol2, double* scratch);
+
 template <bool USE_LDS, bool WARM, int THREADS>
 __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, const d2* __restrict__ in,
                                                           const ConeDesc* __restrict__ cones,
@@ -290,7 +293,9 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
     const double tol2 = tol * tol;
 
     if (k == 64 && sigma > 0.0) {
-        nsweeps = jacobi64<THREADS, THREADS / 32>(G, ld, tid, tol2);
+        // 256 threads: the column halves live in registers (jacobi64_regs); more threads: G stays in LDS (jacobi64)
+        if constexpr (USE_LDS && THREADS == 256) nsweeps = jacobi64_regs(G, ld, tid, tol2, wgt + 2 * k);
+        else nsweeps = jacobi64<THREADS, THREADS / 32>(G, ld, tid, tol2);
     } else if (k > 1 && sigma > 0.0) {
         for (int sweep = 0; sweep < PSD_MAX_SWEEPS; ++sweep) {
             int rotated = 0, big = 0;
@@ -480,21 +485,46 @@ __device__ __forceinline__ void jacobi_angle(double a, double b, double g, doubl
     if (gg > JACOBI_SMALL2 * ab || sn * sn > JACOBI_SMALL2) big = 1;
 }
 
+// The three step functions below are written for R rows per lane and a reducer `Red` whose sum(v) returns the total of v over
+// ALL lanes that share a column, the same bits in each: the wave kernel (R = 32) needs only the add across the two halves of
+// the wavefront; the four-wavefront form (R = 8, jacobi64_regs) adds an exchange through LDS.
+struct RedHalf {
+    __device__ __forceinline__ double sum(double v) { return half_sum(v); }
+    __device__ __forceinline__ int any(int f) { return __ballot(f) != 0; }
+};
+// four wavefronts per matrix: lane (s, h), h = 2 w + (lane >> 5), owns rows 8h .. 8h+7; partial sums go through a double-buffered
+// LDS array [2][4][32] with ONE workgroup barrier per reduction (a wavefront can reach its next write of a buffer only after the
+// barrier in between, which every wavefront passes after its reads of that buffer)
+struct RedQuad {
+    double* buf; int w, s; int phase;
+    __device__ __forceinline__ double sum(double v) {
+        v = half_sum(v);
+        double* b = buf + (phase & 1) * 128;
+        b[w * 32 + s] = v;                       // (both halves of the wavefront hold the same value)
+        __syncthreads();
+        const double t = (b[s] + b[32 + s]) + (b[64 + s] + b[96 + s]);
+        ++phase;
+        return t;
+    }
+    __device__ __forceinline__ int any(int f) { return __syncthreads_or(f); }
+};
+
 // g = U . V over the 64 rows (the squared norms a, b are NOT recomputed per step: they travel with the columns and are
 // updated by the rotation -- a' = a - t g, b' = b + t g, t = tan(theta) -- and refreshed from the columns at every sweep start)
-__device__ __forceinline__ double dot32(const double (&U)[32], const double (&V)[32]) {
+template <int R, class Red>
+__device__ __forceinline__ double dotR(const double (&U)[R], const double (&V)[R], Red& red) {
     double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
 #pragma unroll
-    for (int r = 0; r < 32; r += 4) {
+    for (int r = 0; r < R; r += 4) {
         g0 += U[r] * V[r]; g1 += U[r + 1] * V[r + 1]; g2 += U[r + 2] * V[r + 2]; g3 += U[r + 3] * V[r + 3];
     }
-    return half_sum((g0 + g1) + (g2 + g3));
+    return red.sum((g0 + g1) + (g2 + g3));
 }
-__device__ __forceinline__ double norm32(const double (&U)[32]) { return dot32(U, U); }
 
 // even step: the two columns of the lane's own seat pair
-__device__ __forceinline__ void jstep_even(double (&U)[32], double (&V)[32], double& a, double& b, double tol2, int& rotated, int& big) {
-    const double g = dot32(U, V);
+template <int R, class Red>
+__device__ __forceinline__ void jstep_even(double (&U)[R], double (&V)[R], double& a, double& b, double tol2, int& rotated, int& big, Red& red) {
+    const double g = dotR<R>(U, V, red);
     const double gg = g * g, ab = a * b;
     const bool need = gg > tol2 * ab;
     if (__ballot(need) == 0) return;
@@ -506,7 +536,7 @@ __device__ __forceinline__ void jstep_even(double (&U)[32], double (&V)[32], dou
         a = fmax(a - tg, 0.0); b = b + tg;
     }
 #pragma unroll
-    for (int r = 0; r < 32; ++r) {
+    for (int r = 0; r < R; ++r) {
         const double u = U[r], v = V[r];
         U[r] = cs * u - sn * v;
         V[r] = sn * u + cs * v;
@@ -517,12 +547,13 @@ __device__ __forceinline__ void jstep_even(double (&U)[32], double (&V)[32], dou
 // the rotated partner takes the lane's seat and the rotated own column moves up into W of lane s+1.  Seat pair 31 has no upper
 // neighbour: its U stays, and what it sends "up" -- into lane (0, h=1), which has no lower neighbour -- is that lane's own W,
 // which it has just fetched.
-__device__ __forceinline__ void jstep_odd(double (&U)[32], double (&W)[32], double& a, double& bw, bool last, double tol2, int& rotated, int& big) {
-    double X[32];
+template <int R, class Red>
+__device__ __forceinline__ void jstep_odd(double (&U)[R], double (&W)[R], double& a, double& bw, bool last, double tol2, int& rotated, int& big, Red& red) {
+    double X[R];
 #pragma unroll
-    for (int r = 0; r < 32; ++r) X[r] = dpp_shift_f64<DPP_WAVE_SHL1>(0.0, W[r]);
+    for (int r = 0; r < R; ++r) X[r] = dpp_shift_f64<DPP_WAVE_SHL1>(0.0, W[r]);
     double b = dpp_shift_f64<DPP_WAVE_SHL1>(0.0, bw);
-    const double g = dot32(U, X);
+    const double g = dotR<R>(U, X, red);
     const double gg = g * g, ab = a * b;
     const bool need = !last && gg > tol2 * ab;
     double cs = 1.0, sn = 0.0, an = a;
@@ -535,7 +566,7 @@ __device__ __forceinline__ void jstep_odd(double (&U)[32], double (&W)[32], doub
     // new own seat = c1 U + c2 X ; sent up = c3 U + c4 X      (rotation + seat swap; identity for the last seat pair)
     const double c1 = last ? 1.0 : sn, c2 = last ? 0.0 : cs, c3 = last ? 0.0 : cs, c4 = last ? 1.0 : -sn;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) {
+    for (int r = 0; r < R; ++r) {
         const double u = U[r], x = X[r];
         const double up = c3 * u + c4 * x;
         U[r] = c1 * u + c2 * x;
@@ -544,6 +575,44 @@ __device__ __forceinline__ void jstep_odd(double (&U)[32], double (&W)[32], doub
     // the squared norms travel with their columns
     a = last ? a : b;
     bw = dpp_shift_f64<DPP_WAVE_SHR1>(bw, last ? b : an);
+}
+
+// the sweeps of an order-64 matrix with the column halves (R rows per lane) in registers: odd-even ordering, 64 steps per sweep
+template <int R, class Red>
+__device__ __forceinline__ int jacobi64_sweeps(double (&A)[R], double (&B)[R], bool last, double tol2, Red& red) {
+    int nsweeps = 0;
+    for (int sweep = 0; sweep < PSD_MAX_SWEEPS; ++sweep) {
+        int rotated = 0, big = 0;
+        nsweeps = sweep + 1;
+        double na = dotR<R>(A, A, red), nb = dotR<R>(B, B, red);
+        for (int q = 0; q < 16; ++q) {
+            jstep_even<R>(A, B, na, nb, tol2, rotated, big, red);          // seats (2s, 2s+1) = (A, B); afterwards seat 2s+1 holds A
+            jstep_odd<R>(A, B, na, nb, last, tol2, rotated, big, red);     // seat 2s+1 (A) with seat 2s+2 (B of lane s+1)
+            jstep_even<R>(A, B, na, nb, tol2, rotated, big, red);          // afterwards seat 2s+1 holds B
+            jstep_odd<R>(B, A, nb, na, last, tol2, rotated, big, red);     // seat 2s+1 (B) with seat 2s+2 (A of lane s+1)
+        }
+        if (!red.any(rotated)) break;
+        if (!red.any(big)) break;
+    }
+    return nsweeps;
+}
+
+// jacobi64 for a workgroup of FOUR wavefronts with the columns in registers (a batch too small to give every SIMD a matrix of
+// its own -- a shard of a multi-GPU run): G (LDS, column-major) is read once, rotated in registers, written back.  `scratch`:
+// 256 doubles of LDS for the reducer.
+__device__ __forceinline__ int jacobi64_regs(double* __restrict__ G, const int ld, const int tid, const double tol2, double* scratch) {
+    const int w = tid >> 6, ln = tid & 63, s = ln & 31, h = 2 * w + (ln >> 5);
+    double A[8], B[8];
+    double* ga = G + 8 * h + (size_t)(2 * s) * ld;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { A[r] = ga[r]; B[r] = ga[r + ld]; }
+    RedQuad red{scratch, w, s, 0};
+    const int nsweeps = jacobi64_sweeps<8>(A, B, s == 31, tol2, red);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { ga[r] = A[r]; ga[r + ld] = B[r]; }
+    __syncthreads();
+    return nsweeps;
 }
 
 template <bool WARM>
@@ -640,21 +709,8 @@ __global__ __launch_bounds__(64) void psd64_wave_kernel(d2* __restrict__ out, co
     int nsweeps = 0;
     if (sigma > 0.0) {
         const double tol = 64.0 * 2.220446049250313e-16;
-        const double tol2 = tol * tol;
-        const bool last = s == 31;
-        for (int sweep = 0; sweep < PSD_MAX_SWEEPS; ++sweep) {
-            int rotated = 0, big = 0;
-            nsweeps = sweep + 1;
-            double na = norm32(A), nb = norm32(B);
-            for (int q = 0; q < 16; ++q) {
-                jstep_even(A, B, na, nb, tol2, rotated, big);          // seats (2s, 2s+1) = (A, B); afterwards seat 2s+1 holds A
-                jstep_odd(A, B, na, nb, last, tol2, rotated, big);     // seat 2s+1 (A) with seat 2s+2 (B of lane s+1)
-                jstep_even(A, B, na, nb, tol2, rotated, big);          // afterwards seat 2s+1 holds B
-                jstep_odd(B, A, nb, na, last, tol2, rotated, big);     // seat 2s+1 (B) with seat 2s+2 (A of lane s+1)
-            }
-            if (__ballot(rotated) == 0) break;
-            if (__ballot(big) == 0) break;
-        }
+        RedHalf red;
+        nsweeps = jacobi64_sweeps<32>(A, B, s == 31, tol * tol, red);
     }
     if (stats && lane == 0) stats[blockIdx.x] = nsweeps;
     if (phase_limit == 3) return;
@@ -758,12 +814,13 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) { set_error("hipGetDevice failed or device id >= %d", MAXDEV); return FOS_EHIP; }
     if (!cus_of[dev]) { hipDeviceProp_t prop; cus_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
     const int cus = cus_of[dev];
-    // every cone of order 64: one wavefront per matrix, sweeps in registers (FOS_PSD_WAVE=0: the workgroup kernel; =1: always).
-    // With fewer matrices than half the CUs (a shard of a multi-GPU run) most SIMDs would idle next to one busy wavefront: the
-    // 512-thread workgroup kernel is then as fast or faster (128 matrices: 166 vs 173 us).
+    // every cone of order 64: the sweeps run in registers, one WAVEFRONT per matrix when there are more than two matrices per CU
+    // (every SIMD then has a wavefront of its own: 1024 matrices 195 us against 288), one WORKGROUP of four wavefronts per matrix
+    // (psd_kernel<.., 256>, jacobi64_regs) below that (a shard of a multi-GPU run; 128 / 256 / 512 matrices: 118 / 127 / 179 us
+    // against 173 / 182 / 190).  FOS_PSD_WAVE=0 / 1 forces the workgroup / the wavefront form.
     const char* wave_str = getenv("FOS_PSD_WAVE");          // (read per call: the tests switch it)
     const int wave_env = wave_str ? atoi(wave_str) : -1;
-    if (kmin == 64 && kmax == 64 && wave_env != 0 && (wave_env == 1 || 4 * ncones > cus)) {
+    if (kmin == 64 && kmax == 64 && wave_env != 0 && (wave_env == 1 || ncones > cus)) {
         const size_t wl = psd64w_lds_bytes();
         const size_t vs = (size_t)64 * 64;
         if (vin && vout)
@@ -777,7 +834,9 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     const bool warm = vin && vout && kmax <= 64 && use_lds;
     // few matrices (a shard of a multi-GPU run, a small problem): 512 threads per matrix cut the latency of one
     // projection; many matrices: 256 threads (4 per CU) maximise throughput.  Per DEVICE: a process may hold handles on several.
-    const bool wide = (warm && (2 * ncones <= 2 * cus) && !getenv("FOS_PSD_NARROW")) || (warm && getenv("FOS_PSD_WIDE"));
+    // (order 64 everywhere: the 256-thread kernel keeps the column halves in registers and beats 512 threads on a small batch)
+    const bool all64 = kmin == 64 && kmax == 64;
+    const bool wide = (warm && !all64 && (2 * ncones <= 2 * cus) && !getenv("FOS_PSD_NARROW")) || (warm && getenv("FOS_PSD_WIDE"));
     if (use_lds && !attr_set[dev]) {          // hipFuncSetAttribute acts on the CURRENT device
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, false, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
