@@ -108,13 +108,26 @@ def main():
     ap.add_argument("--no-weak-extra", action="store_true", help="N > 1: skip the additional weak-scaling measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as CHILD processes of torch.distributed.run,
+        # BEFORE this process touches the GPU (it never does), pass their output through and exit with the launcher's code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        proc = subprocess.run(cmd, env=env)
+        raise SystemExit(proc.returncode)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -363,7 +376,8 @@ def main():
                           "timed iterations %d..%d" % (l_global * EPS, i_floor, warm + 1, warm + args.steps),
                 "local_m": int(prob.m), "local_n": int(prob.n), "local_nnz": int(prob.nnz),
                 "cg_iters_per_step": round(cg_timed / max(1, args.steps), 2),
-                "cg_launches_per_iteration": 2 if os.environ.get("FOS_CG_FUSE_P") == "1" else 3,
+                "cg_variant": dev.cg_variant_name(),
+                "cg_launches_per_iteration": 3 if dev.cg_variant_name() == "reference" else 2,
                 "parallelism": "cone-sharded x%d (scalar sums: %s)" % (world, reduction) if dist is not None else "single GPU",
                 "residuals_after_run": {"p": chk.p, "d": chk.d, "g": chk.g, "iteration": it},
                 "setup_s": round(t_setup, 2), "generate_s": round(t_gen, 2),

@@ -119,26 +119,41 @@ __device__ __forceinline__ double ld_coh(const double* p) { return __hip_atomic_
 // evaluates it on the same records in the same order (so all take the same decision); workgroup 0 stores the scalars.
 // r.r ping-pongs: RN[k] = r.r after iteration k (RN[0]: the start) lives in st->rn2[k & 1]; iteration j's alpha reads RN[j-1].
 struct CgClose { double beta; bool stop; bool ok; };
+
+// <= 1024 per-workgroup records added by EVERY wavefront itself (lane-strided, then the butterfly): no LDS, no workgroup
+// barrier, all loads in flight together; the same bits in every wavefront of the grid
+__device__ __forceinline__ double wave_sum_records(const double* __restrict__ rec, int count) {
+    const int lane = threadIdx.x & 63;
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (lane + 64 * k < count) ? rec[lane + 64 * k] : 0.0;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += v[k];
+    return wave_sum(s);
+}
+
+// CG has stopped at iteration jd (one thread of one workgroup): iteration count, flag, and the record the host may be spinning on
+__device__ __forceinline__ void cg_signal_stop(DevState* st, int jd, int maxit, double rr, uint32_t epoch) {
+    st->iter = jd;
+    st->hit_max = (jd == maxit) ? 1 : 0;                          // conjugategradients.jl:53
+    __threadfence();
+    st->done = 1;
+    if (st->hostmark) {                                           // tell the host directly
+        HostMark* m = reinterpret_cast<HostMark*>(st->hostmark);
+        m->iter = jd; m->hit_max = (jd == maxit) ? 1 : 0; m->rr = rr;
+        __threadfence_system();
+        __hip_atomic_store(&m->seq, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __device__ __forceinline__ CgClose cg_close_iteration(DevState* st, const double* __restrict__ rr_partials, int count,
                                                       const double* __restrict__ reduced, int from_reduced,
                                                       const d2* __restrict__ r, int64_t l, int jd, const PeerBox& pb, uint32_t seq_base) {
-    // Every WAVEFRONT adds the <= 1024 records itself (lane-strided, then the butterfly): no LDS, no workgroup barrier, and
-    // all loads of this prologue are in flight together -- it is latency that every workgroup of a sweep pays before its first tile.
-    const int lane = threadIdx.x & 63;
     const d2 rt = r[l - 1];
     const double rnold = st->rn2[(jd - 1) & 1], tol = st->tol;
     const int maxit = st->maxit;
-    double s = 0.0;
-    if (from_reduced) {
-        s = reduced[0];
-    } else {
-        double v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = (lane + 64 * k < count) ? rr_partials[lane + 64 * k] : 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += v[k];
-        s = wave_sum(s);
-    }
+    double s = from_reduced ? reduced[0] : wave_sum_records(rr_partials, count);
     CgClose c{0.0, true, true};
     if (pb.nranks > 0) {
         __shared__ double sums[1];
@@ -153,16 +168,7 @@ __device__ __forceinline__ CgClose cg_close_iteration(DevState* st, const double
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->rr = rr;
         if (c.stop) {
-            st->iter = jd;
-            st->hit_max = (jd == maxit) ? 1 : 0;                  // :53
-            __threadfence();
-            st->done = 1;
-            if (st->hostmark) {                                   // tell the host directly (it may be spinning on this record)
-                HostMark* m = reinterpret_cast<HostMark*>(st->hostmark);
-                m->iter = jd; m->hit_max = (jd == maxit) ? 1 : 0; m->rr = rr;
-                __threadfence_system();
-                __hip_atomic_store(&m->seq, seq_base >> 11, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            cg_signal_stop(st, jd, maxit, rr, seq_base >> 11);
         } else {
             st->rn_old = rnold;
             st->rn = rr;
@@ -172,6 +178,30 @@ __device__ __forceinline__ CgClose cg_close_iteration(DevState* st, const double
         }
     }
     return c;
+}
+
+// Merged-reduction CG, single GPU (CgmIter::close_in_update == false): the SWEEP behind the update of iteration jd closes it --
+// r.r from that update's records, the stop test of conjugategradients.jl:42; every workgroup evaluates it on the same records in
+// the same order and returns true when CG has stopped (then nothing is swept).  Workgroup 0 stores g_jd for the next update.
+__device__ __forceinline__ bool cgm_close_in_sweep(DevState* st, const double* __restrict__ rr_partials, int count,
+                                                   const d2* __restrict__ r, int64_t l, int jd, uint32_t epoch, int32_t batch_mark) {
+    const d2 rt = r[l - 1];
+    const double tol = st->tol;
+    const int maxit = st->maxit;
+    const double rr = wave_sum_records(rr_partials, count) + (rt.x * rt.x + rt.y * rt.y);
+    const bool stop = (sqrt(rr) <= tol) || (jd >= maxit);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->rr = rr;
+        if (stop) {
+            cg_signal_stop(st, jd, maxit, rr, epoch);
+        } else {
+            st->rn2[jd & 1] = rr;
+            st->iter = jd + 1;
+            if (batch_mark != 0 && st->hostmark)                  // the host's batch is used up, CG is not done
+                __hip_atomic_store(&reinterpret_cast<HostMark*>(st->hostmark)->batch, batch_mark, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    return stop;
 }
 
 }  // namespace fos

@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -167,7 +168,8 @@ struct DevState {
     double rn, rn_old, alpha, beta, pAp, rr, tol;
     double rn2[2];         // r.r ping-pong: CG iteration j reads rn2[j&1] and writes rn2[(j+1)&1] (lets every workgroup of the
                            // fused finalize+p-update kernel derive beta itself without racing the one that stores it)
-    int32_t iter, done, maxit, hit_max;
+    int32_t iter, done;    // (adjacent and 8-byte aligned: cg_pupdate_kernel reads the pair with ONE load)
+    int32_t maxit, hit_max;
     int32_t xchg_failed;   // a peer-mailbox exchange timed out (PeerBox below); every later exchange is skipped
     int32_t bar_failed;    // a wait between workgroups inside a kernel timed out (cg_update_kernel's producer flags)
     // algorithm scalars
@@ -178,7 +180,15 @@ struct DevState {
     // host-visible (pinned, mapped) record the kernel that ends a CG solve fills: lets the host see the end of the solve
     // without a stream synchronisation (HostMark below; 0: none)
     unsigned long long hostmark;
+    // merged-reduction CG (cgm_update_kernel): the step lengths ping-pong like r.r (iteration j reads alpha2[j & 1], written by
+    // the launch before, and writes alpha2[(j + 1) & 1]); vtau = the tau element of the vector the last sweep applied M to
+    // (stashed by the sweep: the update kernel overwrites that vector while other workgroups still need the element)
+    double alpha2[2];
+    double vtau[2];
+    int32_t dbg_delay;     // test hook (fos_debug_set): workgroups != 0 of cg_pupdate_kernel wait this many 100 MHz ticks at entry
+    int32_t pad_;
 };
+static_assert(offsetof(DevState, iter) % 8 == 0 && offsetof(DevState, done) == offsetof(DevState, iter) + 4, "iter/done are read as one 64-bit word");
 struct HostMark { uint32_t seq; int32_t iter; int32_t hit_max; int32_t batch; double rr; };   // seq = the solve's number, written last;
                                                                                             // batch: id of a batch of iterations that ended WITHOUT convergence
 
@@ -239,6 +249,12 @@ struct LaunchCtx {
     void* between_arg;
     double* pre = nullptr;           // 3 x 16 doubles + 16 flags: the producer workgroups' sums of the sweep records (cg_update_kernel)
     const int32_t* gate = nullptr;   // non-null: the relaxation / cone kernels run only if *gate != 0 (DevState.done: enqueued behind a CG batch)
+    // batched PSD projection: the handle's device and switches (read once at fos_create)
+    int32_t cus = 0;                 // compute units of the handle's device
+    int32_t psd_wave = -1;           // FOS_PSD_WAVE: -1 decide from the batch size, 0 / 1 force the workgroup / wavefront kernel at order 64
+    bool psd_narrow = false, psd_wide = false;
+    int32_t psd_wide_threads = 512;
+    bool* psd_attr_set = nullptr;    // the handle's "LDS opt-in done" flag
     int32_t count_repl;         // 1: this rank counts the replicated entries in scalar sums (always 1 when not row-sharded)
     int64_t n_repl;             // replicated leading entries of every vector (0 when not row-sharded)
 };
@@ -271,6 +287,32 @@ void launch_kkt2_cg(const LaunchCtx& c, const CgIter& it, double2* Ap);
 void launch_cg_stop_check(const LaunchCtx& c, const CgIter& it);      // closes iteration it.j - 1 when no sweep follows in this batch
 void launch_cg_update(const LaunchCtx& c, const CgIter& it, double2* x, double2* r, double2* Ap, int kkt_from_reduced);
 void launch_cg_pupdate(const LaunchCtx& c, const CgIter& it, double2* x, double2* p_next);   // !fuse_p: x += alpha p_j, closes iteration j, p_{j+1} = r + beta p_j
+
+// Merged-reduction CG (Chronopoulos & Gear 1989; SURVEY 7 "hard parts"): the same Krylov iterates as conjugategradients.jl:31-55
+// in exact arithmetic, rearranged so that ONE reduction point per iteration carries both inner products -- one exchange per
+// iteration when sharded, and two launches instead of three:
+//     w_0 = M r_0 ;  iteration j (i = j-1):   beta_i = g_i / g_{i-1} (0 for i = 0),  alpha_i = g_i / (d_i - beta_i g_i / alpha_{i-1})
+//     UPDATE  p = r + beta p ; s = w + beta s (= M p) ; x += alpha p ; r -= alpha s ; partial sums of g_{i+1} = r.r
+//     SWEEP   w = M r ; partial sums of d_{i+1} = w.r and of the tau row
+// with g = r.r, d = w.r.  The stop test of iteration j (norm(r) <= tol || j >= max_iters, conjugategradients.jl:42) needs g_j:
+//   close_in_update = false  the sweep behind the update adds the r.r records in its prologue and returns when CG has stopped
+//                            (single GPU: no sweep is wasted; costs every sweep workgroup a short prologue);
+//   close_in_update = true   the NEXT update adds them together with the sweep's sums -- one exchange of four doubles per iteration
+//                            (sharded handles); the sweep of the last iteration has then run for nothing, and a batch of
+//                            enqueued iterations ends with a one-workgroup launch of the update kernel that only closes.
+// p lives in PB[0], s in PB[1], w in AP.
+struct CgmIter {
+    int j;                     // iteration number, from 1
+    double2 *x, *r, *p, *s, *w;
+    bool close_in_update;
+    int from_reduced;          // the four sums were all-reduced into c.reduced (RCCL / host collective)
+    const PeerBox* fold;       // non-null: the exchange happens inside the update kernel (peer mailboxes)
+    uint32_t seq_base;
+    int32_t batch_mark = 0;    // != 0: the launch that ends the host's batch tells the host when CG goes on after it (HostMark.batch)
+};
+constexpr int CGM_RR_STRIDE = 1024;   // r.r records ping-pong: the update of iteration j writes [j & 1][...]
+void launch_cgm_sweep(const LaunchCtx& c, const CgmIter& it, int closes);        // w = M r (gated); closes > 0: first closes that iteration
+void launch_cgm_update(const LaunchCtx& c, const CgmIter& it, bool close_only);
 
 // single right-hand side Q apply on component `comp` of an interleaved vector
 //   Q_PLAIN : out_plain[i] = sign * (Q v)_i            (rows 0..n+m-1; tau row by q1_finalize)

@@ -692,6 +692,10 @@ struct KktArgs {
     PeerBox pb;                // FUSEP: nranks > 0 -> the r.r exchange happens here (peer mailboxes)
     uint32_t seq_base;
     int count_repl;            // FOLD: 0 = the slot-free part of the slot-spread rows is counted by another rank (row-sharded)
+    // merged-reduction CG (fos_internal.hpp, CgmIter): the sweep applies M to r
+    double* vt_out;            // non-null: workgroup 0 stashes the applied vector's tau element here (DevState.vtau)
+    int close_j;               // > 0: close iteration close_j first (r.r records of its update, stop test) and return when CG has stopped
+    int32_t batch_mark;
 };
 
 template <bool DEFER, bool FUSEP, bool FOLD>
@@ -709,10 +713,12 @@ __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBl
         gat.r = a.r; gat.pold = a.w; gat.beta = cl.beta;
     } else {
         gat.w = a.w;
+        if (a.close_j > 0 && cgm_close_in_sweep(a.st, a.rr_partials, a.rr_count, a.w, (int64_t)a.nm + 1, a.close_j, a.seq_base >> 11, a.batch_mark)) return;
     }
     EpiKkt<G, FOLD> epi;
     epi.gat = gat; epi.out = a.out; epi.pnew = a.pnew; epi.cb = a.cb; epi.n = a.n; epi.wt = gat.load_u(a.nm);
     epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
+    if (a.vt_out && blockIdx.x == 0 && threadIdx.x == 0) { a.vt_out[0] = epi.wt.x; a.vt_out[1] = epi.wt.y; }
     if constexpr (FUSEP) {
         if (blockIdx.x == 0 && threadIdx.x == 0) a.pnew[a.nm] = epi.wt;          // the tau element has no row in S
     }
@@ -733,9 +739,11 @@ __global__ __launch_bounds__(WIN_THREADS, 4) void kkt2_win_kernel(DevBlkCsr S, K
     extern __shared__ __attribute__((aligned(16))) double wlds[];
     GatherW gat;
     gat.w = a.w;
+    if (a.close_j > 0 && cgm_close_in_sweep(a.st, a.rr_partials, a.rr_count, a.w, (int64_t)a.nm + 1, a.close_j, a.seq_base >> 11, a.batch_mark)) return;
     EpiKkt<GatherW, false> epi;
     epi.gat = gat; epi.out = a.out; epi.pnew = nullptr; epi.cb = a.cb; epi.n = a.n; epi.wt = gat.load_u(a.nm);
     epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
+    if (a.vt_out && blockIdx.x == 0 && threadIdx.x == 0) { a.vt_out[0] = epi.wt.x; a.vt_out[1] = epi.wt.y; }
     win_walk(S, gat, epi, wlds);
     block_reduce_store<3, WIN_THREADS>(epi.acc, wlds + (size_t)(WIN_COLS + WIN_ROWS) * 2, a.partials + 3 * (int64_t)blockIdx.x);
 }
@@ -935,6 +943,21 @@ void launch_kkt2_cg(const LaunchCtx& c, const CgIter& it, double2* Ap) {
         if (fused) hipLaunchKernelGGL((kkt2_kernel<false, true, false>), grid, block, 0, c.stream, c.S, a);
         else hipLaunchKernelGGL((kkt2_kernel<false, false, false>), grid, block, 0, c.stream, c.S, a);
     }
+}
+// merged-reduction CG: w = M r with the sums of w.r and of the tau row (c.S.nwg records at record 0), gated on DevState.done.
+// closes > 0 (single GPU): the sweep first closes that iteration from the r.r records its update left (cgm_close_in_sweep).
+void launch_cgm_sweep(const LaunchCtx& c, const CgmIter& it, int closes) {
+    KktArgs a = plain_args(c, it.r, it.w, 1);
+    a.vt_out = c.st->vtau;
+    a.seq_base = it.seq_base;
+    if (closes > 0) {
+        a.close_j = closes; a.batch_mark = it.batch_mark;
+        a.rr_partials = c.partials + 3 * (size_t)PART_CAP + (size_t)(closes & 1) * CGM_RR_STRIDE; a.rr_count = c.cg_blocks;
+    }
+    if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
+    dim3 grid(c.S.nwg), block(SPMV_THREADS);
+    if (c.S.ndef > 0) hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
+    else hipLaunchKernelGGL((kkt2_kernel<false, false, false>), grid, block, 0, c.stream, c.S, a);
 }
 void launch_cg_stop_check(const LaunchCtx& c, const CgIter& it) {
     KktArgs a = plain_args(c, nullptr, nullptr, 1);

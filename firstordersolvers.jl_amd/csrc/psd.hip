@@ -807,19 +807,14 @@ size_t psd_basis_doubles(int kmax, int ncones) {       // one warm-start basis b
 int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones, int kmin, int kmax, double* gscratch,
                      const double* vin, double* vout, int have_prev, int* stats, int phase_limit) {
     if (ncones <= 0) return FOS_OK;
-    constexpr int MAXDEV = 64;
-    static int cus_of[MAXDEV] = {0};
-    static bool attr_set[MAXDEV] = {false};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) { set_error("hipGetDevice failed or device id >= %d", MAXDEV); return FOS_EHIP; }
-    if (!cus_of[dev]) { hipDeviceProp_t prop; cus_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
-    const int cus = cus_of[dev];
+    // per-handle configuration (fos_create reads the device's CU count and the FOS_PSD_* switches ONCE: two host threads driving
+    // handles on different devices share nothing here, and the kernel choice cannot change between a speculative enqueue and its re-run)
+    const int cus = c.cus > 0 ? c.cus : 256;
     // every cone of order 64: the sweeps run in registers, one WAVEFRONT per matrix when there are more than two matrices per CU
     // (every SIMD then has a wavefront of its own: 1024 matrices 195 us against 288), one WORKGROUP of four wavefronts per matrix
     // (psd_kernel<.., 256>, jacobi64_regs) below that (a shard of a multi-GPU run; 128 / 256 / 512 matrices: 118 / 127 / 179 us
     // against 173 / 182 / 190).  FOS_PSD_WAVE=0 / 1 forces the workgroup / the wavefront form.
-    const char* wave_str = getenv("FOS_PSD_WAVE");          // (read per call: the tests switch it)
-    const int wave_env = wave_str ? atoi(wave_str) : -1;
+    const int wave_env = c.psd_wave;
     if (kmin == 64 && kmax == 64 && wave_env != 0 && (wave_env == 1 || ncones > cus)) {
         const size_t wl = psd64w_lds_bytes();
         const size_t vs = (size_t)64 * 64;
@@ -836,18 +831,18 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     // projection; many matrices: 256 threads (4 per CU) maximise throughput.  Per DEVICE: a process may hold handles on several.
     // (order 64 everywhere: the 256-thread kernel keeps the column halves in registers and beats 512 threads on a small batch)
     const bool all64 = kmin == 64 && kmax == 64;
-    const bool wide = (warm && !all64 && (2 * ncones <= 2 * cus) && !getenv("FOS_PSD_NARROW")) || (warm && getenv("FOS_PSD_WIDE"));
-    if (use_lds && !attr_set[dev]) {          // hipFuncSetAttribute acts on the CURRENT device
+    const bool wide = (warm && !all64 && (2 * ncones <= 2 * cus) && !c.psd_narrow) || (warm && c.psd_wide);
+    if (use_lds && !*c.psd_attr_set) {        // hipFuncSetAttribute acts on the CURRENT device; once per handle
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, false, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(psd_kernel): %s", hipGetErrorString(e)); return FOS_EHIP; }
-        attr_set[dev] = true;
+        *c.psd_attr_set = true;
     }
     const size_t stride = (size_t)(kmax * psd_ld(kmax) + 2 * kmax + 16);
     const size_t vstride = (size_t)kmax * kmax;
-    static const int wide_threads = getenv("FOS_PSD_THREADS") ? atoi(getenv("FOS_PSD_THREADS")) : 512;
+    const int wide_threads = c.psd_wide_threads;
     if (warm && wide && wide_threads == 512)
         hipLaunchKernelGGL((psd_kernel<true, true, 512>), dim3(2 * ncones), dim3(512), lds, c.stream, out, in, cones, gscratch, stride, vin, vout, vstride, have_prev, stats, phase_limit, c.gate);
     else if (warm && wide && wide_threads == 1024)

@@ -7,6 +7,7 @@
 #include <functional>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <memory>
 
@@ -138,6 +139,9 @@ struct fos_solver {
     int psd_cur = 0, psd_have_prev = 0;
     int* psd_stats = nullptr;                  // Jacobi sweeps of the last projection, per (cone, copy)  (fos_psd_debug)
     int psd_phase_limit = 0;                   // diagnostic: stop the PSD kernel after a phase (wrong results!)
+    int cus = 256;                             // compute units of `device`
+    int psd_wave = -1; bool psd_narrow = false, psd_wide = false; int psd_wide_threads = 512;      // FOS_PSD_* (read at fos_create)
+    mutable bool psd_attr_set = false;
 
     // scalars
     DevState* st = nullptr;
@@ -154,6 +158,7 @@ struct fos_solver {
     int cg_blocks = 0;
     uint32_t* def_mask = nullptr;              // bit i: row i of S is finished from partial slots (dual tiles)
     bool fuse_p = false;                       // the p update of CG rides on the next sweep (2 launches per iteration)
+    int cg_variant = -1;                       // FOS_CG_*: -1 = the handle's default (sharded: merged reduction, closing in the update)
 
     // algorithm (gap.jl:6-21, gapa.jl:9-25, fista.jl:6-18, dykstra.jl:5-17)
     int alg = FOS_ALG_GAP;
@@ -221,6 +226,8 @@ struct fos_solver {
         c.def_mask = def_mask;
         c.pre = pre_on ? pre_sums : nullptr;
         c.between = nullptr; c.between_arg = nullptr;
+        c.cus = cus; c.psd_wave = psd_wave; c.psd_narrow = psd_narrow; c.psd_wide = psd_wide; c.psd_wide_threads = psd_wide_threads;
+        c.psd_attr_set = &psd_attr_set;
         c.count_repl = (!row_sharded || rank == 0) ? 1 : 0;
         c.n_repl = row_sharded ? n : 0;
         if (row_sharded) { c.between = &fos_solver::sum_slots_over_ranks; c.between_arg = const_cast<fos_solver*>(this); }
@@ -338,6 +345,9 @@ int poll_state(fos_solver* h) {
 int wait_cg_mark(fos_solver* h, uint32_t epoch, int32_t batch_id, bool* ended) {
     FOS_TRY(check_launch("poll"));
     volatile HostMark* m = h->mark;
+    // a wall-clock bound (FOS_CG_WAIT_S, default 120 s): a kernel of the solve that never ends must not hang the host either
+    static const double wait_s = getenv("FOS_CG_WAIT_S") ? atof(getenv("FOS_CG_WAIT_S")) : 120.0;
+    const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spin = 1;; ++spin) {
         if (__atomic_load_n(&m->seq, __ATOMIC_ACQUIRE) == epoch) { *ended = true; break; }
         if (__atomic_load_n(&m->batch, __ATOMIC_ACQUIRE) == batch_id) { *ended = false; break; }
@@ -349,6 +359,10 @@ int wait_cg_mark(fos_solver* h, uint32_t epoch, int32_t batch_id, bool* ended) {
             FOS_TRY(poll_state(h));
             *ended = h->st_host->done != 0;
             return FOS_OK;
+        }
+        if ((spin & 0xFFFFFu) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_s) {
+            set_error("CG solve %u: neither its end mark nor its batch mark arrived within %.0f s (a kernel of the solve does not finish)", epoch, wait_s);
+            return FOS_EHIP;
         }
     }
     if (*ended) { h->st_host->done = 1; h->st_host->iter = m->iter; h->st_host->hit_max = m->hit_max; h->st_host->rr = m->rr; }
@@ -403,23 +417,81 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     static const bool fold_env = !(getenv("FOS_PEER_FOLD") && atoi(getenv("FOS_PEER_FOLD")) == 0);
     const bool fold = h->peer_on && fold_env;
     const bool rccl = h->sharded() && !fold;  // sums cross the ranks between the kernels (reduce kernel + all-reduce, or unfolded mailboxes)
+    // which recurrence: the reference's (three launches, two reduction points per iteration) or the merged-reduction form (two
+    // launches, one reduction point); sharded handles take the latter by default and always close in the update kernel
+    int32_t variant = FOS_CG_REFERENCE;
+    FOS_TRY(fos_get_cg_variant(h, &variant));
+    const bool merged = variant == FOS_CG_MERGED_SWEEP || variant == FOS_CG_MERGED_UPDATE;
+    const bool close_in_update = variant == FOS_CG_MERGED_UPDATE;
+    const bool fuse_p = variant == FOS_CG_FUSED_P;
     h->cg_epoch += 1;                        // the same on every rank: all ranks make the same calls
     const uint32_t seq_base = (uint32_t)(h->cg_epoch * 2048u);          // + 2 j + phase  (j <= 1000)
     auto iter_desc = [&](int j) {
         CgIter it;
         it.j = j; it.r = h->R; it.p_prev = h->PB[(j - 1) & 1]; it.p_cur = h->PB[j & 1];
-        it.fuse_p = h->fuse_p; it.rr_from_reduced = rccl ? 1 : 0; it.fold = fold ? &h->peer : nullptr; it.seq_base = seq_base;
+        it.fuse_p = fuse_p; it.rr_from_reduced = rccl ? 1 : 0; it.fold = fold ? &h->peer : nullptr; it.seq_base = seq_base;
+        return it;
+    };
+    auto merged_desc = [&](int j) {
+        CgmIter it;
+        it.j = j; it.x = x; it.r = h->R; it.p = h->PB[0]; it.s = h->PB[1]; it.w = h->AP;
+        it.close_in_update = close_in_update; it.from_reduced = rccl ? 1 : 0; it.fold = fold ? &h->peer : nullptr; it.seq_base = seq_base;
         return it;
     };
     const size_t prof_start = h->prof_used;
     // (sharded: only with the exchanges folded into the CG kernels -- no collective call sits in the stream -- and only for GAP,
     //  whose post-solve kernels contain no reduction; every rank takes the same decisions, so all mispredict together.
     //  Solve number 0 mod 2^21 is the mark's initial value.)
-    const bool spec = post && h->speculate && !c.between && !h->fuse_p && (seq_base >> 11) != 0u &&
+    const bool spec = post && h->speculate && !c.between && !fuse_p && (seq_base >> 11) != 0u &&
                       (!h->sharded() || (fold && h->alg == FOS_ALG_GAP));
     const int32_t batch_id = (int32_t)(((seq_base >> 11) & 0x7FFFFFu) << 8 | 1u);
-    bool mark_last = spec;                   // the first batch ends with a marked p update
+    bool mark_last = spec;                   // the first batch ends with a marked launch
+    // merged reduction, sharded without folded mailboxes: the sweep's three sums and the update's r.r cross the ranks together,
+    // between the sweep of iteration j-1 and the update of iteration j -- ONE all-reduce of four doubles per iteration
+    auto merged_reduce = [&](int j) -> int {
+        if (c.between) FOS_TRY(c.between(c.between_arg));         // row-sharded: A'y partial sums over the ranks (n-vector)
+        if (!rccl) return FOS_OK;
+        launch_reduce1(c, c.S.nwg, 3, 1, 0);
+        if (j >= 2) {
+            LaunchCtx c2 = c;
+            c2.partials = c.partials + 3 * (size_t)PART_CAP + (size_t)((j - 1) & 1) * CGM_RR_STRIDE;
+            c2.reduced = c.reduced + 3;
+            launch_reduce1(c2, c.cg_blocks, 1, 1);
+        }
+        return allreduce(h, 4);
+    };
+    if (merged) {                            // w_0 = M r_0 (+ its sums): the sweep every iteration's update starts from
+        CgmIter it0 = merged_desc(0);
+        const int pe = prof_begin(h, FOS_PROF_KKT, 0, h->cg_total);
+        launch_cgm_sweep(c, it0, 0);
+        prof_end(h, pe);
+    }
     auto enqueue = [&](int count) -> int {
+        if (merged) {
+            for (int q = 0; q < count && next_j <= maxit; ++q, ++next_j) {
+                CgmIter it = merged_desc(next_j);
+                const bool last = q == count - 1 || next_j == maxit;
+                if (mark_last && last) it.batch_mark = batch_id;
+                FOS_TRY(merged_reduce(next_j));
+                // launch 1: scalars, p = r + beta p, s = w + beta s, x += alpha p, r -= alpha s, r.r partials             :39-41,:46-50
+                int pe = prof_begin(h, FOS_PROF_CGVEC, next_j, (h->cg_total + next_j - 1) % 4 == 1 ? (h->cg_total + next_j - 1) / 4 : 1);
+                launch_cgm_update(c, it, false);
+                prof_end(h, pe);
+                // launch 2: [close iteration j: r.r, stop test] sweep w = M r + partial sums                               :38,:42
+                // (closing in the sweep: the sweep behind the LAST update returns in its prologue -- recorded as iteration j+1, which
+                //  the profile drops)
+                pe = prof_begin(h, FOS_PROF_KKT, next_j + (close_in_update ? 0 : 1), h->cg_total + next_j);
+                launch_cgm_sweep(c, it, close_in_update ? 0 : next_j);
+                prof_end(h, pe);
+            }
+            if (close_in_update) {           // the last enqueued iteration is closed by a one-workgroup launch of the update kernel
+                CgmIter it = merged_desc(next_j);
+                if (mark_last) it.batch_mark = batch_id;
+                FOS_TRY(merged_reduce(next_j));
+                launch_cgm_update(c, it, true);
+            }
+            return FOS_OK;
+        }
         for (int q = 0; q < count && next_j <= maxit; ++q, ++next_j) {
             CgIter it = iter_desc(next_j);
             if (mark_last && (q == count - 1 || next_j == maxit)) it.batch_mark = batch_id;
@@ -440,11 +512,11 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
                 FOS_TRY(allreduce(h, 1));
             }
             // gather-bound operators: closing the iteration and p_{j+1} = r + beta p_j stay a launch of their own           :42-51
-            if (!h->fuse_p) launch_cg_pupdate(c, it, x, h->PB[(next_j + 1) & 1]);
+            if (!fuse_p) launch_cg_pupdate(c, it, x, h->PB[(next_j + 1) & 1]);
             prof_end(h, pe);
         }
         // the last update of the batch is closed by a one-workgroup launch (a following batch's sweep repeats it, same result)
-        if (h->fuse_p) launch_cg_stop_check(c, iter_desc(next_j));
+        if (fuse_p) launch_cg_stop_check(c, iter_desc(next_j));
         return FOS_OK;
     };
     static const int pred_slack = getenv("FOS_CG_SLACK") ? atoi(getenv("FOS_CG_SLACK")) : 1;   // iterations enqueued beyond the last solve's count (each costs a few gated no-op launches when not needed; too few costs a poll)
@@ -868,6 +940,11 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     hipDeviceProp_t prop;
     FOS_HIP(hipGetDeviceProperties(&prop, device));
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->cus = cus;
+    if (const char* e = getenv("FOS_PSD_WAVE")) h->psd_wave = atoi(e);
+    h->psd_narrow = getenv("FOS_PSD_NARROW") != nullptr;
+    h->psd_wide = getenv("FOS_PSD_WIDE") != nullptr;
+    if (const char* e = getenv("FOS_PSD_THREADS")) h->psd_wide_threads = atoi(e);
     if (const char* e = getenv("FOS_SPMV_WG")) h->nwg_target = std::max(1, std::min(16384, atoi(e)));
     else h->nwg_target = cus * 12;      // ~1.7x the resident workgroups (7/CU): measured best for the KKT sweep (dynamic balance)
 
@@ -969,6 +1046,7 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     // 64-block shard: 13 -> 20 us against 5 us), so it stays an option (fos_set_tuning / FOS_CG_FUSE_P)
     h->fuse_p = false;
     if (const char* e = getenv("FOS_CG_FUSE_P")) h->fuse_p = atoi(e) != 0;
+    if (const char* e = getenv("FOS_CG_VARIANT")) h->cg_variant = std::max(-1, std::min((int)FOS_CG_MERGED_UPDATE, atoi(e)));
     h->S.npart = h->S.nwg_def > 0 ? h->S.nwg_def : h->S.nwg;
     h->S.part_off = h->S.nwg_def > 0 ? h->S.nwg : 0;
     // free the big host arrays (keep block table for re-partitioning)
@@ -1090,6 +1168,7 @@ int fos_comm_get_unique_id(void* id128) {
 
 int fos_comm_init(fos_handle h, int nranks, int rank, const void* id128) {
     if (!h || nranks < 1 || rank < 0 || rank >= nranks) { set_error("bad comm arguments"); return FOS_EINVAL; }
+    if (h->ls_interval > 0) { set_error("switch the LineSearchWrapper off before sharding the handle (fos_set_linesearch(h, 0))"); return FOS_EUNSUPPORTED; }
     FOS_TRY(rccl_load());
     FOS_HIP(hipSetDevice(h->device));
     ncclUniqueId id;
@@ -1105,6 +1184,7 @@ int fos_comm_init(fos_handle h, int nranks, int rank, const void* id128) {
 // processes (tests/test_gpu_peer_mailbox.py::test_row_sharded_two_processes_host_exchange).
 int fos_comm_init_host(fos_handle h, int nranks, int rank, fos_allreduce_fn fn, void* user) {
     if (!h || !fn || nranks < 1 || rank < 0 || rank >= nranks) { set_error("bad comm arguments"); return FOS_EINVAL; }
+    if (h->ls_interval > 0) { set_error("switch the LineSearchWrapper off before sharding the handle (fos_set_linesearch(h, 0))"); return FOS_EUNSUPPORTED; }
     if (h->comm || h->peer_on) { set_error("this handle already has a communicator"); return FOS_EINVAL; }
     FOS_HIP(hipSetDevice(h->device));
     if (!h->host_buf) {
@@ -1217,6 +1297,7 @@ int fos_peer_selftest(fos_handle h, int rounds, int32_t* ok) {
 int fos_peer_enable(fos_handle h, int32_t on) {
     if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
     if (on && !h->peer.box) { set_error("fos_peer_enable before fos_peer_open"); return FOS_EINVAL; }
+    if (on && h->ls_interval > 0) { set_error("switch the LineSearchWrapper off before sharding the handle (fos_set_linesearch(h, 0))"); return FOS_EUNSUPPORTED; }
     FOS_HIP(hipSetDevice(h->device));
     FOS_HIP(hipStreamSynchronize(h->stream));
     h->peer_on = on != 0;
@@ -1413,6 +1494,11 @@ int fos_set_linesearch(fos_handle h, int64_t lsinterval) {
     if (!h || lsinterval < 0) { set_error("bad argument"); return FOS_EINVAL; }
     if (lsinterval > 0 && h->alg != FOS_ALG_GAP && h->alg != FOS_ALG_GAPA) {
         set_error("this algorithm does not support line search (support_linesearch: GAP and GAPA only, solvers/defaults.jl:22)");
+        return FOS_EUNSUPPORTED;
+    }
+    if (lsinterval > 0 && (h->sharded() || h->row_sharded)) {
+        // normres / normdiff (linesearch.jl:50,62) are GLOBAL norms; the search below adds this rank's partial sums only
+        set_error("LineSearchWrapper is built for single-GPU handles only (its step-length scores are global norms)");
         return FOS_EUNSUPPORTED;
     }
     h->ls_interval = lsinterval;
@@ -1692,14 +1778,34 @@ int fos_bench_cg_chain(fos_handle h, int32_t iters, int32_t reps, int32_t use_gr
     FOS_TRY(kkt_apply_full(h, c, h->W, h->AP));
     launch_cg_init(c, h->RHS, h->AP, h->R, h->PB[1]);
     launch_cg_init_finalize(c, h->R, -1.0, INT32_MAX, 0);
+    const int variant = h->cg_variant >= 0 ? h->cg_variant : (h->fuse_p ? FOS_CG_FUSED_P : FOS_CG_REFERENCE);
+    const bool merged = variant == FOS_CG_MERGED_SWEEP || variant == FOS_CG_MERGED_UPDATE;
+    // (the producer flags of the update kernels carry the launch's sequence number: a replayed graph would present the SAME
+    //  numbers again and the consumers would not wait -- the graph runs without the producers)
+    if (use_graph) c.pre = nullptr;
+    uint32_t chain_no = 0;
     auto chain = [&]() {
+        const uint32_t seq_base = (++chain_no) * 2048u;
+        if (merged) {
+            CgmIter it;
+            it.x = h->W; it.r = h->R; it.p = h->PB[0]; it.s = h->PB[1]; it.w = h->AP;
+            it.close_in_update = variant == FOS_CG_MERGED_UPDATE; it.from_reduced = 0; it.fold = nullptr; it.seq_base = seq_base;
+            it.j = 0;
+            launch_cgm_sweep(c, it, 0);
+            for (int j = 1; j <= iters; ++j) {
+                it.j = j;
+                launch_cgm_update(c, it, false);
+                launch_cgm_sweep(c, it, it.close_in_update ? 0 : j);
+            }
+            return;
+        }
         for (int j = 1; j <= iters; ++j) {
             CgIter it;
             it.j = j; it.r = h->R; it.p_prev = h->PB[(j - 1) & 1]; it.p_cur = h->PB[j & 1];
-            it.fuse_p = h->fuse_p; it.rr_from_reduced = 0; it.fold = nullptr; it.seq_base = 0;
+            it.fuse_p = variant == FOS_CG_FUSED_P; it.rr_from_reduced = 0; it.fold = nullptr; it.seq_base = seq_base;
             launch_kkt2_cg(c, it, h->AP);
             launch_cg_update(c, it, h->W, h->R, h->AP, 0);
-            if (!h->fuse_p) launch_cg_pupdate(c, it, h->W, h->PB[(j + 1) & 1]);
+            if (!it.fuse_p) launch_cg_pupdate(c, it, h->W, h->PB[(j + 1) & 1]);
         }
     };
     hipEvent_t e0, e1;
@@ -1784,7 +1890,7 @@ int fos_sync(fos_handle h) {
 int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int32_t fuse_p) {
     if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
     FOS_HIP(hipSetDevice(h->device));
-    if (fuse_p >= 0) h->fuse_p = fuse_p != 0;
+    if (fuse_p >= 0) { h->fuse_p = fuse_p != 0; h->cg_variant = -1; }
     if (cg_chunk > 0) h->cg_chunk = cg_chunk;
     if (spmv_workgroups > 0 && h->S.npanel > 0) {
         // window panels: the grid is a number of persistent workgroups walking the panels
@@ -1803,6 +1909,40 @@ int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int3
         h->nwg_target = spmv_workgroups;
     }
     return FOS_OK;
+}
+
+// which CG recurrence the affine projection runs (FOS_CG_*; -1: the handle's default)
+int fos_set_cg_variant(fos_handle h, int32_t variant) {
+    if (!h || variant < -1 || variant > FOS_CG_MERGED_UPDATE) { set_error("unknown CG variant %d", (int)variant); return FOS_EINVAL; }
+    h->cg_variant = variant;
+    if (variant >= 0) h->fuse_p = variant == FOS_CG_FUSED_P;
+    h->last_cg_pred = 0; h->cg_same_run = 0;
+    return FOS_OK;
+}
+
+// the variant the next affine projection will run (the default resolved: sharded handles take the merged recurrence)
+int fos_get_cg_variant(fos_handle h, int32_t* variant) {
+    if (!h || !variant) { set_error("NULL argument"); return FOS_EINVAL; }
+    static const bool fold_env = !(getenv("FOS_PEER_FOLD") && atoi(getenv("FOS_PEER_FOLD")) == 0);
+    int v = h->cg_variant >= 0 ? h->cg_variant : (h->fuse_p ? FOS_CG_FUSED_P : (h->sharded() ? FOS_CG_MERGED_UPDATE : FOS_CG_REFERENCE));
+    if (v == FOS_CG_MERGED_SWEEP && h->sharded()) v = FOS_CG_MERGED_UPDATE;
+    if (v == FOS_CG_MERGED_UPDATE && h->peer_on && !fold_env) v = FOS_CG_REFERENCE;
+    *variant = v;
+    return FOS_OK;
+}
+
+// test hooks
+int fos_debug_set(fos_handle h, int32_t what, int64_t value) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    if (what == FOS_DEBUG_PUPDATE_DELAY) {
+        const int32_t v = (int32_t)std::max<int64_t>(0, std::min<int64_t>(value, 100000000));     // <= 1 s
+        FOS_HIP(hipStreamSynchronize(h->stream));
+        FOS_HIP(hipMemcpy(&h->st->dbg_delay, &v, sizeof(v), hipMemcpyHostToDevice));
+        return FOS_OK;
+    }
+    set_error("unknown debug switch %d", (int)what);
+    return FOS_EINVAL;
 }
 
 }  // extern "C"

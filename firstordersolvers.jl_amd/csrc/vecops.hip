@@ -65,6 +65,45 @@ __global__ __launch_bounds__(FIN_THREADS) void cg_init_finalize_kernel(const dou
     }
 }
 
+// The sweep's three sums (Ap.p without the tau rows, [c;b].p1, [c;b].p2) -> sums[0..2] (shared), the same bits in every workgroup.
+__device__ __forceinline__ void sweep_sums3(double* sums, const double* __restrict__ kkt_partials, int nkkt, const double* __restrict__ reduced,
+                                            int from_reduced, double* __restrict__ pre, uint32_t pre_seq, DevState* st) {
+    if (from_reduced) { if (threadIdx.x < 3) sums[threadIdx.x] = reduced[threadIdx.x]; __syncthreads(); }
+    else if (pre != nullptr) {
+        // Thousands of sweep records (C4: 4 224): every workgroup adding them all again cost ~6 us of this kernel.  Instead the
+        // first PRE_NPROD workgroups -- always dispatched first, so a waiting workgroup can never keep them from running --
+        // add a slice each, publish the three sums (written through to memory) and raise a flag carrying this launch's
+        // number; everybody waits for the flags (cache-bypassing loads: no atomics, nothing serialises) and adds the
+        // PRE_NPROD partial results in order.  Fixed order, same bits in every workgroup.
+        uint32_t* flags = reinterpret_cast<uint32_t*>(pre + 3 * PRE_NPROD);
+        if (blockIdx.x < PRE_NPROD) {
+            const int per = (nkkt + PRE_NPROD - 1) / PRE_NPROD;
+            const int lo = min((int)blockIdx.x * per, nkkt), cnt = min(per, nkkt - lo);
+            reduce_partials<3>(kkt_partials + 3 * (size_t)lo, cnt, sums);
+            if (threadIdx.x < 3) st_coh(pre + 3 * blockIdx.x + threadIdx.x, sums[threadIdx.x]);
+            __builtin_amdgcn_s_waitcnt(0);                       // the three write-through stores have been acknowledged by memory ...
+            __syncthreads();                                     // ... before thread 0 raises the flag (an agent-scope release would
+                                                                 // write back the whole L2: 20-70 us, DESIGN.md "measured dead ends")
+            if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, pre_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (threadIdx.x < PRE_NPROD) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pre_seq) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 500000000LL) { st->bar_failed = 1; st->done = 1; break; }      // 5 s of the 100 MHz clock: give up, flag the state
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            double sum = 0.0;
+            for (int b = 0; b < PRE_NPROD; ++b) sum += ld_coh(pre + 3 * b + threadIdx.x);
+            sums[threadIdx.x] = sum;
+        }
+        __syncthreads();
+    }
+    else reduce_partials<3>(kkt_partials, nkkt, sums);
+}
+
 // Second launch of a CG iteration.  EVERY workgroup reduces the sweep's 3 x nkkt partial sums in the same fixed order, finishes
 // the tau rows of Ap = M p and alpha = rn / (Ap.p) itself (so no workgroup waits for another), then updates its slice:
 // x += alpha p ; r -= alpha Ap ; partial r.r.  Workgroup 0 stores Ap[tau], pAp and alpha.     conjugategradients.jl:39-41,46
@@ -92,38 +131,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
     if (st->done) return;
     if (FOLD && st->xchg_failed) return;
     __shared__ double sums[3];
-    if (from_reduced) { if (threadIdx.x < 3) sums[threadIdx.x] = reduced[threadIdx.x]; __syncthreads(); }
-    else if (pre != nullptr) {
-        // Thousands of sweep records (C4: 4 224): every workgroup adding them all again cost ~6 us of this kernel.  Instead the
-        // first PRE_NPROD workgroups -- always dispatched first, so a waiting workgroup can never keep them from running --
-        // add a slice each, publish the three sums (written through to memory) and raise a flag carrying this launch's
-        // number; everybody waits for the flags (cache-bypassing loads: no atomics, nothing serialises) and adds the
-        // PRE_NPROD partial results in order.  Fixed order, same bits in every workgroup.
-        uint32_t* flags = reinterpret_cast<uint32_t*>(pre + 3 * PRE_NPROD);
-        if (blockIdx.x < PRE_NPROD) {
-            const int per = (nkkt + PRE_NPROD - 1) / PRE_NPROD;
-            const int lo = min((int)blockIdx.x * per, nkkt), cnt = min(per, nkkt - lo);
-            reduce_partials<3>(kkt_partials + 3 * (size_t)lo, cnt, sums);
-            if (threadIdx.x < 3) st_coh(pre + 3 * blockIdx.x + threadIdx.x, sums[threadIdx.x]);
-            __syncthreads();                                     // (the three stores have been acknowledged)
-            if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, pre_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (threadIdx.x < PRE_NPROD) {
-            const long long t0 = wall_clock64();
-            while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pre_seq) {
-                __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > 500000000LL) { st->bar_failed = 1; st->done = 1; break; }      // 5 s of the 100 MHz clock: give up, flag the state
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 3) {
-            double sum = 0.0;
-            for (int b = 0; b < PRE_NPROD; ++b) sum += ld_coh(pre + 3 * b + threadIdx.x);
-            sums[threadIdx.x] = sum;
-        }
-        __syncthreads();
-    }
-    else reduce_partials<3>(kkt_partials, nkkt, sums);
+    sweep_sums3(sums, kkt_partials, nkkt, reduced, from_reduced, pre, pre_seq, st);
     if constexpr (FOLD) {
         if (!peer_fold_sum<3>(pb, seq_base + 2u * (uint32_t)j, sums, st)) return;
     }
@@ -217,8 +225,7 @@ void launch_cg_update(const LaunchCtx& c, const CgIter& it, double2* x, double2*
 }
 
 // Third launch of a CG iteration when the p update is NOT fused into the next sweep: closes iteration j (every workgroup,
-// same order: cg_close_iteration) and forms p_{j+1} = beta p_j + r.  A workgroup that starts after workgroup 0 has set `done`
-// simply exits: p is not needed once CG has stopped.                       conjugategradients.jl:42-51
+// same order: cg_close_iteration) and forms p_{j+1} = beta p_j + r.                   conjugategradients.jl:42-51
 // It also carries x += alpha p_j (conjugategradients.jl:40) of the iteration it closes -- p_j is read here anyway -- and does so
 // whether or not CG stops at this iteration (alpha = DevState.alpha, stored by the update kernel before this launch).
 __global__ __launch_bounds__(VEC_THREADS) void cg_pupdate_kernel(int64_t l, d2* __restrict__ pnext, const d2* __restrict__ pcur,
@@ -230,7 +237,18 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_pupdate_kernel(int64_t l, d2* 
     const int64_t i0 = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x;
     d2 p0 = make_double2(0.0, 0.0), r0 = p0, x0 = p0;
     if (i0 < l) { p0 = pcur[i0]; r0 = r[i0]; x0 = x[i0]; }     // requested before the scalar prologue (latency)
-    if (st->done) return;
+    if (st->dbg_delay > 0 && blockIdx.x != 0) {                // test hook: let workgroup 0 finish first (tests/test_gpu_parity.py)
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < st->dbg_delay) __builtin_amdgcn_s_sleep(8);
+    }
+    // The entry gate must not be the live `done` alone: workgroup 0 of THIS launch sets it (cg_close_iteration) when CG stops at
+    // iteration j, and a workgroup that starts after that store would skip the x update of iteration j.  A stop recorded by an
+    // earlier launch has iter < j; one recorded by this launch has iter == j (stored before `done`, one 8-byte word with it, so
+    // a single load sees a consistent pair) -- then this workgroup goes on, takes the same stop decision and applies x += alpha p.
+    {
+        const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&st->iter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(w >> 32) != 0u && (int32_t)(uint32_t)w != j) return;
+    }
     if (pb.nranks > 0 && st->xchg_failed) return;
     const double alpha = st->alpha;
     const CgClose cl = cg_close_iteration(st, partials, count, reduced, from_reduced, r, l, j, pb, seq_base);
@@ -260,6 +278,176 @@ void launch_cg_pupdate(const LaunchCtx& c, const CgIter& it, double2* x, double2
     hipLaunchKernelGGL(cg_pupdate_kernel, dim3(c.cg_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p_next, (const d2*)it.p_cur, x, it.r, c.st,
                        c.partials + 3 * (size_t)PART_CAP, c.cg_blocks, c.reduced, it.rr_from_reduced, it.j,
                        it.fold ? *it.fold : PeerBox{}, it.seq_base, it.batch_mark);
+}
+
+// ------------------------------------------------------------------------------------------------ merged-reduction CG
+// The update launch of iteration j (i = j-1) of the merged-reduction recurrence (fos_internal.hpp, CgmIter).  EVERY workgroup
+// forms the scalars itself from the same records in the same order:
+//   the sweep's three sums (w.r without the tau row, [c;b].r1, [c;b].r2)  -> the tau row of w = M r_i and d_i = w.r ;
+//   g_i = r_i.r_i : DevState.rn2[i & 1] (stored by the launch that closed iteration i), or -- CLOSE: this kernel closes
+//   iteration i itself -- the r.r records of the previous update (+ the stop test of conjugategradients.jl:42: all return);
+//   beta_i = g_i / g_{i-1},  alpha_i = g_i / (d_i - beta_i g_i / alpha_{i-1})   (i = 0: beta = 0, alpha = g_0 / d_0);
+// then its slice:  p = p beta + r ; s = s beta + w ; x += alpha p ; r -= alpha s ; partial r.r  (= conjugategradients.jl:39-41,49-50
+// with Ap replaced by the recurrence s = M p).  Sharded with peer mailboxes (FOLD): the four local sums cross the ranks in ONE
+// exchange here.  DEF: rows of w the sweep left spread over dual-tile slots are finished here, as in cg_update_kernel.
+// close_only: a one-workgroup launch at the end of a batch of enqueued iterations -- the scalar part alone.
+struct CgmArgs {
+    int64_t l;
+    d2 *x, *r, *p, *s;
+    const d2* w;
+    DevState* st;
+    const double* kkt_partials; int nkkt;
+    const double* rr_in; int nrr;          // the r.r records of the update of iteration i
+    double* rr_out;                        // ... of this one
+    const double* reduced; int from_reduced;
+    int j;
+    int close_here, close_only;
+    const double* cb; int n;
+    const uint32_t* def_mask;
+    PeerBox pb; uint32_t seq_base; int count_repl;
+    double* pre; uint32_t pre_seq;
+    int32_t batch_mark;
+};
+template <bool DEF, bool FOLD>
+__global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevBlkCsr S) {
+    const int64_t l = a.l;
+    const int64_t stride = (int64_t)gridDim.x * VEC_THREADS;
+    const int64_t i0 = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x;
+    const int i = a.j - 1;
+    const bool first = i == 0;
+    DevState* st = a.st;
+    bool have0 = i0 < l && !a.close_only;
+    if constexpr (DEF) { if (have0 && ((a.def_mask[i0 >> 5] >> (i0 & 31)) & 1u)) have0 = false; }
+    d2 w0 = make_double2(0.0, 0.0), r0 = w0, x0 = w0, p0 = w0, s0 = w0;
+    if (have0) { w0 = a.w[i0]; r0 = a.r[i0]; x0 = a.x[i0]; if (!first) { p0 = a.p[i0]; s0 = a.s[i0]; } }      // requested before the scalar prologue
+    if (st->done) return;
+    if (FOLD && st->xchg_failed) return;
+    __shared__ double sums[4];
+    sweep_sums3(sums, a.kkt_partials, a.nkkt, a.reduced, a.from_reduced, a.pre, a.pre_seq, st);
+    const bool closing = a.close_here && !first;
+    if (closing || FOLD) {
+        const double rs = (a.from_reduced || !closing) ? (closing ? a.reduced[3] : 0.0) : wave_sum_records(a.rr_in, a.nrr);
+        if (threadIdx.x == 0) sums[3] = rs;
+        __syncthreads();
+    }
+    if constexpr (FOLD) {
+        if (!peer_fold_sum<4>(a.pb, a.seq_base + (uint32_t)a.j, sums, st)) return;
+    }
+    const double vtx = st->vtau[0], vty = st->vtau[1];           // tau element of r_i (stashed by the sweep that applied M to it)
+    const double S1 = sums[0], T1 = sums[1], T2 = sums[2];
+    const double gam = closing ? sums[3] + (vtx * vtx + vty * vty) : st->rn2[i & 1];
+    const bool w0blk = blockIdx.x == 0 && threadIdx.x == 0;
+    if (closing) {
+        const int maxit = st->maxit;
+        if (sqrt(gam) <= st->tol || i >= maxit) {                  // conjugategradients.jl:42 for iteration i
+            if (w0blk) { st->rr = gam; cg_signal_stop(st, i, maxit, gam, a.seq_base >> 11); }
+            return;
+        }
+    }
+    const double wt1 = vtx + T2;             // r1_tau - (Q r2)_tau ,  (Q v)_tau = -[c;b].v        HSDEAffine.jl:57
+    const double wt2 = -T1 - vty;            // (Q r1)_tau - r2_tau
+    const double delta = S1 + (wt1 * vtx + wt2 * vty);
+    double beta = 0.0, alpha;
+    if (first) alpha = gam / delta;
+    else {
+        const double gprev = st->rn2[(i - 1) & 1], aprev = st->alpha2[(i - 1) & 1];
+        beta = gam / gprev;
+        alpha = gam / (delta - beta * gam / aprev);
+    }
+    if (w0blk) {
+        if (closing) st->rn2[i & 1] = gam;
+        st->alpha2[i & 1] = alpha;
+        st->alpha = alpha; st->beta = beta; st->pAp = gam / alpha; st->rr = gam;
+        st->iter = a.j;
+        if (a.close_only && a.batch_mark != 0 && st->hostmark)      // the host's batch is used up, CG is not done
+            __hip_atomic_store(&reinterpret_cast<HostMark*>(st->hostmark)->batch, a.batch_mark, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (a.close_only) return;
+    double acc[1] = {0.0};
+    // one element: (w, r, p, s, x) -> (p, s, x, r); returns r.r of the element
+    auto upd = [&](int64_t idx, d2 wi, d2 ri, d2 pi, d2 si, d2 xi) -> double {
+        if (first) { pi = ri; si = wi; }
+        else {
+            pi.x = pi.x * beta + ri.x; pi.y = pi.y * beta + ri.y;          // p .*= beta ; p .+= r      :49-50
+            si.x = si.x * beta + wi.x; si.y = si.y * beta + wi.y;          // s = M p by the same recurrence
+        }
+        xi.x += alpha * pi.x; xi.y += alpha * pi.y;                        // :40
+        ri.x -= alpha * si.x; ri.y -= alpha * si.y;                        // :41
+        a.p[idx] = pi; a.s[idx] = si; a.x[idx] = xi; a.r[idx] = ri;
+        return ri.x * ri.x + ri.y * ri.y;
+    };
+    if constexpr (DEF) {
+        const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots_rd);
+        const int lpr = S.def_lpr, sh = 31 - __clz(lpr);
+        const int rows_per_pass = (gridDim.x * VEC_THREADS) >> sh;
+        const int lig = threadIdx.x & (lpr - 1);
+        const int npass = (S.ndef + rows_per_pass - 1) / rows_per_pass;       // uniform trip count: the DPP sums need full waves
+        int q = (blockIdx.x * VEC_THREADS + threadIdx.x) >> sh;
+        for (int pass = 0; pass < npass; ++pass, q += rows_per_pass) {
+            const bool ok = q < S.ndef;
+            const int row = ok ? S.def_rows[q] : 0;
+            const bool own = ok && lig == 0;
+            d2 ri = make_double2(0.0, 0.0), pi = ri, si = ri, xi = ri;
+            double c = 0.0;
+            if (own) { ri = a.r[row]; xi = a.x[row]; c = a.cb[row]; if (!first) { pi = a.p[row]; si = a.s[row]; } }
+            double u1 = 0.0, u2 = 0.0;
+            if (ok) {
+                const int k1 = S.def_ptr[q + 1];
+                for (int k = S.def_ptr[q] + lig; k < k1; k += lpr) {
+                    const d2 sl = slots[S.def_idx[k]];
+                    u1 += sl.x; u2 += sl.y;
+                }
+            }
+            u1 = group_sum(u1, lpr);
+            u2 = group_sum(u2, lpr);
+            if (own) {
+                double q1, q2;                                  // EpiKkt::row (kernels.hip) on the applied vector r_i
+                if (row < a.n) { q1 = u1 + vtx * c; q2 = u2 + vty * c; }
+                else { q1 = -(u1 - vtx * c); q2 = -(u2 - vty * c); }
+                const d2 wi = make_double2(ri.x - q2, q1 - ri.y);
+                const double rr = upd(row, wi, ri, pi, si, xi);
+                if (a.count_repl) acc[0] += rr;                  // (row-sharded: replicated rows are counted by one rank)
+            }
+        }
+    }
+    if (have0) {
+        if (i0 == l - 1) w0 = make_double2(wt1, wt2);
+        const double rr = upd(i0, w0, r0, p0, s0, x0);
+        if (i0 != l - 1) acc[0] += rr;
+    }
+    for (int64_t k = i0 + stride; k < l; k += stride) {
+        if constexpr (DEF) { if ((a.def_mask[k >> 5] >> (k & 31)) & 1u) continue; }
+        const d2 wi = (k == l - 1) ? make_double2(wt1, wt2) : a.w[k];
+        const d2 ri = a.r[k], xi = a.x[k];
+        d2 pi = make_double2(0.0, 0.0), si = pi;
+        if (!first) { pi = a.p[k]; si = a.s[k]; }
+        const double rr = upd(k, wi, ri, pi, si, xi);
+        if (k != l - 1) acc[0] += rr;
+    }
+    block_reduce_store<1>(acc, a.rr_out + blockIdx.x);
+}
+void launch_cgm_update(const LaunchCtx& c, const CgmIter& it, bool close_only) {
+    CgmArgs a{};
+    a.l = c.l; a.x = it.x; a.r = it.r; a.p = it.p; a.s = it.s; a.w = it.w; a.st = c.st;
+    a.kkt_partials = c.partials; a.nkkt = c.S.nwg;
+    double* rr = c.partials + 3 * (size_t)PART_CAP;
+    a.rr_in = rr + (size_t)((it.j - 1) & 1) * CGM_RR_STRIDE; a.nrr = c.cg_blocks;
+    a.rr_out = rr + (size_t)(it.j & 1) * CGM_RR_STRIDE;
+    a.reduced = c.reduced; a.from_reduced = it.fold ? 0 : it.from_reduced;
+    a.j = it.j; a.close_here = it.close_in_update ? 1 : 0; a.close_only = close_only ? 1 : 0;
+    a.cb = c.cb; a.n = (int)c.n; a.def_mask = c.def_mask;
+    a.pb = it.fold ? *it.fold : PeerBox{}; a.seq_base = it.seq_base; a.count_repl = (int)c.count_repl;
+    a.pre = (c.pre && !it.fold && !it.from_reduced && !close_only && c.S.nwg >= 2048 && c.cg_blocks >= 4 * PRE_NPROD) ? c.pre : nullptr;
+    a.pre_seq = (uint32_t)(it.seq_base + 2u * (uint32_t)it.j + 1u);
+    a.batch_mark = it.batch_mark;
+    dim3 grid(close_only ? 1 : c.cg_blocks), block(VEC_THREADS);
+    if (c.S.ndef > 0) {
+        if (it.fold) hipLaunchKernelGGL((cgm_update_kernel<true, true>), grid, block, 0, c.stream, a, c.S);
+        else hipLaunchKernelGGL((cgm_update_kernel<true, false>), grid, block, 0, c.stream, a, c.S);
+    } else {
+        if (it.fold) hipLaunchKernelGGL((cgm_update_kernel<false, true>), grid, block, 0, c.stream, a, c.S);
+        else hipLaunchKernelGGL((cgm_update_kernel<false, false>), grid, block, 0, c.stream, a, c.S);
+    }
 }
 
 void launch_cg_init(const LaunchCtx& c, const double2* rhs, const double2* Ap, double2* r, double2* p) {

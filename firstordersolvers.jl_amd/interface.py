@@ -372,6 +372,20 @@ class HipHSDE:
         """fuse_p: -1 keeps the library's choice, 0 / 1 force the three- / two-launch CG iteration."""
         _lib.check(self._lib.fos_set_tuning(self._h, spmv_workgroups, cg_chunk, fuse_p))
 
+    def set_cg_variant(self, variant):
+        """which CG recurrence the affine projection runs: 'reference' | 'fused_p' | 'merged_sweep' | 'merged_update' | None (default)."""
+        codes = {None: -1, "default": -1, "reference": _lib.CG_REFERENCE, "fused_p": _lib.CG_FUSED_P,
+                 "merged_sweep": _lib.CG_MERGED_SWEEP, "merged_update": _lib.CG_MERGED_UPDATE}
+        _lib.check(self._lib.fos_set_cg_variant(self._h, codes[variant] if not isinstance(variant, int) else variant))
+
+    def cg_variant_name(self):
+        v = C.c_int32(0)
+        _lib.check(self._lib.fos_get_cg_variant(self._h, C.byref(v)))
+        return ("reference", "fused_p", "merged_sweep", "merged_update")[v.value]
+
+    def debug_set(self, what, value):
+        _lib.check(self._lib.fos_debug_set(self._h, int(what), int(value)))
+
     def profile_read_classes(self):
         """{'kkt' | 'psd' | 'cgvec': (launch groups, summed ms)} of the bracketed launches since the last read."""
         n = (C.c_int64 * 3)()
@@ -543,6 +557,8 @@ class FOSMathProgModel:
             self.data.close()
         self.data = HipHSDE(A, self.b, self.c, self.K1, self.K2, device=self.device)     # init_algorithm!  :58
         self.data.set_alg(self.alg)
+        if "cg_variant" in self.options:                           # device-side key (the reference ignores unknown option keys):
+            self.data.set_cg_variant(self.options["cg_variant"])   # which CG recurrence the affine projection runs (foship.h FOS_CG_*)
         if self.alg.direct:                                        # HSDE(model, direct=alg.direct)   HSDE.jl:12-15
             self.data.enable_direct(A)
         self.init_duration = time.perf_counter_ns() - t1

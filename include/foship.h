@@ -286,6 +286,28 @@ int fos_host_stacked_spmv_mode(int64_t m, int64_t n, const int64_t* colptr, cons
  * fuse_p: -1 keeps the choice made at fos_create, 0 / 1 force the three- / two-launch CG iteration (see fos_bench_cg_chain) */
 int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int32_t fuse_p);
 
+/* Which recurrence conjugategradient! (src/utilities/conjugategradients.jl:31-55) runs in.  All four produce the same Krylov
+ * iterates in exact arithmetic, count iterations as the reference does and apply its stop test (norm(r) <= tol || iter >=
+ * max_iters) to the same recursively updated residual; they differ in launches and reduction points per iteration:
+ *   FOS_CG_REFERENCE      the reference's recurrence: sweep Ap = M p -> alpha, x, r update -> beta, p update   (3 launches, 2 reduction points)
+ *   FOS_CG_FUSED_P        the p update rides on the next sweep                                                (2 launches, 2 reduction points; measured slower)
+ *   FOS_CG_MERGED_SWEEP   merged-reduction (Chronopoulos-Gear) recurrence: s = M p by recurrence from w = M r, one
+ *                         reduction point carrying r.r and w.r; the sweep closes the iteration            (2 launches, single GPU only)
+ *   FOS_CG_MERGED_UPDATE  the same, the update kernel closes the iteration: ONE exchange of four doubles per iteration
+ *                         when sharded; the sweep of the last iteration runs for nothing                  (2 launches; default for sharded handles)
+ * variant = -1 restores the handle's default (FOS_CG_REFERENCE on one GPU). */
+#define FOS_CG_REFERENCE     0
+#define FOS_CG_FUSED_P       1
+#define FOS_CG_MERGED_SWEEP  2
+#define FOS_CG_MERGED_UPDATE 3
+int fos_set_cg_variant(fos_handle h, int32_t variant);
+int fos_get_cg_variant(fos_handle h, int32_t* variant);   /* the variant the next projection runs (defaults resolved) */
+
+/* test hooks.  FOS_DEBUG_PUPDATE_DELAY: every workgroup but the first of the kernel that closes a CG iteration waits `value`
+ * ticks of the 100 MHz clock at entry (tests/test_gpu_parity.py: a late workgroup must still apply the last x update). */
+#define FOS_DEBUG_PUPDATE_DELAY 1
+int fos_debug_set(fos_handle h, int32_t what, int64_t value);
+
 #ifdef __cplusplus
 }
 #endif

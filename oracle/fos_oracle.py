@@ -297,6 +297,50 @@ def conjugategradient(x, A, b, r, p, Ap, tol=None, max_iters=10000, space=LOCAL)
     return it
 
 
+def conjugategradient_merged(x, A, b, r, p, s, w, tol=None, max_iters=10000, space=LOCAL):
+    """NOT in the reference: the merged-reduction (Chronopoulos & Gear) rearrangement of the recurrence above that the HIP path
+    offers as a CG variant (include/foship.h FOS_CG_MERGED_*; default on sharded handles).  Same Krylov iterates in exact
+    arithmetic, the same iteration count convention and the same stop test on the same recursively updated residual
+    (conjugategradients.jl:42); what changes is where the inner products are formed: w = A r is swept instead of A p, s = A p
+    follows by recurrence, and ONE reduction point per iteration carries r.r and w.r:
+        beta_i = g_i / g_{i-1},   alpha_i = g_i / (d_i - beta_i g_i / alpha_{i-1}),   g = r.r, d = w.r   (i = it - 1).
+    Exists so that the parity tests of that variant compare against the same arithmetic; nothing else uses it."""
+    if tol is None:
+        tol = A.shape[1] * EPS
+    A.mul(w, x)                                  # :32
+    np.subtract(b, w, out=r)                     # :33
+    gam = space.dotN(r, r)                       # :35
+    A.mul(w, r)
+    delta = space.dotN(w, r)
+    gam_prev = alpha_prev = None
+    it = 1                                       # :36
+    while True:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if it == 1:
+                alpha = gam / delta
+                p[:] = r
+                s[:] = w
+            else:
+                beta = gam / gam_prev
+                alpha = gam / (delta - beta * gam / alpha_prev)
+                p *= beta                        # :49
+                p += r                           # :50
+                s *= beta
+                s += w
+        x += alpha * p                           # :40
+        r -= alpha * s                           # :41   (s = A p)
+        gam_prev, alpha_prev = gam, alpha
+        gam = space.dotN(r, r)
+        if np.sqrt(gam) <= tol or it >= max_iters:   # :42
+            break
+        A.mul(w, r)
+        delta = space.dotN(w, r)
+        it += 1                                  # :51
+    if it == max_iters:                          # :53
+        warnings.warn("CG reached max iterations, result may be inaccurate")
+    return it
+
+
 class CGdata:
     """conjugategradients.jl:1-11."""
 
@@ -330,6 +374,7 @@ class AffinePlusLinear:
         self.i = 1                                           # :78 call counter (decides tol)
         self.cgiter = 0
         self.cgdata = CGdata(am + an)
+        self.cg_variant = "reference"                        # "merged": conjugategradient_merged (the HIP path's variant; tests only)
 
     def getcgiter(self):                                     # :81
         return self.cgiter
@@ -358,8 +403,14 @@ class AffinePlusLinear:
         tol = self.tolerance()                               # :108-112
         self.i += 1                                          # :114
         max_iters = 1000                                     # :115
-        it = conjugategradient(y, self.M, self.rhs, cg.r, cg.p, cg.z, tol=tol, max_iters=max_iters,
-                               space=getattr(self.A, "space", LOCAL))                                 # :117
+        if self.cg_variant == "merged":
+            if not hasattr(cg, "s"):
+                cg.s = np.empty_like(cg.r)
+            it = conjugategradient_merged(y, self.M, self.rhs, cg.r, cg.p, cg.s, cg.z, tol=tol, max_iters=max_iters,
+                                          space=getattr(self.A, "space", LOCAL))
+        else:
+            it = conjugategradient(y, self.M, self.rhs, cg.r, cg.p, cg.z, tol=tol, max_iters=max_iters,
+                                   space=getattr(self.A, "space", LOCAL))                             # :117
         self.cgiter = it                                     # :121
         cg.xinit[:] = y                                      # :122
         y[an:an + am] *= beta                                # :124
