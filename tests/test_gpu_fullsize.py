@@ -30,6 +30,71 @@ def _operator_properties(d, rng, tol=1e-11):
     assert np.linalg.norm(Mx - ref) <= tol * np.linalg.norm(ref)
 
 
+def _operator_vs_oracle(prob, d, rng, tol=1e-12):
+    """The operators at full size against the oracle directly: mul!(Y, Q, B), mul!(Y, transpose(Q), B) (HSDEAffine.jl:41-65) and
+    mul!(y, KKTMatrix(Q), x) (affinepluslinear.jl:37-52) are one scipy SpMV pair each -- as test/HSDEAffine.jl:26-62 does against
+    the explicit matrix.  Catches what the properties above cannot: a defect that is linear and hits A and A' alike."""
+    import fos_oracle as orc
+    Q = orc.HSDEMatrixQ(prob.A, prob.b, prob.c)
+    u = rng.standard_normal(d.l)
+    ref = np.empty(d.l)
+    Q.mul(ref, u)
+    got = d.q_apply(u)
+    assert np.linalg.norm(got - ref) <= tol * np.linalg.norm(ref)
+    assert np.max(np.abs(got - ref)) <= 50 * tol * np.max(np.abs(ref))          # no single row is off (a dropped tile, a short window)
+    Q.mul_t(ref, u)
+    assert np.linalg.norm(d.q_apply(u, transpose=True) - ref) <= tol * np.linalg.norm(ref)
+    x = rng.standard_normal(d.N)
+    ref2 = np.empty(d.N)
+    orc.KKTMatrix(Q).mul(ref2, x)
+    got2 = d.kkt_apply(x)
+    assert np.linalg.norm(got2 - ref2) <= tol * np.linalg.norm(ref2)
+    assert np.max(np.abs(got2 - ref2)) <= 50 * tol * np.max(np.abs(ref2))
+    # structured inputs: unit-like vectors excite single columns / the tau column alone
+    e = np.zeros(d.l)
+    e[d.l - 1] = 1.0
+    Q.mul(ref, e)
+    assert np.linalg.norm(d.q_apply(e) - ref) <= tol * max(1.0, np.linalg.norm(ref))
+    e = np.zeros(d.l)
+    e[::997] = 1.0
+    Q.mul(ref, e)
+    assert np.linalg.norm(d.q_apply(e) - ref) <= tol * max(1.0, np.linalg.norm(ref))
+
+
+def _same_step_vs_oracle(pkg, prob, alg, oalg, warm, tol):
+    """ONE outer iteration of the device and of the oracle from the same steady-state point (iterate, CG warm start, call counter,
+    GAPA's alpha12 handed over): solverwrapper.jl:23-29 -> step -> prox!(S1) (CG to the tolerance floor) -> prox!(S2) -> relaxations."""
+    import fos_oracle as orc
+    BIG = 10 ** 12
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d.set_alg(alg)
+    d.set_iterate(None)
+    done, _, _ = d.step(1, warm, BIG, 1e-8)
+    assert done == warm
+    z = d.get_iterate()
+    xinit, pi, _ = d.get_affine_state()
+    om = orc.Model(prob.A, prob.b, prob.c, [(orc.CONE_CODES[k], l) for k, l in prob.K1], [(orc.CONE_CODES[k], l) for k, l in prob.K2])
+    oalg.init(om)
+    oalg.S1.cgdata.xinit[:] = xinit
+    oalg.S1.cgdata.firstrun = False
+    oalg.S1.i = pi
+    if isinstance(oalg, orc.GAPA):
+        oalg.alpha12 = d.alpha12()
+    st = orc.HSDEStatus(om, BIG, 1e-8, 0, 0)
+    st.i = warm + 1
+    xo = z.copy()
+    oalg.step(xo, warm + 1, st)
+    d.step(warm + 1, 1, BIG, 1e-8)
+    zg = d.get_iterate()
+    dev = float(np.linalg.norm(zg - xo) / max(1.0, np.linalg.norm(xo)))
+    cg_dev, cg_orc = d.cgiter(), oalg.S1.getcgiter()
+    d.close()
+    print("same-step rel. dev. %.2e, CG iterations %d (oracle %d)" % (dev, cg_dev, cg_orc))
+    assert abs(cg_dev - cg_orc) <= 2, (cg_dev, cg_orc)
+    assert dev <= tol, dev
+    assert np.linalg.norm(zg - z) > 1e3 * tol * max(1.0, np.linalg.norm(z))      # (the step moved the iterate: the comparison is not vacuous)
+
+
 def _projection_properties(d, rng):
     z = rng.standard_normal(d.N)
     p = d.prox_cones(z)
@@ -62,6 +127,7 @@ def test_c4_operators_and_projections_full_size(pkg, c4):
     assert prob.nnz <= st["vals"] <= 1.05 * prob.nnz and st["cols"] < 0.01 * prob.nnz, st
     rng = np.random.default_rng(0)
     _operator_properties(d, rng)
+    _operator_vs_oracle(prob, d, rng)
     _projection_properties(d, rng)
 
 
@@ -97,6 +163,7 @@ def test_c2_full_size_operators_and_progress(pkg):
     assert prob.nnz == 5000 * 10000
     rng = np.random.default_rng(1)
     _operator_properties(d, rng)
+    _operator_vs_oracle(prob, d, rng)
     _projection_properties(d, rng)
     d.set_alg(pkg.DR())
     d.set_iterate(None)
@@ -111,6 +178,7 @@ def test_c3_full_size_gapa(pkg):
     prob = pkg.workloads.c3_socp()
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     _operator_properties(d, np.random.default_rng(2))
+    _operator_vs_oracle(prob, d, np.random.default_rng(12))
     _projection_properties(d, np.random.default_rng(3))
     d.close()
     model = pkg.solve(prob, pkg.GAPA(eps=1e-4, max_iters=6000, verbose=0, checki=250))
@@ -127,6 +195,7 @@ def test_c5_full_size_fista_residuals_vs_oracle(pkg, oracle):
     assert 9.9e5 < prob.m + prob.n + 1 < 1.01e6
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     _operator_properties(d, np.random.default_rng(4))
+    _operator_vs_oracle(prob, d, np.random.default_rng(14))
     _projection_properties(d, np.random.default_rng(5))
     d.set_alg(pkg.FISTA())
     d.set_iterate(None)
@@ -144,3 +213,17 @@ def test_c5_full_size_fista_residuals_vs_oracle(pkg, oracle):
     _, _, res2 = d.step(41, 160, 200, 1e-8)
     assert res2.p < res.p and res2.d < res.d             # and FISTA makes progress at this size
     d.close()
+
+
+def test_c3_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle):
+    """C3 (GAPA), outer iteration 261 from the device's state at iteration 260 (past the CG tolerance floor, ~97 CG iterations):
+    the device's iterate against the oracle's, relative 1e-9 (BASELINE tolerance 1e-8)."""
+    prob = pkg.workloads.c3_socp()
+    _same_step_vs_oracle(pkg, prob, pkg.GAPA(), oracle.GAPA(), 260, 1e-9)
+
+
+def test_c5_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle):
+    """C5's operator (window panels) and cone stack (NonNeg + 2000 SOC + 72 PSD(64)) under DR -- FISTA's extrapolation state
+    lives on the device only -- outer iteration 241 from the device's state at iteration 240, against the oracle."""
+    prob = pkg.workloads.c5_mixed()
+    _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 240, 1e-9)
