@@ -39,9 +39,25 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
     double acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
-    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    // (chunks of U records per thread with all loads of a chunk issued before the first add: one memory round trip for up to
+    //  U x blockDim records instead of one per record -- these sums sit on the latency chain of every CG iteration; same
+    //  summation order as the plain strided loop)
+    constexpr int U = NACC <= 3 ? 8 : 4;
+    for (int base = threadIdx.x; base < count; base += U * blockDim.x) {
+        double v[U][NACC];
 #pragma unroll
-        for (int a = 0; a < NACC; ++a) acc[a] += partials[(int64_t)i * NACC + a];
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * blockDim.x;
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) v[u][a] = (i < count) ? partials[(int64_t)i * NACC + a] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base + u * (int)blockDim.x < count) {
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) acc[a] += v[u][a];
+            }
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
@@ -185,10 +201,12 @@ __device__ __forceinline__ CgClose cg_close_iteration(DevState* st, const double
 // the same order and returns true when CG has stopped (then nothing is swept).  Workgroup 0 stores g_jd for the next update.
 __device__ __forceinline__ bool cgm_close_in_sweep(DevState* st, const double* __restrict__ rr_partials, int count,
                                                    const d2* __restrict__ r, int64_t l, int jd, uint32_t epoch, int32_t batch_mark) {
+    // (everything is requested before the gate on `done` is evaluated: one memory round trip for the whole prologue)
     const d2 rt = r[l - 1];
     const double tol = st->tol;
-    const int maxit = st->maxit;
+    const int maxit = st->maxit, done = st->done;
     const double rr = wave_sum_records(rr_partials, count) + (rt.x * rt.x + rt.y * rt.y);
+    if (done) return true;
     const bool stop = (sqrt(rr) <= tol) || (jd >= maxit);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->rr = rr;

@@ -701,7 +701,7 @@ struct KktArgs {
 template <bool DEFER, bool FUSEP, bool FOLD>
 __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBlkCsr S, KktArgs a) {
     static_assert(!FOLD || DEFER, "FOLD is about deferred rows");
-    if ((FUSEP || a.gate) && a.st->done) return;
+    if ((FUSEP || a.gate) && a.close_j <= 0 && a.st->done) return;        // (close_j > 0: cgm_close_in_sweep below tests `done` with its other loads)
     __shared__ __attribute__((aligned(16))) double prod[SPMV_WAVES * WNNZ * 2];
     __shared__ double red[16];
     using G = typename std::conditional<FUSEP, GatherP, GatherW>::type;
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBl
 
 // window-panel form of the sweep (stand-alone applies and CG iterations alike: no dual tiles, the p update is a kernel of its own)
 __global__ __launch_bounds__(WIN_THREADS, 4) void kkt2_win_kernel(DevBlkCsr S, KktArgs a) {
-    if (a.gate && a.st->done) return;
+    if (a.gate && a.close_j <= 0 && a.st->done) return;
     extern __shared__ __attribute__((aligned(16))) double wlds[];
     GatherW gat;
     gat.w = a.w;

@@ -320,26 +320,29 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
     if constexpr (DEF) { if (have0 && ((a.def_mask[i0 >> 5] >> (i0 & 31)) & 1u)) have0 = false; }
     d2 w0 = make_double2(0.0, 0.0), r0 = w0, x0 = w0, p0 = w0, s0 = w0;
     if (have0) { w0 = a.w[i0]; r0 = a.r[i0]; x0 = a.x[i0]; if (!first) { p0 = a.p[i0]; s0 = a.s[i0]; } }      // requested before the scalar prologue
-    if (st->done) return;
-    if (FOLD && st->xchg_failed) return;
+    // the scalars this launch needs (stored by EARLIER launches: nothing below races them) and the r.r records are requested
+    // together with the gate -- the prologue is a latency chain every CG iteration pays
+    const bool closing = a.close_here && !first;
+    const int done = st->done, xfail = st->xchg_failed, maxit = st->maxit;
+    const double vtx = st->vtau[0], vty = st->vtau[1];           // tau element of r_i (stashed by the sweep that applied M to it)
+    const double g_cur = st->rn2[i & 1], g_prev = st->rn2[(i + 1) & 1], a_prev = st->alpha2[(i + 1) & 1], tol = st->tol;
+    const double rs = !closing ? 0.0 : (a.from_reduced ? a.reduced[3] : wave_sum_records(a.rr_in, a.nrr));
+    if (done) return;
+    if (FOLD && xfail) return;
     __shared__ double sums[4];
     sweep_sums3(sums, a.kkt_partials, a.nkkt, a.reduced, a.from_reduced, a.pre, a.pre_seq, st);
-    const bool closing = a.close_here && !first;
     if (closing || FOLD) {
-        const double rs = (a.from_reduced || !closing) ? (closing ? a.reduced[3] : 0.0) : wave_sum_records(a.rr_in, a.nrr);
         if (threadIdx.x == 0) sums[3] = rs;
         __syncthreads();
     }
     if constexpr (FOLD) {
         if (!peer_fold_sum<4>(a.pb, a.seq_base + (uint32_t)a.j, sums, st)) return;
     }
-    const double vtx = st->vtau[0], vty = st->vtau[1];           // tau element of r_i (stashed by the sweep that applied M to it)
     const double S1 = sums[0], T1 = sums[1], T2 = sums[2];
-    const double gam = closing ? sums[3] + (vtx * vtx + vty * vty) : st->rn2[i & 1];
+    const double gam = closing ? sums[3] + (vtx * vtx + vty * vty) : g_cur;
     const bool w0blk = blockIdx.x == 0 && threadIdx.x == 0;
     if (closing) {
-        const int maxit = st->maxit;
-        if (sqrt(gam) <= st->tol || i >= maxit) {                  // conjugategradients.jl:42 for iteration i
+        if (sqrt(gam) <= tol || i >= maxit) {                      // conjugategradients.jl:42 for iteration i
             if (w0blk) { st->rr = gam; cg_signal_stop(st, i, maxit, gam, a.seq_base >> 11); }
             return;
         }
@@ -350,9 +353,8 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
     double beta = 0.0, alpha;
     if (first) alpha = gam / delta;
     else {
-        const double gprev = st->rn2[(i - 1) & 1], aprev = st->alpha2[(i - 1) & 1];
-        beta = gam / gprev;
-        alpha = gam / (delta - beta * gam / aprev);
+        beta = gam / g_prev;
+        alpha = gam / (delta - beta * gam / a_prev);
     }
     if (w0blk) {
         if (closing) st->rn2[i & 1] = gam;

