@@ -272,7 +272,7 @@ def main():
         #     read + the result written; the gathered columns of the vector are served from L2.
         ost = dev.operator_stats()
         nmr = prob.m + prob.n
-        stored_bytes = (8.0 * ost["vals"] + 4.0 * ost["cols"] + 32.0 * ost["blocks"] + 16.0 * ost["slots"]
+        stored_bytes = (8.0 * ost["vals"] + 4.0 * ost["cols"] + 48.0 * ost["blocks"] + 16.0 * ost["slots"]
                         + 16.0 * nmr + 8.0 * nmr + 16.0 * nmr)
         # (2) the same from rocprofv3 PMC passes of THIS round's kernels (tools/gpu_profile_r02.sh -> profiles/), when committed
         traffic, traffic_src = None, None

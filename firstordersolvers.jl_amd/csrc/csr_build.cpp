@@ -58,6 +58,9 @@ void partition_workgroups(HostBlkCsr* S, int nwg_target) {
         S->wave_blk0[g] = b;
     }
     S->wave_blk0[nwaves] = nblk;
+    S->wave_first.assign(nwaves, BlkDesc{});
+    for (int g = 0; g < nwaves; ++g)
+        if (S->wave_blk0[g] < S->wave_blk0[g + 1] && !S->blk.empty()) S->wave_first[g] = S->blk[S->wave_blk0[g]];
     S->nwg = nwg;
     S->nwaves = nwaves;
 }
@@ -332,10 +335,11 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             for (int k = 0; k < g.nchunk; ++k) {
                 const int64_t tc = std::min<int64_t>(tcmax, g.C - (int64_t)k * tcmax);
                 const int64_t tpad = (tc + TILE_GROUP - 1) / TILE_GROUP * TILE_GROUP;
-                BlkDesc d;
+                BlkDesc d{};
                 d.nnz0 = align(pos);
                 d.colpos = align(cpos);
                 d.cnt = 64 * tpad;
+                S.tile_tmax = std::max<int32_t>(S.tile_tmax, (int32_t)tpad);
                 d.row0 = (int32_t)r;
                 d.info = (int32_t)g.R | (BLK_TILE << 8) | (1 << 10) | ((int32_t)tpad << 16);
                 TileRec t;
@@ -360,7 +364,7 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         // a block is homogeneous in run-ness; its rows end where the flag flips (or at a row the sweep does not contain)
         int64_t r_lim = r;
         while (r_lim < nrows && (r_lim - r0) < WROWS && !skip[r_lim] && (compress && is_run[r_lim]) == run0) ++r_lim;
-        BlkDesc d;
+        BlkDesc d{};
         d.nnz0 = blk_start;
         d.colpos = col_start;
         d.row0 = (int32_t)r0;
@@ -486,6 +490,7 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         S.col[d.colpos + 1] = t.cslot;
         S.col[d.colpos + 2] = t.rslot;
         S.col[d.colpos + 3] = (int32_t)std::min<int64_t>(tcmax, groups[t.group].C - (int64_t)t.chunk * tcmax);
+        for (int q = 0; q < 4; ++q) S.blk[t.blk].meta[q] = S.col[d.colpos + q];      // the kernels read the descriptor's copy
     }
     auto place = [&](int64_t row, int64_t e) -> int64_t {        // offset of entry e of `row` relative to its block base
         const int64_t tpr = row_tpr[row];

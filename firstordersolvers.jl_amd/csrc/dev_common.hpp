@@ -84,7 +84,10 @@ __device__ __forceinline__ bool peer_fold_sum(const PeerBox& pb, uint32_t seq, d
     const int t = threadIdx.x;
     if (t == 0) failed = 0;
     __syncthreads();
-    const size_t par = (size_t)(seq & 1u) * PEER_MAX_RANKS;
+    // four slots: (CG solve number & 1, sequence number & 1).  Inside a solve consecutive exchanges alternate in the low bit; the
+    // first exchange of the NEXT solve takes the other pair, so it can never overwrite words a slower peer is still polling for
+    // (the merged-reduction recurrence ends a solve on either parity)
+    const size_t par = (size_t)((((seq >> 11) & 1u) << 1) | (seq & 1u)) * PEER_MAX_RANKS;
     if (t < pb.nranks * NACC * 2) {
         const int hh = t & 1, v = (t >> 1) % NACC, r = (t >> 1) / NACC;
         const unsigned long long bits = (unsigned long long)__double_as_longlong(sums[v]);
@@ -123,6 +126,23 @@ __device__ __forceinline__ bool peer_fold_sum(const PeerBox& pb, uint32_t seq, d
     }
     __syncthreads();
     return true;
+}
+
+// A lane's share of a slot-spread row's list (entries k0, k0 + lpr, ... < k1): index loads of a chunk of four entries, then the
+// four slot loads, then the adds in list order -- two memory round trips per chunk instead of two per entry (on small operators
+// this loop is the latency of the kernel; C4: 33 slots per row over 8 lanes = one chunk and a tail).
+__device__ __forceinline__ void slot_list_sum(const d2* __restrict__ slots, const int32_t* __restrict__ def_idx, int k0, int k1, int lpr,
+                                              double& u1, double& u2) {
+    for (int k = k0; k < k1; k += 4 * lpr) {
+        int id[4];
+        d2 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) id[q] = (k + q * lpr < k1) ? def_idx[k + q * lpr] : -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = id[q] >= 0 ? slots[id[q]] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (id[q] >= 0) { u1 += v[q].x; u2 += v[q].y; }
+    }
 }
 
 // Values that cross workgroups INSIDE a kernel: the L2s of the XCDs are not coherent with each other between kernel boundaries,
@@ -207,6 +227,10 @@ __device__ __forceinline__ bool cgm_close_in_sweep(DevState* st, const double* _
     const int maxit = st->maxit, done = st->done;
     const double rr = wave_sum_records(rr_partials, count) + (rt.x * rt.x + rt.y * rt.y);
     if (done) return true;
+    if (jd == 0) {                                                // the start: g_0 = r_0.r_0, no stop test (conjugategradients.jl:35-36)
+        if (blockIdx.x == 0 && threadIdx.x == 0) { st->rn2[0] = rr; st->rn = rr; }
+        return false;
+    }
     const bool stop = (sqrt(rr) <= tol) || (jd >= maxit);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->rr = rr;

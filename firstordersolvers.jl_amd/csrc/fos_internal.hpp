@@ -63,6 +63,7 @@ constexpr int TILE_MIN_ROWS = 16;   // fewer rows: not worth a 64-lane wavefront
 constexpr int TILE_MIN_COLS = 8;
 constexpr int TILE_TC_MAX = 64;     // columns (steps) per tile: 32 KB of values per wavefront work unit (measured best on C2: 32..128 tried)
 constexpr int TILE_GROUP = 8;       // steps per butterfly; stored steps are padded to a multiple
+constexpr int TILE_DEEP_T = 32;     // deep variant: tiles of at most this many steps, all values requested up front
 
 // Window panels (gather-bound random-sparse operators, C5 class).  A PANEL = WIN_ROWS consecutive rows of S, the unit of
 // work of ONE WORKGROUP (two of them share a CU), which walks the column WINDOWS (WIN_COLS consecutive entries of the stacked vector) its rows touch:
@@ -81,13 +82,15 @@ struct WinSeg { int32_t col0, ncols, slice0, nslice; };
 struct WinSlice { int64_t off; int32_t steps, pad; };       // values/columns at off + 64 t + lane (off a multiple of 64)
 
 
-struct BlkDesc {                    // one row block = the unit of work of ONE wavefront (32 bytes)
+struct BlkDesc {                    // one row block = the unit of work of ONE wavefront (48 bytes, wave-uniform: read by scalar loads)
     int64_t nnz0;                   // first value in `val` (multiple of NNZ_ALIGN)
     int64_t colpos;                 // first entry in `col`: per-entry column indices, or -- for a RUN block, whose rows
                                     // all have consecutive columns -- one first-column per row (index compression)
     int64_t cnt;                    // stored values (ELL: 64 * steps, padding included; LONG: entries per row, rows at stride align4(cnt))
     int32_t row0;                   // first row
     int32_t info;                   // nrows (bits 0..7) | kind << 8 | run << 10 | ELL steps T << 16
+    int32_t meta[4];                // dual tile: first column, column-slot base, row-slot base (-1: none), real columns -- in the
+                                    // descriptor so that a tile costs ONE dependent load before its values, not two (0 otherwise)
     __host__ __device__ int nrows() const { return info & 0xFF; }
     __host__ __device__ int kind() const { return (info >> 8) & 0x3; }
     __host__ __device__ int run() const { return (info >> 10) & 0x1; }
@@ -102,6 +105,8 @@ struct HostBlkCsr {
     std::vector<BlkDesc> blk;          // [nblk]
     std::vector<uint16_t> row_rel;     // [nrows]  row start relative to its block's nnz0 (stream blocks)
     std::vector<int32_t> wave_blk0;    // [nwaves+1]  row blocks owned by each wavefront of the grid
+    std::vector<BlkDesc> wave_first;   // [nwaves]    blk[wave_blk0[w]] (zero for a wavefront without blocks)
+    int32_t tile_tmax = 0;             // longest dual tile, in steps (0: no tile)
     int32_t nblk = 0, nwg = 0, nwaves = 0;
     // dual tiles / deferred rows (empty when the operator has no tile)
     int64_t nslots = 0;                // partial-sum slots (2 doubles each)
@@ -128,7 +133,10 @@ struct DevBlkCsr {
     const BlkDesc* blk;
     const uint16_t* row_rel;
     const int32_t* wave_blk0;
+    const BlkDesc* wave_first;         // [nwaves] copy of each wavefront's first descriptor (requested together with wave_blk0)
     int32_t nblk, nwg, nwaves;
+    int32_t tile_deep;                 // 1: every dual tile has <= TILE_DEEP_T steps and the operator is small -- the sweep
+                                       // requests a whole tile at once (kkt2_kernel<.., DEEP>): latency, not occupancy, bounds it
     // dual tiles / deferred rows (ndef == 0: none)
     double* slots;                     // [nslots][2]   written by the sweeps
     const double* slots_rd;            // what the slot-list sums read: == slots, or -- row-sharded operators -- the all-reduced copy
@@ -217,7 +225,8 @@ struct ConeDesc {          // a SOC / rotated SOC / PSD cone in stacked index sp
 // number selects the half a given exchange uses (a rank can be at most one exchange ahead of a peer).
 constexpr int PEER_MAX_RANKS = 16;
 constexpr int PEER_MAX_VALS = 8;
-constexpr size_t PEER_BOX_WORDS = (size_t)2 * PEER_MAX_RANKS * PEER_MAX_VALS * 2;
+constexpr size_t PEER_BOX_WORDS = (size_t)2 * PEER_MAX_RANKS * PEER_MAX_VALS * 2;     // region 0; region 1 (folded exchanges, four slots) is twice that
+constexpr size_t PEER_BOX_TOTAL_WORDS = 3 * PEER_BOX_WORDS;
 // A mailbox has TWO such regions: region 0 for the exchanges of the single-workgroup reduce kernel (sequence = a device
 // counter of executed exchanges), region 1 for the two exchanges of a CG iteration that are FOLDED into the CG vector kernels
 // (every workgroup reduces the local records itself, workgroup 0 also writes them to the peers, every workgroup polls; the
@@ -311,8 +320,12 @@ struct CgmIter {
     int32_t batch_mark = 0;    // != 0: the launch that ends the host's batch tells the host when CG goes on after it (HostMark.batch)
 };
 constexpr int CGM_RR_STRIDE = 1024;   // r.r records ping-pong: the update of iteration j writes [j & 1][...]
-void launch_cgm_sweep(const LaunchCtx& c, const CgmIter& it, int closes);        // w = M r (gated); closes > 0: first closes that iteration
+void launch_cgm_sweep(const LaunchCtx& c, const CgmIter& it, int closes);        // w = M r (gated); closes >= 0: first closes that iteration (0: the start, g_0 only)
 void launch_cgm_update(const LaunchCtx& c, const CgmIter& it, bool close_only);
+// the start of a solve: the sweep it.w = M v (all rows but the tau row, slot-spread rows unfinished; launch_cgm_apply) and
+// r = rhs - M v with the r.r records of "iteration 0"; its first workgroup also opens the solve in DevState (done = 0, tol, ...)
+void launch_cgm_apply(const LaunchCtx& c, const CgmIter& it, const double2* v);
+void launch_cgm_start(const LaunchCtx& c, const CgmIter& it, const double2* rhs, const double2* v, double tol, int maxit);
 
 // single right-hand side Q apply on component `comp` of an interleaved vector
 //   Q_PLAIN : out_plain[i] = sign * (Q v)_i            (rows 0..n+m-1; tau row by q1_finalize)
@@ -332,8 +345,11 @@ void launch_normdiff(const LaunchCtx& c, const double2* x, const double2* y);   
 void launch_shift_part2(const LaunchCtx& c, double2* out, const double2* y, const double2* x);   // out = (y.x, y.y - x.y)
 void launch_axpby(const LaunchCtx& c, double2* out, double a, const double2* x, double b, const double2* y);          // out = a x + b y
 void launch_relax_a12(const LaunchCtx& c, double2* out, const double2* y, const double2* x);                          // out = a12 y + (1-a12) x, a12 from state
-void launch_gap_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha, double alpha2);   // x = alpha(alpha2 t2+(1-alpha2)t1) + (1-alpha) x
-void launch_gapa_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha);           // + normedScalar partials
+// shift_out != nullptr: also shift_out = sol - [0; x2_new] (launch_shift_part2 for the next affine projection, saved a launch)
+void launch_gap_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha, double alpha2,
+                      double2* shift_out = nullptr, const double2* sol = nullptr);   // x = alpha(alpha2 t2+(1-alpha2)t1) + (1-alpha) x
+void launch_gapa_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha,
+                       double2* shift_out = nullptr, const double2* sol = nullptr);  // + normedScalar partials
 void launch_gapa_finalize(const LaunchCtx& c, double beta, int from_reduced);
 void launch_fista_extrap(const LaunchCtx& c, double2* y, const double2* x, const double2* xold, double coef);         // y = x + coef (x - xold)
 void launch_add(const LaunchCtx& c, double2* out, const double2* a, const double2* b);                                // out = a + b

@@ -288,17 +288,41 @@ __device__ __forceinline__ void long_steps(const G& gat, const double* __restric
     }
 }
 
-template <bool DEFER, class G, class Epi>
-__device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi& epi, double* prod_all) {
+// wave-uniform descriptor through the constant address space (scalar loads)
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) v4i* cptr_v4i;
+__device__ __forceinline__ BlkDesc ld_desc(const BlkDesc* p) {
+    static_assert(sizeof(BlkDesc) == 48, "three 16-byte scalar loads");
+    union { v4i q[3]; BlkDesc d; } u;
+    const cptr_v4i src = (cptr_v4i)(p);
+    u.q[0] = src[0]; u.q[1] = src[1]; u.q[2] = src[2];
+    return u.d;
+}
+
+// the slice of row blocks a wavefront owns and its FIRST descriptor, both requested at once (WaveWork: a kernel asks for them
+// before its scalar prologue, so that the prologue's round trip covers them too)
+struct WaveWork { int b_lo, b_hi; BlkDesc first; };
+__device__ __forceinline__ WaveWork wave_work(const DevBlkCsr& S) {
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = xcd_remap(blockIdx.x, S.nwg) * SPMV_WAVES + wv;
+    WaveWork w;
+    w.b_lo = S.wave_blk0[wave]; w.b_hi = S.wave_blk0[wave + 1];
+    w.first = ld_desc(S.wave_first + wave);
+    return w;
+}
+
+template <bool DEFER, bool DEEP, class G, class Epi>
+__device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi& epi, double* prod_all, const WaveWork& ww) {
     constexpr int NRHS = G::NRHS;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = xcd_remap(blockIdx.x, S.nwg);
     double* prod = prod_all + (size_t)wv * (WNNZ * NRHS);          // this wavefront's LDS slice
-    const int wave = g * SPMV_WAVES + wv;
-    const int b_lo = S.wave_blk0[wave], b_hi = S.wave_blk0[wave + 1];
+    const int b_lo = ww.b_lo, b_hi = ww.b_hi;
+    BlkDesc dnext = ww.first;
     for (int b = b_lo; b < b_hi; ++b) {
-        const BlkDesc d = S.blk[b];
+        const BlkDesc d = dnext;
+        if constexpr (G::FUSED) { if (b + 1 < b_hi) dnext = S.blk[b + 1]; }     // (the two-launch variant sits at its register limit: plain load)
+        else { if (b + 1 < b_hi) dnext = ld_desc(S.blk + b + 1); }             // one block ahead: its latency hides behind this block's loads
         const int kind = d.kind();
         if (kind == BLK_LONG) {
             // ---------------- long row d.row0
@@ -329,10 +353,7 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
             // ---------------- dual tile: lane = row, step = column; row sums stay in the lanes, column sums go to slots
             if constexpr (DEFER) {
                 const int R = d.nrows(), T = d.steps();
-                const int c0 = __builtin_amdgcn_readfirstlane(S.col[d.colpos]);
-                const int cslot = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 1]);
-                const int rslot = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 2]);
-                const int tc = __builtin_amdgcn_readfirstlane(S.col[d.colpos + 3]);      // real columns (steps beyond: padding)
+                const int c0 = d.meta[0], cslot = d.meta[1], rslot = d.meta[2], tc = d.meta[3];      // (tc: real columns; steps beyond are padding)
                 const bool valid = lane < R;
                 const int row = d.row0 + lane;
                 RowPre pr{};
@@ -341,6 +362,43 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
                 const double* __restrict__ val = S.val + d.nnz0 + lane;
                 d2* __restrict__ slots = reinterpret_cast<d2*>(S.slots);
                 double r1 = 0.0, r2 = 0.0;
+                if constexpr (DEEP && !G::FUSED && NRHS == 2) {
+                    // small operators (a shard of a multi-GPU run): the WHOLE tile (<= TILE_DEEP_T steps) is requested at once --
+                    // with one or two tiles per SIMD the sweep is a chain of memory latencies, not a stream
+                    constexpr int NG = TILE_DEEP_T / TILE_GROUP;
+                    double v[NG][TILE_GROUP];
+                    d2 xl[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        xl[g] = make_double2(0.0, 0.0);
+                        if (g * TILE_GROUP < T) {
+                            if constexpr (Epi::FOLDDEF) { if (lane < TILE_GROUP && g * TILE_GROUP + lane < tc) xl[g] = gat.load(c0 + g * TILE_GROUP + lane); }
+#pragma unroll
+                            for (int u = 0; u < TILE_GROUP; ++u) v[g][u] = nt_load(val + 64 * (g * TILE_GROUP + u));
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        if (g * TILE_GROUP < T) {
+                            const int t = g * TILE_GROUP;
+                            d2 x[TILE_GROUP];
+                            double p1[TILE_GROUP], p2[TILE_GROUP];
+#pragma unroll
+                            for (int u = 0; u < TILE_GROUP; ++u) x[u] = (t + u < tc) ? gat.load_u(c0 + t + u) : make_double2(0.0, 0.0);
+#pragma unroll
+                            for (int u = 0; u < TILE_GROUP; ++u) {
+                                r1 += v[g][u] * x[u].x; p1[u] = v[g][u] * wr.x;
+                                r2 += v[g][u] * x[u].y; p2[u] = v[g][u] * wr.y;
+                            }
+                            const double s1 = tile_colsum8(p1, lane);
+                            const double s2 = tile_colsum8(p2, lane);
+                            if (lane < TILE_GROUP) {
+                                slots[cslot + t + lane] = make_double2(s1, s2);
+                                epi.park(c0 + t + lane, s1, s2, xl[g]);
+                            }
+                        }
+                    }
+                } else {
                 double vn[TILE_GROUP];                 // the next group's values are in flight while this group is reduced
                 // the element of this lane's column slot (lanes 0..7), for epi.park: fetched one group AHEAD and BEFORE that
                 // group's values -- vmcnt retires in order, so a load issued behind the value prefetch could only be waited
@@ -391,6 +449,7 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
                         slots[cslot + t + lane] = make_double2(s1, s2);
                         epi.park(c0 + t + lane, s1, s2, xl);
                     }
+                }
                 }
                 if (valid) {
                     if (rslot < 0) epi.row(row, r1, r2, pr);
@@ -694,14 +753,16 @@ struct KktArgs {
     int count_repl;            // FOLD: 0 = the slot-free part of the slot-spread rows is counted by another rank (row-sharded)
     // merged-reduction CG (fos_internal.hpp, CgmIter): the sweep applies M to r
     double* vt_out;            // non-null: workgroup 0 stashes the applied vector's tau element here (DevState.vtau)
-    int close_j;               // > 0: close iteration close_j first (r.r records of its update, stop test) and return when CG has stopped
+    int close_j;               // >= 0: close iteration close_j first (r.r records of its update, stop test) and return when CG has stopped (plain_args: -1)
     int32_t batch_mark;
 };
 
-template <bool DEFER, bool FUSEP, bool FOLD>
+template <bool DEFER, bool FUSEP, bool FOLD, bool DEEP = false>
 __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBlkCsr S, KktArgs a) {
     static_assert(!FOLD || DEFER, "FOLD is about deferred rows");
-    if ((FUSEP || a.gate) && a.close_j <= 0 && a.st->done) return;        // (close_j > 0: cgm_close_in_sweep below tests `done` with its other loads)
+    WaveWork ww;                             // requested before the gate / the closing prologue: their round trip covers it
+    if constexpr (!FUSEP) ww = wave_work(S);
+    if ((FUSEP || a.gate) && a.close_j < 0 && a.st->done) return;        // (close_j > 0: cgm_close_in_sweep below tests `done` with its other loads)
     __shared__ __attribute__((aligned(16))) double prod[SPMV_WAVES * WNNZ * 2];
     __shared__ double red[16];
     using G = typename std::conditional<FUSEP, GatherP, GatherW>::type;
@@ -711,9 +772,10 @@ __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBl
         const CgClose cl = cg_close_iteration(a.st, a.rr_partials, a.rr_count, a.reduced, a.from_reduced, a.r, (int64_t)a.nm + 1, a.j - 1, a.pb, a.seq_base);
         if (!cl.ok || cl.stop) return;
         gat.r = a.r; gat.pold = a.w; gat.beta = cl.beta;
+        ww = wave_work(S);
     } else {
         gat.w = a.w;
-        if (a.close_j > 0 && cgm_close_in_sweep(a.st, a.rr_partials, a.rr_count, a.w, (int64_t)a.nm + 1, a.close_j, a.seq_base >> 11, a.batch_mark)) return;
+        if (a.close_j >= 0 && cgm_close_in_sweep(a.st, a.rr_partials, a.rr_count, a.w, (int64_t)a.nm + 1, a.close_j, a.seq_base >> 11, a.batch_mark)) return;
     }
     EpiKkt<G, FOLD> epi;
     epi.gat = gat; epi.out = a.out; epi.pnew = a.pnew; epi.cb = a.cb; epi.n = a.n; epi.wt = gat.load_u(a.nm);
@@ -729,17 +791,17 @@ __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBl
             for (int q = blockIdx.x * SPMV_THREADS + threadIdx.x; q < S.ndef; q += gridDim.x * SPMV_THREADS) { const int i = S.def_rows[q]; a.pnew[i] = gat.load(i); }
         }
     }
-    spmv_walk<DEFER>(S, gat, epi, prod);
+    spmv_walk<DEFER, DEEP>(S, gat, epi, prod, ww);
     block_reduce_store<3, SPMV_THREADS>(epi.acc, red, a.partials + 3 * (int64_t)blockIdx.x);
 }
 
 // window-panel form of the sweep (stand-alone applies and CG iterations alike: no dual tiles, the p update is a kernel of its own)
 __global__ __launch_bounds__(WIN_THREADS, 4) void kkt2_win_kernel(DevBlkCsr S, KktArgs a) {
-    if (a.gate && a.close_j <= 0 && a.st->done) return;
+    if (a.gate && a.close_j < 0 && a.st->done) return;
     extern __shared__ __attribute__((aligned(16))) double wlds[];
     GatherW gat;
     gat.w = a.w;
-    if (a.close_j > 0 && cgm_close_in_sweep(a.st, a.rr_partials, a.rr_count, a.w, (int64_t)a.nm + 1, a.close_j, a.seq_base >> 11, a.batch_mark)) return;
+    if (a.close_j >= 0 && cgm_close_in_sweep(a.st, a.rr_partials, a.rr_count, a.w, (int64_t)a.nm + 1, a.close_j, a.seq_base >> 11, a.batch_mark)) return;
     EpiKkt<GatherW, false> epi;
     epi.gat = gat; epi.out = a.out; epi.pnew = nullptr; epi.cb = a.cb; epi.n = a.n; epi.wt = gat.load_u(a.nm);
     epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
@@ -778,11 +840,7 @@ __device__ __forceinline__ void deferred_rows(const DevBlkCsr& S, Epi& epi) {
         if (ok && lig == 0) pr = epi.pre(row);
         double u1 = 0.0, u2 = 0.0;
         if (ok) {
-            const int k1 = S.def_ptr[q + 1];
-            for (int k = S.def_ptr[q] + lig; k < k1; k += lpr) {
-                const d2 p = slots[S.def_idx[k]];
-                u1 += p.x; u2 += p.y;
-            }
+            slot_list_sum(slots, S.def_idx, S.def_ptr[q] + lig, S.def_ptr[q + 1], lpr, u1, u2);
         }
         u1 = group_sum(u1, lpr);
         u2 = group_sum(u2, lpr);
@@ -907,6 +965,7 @@ static KktArgs plain_args(const LaunchCtx& c, const double2* w, double2* out, in
     KktArgs a{};
     a.w = w; a.out = out; a.cb = c.cb; a.n = (int)c.n; a.nm = (int)(c.n + c.m); a.partials = c.partials; a.st = c.st; a.gate = gate;
     a.count_repl = c.count_repl;
+    a.close_j = -1;
     return a;
 }
 // stand-alone apply: sweep (+ deferred-row kernel when the operator has dual tiles); leaves c.S.npart records at c.S.part_off
@@ -914,7 +973,8 @@ void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
     const KktArgs a = plain_args(c, w, out, gate);
     if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
     if (c.S.ndef > 0) {
-        hipLaunchKernelGGL((kkt2_kernel<true, false, false>), dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, a);
+        if (c.S.tile_deep) hipLaunchKernelGGL((kkt2_kernel<true, false, false, true>), dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, a);
+        else hipLaunchKernelGGL((kkt2_kernel<true, false, false>), dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, a);
         if (c.between) (void)c.between(c.between_arg);        // row-sharded: the slots are summed over the ranks here
         hipLaunchKernelGGL(kkt2_deferred_kernel, dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, w, out, c.cb, (int)c.n,
                            (int)(c.n + c.m), c.partials, c.st, gate, (int)c.count_repl);
@@ -938,6 +998,7 @@ void launch_kkt2_cg(const LaunchCtx& c, const CgIter& it, double2* Ap) {
     dim3 grid(c.S.nwg), block(SPMV_THREADS);
     if (c.S.ndef > 0) {
         if (fused) hipLaunchKernelGGL((kkt2_kernel<true, true, true>), grid, block, 0, c.stream, c.S, a);
+        else if (c.S.tile_deep) hipLaunchKernelGGL((kkt2_kernel<true, false, true, true>), grid, block, 0, c.stream, c.S, a);
         else hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
     } else {
         if (fused) hipLaunchKernelGGL((kkt2_kernel<false, true, false>), grid, block, 0, c.stream, c.S, a);
@@ -950,13 +1011,29 @@ void launch_cgm_sweep(const LaunchCtx& c, const CgmIter& it, int closes) {
     KktArgs a = plain_args(c, it.r, it.w, 1);
     a.vt_out = c.st->vtau;
     a.seq_base = it.seq_base;
-    if (closes > 0) {
+    if (closes >= 0) {
         a.close_j = closes; a.batch_mark = it.batch_mark;
         a.rr_partials = c.partials + 3 * (size_t)PART_CAP + (size_t)(closes & 1) * CGM_RR_STRIDE; a.rr_count = c.cg_blocks;
     }
     if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
     dim3 grid(c.S.nwg), block(SPMV_THREADS);
-    if (c.S.ndef > 0) hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
+    if (c.S.ndef > 0) {
+        if (c.S.tile_deep) hipLaunchKernelGGL((kkt2_kernel<true, false, true, true>), grid, block, 0, c.stream, c.S, a);
+        else hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
+    }
+    else hipLaunchKernelGGL((kkt2_kernel<false, false, false>), grid, block, 0, c.stream, c.S, a);
+}
+// merged-reduction CG, start of a solve: it.w = M v, every row but tau, slot-spread rows left in their slots (the start kernel
+// finishes them); the sums of the tau row at record 0 (FOLD form: complete without the deferred-row kernel); NOT gated
+void launch_cgm_apply(const LaunchCtx& c, const CgmIter& it, const double2* v) {
+    KktArgs a = plain_args(c, v, it.w, 0);
+    a.vt_out = c.st->vtau;
+    if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
+    dim3 grid(c.S.nwg), block(SPMV_THREADS);
+    if (c.S.ndef > 0) {
+        if (c.S.tile_deep) hipLaunchKernelGGL((kkt2_kernel<true, false, true, true>), grid, block, 0, c.stream, c.S, a);
+        else hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
+    }
     else hipLaunchKernelGGL((kkt2_kernel<false, false, false>), grid, block, 0, c.stream, c.S, a);
 }
 void launch_cg_stop_check(const LaunchCtx& c, const CgIter& it) {
@@ -1055,7 +1132,7 @@ __global__ __launch_bounds__(SPMV_THREADS) void q1_kernel(DevBlkCsr S, const dou
     for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
     epi.init(vcomp[2 * (int64_t)nm]);      // the tau entry of the gathered component
     Gather1 gat{vcomp};
-    spmv_walk<DEFER>(S, gat, epi, prod);
+    spmv_walk<DEFER, false>(S, gat, epi, prod, wave_work(S));
     block_reduce_store<NACC, SPMV_THREADS>(epi.acc, red, partials + NACC * (int64_t)blockIdx.x);
 }
 template <class Epi, int NACC>

@@ -180,6 +180,9 @@ struct fos_solver {
     bool firstrun2 = true;                     // HSDEMatrix.cgdata.firstrun
     int last_cg_pred = 0;
     // LineSearchWrapper (wrappers/linesearch.jl): every ls_interval-th iteration is a 31-point step-length search
+    bool shift_ready = false;                  // RHS already holds SOL - [0; X.y] (written by the step's last kernel): inside fos_step only
+    bool shift_fuse = true;                    // FOS_SHIFT_FUSE=0: every projection runs its own shift pass
+    bool in_step = false;
     int64_t ls_interval = 0;
     bool ls_now = false;                       // the iteration in flight is a line-search iteration (between step_once and step_finish)
     double ls_log[34] = {0};                   // last search: ||res||, the 31 test residuals, the chosen alpha, the iteration
@@ -408,11 +411,6 @@ typedef std::function<int(const LaunchCtx&)> PostFn;
 int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t* iters, const d2* apply_on = nullptr,
              const PostFn* post = nullptr, bool* post_ran = nullptr) {
     LaunchCtx c = h->ctx();
-    int fr = 0;
-    FOS_TRY(kkt_apply_full(h, c, apply_on ? apply_on : x, h->AP));    // :32  mul!(Ap, A, x)
-    launch_cg_init(c, rhs, h->AP, h->R, h->PB[1]);                     // :33-34   (p_1 in buffer 1)
-    FOS_TRY(finish_reduce(h, c, c.vec_blocks, 1, 0, &fr));
-    launch_cg_init_finalize(c, h->R, tol, maxit, fr);                  // :35-36
     int next_j = 1;                          // iteration number of the next enqueued launch group (if CG still runs)
     static const bool fold_env = !(getenv("FOS_PEER_FOLD") && atoi(getenv("FOS_PEER_FOLD")) == 0);
     const bool fold = h->peer_on && fold_env;
@@ -452,19 +450,30 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
         if (c.between) FOS_TRY(c.between(c.between_arg));         // row-sharded: A'y partial sums over the ranks (n-vector)
         if (!rccl) return FOS_OK;
         launch_reduce1(c, c.S.nwg, 3, 1, 0);
-        if (j >= 2) {
-            LaunchCtx c2 = c;
-            c2.partials = c.partials + 3 * (size_t)PART_CAP + (size_t)((j - 1) & 1) * CGM_RR_STRIDE;
-            c2.reduced = c.reduced + 3;
-            launch_reduce1(c2, c.cg_blocks, 1, 1);
-        }
+        LaunchCtx c2 = c;
+        c2.partials = c.partials + 3 * (size_t)PART_CAP + (size_t)((j - 1) & 1) * CGM_RR_STRIDE;
+        c2.reduced = c.reduced + 3;
+        launch_reduce1(c2, c.cg_blocks, 1, 1);
         return allreduce(h, 4);
     };
-    if (merged) {                            // w_0 = M r_0 (+ its sums): the sweep every iteration's update starts from
+    if (merged) {
+        // start: sweep M v, ONE launch for r = rhs - M v (+ r.r records, tau row, slot-spread rows, the solve's scalars), then
+        // w_0 = M r_0, the sweep every iteration's update starts from (it also adds g_0 = r_0.r_0 unless the first update does)
         CgmIter it0 = merged_desc(0);
+        const d2* v = apply_on ? apply_on : x;
+        launch_cgm_apply(c, it0, v);                                       // :32  mul!(Ap, A, x)
+        if (c.between) FOS_TRY(c.between(c.between_arg));
+        if (rccl) { launch_reduce1(c, c.S.nwg, 3, 0, 0); FOS_TRY(allreduce(h, 3)); }
+        launch_cgm_start(c, it0, rhs, v, tol, maxit);                      // :33-36
         const int pe = prof_begin(h, FOS_PROF_KKT, 0, h->cg_total);
-        launch_cgm_sweep(c, it0, 0);
+        launch_cgm_sweep(c, it0, close_in_update ? -1 : 0);
         prof_end(h, pe);
+    } else {
+        int fr = 0;
+        FOS_TRY(kkt_apply_full(h, c, apply_on ? apply_on : x, h->AP));    // :32  mul!(Ap, A, x)
+        launch_cg_init(c, rhs, h->AP, h->R, h->PB[1]);                     // :33-34   (p_1 in buffer 1)
+        FOS_TRY(finish_reduce(h, c, c.vec_blocks, 1, 0, &fr));
+        launch_cg_init_finalize(c, h->R, tol, maxit, fr);                  // :35-36
     }
     auto enqueue = [&](int count) -> int {
         if (merged) {
@@ -481,7 +490,7 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
                 // (closing in the sweep: the sweep behind the LAST update returns in its prologue -- recorded as iteration j+1, which
                 //  the profile drops)
                 pe = prof_begin(h, FOS_PROF_KKT, next_j + (close_in_update ? 0 : 1), h->cg_total + next_j);
-                launch_cgm_sweep(c, it, close_in_update ? 0 : next_j);
+                launch_cgm_sweep(c, it, close_in_update ? -1 : next_j);
                 prof_end(h, pe);
             }
             if (close_in_update) {           // the last enqueued iteration is closed by a one-workgroup launch of the update kernel
@@ -591,7 +600,8 @@ int prox_affine(fos_solver* h, const d2* x, const PostFn* post = nullptr, bool* 
         FOS_HIP(hipMemcpyAsync(h->SOL, x, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));
         h->firstrun = false;
     }
-    if (fused_rhs) launch_shift_part2(c, h->RHS, h->SOL, x);           // RHS buffer := y - [0; x2]
+    if (fused_rhs && !(h->shift_ready && x == h->X)) launch_shift_part2(c, h->RHS, h->SOL, x);           // RHS buffer := y - [0; x2]
+    h->shift_ready = false;                                             // (SOL changes below)
     // :108-112   tol = max(0.2^sqrt(i), size(A,2)*eps())
     const double eps = 2.220446049250313e-16;
     double tol = std::max(std::pow(0.2, std::sqrt((double)h->prox_i)), (double)h->l_global * eps);
@@ -779,11 +789,17 @@ int step_finish(fos_solver* h, int64_t i) {
 }
 int step_finish_launch(fos_solver* h, const LaunchCtx& c) {
     switch (h->alg) {
-        case FOS_ALG_GAP:
-            launch_gap_final(c, h->X, h->T2, h->T1, h->alpha, h->alpha2);          // gap.jl:58,78
+        case FOS_ALG_GAP: {
+            // (inside fos_step, CG projection: the kernel also leaves SOL - [0; X.y] in RHS for the next iteration's CG start)
+            const bool sh = h->in_step && h->shift_fuse && !h->direct;
+            launch_gap_final(c, h->X, h->T2, h->T1, h->alpha, h->alpha2, sh ? h->RHS : nullptr, h->SOL);          // gap.jl:58,78
+            h->shift_ready = sh;
             return FOS_OK;
+        }
         case FOS_ALG_GAPA: {
-            launch_gapa_final(c, h->X, h->T2, h->T1, h->alpha);                    // gapa.jl:77,96,103
+            const bool sh = h->in_step && h->shift_fuse && !h->direct;
+            launch_gapa_final(c, h->X, h->T2, h->T1, h->alpha, sh ? h->RHS : nullptr, h->SOL);                    // gapa.jl:77,96,103
+            h->shift_ready = sh;
             int fr = 0;
             FOS_TRY(finish_reduce(h, c, c.vec_blocks, 3, 0, &fr));
             launch_gapa_finalize(c, h->beta, fr);                                  // gapa.jl:96-101
@@ -936,6 +952,7 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     FOS_HIP(hipHostMalloc((void**)&h->mark, sizeof(HostMark), hipHostMallocMapped));
     memset(h->mark, 0, sizeof(HostMark));
     h->speculate = !(getenv("FOS_SPECULATE") && atoi(getenv("FOS_SPECULATE")) == 0);
+    h->shift_fuse = !(getenv("FOS_SHIFT_FUSE") && atoi(getenv("FOS_SHIFT_FUSE")) == 0);
 
     hipDeviceProp_t prop;
     FOS_HIP(hipGetDeviceProperties(&prop, device));
@@ -979,6 +996,12 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
         std::copy(hs.wave_blk0.begin(), hs.wave_blk0.end(), wv.begin());
         FOS_TRY(dev_upload(h, &dwv, wv));
     }
+    BlkDesc* dwf = nullptr;
+    {
+        std::vector<BlkDesc> wf(std::max<size_t>(hs.wave_first.size(), (size_t)SPMV_WAVES * 16384 + 16), BlkDesc{});
+        std::copy(hs.wave_first.begin(), hs.wave_first.end(), wf.begin());
+        FOS_TRY(dev_upload(h, &dwf, wf));
+    }
     if (windowed) {
         // window panels: persistent workgroups, one per CU (96 KB of LDS each), walking the panels (measured on C5: 116 us per
         // sweep with 256 workgroups, 122 us with one workgroup per panel)
@@ -1006,7 +1029,11 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     }
     h->S.nrows = hs.nrows; h->S.nnz = hs.nnz; h->S.nnz_padded = hs.nnz_padded;
     h->S.val = dval; h->S.col = dcol; h->S.blk = dblk;
-    h->S.row_rel = drr; h->S.wave_blk0 = dwv; h->S.nblk = hs.nblk; h->S.nwg = hs.nwg; h->S.nwaves = hs.nwaves;
+    h->S.row_rel = drr; h->S.wave_blk0 = dwv; h->S.wave_first = dwf; h->S.nblk = hs.nblk; h->S.nwg = hs.nwg; h->S.nwaves = hs.nwaves;
+    // small tile operators (a shard of a multi-GPU run): at most a few tiles per SIMD, none longer than TILE_DEEP_T steps -- the
+    // sweep requests whole tiles at once (kkt2_kernel<.., DEEP>); FOS_TILE_DEEP=0/1 forces
+    h->S.tile_deep = (hs.ntiles > 0 && hs.tile_tmax <= TILE_DEEP_T && hs.ntiles <= (int64_t)16 * cus) ? 1 : 0;
+    if (const char* e = getenv("FOS_TILE_DEEP")) h->S.tile_deep = (atoi(e) != 0 && hs.ntiles > 0 && hs.tile_tmax <= TILE_DEEP_T) ? 1 : 0;
     // dual tiles: partial-sum slots and the deferred rows' slot lists
     h->S.slots = nullptr; h->S.slots_rd = nullptr; h->S.row_defer = nullptr; h->S.def_rows = nullptr; h->S.def_ptr = nullptr; h->S.def_idx = nullptr;
     h->S.ndef = (int32_t)hs.def_rows.size();
@@ -1205,7 +1232,7 @@ int fos_peer_export(fos_handle h, void* handle64) {
     FOS_HIP(hipSetDevice(h->device));
     if (!h->peer_mbox) {
         void* q = nullptr;
-        const size_t bytes = 2 * PEER_BOX_WORDS * sizeof(unsigned long long);      // region 0 + region 1
+        const size_t bytes = PEER_BOX_TOTAL_WORDS * sizeof(unsigned long long);    // region 0 + region 1 (four slots)
         hipError_t e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached);
         if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained); }
         if (e != hipSuccess) { set_error("hipExtMallocWithFlags(mailbox): %s", hipGetErrorString(e)); return FOS_ENOMEM; }
@@ -1464,6 +1491,9 @@ int fos_step(fos_handle h, int64_t i_first, int64_t count, int64_t checki, doubl
     FOS_HIP(hipSetDevice(h->device));
     if (checked) *checked = 0;
     int64_t done = 0;
+    h->shift_ready = false;
+    struct InStep { fos_solver* h; ~InStep() { h->in_step = false; h->shift_ready = false; } } in_step{h};
+    h->in_step = true;
     for (int64_t i = i_first; done < count; ++i) {
         const d2* check_on = nullptr;
         const bool do_check = (i % checki) == 0;                         // HSDEStatus.jl:28
@@ -1791,11 +1821,13 @@ int fos_bench_cg_chain(fos_handle h, int32_t iters, int32_t reps, int32_t use_gr
             it.x = h->W; it.r = h->R; it.p = h->PB[0]; it.s = h->PB[1]; it.w = h->AP;
             it.close_in_update = variant == FOS_CG_MERGED_UPDATE; it.from_reduced = 0; it.fold = nullptr; it.seq_base = seq_base;
             it.j = 0;
-            launch_cgm_sweep(c, it, 0);
+            launch_cgm_apply(c, it, h->W);
+            launch_cgm_start(c, it, h->RHS, h->W, -1.0, INT32_MAX);
+            launch_cgm_sweep(c, it, it.close_in_update ? -1 : 0);
             for (int j = 1; j <= iters; ++j) {
                 it.j = j;
                 launch_cgm_update(c, it, false);
-                launch_cgm_sweep(c, it, it.close_in_update ? 0 : j);
+                launch_cgm_sweep(c, it, it.close_in_update ? -1 : j);
             }
             return;
         }
@@ -1902,6 +1934,8 @@ int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int3
         partition_workgroups(&h->hostS, spmv_workgroups);
         FOS_HIP(hipMemcpy(const_cast<int32_t*>(h->S.wave_blk0), h->hostS.wave_blk0.data(),
                           h->hostS.wave_blk0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        FOS_HIP(hipMemcpy(const_cast<BlkDesc*>(h->S.wave_first), h->hostS.wave_first.data(),
+                          h->hostS.wave_first.size() * sizeof(BlkDesc), hipMemcpyHostToDevice));
         h->S.nwg = h->hostS.nwg;
         h->S.npart = h->S.nwg_def > 0 ? h->S.nwg_def : h->S.nwg;
         h->S.part_off = h->S.nwg_def > 0 ? h->S.nwg : 0;

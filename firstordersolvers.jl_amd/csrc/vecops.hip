@@ -163,11 +163,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
             if (own) { pi = p[row]; ri = r[row]; c = cb[row]; if constexpr (XUPD) xi = x[row]; }
             double u1 = 0.0, u2 = 0.0;
             if (ok) {
-                const int k1 = S.def_ptr[q + 1];
-                for (int k = S.def_ptr[q] + lig; k < k1; k += lpr) {
-                    const d2 s = slots[S.def_idx[k]];
-                    u1 += s.x; u2 += s.y;
-                }
+                slot_list_sum(slots, S.def_idx, S.def_ptr[q] + lig, S.def_ptr[q + 1], lpr, u1, u2);
             }
             u1 = group_sum(u1, lpr);
             u2 = group_sum(u2, lpr);
@@ -322,7 +318,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
     if (have0) { w0 = a.w[i0]; r0 = a.r[i0]; x0 = a.x[i0]; if (!first) { p0 = a.p[i0]; s0 = a.s[i0]; } }      // requested before the scalar prologue
     // the scalars this launch needs (stored by EARLIER launches: nothing below races them) and the r.r records are requested
     // together with the gate -- the prologue is a latency chain every CG iteration pays
-    const bool closing = a.close_here && !first;
+    const bool closing = a.close_here != 0;      // (i = 0: g_0 from the start kernel's records, no stop test -- at least one iteration runs)
     const int done = st->done, xfail = st->xchg_failed, maxit = st->maxit;
     const double vtx = st->vtau[0], vty = st->vtau[1];           // tau element of r_i (stashed by the sweep that applied M to it)
     const double g_cur = st->rn2[i & 1], g_prev = st->rn2[(i + 1) & 1], a_prev = st->alpha2[(i + 1) & 1], tol = st->tol;
@@ -341,7 +337,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
     const double S1 = sums[0], T1 = sums[1], T2 = sums[2];
     const double gam = closing ? sums[3] + (vtx * vtx + vty * vty) : g_cur;
     const bool w0blk = blockIdx.x == 0 && threadIdx.x == 0;
-    if (closing) {
+    if (closing && !first) {
         if (sqrt(gam) <= tol || i >= maxit) {                      // conjugategradients.jl:42 for iteration i
             if (w0blk) { st->rr = gam; cg_signal_stop(st, i, maxit, gam, a.seq_base >> 11); }
             return;
@@ -394,11 +390,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
             if (own) { ri = a.r[row]; xi = a.x[row]; c = a.cb[row]; if (!first) { pi = a.p[row]; si = a.s[row]; } }
             double u1 = 0.0, u2 = 0.0;
             if (ok) {
-                const int k1 = S.def_ptr[q + 1];
-                for (int k = S.def_ptr[q] + lig; k < k1; k += lpr) {
-                    const d2 sl = slots[S.def_idx[k]];
-                    u1 += sl.x; u2 += sl.y;
-                }
+                slot_list_sum(slots, S.def_idx, S.def_ptr[q] + lig, S.def_ptr[q + 1], lpr, u1, u2);
             }
             u1 = group_sum(u1, lpr);
             u2 = group_sum(u2, lpr);
@@ -427,6 +419,109 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
         if (k != l - 1) acc[0] += rr;
     }
     block_reduce_store<1>(acc, a.rr_out + blockIdx.x);
+}
+// Start of a merged-reduction solve (conjugategradients.jl:32-36 in one launch behind the sweep w = M v): finishes w -- the tau
+// row from the sweep's sums, the slot-spread rows from their slot lists -- and forms r = rhs - w with the r.r records of
+// "iteration 0" (added by whoever closes it: the next sweep, or the first update when sharded).  Its first workgroup opens the
+// solve in DevState.  Not gated: `done` still holds the previous solve's 1.
+struct CgmStartArgs {
+    int64_t l;
+    const d2 *rhs, *v, *w;
+    d2* r;
+    DevState* st;
+    const double* kkt_partials; int nkkt;
+    const double* reduced; int from_reduced;
+    double* rr_out;
+    const double* cb; int n;
+    const uint32_t* def_mask;
+    PeerBox pb; uint32_t seq_base; int count_repl;
+    double tol; int maxit;
+};
+template <bool DEF, bool FOLD>
+__global__ __launch_bounds__(VEC_THREADS) void cgm_start_kernel(CgmStartArgs a, DevBlkCsr S) {
+    const int64_t l = a.l;
+    const int64_t stride = (int64_t)gridDim.x * VEC_THREADS;
+    const int64_t i0 = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x;
+    DevState* st = a.st;
+    bool have0 = i0 < l;
+    if constexpr (DEF) { if (have0 && ((a.def_mask[i0 >> 5] >> (i0 & 31)) & 1u)) have0 = false; }
+    d2 w0 = make_double2(0.0, 0.0), b0 = w0;
+    if (have0) { w0 = a.w[i0]; b0 = a.rhs[i0]; }
+    const double vtx = st->vtau[0], vty = st->vtau[1];           // tau element of v (stashed by the sweep)
+    if (FOLD && st->xchg_failed) return;
+    __shared__ double sums[3];
+    sweep_sums3(sums, a.kkt_partials, a.nkkt, a.reduced, a.from_reduced, nullptr, 0u, st);
+    if constexpr (FOLD) {
+        if (!peer_fold_sum<3>(a.pb, a.seq_base, sums, st)) return;
+    }
+    const double T1 = sums[1], T2 = sums[2];
+    const double wt1 = vtx + T2, wt2 = -T1 - vty;                // HSDEAffine.jl:57
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->iter = 1; st->hit_max = 0; st->tol = a.tol; st->maxit = a.maxit; st->rn_old = 0.0;       // conjugategradients.jl:36
+        st->done = 0;
+    }
+    double acc[1] = {0.0};
+    if constexpr (DEF) {
+        const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots_rd);
+        const int lpr = S.def_lpr, sh = 31 - __clz(lpr);
+        const int rows_per_pass = (gridDim.x * VEC_THREADS) >> sh;
+        const int lig = threadIdx.x & (lpr - 1);
+        const int npass = (S.ndef + rows_per_pass - 1) / rows_per_pass;
+        int q = (blockIdx.x * VEC_THREADS + threadIdx.x) >> sh;
+        for (int pass = 0; pass < npass; ++pass, q += rows_per_pass) {
+            const bool ok = q < S.ndef;
+            const int row = ok ? S.def_rows[q] : 0;
+            const bool own = ok && lig == 0;
+            d2 vi = make_double2(0.0, 0.0), bi = vi;
+            double c = 0.0;
+            if (own) { vi = a.v[row]; bi = a.rhs[row]; c = a.cb[row]; }
+            double u1 = 0.0, u2 = 0.0;
+            if (ok) slot_list_sum(slots, S.def_idx, S.def_ptr[q] + lig, S.def_ptr[q + 1], lpr, u1, u2);
+            u1 = group_sum(u1, lpr);
+            u2 = group_sum(u2, lpr);
+            if (own) {
+                double q1, q2;                                  // EpiKkt::row (kernels.hip)
+                if (row < a.n) { q1 = u1 + vtx * c; q2 = u2 + vty * c; }
+                else { q1 = -(u1 - vtx * c); q2 = -(u2 - vty * c); }
+                const d2 ri = make_double2(bi.x - (vi.x - q2), bi.y - (q1 - vi.y));       // r = b - Ap      :33
+                a.r[row] = ri;
+                if (a.count_repl) acc[0] += ri.x * ri.x + ri.y * ri.y;
+            }
+        }
+    }
+    if (have0) {
+        if (i0 == l - 1) w0 = make_double2(wt1, wt2);
+        const d2 ri = make_double2(b0.x - w0.x, b0.y - w0.y);
+        a.r[i0] = ri;
+        if (i0 != l - 1) acc[0] += ri.x * ri.x + ri.y * ri.y;
+    }
+    for (int64_t k = i0 + stride; k < l; k += stride) {
+        if constexpr (DEF) { if ((a.def_mask[k >> 5] >> (k & 31)) & 1u) continue; }
+        const d2 wi = (k == l - 1) ? make_double2(wt1, wt2) : a.w[k];
+        const d2 bi = a.rhs[k];
+        const d2 ri = make_double2(bi.x - wi.x, bi.y - wi.y);
+        a.r[k] = ri;
+        if (k != l - 1) acc[0] += ri.x * ri.x + ri.y * ri.y;
+    }
+    block_reduce_store<1>(acc, a.rr_out + blockIdx.x);
+}
+void launch_cgm_start(const LaunchCtx& c, const CgmIter& it, const double2* rhs, const double2* v, double tol, int maxit) {
+    CgmStartArgs a{};
+    a.l = c.l; a.rhs = rhs; a.v = v; a.w = it.w; a.r = it.r; a.st = c.st;
+    a.kkt_partials = c.partials; a.nkkt = c.S.nwg;
+    a.reduced = c.reduced; a.from_reduced = it.fold ? 0 : it.from_reduced;
+    a.rr_out = c.partials + 3 * (size_t)PART_CAP;                 // records of "iteration 0"
+    a.cb = c.cb; a.n = (int)c.n; a.def_mask = c.def_mask;
+    a.pb = it.fold ? *it.fold : PeerBox{}; a.seq_base = it.seq_base; a.count_repl = (int)c.count_repl;
+    a.tol = tol; a.maxit = maxit;
+    dim3 grid(c.cg_blocks), block(VEC_THREADS);
+    if (c.S.ndef > 0) {
+        if (it.fold) hipLaunchKernelGGL((cgm_start_kernel<true, true>), grid, block, 0, c.stream, a, c.S);
+        else hipLaunchKernelGGL((cgm_start_kernel<true, false>), grid, block, 0, c.stream, a, c.S);
+    } else {
+        if (it.fold) hipLaunchKernelGGL((cgm_start_kernel<false, true>), grid, block, 0, c.stream, a, c.S);
+        else hipLaunchKernelGGL((cgm_start_kernel<false, false>), grid, block, 0, c.stream, a, c.S);
+    }
 }
 void launch_cgm_update(const LaunchCtx& c, const CgmIter& it, bool close_only) {
     CgmArgs a{};
@@ -485,8 +580,11 @@ __global__ __launch_bounds__(VEC_THREADS) void relax_a12_kernel(int64_t l, d2* _
     }
 }
 // tmp2 = a2 tmp2 + (1-a2) tmp1 ; x = a tmp2 + (1-a) x           gap.jl:58,78
+// shift_out (optional): also the vector the NEXT affine projection's CG start applies M to, sol - [0; x2_new] (shift_part2_kernel),
+// so that projection needs no pass of its own for it
 __global__ __launch_bounds__(VEC_THREADS) void gap_final_kernel(int64_t l, d2* __restrict__ x, const d2* __restrict__ t2,
-                                                                const d2* __restrict__ t1, double alpha, double alpha2, const int32_t* __restrict__ gate) {
+                                                                const d2* __restrict__ t1, double alpha, double alpha2, const int32_t* __restrict__ gate,
+                                                                d2* __restrict__ shift_out, const d2* __restrict__ sol) {
     if (gate && !*gate) return;                  // speculatively enqueued behind a CG batch that did not converge: no-op
     const double b2 = 1 - alpha2, b = 1 - alpha;
     GRID_STRIDE(i, l) {
@@ -496,13 +594,15 @@ __global__ __launch_bounds__(VEC_THREADS) void gap_final_kernel(int64_t l, d2* _
         xi.x = alpha * rx + b * xi.x;
         xi.y = alpha * ry + b * xi.y;
         x[i] = xi;
+        if (shift_out) { const d2 y = sol[i]; shift_out[i] = make_double2(y.x, y.y - xi.y); }
     }
 }
 // GAPA: same with a12 from the state, plus the three sums of normedScalar(tmp2,tmp1,tmp1,x)   gapa.jl:36-47,77,96,103
 // tau-row contributions go to reduced[8..10] (replicated across shards, added after the all-reduce).
 __global__ __launch_bounds__(VEC_THREADS) void gapa_final_kernel(int64_t l, d2* __restrict__ x, const d2* __restrict__ t2,
                                                                  const d2* __restrict__ t1, double alpha, const DevState* st,
-                                                                 double* __restrict__ partials, double* __restrict__ reduced, int64_t acc_from, const int32_t* __restrict__ gate) {
+                                                                 double* __restrict__ partials, double* __restrict__ reduced, int64_t acc_from, const int32_t* __restrict__ gate,
+                                                                 d2* __restrict__ shift_out, const d2* __restrict__ sol) {
     if (gate && !*gate) return;                  // speculatively enqueued behind a CG batch that did not converge: no-op
     const double a12 = st->alpha12, b12 = 1 - a12, b = 1 - alpha;
     double acc[3] = {0.0, 0.0, 0.0};
@@ -518,6 +618,7 @@ __global__ __launch_bounds__(VEC_THREADS) void gapa_final_kernel(int64_t l, d2* 
         xi.x = alpha * rx + b * xi.x;
         xi.y = alpha * ry + b * xi.y;
         x[i] = xi;
+        if (shift_out) { const d2 y = sol[i]; shift_out[i] = make_double2(y.x, y.y - xi.y); }
     }
     block_reduce_store<3>(acc, partials + 3 * (int64_t)blockIdx.x);
 }
@@ -590,12 +691,12 @@ void launch_axpby(const LaunchCtx& c, double2* out, double a, const double2* x, 
 void launch_relax_a12(const LaunchCtx& c, double2* out, const double2* y, const double2* x) {
     hipLaunchKernelGGL(relax_a12_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, y, x, c.st, c.gate);
 }
-void launch_gap_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha, double alpha2) {
-    hipLaunchKernelGGL(gap_final_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, t2, t1, alpha, alpha2, c.gate);
+void launch_gap_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha, double alpha2, double2* shift_out, const double2* sol) {
+    hipLaunchKernelGGL(gap_final_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, t2, t1, alpha, alpha2, c.gate, shift_out, sol);
 }
-void launch_gapa_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha) {
+void launch_gapa_final(const LaunchCtx& c, double2* x, const double2* t2, const double2* t1, double alpha, double2* shift_out, const double2* sol) {
     hipLaunchKernelGGL(gapa_final_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, t2, t1, alpha, c.st, c.partials, c.reduced,
-                       c.count_repl ? (int64_t)0 : c.n_repl, c.gate);
+                       c.count_repl ? (int64_t)0 : c.n_repl, c.gate, shift_out, sol);
 }
 void launch_gapa_finalize(const LaunchCtx& c, double beta, int from_reduced) {
     hipLaunchKernelGGL(gapa_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.vec_blocks, c.reduced, from_reduced, beta, c.st, c.gate);
