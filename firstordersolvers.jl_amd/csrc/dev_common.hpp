@@ -32,33 +32,53 @@ __device__ __forceinline__ double group_sum(double v, int tpr) {
     return v;
 }
 
-// sums partials[count][NACC] -> sums[NACC] (shared) in a fixed order; any block size that is a multiple of 64, <= 1024
-template <int NACC>
-__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int count, double* sums) {
-    __shared__ double smem[16 * NACC];
-    double acc[NACC];
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
-    // (chunks of U records per thread with all loads of a chunk issued before the first add: one memory round trip for up to
-    //  U x blockDim records instead of one per record -- these sums sit on the latency chain of every CG iteration; same
-    //  summation order as the plain strided loop)
-    constexpr int U = NACC <= 3 ? 8 : 4;
-    for (int base = threadIdx.x; base < count; base += U * blockDim.x) {
-        double v[U][NACC];
+// sums partials[count][NACC] -> sums[NACC] (shared) in a fixed order; any block size that is a multiple of 64, <= 1024.
+// Three pieces, so that a kernel on a latency chain can request the records early and add them late:
+//   PartialRegs::load   all loads of a thread's first U records (one memory round trip for up to U x blockDim records instead of
+//                       one per record), no use of the values yet;
+//   PartialRegs::sum    the thread's sum in record order (records beyond U x blockDim by a plain loop) -- the same summation
+//                       order as a strided loop over all records;
+//   partials_combine    wavefront butterflies + one LDS pass.
+template <int NACC, int U = (NACC <= 3 ? 8 : 4)>
+struct PartialRegs {
+    double v[U][NACC];
+    __device__ __forceinline__ void load(const double* __restrict__ partials, int count) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = base + u * blockDim.x;
+            const int i = threadIdx.x + u * blockDim.x;
 #pragma unroll
             for (int a = 0; a < NACC; ++a) v[u][a] = (i < count) ? partials[(int64_t)i * NACC + a] : 0.0;
         }
+    }
+    __device__ __forceinline__ void sum(const double* __restrict__ partials, int count, double (&acc)[NACC]) const {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (base + u * (int)blockDim.x < count) {
+            if ((int)(threadIdx.x + u * blockDim.x) < count) {
 #pragma unroll
                 for (int a = 0; a < NACC; ++a) acc[a] += v[u][a];
             }
         }
+        for (int i = threadIdx.x + U * blockDim.x; i < count; i += blockDim.x) {
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) acc[a] += partials[(int64_t)i * NACC + a];
+        }
     }
+};
+template <int NACC>
+__device__ __forceinline__ void partials_combine(const double (&acc)[NACC], double* sums);
+template <int NACC>
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int count, double* sums) {
+    PartialRegs<NACC> regs;
+    regs.load(partials, count);
+    double acc[NACC];
+    regs.sum(partials, count, acc);
+    partials_combine<NACC>(acc, sums);
+}
+template <int NACC>
+__device__ __forceinline__ void partials_combine(const double (&acc)[NACC], double* sums) {
+    __shared__ double smem[16 * NACC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
     for (int a = 0; a < NACC; ++a) {

@@ -63,7 +63,6 @@ constexpr int TILE_MIN_ROWS = 16;   // fewer rows: not worth a 64-lane wavefront
 constexpr int TILE_MIN_COLS = 8;
 constexpr int TILE_TC_MAX = 64;     // columns (steps) per tile: 32 KB of values per wavefront work unit (measured best on C2: 32..128 tried)
 constexpr int TILE_GROUP = 8;       // steps per butterfly; stored steps are padded to a multiple
-constexpr int TILE_DEEP_T = 32;     // deep variant: tiles of at most this many steps, all values requested up front
 
 // Window panels (gather-bound random-sparse operators, C5 class).  A PANEL = WIN_ROWS consecutive rows of S, the unit of
 // work of ONE WORKGROUP (two of them share a CU), which walks the column WINDOWS (WIN_COLS consecutive entries of the stacked vector) its rows touch:
@@ -135,8 +134,6 @@ struct DevBlkCsr {
     const int32_t* wave_blk0;
     const BlkDesc* wave_first;         // [nwaves] copy of each wavefront's first descriptor (requested together with wave_blk0)
     int32_t nblk, nwg, nwaves;
-    int32_t tile_deep;                 // 1: every dual tile has <= TILE_DEEP_T steps and the operator is small -- the sweep
-                                       // requests a whole tile at once (kkt2_kernel<.., DEEP>): latency, not occupancy, bounds it
     // dual tiles / deferred rows (ndef == 0: none)
     double* slots;                     // [nslots][2]   written by the sweeps
     const double* slots_rd;            // what the slot-list sums read: == slots, or -- row-sharded operators -- the all-reduced copy

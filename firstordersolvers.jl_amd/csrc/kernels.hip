@@ -311,7 +311,7 @@ __device__ __forceinline__ WaveWork wave_work(const DevBlkCsr& S) {
     return w;
 }
 
-template <bool DEFER, bool DEEP, class G, class Epi>
+template <bool DEFER, class G, class Epi>
 __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi& epi, double* prod_all, const WaveWork& ww) {
     constexpr int NRHS = G::NRHS;
     const int lane = threadIdx.x & 63;
@@ -362,43 +362,7 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
                 const double* __restrict__ val = S.val + d.nnz0 + lane;
                 d2* __restrict__ slots = reinterpret_cast<d2*>(S.slots);
                 double r1 = 0.0, r2 = 0.0;
-                if constexpr (DEEP && !G::FUSED && NRHS == 2) {
-                    // small operators (a shard of a multi-GPU run): the WHOLE tile (<= TILE_DEEP_T steps) is requested at once --
-                    // with one or two tiles per SIMD the sweep is a chain of memory latencies, not a stream
-                    constexpr int NG = TILE_DEEP_T / TILE_GROUP;
-                    double v[NG][TILE_GROUP];
-                    d2 xl[NG];
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        xl[g] = make_double2(0.0, 0.0);
-                        if (g * TILE_GROUP < T) {
-                            if constexpr (Epi::FOLDDEF) { if (lane < TILE_GROUP && g * TILE_GROUP + lane < tc) xl[g] = gat.load(c0 + g * TILE_GROUP + lane); }
-#pragma unroll
-                            for (int u = 0; u < TILE_GROUP; ++u) v[g][u] = nt_load(val + 64 * (g * TILE_GROUP + u));
-                        }
-                    }
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        if (g * TILE_GROUP < T) {
-                            const int t = g * TILE_GROUP;
-                            d2 x[TILE_GROUP];
-                            double p1[TILE_GROUP], p2[TILE_GROUP];
-#pragma unroll
-                            for (int u = 0; u < TILE_GROUP; ++u) x[u] = (t + u < tc) ? gat.load_u(c0 + t + u) : make_double2(0.0, 0.0);
-#pragma unroll
-                            for (int u = 0; u < TILE_GROUP; ++u) {
-                                r1 += v[g][u] * x[u].x; p1[u] = v[g][u] * wr.x;
-                                r2 += v[g][u] * x[u].y; p2[u] = v[g][u] * wr.y;
-                            }
-                            const double s1 = tile_colsum8(p1, lane);
-                            const double s2 = tile_colsum8(p2, lane);
-                            if (lane < TILE_GROUP) {
-                                slots[cslot + t + lane] = make_double2(s1, s2);
-                                epi.park(c0 + t + lane, s1, s2, xl[g]);
-                            }
-                        }
-                    }
-                } else {
+                {
                 double vn[TILE_GROUP];                 // the next group's values are in flight while this group is reduced
                 // the element of this lane's column slot (lanes 0..7), for epi.park: fetched one group AHEAD and BEFORE that
                 // group's values -- vmcnt retires in order, so a load issued behind the value prefetch could only be waited
@@ -757,7 +721,7 @@ struct KktArgs {
     int32_t batch_mark;
 };
 
-template <bool DEFER, bool FUSEP, bool FOLD, bool DEEP = false>
+template <bool DEFER, bool FUSEP, bool FOLD>
 __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBlkCsr S, KktArgs a) {
     static_assert(!FOLD || DEFER, "FOLD is about deferred rows");
     WaveWork ww;                             // requested before the gate / the closing prologue: their round trip covers it
@@ -791,7 +755,7 @@ __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBl
             for (int q = blockIdx.x * SPMV_THREADS + threadIdx.x; q < S.ndef; q += gridDim.x * SPMV_THREADS) { const int i = S.def_rows[q]; a.pnew[i] = gat.load(i); }
         }
     }
-    spmv_walk<DEFER, DEEP>(S, gat, epi, prod, ww);
+    spmv_walk<DEFER>(S, gat, epi, prod, ww);
     block_reduce_store<3, SPMV_THREADS>(epi.acc, red, a.partials + 3 * (int64_t)blockIdx.x);
 }
 
@@ -973,8 +937,7 @@ void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
     const KktArgs a = plain_args(c, w, out, gate);
     if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
     if (c.S.ndef > 0) {
-        if (c.S.tile_deep) hipLaunchKernelGGL((kkt2_kernel<true, false, false, true>), dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, a);
-        else hipLaunchKernelGGL((kkt2_kernel<true, false, false>), dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, a);
+        hipLaunchKernelGGL((kkt2_kernel<true, false, false>), dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, a);
         if (c.between) (void)c.between(c.between_arg);        // row-sharded: the slots are summed over the ranks here
         hipLaunchKernelGGL(kkt2_deferred_kernel, dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, w, out, c.cb, (int)c.n,
                            (int)(c.n + c.m), c.partials, c.st, gate, (int)c.count_repl);
@@ -998,7 +961,6 @@ void launch_kkt2_cg(const LaunchCtx& c, const CgIter& it, double2* Ap) {
     dim3 grid(c.S.nwg), block(SPMV_THREADS);
     if (c.S.ndef > 0) {
         if (fused) hipLaunchKernelGGL((kkt2_kernel<true, true, true>), grid, block, 0, c.stream, c.S, a);
-        else if (c.S.tile_deep) hipLaunchKernelGGL((kkt2_kernel<true, false, true, true>), grid, block, 0, c.stream, c.S, a);
         else hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
     } else {
         if (fused) hipLaunchKernelGGL((kkt2_kernel<false, true, false>), grid, block, 0, c.stream, c.S, a);
@@ -1018,8 +980,7 @@ void launch_cgm_sweep(const LaunchCtx& c, const CgmIter& it, int closes) {
     if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
     dim3 grid(c.S.nwg), block(SPMV_THREADS);
     if (c.S.ndef > 0) {
-        if (c.S.tile_deep) hipLaunchKernelGGL((kkt2_kernel<true, false, true, true>), grid, block, 0, c.stream, c.S, a);
-        else hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
+        hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
     }
     else hipLaunchKernelGGL((kkt2_kernel<false, false, false>), grid, block, 0, c.stream, c.S, a);
 }
@@ -1031,8 +992,7 @@ void launch_cgm_apply(const LaunchCtx& c, const CgmIter& it, const double2* v) {
     if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
     dim3 grid(c.S.nwg), block(SPMV_THREADS);
     if (c.S.ndef > 0) {
-        if (c.S.tile_deep) hipLaunchKernelGGL((kkt2_kernel<true, false, true, true>), grid, block, 0, c.stream, c.S, a);
-        else hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
+        hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
     }
     else hipLaunchKernelGGL((kkt2_kernel<false, false, false>), grid, block, 0, c.stream, c.S, a);
 }
@@ -1132,7 +1092,7 @@ __global__ __launch_bounds__(SPMV_THREADS) void q1_kernel(DevBlkCsr S, const dou
     for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
     epi.init(vcomp[2 * (int64_t)nm]);      // the tau entry of the gathered component
     Gather1 gat{vcomp};
-    spmv_walk<DEFER, false>(S, gat, epi, prod, wave_work(S));
+    spmv_walk<DEFER>(S, gat, epi, prod, wave_work(S));
     block_reduce_store<NACC, SPMV_THREADS>(epi.acc, red, partials + NACC * (int64_t)blockIdx.x);
 }
 template <class Epi, int NACC>

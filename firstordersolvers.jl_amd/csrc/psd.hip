@@ -38,7 +38,7 @@ __host__ __device__ inline int psd_ld(int k) {
     return ld;
 }
 
-constexpr int PSD_RED_SCRATCH = 256;      // doubles of LDS behind wgt / inv: the reducer of jacobi64_regs (order 64 only)
+constexpr int PSD_RED_SCRATCH = 512;      // doubles of LDS behind wgt / inv: the reducer of jacobi64_regs (order 64 only; [2][8][32])
 __host__ inline size_t psd_lds_bytes(int k) { return (size_t)(32 + k * psd_ld(k) + 2 * k + 16 + (k == 64 ? PSD_RED_SCRATCH : 0)) * sizeof(double); }
 
 __device__ __forceinline__ void idx_to_ij(int idx, int k, int& i, int& j) {
@@ -165,6 +165,7 @@ __device__ __forceinline__ int jacobi64(double* __restrict__ G, const int ld, co
 // ended with at the previous outer iteration (read from vin, the new basis is written to vout).  The iterates of the
 // solver change slowly, so V_prev nearly diagonalises the new matrix and 3-5 sweeps replace 9-10 (the convergence
 // test -- a full sweep without a rotation -- is unchanged, so accuracy does not depend on the start).  Orders <= 64.
+template <int NW>
 __device__ __forceinline__ int jacobi64_regs(double* __restrict__ G, const int ld, const int tid, const double tol2, double* scratch);
 
 template <bool USE_LDS, bool WARM, int THREADS>
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
 
     if (k == 64 && sigma > 0.0) {
         // 256 threads: the column halves live in registers (jacobi64_regs); more threads: G stays in LDS (jacobi64)
-        if constexpr (USE_LDS && THREADS == 256) nsweeps = jacobi64_regs(G, ld, tid, tol2, wgt + 2 * k);
+        if constexpr (USE_LDS && (THREADS == 256 || THREADS == 512)) nsweeps = jacobi64_regs<THREADS / 64>(G, ld, tid, tol2, wgt + 2 * k);
         else nsweeps = jacobi64<THREADS, THREADS / 32>(G, ld, tid, tol2);
     } else if (k > 1 && sigma > 0.0) {
         for (int sweep = 0; sweep < PSD_MAX_SWEEPS; ++sweep) {
@@ -495,14 +496,17 @@ struct RedHalf {
 // four wavefronts per matrix: lane (s, h), h = 2 w + (lane >> 5), owns rows 8h .. 8h+7; partial sums go through a double-buffered
 // LDS array [2][4][32] with ONE workgroup barrier per reduction (a wavefront can reach its next write of a buffer only after the
 // barrier in between, which every wavefront passes after its reads of that buffer)
-struct RedQuad {
+template <int NW>
+struct RedWaves {
     double* buf; int w, s; int phase;
     __device__ __forceinline__ double sum(double v) {
         v = half_sum(v);
-        double* b = buf + (phase & 1) * 128;
+        double* b = buf + (phase & 1) * (NW * 32);
         b[w * 32 + s] = v;                       // (both halves of the wavefront hold the same value)
         __syncthreads();
-        const double t = (b[s] + b[32 + s]) + (b[64 + s] + b[96 + s]);
+        double t;
+        if constexpr (NW == 4) t = (b[s] + b[32 + s]) + (b[64 + s] + b[96 + s]);
+        else t = ((b[s] + b[32 + s]) + (b[64 + s] + b[96 + s])) + ((b[128 + s] + b[160 + s]) + (b[192 + s] + b[224 + s]));
         ++phase;
         return t;
     }
@@ -600,17 +604,21 @@ __device__ __forceinline__ int jacobi64_sweeps(double (&A)[R], double (&B)[R], b
 // jacobi64 for a workgroup of FOUR wavefronts with the columns in registers (a batch too small to give every SIMD a matrix of
 // its own -- a shard of a multi-GPU run): G (LDS, column-major) is read once, rotated in registers, written back.  `scratch`:
 // 256 doubles of LDS for the reducer.
+// NW = 8 (512 threads, 4 rows per lane): for batches so small that four wavefronts per matrix would leave half of the SIMDs idle
+// (128 matrices on 256 CUs: a 1/8 shard of the 512-block SDP).
+template <int NW>
 __device__ __forceinline__ int jacobi64_regs(double* __restrict__ G, const int ld, const int tid, const double tol2, double* scratch) {
+    constexpr int R = 32 / NW;
     const int w = tid >> 6, ln = tid & 63, s = ln & 31, h = 2 * w + (ln >> 5);
-    double A[8], B[8];
-    double* ga = G + 8 * h + (size_t)(2 * s) * ld;
+    double A[R], B[R];
+    double* ga = G + R * h + (size_t)(2 * s) * ld;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { A[r] = ga[r]; B[r] = ga[r + ld]; }
-    RedQuad red{scratch, w, s, 0};
-    const int nsweeps = jacobi64_sweeps<8>(A, B, s == 31, tol2, red);
+    for (int r = 0; r < R; ++r) { A[r] = ga[r]; B[r] = ga[r + ld]; }
+    RedWaves<NW> red{scratch, w, s, 0};
+    const int nsweeps = jacobi64_sweeps<R>(A, B, s == 31, tol2, red);
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { ga[r] = A[r]; ga[r + ld] = B[r]; }
+    for (int r = 0; r < R; ++r) { ga[r] = A[r]; ga[r + ld] = B[r]; }
     __syncthreads();
     return nsweeps;
 }
@@ -831,7 +839,9 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     // projection; many matrices: 256 threads (4 per CU) maximise throughput.  Per DEVICE: a process may hold handles on several.
     // (order 64 everywhere: the 256-thread kernel keeps the column halves in registers and beats 512 threads on a small batch)
     const bool all64 = kmin == 64 && kmax == 64;
-    const bool wide = (warm && !all64 && (2 * ncones <= 2 * cus) && !c.psd_narrow) || (warm && c.psd_wide);
+    // order 64 everywhere and at most one matrix per two CUs (a 1/8 shard of the 512-block SDP: 128 matrices): eight wavefronts
+    // per matrix, four rows of the two columns per lane -- every SIMD of the chip gets a wavefront
+    const bool wide = (warm && !all64 && (2 * ncones <= 2 * cus) && !c.psd_narrow) || (warm && all64 && (4 * ncones <= cus) && !c.psd_narrow) || (warm && c.psd_wide);
     if (use_lds && !*c.psd_attr_set) {        // hipFuncSetAttribute acts on the CURRENT device; once per handle
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, false, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);

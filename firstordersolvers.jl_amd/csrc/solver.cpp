@@ -1030,10 +1030,6 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     h->S.nrows = hs.nrows; h->S.nnz = hs.nnz; h->S.nnz_padded = hs.nnz_padded;
     h->S.val = dval; h->S.col = dcol; h->S.blk = dblk;
     h->S.row_rel = drr; h->S.wave_blk0 = dwv; h->S.wave_first = dwf; h->S.nblk = hs.nblk; h->S.nwg = hs.nwg; h->S.nwaves = hs.nwaves;
-    // small tile operators (a shard of a multi-GPU run): at most a few tiles per SIMD, none longer than TILE_DEEP_T steps -- the
-    // sweep requests whole tiles at once (kkt2_kernel<.., DEEP>); FOS_TILE_DEEP=0/1 forces
-    h->S.tile_deep = (hs.ntiles > 0 && hs.tile_tmax <= TILE_DEEP_T && hs.ntiles <= (int64_t)16 * cus) ? 1 : 0;
-    if (const char* e = getenv("FOS_TILE_DEEP")) h->S.tile_deep = (atoi(e) != 0 && hs.ntiles > 0 && hs.tile_tmax <= TILE_DEEP_T) ? 1 : 0;
     // dual tiles: partial-sum slots and the deferred rows' slot lists
     h->S.slots = nullptr; h->S.slots_rd = nullptr; h->S.row_defer = nullptr; h->S.def_rows = nullptr; h->S.def_ptr = nullptr; h->S.def_idx = nullptr;
     h->S.ndef = (int32_t)hs.def_rows.size();

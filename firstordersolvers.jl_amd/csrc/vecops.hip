@@ -314,19 +314,59 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
     DevState* st = a.st;
     bool have0 = i0 < l && !a.close_only;
     if constexpr (DEF) { if (have0 && ((a.def_mask[i0 >> 5] >> (i0 & 31)) & 1u)) have0 = false; }
+    // ---- everything this launch needs from memory is requested in STAGES, each stage's loads issued together, before the first
+    // use: the kernel is a chain of memory latencies on small operators (a shard of a multi-GPU run steps through 17 x 2 of them)
+    // stage 1: the thread's first element; the scalars (stored by EARLIER launches: nothing below races them) and the r.r records;
+    //          the sweep's records; the slot-spread row this lane works on in the first pass (its list bounds and row number)
     d2 w0 = make_double2(0.0, 0.0), r0 = w0, x0 = w0, p0 = w0, s0 = w0;
-    if (have0) { w0 = a.w[i0]; r0 = a.r[i0]; x0 = a.x[i0]; if (!first) { p0 = a.p[i0]; s0 = a.s[i0]; } }      // requested before the scalar prologue
-    // the scalars this launch needs (stored by EARLIER launches: nothing below races them) and the r.r records are requested
-    // together with the gate -- the prologue is a latency chain every CG iteration pays
+    if (have0) { w0 = a.w[i0]; r0 = a.r[i0]; x0 = a.x[i0]; if (!first) { p0 = a.p[i0]; s0 = a.s[i0]; } }
     const bool closing = a.close_here != 0;      // (i = 0: g_0 from the start kernel's records, no stop test -- at least one iteration runs)
     const int done = st->done, xfail = st->xchg_failed, maxit = st->maxit;
     const double vtx = st->vtau[0], vty = st->vtau[1];           // tau element of r_i (stashed by the sweep that applied M to it)
     const double g_cur = st->rn2[i & 1], g_prev = st->rn2[(i + 1) & 1], a_prev = st->alpha2[(i + 1) & 1], tol = st->tol;
+    const bool plain_sums = !a.from_reduced && a.pre == nullptr;
+    PartialRegs<3> kreg;
+    if (plain_sums) kreg.load(a.kkt_partials, a.nkkt);
+    const int lpr = DEF ? S.def_lpr : 1, sh = 31 - __clz(lpr);
+    const int rows_per_pass = (gridDim.x * VEC_THREADS) >> sh;
+    const int lig = threadIdx.x & (lpr - 1);
+    const int q0 = (blockIdx.x * VEC_THREADS + threadIdx.x) >> sh;
+    const bool ok0 = DEF && !a.close_only && q0 < S.ndef;
+    int dk0 = 0, dk1 = 0, drow0 = 0;
+    if (ok0) { dk0 = S.def_ptr[q0] + lig; dk1 = S.def_ptr[q0 + 1]; drow0 = S.def_rows[q0]; }
     const double rs = !closing ? 0.0 : (a.from_reduced ? a.reduced[3] : wave_sum_records(a.rr_in, a.nrr));
+    // stage 2: the first four slot indices of that row's list; the row's vector elements
+    int did[4] = {-1, -1, -1, -1};
+    d2 dri = make_double2(0.0, 0.0), dpi = dri, dsi = dri, dxi = dri;
+    double dc = 0.0;
+    if constexpr (DEF) {
+        if (ok0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) did[q] = (dk0 + q * lpr < dk1) ? S.def_idx[dk0 + q * lpr] : -1;
+            if (lig == 0) { dri = a.r[drow0]; dxi = a.x[drow0]; dc = a.cb[drow0]; if (!first) { dpi = a.p[drow0]; dsi = a.s[drow0]; } }
+        }
+    }
     if (done) return;
     if (FOLD && xfail) return;
+    // stage 3: those slots (the rest of a longer list follows by the ordinary chunks)
+    double du1 = 0.0, du2 = 0.0;
+    if constexpr (DEF) {
+        const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots_rd);
+        d2 dv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dv[q] = did[q] >= 0 ? slots[did[q]] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (did[q] >= 0) { du1 += dv[q].x; du2 += dv[q].y; }
+        if (ok0) slot_list_sum(slots, S.def_idx, dk0 + 4 * lpr, dk1, lpr, du1, du2);
+    }
     __shared__ double sums[4];
-    sweep_sums3(sums, a.kkt_partials, a.nkkt, a.reduced, a.from_reduced, a.pre, a.pre_seq, st);
+    if (plain_sums) {
+        double acc3[3];
+        kreg.sum(a.kkt_partials, a.nkkt, acc3);
+        partials_combine<3>(acc3, sums);
+    } else {
+        sweep_sums3(sums, a.kkt_partials, a.nkkt, a.reduced, a.from_reduced, a.pre, a.pre_seq, st);
+    }
     if (closing || FOLD) {
         if (threadIdx.x == 0) sums[3] = rs;
         __syncthreads();
@@ -376,22 +416,20 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
     };
     if constexpr (DEF) {
         const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots_rd);
-        const int lpr = S.def_lpr, sh = 31 - __clz(lpr);
-        const int rows_per_pass = (gridDim.x * VEC_THREADS) >> sh;
-        const int lig = threadIdx.x & (lpr - 1);
         const int npass = (S.ndef + rows_per_pass - 1) / rows_per_pass;       // uniform trip count: the DPP sums need full waves
-        int q = (blockIdx.x * VEC_THREADS + threadIdx.x) >> sh;
+        int q = q0;
         for (int pass = 0; pass < npass; ++pass, q += rows_per_pass) {
             const bool ok = q < S.ndef;
-            const int row = ok ? S.def_rows[q] : 0;
-            const bool own = ok && lig == 0;
-            d2 ri = make_double2(0.0, 0.0), pi = ri, si = ri, xi = ri;
-            double c = 0.0;
-            if (own) { ri = a.r[row]; xi = a.x[row]; c = a.cb[row]; if (!first) { pi = a.p[row]; si = a.s[row]; } }
-            double u1 = 0.0, u2 = 0.0;
-            if (ok) {
-                slot_list_sum(slots, S.def_idx, S.def_ptr[q] + lig, S.def_ptr[q + 1], lpr, u1, u2);
+            int row = drow0;
+            d2 ri = dri, pi = dpi, si = dsi, xi = dxi;
+            double c = dc, u1 = du1, u2 = du2;
+            if (pass > 0) {                                      // (the first pass was requested in the prologue's stages)
+                row = ok ? S.def_rows[q] : 0;
+                ri = make_double2(0.0, 0.0); pi = ri; si = ri; xi = ri; c = 0.0; u1 = 0.0; u2 = 0.0;
+                if (ok && lig == 0) { ri = a.r[row]; xi = a.x[row]; c = a.cb[row]; if (!first) { pi = a.p[row]; si = a.s[row]; } }
+                if (ok) slot_list_sum(slots, S.def_idx, S.def_ptr[q] + lig, S.def_ptr[q + 1], lpr, u1, u2);
             }
+            const bool own = ok && lig == 0;
             u1 = group_sum(u1, lpr);
             u2 = group_sum(u2, lpr);
             if (own) {
