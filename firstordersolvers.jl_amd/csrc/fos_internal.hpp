@@ -133,6 +133,8 @@ struct DevBlkCsr {
     const uint16_t* row_rel;
     const int32_t* wave_blk0;
     const BlkDesc* wave_first;         // [nwaves] copy of each wavefront's first descriptor (requested together with wave_blk0)
+    int32_t resident;                  // 1: the whole operator stays in the caches from sweep to sweep -- ordinary loads for the matrix stream
+    int32_t dbg_flags;                 // timing experiments only (WRONG results): bit 0 = dual tiles skip the column-sum butterflies
     int32_t nblk, nwg, nwaves;
     // dual tiles / deferred rows (ndef == 0: none)
     double* slots;                     // [nslots][2]   written by the sweeps
@@ -350,6 +352,7 @@ void launch_gapa_final(const LaunchCtx& c, double2* x, const double2* t2, const 
 void launch_gapa_finalize(const LaunchCtx& c, double beta, int from_reduced);
 void launch_fista_extrap(const LaunchCtx& c, double2* y, const double2* x, const double2* xold, double coef);         // y = x + coef (x - xold)
 void launch_add(const LaunchCtx& c, double2* out, const double2* a, const double2* b);                                // out = a + b
+void launch_copy(const LaunchCtx& c, double2* out, const double2* in);                                                 // out = in (gateable)
 void launch_dykstra_corr(const LaunchCtx& c, double2* p, const double2* x, const double2* y);                         // p = x + p - y
 
 // direct = true (HSDE.jl:12-15): dense set-up helpers and the per-projection kernels

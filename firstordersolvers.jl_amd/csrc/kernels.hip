@@ -62,6 +62,11 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
 
 template <class T>
 __device__ __forceinline__ T nt_load(const T* p) { return __builtin_nontemporal_load(p); }
+// matrix stream of the row-block formats: non-temporal (read once per sweep; keeps the gathered vector in L2) unless the whole
+// operator is small enough to STAY in the XCDs' L2s / the Infinity Cache from one sweep to the next (G::NT = false: a shard of a
+// multi-GPU run, C3) -- a non-temporal line is dropped behind its reader, so every sweep would fetch the operator from HBM again
+template <bool NT, class T>
+__device__ __forceinline__ T mload(const T* p) { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
 
 // what a row epilogue needs from memory besides the row sum: loaded at the START of the row block so that its
 // latency overlaps the sweep of the block instead of trailing it
@@ -84,16 +89,20 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) v2d* cptr_v2d;
 __device__ __forceinline__ d2 ld_const(const d2* p) { const v2d t = *(cptr_v2d)(p); return make_double2(t.x, t.y); }
 typedef const __attribute__((address_space(4))) double* cptr_f64;
-struct GatherW {
+template <bool NTV>
+struct GatherWT {
     static constexpr int NRHS = 2;
     static constexpr bool FUSED = false;
+    static constexpr bool NT = NTV;
     const d2* w;
     __device__ __forceinline__ d2 load(int c) const { return w[c]; }
     __device__ __forceinline__ d2 load_u(int c) const { return ld_const(w + c); }
 };
+typedef GatherWT<true> GatherW;
 struct GatherP {
     static constexpr int NRHS = 2;
     static constexpr bool FUSED = true;
+    static constexpr bool NT = true;
     const d2* r;
     const d2* pold;
     double beta;
@@ -117,6 +126,7 @@ struct GatherP {
 struct Gather1 {
     static constexpr int NRHS = 1;
     static constexpr bool FUSED = false;
+    static constexpr bool NT = true;
     const double* w;   // points at the chosen component of an interleaved vector: element c at w[2c]
     __device__ __forceinline__ d2 load(int c) const { return make_double2(w[2 * (int64_t)c], 0.0); }
     __device__ __forceinline__ d2 load_u(int c) const { return make_double2(*(cptr_f64)(w + 2 * (int64_t)c), 0.0); }
@@ -205,7 +215,7 @@ __device__ __forceinline__ void long_run_rows(const DevBlkCsr& S, const G& gat, 
 #pragma unroll
         for (int i = 0; i < NR; ++i)
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[i][u] = nt_load(val + i * stride + k + 64 * u);
+            for (int u = 0; u < U; ++u) v[i][u] = mload<G::NT>(val + i * stride + k + 64 * u);
         d2 x[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) x[u] = gat.load(c00 + k + 64 * u);
@@ -221,7 +231,7 @@ __device__ __forceinline__ void long_run_rows(const DevBlkCsr& S, const G& gat, 
         const d2 x = gat.load(c00 + k);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const double v = nt_load(val + i * stride + k);
+            const double v = mload<G::NT>(val + i * stride + k);
             a1[i] += v * x.x;
             if constexpr (G::NRHS == 2) a2[i] += v * x.y;
         }
@@ -245,10 +255,10 @@ __device__ __forceinline__ void ell_steps(const G& gat, const double* __restrict
     double v[U];
     int c[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = nt_load(val + 64 * (t + u));
+    for (int u = 0; u < U; ++u) v[u] = mload<G::NT>(val + 64 * (t + u));
     if constexpr (!RUN) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) c[u] = nt_load(col + 64 * (t + u));
+        for (int u = 0; u < U; ++u) c[u] = mload<G::NT>(col + 64 * (t + u));
     }
     bool m[U];
 #pragma unroll
@@ -275,9 +285,9 @@ __device__ __forceinline__ void long_steps(const G& gat, const double* __restric
     double v[U];
     int c[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = nt_load(val + k + 64 * u);
+    for (int u = 0; u < U; ++u) v[u] = mload<G::NT>(val + k + 64 * u);
 #pragma unroll
-    for (int u = 0; u < U; ++u) c[u] = nt_load(col + k + 64 * u);
+    for (int u = 0; u < U; ++u) c[u] = mload<G::NT>(col + k + 64 * u);
     d2 p[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) p[u] = gprod(gat, v[u], c[u]);
@@ -370,7 +380,7 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
                 d2 xln = make_double2(0.0, 0.0);
                 if constexpr (Epi::FOLDDEF) { if (lane < TILE_GROUP && lane < tc) xln = gat.load(c0 + lane); }
 #pragma unroll
-                for (int u = 0; u < TILE_GROUP; ++u) vn[u] = nt_load(val + 64 * u);
+                for (int u = 0; u < TILE_GROUP; ++u) vn[u] = mload<G::NT>(val + 64 * u);
                 for (int t = 0; t < T; t += TILE_GROUP) {
                     double v[TILE_GROUP];
                     d2 x[TILE_GROUP];
@@ -380,7 +390,7 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
                     if (t + TILE_GROUP < T) {
                         if constexpr (Epi::FOLDDEF) { if (lane < TILE_GROUP && t + TILE_GROUP + lane < tc) xln = gat.load(c0 + t + TILE_GROUP + lane); }
 #pragma unroll
-                        for (int u = 0; u < TILE_GROUP; ++u) vn[u] = nt_load(val + 64 * (t + TILE_GROUP + u));
+                        for (int u = 0; u < TILE_GROUP; ++u) vn[u] = mload<G::NT>(val + 64 * (t + TILE_GROUP + u));
                     }
                     double p1[TILE_GROUP], p2[TILE_GROUP];
                     if constexpr (G::FUSED) {
@@ -406,9 +416,12 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
                             if constexpr (NRHS == 2) { r2 += v[u] * x[u].y; p2[u] = v[u] * wr.y; }
                         }
                     }
-                    const double s1 = tile_colsum8(p1, lane);
-                    double s2 = 0.0;
-                    if constexpr (NRHS == 2) s2 = tile_colsum8(p2, lane);
+                    double s1, s2 = 0.0;
+                    if (S.dbg_flags & 1) { s1 = p1[0]; if constexpr (NRHS == 2) s2 = p2[0]; }       // (timing experiment: no butterflies)
+                    else {
+                        s1 = tile_colsum8(p1, lane);
+                        if constexpr (NRHS == 2) s2 = tile_colsum8(p2, lane);
+                    }
                     if (lane < TILE_GROUP) {
                         slots[cslot + t + lane] = make_double2(s1, s2);
                         epi.park(c0 + t + lane, s1, s2, xl);
@@ -474,8 +487,8 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
                 for (int j = 0; j < WPL; ++j) {
                     const int k = lane + j * 64;
                     const bool ok = k < cnt;
-                    v[j] = ok ? nt_load(val + k) : 0.0;
-                    c[j] = ok ? nt_load(col + k) : 0;
+                    v[j] = ok ? mload<G::NT>(val + k) : 0.0;
+                    c[j] = ok ? mload<G::NT>(col + k) : 0;
                 }
 #pragma unroll
                 for (int j = 0; j < WPL; ++j) {
@@ -721,15 +734,16 @@ struct KktArgs {
     int32_t batch_mark;
 };
 
-template <bool DEFER, bool FUSEP, bool FOLD>
+template <bool DEFER, bool FUSEP, bool FOLD, bool NT = true>
 __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBlkCsr S, KktArgs a) {
+    static_assert(NT || !FUSEP, "the resident-operator form exists for the plain sweeps only");
     static_assert(!FOLD || DEFER, "FOLD is about deferred rows");
     WaveWork ww;                             // requested before the gate / the closing prologue: their round trip covers it
     if constexpr (!FUSEP) ww = wave_work(S);
     if ((FUSEP || a.gate) && a.close_j < 0 && a.st->done) return;        // (close_j > 0: cgm_close_in_sweep below tests `done` with its other loads)
     __shared__ __attribute__((aligned(16))) double prod[SPMV_WAVES * WNNZ * 2];
     __shared__ double red[16];
-    using G = typename std::conditional<FUSEP, GatherP, GatherW>::type;
+    using G = typename std::conditional<FUSEP, GatherP, GatherWT<NT>>::type;
     G gat;
     if constexpr (FUSEP) {
         if (a.pb.nranks > 0 && a.st->xchg_failed) return;
@@ -932,17 +946,34 @@ static KktArgs plain_args(const LaunchCtx& c, const double2* w, double2* out, in
     a.close_j = -1;
     return a;
 }
+// the plain (not fused-p) sweep in the form the operator wants: FOLD = slot-spread rows' share of the sums added by the sweep;
+// resident operators read their matrix stream with ordinary (cache-retaining) loads
+static void launch_plain_sweep(const LaunchCtx& c, const KktArgs& a, bool fold) {
+    dim3 grid(c.S.nwg), block(SPMV_THREADS);
+    if (c.S.ndef > 0) {
+        if (fold) {
+            if (c.S.resident) hipLaunchKernelGGL((kkt2_kernel<true, false, true, false>), grid, block, 0, c.stream, c.S, a);
+            else hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
+        } else {
+            if (c.S.resident) hipLaunchKernelGGL((kkt2_kernel<true, false, false, false>), grid, block, 0, c.stream, c.S, a);
+            else hipLaunchKernelGGL((kkt2_kernel<true, false, false>), grid, block, 0, c.stream, c.S, a);
+        }
+    } else {
+        if (c.S.resident) hipLaunchKernelGGL((kkt2_kernel<false, false, false, false>), grid, block, 0, c.stream, c.S, a);
+        else hipLaunchKernelGGL((kkt2_kernel<false, false, false>), grid, block, 0, c.stream, c.S, a);
+    }
+}
 // stand-alone apply: sweep (+ deferred-row kernel when the operator has dual tiles); leaves c.S.npart records at c.S.part_off
 void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
     const KktArgs a = plain_args(c, w, out, gate);
     if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
     if (c.S.ndef > 0) {
-        hipLaunchKernelGGL((kkt2_kernel<true, false, false>), dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, a);
+        launch_plain_sweep(c, a, false);
         if (c.between) (void)c.between(c.between_arg);        // row-sharded: the slots are summed over the ranks here
         hipLaunchKernelGGL(kkt2_deferred_kernel, dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, w, out, c.cb, (int)c.n,
                            (int)(c.n + c.m), c.partials, c.st, gate, (int)c.count_repl);
     } else {
-        hipLaunchKernelGGL((kkt2_kernel<false, false, false>), dim3(c.S.nwg), dim3(SPMV_THREADS), 0, c.stream, c.S, a);
+        launch_plain_sweep(c, a, false);
     }
 }
 // the sweep of CG iteration j (gated on DevState.done); leaves c.S.nwg records at record 0.
@@ -959,13 +990,9 @@ void launch_kkt2_cg(const LaunchCtx& c, const CgIter& it, double2* Ap) {
         if (it.fold) { a.pb = *it.fold; a.seq_base = it.seq_base; }
     }
     dim3 grid(c.S.nwg), block(SPMV_THREADS);
-    if (c.S.ndef > 0) {
-        if (fused) hipLaunchKernelGGL((kkt2_kernel<true, true, true>), grid, block, 0, c.stream, c.S, a);
-        else hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
-    } else {
-        if (fused) hipLaunchKernelGGL((kkt2_kernel<false, true, false>), grid, block, 0, c.stream, c.S, a);
-        else hipLaunchKernelGGL((kkt2_kernel<false, false, false>), grid, block, 0, c.stream, c.S, a);
-    }
+    if (!fused) { launch_plain_sweep(c, a, true); return; }
+    if (c.S.ndef > 0) hipLaunchKernelGGL((kkt2_kernel<true, true, true>), grid, block, 0, c.stream, c.S, a);
+    else hipLaunchKernelGGL((kkt2_kernel<false, true, false>), grid, block, 0, c.stream, c.S, a);
 }
 // merged-reduction CG: w = M r with the sums of w.r and of the tau row (c.S.nwg records at record 0), gated on DevState.done.
 // closes > 0 (single GPU): the sweep first closes that iteration from the r.r records its update left (cgm_close_in_sweep).
@@ -978,11 +1005,7 @@ void launch_cgm_sweep(const LaunchCtx& c, const CgmIter& it, int closes) {
         a.rr_partials = c.partials + 3 * (size_t)PART_CAP + (size_t)(closes & 1) * CGM_RR_STRIDE; a.rr_count = c.cg_blocks;
     }
     if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
-    dim3 grid(c.S.nwg), block(SPMV_THREADS);
-    if (c.S.ndef > 0) {
-        hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
-    }
-    else hipLaunchKernelGGL((kkt2_kernel<false, false, false>), grid, block, 0, c.stream, c.S, a);
+    launch_plain_sweep(c, a, true);
 }
 // merged-reduction CG, start of a solve: it.w = M v, every row but tau, slot-spread rows left in their slots (the start kernel
 // finishes them); the sums of the tau row at record 0 (FOLD form: complete without the deferred-row kernel); NOT gated
@@ -990,11 +1013,7 @@ void launch_cgm_apply(const LaunchCtx& c, const CgmIter& it, const double2* v) {
     KktArgs a = plain_args(c, v, it.w, 0);
     a.vt_out = c.st->vtau;
     if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
-    dim3 grid(c.S.nwg), block(SPMV_THREADS);
-    if (c.S.ndef > 0) {
-        hipLaunchKernelGGL((kkt2_kernel<true, false, true>), grid, block, 0, c.stream, c.S, a);
-    }
-    else hipLaunchKernelGGL((kkt2_kernel<false, false, false>), grid, block, 0, c.stream, c.S, a);
+    launch_plain_sweep(c, a, true);
 }
 void launch_cg_stop_check(const LaunchCtx& c, const CgIter& it) {
     KktArgs a = plain_args(c, nullptr, nullptr, 1);

@@ -839,9 +839,10 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     // projection; many matrices: 256 threads (4 per CU) maximise throughput.  Per DEVICE: a process may hold handles on several.
     // (order 64 everywhere: the 256-thread kernel keeps the column halves in registers and beats 512 threads on a small batch)
     const bool all64 = kmin == 64 && kmax == 64;
-    // order 64 everywhere and at most one matrix per two CUs (a 1/8 shard of the 512-block SDP: 128 matrices): eight wavefronts
-    // per matrix, four rows of the two columns per lane -- every SIMD of the chip gets a wavefront
-    const bool wide = (warm && !all64 && (2 * ncones <= 2 * cus) && !c.psd_narrow) || (warm && all64 && (4 * ncones <= cus) && !c.psd_narrow) || (warm && c.psd_wide);
+    // (order 64 with EIGHT wavefronts per matrix, four rows of the two columns per lane -- psd_kernel<.., 512> through jacobi64_regs<8>,
+    //  FOS_PSD_WIDE=1 -- was measured on 128 matrices: 145 us against 118 for four wavefronts; the barrier across eight wavefronts
+    //  per step costs more than the halved arithmetic saves)
+    const bool wide = (warm && !all64 && (2 * ncones <= 2 * cus) && !c.psd_narrow) || (warm && c.psd_wide);
     if (use_lds && !*c.psd_attr_set) {        // hipFuncSetAttribute acts on the CURRENT device; once per handle
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, false, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd_kernel<true, true, PSD_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);

@@ -441,7 +441,7 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     //  whose post-solve kernels contain no reduction; every rank takes the same decisions, so all mispredict together.
     //  Solve number 0 mod 2^21 is the mark's initial value.)
     const bool spec = post && h->speculate && !c.between && !fuse_p && (seq_base >> 11) != 0u &&
-                      (!h->sharded() || (fold && h->alg == FOS_ALG_GAP));
+                      (!h->sharded() || (fold && h->alg != FOS_ALG_GAPA));
     const int32_t batch_id = (int32_t)(((seq_base >> 11) & 0x7FFFFFu) << 8 | 1u);
     bool mark_last = spec;                   // the first batch ends with a marked launch
     // merged reduction, sharded without folded mailboxes: the sweep's three sums and the update's r.r cross the ranks together,
@@ -723,6 +723,26 @@ int ls_finish(fos_solver* h, int64_t i) {
 
 // one outer iteration; *check_on receives the vector checkstatus is evaluated on (the cone-feasible point)
 int step_finish_launch(fos_solver* h, const LaunchCtx& c);
+
+// prox!(.., S1, in) followed by `post` -- everything of the step behind the CG solve (relaxation, cone projection and, when no
+// status check sits in between, the step's last pass).  `post` is handed to the solve, which enqueues it behind the first CG
+// batch, gated, so that the GPU does not wait for the host to learn the iteration count (cg_solve); if the batch did not
+// suffice the gated launches were no-ops: the host-side state they advanced is rolled back and `post` runs again, ungated.
+int affine_then(fos_solver* h, const LaunchCtx& c, const d2* in, const PostFn& post) {
+    const int psd_cur = h->psd_cur, psd_have_prev = h->psd_have_prev;
+    const size_t prof_used = h->prof_used;
+    const int64_t psd_seen = h->prof_seen[FOS_PROF_PSD];
+    const double fista_t = h->fista_t;
+    bool ran = false;
+    FOS_TRY(prox_affine(h, in, &post, &ran));
+    if (!ran) {
+        h->psd_cur = psd_cur; h->psd_have_prev = psd_have_prev; h->prof_seen[FOS_PROF_PSD] = psd_seen; h->fista_t = fista_t;
+        // (event pairs recorded around no-op launches: forget them; the CG records of this solve stay)
+        for (size_t k = prof_used; k < h->prof_used; ++k) if (h->prof_recs[k].cls == FOS_PROF_PSD) h->prof_recs[k].cls = -1;
+        FOS_TRY(post(c));
+    }
+    return FOS_OK;
+}
 int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bool* finish_done) {
     LaunchCtx c = h->ctx();
     *finish_done = false;
@@ -742,38 +762,37 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bo
                 if (!will_check) FOS_TRY(step_finish_launch(h, cg));
                 return FOS_OK;
             };
-            // host-side state the post work advances (restored if its launches turn out to have been no-ops)
-            const int psd_cur = h->psd_cur, psd_have_prev = h->psd_have_prev;
-            const size_t prof_used = h->prof_used;
-            const int64_t psd_seen = h->prof_seen[FOS_PROF_PSD];
-            bool ran = false;
-            FOS_TRY(prox_affine(h, h->X, &post, &ran));                  // S1!: prox!(y,S1,x)          :45
-            if (!ran) {
-                h->psd_cur = psd_cur; h->psd_have_prev = psd_have_prev; h->prof_seen[FOS_PROF_PSD] = psd_seen;
-                // (event pairs recorded around no-op launches: forget them; the CG records of this solve stay)
-                for (size_t k = prof_used; k < h->prof_used; ++k) if (h->prof_recs[k].cls == FOS_PROF_PSD) h->prof_recs[k].cls = -1;
-                FOS_TRY(post(c));
-            }
+            FOS_TRY(affine_then(h, c, h->X, post));                      // S1!: prox!(y,S1,x)          :45
             *check_on = h->T2;                                           //   checkstatus(status, y)    :56
             *finish_done = !will_check;
             return FOS_OK;
         }
         case FOS_ALG_FISTA: {                                            // fista.jl:28-48
             if (i == 1) FOS_HIP(hipMemcpyAsync(h->Y, h->X, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));   // :31-33
-            FOS_TRY(prox_affine(h, h->Y));                               // :35
-            launch_axpby(c, h->T1, h->alpha, h->SOL, 1 - h->alpha, h->Y);     // :37
-            FOS_HIP(hipMemcpyAsync(h->XOLD, h->X, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));           // :39
-            FOS_TRY(prox_cones(h, h->X, h->T1));                         // :40
+            const PostFn post = [h, will_check](const LaunchCtx& cg) -> int {
+                launch_axpby(cg, h->T1, h->alpha, h->SOL, 1 - h->alpha, h->Y);                 // :37
+                launch_copy(cg, h->XOLD, h->X);                                               // :39  xold .= x
+                FOS_TRY(prox_cones(h, h->X, h->T1, cg.gate));                                 // :40
+                if (!will_check) FOS_TRY(step_finish_launch(h, cg));
+                return FOS_OK;
+            };
+            FOS_TRY(affine_then(h, c, h->Y, post));                      // :35
             *check_on = h->X;                                            // :41
+            *finish_done = !will_check;
             return FOS_OK;
         }
         case FOS_ALG_DYKSTRA: {                                          // dykstra.jl:25-36   (p = Y, q = XOLD)
             launch_add(c, h->W, h->X, h->Y);                             // x .+ p
-            FOS_TRY(prox_affine(h, h->W));                               // prox!(y, S1, x .+ p)        :28
-            launch_dykstra_corr(c, h->Y, h->X, h->SOL);                  // p .= x .+ p .- y            :30
-            launch_add(c, h->W, h->SOL, h->XOLD);                        // y .+ q
-            FOS_TRY(prox_cones(h, h->X, h->W));                          // prox!(x, S2, y .+ q)        :31
+            const PostFn post = [h, will_check](const LaunchCtx& cg) -> int {
+                launch_dykstra_corr(cg, h->Y, h->X, h->SOL);                                  // p .= x .+ p .- y            :30
+                launch_add(cg, h->W, h->SOL, h->XOLD);                                        // y .+ q
+                FOS_TRY(prox_cones(h, h->X, h->W, cg.gate));                                  // prox!(x, S2, y .+ q)        :31
+                if (!will_check) FOS_TRY(step_finish_launch(h, cg));
+                return FOS_OK;
+            };
+            FOS_TRY(affine_then(h, c, h->W, post));                      // prox!(y, S1, x .+ p)        :28
             *check_on = h->X;                                            // :32
+            *finish_done = !will_check;
             return FOS_OK;
         }
     }
@@ -1029,6 +1048,16 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     }
     h->S.nrows = hs.nrows; h->S.nnz = hs.nnz; h->S.nnz_padded = hs.nnz_padded;
     h->S.val = dval; h->S.col = dcol; h->S.blk = dblk;
+    h->S.dbg_flags = getenv("FOS_DBG_FLAGS") ? atoi(getenv("FOS_DBG_FLAGS")) : 0;
+    // an operator whose stored form (with the dozen vectors of the solver beside it) fits the XCDs' L2s / the Infinity Cache is
+    // read with ordinary loads: it then stays on-die from one sweep to the next (FOS_RESIDENT=0/1 forces)
+    {
+        const double op_bytes = 8.0 * (double)hs.nnz_padded + 4.0 * (double)hs.ncol_stored + 48.0 * (double)hs.nblk;
+        // (measured: C3, 12 MB, sweep 22.0 -> 17.1 us; the 64-block shard of C4, 34 MB = 4.3 MB per XCD against 4 MB of L2 each,
+        //  24.5 -> 26.2 us per CG iteration: an operator that does not fit the L2s only evicts the vectors)
+        h->S.resident = (!windowed && op_bytes <= 20e6) ? 1 : 0;
+        if (const char* e = getenv("FOS_RESIDENT")) h->S.resident = atoi(e) != 0 ? 1 : 0;
+    }
     h->S.row_rel = drr; h->S.wave_blk0 = dwv; h->S.wave_first = dwf; h->S.nblk = hs.nblk; h->S.nwg = hs.nwg; h->S.nwaves = hs.nwaves;
     // dual tiles: partial-sum slots and the deferred rows' slot lists
     h->S.slots = nullptr; h->S.slots_rd = nullptr; h->S.row_defer = nullptr; h->S.def_rows = nullptr; h->S.def_ptr = nullptr; h->S.def_idx = nullptr;

@@ -680,17 +680,25 @@ __global__ __launch_bounds__(FIN_THREADS) void gapa_finalize_kernel(const double
 }
 // y = x + coef (x - xold)                                          fista.jl:46
 __global__ __launch_bounds__(VEC_THREADS) void fista_extrap_kernel(int64_t l, d2* __restrict__ y, const d2* __restrict__ x,
-                                                                   const d2* __restrict__ xold, double coef) {
+                                                                   const d2* __restrict__ xold, double coef, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;
     GRID_STRIDE(i, l) {
         const d2 xi = x[i], xo = xold[i];
         y[i] = make_double2(xi.x + coef * (xi.x - xo.x), xi.y + coef * (xi.y - xo.y));
     }
 }
-__global__ __launch_bounds__(VEC_THREADS) void add_kernel(int64_t l, d2* __restrict__ out, const d2* __restrict__ a, const d2* __restrict__ b) {
+__global__ __launch_bounds__(VEC_THREADS) void add_kernel(int64_t l, d2* __restrict__ out, const d2* __restrict__ a, const d2* __restrict__ b, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;
     GRID_STRIDE(i, l) { const d2 u = a[i], v = b[i]; out[i] = make_double2(u.x + v.x, u.y + v.y); }
 }
+// out = in (a copy that can be gated, unlike hipMemcpyAsync: fista.jl:39 xold .= x behind a speculatively enqueued CG batch)
+__global__ __launch_bounds__(VEC_THREADS) void copy_kernel(int64_t l, d2* __restrict__ out, const d2* __restrict__ in, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;
+    GRID_STRIDE(i, l) out[i] = in[i];
+}
 // p .= x .+ p .- y                                                 dykstra.jl:29,33
-__global__ __launch_bounds__(VEC_THREADS) void dykstra_corr_kernel(int64_t l, d2* __restrict__ p, const d2* __restrict__ x, const d2* __restrict__ y) {
+__global__ __launch_bounds__(VEC_THREADS) void dykstra_corr_kernel(int64_t l, d2* __restrict__ p, const d2* __restrict__ x, const d2* __restrict__ y, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;
     GRID_STRIDE(i, l) {
         const d2 xi = x[i], yi = y[i];
         d2 pi = p[i];
@@ -740,13 +748,16 @@ void launch_gapa_finalize(const LaunchCtx& c, double beta, int from_reduced) {
     hipLaunchKernelGGL(gapa_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials, c.vec_blocks, c.reduced, from_reduced, beta, c.st, c.gate);
 }
 void launch_fista_extrap(const LaunchCtx& c, double2* y, const double2* x, const double2* xold, double coef) {
-    hipLaunchKernelGGL(fista_extrap_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, y, x, xold, coef);
+    hipLaunchKernelGGL(fista_extrap_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, y, x, xold, coef, c.gate);
 }
 void launch_add(const LaunchCtx& c, double2* out, const double2* a, const double2* b) {
-    hipLaunchKernelGGL(add_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, a, b);
+    hipLaunchKernelGGL(add_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, a, b, c.gate);
+}
+void launch_copy(const LaunchCtx& c, double2* out, const double2* in) {
+    hipLaunchKernelGGL(copy_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, in, c.gate);
 }
 void launch_dykstra_corr(const LaunchCtx& c, double2* p, const double2* x, const double2* y) {
-    hipLaunchKernelGGL(dykstra_corr_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p, x, y);
+    hipLaunchKernelGGL(dykstra_corr_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, p, x, y, c.gate);
 }
 
 // ------------------------------------------------------------------------------------------------ direct = true (HSDE.jl:12-15)
