@@ -41,8 +41,20 @@ const char* last_error_cstr() { return g_err; }
 void partition_workgroups(HostBlkCsr* S, int nwg_target) {
     const int nblk = S->nblk;
     int nwg = std::max(1, std::min(nwg_target, (nblk + SPMV_WAVES - 1) / SPMV_WAVES));
-    if (nwg >= 8) nwg -= nwg % 8;     // XCD remap in the kernel wants a multiple of 8
+    // one block per wavefront when the grid allows it (blocks of unequal cost -- tall tiles of 4 and 5 sub-tiles -- must not be
+    // paired up by the cost balance below while other wavefronts stay empty)
+    const bool one_each = (nblk + SPMV_WAVES - 1) / SPMV_WAVES <= nwg_target;
+    if (nwg >= 8) nwg = one_each ? std::min(16384, (nwg + 7) / 8 * 8) : nwg - nwg % 8;     // XCD remap in the kernel wants a multiple of 8
     const int nwaves = nwg * SPMV_WAVES;
+    if (one_each && nblk <= nwaves) {
+        S->wave_blk0.assign(nwaves + 1, 0);
+        for (int g = 0; g <= nwaves; ++g) S->wave_blk0[g] = std::min(g, nblk);
+        S->wave_first.assign(nwaves, BlkDesc{});
+        for (int g = 0; g < nblk; ++g) S->wave_first[g] = S->blk[g];
+        S->nwg = nwg;
+        S->nwaves = nwaves;
+        return;
+    }
     // cost of a block: its non-zeros plus a per-row term for the epilogue and a fixed per-block term
     std::vector<double> cost(nblk + 1, 0.0);
     for (int b = 0; b < nblk; ++b)
@@ -168,7 +180,7 @@ static bool build_window_panels(int64_t m, int64_t n, const int64_t* colptr, con
 }
 
 int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
-                      int nwg_target, HostBlkCsr* out, int resident_waves, int window_mode, bool row_sharded) {
+                      int nwg_target, HostBlkCsr* out, int resident_waves, int window_mode, bool row_sharded, int tall_target) {
     if (m < 0 || n < 0) { set_error("negative dimension"); return FOS_EINVAL; }
     if (n + m + 1 > (int64_t)INT32_MAX / 2) { set_error("n+m too large for int32 column indices"); return FOS_EUNSUPPORTED; }
     if (colptr[0] != 1) { set_error("colptr must be 1-based (colptr[1] == 1)"); return FOS_EINVAL; }
@@ -207,7 +219,12 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     // apply -- narrower tiles shorten a wavefront's serial chain, but every chunk adds a row-partial slot per row
     int64_t tcmax = TILE_TC_MAX;
     if (getenv("FOS_TILE_TC")) tcmax = std::max(TILE_GROUP, atoi(getenv("FOS_TILE_TC")) / TILE_GROUP * TILE_GROUP);
-    struct Group { int64_t i0; int R; int32_t c0; int64_t C; int nchunk; int64_t first_tile; };
+    struct Group { int64_t i0; int R; int32_t c0; int64_t C; int nchunk; int64_t first_tile; int tall; int sub; };
+    // TALL tiles: K vertically adjacent groups over the same run of columns (all but the last 64 rows high) form ONE block, walked
+    // by one wavefront, whose column sums are added up over the K sub-tiles before they go to the slot array: K times fewer
+    // partial-sum slots and slot-list entries for the columns (C4: 33 -> 9 per column at K = 4).  FOS_TILE_TALL = largest K.
+    struct Tall { int first_group; int K; };
+    std::vector<Tall> talls;
     std::vector<Group> groups;
     std::vector<int32_t> tile_of(m, -1);
     if (tiles_on) {
@@ -223,7 +240,7 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
                 Group g;
                 g.i0 = i; g.R = (int)(j - i); g.c0 = first_col[n + i]; g.C = alen[i];
                 g.nchunk = (int)((g.C + tcmax - 1) / tcmax);
-                g.first_tile = 0;
+                g.first_tile = 0; g.tall = 0; g.sub = 0;
                 for (int64_t q = i; q < j; ++q) tile_of[q] = (int32_t)groups.size();
                 groups.push_back(g);
             }
@@ -231,6 +248,42 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         }
     }
     const bool have_tiles = !groups.empty();
+    {
+        // stack height: the smallest K for which the tile blocks fit ONE resident round of wavefronts (`tall_target`, 16 per CU) --
+        // a small operator (a shard of a multi-GPU run) keeps K = 1 and all its parallelism, C4 (16 896 sub-tiles) takes K = 5
+        // (3 584 blocks), the dense LP C2 K = 4.  FOS_TILE_TALL forces the largest K.
+        auto blocks_at = [&](int k) {
+            int64_t nb = 0;
+            size_t a = 0;
+            while (a < groups.size()) {
+                size_t b2 = a + 1;
+                while (b2 < groups.size() && groups[b2 - 1].R == 64 && groups[b2].i0 == groups[b2 - 1].i0 + 64 &&
+                       groups[b2].c0 == groups[a].c0 && groups[b2].C == groups[a].C) ++b2;
+                nb += (int64_t)((b2 - a + k - 1) / k) * groups[a].nchunk;
+                a = b2;
+            }
+            return nb;
+        };
+        int kmax = 1;
+        const int64_t target = tall_target > 0 ? tall_target : 4096;
+        while (kmax < TILE_TALL_MAX && blocks_at(kmax) > target) ++kmax;
+        if (const char* e = getenv("FOS_TILE_TALL")) kmax = std::max(1, std::min(TILE_TALL_MAX, atoi(e)));
+        size_t g0 = 0;
+        while (g0 < groups.size()) {
+            size_t g1 = g0 + 1;        // [g0, g1): a stack of groups directly below each other over the same columns
+            while (g1 < groups.size() && groups[g1 - 1].R == 64 && groups[g1].i0 == groups[g1 - 1].i0 + 64 &&
+                   groups[g1].c0 == groups[g0].c0 && groups[g1].C == groups[g0].C) ++g1;
+            const size_t G = g1 - g0, ntall = (G + kmax - 1) / kmax;
+            size_t g = g0;
+            for (size_t q = 0; q < ntall; ++q) {                 // sizes as equal as possible: G = 33, kmax = 4 -> 4,4,4,4,4,4,3,3,3
+                const size_t K = G / ntall + (q < G % ntall ? 1 : 0);
+                for (size_t j = 0; j < K; ++j) { groups[g + j].tall = (int)talls.size(); groups[g + j].sub = (int)j; }
+                talls.push_back(Tall{(int)g, (int)K});
+                g += K;
+            }
+            g0 = g1;
+        }
+    }
 
     // ---- gather-bound operators: window panels instead of row blocks (decided from the operator; FOS_WINDOWS=0/1 forces)
     {
@@ -289,8 +342,11 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     if (have_tiles) {
         S.row_defer.assign(nrows, -1);
         ndef_slots.assign(nrows, 0);
-        for (const Group& g : groups) {
+        for (const Tall& t : talls) {
+            const Group& g = groups[t.first_group];
             for (int64_t c = g.c0; c < g.c0 + g.C; ++c) ndef_slots[c] += 1;
+        }
+        for (const Group& g : groups) {
             for (int q = 0; q < g.R; ++q) {
                 skip[n + g.i0 + q] = 1;
                 if (g.nchunk > 1) { ndef_slots[n + g.i0 + q] = g.nchunk; S.row_defer[n + g.i0 + q] = -2; }
@@ -323,37 +379,42 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         ell_cap = std::max<int64_t>(256, std::min<int64_t>(ELL_MAX, ell_cap));
     }
     if (getenv("FOS_ELL_CAP")) ell_cap = std::max(64, atoi(getenv("FOS_ELL_CAP")) / 64 * 64);
-    struct TileRec { int32_t blk; int32_t group; int32_t chunk; int32_t tpad; int32_t cslot, rslot; };
+    struct TileRec { int32_t blk; int32_t group; int32_t chunk; int32_t tpad; int32_t cslot, rslot; int32_t K; };
     std::vector<TileRec> tiles;
     int64_t pos = 0, cpos = 0;
     int64_t r = 0;
     while (r < nrows) {
         if (r >= n && tile_of[r - n] >= 0) {
-            // ---- the tile blocks of this group of rows, one per chunk of tcmax columns
+            // ---- the tile blocks of this TALL tile (K groups below each other), one per chunk of tcmax columns; sub-tile j of a
+            //      block holds rows i0 + 64 j .. and sits at nnz0 + j * 64 * tpad
             Group& g = groups[tile_of[r - n]];
-            g.first_tile = (int64_t)tiles.size();
+            const Tall& tl = talls[g.tall];
+            int64_t rows_total = 0;
+            for (int j = 0; j < tl.K; ++j) rows_total += groups[tl.first_group + j].R;
+            const int r_last = groups[tl.first_group + tl.K - 1].R;
+            for (int j = 0; j < tl.K; ++j) groups[tl.first_group + j].first_tile = (int64_t)tiles.size();
             for (int k = 0; k < g.nchunk; ++k) {
                 const int64_t tc = std::min<int64_t>(tcmax, g.C - (int64_t)k * tcmax);
                 const int64_t tpad = (tc + TILE_GROUP - 1) / TILE_GROUP * TILE_GROUP;
                 BlkDesc d{};
                 d.nnz0 = align(pos);
                 d.colpos = align(cpos);
-                d.cnt = 64 * tpad;
+                d.cnt = (int64_t)tl.K * 64 * tpad;
                 S.tile_tmax = std::max<int32_t>(S.tile_tmax, (int32_t)tpad);
                 d.row0 = (int32_t)r;
-                d.info = (int32_t)g.R | (BLK_TILE << 8) | (1 << 10) | ((int32_t)tpad << 16);
+                d.info = (int32_t)r_last | (BLK_TILE << 8) | (1 << 10) | (tl.K << 11) | ((int32_t)tpad << 16);
                 TileRec t;
-                t.blk = (int32_t)S.blk.size(); t.group = tile_of[r - n]; t.chunk = k; t.tpad = (int32_t)tpad;
+                t.blk = (int32_t)S.blk.size(); t.group = tl.first_group; t.chunk = k; t.tpad = (int32_t)tpad; t.K = tl.K;
                 t.cslot = (int32_t)S.nslots; S.nslots += tpad;
                 t.rslot = -1;
-                if (g.nchunk > 1) { t.rslot = (int32_t)S.nslots; S.nslots += g.R; }
+                if (g.nchunk > 1) { t.rslot = (int32_t)S.nslots; S.nslots += 64 * (tl.K - 1) + r_last; }
                 tiles.push_back(t);
                 S.blk.push_back(d);
                 pos = d.nnz0 + d.cnt;
                 cpos = d.colpos + 4;                // first column, column-slot base, row-slot base, real columns
-                S.tile_values += (int64_t)g.R * tc;
+                S.tile_values += rows_total * tc;
             }
-            r += g.R;
+            r += rows_total;
             continue;
         }
         if (skip[r]) { ++r; continue; }
@@ -519,7 +580,7 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
                     const Group& g = groups[tile_of[i]];
                     const int64_t cc = j - g.c0;
                     const TileRec& t = tiles[g.first_tile + cc / tcmax];
-                    S.val[S.blk[t.blk].nnz0 + (cc % tcmax) * 64 + (i - g.i0)] = nzval[k];
+                    S.val[S.blk[t.blk].nnz0 + (int64_t)g.sub * 64 * t.tpad + (cc % tcmax) * 64 + (i - g.i0)] = nzval[k];
                     continue;
                 }
                 const int64_t off = place(n + i, fill[i]++);
@@ -553,7 +614,10 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             const int64_t tc = std::min<int64_t>(tcmax, g.C - (int64_t)t.chunk * tcmax);
             for (int64_t c = 0; c < tc; ++c) idx[cur[cc0 + c]++] = t.cslot + (int32_t)c;
             if (t.rslot >= 0)
-                for (int q = 0; q < g.R; ++q) idx[cur[n + g.i0 + q]++] = t.rslot + q;
+                for (int j = 0; j < t.K; ++j) {
+                    const Group& gj = groups[t.group + j];
+                    for (int q = 0; q < gj.R; ++q) idx[cur[n + gj.i0 + q]++] = t.rslot + 64 * j + q;
+                }
         }
         S.def_ptr.push_back(0);
         for (int64_t q = 0; q < nrows; ++q) {
@@ -632,26 +696,37 @@ int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::st
         if (d.nnz0 % NNZ_ALIGN) return fail("block not aligned", b);
         const int R = d.nrows();
         if (d.kind() == BLK_TILE) {
-            const int T = d.steps();
-            if (d.cnt != 64 * (int64_t)T || T % TILE_GROUP || R > 64) return fail("bad tile block", b);
-            const int64_t c0 = S.col[d.colpos], cslot = S.col[d.colpos + 1], rslot = S.col[d.colpos + 2], tc = S.col[d.colpos + 3];
+            const int T = d.steps(), K = d.tall();
+            if (K < 1 || K > TILE_TALL_MAX || d.cnt != (int64_t)K * 64 * T || T % TILE_GROUP || R > 64) return fail("bad tile block", b);
+            const int64_t c0 = d.meta[0], cslot = d.meta[1], rslot = d.meta[2], tc = d.meta[3];
+            for (int q = 0; q < 4; ++q) if (S.col[d.colpos + q] != d.meta[q]) return fail("tile descriptor and column copy disagree in block", b);
+            const int64_t rows_total = 64 * (int64_t)(K - 1) + R;
             if (c0 < 0 || tc < 1 || tc > T || T - tc >= TILE_GROUP || c0 + tc > S.nrows) return fail("tile columns out of range in block", b);
-            if (cslot < 0 || cslot + T > S.nslots || (rslot >= 0 && rslot + R > S.nslots)) return fail("tile slots out of range in block", b);
-            for (int t = 0; t < T; ++t) {                                        // column sums: over the lanes
-                double acc = 0.0;
-                for (int lane = 0; lane < 64; ++lane) {
-                    const double a = S.val[d.nnz0 + (int64_t)t * 64 + lane];
-                    if (lane >= R || t >= tc) { if (a != 0.0) return fail("tile padding not zero in block", b); continue; }
-                    acc += a * v[d.row0 + lane];
+            if (cslot < 0 || cslot + T > S.nslots || (rslot >= 0 && rslot + rows_total > S.nslots)) return fail("tile slots out of range in block", b);
+            for (int t = 0; t < T; ++t) {                                        // column sums: sub-tile by sub-tile, over the lanes
+                double tot = 0.0;
+                for (int j = 0; j < K; ++j) {
+                    const int Rj = (j + 1 < K) ? 64 : R;
+                    double acc = 0.0;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const double a = S.val[d.nnz0 + ((int64_t)j * T + t) * 64 + lane];
+                        if (lane >= Rj || t >= tc) { if (a != 0.0) return fail("tile padding not zero in block", b); continue; }
+                        acc += a * v[d.row0 + 64 * j + lane];
+                    }
+                    tot = (j == 0) ? acc : tot + acc;
                 }
-                slots[cslot + t] = acc;
+                slots[cslot + t] = tot;
                 slot_written[cslot + t]++;
             }
-            for (int lane = 0; lane < R; ++lane) {                                // row sums: over the steps
-                double acc = 0.0;
-                for (int t = 0; t < tc; ++t) acc += S.val[d.nnz0 + (int64_t)t * 64 + lane] * v[c0 + t];
-                if (rslot >= 0) { slots[rslot + lane] = acc; slot_written[rslot + lane]++; }
-                else { out[d.row0 + lane] = acc; seen[d.row0 + lane]++; }
+            for (int j = 0; j < K; ++j) {                                        // row sums: over the steps
+                const int Rj = (j + 1 < K) ? 64 : R;
+                for (int lane = 0; lane < Rj; ++lane) {
+                    double acc = 0.0;
+                    for (int t = 0; t < tc; ++t) acc += S.val[d.nnz0 + ((int64_t)j * T + t) * 64 + lane] * v[c0 + t];
+                    const int64_t row = d.row0 + 64 * j + lane;
+                    if (rslot >= 0) { slots[rslot + 64 * j + lane] = acc; slot_written[rslot + 64 * j + lane]++; }
+                    else { out[row] = acc; seen[row]++; }
+                }
             }
         } else if (d.kind() == BLK_LONG) {
             const int64_t stride = (d.cnt + NNZ_ALIGN - 1) / NNZ_ALIGN * NNZ_ALIGN;

@@ -63,6 +63,7 @@ constexpr int TILE_MIN_ROWS = 16;   // fewer rows: not worth a 64-lane wavefront
 constexpr int TILE_MIN_COLS = 8;
 constexpr int TILE_TC_MAX = 64;     // columns (steps) per tile: 32 KB of values per wavefront work unit (measured best on C2: 32..128 tried)
 constexpr int TILE_GROUP = 8;       // steps per butterfly; stored steps are padded to a multiple
+constexpr int TILE_TALL_MAX = 16;   // sub-tiles a tall tile may stack (5 bits in the descriptor)
 
 // Window panels (gather-bound random-sparse operators, C5 class).  A PANEL = WIN_ROWS consecutive rows of S, the unit of
 // work of ONE WORKGROUP (two of them share a CU), which walks the column WINDOWS (WIN_COLS consecutive entries of the stacked vector) its rows touch:
@@ -87,13 +88,15 @@ struct BlkDesc {                    // one row block = the unit of work of ONE w
                                     // all have consecutive columns -- one first-column per row (index compression)
     int64_t cnt;                    // stored values (ELL: 64 * steps, padding included; LONG: entries per row, rows at stride align4(cnt))
     int32_t row0;                   // first row
-    int32_t info;                   // nrows (bits 0..7) | kind << 8 | run << 10 | ELL steps T << 16
+    int32_t info;                   // nrows (bits 0..7; dual tile: rows of its LAST sub-tile) | kind << 8 | run << 10 | sub-tiles of a
+                                    // tall dual tile << 11 (5 bits) | ELL steps T << 16
     int32_t meta[4];                // dual tile: first column, column-slot base, row-slot base (-1: none), real columns -- in the
                                     // descriptor so that a tile costs ONE dependent load before its values, not two (0 otherwise)
     __host__ __device__ int nrows() const { return info & 0xFF; }
     __host__ __device__ int kind() const { return (info >> 8) & 0x3; }
     __host__ __device__ int run() const { return (info >> 10) & 0x1; }
     __host__ __device__ int steps() const { return (info >> 16) & 0xFFFF; }
+    __host__ __device__ int tall() const { return (info >> 11) & 0x1F; }
 };
 
 // Host-side result of building the stacked operator; uploaded verbatim.
@@ -161,7 +164,7 @@ struct DevBlkCsr {
 // Builds S = [[0, A'],[A, 0]] from Julia CSC (1-based).  Returns FOS_EINVAL on malformed input.
 int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
                       int nwg_target, HostBlkCsr* out, int resident_waves = 0, int window_mode = -1,   // -1: decide from the operator, 0 / 1: force
-                      bool row_sharded = false);
+                      bool row_sharded = false, int tall_target = 0);   // tall_target: tile blocks that fit one resident round (0: 4096)
 void partition_workgroups(HostBlkCsr* S, int nwg_target);
 int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::string* why);
 constexpr int DEF_THREADS = 256;    // deferred-row kernel: one thread per deferred row

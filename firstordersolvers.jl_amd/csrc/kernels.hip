@@ -362,33 +362,32 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
         } else if (kind == BLK_TILE) {
             // ---------------- dual tile: lane = row, step = column; row sums stay in the lanes, column sums go to slots
             if constexpr (DEFER) {
-                const int R = d.nrows(), T = d.steps();
+                // A TALL tile: K sub-tiles of 64 rows (the last: d.nrows()) below each other over the same tc columns.  Per
+                // sub-tile the row sums stay in the lanes; the column sums of 8 steps at a time come out of the butterfly in
+                // lanes 0..7 and are ADDED UP over the sub-tiles in the wavefront's LDS slice (same lane, same address: no
+                // hazard), so that one slot per column leaves the tall tile -- K times fewer slots for whoever adds the lists.
+                const int Rl = d.nrows(), T = d.steps(), K = d.tall();
                 const int c0 = d.meta[0], cslot = d.meta[1], rslot = d.meta[2], tc = d.meta[3];      // (tc: real columns; steps beyond are padding)
+                d2* __restrict__ slots = reinterpret_cast<d2*>(S.slots);
+                d2* colacc = reinterpret_cast<d2*>(prod);
+                for (int j = 0; j < K; ++j) {
+                const int R = (j + 1 < K) ? 64 : Rl;
                 const bool valid = lane < R;
-                const int row = d.row0 + lane;
+                const int row = d.row0 + 64 * j + lane;
                 RowPre pr{};
                 if (valid && rslot < 0) pr = epi.pre(row);
                 const d2 wr = valid ? gat.load(row) : make_double2(0.0, 0.0);
-                const double* __restrict__ val = S.val + d.nnz0 + lane;
-                d2* __restrict__ slots = reinterpret_cast<d2*>(S.slots);
+                const double* __restrict__ val = S.val + d.nnz0 + (int64_t)j * 64 * T + lane;
                 double r1 = 0.0, r2 = 0.0;
-                {
                 double vn[TILE_GROUP];                 // the next group's values are in flight while this group is reduced
-                // the element of this lane's column slot (lanes 0..7), for epi.park: fetched one group AHEAD and BEFORE that
-                // group's values -- vmcnt retires in order, so a load issued behind the value prefetch could only be waited
-                // for together with it, which would serialise the pipeline
-                d2 xln = make_double2(0.0, 0.0);
-                if constexpr (Epi::FOLDDEF) { if (lane < TILE_GROUP && lane < tc) xln = gat.load(c0 + lane); }
 #pragma unroll
                 for (int u = 0; u < TILE_GROUP; ++u) vn[u] = mload<G::NT>(val + 64 * u);
                 for (int t = 0; t < T; t += TILE_GROUP) {
                     double v[TILE_GROUP];
                     d2 x[TILE_GROUP];
-                    const d2 xl = xln;
 #pragma unroll
                     for (int u = 0; u < TILE_GROUP; ++u) v[u] = vn[u];
                     if (t + TILE_GROUP < T) {
-                        if constexpr (Epi::FOLDDEF) { if (lane < TILE_GROUP && t + TILE_GROUP + lane < tc) xln = gat.load(c0 + t + TILE_GROUP + lane); }
 #pragma unroll
                         for (int u = 0; u < TILE_GROUP; ++u) vn[u] = mload<G::NT>(val + 64 * (t + TILE_GROUP + u));
                     }
@@ -423,15 +422,26 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
                         if constexpr (NRHS == 2) s2 = tile_colsum8(p2, lane);
                     }
                     if (lane < TILE_GROUP) {
-                        slots[cslot + t + lane] = make_double2(s1, s2);
-                        epi.park(c0 + t + lane, s1, s2, xl);
+                        if (j > 0) { const d2 o = colacc[t + lane]; s1 += o.x; s2 += o.y; }
+                        colacc[t + lane] = make_double2(s1, s2);
                     }
-                }
                 }
                 if (valid) {
                     if (rslot < 0) epi.row(row, r1, r2, pr);
-                    else { slots[rslot + lane] = make_double2(r1, r2); epi.park(row, r1, r2, wr); }
+                    else { slots[rslot + 64 * j + lane] = make_double2(r1, r2); epi.park(row, r1, r2, wr); }
                 }
+                }
+                // the tall tile's column sums: lane = column
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < T) {
+                    const d2 sc = colacc[lane];
+                    slots[cslot + lane] = sc;
+                    if constexpr (Epi::FOLDDEF) { if (lane < tc) epi.park(c0 + lane, sc.x, sc.y, gat.load(c0 + lane)); }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         } else if (kind == BLK_ELL) {
             // ---------------- lane-major block: lane (row, lig) owns entries lig, lig + tpr, ... of its row

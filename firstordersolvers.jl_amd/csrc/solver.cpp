@@ -987,7 +987,7 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     // ---- operator
     HostBlkCsr& hs = h->hostS;
     h->row_sharded = (flags & FOS_CREATE_ROW_SHARDED) != 0;
-    FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, h->nwg_target, &hs, cus * 28, -1, h->row_sharded));
+    FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, h->nwg_target, &hs, cus * 28, -1, h->row_sharded, cus * 16));
     const bool windowed = !hs.wpanel.empty();
     if (!windowed && !getenv("FOS_SPMV_WG") && hs.nblk / SPMV_WAVES < h->nwg_target) {
         // small operators: one row block per wavefront up to ONE resident round of workgroups (4 per CU); beyond that a
@@ -1055,7 +1055,9 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
         const double op_bytes = 8.0 * (double)hs.nnz_padded + 4.0 * (double)hs.ncol_stored + 48.0 * (double)hs.nblk;
         // (measured: C3, 12 MB, sweep 22.0 -> 17.1 us; the 64-block shard of C4, 34 MB = 4.3 MB per XCD against 4 MB of L2 each,
         //  24.5 -> 26.2 us per CG iteration: an operator that does not fit the L2s only evicts the vectors)
-        h->S.resident = (!windowed && op_bytes <= 20e6) ? 1 : 0;
+        //  (C3's stored form is 34.4 MB too -- what differs is the access: row blocks that GATHER (explicit column indices, latency
+        //  bound) gain from a cache-resident matrix, a streamed dual-tile operator of that size does not)
+        h->S.resident = (!windowed && hs.ntiles == 0 && op_bytes <= 48e6) ? 1 : 0;
         if (const char* e = getenv("FOS_RESIDENT")) h->S.resident = atoi(e) != 0 ? 1 : 0;
     }
     h->S.row_rel = drr; h->S.wave_blk0 = dwv; h->S.wave_first = dwf; h->S.nblk = hs.nblk; h->S.nwg = hs.nwg; h->S.nwaves = hs.nwaves;

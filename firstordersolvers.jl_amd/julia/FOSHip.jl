@@ -111,6 +111,9 @@ for T in (:GAP, :GAPA, :FISTA, :Dykstra)
                 HSDEStatus(sm, sn, 0, mo, :Continue, checki, eps, verbose, false, alg.direct, time_ns(), model.init_duration, debug)
             data = HipData(model, get(model.options, :device, 0))
             set_alg!(data, alg)
+            if haskey(model.options, :cg_variant)      # device-side key: which CG recurrence the affine projection runs (FOS_CG_* of foship.h)
+                check(ccall((:fos_set_cg_variant, libfoship), Cint, (Ptr{Cvoid}, Int32), data.handle, Int32(model.options[:cg_variant])))
+            end
             if alg.direct            # HSDE.jl:12-15: S1 = IndAffine([Q -I], 0) -> exact projection, (I + Q Q')^-1 formed once on the device
                 A = model.A
                 GC.@preserve A check(ccall((:fos_enable_direct, libfoship), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}),

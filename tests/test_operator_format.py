@@ -211,3 +211,34 @@ def test_window_panels_chosen_for_large_random_sparse_only(pkg):
     dense = sp.csc_matrix(rng.standard_normal((128, 96)))
     st = _host_spmv_mode(pkg, dense, rng.standard_normal(224), -1)[1]
     assert st[12] == 0 and st[8] > 0
+
+
+def test_tall_dual_tiles_stack_vertically_adjacent_groups(pkg, monkeypatch):
+    """Tall dual tiles (fos_internal.hpp): K groups of 64 rows below each other over the same columns become ONE block whose
+    column sums leave it added up -- K times fewer partial-sum slots.  The host walk (same traversal as the kernel) must give
+    S v for every K, the stored values never change, and the slot count shrinks as the stacks grow."""
+    import ctypes as C
+    lib = pkg.lib.load()
+    rng = np.random.default_rng(0)
+    A = sp.block_diag([rng.standard_normal((300, 20)) for _ in range(3)] + [rng.standard_normal((70, 150))], format="csc")
+    m, n = A.shape
+    S = sp.bmat([[None, A.T], [A, None]]).tocsr()
+    v = rng.standard_normal(m + n)
+    ref = S @ v
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    colptr, rowval, nz = (A.indptr + 1).astype(np.int64), (A.indices + 1).astype(np.int64), A.data.astype(np.float64)
+    seen = {}
+    for tall in (1, 2, 3, 4, 8, 16):
+        monkeypatch.setenv("FOS_TILE_TALL", str(tall))
+        out = np.empty(m + n)
+        st = (C.c_int64 * 12)()
+        rc = lib.fos_host_stacked_spmv(m, n, p(colptr, C.c_int64), p(rowval, C.c_int64), p(nz, C.c_double), p(v, C.c_double),
+                                       p(out, C.c_double), 0, 0, st)
+        assert rc == 0, lib.fos_last_error()
+        assert np.linalg.norm(out - ref) <= 1e-13 * np.linalg.norm(ref), tall
+        seen[tall] = dict(blocks=st[0], vals=st[5], tiles=st[8], slots=st[9], deferred=st[10], tile_vals=st[11])
+    assert len({s["vals"] for s in seen.values()}) == 1 and len({s["tile_vals"] for s in seen.values()}) == 1
+    assert seen[1]["tiles"] == 3 * 5 + 3              # 300 rows = 5 groups per block; 70 x 150: one 64-row group x three 64-column chunks (6 rows left over)
+    assert seen[4]["tiles"] == 3 * 2 + 3 and seen[8]["tiles"] == 3 * 1 + 3
+    slots = [seen[t]["slots"] for t in (1, 2, 3, 4, 8, 16)]
+    assert all(a >= b for a, b in zip(slots, slots[1:])) and slots[0] > slots[3] > 0
