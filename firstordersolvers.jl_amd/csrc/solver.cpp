@@ -989,19 +989,20 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     h->row_sharded = (flags & FOS_CREATE_ROW_SHARDED) != 0;
     FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, h->nwg_target, &hs, cus * 28, -1, h->row_sharded, cus * 16));
     const bool windowed = !hs.wpanel.empty();
-    if (!windowed && !getenv("FOS_SPMV_WG") && hs.nblk / SPMV_WAVES < h->nwg_target) {
+    if (!windowed && !getenv("FOS_SPMV_WG") && hs.ntiles > hs.nblk / 2) {
+        // tile-dominated operator: the blocks are (nearly) equal work units, so give every wavefront the SAME whole number of them
+        // -- one, unless that needs more than 16384 workgroups (C4: 16896 tiles over 12288 wavefronts leaves 3/8 of them with
+        // twice the work: 77 us; 4224 workgroups: 71 us; tall tiles: 8704 blocks over 4096 wavefronts 73 us, one each 64)
+        const int64_t waves_target = (int64_t)h->nwg_target * SPMV_WAVES;
+        int64_t per_wave = std::max<int64_t>(1, (hs.nblk + waves_target / 2) / waves_target);
+        while ((hs.nblk + SPMV_WAVES * per_wave - 1) / (SPMV_WAVES * per_wave) > 16384) ++per_wave;
+        h->nwg_target = (int)((hs.nblk + SPMV_WAVES * per_wave - 1) / (SPMV_WAVES * per_wave));
+        partition_workgroups(&hs, h->nwg_target);
+    } else if (!windowed && !getenv("FOS_SPMV_WG") && hs.nblk / SPMV_WAVES < h->nwg_target) {
         // small operators: one row block per wavefront up to ONE resident round of workgroups (4 per CU); beyond that a
         // wavefront walks several blocks rather than queueing a second round behind the first (C3, 11 736 blocks: 2 934
         // workgroups 38.3 us per CG iteration, 1 024: 32.6, 1 152: 40.7)
         h->nwg_target = std::min(cus * 4, std::max(cus, (hs.nblk + SPMV_WAVES - 1) / SPMV_WAVES));
-        partition_workgroups(&hs, h->nwg_target);
-    }
-    if (!windowed && !getenv("FOS_SPMV_WG") && hs.ntiles > hs.nblk / 2 && hs.nblk / SPMV_WAVES >= h->nwg_target) {
-        // tile-dominated operator: the blocks are equal work units, so give every wavefront the SAME whole number of them
-        // (C4: 16896 tiles over 12288 wavefronts leaves 3/8 of them with twice the work: 77 us; 4224 workgroups: 71 us)
-        const int64_t waves_target = (int64_t)h->nwg_target * SPMV_WAVES;
-        const int64_t per_wave = std::max<int64_t>(1, (hs.nblk + waves_target / 2) / waves_target);
-        h->nwg_target = (int)std::min<int64_t>(16384, (hs.nblk + SPMV_WAVES * per_wave - 1) / (SPMV_WAVES * per_wave));
         partition_workgroups(&hs, h->nwg_target);
     }
     double* dval; int32_t* dcol; BlkDesc* dblk; uint16_t* drr; int32_t* dwv;

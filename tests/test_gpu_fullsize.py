@@ -124,7 +124,7 @@ def test_c4_operators_and_projections_full_size(pkg, c4):
     # all 16384 columns of A finished by the deferred-row kernel
     st = d.operator_stats()
     # (33 tiles of 64 rows per block, stacked into tall tiles of at most FOS_TILE_TALL (default 4) sub-tiles: 9 blocks of 4,4,4,4,4,4,3,3,3)
-    assert st["tiles"] in (512 * 33, 512 * 17, 512 * 9, 512 * 5, 512 * 3) and st["tile_vals"] == prob.nnz and st["deferred"] == prob.n
+    assert st["tiles"] % 512 == 0 and 3 <= st["tiles"] // 512 <= 33 and st["tile_vals"] == prob.nnz and st["deferred"] == prob.n
     assert st["slots"] == 32 * st["tiles"]
     assert prob.nnz <= st["vals"] <= 1.05 * prob.nnz and st["cols"] < 0.01 * prob.nnz, st
     rng = np.random.default_rng(0)

@@ -10,9 +10,9 @@ run() { # tag env... -- flags
   envs=""; while [ "$1" != "--" ]; do envs="$envs $1"; shift; done; shift
   env $envs python3 bench.py --no-cpu-baseline --steps 30 "$@" 2> $OUT/$tag.err | tail -1 > $OUT/$tag.json
 }
-for K in 1 2 3 5 8; do run c4_k$K FOS_TILE_TALL=$K -- ; done
+for K in 1 2 3 4 5 6 8; do run c4_k$K FOS_TILE_TALL=$K -- ; done
 run c4_auto A=1 --
-for K in 1 2 4 8; do run c2_k$K FOS_TILE_TALL=$K -- --workload C2; done
+for K in 1 2 4 8 16; do run c2_k$K FOS_TILE_TALL=$K -- --workload C2; done
 run c3 A=1 -- --workload C3
 python3 - <<'PY'
 import json,glob
