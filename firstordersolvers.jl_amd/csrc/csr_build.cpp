@@ -249,24 +249,16 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     }
     const bool have_tiles = !groups.empty();
     {
-        // stack height: the smallest K for which the tile blocks fit ONE resident round of wavefronts (`tall_target`, 16 per CU) --
-        // a small operator (a shard of a multi-GPU run) keeps K = 1 and all its parallelism, C4 (16 896 sub-tiles) takes K = 5
-        // (3 584 blocks), the dense LP C2 K = 4.  FOS_TILE_TALL forces the largest K.
-        auto blocks_at = [&](int k) {
-            int64_t nb = 0;
-            size_t a = 0;
-            while (a < groups.size()) {
-                size_t b2 = a + 1;
-                while (b2 < groups.size() && groups[b2 - 1].R == 64 && groups[b2].i0 == groups[b2 - 1].i0 + 64 &&
-                       groups[b2].c0 == groups[a].c0 && groups[b2].C == groups[a].C) ++b2;
-                nb += (int64_t)((b2 - a + k - 1) / k) * groups[a].nchunk;
-                a = b2;
-            }
-            return nb;
-        };
-        int kmax = 1;
-        const int64_t target = tall_target > 0 ? tall_target : 4096;
-        while (kmax < TILE_TALL_MAX && blocks_at(kmax) > target) ++kmax;
+        // stack height.  Measured (MI355X, outer iterations per second, FOS_TILE_TALL = 1 / 2 / 3 / 4 / 5 / 6 / 8):
+        //   C4 (33 groups per block column, ONE column chunk):   517 / 511 / 521 / 483 / 491 / 515 / 496 -- the update kernel gains what
+        //      the sweep loses (fewer, longer wavefronts; grids that do not divide evenly over the CUs lose 5 %): K = 1 stays;
+        //   C2 (dense LP, 79 groups x 157 column chunks):        196 / 203 / - / 193 / - / - / 212 (16: 159) -- a quarter of the sweep's
+        //      slot traffic and of the update kernel's list entries goes away: K = 8.
+        // So: stack only operators whose rows are cut into several column chunks (their slot arrays are large), eight high.
+        (void)tall_target;
+        bool multi_chunk = false;
+        for (const Group& g : groups) multi_chunk = multi_chunk || g.nchunk > 1;
+        int kmax = multi_chunk ? 8 : 1;
         if (const char* e = getenv("FOS_TILE_TALL")) kmax = std::max(1, std::min(TILE_TALL_MAX, atoi(e)));
         size_t g0 = 0;
         while (g0 < groups.size()) {
