@@ -53,15 +53,17 @@ def tolerance_floor_iteration(l_global):
 
 
 
-def build_problem(pkg, workload, nranks, rank, small, weak=False):
+def build_problem(pkg, workload, nranks, rank, small, weak=False, c4_scale=None):
     w = pkg.workloads
     if workload == "C4":
         nb = 64 if small else 512
         if weak:
             nb *= nranks                                  # every rank owns 512 blocks of a 512 N-block problem
         lo, hi = (nb * rank) // nranks, (nb * (rank + 1)) // nranks
-        prob = w.c4_block_sdp(nblocks=nb, block_range=(lo, hi))
+        prob = w.c4_block_sdp(nblocks=nb, block_range=(lo, hi), scale=c4_scale)
         desc = "C4 block-diagonal SDP, %d PSD(64) blocks, 32 free vars/block, DR" % nb
+        if c4_scale is not None:
+            desc += " [A_j / %g instead of A_j / 32]" % c4_scale
         alg = pkg.DR()
         glob = dict(m=nb * 2080, n=nb * 32, nnz=nb * 2080 * 32)
     elif workload == "C5":
@@ -106,6 +108,9 @@ def main():
                     help="N > 1, C4: strong = the 512-block problem split over the ranks (default, the metric's definition); "
                          "weak = 512 blocks per rank")
     ap.add_argument("--no-weak-extra", action="store_true", help="N > 1: skip the additional weak-scaling measurement")
+    ap.add_argument("--c4-scale", type=float, default=None,
+                    help="C4: divide the random symmetric constraint matrices by this instead of 32 (1 = the raw, badly conditioned "
+                         "instance: ~4x the CG iterations per outer iteration; not the headline configuration)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -169,7 +174,7 @@ def main():
         """Build the (shard of the) problem, warm up to the steady state, time exactly --steps outer iterations."""
         reduction = "in-stream RCCL all-reduce"
         t0 = time.time()
-        prob, alg, desc, glob = build_problem(pkg, args.workload, world, rank, args.small, weak=weak)
+        prob, alg, desc, glob = build_problem(pkg, args.workload, world, rank, args.small, weak=weak, c4_scale=args.c4_scale)
         t_gen = time.time() - t0
         t0 = time.time()
         dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2, device=local_rank)
@@ -387,8 +392,9 @@ def main():
                 "parallelism": "cone-sharded x%d (scalar sums: %s)" % (world, reduction) if dist is not None else "single GPU",
                 "residuals_after_run": {"p": chk.p, "d": chk.d, "g": chk.g, "iteration": it},
                 "setup_s": round(t_setup, 2), "generate_s": round(t_gen, 2),
-                "instance_note": "data scaled as BASELINE.md 3 records (||b|| = ||c|| = 10, A_j / 32): a well-conditioned instance, 17 CG "
-                                 "iterations per outer iteration at the floor; unscaled data needs ~75" if args.workload == "C4" else None,
+                "instance_note": ("data scaled as BASELINE.md 3 records (||b|| = ||c|| = 10, A_j / 32): a well-conditioned instance, 17 CG "
+                                  "iterations per outer iteration at the floor; unscaled data needs ~75" if args.c4_scale is None else
+                                  "NOT the headline instance: A_j / %g" % args.c4_scale) if args.workload == "C4" else None,
             },
             "dominant_kernel": dominant,
             "time_shares": shares,

@@ -56,3 +56,20 @@ def test_bench_two_ranks_on_one_gpu_matches_single_rank():
     for k in ("p", "d", "g"):
         assert rb[k] == pytest.approx(ra[k], rel=1e-4), k
     assert out2["config"]["cg_iters_per_step"] == pytest.approx(out1["config"]["cg_iters_per_step"], abs=1.5)
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how a user -- or a driver without torchrun -- calls it): the
+    script starts torch.distributed.run itself, as a child process and before it touches the GPU, passes the ranks' single JSON
+    line through and exits with the launcher's code.  (gloo coordination: two ranks share the test box's one GPU.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(FOS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--small", "--no-weak-extra"]
+    r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0
+    assert out["config"]["cg_variant"] == "merged_update" and out["config"]["cg_launches_per_iteration"] == 2
+    # a failing child must fail the call: an unknown workload makes every rank exit non-zero
+    bad = subprocess.run(cmd + ["--workload", "nope"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0

@@ -453,3 +453,26 @@ def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname):
     assert np.linalg.norm(zz - z) <= tol * max(1.0, np.linalg.norm(z))
     assert g0["res"]["norm_b"] == pytest.approx(res.norm_b, rel=1e-12) and g0["res"]["norm_c"] == pytest.approx(res.norm_c, rel=1e-12)
     d0.close()
+    # ... and against the ORACLE (not another HIP handle): the gathered operator product, the status values on the common vector
+    # and the first outer iteration of the reference's recurrences on the whole problem (the oracle's own RowShardedSpace run
+    # equals its unsharded run: tests/test_sharding_gloo.py::test_row_sharded_oracle_matches_unsharded)
+    orc = oracle
+    codes = lambda cs: [(orc.CONE_CODES[k], l) for k, l in cs]
+    om = orc.Model(prob.A, prob.b, prob.c, codes(prob.K1), codes(prob.K2))
+    ref = np.empty(zg.shape[0])
+    orc.KKTMatrix(orc.HSDEMatrixQ(prob.A, prob.b, prob.c)).mul(ref, zg)                # affinepluslinear.jl:37-52
+    assert np.linalg.norm(kk - ref) <= 1e-12 * np.linalg.norm(ref)
+    ost = orc.HSDEStatus(om, 10, 1e-6, 0, 1)
+    ost.i = 1
+    ost.checkstatus(zg, override=True)                                                  # HSDEStatus.jl:27-71
+    for key in ("p", "d", "g", "ctx", "bty"):
+        assert g0["chk"][key] == pytest.approx(ost.last[key], rel=1e-9, abs=1e-12), key
+    oalg = {"DR": orc.DR, "GAPA": lambda: orc.GAPA(0.8, 0.5)}[algname]()
+    oalg.init(om)
+    oalg.S1.cg_variant = "merged"                 # the recurrence sharded handles run (conjugategradient_merged)
+    xo = orc.hsde_initialvalue(om)
+    st1 = orc.HSDEStatus(om, 10 ** 9, 1e-9, 0, 0)
+    st1.i = 1
+    oalg.step(xo, 1, st1)
+    assert abs(g0["cg"][0] - oalg.S1.getcgiter()) <= 1
+    assert np.linalg.norm(zz1 - xo) <= 1e-7 * max(1.0, np.linalg.norm(xo))
