@@ -620,6 +620,24 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             S.def_ptr.push_back((int32_t)S.def_idx.size());
         }
     }
+    // ---- the lists in the form the kernels read: own partial first, then a progression of tile partials where it is one
+    S.def_rec.resize(S.def_rows.size());
+    for (size_t q = 0; q < S.def_rows.size(); ++q) {
+        DefRow& d = S.def_rec[q];
+        d = DefRow{};
+        d.row = S.def_rows[q];
+        int32_t k0 = S.def_ptr[q];
+        const int32_t k1 = S.def_ptr[q + 1];
+        d.own = -1;
+        if (!S.row_defer.empty() && S.row_defer[d.row] >= 0 && k0 < k1 && S.def_idx[k0] == S.row_defer[d.row]) { d.own = S.def_idx[k0]; ++k0; }
+        d.count = k1 - k0;
+        d.kidx = k0;
+        d.base = d.count > 0 ? S.def_idx[k0] : 0;
+        d.stride = d.count > 1 ? S.def_idx[k0 + 1] - S.def_idx[k0] : 0;
+        for (int32_t k = k0 + 1; k < k1 && d.stride != DEF_EXPLICIT; ++k)
+            if (S.def_idx[k] - S.def_idx[k - 1] != d.stride) d.stride = DEF_EXPLICIT;
+        if (getenv("FOS_DEF_EXPLICIT")) d.stride = DEF_EXPLICIT;
+    }
     partition_workgroups(&S, nwg_target);
     return FOS_OK;
 }
@@ -772,6 +790,16 @@ int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::st
         if (row < 0 || row >= S.nrows || !defer || S.row_defer[row] == -1) return fail("deferred row without a flag:", row);
         if (q > 0 && S.def_rows[q - 1] >= row) return fail("deferred rows not ascending at", (long long)q);
         double acc = 0.0;
+        if (S.def_rec.size() != S.def_rows.size()) return fail("slot-list records missing", (long long)S.def_rec.size());
+        {
+            const DefRow& dr = S.def_rec[q];                    // the form the kernels read must spell the same list
+            if (dr.row != row || dr.count + (dr.own >= 0 ? 1 : 0) != S.def_ptr[q + 1] - S.def_ptr[q]) return fail("slot-list record of row", row);
+            for (int32_t e = 0; e < S.def_ptr[q + 1] - S.def_ptr[q]; ++e) {
+                const int32_t k = e - (dr.own >= 0 ? 1 : 0);
+                const int32_t sl2 = (dr.own >= 0 && e == 0) ? dr.own : (dr.stride != DEF_EXPLICIT ? dr.base + k * dr.stride : S.def_idx[dr.kidx + k]);
+                if (sl2 != S.def_idx[S.def_ptr[q] + e]) return fail("slot-list record disagrees with the list of row", row);
+            }
+        }
         for (int32_t k = S.def_ptr[q]; k < S.def_ptr[q + 1]; ++k) {
             const int32_t sl = S.def_idx[k];
             if (sl < 0 || sl >= S.nslots) return fail("slot out of range for row", row);

@@ -148,16 +148,29 @@ __device__ __forceinline__ bool peer_fold_sum(const PeerBox& pb, uint32_t seq, d
     return true;
 }
 
-// A lane's share of a slot-spread row's list (entries k0, k0 + lpr, ... < k1): index loads of a chunk of four entries, then the
-// four slot loads, then the adds in list order -- two memory round trips per chunk instead of two per entry (on small operators
-// this loop is the latency of the kernel; C4: 33 slots per row over 8 lanes = one chunk and a tail).
-__device__ __forceinline__ void slot_list_sum(const d2* __restrict__ slots, const int32_t* __restrict__ def_idx, int k0, int k1, int lpr,
+// A lane's share of a slot-spread row's list (DefRow, fos_internal.hpp): list elements lig, lig + lpr, ... in chunks of four --
+// the four slot numbers (computed for a progression, loaded for an explicit list), then the four slot loads, then the adds in list
+// order.  On small operators this loop is the latency of the kernels that add the lists.
+__device__ __forceinline__ DefRow ld_defrow(const DefRow* p) {
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    union { v4i_ q[2]; DefRow d; } u;
+    const v4i_* src = reinterpret_cast<const v4i_*>(p);
+    u.q[0] = src[0]; u.q[1] = src[1];
+    return u.d;
+}
+__device__ __forceinline__ int defrow_slot(const DefRow& r, const int32_t* __restrict__ def_idx, int e) {
+    const int k = e - (r.own >= 0 ? 1 : 0);
+    if (k < 0) return r.own;
+    return r.stride != DEF_EXPLICIT ? r.base + k * r.stride : def_idx[r.kidx + k];
+}
+__device__ __forceinline__ void slot_list_sum(const d2* __restrict__ slots, const int32_t* __restrict__ def_idx, const DefRow& r, int e0, int lpr,
                                               double& u1, double& u2) {
-    for (int k = k0; k < k1; k += 4 * lpr) {
+    const int n = r.count + (r.own >= 0 ? 1 : 0);
+    for (int e = e0; e < n; e += 4 * lpr) {
         int id[4];
         d2 v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) id[q] = (k + q * lpr < k1) ? def_idx[k + q * lpr] : -1;
+        for (int q = 0; q < 4; ++q) id[q] = (e + q * lpr < n) ? defrow_slot(r, def_idx, e + q * lpr) : -1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = id[q] >= 0 ? slots[id[q]] : make_double2(0.0, 0.0);
 #pragma unroll

@@ -82,6 +82,14 @@ struct WinSeg { int32_t col0, ncols, slice0, nslice; };
 struct WinSlice { int64_t off; int32_t steps, pad; };       // values/columns at off + 64 t + lane (off a multiple of 64)
 
 
+// One slot-spread row and its list of partial-sum slots, in summation order: [its own partial `own` (>= 0) from the sweep] followed
+// by `count` tile partials, which for regular tilings form an arithmetic progression base + k * stride (dense blocks: one slot
+// per tile below each other) -- then the kernels compute the slot numbers instead of loading them (one memory round trip less
+// in the kernels that add the lists: they sit on the latency chain of every CG iteration); stride == DEF_EXPLICIT: the slot
+// numbers are def_idx[kidx + k].
+constexpr int32_t DEF_EXPLICIT = INT32_MIN;
+struct DefRow { int32_t row, own, base, stride, count, kidx, pad0, pad1; };     // 32 bytes
+
 struct BlkDesc {                    // one row block = the unit of work of ONE wavefront (48 bytes, wave-uniform: read by scalar loads)
     int64_t nnz0;                   // first value in `val` (multiple of NNZ_ALIGN)
     int64_t colpos;                 // first entry in `col`: per-entry column indices, or -- for a RUN block, whose rows
@@ -118,6 +126,7 @@ struct HostBlkCsr {
     std::vector<int32_t> def_rows;     // [ndef]   deferred rows, ascending
     std::vector<int32_t> def_ptr;      // [ndef+1] their slot lists
     std::vector<int32_t> def_idx;      // slot indices, in summation order
+    std::vector<DefRow> def_rec;       // [ndef]   the same lists in the form the kernels read (progressions where they are ones)
     bool row_sharded = false;          // every row of A' is deferred with the single slot `row` (summed over the ranks before use)
     // window panels (empty unless the operator is stored that way; then blk is empty and val/col are unused)
     std::vector<WinPanel> wpanel;
@@ -146,6 +155,7 @@ struct DevBlkCsr {
     const int32_t* def_rows;
     const int32_t* def_ptr;
     const int32_t* def_idx;
+    const DefRow* def_rec;
     int32_t ndef, nwg_def;             // deferred rows, workgroups of the deferred-row kernel
     int32_t def_lpr;                   // lanes per deferred row (power of two <= 64)
     int32_t npart, part_off;           // the partial-sum records a sweep leaves for its consumers: `npart` records starting at

@@ -823,13 +823,13 @@ __device__ __forceinline__ void deferred_rows(const DevBlkCsr& S, Epi& epi) {
     int q = (blockIdx.x * DEF_THREADS + threadIdx.x) >> sh;
     for (int pass = 0; pass < npass; ++pass, q += rows_per_pass) {
         const bool ok = q < S.ndef;
-        const int row = ok ? S.def_rows[q] : 0;
+        DefRow dr{};
+        if (ok) dr = ld_defrow(S.def_rec + q);
+        const int row = dr.row;
         RowPre pr{};
         if (ok && lig == 0) pr = epi.pre(row);
         double u1 = 0.0, u2 = 0.0;
-        if (ok) {
-            slot_list_sum(slots, S.def_idx, S.def_ptr[q] + lig, S.def_ptr[q + 1], lpr, u1, u2);
-        }
+        if (ok) slot_list_sum(slots, S.def_idx, dr, lig, lpr, u1, u2);
         u1 = group_sum(u1, lpr);
         u2 = group_sum(u2, lpr);
         if (ok && lig == 0) epi.row(row, u1, u2, pr);

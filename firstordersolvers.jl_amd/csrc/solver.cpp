@@ -1064,6 +1064,7 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     h->S.row_rel = drr; h->S.wave_blk0 = dwv; h->S.wave_first = dwf; h->S.nblk = hs.nblk; h->S.nwg = hs.nwg; h->S.nwaves = hs.nwaves;
     // dual tiles: partial-sum slots and the deferred rows' slot lists
     h->S.slots = nullptr; h->S.slots_rd = nullptr; h->S.row_defer = nullptr; h->S.def_rows = nullptr; h->S.def_ptr = nullptr; h->S.def_idx = nullptr;
+    h->S.def_rec = nullptr;
     h->S.ndef = (int32_t)hs.def_rows.size();
     h->S.nwg_def = 0; h->S.def_lpr = 1;
     if (h->S.ndef > 0) {
@@ -1073,6 +1074,9 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
         FOS_TRY(dev_upload(h, &ddr, hs.def_rows));
         FOS_TRY(dev_upload(h, &ddp, hs.def_ptr));
         FOS_TRY(dev_upload(h, &ddi, hs.def_idx));
+        DefRow* ddrec = nullptr;
+        FOS_TRY(dev_upload(h, &ddrec, hs.def_rec));
+        h->S.def_rec = ddrec;
         FOS_TRY(dev_alloc(h, &dsl, (size_t)2 * hs.nslots));
         FOS_HIP(hipMemset(dsl, 0, sizeof(double) * 2 * hs.nslots));
         h->S.slots = dsl; h->S.slots_rd = dsl; h->S.row_defer = drd; h->S.def_rows = ddr; h->S.def_ptr = ddp; h->S.def_idx = ddi;

@@ -156,15 +156,15 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
         int q = (blockIdx.x * VEC_THREADS + threadIdx.x) >> sh;
         for (int pass = 0; pass < npass; ++pass, q += rows_per_pass) {
             const bool ok = q < S.ndef;
-            const int row = ok ? S.def_rows[q] : 0;
+            DefRow dr{};
+            if (ok) dr = ld_defrow(S.def_rec + q);
+            const int row = dr.row;
             const bool own = ok && lig == 0;
             d2 pi = make_double2(0.0, 0.0), xi = pi, ri = pi;
             double c = 0.0;
             if (own) { pi = p[row]; ri = r[row]; c = cb[row]; if constexpr (XUPD) xi = x[row]; }
             double u1 = 0.0, u2 = 0.0;
-            if (ok) {
-                slot_list_sum(slots, S.def_idx, S.def_ptr[q] + lig, S.def_ptr[q + 1], lpr, u1, u2);
-            }
+            if (ok) slot_list_sum(slots, S.def_idx, dr, lig, lpr, u1, u2);
             u1 = group_sum(u1, lpr);
             u2 = group_sum(u2, lpr);
             if (own) {
@@ -332,8 +332,9 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
     const int lig = threadIdx.x & (lpr - 1);
     const int q0 = (blockIdx.x * VEC_THREADS + threadIdx.x) >> sh;
     const bool ok0 = DEF && !a.close_only && q0 < S.ndef;
-    int dk0 = 0, dk1 = 0, drow0 = 0;
-    if (ok0) { dk0 = S.def_ptr[q0] + lig; dk1 = S.def_ptr[q0 + 1]; drow0 = S.def_rows[q0]; }
+    DefRow dr0{};
+    if (ok0) dr0 = ld_defrow(S.def_rec + q0);
+    const int drow0 = dr0.row, dn0 = dr0.count + (dr0.own >= 0 ? 1 : 0);
     const double rs = !closing ? 0.0 : (a.from_reduced ? a.reduced[3] : wave_sum_records(a.rr_in, a.nrr));
     // stage 2: the first four slot indices of that row's list; the row's vector elements
     int did[4] = {-1, -1, -1, -1};
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
     if constexpr (DEF) {
         if (ok0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) did[q] = (dk0 + q * lpr < dk1) ? S.def_idx[dk0 + q * lpr] : -1;
+            for (int q = 0; q < 4; ++q) did[q] = (lig + q * lpr < dn0) ? defrow_slot(dr0, S.def_idx, lig + q * lpr) : -1;
             if (lig == 0) { dri = a.r[drow0]; dxi = a.x[drow0]; dc = a.cb[drow0]; if (!first) { dpi = a.p[drow0]; dsi = a.s[drow0]; } }
         }
     }
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
         for (int q = 0; q < 4; ++q) dv[q] = did[q] >= 0 ? slots[did[q]] : make_double2(0.0, 0.0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (did[q] >= 0) { du1 += dv[q].x; du2 += dv[q].y; }
-        if (ok0) slot_list_sum(slots, S.def_idx, dk0 + 4 * lpr, dk1, lpr, du1, du2);
+        if (ok0) slot_list_sum(slots, S.def_idx, dr0, lig + 4 * lpr, lpr, du1, du2);
     }
     __shared__ double sums[4];
     if (plain_sums) {
@@ -424,10 +425,12 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
             d2 ri = dri, pi = dpi, si = dsi, xi = dxi;
             double c = dc, u1 = du1, u2 = du2;
             if (pass > 0) {                                      // (the first pass was requested in the prologue's stages)
-                row = ok ? S.def_rows[q] : 0;
+                DefRow dr{};
+                if (ok) dr = ld_defrow(S.def_rec + q);
+                row = dr.row;
                 ri = make_double2(0.0, 0.0); pi = ri; si = ri; xi = ri; c = 0.0; u1 = 0.0; u2 = 0.0;
                 if (ok && lig == 0) { ri = a.r[row]; xi = a.x[row]; c = a.cb[row]; if (!first) { pi = a.p[row]; si = a.s[row]; } }
-                if (ok) slot_list_sum(slots, S.def_idx, S.def_ptr[q] + lig, S.def_ptr[q + 1], lpr, u1, u2);
+                if (ok) slot_list_sum(slots, S.def_idx, dr, lig, lpr, u1, u2);
             }
             const bool own = ok && lig == 0;
             u1 = group_sum(u1, lpr);
@@ -508,13 +511,15 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_start_kernel(CgmStartArgs a, 
         int q = (blockIdx.x * VEC_THREADS + threadIdx.x) >> sh;
         for (int pass = 0; pass < npass; ++pass, q += rows_per_pass) {
             const bool ok = q < S.ndef;
-            const int row = ok ? S.def_rows[q] : 0;
+            DefRow dr{};
+            if (ok) dr = ld_defrow(S.def_rec + q);
+            const int row = dr.row;
             const bool own = ok && lig == 0;
             d2 vi = make_double2(0.0, 0.0), bi = vi;
             double c = 0.0;
             if (own) { vi = a.v[row]; bi = a.rhs[row]; c = a.cb[row]; }
             double u1 = 0.0, u2 = 0.0;
-            if (ok) slot_list_sum(slots, S.def_idx, S.def_ptr[q] + lig, S.def_ptr[q + 1], lpr, u1, u2);
+            if (ok) slot_list_sum(slots, S.def_idx, dr, lig, lpr, u1, u2);
             u1 = group_sum(u1, lpr);
             u2 = group_sum(u2, lpr);
             if (own) {
