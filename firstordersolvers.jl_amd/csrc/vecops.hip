@@ -128,19 +128,6 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
     if constexpr (DEF) { if (have0 && ((def_mask[i0 >> 5] >> (i0 & 31)) & 1u)) have0 = false; }
     d2 p0 = make_double2(0.0, 0.0), a0 = p0, x0 = p0, r0 = p0;
     if (have0) { a0 = Ap[i0]; r0 = r[i0]; if constexpr (XUPD) { p0 = p[i0]; x0 = x[i0]; } }
-    // ... and so are the next NPRE elements (XUPD = false; rows finished from slots are loaded too and dropped at use: no mask
-    // load in front of the requests): the scalar prologue and the slot lists of the slot-spread rows -- three to four dependent
-    // round trips every thread walks through first -- then overlap the stream instead of preceding it (C4: this kernel moves
-    // 64 MB, and ran 6 us longer than the same kernel on an operator without slot-spread rows)
-    constexpr int NPRE = XUPD ? 0 : 8;
-    d2 av[NPRE > 0 ? NPRE : 1], rv[NPRE > 0 ? NPRE : 1];
-    uint32_t mk[NPRE > 0 ? NPRE : 1];
-#pragma unroll
-    for (int u = 0; u < NPRE; ++u) {
-        const int64_t i = i0 + (u + 1) * stride;
-        av[u] = make_double2(0.0, 0.0); rv[u] = av[u]; mk[u] = 0u;
-        if (i < l) { av[u] = Ap[i]; rv[u] = r[i]; if constexpr (DEF) mk[u] = def_mask[i >> 5]; }
-    }
     if (st->done) return;
     if (FOLD && st->xchg_failed) return;
     __shared__ double sums[3];
@@ -199,18 +186,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
         r[i0] = r0;
         if (i0 != l - 1) acc[0] += r0.x * r0.x + r0.y * r0.y;
     }
-#pragma unroll
-    for (int u = 0; u < NPRE; ++u) {
-        const int64_t i = i0 + (u + 1) * stride;
-        if (i >= l) continue;
-        if constexpr (DEF) { if ((mk[u] >> (i & 31)) & 1u) continue; }
-        const d2 ai = (i == l - 1) ? make_double2(at1, at2) : av[u];
-        d2 ri = rv[u];
-        ri.x -= alpha * ai.x; ri.y -= alpha * ai.y;
-        r[i] = ri;
-        if (i != l - 1) acc[0] += ri.x * ri.x + ri.y * ri.y;
-    }
-    for (int64_t i = i0 + (NPRE + 1) * stride; i < l; i += stride) {
+    for (int64_t i = i0 + stride; i < l; i += stride) {
         if constexpr (DEF) { if ((def_mask[i >> 5] >> (i & 31)) & 1u) continue; }
         const d2 ai = (i == l - 1) ? make_double2(at1, at2) : Ap[i];
         d2 ri = r[i];
