@@ -279,10 +279,10 @@ def main():
         nmr = prob.m + prob.n
         stored_bytes = (8.0 * ost["vals"] + 4.0 * ost["cols"] + 48.0 * ost["blocks"] + 16.0 * ost["slots"]
                         + 16.0 * nmr + 8.0 * nmr + 16.0 * nmr)
-        # (2) the same from rocprofv3 PMC passes of THIS round's kernels (tools/gpu_profile_r02.sh -> profiles/), when committed
+        # (2) the same from rocprofv3 PMC passes of the latest round's kernels (tools/gpu_profile_r03.sh -> profiles/), when committed
         traffic, traffic_src = None, None
         try:
-            cands = sorted(Path(ROOT / "profiles").glob("r02_kkt_traffic.json"))
+            cands = sorted(Path(ROOT / "profiles").glob("r0*_kkt_traffic.json"))          # the latest round's PMC passes
             if cands and not args.small and world == 1:
                 ent = json.load(open(cands[-1])).get(args.workload, {})
                 traffic, traffic_src = ent.get("traffic_bytes"), ent.get("source")
@@ -363,7 +363,7 @@ def main():
                 "avg_kernel_ms": round(avg_psd_ms, 5), "launches_timed": psd_n,
                 "note": "issue bound: one wavefront per SIMD issues an fp64 VALU op every 7.5 cycles and a DPP move every 9 (measured; "
                         "4 waves per SIMD reach ~5), and 1024 matrices are one wavefront per SIMD; the two dense contractions are "
-                        "12 % of its time (profiles/r02_psd_phases_wave.json)",
+                        "12 % of its time (profiles/r02_psd_phases_wave.json; the kernel is unchanged since)",
                 "kernel_share_of_step": shares["psd_projection"],
             }
         out = {

@@ -59,6 +59,17 @@ for k in sorted(acc):
                       m.get("TCP_TCC_READ_REQ_sum", float("nan")), m.get("TCP_TCC_READ_REQ_sum", float("nan")) / t_us / 1e3))
     lines.append("")
 open("gpurun_out/%s/pmc_%s.md" % (tag, wl), "w").write("\n".join(lines) + "\n")
+import json
+js = {}
+for k in sorted(acc):
+    mm = {c: (lambda v: sum(v[1:]) / len(v[1:]) if len(v) > 2 else sum(v) / len(v))(acc[k][c]) for c in acc[k]}
+    d = sorted(dur.get(k, []))
+    d = d[len(d) // 4: max(len(d) // 4 + 1, 3 * len(d) // 4)] if d else []
+    if "FETCH_SIZE" in mm and "WRITE_SIZE" in mm:
+        js[k.replace("fos::", "").replace("void ", "").strip()] = {"fetch_kib": mm["FETCH_SIZE"], "write_kib": mm["WRITE_SIZE"], "bytes": (2 * mm["FETCH_SIZE"] + mm["WRITE_SIZE"]) * 1024,
+                 "kernel_trace_us": (sum(d) / len(d)) if d else None}
+json.dump(js, open("gpurun_out/%s/pmc_%s.json" % (tag, wl), "w"), indent=1)
 print("\n".join(lines))
 PY
+  rm -rf $OUT
 done
