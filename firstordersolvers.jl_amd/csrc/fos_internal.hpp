@@ -303,6 +303,7 @@ struct CgIter {
     const PeerBox* fold;       // non-null: the two exchanges of the iteration happen inside the two kernels (peer mailboxes)
     uint32_t seq_base;
     int32_t batch_mark = 0;    // != 0: this is the last iteration the host enqueued; if CG goes on after it, the p update tells the host (HostMark.batch)
+    bool start_fused = false;  // the solve was started by launch_cgm_apply / launch_cgm_start: the sweep of iteration 1 adds g_0 = r_0.r_0
 };
 void launch_kkt2_cg(const LaunchCtx& c, const CgIter& it, double2* Ap);
 void launch_cg_stop_check(const LaunchCtx& c, const CgIter& it);      // closes iteration it.j - 1 when no sweep follows in this batch
@@ -337,7 +338,8 @@ void launch_cgm_update(const LaunchCtx& c, const CgmIter& it, bool close_only);
 // the start of a solve: the sweep it.w = M v (all rows but the tau row, slot-spread rows unfinished; launch_cgm_apply) and
 // r = rhs - M v with the r.r records of "iteration 0"; its first workgroup also opens the solve in DevState (done = 0, tol, ...)
 void launch_cgm_apply(const LaunchCtx& c, const CgmIter& it, const double2* v);
-void launch_cgm_start(const LaunchCtx& c, const CgmIter& it, const double2* rhs, const double2* v, double tol, int maxit);
+void launch_cgm_start(const LaunchCtx& c, const CgmIter& it, const double2* rhs, const double2* v, double tol, int maxit,
+                      double2* p_out = nullptr);     // p_out: also p_1 = r_0 (the reference recurrence started this way)
 
 // single right-hand side Q apply on component `comp` of an interleaved vector
 //   Q_PLAIN : out_plain[i] = sign * (Q v)_i            (rows 0..n+m-1; tau row by q1_finalize)

@@ -991,7 +991,6 @@ void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
 //   otherwise applies to p_cur as it stands (iteration 1, or the p update ran as its own kernel).
 void launch_kkt2_cg(const LaunchCtx& c, const CgIter& it, double2* Ap) {
     KktArgs a = plain_args(c, it.p_cur, Ap, 1);
-    if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }       // (fuse_p is never set for window-panel operators)
     const bool fused = it.fuse_p && it.j >= 2;
     if (fused) {
         a.w = it.p_prev; a.r = it.r; a.pnew = it.p_cur;
@@ -999,6 +998,11 @@ void launch_kkt2_cg(const LaunchCtx& c, const CgIter& it, double2* Ap) {
         a.reduced = c.reduced; a.from_reduced = it.rr_from_reduced; a.j = it.j;
         if (it.fold) { a.pb = *it.fold; a.seq_base = it.seq_base; }
     }
+    if (it.j == 1 && it.start_fused) {       // the start kernel left the r.r records of "iteration 0": this sweep adds them (g_0)
+        a.close_j = 0; a.seq_base = it.seq_base;
+        a.rr_partials = c.partials + 3 * (size_t)PART_CAP; a.rr_count = c.cg_blocks;
+    }
+    if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }       // (fuse_p is never set for window-panel operators)
     dim3 grid(c.S.nwg), block(SPMV_THREADS);
     if (!fused) { launch_plain_sweep(c, a, true); return; }
     if (c.S.ndef > 0) hipLaunchKernelGGL((kkt2_kernel<true, true, true>), grid, block, 0, c.stream, c.S, a);

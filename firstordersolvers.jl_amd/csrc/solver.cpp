@@ -422,12 +422,17 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     const bool merged = variant == FOS_CG_MERGED_SWEEP || variant == FOS_CG_MERGED_UPDATE;
     const bool close_in_update = variant == FOS_CG_MERGED_UPDATE;
     const bool fuse_p = variant == FOS_CG_FUSED_P;
+    // single GPU, reference recurrence: the solve starts like the merged one -- sweep, ONE launch for r_0 = rhs - M v, p_1 = r_0,
+    // the tau row, the slot-spread rows and the r.r records (added by the sweep of iteration 1) -- instead of five launches
+    static const bool start_env = !(getenv("FOS_CG_FUSED_START") && atoi(getenv("FOS_CG_FUSED_START")) == 0);
+    const bool start_fused = !merged && !h->sharded() && !c.between && start_env;
     h->cg_epoch += 1;                        // the same on every rank: all ranks make the same calls
     const uint32_t seq_base = (uint32_t)(h->cg_epoch * 2048u);          // + 2 j + phase  (j <= 1000)
     auto iter_desc = [&](int j) {
         CgIter it;
         it.j = j; it.r = h->R; it.p_prev = h->PB[(j - 1) & 1]; it.p_cur = h->PB[j & 1];
         it.fuse_p = fuse_p; it.rr_from_reduced = rccl ? 1 : 0; it.fold = fold ? &h->peer : nullptr; it.seq_base = seq_base;
+        it.start_fused = start_fused;
         return it;
     };
     auto merged_desc = [&](int j) {
@@ -468,6 +473,11 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
         const int pe = prof_begin(h, FOS_PROF_KKT, 0, h->cg_total);
         launch_cgm_sweep(c, it0, close_in_update ? -1 : 0);
         prof_end(h, pe);
+    } else if (start_fused) {
+        CgmIter it0 = merged_desc(0);
+        const d2* v = apply_on ? apply_on : x;
+        launch_cgm_apply(c, it0, v);                                       // :32  mul!(Ap, A, x)
+        launch_cgm_start(c, it0, rhs, v, tol, maxit, h->PB[1]);            // :33-36   (p_1 in buffer 1)
     } else {
         int fr = 0;
         FOS_TRY(kkt_apply_full(h, c, apply_on ? apply_on : x, h->AP));    // :32  mul!(Ap, A, x)

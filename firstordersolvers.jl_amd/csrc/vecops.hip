@@ -469,6 +469,7 @@ struct CgmStartArgs {
     int64_t l;
     const d2 *rhs, *v, *w;
     d2* r;
+    d2* p;                                 // non-null: also p_1 = r_0 (the reference recurrence's first direction, conjugategradients.jl:34)
     DevState* st;
     const double* kkt_partials; int nkkt;
     const double* reduced; int from_reduced;
@@ -528,6 +529,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_start_kernel(CgmStartArgs a, 
                 else { q1 = -(u1 - vtx * c); q2 = -(u2 - vty * c); }
                 const d2 ri = make_double2(bi.x - (vi.x - q2), bi.y - (q1 - vi.y));       // r = b - Ap      :33
                 a.r[row] = ri;
+                if (a.p) a.p[row] = ri;
                 if (a.count_repl) acc[0] += ri.x * ri.x + ri.y * ri.y;
             }
         }
@@ -536,6 +538,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_start_kernel(CgmStartArgs a, 
         if (i0 == l - 1) w0 = make_double2(wt1, wt2);
         const d2 ri = make_double2(b0.x - w0.x, b0.y - w0.y);
         a.r[i0] = ri;
+        if (a.p) a.p[i0] = ri;
         if (i0 != l - 1) acc[0] += ri.x * ri.x + ri.y * ri.y;
     }
     for (int64_t k = i0 + stride; k < l; k += stride) {
@@ -544,13 +547,14 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_start_kernel(CgmStartArgs a, 
         const d2 bi = a.rhs[k];
         const d2 ri = make_double2(bi.x - wi.x, bi.y - wi.y);
         a.r[k] = ri;
+        if (a.p) a.p[k] = ri;
         if (k != l - 1) acc[0] += ri.x * ri.x + ri.y * ri.y;
     }
     block_reduce_store<1>(acc, a.rr_out + blockIdx.x);
 }
-void launch_cgm_start(const LaunchCtx& c, const CgmIter& it, const double2* rhs, const double2* v, double tol, int maxit) {
+void launch_cgm_start(const LaunchCtx& c, const CgmIter& it, const double2* rhs, const double2* v, double tol, int maxit, double2* p_out) {
     CgmStartArgs a{};
-    a.l = c.l; a.rhs = rhs; a.v = v; a.w = it.w; a.r = it.r; a.st = c.st;
+    a.l = c.l; a.rhs = rhs; a.v = v; a.w = it.w; a.r = it.r; a.p = p_out; a.st = c.st;
     a.kkt_partials = c.partials; a.nkkt = c.S.nwg;
     a.reduced = c.reduced; a.from_reduced = it.fold ? 0 : it.from_reduced;
     a.rr_out = c.partials + 3 * (size_t)PART_CAP;                 // records of "iteration 0"
