@@ -15,7 +15,7 @@ FOS_OK = 0
 CONE_CODES = {"Free": 0, "Zero": 1, "NonNeg": 2, "NonPos": 3, "SOC": 4, "SOCRotated": 5, "SDP": 6,
               "ExpPrimal": 7, "ExpDual": 8}
 ALG_GAP, ALG_GAPA, ALG_FISTA, ALG_DYKSTRA = 0, 1, 2, 3
-CG_REFERENCE, CG_FUSED_P, CG_MERGED_SWEEP, CG_MERGED_UPDATE, CG_PIPELINED = 0, 1, 2, 3, 4
+CG_REFERENCE, CG_FUSED_P, CG_MERGED_SWEEP, CG_MERGED_UPDATE = 0, 1, 2, 3
 DEBUG_PUPDATE_DELAY = 1
 STATUS_NAMES = {0: "Continue", 1: "Optimal", 2: "Unbounded", 3: "Infeasible"}
 

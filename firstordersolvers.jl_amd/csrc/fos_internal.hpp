@@ -205,7 +205,6 @@ struct DevState {
     // (stashed by the sweep: the update kernel overwrites that vector while other workgroups still need the element)
     double alpha2[2];
     double vtau[2];
-    double vt2[8];         // pipelined CG: (r_tau, w_tau) of iteration parity 0 / 1 (the launch that updates the tau element stashes the next pair)
     int32_t dbg_delay;     // test hook (fos_debug_set): workgroups != 0 of cg_pupdate_kernel wait this many 100 MHz ticks at entry
     int32_t pad_;
 };
@@ -341,24 +340,6 @@ void launch_cgm_update(const LaunchCtx& c, const CgmIter& it, bool close_only);
 void launch_cgm_apply(const LaunchCtx& c, const CgmIter& it, const double2* v);
 void launch_cgm_start(const LaunchCtx& c, const CgmIter& it, const double2* rhs, const double2* v, double tol, int maxit,
                       double2* p_out = nullptr);     // p_out: also p_1 = r_0 (the reference recurrence started this way)
-
-// Pipelined CG (kernels.hip "pipelined CG"): ONE launch per iteration -- the sweep q = M w with every vector update in its row
-// epilogue -- plus a small launch for the rows spread over dual-tile slots.  x, r, p, s, z and the two w buffers (w_i lives in
-// wbuf[i & 1]).  Start: launch_cgm_apply + launch_cgm_start (r_0), launch_cgm_sweep on r_0 (w_0, unfinished rows), launch_cgp_finish
-// (finishes w_0, records of iteration 0, the tau stash); then launch_cgp_sweep(j = 1, 2, ...), launch_cgp_close at a batch end.
-struct CgpIter {
-    int j;
-    double2 *x, *r, *p, *s, *z;
-    double2* wbuf[2];
-    int nrec_in;               // records the prologue adds: c.cg_blocks after the finish kernel, c.S.nwg + c.S.nwg_def after a sweep
-    int from_reduced;
-    const PeerBox* fold;
-    uint32_t seq_base;
-    int32_t batch_mark = 0;
-};
-void launch_cgp_finish(const LaunchCtx& c, const CgpIter& it);
-void launch_cgp_sweep(const LaunchCtx& c, const CgpIter& it);
-void launch_cgp_close(const LaunchCtx& c, const CgpIter& it);
 
 // single right-hand side Q apply on component `comp` of an interleaved vector
 //   Q_PLAIN : out_plain[i] = sign * (Q v)_i            (rows 0..n+m-1; tau row by q1_finalize)

@@ -144,12 +144,12 @@ constexpr int WPL = WNNZ / 64;      // stream entries per lane
 // A row the sweep has summed: run its epilogue, or -- a DEFERRED row (dual tiles hold the rest of it) -- park the sum in
 // the row's own partial slot for whoever adds the slot lists (epi.park: a CG sweep adds the row's share of Ap.p there).
 template <bool DEFER, class Epi>
-__device__ __forceinline__ void finish_row(const DevBlkCsr& S, Epi& epi, int row, double a1, double a2, const typename Epi::Pre& pr) {
+__device__ __forceinline__ void finish_row(const DevBlkCsr& S, Epi& epi, int row, double a1, double a2, const RowPre& pr) {
     if constexpr (DEFER) {
         const int ds = S.row_defer[row];
         if (ds >= 0) {
             reinterpret_cast<d2*>(S.slots)[ds] = make_double2(a1, a2);
-            if constexpr (Epi::FOLDDEF) epi.park(row, a1, a2, pr.v);
+            epi.park(row, a1, a2, pr.v);
             return;
         }
     }
@@ -206,7 +206,7 @@ __device__ __forceinline__ void long_run_rows(const DevBlkCsr& S, const G& gat, 
     double a1[NR], a2[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) { a1[i] = 0.0; a2[i] = 0.0; }
-    typename Epi::Pre pr{};
+    RowPre pr{};
     if (lane < NR) pr = epi.pre(row0 + lane);
     constexpr int U = (NR >= 4) ? 2 : (NR == 2 ? 4 : 8);
     int k = lane;
@@ -337,7 +337,7 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
         if (kind == BLK_LONG) {
             // ---------------- long row d.row0
             double a1 = 0.0, a2 = 0.0;
-            typename Epi::Pre pr{};
+            RowPre pr{};
             if (lane == 0 && !d.run()) pr = epi.pre(d.row0);
             const double* __restrict__ val = S.val + d.nnz0;
             const int32_t* __restrict__ col = S.col + d.colpos;
@@ -374,7 +374,7 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
                 const int R = (j + 1 < K) ? 64 : Rl;
                 const bool valid = lane < R;
                 const int row = d.row0 + 64 * j + lane;
-                typename Epi::Pre pr{};
+                RowPre pr{};
                 if (valid && rslot < 0) pr = epi.pre(row);
                 const d2 wr = valid ? gat.load(row) : make_double2(0.0, 0.0);
                 const double* __restrict__ val = S.val + d.nnz0 + (int64_t)j * 64 * T + lane;
@@ -452,7 +452,7 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
             const int row = lane >> sh, lig = lane & (tpr - 1);
             const int len = (row < R) ? (int)S.row_rel[d.row0 + row] : 0;
             const bool owner = row < R && lig == 0;
-            typename Epi::Pre pr{};
+            RowPre pr{};
             if (owner) pr = epi.pre(d.row0 + row);
             const double* __restrict__ val = S.val + d.nnz0 + lane;
             double a1 = 0.0, a2 = 0.0;
@@ -484,7 +484,7 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
             const int sh = 31 - __clz(tpr);
             const int row = lane >> sh, lig = lane & (tpr - 1);
             const bool owner = row < R && lig == 0;
-            typename Epi::Pre pr{};
+            RowPre pr{};
             int s0 = 0, e = 0;
             if (row < R) {
                 s0 = S.row_rel[d.row0 + row];
@@ -655,7 +655,7 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
         __syncthreads();
         for (int i = tid; i < wp.nrows; i += WIN_THREADS) {
             const int row = wp.row0 + i;
-            const typename Epi::Pre pr = epi.pre(row);
+            const RowPre pr = epi.pre(row);
             if constexpr (NRHS == 2) { const d2 a = acc[i]; epi.row(row, a.x, a.y, pr); }
             else epi.row(row, acc[i], 0.0, pr);
         }
@@ -673,7 +673,6 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
 //   so whoever WRITES a slot adds its term (park), and the slot-free part is added once per deferred row by kkt_deferred_local.
 template <class G, bool FOLD>
 struct EpiKkt {
-    typedef RowPre Pre;
     static constexpr bool FOLDDEF = FOLD;
     G gat;
     d2* out;
@@ -827,7 +826,7 @@ __device__ __forceinline__ void deferred_rows(const DevBlkCsr& S, Epi& epi) {
         DefRow dr{};
         if (ok) dr = ld_defrow(S.def_rec + q);
         const int row = dr.row;
-        typename Epi::Pre pr{};
+        RowPre pr{};
         if (ok && lig == 0) pr = epi.pre(row);
         double u1 = 0.0, u2 = 0.0;
         if (ok) slot_list_sum(slots, S.def_idx, dr, lig, lpr, u1, u2);
@@ -860,183 +859,6 @@ __global__ __launch_bounds__(DEF_THREADS) void kkt2_deferred_kernel(DevBlkCsr S,
     block_reduce_store<3, DEF_THREADS>(epi.acc, red, partials + 3 * (int64_t)(S.nwg + blockIdx.x));
 }
 
-// ------------------------------------------------------------------------------------------------ pipelined CG
-// Pipelined (Ghysels-Vanroose) form of conjugategradients.jl:31-55: the same Krylov iterates in exact arithmetic, the reference's
-// iteration counting and stop test, but ONE launch per iteration (plus a small one for rows spread over dual-tile slots) -- every
-// vector update becomes local to the row the sweep has just finished:
-//     state: x, r, p, s = M p, w = M r, z = M s.    iteration j (i = j-1), from g_i = r.r, d_i = w.r (records of the launch before):
-//     beta_i = g_i / g_{i-1} (0 for i = 0),  alpha_i = g_i / (d_i - beta_i g_i / alpha_{i-1});      sweep q = M w;   then per row
-//     z = q + beta z ;  s = w + beta s ;  p = r + beta p ;  x += alpha p ;  r -= alpha s ;  w' = w - alpha z     (w' to the OTHER w buffer:
-//     other wavefronts still gather w), with the records of g_{i+1} = r.r, d_{i+1} = w'.r and of the tau row of the next sweep,
-//     [c;b].w'_1 and [c;b].w'_2, accumulated in the same pass.
-// The prologue (every workgroup, same records, same order) closes iteration i: stop test, then alpha, beta; workgroup 0 also
-// updates the tau element (the tau row of q comes from the records) and stashes the new (r_tau, w_tau) for the next launch, which
-// cannot read them from r while r is being updated.  Sharded: the four sums cross the ranks in the prologue (one exchange per
-// iteration).  Measured / motivation: DESIGN.md 3 "pipelined CG".
-struct PipeArgs {
-    const d2* wcur; d2* wnext;
-    d2 *r, *z, *s, *p, *x;
-    const double* cb; int n, nm;
-    DevState* st;
-    const double* rec_in; int nrec_in;     // records {r.r, w.r, [c;b].w1, [c;b].w2} of the launches that produced r_i, w_i
-    double* rec_out;                       // ... of this launch (4 per workgroup)
-    const double* reduced; int from_reduced;
-    int j;
-    PeerBox pb; uint32_t seq_base;
-    int32_t batch_mark;
-    int close_only;
-};
-struct PipeScalars { double alpha, beta, wtx, wty; bool first, go; };
-
-// closes iteration i = a.j - 1 and forms the scalars of iteration a.j; go = false: CG has stopped (or an exchange failed)
-template <bool FOLDX>
-__device__ __forceinline__ PipeScalars cgp_prologue(const PipeArgs& a) {
-    DevState* st = a.st;
-    const int i = a.j - 1;
-    PipeScalars ps{0.0, 0.0, 0.0, 0.0, i == 0, false};
-    const int done = st->done, xfail = st->xchg_failed, maxit = st->maxit;
-    const double tol = st->tol;
-    const double rtx = st->vt2[(i & 1) * 4 + 0], rty = st->vt2[(i & 1) * 4 + 1], wtx = st->vt2[(i & 1) * 4 + 2], wty = st->vt2[(i & 1) * 4 + 3];
-    const double g_prev = st->rn2[(i + 1) & 1], a_prev = st->alpha2[(i + 1) & 1];
-    __shared__ double sums[4];
-    if (a.from_reduced) { if (threadIdx.x < 4) sums[threadIdx.x] = a.reduced[threadIdx.x]; __syncthreads(); }
-    else {
-        PartialRegs<4> regs;
-        regs.load(a.rec_in, a.nrec_in);
-        double acc[4];
-        regs.sum(a.rec_in, a.nrec_in, acc);
-        partials_combine<4>(acc, sums);
-    }
-    if (done) return ps;
-    if (FOLDX && xfail) return ps;
-    if constexpr (FOLDX) {
-        if (!peer_fold_sum<4>(a.pb, a.seq_base + (uint32_t)a.j, sums, st)) return ps;
-    }
-    const double gam = sums[0] + (rtx * rtx + rty * rty);
-    const double delta = sums[1] + (wtx * rtx + wty * rty);
-    const double T1 = sums[2], T2 = sums[3];
-    const bool w0 = blockIdx.x == 0 && threadIdx.x == 0;
-    if (i >= 1 && (sqrt(gam) <= tol || i >= maxit)) {                  // conjugategradients.jl:42 for iteration i
-        if (w0) { st->rr = gam; cg_signal_stop(st, i, maxit, gam, a.seq_base >> 11); }
-        return ps;
-    }
-    if (ps.first) ps.alpha = gam / delta;
-    else { ps.beta = gam / g_prev; ps.alpha = gam / (delta - ps.beta * gam / a_prev); }
-    ps.wtx = wtx; ps.wty = wty;
-    ps.go = true;
-    if (w0) {
-        st->rn2[i & 1] = gam; st->alpha2[i & 1] = ps.alpha;
-        st->alpha = ps.alpha; st->beta = ps.beta; st->rr = gam; st->iter = a.j;
-        if (a.close_only) {
-            if (a.batch_mark != 0 && st->hostmark)                     // the host's batch is used up, CG is not done
-                __hip_atomic_store(&reinterpret_cast<HostMark*>(st->hostmark)->batch, a.batch_mark, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        } else {
-            // the tau element: (M w)_tau = (w1_tau - (Q w2)_tau, (Q w1)_tau - w2_tau),  (Q v)_tau = -[c;b].v         HSDEAffine.jl:57
-            const int t = a.nm;
-            const double q1 = wtx + T2, q2 = -T1 - wty;
-            d2 zt = make_double2(q1, q2), st_ = make_double2(wtx, wty), pt = make_double2(rtx, rty);
-            if (!ps.first) {
-                const d2 zo = a.z[t], so = a.s[t], po = a.p[t];
-                zt.x += ps.beta * zo.x; zt.y += ps.beta * zo.y;
-                st_.x += ps.beta * so.x; st_.y += ps.beta * so.y;
-                pt.x += ps.beta * po.x; pt.y += ps.beta * po.y;
-            }
-            d2 xt = a.x[t];
-            xt.x += ps.alpha * pt.x; xt.y += ps.alpha * pt.y;
-            const double rnx = rtx - ps.alpha * st_.x, rny = rty - ps.alpha * st_.y;
-            const double wnx = wtx - ps.alpha * zt.x, wny = wty - ps.alpha * zt.y;
-            a.z[t] = zt; a.s[t] = st_; a.p[t] = pt; a.x[t] = xt;
-            a.r[t] = make_double2(rnx, rny); a.wnext[t] = make_double2(wnx, wny);
-            double* nx = st->vt2 + ((i + 1) & 1) * 4;
-            nx[0] = rnx; nx[1] = rny; nx[2] = wnx; nx[3] = wny;
-        }
-    }
-    return ps;
-}
-
-// row epilogue of the pipelined sweep: q = (M w)_i from the row sums, then all six vector updates of the row and its share of
-// the four records
-struct PipePre { d2 w, r, z, s, p, x; double c; };
-template <class G>
-struct EpiPipe {
-    typedef PipePre Pre;
-    static constexpr bool FOLDDEF = false;
-    G gat;
-    d2 *wnext, *r, *z, *s, *p, *x;
-    const double* cb;
-    int n;
-    double wtx, wty, alpha, beta;
-    bool first;
-    double acc[4];
-    __device__ __forceinline__ void park(int, double, double, const d2&) {}
-    __device__ __forceinline__ PipePre pre(int i) const {
-        PipePre q;
-        q.w = gat.load(i); q.r = r[i]; q.x = x[i]; q.c = cb[i];
-        if (!first) { q.z = z[i]; q.s = s[i]; q.p = p[i]; }
-        else { q.z = make_double2(0.0, 0.0); q.s = q.z; q.p = q.z; }
-        return q;
-    }
-    __device__ __forceinline__ void row(int i, double u1, double u2, const PipePre& pr) {
-        const double c = pr.c;
-        double q1, q2;                                  // (Q w1)_i, (Q w2)_i   HSDEAffine.jl:51-56
-        if (i < n) { q1 = u1 + wtx * c; q2 = u2 + wty * c; }
-        else { q1 = -(u1 - wtx * c); q2 = -(u2 - wty * c); }
-        d2 zi = make_double2(pr.w.x - q2, q1 - pr.w.y);                 // q = M w      affinepluslinear.jl:45-48
-        d2 si = pr.w, pi = pr.r;
-        if (!first) {
-            zi.x += beta * pr.z.x; zi.y += beta * pr.z.y;
-            si.x += beta * pr.s.x; si.y += beta * pr.s.y;
-            pi.x += beta * pr.p.x; pi.y += beta * pr.p.y;
-        }
-        const d2 xi = make_double2(pr.x.x + alpha * pi.x, pr.x.y + alpha * pi.y);
-        const d2 ri = make_double2(pr.r.x - alpha * si.x, pr.r.y - alpha * si.y);
-        const d2 wi = make_double2(pr.w.x - alpha * zi.x, pr.w.y - alpha * zi.y);
-        z[i] = zi; s[i] = si; p[i] = pi; x[i] = xi; r[i] = ri; wnext[i] = wi;
-        acc[0] += ri.x * ri.x + ri.y * ri.y;
-        acc[1] += wi.x * ri.x + wi.y * ri.y;
-        acc[2] += c * wi.x;
-        acc[3] += c * wi.y;
-    }
-};
-
-template <bool DEFER, bool FOLDX, bool NT>
-__global__ __launch_bounds__(SPMV_THREADS) void kkt2p_kernel(DevBlkCsr S, PipeArgs a) {
-    const WaveWork ww = wave_work(S);
-    const PipeScalars ps = cgp_prologue<FOLDX>(a);
-    if (!ps.go) return;
-    __shared__ __attribute__((aligned(16))) double prod[SPMV_WAVES * WNNZ * 2];
-    __shared__ double red[16];
-    typedef GatherWT<NT> G;
-    EpiPipe<G> epi;
-    epi.gat.w = a.wcur;
-    epi.wnext = a.wnext; epi.r = a.r; epi.z = a.z; epi.s = a.s; epi.p = a.p; epi.x = a.x; epi.cb = a.cb; epi.n = a.n;
-    epi.wtx = ps.wtx; epi.wty = ps.wty; epi.alpha = ps.alpha; epi.beta = ps.beta; epi.first = ps.first;
-    epi.acc[0] = epi.acc[1] = epi.acc[2] = epi.acc[3] = 0.0;
-    spmv_walk<DEFER>(S, epi.gat, epi, prod, ww);
-    block_reduce_store<4, SPMV_THREADS>(epi.acc, red, a.rec_out + 4 * (int64_t)blockIdx.x);
-}
-// the rows spread over dual-tile slots, after the sweep: the same epilogue from the slot lists; scalars from DevState (stored by
-// the sweep's first workgroup); records behind the sweep's
-__global__ __launch_bounds__(DEF_THREADS) void kkt2p_deferred_kernel(DevBlkCsr S, PipeArgs a, int count_repl) {
-    DevState* st = a.st;
-    if (st->done) return;
-    __shared__ double red[16];
-    const int i = a.j - 1;
-    EpiPipe<GatherWT<true>> epi;
-    epi.gat.w = a.wcur;
-    epi.wnext = a.wnext; epi.r = a.r; epi.z = a.z; epi.s = a.s; epi.p = a.p; epi.x = a.x; epi.cb = a.cb; epi.n = a.n;
-    epi.wtx = st->vt2[(i & 1) * 4 + 2]; epi.wty = st->vt2[(i & 1) * 4 + 3]; epi.alpha = st->alpha; epi.beta = st->beta; epi.first = i == 0;
-    epi.acc[0] = epi.acc[1] = epi.acc[2] = epi.acc[3] = 0.0;
-    deferred_rows(S, epi);
-    if (!count_repl) epi.acc[0] = epi.acc[1] = epi.acc[2] = epi.acc[3] = 0.0;
-    block_reduce_store<4, DEF_THREADS>(epi.acc, red, a.rec_out + 4 * (int64_t)(S.nwg + blockIdx.x));
-}
-// end of a batch of enqueued iterations: the prologue alone (stop test of the last iteration, or the host's batch mark)
-template <bool FOLDX>
-__global__ __launch_bounds__(SPMV_THREADS) void cgp_close_kernel(PipeArgs a) {
-    (void)cgp_prologue<FOLDX>(a);
-}
-
 constexpr int FIN_THREADS = 1024;
 
 // generic: partials[count][nacc] -> reduced[nacc]; sharded path: the all-reduce then runs on `reduced` (RCCL), or --
@@ -1051,7 +873,6 @@ __global__ __launch_bounds__(FIN_THREADS) void reduce_kernel(const double* __res
     switch (nacc) {
         case 1: reduce_partials<1>(partials, count, sums); break;
         case 3: reduce_partials<3>(partials, count, sums); break;
-        case 4: reduce_partials<4>(partials, count, sums); break;
         case 6: reduce_partials<6>(partials, count, sums); break;
         default: return;
     }
@@ -1208,42 +1029,6 @@ void launch_cgm_apply(const LaunchCtx& c, const CgmIter& it, const double2* v) {
     if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
     launch_plain_sweep(c, a, true);
 }
-// pipelined CG (PipeArgs above): one launch per iteration, a small one behind it for the rows spread over dual-tile slots, and a
-// one-workgroup launch of the prologue at the end of a batch of enqueued iterations.  Records: 4 doubles per workgroup, two
-// regions by iteration parity (a late workgroup of launch j+1 may still read the records of launch j)
-static PipeArgs pipe_args(const LaunchCtx& c, const CgpIter& it) {
-    PipeArgs a{};
-    const int i = it.j - 1;
-    a.wcur = it.wbuf[i & 1]; a.wnext = it.wbuf[(i + 1) & 1];
-    a.r = it.r; a.z = it.z; a.s = it.s; a.p = it.p; a.x = it.x;
-    a.cb = c.cb; a.n = (int)c.n; a.nm = (int)(c.n + c.m); a.st = c.st;
-    a.rec_in = c.partials + (size_t)(i & 1) * 4 * PART_CAP; a.nrec_in = it.nrec_in;
-    a.rec_out = c.partials + (size_t)((i + 1) & 1) * 4 * PART_CAP;
-    a.reduced = c.reduced; a.from_reduced = it.fold ? 0 : it.from_reduced;
-    a.j = it.j;
-    if (it.fold) a.pb = *it.fold;
-    a.seq_base = it.seq_base + 1u;            // (+1: the start kernel and the finish kernel exchange before iteration 1)
-    a.batch_mark = it.batch_mark;
-    return a;
-}
-void launch_cgp_sweep(const LaunchCtx& c, const CgpIter& it) {
-    const PipeArgs a = pipe_args(c, it);
-    dim3 grid(c.S.nwg), block(SPMV_THREADS);
-#define FOS_PIPE(DEFER, FOLDX)                                                                                                   \
-    do { if (c.S.resident) hipLaunchKernelGGL((kkt2p_kernel<DEFER, FOLDX, false>), grid, block, 0, c.stream, c.S, a);            \
-         else hipLaunchKernelGGL((kkt2p_kernel<DEFER, FOLDX, true>), grid, block, 0, c.stream, c.S, a); } while (0)
-    if (c.S.ndef > 0) { if (it.fold) FOS_PIPE(true, true); else FOS_PIPE(true, false); }
-    else { if (it.fold) FOS_PIPE(false, true); else FOS_PIPE(false, false); }
-#undef FOS_PIPE
-    if (c.S.ndef > 0)
-        hipLaunchKernelGGL(kkt2p_deferred_kernel, dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, a, (int)c.count_repl);
-}
-void launch_cgp_close(const LaunchCtx& c, const CgpIter& it) {
-    PipeArgs a = pipe_args(c, it);
-    a.close_only = 1;
-    if (it.fold) hipLaunchKernelGGL(cgp_close_kernel<true>, dim3(1), dim3(SPMV_THREADS), 0, c.stream, a);
-    else hipLaunchKernelGGL(cgp_close_kernel<false>, dim3(1), dim3(SPMV_THREADS), 0, c.stream, a);
-}
 void launch_cg_stop_check(const LaunchCtx& c, const CgIter& it) {
     KktArgs a = plain_args(c, nullptr, nullptr, 1);
     a.r = it.r;
@@ -1267,7 +1052,6 @@ void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int
 // ------------------------------------------------------------------------------------------------ single RHS Q apply
 
 struct EpiQPlain {
-    typedef RowPre Pre;
     static constexpr bool FOLDDEF = false;
     __device__ __forceinline__ void park(int, double, double, const d2&) {}     // out_plain[i] = sign * (Q v)_i ; acc[0] = [c;b].v
     const double* vcomp; double* out; const double* cb; int n; double vt, sign; double acc[1];
@@ -1281,7 +1065,6 @@ struct EpiQPlain {
     }
 };
 struct EpiQRhs {
-    typedef RowPre Pre;
     static constexpr bool FOLDDEF = false;
     __device__ __forceinline__ void park(int, double, double, const d2&) {}       // out[i] = (x1_i - (Q x2)_i, 0)      affinepluslinear.jl:94-95 (beta = 1, q = 0, rhs2 = b = 0)
     const d2* x; d2* out; const double* cb; int n; double vt; double acc[1];
@@ -1296,7 +1079,6 @@ struct EpiQRhs {
     }
 };
 struct EpiQVfromU {
-    typedef RowPre Pre;
     static constexpr bool FOLDDEF = false;
     __device__ __forceinline__ void park(int, double, double, const d2&) {}    // out[i] = (y_i.x, (Q y.x)_i)        HSDEAffine.jl:122-124  v = Q u
     const d2* y; d2* out; const double* cb; int n; double vt; double acc[1];
@@ -1311,7 +1093,6 @@ struct EpiQVfromU {
     }
 };
 struct EpiQStatus {
-    typedef RowPre Pre;
     static constexpr bool FOLDDEF = false;
     __device__ __forceinline__ void park(int, double, double, const d2&) {}    // residual sums of checkstatus  HSDEStatus.jl:34-38,59,61  (z = [x;y;tau | r;s;kappa] interleaved)
     const d2* z; const double* cb; int n; double tau; double acc[6];

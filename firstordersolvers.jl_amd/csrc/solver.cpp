@@ -127,7 +127,6 @@ struct fos_solver {
     d2 *Y = nullptr, *XOLD = nullptr;                       // FISTA y / xold ; Dykstra p / q
     d2 *W = nullptr;                                        // scratch (Dykstra sums, test entries)
     d2 *SOL2 = nullptr;                                     // HSDEMatrix.cgdata.xinit
-    d2 *WB = nullptr, *ZV = nullptr;                        // pipelined CG: the second w buffer, z = M s
     double* plain = nullptr;                                // 2l doubles: ABI staging
 
     // cones
@@ -421,13 +420,12 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     int32_t variant = FOS_CG_REFERENCE;
     FOS_TRY(fos_get_cg_variant(h, &variant));
     const bool merged = variant == FOS_CG_MERGED_SWEEP || variant == FOS_CG_MERGED_UPDATE;
-    const bool piped = variant == FOS_CG_PIPELINED;
     const bool close_in_update = variant == FOS_CG_MERGED_UPDATE;
     const bool fuse_p = variant == FOS_CG_FUSED_P;
     // single GPU, reference recurrence: the solve starts like the merged one -- sweep, ONE launch for r_0 = rhs - M v, p_1 = r_0,
     // the tau row, the slot-spread rows and the r.r records (added by the sweep of iteration 1) -- instead of five launches
     static const bool start_env = !(getenv("FOS_CG_FUSED_START") && atoi(getenv("FOS_CG_FUSED_START")) == 0);
-    const bool start_fused = !merged && !piped && !h->sharded() && !c.between && start_env;
+    const bool start_fused = !merged && !h->sharded() && !c.between && start_env;
     h->cg_epoch += 1;                        // the same on every rank: all ranks make the same calls
     const uint32_t seq_base = (uint32_t)(h->cg_epoch * 2048u);          // + 2 j + phase  (j <= 1000)
     auto iter_desc = [&](int j) {
@@ -463,37 +461,7 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
         launch_reduce1(c2, c.cg_blocks, 1, 1);
         return allreduce(h, 4);
     };
-    auto piped_desc = [&](int j) {
-        CgpIter it;
-        it.j = j; it.x = x; it.r = h->R; it.p = h->PB[0]; it.s = h->PB[1]; it.z = h->ZV; it.wbuf[0] = h->AP; it.wbuf[1] = h->WB;
-        it.nrec_in = j <= 1 ? c.cg_blocks : c.S.nwg + c.S.nwg_def;
-        it.from_reduced = rccl ? 1 : 0; it.fold = fold ? &h->peer : nullptr; it.seq_base = seq_base;
-        return it;
-    };
-    // pipelined, sharded without folded mailboxes: the four sums of the launch before cross the ranks in one all-reduce
-    auto piped_reduce = [&](int j) -> int {
-        if (!rccl) return FOS_OK;
-        LaunchCtx c2 = c;
-        c2.partials = c.partials + (size_t)((j - 1) & 1) * 4 * PART_CAP;
-        launch_reduce1(c2, j <= 1 ? c.cg_blocks : c.S.nwg + c.S.nwg_def, 4, 1);
-        return allreduce(h, 4);
-    };
-    if (piped) {
-        // start: r_0 = rhs - M v (sweep + start kernel), w_0 = M r_0 (sweep + finish kernel: tau row, slot-spread rows, the records
-        // of iteration 0); every iteration after that is ONE sweep launch (+ a small one for the slot-spread rows)
-        CgmIter it0 = merged_desc(0);
-        const d2* v = apply_on ? apply_on : x;
-        launch_cgm_apply(c, it0, v);                                       // :32  mul!(Ap, A, x)
-        if (rccl) { launch_reduce1(c, c.S.nwg, 3, 0, 0); FOS_TRY(allreduce(h, 3)); }
-        launch_cgm_start(c, it0, rhs, v, tol, maxit);                      // :33-36
-        LaunchCtx c1 = c;
-        c1.partials = c.partials + 4 * (size_t)PART_CAP;                   // (its sums: the parity-1 region; the finish kernel writes parity 0)
-        const int pe = prof_begin(h, FOS_PROF_KKT, 0, h->cg_total);
-        launch_cgm_sweep(c1, it0, -1);
-        prof_end(h, pe);
-        if (rccl) { launch_reduce1(c1, c.S.nwg, 3, 1, 0); FOS_TRY(allreduce(h, 3)); }
-        launch_cgp_finish(c, piped_desc(1));
-    } else if (merged) {
+    if (merged) {
         // start: sweep M v, ONE launch for r = rhs - M v (+ r.r records, tau row, slot-spread rows, the solve's scalars), then
         // w_0 = M r_0, the sweep every iteration's update starts from (it also adds g_0 = r_0.r_0 unless the first update does)
         CgmIter it0 = merged_desc(0);
@@ -518,21 +486,6 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
         launch_cg_init_finalize(c, h->R, tol, maxit, fr);                  // :35-36
     }
     auto enqueue = [&](int count) -> int {
-        if (piped) {
-            for (int q = 0; q < count && next_j <= maxit; ++q, ++next_j) {
-                CgpIter it = piped_desc(next_j);
-                FOS_TRY(piped_reduce(next_j));
-                // the sweep behind the LAST iteration's returns in its prologue: recorded as iteration j + 1, which the profile drops
-                const int pe = prof_begin(h, FOS_PROF_KKT, next_j, h->cg_total + next_j);
-                launch_cgp_sweep(c, it);
-                prof_end(h, pe);
-            }
-            CgpIter it = piped_desc(next_j);                              // the last enqueued iteration is closed by a one-workgroup launch
-            if (mark_last) it.batch_mark = batch_id;
-            FOS_TRY(piped_reduce(next_j));
-            launch_cgp_close(c, it);
-            return FOS_OK;
-        }
         if (merged) {
             for (int q = 0; q < count && next_j <= maxit; ++q, ++next_j) {
                 CgmIter it = merged_desc(next_j);
@@ -1162,7 +1115,7 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     // 64-block shard: 13 -> 20 us against 5 us), so it stays an option (fos_set_tuning / FOS_CG_FUSE_P)
     h->fuse_p = false;
     if (const char* e = getenv("FOS_CG_FUSE_P")) h->fuse_p = atoi(e) != 0;
-    if (const char* e = getenv("FOS_CG_VARIANT")) h->cg_variant = std::max(-1, std::min((int)FOS_CG_PIPELINED, atoi(e)));
+    if (const char* e = getenv("FOS_CG_VARIANT")) h->cg_variant = std::max(-1, std::min((int)FOS_CG_MERGED_UPDATE, atoi(e)));
     h->S.npart = h->S.nwg_def > 0 ? h->S.nwg_def : h->S.nwg;
     h->S.part_off = h->S.nwg_def > 0 ? h->S.nwg : 0;
     // free the big host arrays (keep block table for re-partitioning)
@@ -1183,7 +1136,7 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
 
     // ---- vectors
     const size_t l = (size_t)h->l;
-    d2** vecs[] = {&h->X, &h->T1, &h->T2, &h->SOL, &h->RHS, &h->R, &h->PB[0], &h->PB[1], &h->AP, &h->Y, &h->XOLD, &h->W, &h->SOL2, &h->WB, &h->ZV};
+    d2** vecs[] = {&h->X, &h->T1, &h->T2, &h->SOL, &h->RHS, &h->R, &h->PB[0], &h->PB[1], &h->AP, &h->Y, &h->XOLD, &h->W, &h->SOL2};
     for (d2** v : vecs) {
         FOS_TRY(dev_alloc(h, v, l));
         FOS_HIP(hipMemset(*v, 0, sizeof(d2) * l));
@@ -1235,7 +1188,7 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     }
     FOS_HIP(hipHostMalloc((void**)&h->st_host, sizeof(DevState), hipHostMallocDefault));
     memset(h->st_host, 0, sizeof(DevState));
-    FOS_TRY(dev_alloc(h, &h->partials, (size_t)8 * PART_CAP));
+    FOS_TRY(dev_alloc(h, &h->partials, (size_t)6 * PART_CAP));
     FOS_TRY(dev_alloc(h, &h->reduced, 16));
     FOS_HIP(hipMemset(h->reduced, 0, sizeof(double) * 16));
     if (const char* e = getenv("FOS_CG_CHUNK")) h->cg_chunk = std::max(1, atoi(e));
@@ -2036,7 +1989,7 @@ int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int3
 
 // which CG recurrence the affine projection runs (FOS_CG_*; -1: the handle's default)
 int fos_set_cg_variant(fos_handle h, int32_t variant) {
-    if (!h || variant < -1 || variant > FOS_CG_PIPELINED) { set_error("unknown CG variant %d", (int)variant); return FOS_EINVAL; }
+    if (!h || variant < -1 || variant > FOS_CG_MERGED_UPDATE) { set_error("unknown CG variant %d", (int)variant); return FOS_EINVAL; }
     h->cg_variant = variant;
     if (variant >= 0) h->fuse_p = variant == FOS_CG_FUSED_P;
     h->last_cg_pred = 0; h->cg_same_run = 0;
@@ -2049,9 +2002,7 @@ int fos_get_cg_variant(fos_handle h, int32_t* variant) {
     static const bool fold_env = !(getenv("FOS_PEER_FOLD") && atoi(getenv("FOS_PEER_FOLD")) == 0);
     int v = h->cg_variant >= 0 ? h->cg_variant : (h->fuse_p ? FOS_CG_FUSED_P : (h->sharded() ? FOS_CG_MERGED_UPDATE : FOS_CG_REFERENCE));
     if (v == FOS_CG_MERGED_SWEEP && h->sharded()) v = FOS_CG_MERGED_UPDATE;
-    // the pipelined form needs row-block / dual-tile storage and whole vectors per rank
-    if (v == FOS_CG_PIPELINED && (h->S.npanel > 0 || h->row_sharded)) v = h->sharded() ? FOS_CG_MERGED_UPDATE : FOS_CG_REFERENCE;
-    if ((v == FOS_CG_MERGED_UPDATE || v == FOS_CG_PIPELINED) && h->peer_on && !fold_env) v = FOS_CG_REFERENCE;
+    if (v == FOS_CG_MERGED_UPDATE && h->peer_on && !fold_env) v = FOS_CG_REFERENCE;
     *variant = v;
     return FOS_OK;
 }

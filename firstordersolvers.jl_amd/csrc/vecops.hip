@@ -570,101 +570,6 @@ void launch_cgm_start(const LaunchCtx& c, const CgmIter& it, const double2* rhs,
         else hipLaunchKernelGGL((cgm_start_kernel<false, false>), grid, block, 0, c.stream, a, c.S);
     }
 }
-// Pipelined CG, start of a solve: behind the sweep w_0 = M r_0 this kernel FINISHES w_0 in place -- the tau row from the sweep's
-// sums, the rows spread over dual-tile slots from their lists (the first pipelined sweep gathers from all of w_0) -- and leaves
-// what the first prologue needs: the records {r.r, w.r, [c;b].w1, [c;b].w2} of iteration 0 and the stash (r_tau, w_tau).
-struct CgpFinishArgs {
-    int64_t l;
-    const d2* r;
-    d2* w;
-    DevState* st;
-    const double* kkt_partials; int nkkt;
-    const double* reduced; int from_reduced;
-    double* rec_out;
-    const double* cb; int n;
-    const uint32_t* def_mask;
-    PeerBox pb; uint32_t seq; int count_repl;
-};
-template <bool DEF, bool FOLD>
-__global__ __launch_bounds__(VEC_THREADS) void cgp_finish_kernel(CgpFinishArgs a, DevBlkCsr S) {
-    const int64_t l = a.l;
-    const int64_t stride = (int64_t)gridDim.x * VEC_THREADS;
-    const int64_t i0 = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x;
-    DevState* st = a.st;
-    const double vtx = st->vtau[0], vty = st->vtau[1];           // tau element of r_0 (stashed by the sweep)
-    if (st->done) return;
-    if (FOLD && st->xchg_failed) return;
-    __shared__ double sums[3];
-    sweep_sums3(sums, a.kkt_partials, a.nkkt, a.reduced, a.from_reduced, nullptr, 0u, st);
-    if constexpr (FOLD) {
-        if (!peer_fold_sum<3>(a.pb, a.seq, sums, st)) return;
-    }
-    const double T1 = sums[1], T2 = sums[2];
-    const double wt1 = vtx + T2, wt2 = -T1 - vty;                // HSDEAffine.jl:57
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        a.w[l - 1] = make_double2(wt1, wt2);
-        st->vt2[0] = vtx; st->vt2[1] = vty; st->vt2[2] = wt1; st->vt2[3] = wt2;
-    }
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    auto add = [&](const d2& ri, const d2& wi, double c) {
-        acc[0] += ri.x * ri.x + ri.y * ri.y;
-        acc[1] += wi.x * ri.x + wi.y * ri.y;
-        acc[2] += c * wi.x;
-        acc[3] += c * wi.y;
-    };
-    if constexpr (DEF) {
-        const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots_rd);
-        const int lpr = S.def_lpr, sh = 31 - __clz(lpr);
-        const int rows_per_pass = (gridDim.x * VEC_THREADS) >> sh;
-        const int lig = threadIdx.x & (lpr - 1);
-        const int npass = (S.ndef + rows_per_pass - 1) / rows_per_pass;
-        int q = (blockIdx.x * VEC_THREADS + threadIdx.x) >> sh;
-        for (int pass = 0; pass < npass; ++pass, q += rows_per_pass) {
-            const bool ok = q < S.ndef;
-            DefRow dr{};
-            if (ok) dr = ld_defrow(S.def_rec + q);
-            const int row = dr.row;
-            const bool own = ok && lig == 0;
-            d2 ri = make_double2(0.0, 0.0);
-            double c = 0.0;
-            if (own) { ri = a.r[row]; c = a.cb[row]; }
-            double u1 = 0.0, u2 = 0.0;
-            if (ok) slot_list_sum(slots, S.def_idx, dr, lig, lpr, u1, u2);
-            u1 = group_sum(u1, lpr);
-            u2 = group_sum(u2, lpr);
-            if (own) {
-                double q1, q2;                                  // EpiKkt::row (kernels.hip) on the applied vector r_0
-                if (row < a.n) { q1 = u1 + vtx * c; q2 = u2 + vty * c; }
-                else { q1 = -(u1 - vtx * c); q2 = -(u2 - vty * c); }
-                const d2 wi = make_double2(ri.x - q2, q1 - ri.y);
-                a.w[row] = wi;
-                if (a.count_repl) add(ri, wi, c);
-            }
-        }
-    }
-    for (int64_t k = i0; k < l - 1; k += stride) {               // (the tau element: added from the stash by the prologue)
-        if constexpr (DEF) { if ((a.def_mask[k >> 5] >> (k & 31)) & 1u) continue; }
-        add(a.r[k], a.w[k], a.cb[k]);
-    }
-    block_reduce_store<4>(acc, a.rec_out + 4 * (int64_t)blockIdx.x);
-}
-void launch_cgp_finish(const LaunchCtx& c, const CgpIter& it) {
-    CgpFinishArgs a{};
-    a.l = c.l; a.r = it.r; a.w = it.wbuf[0]; a.st = c.st;
-    a.kkt_partials = c.partials + 4 * (size_t)PART_CAP; a.nkkt = c.S.nwg;     // the sweep w_0 = M r_0 left its sums in the parity-1 region
-    a.reduced = c.reduced; a.from_reduced = it.fold ? 0 : it.from_reduced;
-    a.rec_out = c.partials;                                       // parity 0 region: iteration 0
-    a.cb = c.cb; a.n = (int)c.n; a.def_mask = c.def_mask;
-    a.pb = it.fold ? *it.fold : PeerBox{}; a.seq = it.seq_base + 1u; a.count_repl = (int)c.count_repl;
-    dim3 grid(c.cg_blocks), block(VEC_THREADS);
-    if (c.S.ndef > 0) {
-        if (it.fold) hipLaunchKernelGGL((cgp_finish_kernel<true, true>), grid, block, 0, c.stream, a, c.S);
-        else hipLaunchKernelGGL((cgp_finish_kernel<true, false>), grid, block, 0, c.stream, a, c.S);
-    } else {
-        if (it.fold) hipLaunchKernelGGL((cgp_finish_kernel<false, true>), grid, block, 0, c.stream, a, c.S);
-        else hipLaunchKernelGGL((cgp_finish_kernel<false, false>), grid, block, 0, c.stream, a, c.S);
-    }
-}
 void launch_cgm_update(const LaunchCtx& c, const CgmIter& it, bool close_only) {
     CgmArgs a{};
     a.l = c.l; a.x = it.x; a.r = it.r; a.p = it.p; a.s = it.s; a.w = it.w; a.st = c.st;

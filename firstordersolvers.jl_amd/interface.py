@@ -375,13 +375,13 @@ class HipHSDE:
     def set_cg_variant(self, variant):
         """which CG recurrence the affine projection runs: 'reference' | 'fused_p' | 'merged_sweep' | 'merged_update' | None (default)."""
         codes = {None: -1, "default": -1, "reference": _lib.CG_REFERENCE, "fused_p": _lib.CG_FUSED_P,
-                 "merged_sweep": _lib.CG_MERGED_SWEEP, "merged_update": _lib.CG_MERGED_UPDATE, "pipelined": _lib.CG_PIPELINED}
+                 "merged_sweep": _lib.CG_MERGED_SWEEP, "merged_update": _lib.CG_MERGED_UPDATE}
         _lib.check(self._lib.fos_set_cg_variant(self._h, codes[variant] if not isinstance(variant, int) else variant))
 
     def cg_variant_name(self):
         v = C.c_int32(0)
         _lib.check(self._lib.fos_get_cg_variant(self._h, C.byref(v)))
-        return ("reference", "fused_p", "merged_sweep", "merged_update", "pipelined")[v.value]
+        return ("reference", "fused_p", "merged_sweep", "merged_update")[v.value]
 
     def debug_set(self, what, value):
         _lib.check(self._lib.fos_debug_set(self._h, int(what), int(value)))

@@ -300,9 +300,6 @@ int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int3
 #define FOS_CG_FUSED_P       1
 #define FOS_CG_MERGED_SWEEP  2
 #define FOS_CG_MERGED_UPDATE 3
-#define FOS_CG_PIPELINED     4   /* pipelined (Ghysels-Vanroose) recurrence: ONE launch per iteration -- every vector update is local to
-                                    the row the sweep has just finished (plus a small launch for rows spread over dual-tile slots); one
-                                    exchange of four doubles per iteration when sharded; row-block / dual-tile operators only */
 int fos_set_cg_variant(fos_handle h, int32_t variant);
 int fos_get_cg_variant(fos_handle h, int32_t* variant);   /* the variant the next projection runs (defaults resolved) */
 

@@ -341,53 +341,6 @@ def conjugategradient_merged(x, A, b, r, p, s, w, tol=None, max_iters=10000, spa
     return it
 
 
-def conjugategradient_pipelined(x, A, b, r, p, s, w, z, q, tol=None, max_iters=10000, space=LOCAL):
-    """NOT in the reference: the pipelined (Ghysels & Vanroose) rearrangement the HIP path offers as FOS_CG_PIPELINED (one kernel
-    launch per iteration: every vector update is local to the row the operator sweep has just finished).  Same Krylov iterates in
-    exact arithmetic, the reference's iteration count convention and stop test (conjugategradients.jl:42) on the recursively
-    updated residual; besides x, r, p it carries s = A p, w = A r and z = A s by recurrence and sweeps q = A w:
-        beta_i = g_i / g_{i-1},  alpha_i = g_i / (d_i - beta_i g_i / alpha_{i-1}),  g = r.r, d = w.r   (i = it - 1)
-        z = q + beta z ; s = w + beta s ; p = r + beta p ; x += alpha p ; r -= alpha s ; w -= alpha z.
-    Exists so that the parity tests of that variant compare against the same arithmetic; nothing else uses it."""
-    if tol is None:
-        tol = A.shape[1] * EPS
-    A.mul(w, x)                                  # :32
-    np.subtract(b, w, out=r)                     # :33
-    A.mul(w, r)
-    gam_prev = alpha_prev = None
-    it = 1                                       # :36
-    while True:
-        gam = space.dotN(r, r)
-        delta = space.dotN(w, r)
-        if it > 1 and (np.sqrt(gam) <= tol or it - 1 >= max_iters):   # :42 for the iteration just finished
-            it -= 1
-            break
-        A.mul(q, w)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            if it == 1:
-                alpha = gam / delta
-                z[:] = q
-                s[:] = w
-                p[:] = r
-            else:
-                beta = gam / gam_prev
-                alpha = gam / (delta - beta * gam / alpha_prev)
-                z *= beta
-                z += q
-                s *= beta
-                s += w
-                p *= beta                        # :49
-                p += r                           # :50
-        x += alpha * p                           # :40
-        r -= alpha * s                           # :41   (s = A p)
-        w -= alpha * z                           #       (z = A s)
-        gam_prev, alpha_prev = gam, alpha
-        it += 1                                  # :51
-    if it == max_iters:                          # :53
-        warnings.warn("CG reached max iterations, result may be inaccurate")
-    return it
-
-
 class CGdata:
     """conjugategradients.jl:1-11."""
 
@@ -450,13 +403,7 @@ class AffinePlusLinear:
         tol = self.tolerance()                               # :108-112
         self.i += 1                                          # :114
         max_iters = 1000                                     # :115
-        if self.cg_variant == "pipelined":
-            for name in ("s", "w2", "zz", "qq"):
-                if not hasattr(cg, name):
-                    setattr(cg, name, np.empty_like(cg.r))
-            it = conjugategradient_pipelined(y, self.M, self.rhs, cg.r, cg.p, cg.s, cg.w2, cg.zz, cg.qq, tol=tol, max_iters=max_iters,
-                                             space=getattr(self.A, "space", LOCAL))
-        elif self.cg_variant == "merged":
+        if self.cg_variant == "merged":
             if not hasattr(cg, "s"):
                 cg.s = np.empty_like(cg.r)
             it = conjugategradient_merged(y, self.M, self.rhs, cg.r, cg.p, cg.s, cg.z, tol=tol, max_iters=max_iters,

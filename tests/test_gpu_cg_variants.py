@@ -15,8 +15,7 @@ import fos_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = ["merged_sweep", "merged_update", "pipelined"]
-ORACLE_CG = {"merged_sweep": "merged", "merged_update": "merged", "pipelined": "pipelined"}
+VARIANTS = ["merged_sweep", "merged_update"]
 
 
 def _codes(cones):
@@ -39,7 +38,7 @@ def _operators():
 def _ocg(fn, M, x0, rhs, tol, maxit):
     N = x0.shape[0]
     x = x0.copy()
-    nb = {orc.conjugategradient_merged: 4, orc.conjugategradient_pipelined: 6}.get(fn, 3)
+    nb = 4 if fn is orc.conjugategradient_merged else 3
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         it = fn(x, M, rhs, *[np.empty(N) for _ in range(nb)], tol=tol, max_iters=maxit)
@@ -65,16 +64,14 @@ def test_merged_cg_matches_dense_solve_and_oracle(pkg, variant):
         # the first iterations agree to rounding with the same recurrence on the host
         for k in (1, 2, 5):
             xk, it = d.cg_kkt(x0, rhs, 1e-300, k)
-            ofn = getattr(orc, "conjugategradient_" + ORACLE_CG[variant])
-            xo, ito = _ocg(ofn, M, x0, rhs, 1e-300, k)
+            xo, ito = _ocg(orc.conjugategradient_merged, M, x0, rhs, 1e-300, k)
             assert it == ito == k, (name, k, it)                  # max_iters cap (conjugategradients.jl:42)
             assert relerr(xk, xo) < 1e-12, (name, k)
-        # tolerance floor: the dense solution, iteration count near both host recurrences (the pipelined recurrence stagnates
-        # near 1e-12 on these systems -- tests/test_cg_merged_oracle.py -- and is asked for 1e-10)
-        tol = d.N * np.finfo(float).eps if variant != "pipelined" else 1e-10
+        # tolerance floor: the dense solution, iteration count near both host recurrences
+        tol = d.N * np.finfo(float).eps
         x, it = d.cg_kkt(x0, rhs, tol, 10000)
-        assert relerr(x, xs) < (1e-12 if variant != "pipelined" else 1e-10), name
-        _, it_m = _ocg(ofn, M, x0, rhs, tol, 10000)
+        assert relerr(x, xs) < 1e-12, name
+        _, it_m = _ocg(orc.conjugategradient_merged, M, x0, rhs, tol, 10000)
         _, it_r = _ocg(orc.conjugategradient, M, x0, rhs, tol, 10000)
         # (hundreds of iterations of a chaotic recurrence on the indefinite system: counts agree to a few per cent)
         assert abs(it - it_m) <= 8 + it_m // 20 and abs(it - it_r) <= 8 + it_r // 20, (name, it, it_m, it_r)
@@ -101,7 +98,7 @@ def test_prox_affine_sequence_merged(pkg, variant):
     d.set_cg_variant(variant)
     Q = orc.HSDEMatrixQ(A, b, c)
     S = orc.AffinePlusLinear(Q, np.zeros(d.l), np.zeros(d.l), 1, decreasing_accuracy=True)
-    S.cg_variant = ORACLE_CG[variant]
+    S.cg_variant = "merged"
     Qd = Q.todense()
     Md = np.block([[np.eye(d.l), Qd.T], [Qd, -np.eye(d.l)]])
     for call in range(1, 7):
@@ -147,8 +144,8 @@ def test_first_iterations_match_merged_oracle(pkg, algname, variant):
     d.set_cg_variant(variant)
     mk = {"DR": lambda M: M.DR(), "GAPA": lambda M: M.GAPA(0.8, 0.5), "FISTA": lambda M: M.FISTA()}[algname]
     iters = 25
-    ref = _oracle_run(prob, mk, iters, False, ORACLE_CG[variant])
-    per = _oracle_run(prob, mk, iters, True, ORACLE_CG[variant])
+    ref = _oracle_run(prob, mk, iters, False, "merged")
+    per = _oracle_run(prob, mk, iters, True, "merged")
     d.set_alg(mk(pkg))
     d.set_iterate(None)
     envelope = kicks = 0.0
@@ -228,7 +225,7 @@ def test_cg_chain_bench_runs_for_every_variant(pkg):
     prob = pkg.workloads.small_lp(seed=21, m=96, n=180)
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     d.set_iterate(None)
-    for variant in ("reference", "fused_p", "merged_sweep", "merged_update", "pipelined"):
+    for variant in ("reference", "fused_p", "merged_sweep", "merged_update"):
         d.set_cg_variant(variant)
         for graph in (0, 1):
             assert d.bench_cg_chain(5, 2, graph) > 0.0
