@@ -78,3 +78,31 @@ def test_linesearch_solve_prints_and_converges(pkg, oracle):
     with pytest.raises(pkg.lib.FosError):
         d.set_linesearch(10)
     d.close()
+
+
+def test_linesearch_is_refused_on_sharded_handles(pkg):
+    """normres / normdiff of the search (linesearch.jl:50,62) are GLOBAL norms; the device search adds one rank's partial sums only,
+    so a sharded handle must refuse the wrapper -- in both orders -- instead of letting the ranks pick different step lengths
+    (round-2 advisor finding)."""
+    prob = pkg.workloads.c1_readme_nnls(seed=2)
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d.set_alg(pkg.DR())
+    d.comm_init_host(1, 0, lambda a: None)                     # a one-rank "sharded" handle
+    with pytest.raises(pkg.lib.FosError) as ei:
+        d.set_linesearch(10)
+    assert ei.value.code == -4                                 # FOS_EUNSUPPORTED
+    d.close()
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d.set_alg(pkg.DR())
+    d.set_linesearch(10)
+    with pytest.raises(pkg.lib.FosError) as ei:
+        d.comm_init_host(1, 0, lambda a: None)
+    assert ei.value.code == -4
+    d.set_linesearch(0)
+    d.comm_init_host(1, 0, lambda a: None)                     # fine once the wrapper is off
+    d.close()
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2, row_sharded=True)
+    d.set_alg(pkg.DR())
+    with pytest.raises(pkg.lib.FosError):
+        d.set_linesearch(10)
+    d.close()
