@@ -119,12 +119,19 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
                                                                 const double* __restrict__ reduced, int from_reduced, int j,
                                                                 double* __restrict__ partials, DevBlkCsr S, const double* __restrict__ cb, int n,
                                                                 const uint32_t* __restrict__ def_mask, PeerBox pb, uint32_t seq_base, int count_repl,
-                                                                double* __restrict__ pre, uint32_t pre_seq) {
+                                                                double* __restrict__ pre, uint32_t pre_seq, int ndb_arg, int dlpr) {
+    // ROLES (ndb > 0; operators with few slot-spread rows and long vectors, C4): the first ndb workgroups finish ONLY the rows
+    // spread over slots (dlpr lanes per row), the others ONLY stream -- the slot lists are a chain of dependent loads that every
+    // thread used to walk through before its first stream element; now the stream runs beside it.
+    const int ndb = DEF ? ndb_arg : 0;
+    const bool def_role = DEF && ndb > 0 && (int)blockIdx.x < ndb;
+    const int nsblk = ndb > 0 ? (int)gridDim.x - ndb : (int)gridDim.x;
+    const int sblk = ndb > 0 ? (def_role ? 0 : (int)blockIdx.x - ndb) : (int)blockIdx.x;
     // the first element of this thread's slice is requested BEFORE the scalar prologue (two dependent round trips and two
     // barriers): on small operators the prologue's latency, not bandwidth, is what this kernel costs
-    const int64_t stride = (int64_t)gridDim.x * VEC_THREADS;
-    const int64_t i0 = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x;
-    bool have0 = i0 < l;
+    const int64_t stride = (int64_t)nsblk * VEC_THREADS;
+    const int64_t i0 = sblk * (int64_t)VEC_THREADS + threadIdx.x;
+    bool have0 = !def_role && i0 < l;
     if constexpr (DEF) { if (have0 && ((def_mask[i0 >> 5] >> (i0 & 31)) & 1u)) have0 = false; }
     d2 p0 = make_double2(0.0, 0.0), a0 = p0, x0 = p0, r0 = p0;
     if (have0) { a0 = Ap[i0]; r0 = r[i0]; if constexpr (XUPD) { p0 = p[i0]; x0 = x[i0]; } }
@@ -148,9 +155,10 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
     }
     double acc[1] = {0.0};
     if constexpr (DEF) {
+      if (ndb == 0 || def_role) {
         const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots_rd);
-        const int lpr = S.def_lpr, sh = 31 - __clz(lpr);
-        const int rows_per_pass = (gridDim.x * VEC_THREADS) >> sh;
+        const int lpr = ndb > 0 ? dlpr : S.def_lpr, sh = 31 - __clz(lpr);
+        const int rows_per_pass = ((ndb > 0 ? ndb : (int)gridDim.x) * VEC_THREADS) >> sh;
         const int lig = threadIdx.x & (lpr - 1);
         const int npass = (S.ndef + rows_per_pass - 1) / rows_per_pass;       // uniform trip count: the DPP sums need full waves
         int q = (blockIdx.x * VEC_THREADS + threadIdx.x) >> sh;
@@ -178,7 +186,9 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
                 if (count_repl) acc[0] += ri.x * ri.x + ri.y * ri.y;       // (row-sharded: replicated rows are counted by one rank)
             }
         }
+      }
     }
+    if (def_role) { block_reduce_store<1>(acc, partials + blockIdx.x); return; }
     if (have0) {
         if (i0 == l - 1) a0 = make_double2(at1, at2);
         if constexpr (XUPD) { x0.x += alpha * p0.x; x0.y += alpha * p0.y; x[i0] = x0; }
@@ -209,10 +219,19 @@ void launch_cg_update(const LaunchCtx& c, const CgIter& it, double2* x, double2*
     dim3 grid(c.cg_blocks), block(VEC_THREADS);
     // many sweep records and enough workgroups: the first PRE_NPROD of them add the records for all (cg_update_kernel)
     double* pre = (c.pre && !it.fold && !kkt_from_reduced && c.S.nwg >= 2048 && c.cg_blocks >= 4 * PRE_NPROD) ? c.pre : nullptr;
+    // roles (cg_update_kernel): a quarter of the grid at most for the slot-spread rows, with as many lanes per row as that allows
+    int ndb = 0, dlpr = 1;
+    static const bool split_env = !(getenv("FOS_UPD_SPLIT") && atoi(getenv("FOS_UPD_SPLIT")) == 0);
+    if (split_env && c.S.ndef > 0 && c.l >= 8 * (int64_t)c.S.ndef && c.cg_blocks >= 64) {
+        const int64_t target = c.cg_blocks / 4;
+        while (dlpr < c.S.def_lpr && ((int64_t)c.S.ndef * (2 * dlpr) + VEC_THREADS - 1) / VEC_THREADS <= target) dlpr *= 2;
+        ndb = (int)(((int64_t)c.S.ndef * dlpr + VEC_THREADS - 1) / VEC_THREADS);
+        if (ndb < 1 || ndb > c.cg_blocks / 2) ndb = 0;
+    }
 #define FOS_UPD(DEF, FOLD, XUPD)                                                                                             \
     hipLaunchKernelGGL((cg_update_kernel<DEF, FOLD, XUPD>), grid, block, 0, c.stream, c.l, x, r, (const d2*)it.p_cur, Ap, c.st, c.partials, \
                        c.S.nwg, c.reduced, it.fold ? 0 : kkt_from_reduced, it.j, rr_out, c.S, c.cb, (int)c.n, c.def_mask, pb, it.seq_base, (int)c.count_repl, \
-                       pre, (uint32_t)(it.seq_base + 2u * (uint32_t)it.j + 1u))
+                       pre, (uint32_t)(it.seq_base + 2u * (uint32_t)it.j + 1u), ndb, dlpr)
 #define FOS_UPD2(DEF, FOLD) do { if (it.fuse_p) FOS_UPD(DEF, FOLD, true); else FOS_UPD(DEF, FOLD, false); } while (0)
     if (c.S.ndef > 0) { if (it.fold) FOS_UPD2(true, true); else FOS_UPD2(true, false); }
     else { if (it.fold) FOS_UPD2(false, true); else FOS_UPD2(false, false); }
