@@ -606,10 +606,7 @@ __device__ __forceinline__ void win_slice_compute(const DevBlkCsr& S, const WinS
 // 136-145 us (twice the barriers); per-lane-count predicated loads 210-260 us; next segment's descriptors requested one segment
 // ahead by scalar loads 111.6 us (they share the LDS counter, so the LDS accesses wait for them anyway), by vector loads from a
 // flat per-(segment, wavefront) table 127 us.
-// WPRE: the NEXT segment's window elements are requested right after this segment's window has been written to LDS, i.e. BEFORE
-// the multiply -- the window registers are free by then, so the fetch of window k+1 runs beside the multiply of window k at no
-// cost in registers or barriers (the slices of segment k+1 still follow the multiply: their registers are in use).
-template <bool WPRE, class G, class Epi>
+template <class G, class Epi>
 __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& epi, double* lds) {
     constexpr int NRHS = G::NRHS;
     constexpr int NWAVES = WIN_THREADS / 64;
@@ -624,36 +621,18 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
         for (int i = tid; i < wp.nrows; i += WIN_THREADS) {
             if constexpr (NRHS == 2) acc[i] = make_double2(0.0, 0.0); else acc[i] = 0.0;
         }
-        d2 wreg[WPT];
-        int ncols_pre = 0;
-        if constexpr (WPRE) {                              // the panel's first window
-            if (wp.nseg > 0) {
-                const cptr_seg s0 = (cptr_seg)(S.wseg + wp.seg0);
-                const int c0 = s0->col0;
-                ncols_pre = s0->ncols;
-#pragma unroll
-                for (int q = 0; q < WPT; ++q) {
-                    const int i = tid + q * WIN_THREADS;
-                    wreg[q] = (i < ncols_pre) ? gat.load(c0 + i) : make_double2(0.0, 0.0);
-                }
-            }
-        }
         for (int sgi = wp.seg0; sgi < wp.seg0 + wp.nseg; ++sgi) {
             const cptr_seg sgp = (cptr_seg)(S.wseg + sgi);
             const int col0 = sgp->col0, ncols = sgp->ncols, slice0 = sgp->slice0, nslice = sgp->nslice;
-            // the next segment's window (WPRE), wave-uniform: requested with this segment's descriptors, used after the second barrier
-            int ncol0 = 0, nncols = 0;
-            if constexpr (WPRE) { if (sgi + 1 < wp.seg0 + wp.nseg) { const cptr_seg sn = (cptr_seg)(S.wseg + sgi + 1); ncol0 = sn->col0; nncols = sn->ncols; } }
             // ---- everything this segment needs from memory is requested here, in one go
             WinSliceRegs r[WIN_NSL];
 #pragma unroll
             for (int u = 0; u < WIN_NSL; ++u) win_slice_desc(S, slice0 + wv + u * NWAVES, wv + u * NWAVES < nslice, r[u]);
-            if constexpr (!WPRE) {
+            d2 wreg[WPT];
 #pragma unroll
-                for (int q = 0; q < WPT; ++q) {
-                    const int i = tid + q * WIN_THREADS;
-                    wreg[q] = (i < ncols) ? gat.load(col0 + i) : make_double2(0.0, 0.0);
-                }
+            for (int q = 0; q < WPT; ++q) {
+                const int i = tid + q * WIN_THREADS;
+                wreg[q] = (i < ncols) ? gat.load(col0 + i) : make_double2(0.0, 0.0);
             }
 #pragma unroll
             for (int u = 0; u < WIN_NSL; ++u) win_slice_issue(S, slice0 + wv + u * NWAVES, lane, r[u]);
@@ -664,13 +643,6 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
                 if (i < ncols) { if constexpr (NRHS == 2) win[i] = wreg[q]; else win[i] = wreg[q].x; }
             }
             __syncthreads();
-            if constexpr (WPRE) {
-#pragma unroll
-                for (int q = 0; q < WPT; ++q) {
-                    const int i = tid + q * WIN_THREADS;
-                    wreg[q] = (i < nncols) ? gat.load(ncol0 + i) : make_double2(0.0, 0.0);
-                }
-            }
 #pragma unroll
             for (int u = 0; u < WIN_NSL; ++u) win_slice_compute<NRHS>(S, r[u], win, acc, lane);
             for (int sl = slice0 + wv + WIN_NSL * NWAVES; sl < slice0 + nslice; sl += NWAVES) {      // (more slices than the registers hold: rare)
@@ -812,7 +784,6 @@ __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBl
 }
 
 // window-panel form of the sweep (stand-alone applies and CG iterations alike: no dual tiles, the p update is a kernel of its own)
-template <bool WPRE>
 __global__ __launch_bounds__(WIN_THREADS, 4) void kkt2_win_kernel(DevBlkCsr S, KktArgs a) {
     if (a.gate && a.close_j < 0 && a.st->done) return;
     extern __shared__ __attribute__((aligned(16))) double wlds[];
@@ -823,7 +794,7 @@ __global__ __launch_bounds__(WIN_THREADS, 4) void kkt2_win_kernel(DevBlkCsr S, K
     epi.gat = gat; epi.out = a.out; epi.pnew = nullptr; epi.cb = a.cb; epi.n = a.n; epi.wt = gat.load_u(a.nm);
     epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
     if (a.vt_out && blockIdx.x == 0 && threadIdx.x == 0) { a.vt_out[0] = epi.wt.x; a.vt_out[1] = epi.wt.y; }
-    win_walk<WPRE>(S, gat, epi, wlds);
+    win_walk(S, gat, epi, wlds);
     block_reduce_store<3, WIN_THREADS>(epi.acc, wlds + (size_t)(WIN_COLS + WIN_ROWS) * 2, a.partials + 3 * (int64_t)blockIdx.x);
 }
 // dynamic LDS above 64 KB needs an opt-in per kernel and device
@@ -834,13 +805,8 @@ static bool win_lds_optin(K kernel, size_t bytes) {
     return true;
 }
 static void launch_kkt2_win(const LaunchCtx& c, const KktArgs& a) {
-    if (c.S.dbg_flags & 2) {                                      // (FOS_DBG_FLAGS bit 1: the form without the window prefetch, for A/B timing)
-        (void)win_lds_optin(kkt2_win_kernel<false>, win_lds_bytes(2));
-        hipLaunchKernelGGL(kkt2_win_kernel<false>, dim3(c.S.nwg), dim3(WIN_THREADS), win_lds_bytes(2), c.stream, c.S, a);
-        return;
-    }
-    (void)win_lds_optin(kkt2_win_kernel<true>, win_lds_bytes(2));       // cheap (a table update); a failure surfaces through check_launch
-    hipLaunchKernelGGL(kkt2_win_kernel<true>, dim3(c.S.nwg), dim3(WIN_THREADS), win_lds_bytes(2), c.stream, c.S, a);
+    (void)win_lds_optin(kkt2_win_kernel, win_lds_bytes(2));       // cheap (a table update); a failure surfaces through check_launch
+    hipLaunchKernelGGL(kkt2_win_kernel, dim3(c.S.nwg), dim3(WIN_THREADS), win_lds_bytes(2), c.stream, c.S, a);
 }
 
 // Deferred rows (dual tiles): `lpr` lanes (a power of two <= 64, S.def_lpr) share a row: lane-strided partial sums of the
@@ -1185,7 +1151,7 @@ __global__ __launch_bounds__(WIN_THREADS, 4) void q1_win_kernel(DevBlkCsr S, con
     for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
     epi.init(vcomp[2 * (int64_t)nm]);
     Gather1 gat{vcomp};
-    win_walk<false>(S, gat, epi, wlds);
+    win_walk(S, gat, epi, wlds);
     block_reduce_store<NACC, WIN_THREADS>(epi.acc, wlds + (size_t)(WIN_COLS + WIN_ROWS), partials + NACC * (int64_t)blockIdx.x);
 }
 template <class Epi, int NACC>
