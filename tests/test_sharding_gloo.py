@@ -113,7 +113,7 @@ def test_row_sharded_oracle_matches_unsharded(pkg, oracle, algname):
     assert got[0][2]["nb"] == pytest.approx(st.last["nb"], rel=1e-12) and got[0][2]["nc"] == pytest.approx(st.last["nc"], rel=1e-12)
 
 
-def _worker(rank, world, port, algname, iters, q):
+def _worker(rank, world, port, algname, iters, q, cg_variant="reference"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, str(ROOT))
@@ -138,6 +138,7 @@ def _worker(rank, world, port, algname, iters, q):
     mo = orc.Model(lp.A, lp.b, lp.c, codes(lp.K1), codes(lp.K2), space=space)
     alg = {"DR": orc.DR, "GAPA": lambda: orc.GAPA(0.8, 0.5), "FISTA": orc.FISTA}[algname]()
     alg.init(mo)
+    alg.S1.cg_variant = cg_variant
     x = orc.hsde_initialvalue(mo)
     st = orc.HSDEStatus(mo, iters, 1e-6, 0, 1, S1=alg.S1)
     cg = []
@@ -150,15 +151,18 @@ def _worker(rank, world, port, algname, iters, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("algname", ["DR", "GAPA", "FISTA"])
-def test_sharded_oracle_matches_unsharded(pkg, oracle, algname):
+@pytest.mark.parametrize("algname,cg_variant", [("DR", "reference"), ("GAPA", "reference"), ("FISTA", "reference"),
+                                                ("DR", "merged"), ("GAPA", "merged")])
+def test_sharded_oracle_matches_unsharded(pkg, oracle, algname, cg_variant):
+    """cg_variant = "merged": the merged-reduction recurrence -- what sharded HIP handles run by default -- with its inner products
+    all-reduced over two gloo ranks (replicated entries counted once) against the unsharded run of the same recurrence."""
     import torch.multiprocessing as mp
     orc = oracle
     iters, world = 12, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, algname, iters, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, algname, iters, q, cg_variant)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -174,6 +178,7 @@ def test_sharded_oracle_matches_unsharded(pkg, oracle, algname):
     mo = orc.Model(prob.A, prob.b, prob.c, codes(prob.K1), codes(prob.K2))
     alg = {"DR": orc.DR, "GAPA": lambda: orc.GAPA(0.8, 0.5), "FISTA": orc.FISTA}[algname]()
     alg.init(mo)
+    alg.S1.cg_variant = cg_variant
     x = orc.hsde_initialvalue(mo)
     st = orc.HSDEStatus(mo, iters, 1e-6, 0, 1, S1=alg.S1)
     cg = []
@@ -192,7 +197,9 @@ def test_sharded_oracle_matches_unsharded(pkg, oracle, algname):
     l1 = shards[1].problem.m + shards[1].problem.n + 1
     assert got[0][0][l0 - 1] == got[1][0][l1 - 1] and got[0][0][-1] == got[1][0][-1]
     if got[0][1] == cg:
-        assert np.linalg.norm(z - x) <= 1e-6 * max(1.0, np.linalg.norm(x))
+        # (12 outer iterations of the chaos envelope of tests/test_gpu_parity.py: summation order differs between the sharded and
+        #  the unsharded inner products; measured 1.4e-6 for the merged recurrence, below 1e-6 for the reference one)
+        assert np.linalg.norm(z - x) <= (1e-6 if cg_variant == "reference" else 1e-5) * max(1.0, np.linalg.norm(x))
     else:
         assert np.linalg.norm(z - x) <= 0.2 * max(1.0, np.linalg.norm(x))
     # status sums agree between ranks (all-reduced) and with the unsharded check on the same kind of point
