@@ -60,6 +60,8 @@ PROTOTYPES = {
     "fos_peer_export": (C.c_int, [_h, C.c_void_p]),
     "fos_peer_open": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p, C.c_double]),
     "fos_peer_selftest": (C.c_int, [_h, C.c_int, C.POINTER(C.c_int32)]),
+    "fos_peer_vec_export": (C.c_int, [_h, C.c_void_p]),
+    "fos_peer_vec_open": (C.c_int, [_h, C.c_void_p]),
     "fos_peer_enable": (C.c_int, [_h, C.c_int32]),
     "fos_set_alg": (C.c_int, [_h, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
     "fos_reset_affine": (C.c_int, [_h]),

@@ -250,6 +250,26 @@ struct PeerBox {
     int64_t timeout_ticks;            // wall_clock64() ticks (100 MHz) an exchange may wait for its peers
 };
 
+// Row-sharded operators without a collective library: the n-vector exchange of HSDEAffine.jl:51 (A'y = sum over the ranks of
+// A_g' y_g, both right-hand sides: 2n doubles) through peer-mapped memory.  Every rank owns a buffer [2 parities][nranks][2n]
+// doubles + flags [2][nranks] in UNCACHED device memory that its peers map through HIP IPC.  An exchange = two launches:
+//   push   every workgroup copies a chunk of this rank's slots into every peer's buffer (slot [parity][this rank]); the LAST
+//          workgroup to finish (a local counter) raises this rank's flag in every peer's flag array with the exchange's number;
+//   sum    every workgroup waits for all peers' flags of this exchange, then adds the contributions in rank order (its own from
+//          the local slots) into slots_rd -- the same bits on every rank.
+// The parity of the exchange number selects the half: a rank can be at most one exchange ahead of a peer (its next push needs
+// the peer's flag of the one in between).  Bandwidth: 16 n (g-1) bytes written over xGMI per rank and apply.
+struct LaunchCtx;
+struct VecBox {
+    double* const* buf;        // device table [nranks]: rank r's buffer (own entry: the local allocation)
+    uint32_t* const* flags;    // device table [nranks]: rank r's flag array
+    uint32_t* counter;         // local: workgroups of the push kernel that have finished
+    int32_t nranks, rank;
+    int64_t n2;                // doubles per contribution (2 n)
+    int64_t timeout_ticks;
+};
+void launch_vec_exchange(const LaunchCtx& c, const VecBox& vb, uint32_t seq, const double* slots, double* slots_rd);
+
 // ---------------------------------------------------------------------------------- kernel launchers (kernels.hip / psd.hip)
 struct LaunchCtx {
     hipStream_t stream;

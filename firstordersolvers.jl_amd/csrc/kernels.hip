@@ -14,6 +14,7 @@
 //   relaxation / extrapolation passes of gap.jl:48,58,78  gapa.jl:67,77,96-103  fista.jl:31-46.
 //
 // Wavefront = 64 lanes; workgroups of 256 threads (4 waves) unless noted; all arithmetic fp64.
+#include <algorithm>
 #include <type_traits>
 
 #include "dev_common.hpp"
@@ -918,6 +919,61 @@ __global__ __launch_bounds__(FIN_THREADS) void reduce_kernel(const double* __res
         }
         if (t == 0) *pb.seq = seq;
     }
+}
+
+// ---- n-vector exchange of a row-sharded operator through peer-mapped memory (fos_internal.hpp, VecBox)
+constexpr int VEC_X_THREADS = 256;
+__global__ __launch_bounds__(VEC_X_THREADS) void vec_push_kernel(VecBox vb, uint32_t seq, const double* __restrict__ slots, DevState* st) {
+    if (st->xchg_failed) return;
+    const size_t half = (size_t)(seq & 1u) * (size_t)vb.nranks;
+    const int64_t n2 = vb.n2;
+    for (int r = 0; r < vb.nranks; ++r) {
+        if (r == vb.rank) continue;
+        double* dst = vb.buf[r] + (half + (size_t)vb.rank) * (size_t)n2;
+        for (int64_t k = blockIdx.x * (int64_t)VEC_X_THREADS + threadIdx.x; k < n2; k += (int64_t)gridDim.x * VEC_X_THREADS)
+            __builtin_nontemporal_store(slots[k], dst + k);
+    }
+    __threadfence_system();                                  // this thread's stores have left for the peers ...
+    __syncthreads();
+    __shared__ int last;
+    if (threadIdx.x == 0) last = (atomicAdd(vb.counter, 1u) == gridDim.x - 1) ? 1 : 0;      // ... before the workgroup is counted
+    __syncthreads();
+    if (last) {
+        __threadfence_system();
+        if ((int)threadIdx.x < vb.nranks && (int)threadIdx.x != vb.rank)
+            __hip_atomic_store(vb.flags[threadIdx.x] + half + vb.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) *vb.counter = 0u;              // (the next push is a later launch)
+    }
+}
+__global__ __launch_bounds__(VEC_X_THREADS) void vec_sum_kernel(VecBox vb, uint32_t seq, const double* __restrict__ slots,
+                                                                double* __restrict__ slots_rd, DevState* st) {
+    if (st->xchg_failed) return;
+    const size_t half = (size_t)(seq & 1u) * (size_t)vb.nranks;
+    __shared__ int failed;
+    if (threadIdx.x == 0) failed = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < vb.nranks && (int)threadIdx.x != vb.rank) {
+        const uint32_t* f = vb.flags[vb.rank] + half + threadIdx.x;
+        const long long t0 = wall_clock64();
+        bool ok;
+        do { ok = __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == seq; } while (!ok && (wall_clock64() - t0) < vb.timeout_ticks);
+        if (!ok) failed = 1;
+    }
+    __syncthreads();
+    if (failed) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->xchg_failed = 1; st->done = 1; } return; }
+    const int64_t n2 = vb.n2;
+    const double* own = vb.buf[vb.rank] + half * (size_t)n2;
+    for (int64_t k = blockIdx.x * (int64_t)VEC_X_THREADS + threadIdx.x; k < n2; k += (int64_t)gridDim.x * VEC_X_THREADS) {
+        double sacc = 0.0;
+        for (int r = 0; r < vb.nranks; ++r)                  // rank order: the same bits on every rank
+            sacc += (r == vb.rank) ? slots[k] : __builtin_nontemporal_load(own + (size_t)r * (size_t)n2 + k);
+        slots_rd[k] = sacc;
+    }
+}
+void launch_vec_exchange(const LaunchCtx& c, const VecBox& vb, uint32_t seq, const double* slots, double* slots_rd) {
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (vb.n2 + VEC_X_THREADS - 1) / VEC_X_THREADS));
+    hipLaunchKernelGGL(vec_push_kernel, dim3(grid), dim3(VEC_X_THREADS), 0, c.stream, vb, seq, slots, c.st);
+    hipLaunchKernelGGL(vec_sum_kernel, dim3(grid), dim3(VEC_X_THREADS), 0, c.stream, vb, seq, slots, slots_rd, c.st);
 }
 
 // tau rows of out = M w from the sweep's partials (the CG iteration does this inside cg_update_kernel)

@@ -201,6 +201,12 @@ struct fos_solver {
     fos_allreduce_fn host_fn = nullptr;
     void* host_user = nullptr;
     double* host_buf = nullptr;                // pinned, max(2n, 16) doubles
+    // row-sharded + peer mailboxes: the n-vector A'y crosses the ranks through peer-mapped memory too (fos_internal.hpp, VecBox)
+    double* vec_buf = nullptr;                 // own exchange buffer: [2][nranks][2n] doubles, then [2][nranks] flags (uncached, IPC-exported)
+    std::vector<void*> vec_opened;
+    VecBox vec{};
+    uint32_t vec_seq = 0;                      // exchanges enqueued so far (the same on every rank: all make the same calls)
+    int vec_nranks = 0;
     bool sharded() const { return comm != nullptr || peer_on || host_fn != nullptr; }
     // row sharding of a non-block-diagonal A: the first n entries (and tau, kappa) of every vector are replicated,
     // the slots of the rows of A' are summed over the ranks (RCCL all-reduce of 2n doubles) between a sweep and its slot-list sums
@@ -251,6 +257,10 @@ static int host_allreduce(fos_solver* h, const double* src, double* dst, size_t 
 int fos_solver::sum_slots_over_ranks(void* self) {
     fos_solver* h = static_cast<fos_solver*>(self);
     if (h->host_fn) return host_allreduce(h, h->S.slots, h->slots_rd, (size_t)2 * (size_t)h->n);
+    if (h->peer_on && h->vec.buf) {            // peer-mapped memory: push + sum, in stream, no library call
+        launch_vec_exchange(h->ctx(), h->vec, ++h->vec_seq, h->S.slots, h->slots_rd);
+        return FOS_OK;
+    }
     if (!h->comm) {            // no communicator yet (set-up calls before fos_comm_init, or a single process): the sum is the copy
         return hipMemcpyAsync(h->slots_rd, h->S.slots, sizeof(double) * 2 * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream) == hipSuccess ? FOS_OK : FOS_EHIP;
     }
@@ -1208,6 +1218,7 @@ int fos_destroy(fos_handle h) {
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     if (h->host_buf) (void)hipHostFree(h->host_buf);
     for (void* q : h->peer_opened) (void)hipIpcCloseMemHandle(q);
+    for (void* q : h->vec_opened) (void)hipIpcCloseMemHandle(q);
     for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (void* p : h->owned) (void)hipFree(p);
     if (h->st_host) (void)hipHostFree(h->st_host);
@@ -1269,7 +1280,6 @@ int fos_comm_init_host(fos_handle h, int nranks, int rank, fos_allreduce_fn fn, 
 // ---- peer mailboxes: the sharded scalar sums without a collective library (fos_internal.hpp, PeerBox)
 int fos_peer_export(fos_handle h, void* handle64) {
     if (!h || !handle64) { set_error("NULL argument"); return FOS_EINVAL; }
-    if (h->row_sharded) { set_error("row-sharded handles exchange an n-vector per Q apply: RCCL (fos_comm_init) only, no peer mailboxes"); return FOS_EUNSUPPORTED; }
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
     FOS_HIP(hipSetDevice(h->device));
     if (!h->peer_mbox) {
@@ -1362,10 +1372,73 @@ int fos_peer_selftest(fos_handle h, int rounds, int32_t* ok) {
     return FOS_OK;
 }
 
+// Row-sharded handles: the exchange buffer of the n-vector A'y (fos_internal.hpp, VecBox).  Protocol as for the mailboxes, after
+// fos_peer_open (which fixes nranks): fos_peer_vec_export -> the host all-gathers the 64-byte handles -> fos_peer_vec_open.
+int fos_peer_vec_export(fos_handle h, void* handle64) {
+    if (!h || !handle64) { set_error("NULL argument"); return FOS_EINVAL; }
+    if (!h->row_sharded) { set_error("fos_peer_vec_export: not a row-sharded handle"); return FOS_EINVAL; }
+    if (!h->peer.box) { set_error("fos_peer_vec_export before fos_peer_open"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    if (!h->vec_buf) {
+        const int g = h->peer.nranks;
+        const size_t doubles = (size_t)2 * g * 2 * (size_t)h->n;
+        const size_t bytes = doubles * sizeof(double) + (size_t)2 * g * sizeof(uint32_t) + 64;
+        void* q = nullptr;
+        hipError_t e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained); }
+        if (e != hipSuccess) { set_error("hipExtMallocWithFlags(vector exchange buffer, %zu bytes): %s", bytes, hipGetErrorString(e)); return FOS_ENOMEM; }
+        h->owned.push_back(q);
+        FOS_HIP(hipMemset(q, 0, bytes));                         // exchange number 0 is never sent
+        h->vec_buf = reinterpret_cast<double*>(q);
+        h->vec_nranks = g;
+    }
+    hipIpcMemHandle_t ipc;
+    FOS_HIP(hipIpcGetMemHandle(&ipc, h->vec_buf));
+    memcpy(handle64, &ipc, sizeof(ipc));
+    return FOS_OK;
+}
+int fos_peer_vec_open(fos_handle h, const void* handles) {
+    if (!h || !handles) { set_error("NULL argument"); return FOS_EINVAL; }
+    if (!h->vec_buf || !h->peer.box) { set_error("fos_peer_vec_open before fos_peer_vec_export"); return FOS_EINVAL; }
+    if (!h->vec_opened.empty() || h->vec.buf) { set_error("the vector exchange buffers are already open"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    const int g = h->peer.nranks, me = h->peer.rank;
+    const size_t doubles = (size_t)2 * g * 2 * (size_t)h->n;
+    std::vector<double*> bt((size_t)g, nullptr);
+    std::vector<uint32_t*> ft((size_t)g, nullptr);
+    for (int r = 0; r < g; ++r) {
+        void* q = h->vec_buf;
+        if (r != me) {
+            hipIpcMemHandle_t ipc;
+            memcpy(&ipc, (const char*)handles + (size_t)r * sizeof(ipc), sizeof(ipc));
+            hipError_t e = hipIpcOpenMemHandle(&q, ipc, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                for (void* o : h->vec_opened) (void)hipIpcCloseMemHandle(o);
+                h->vec_opened.clear();
+                set_error("hipIpcOpenMemHandle(vector exchange buffer of rank %d): %s", r, hipGetErrorString(e));
+                return FOS_ECOMM;
+            }
+            h->vec_opened.push_back(q);
+        }
+        bt[r] = reinterpret_cast<double*>(q);
+        ft[r] = reinterpret_cast<uint32_t*>(reinterpret_cast<double*>(q) + doubles);
+    }
+    double** dbt = nullptr; uint32_t** dft = nullptr; uint32_t* cnt = nullptr;
+    FOS_TRY(dev_upload(h, &dbt, bt));
+    FOS_TRY(dev_upload(h, &dft, ft));
+    FOS_TRY(dev_alloc(h, &cnt, 1));
+    FOS_HIP(hipMemset(cnt, 0, sizeof(uint32_t)));
+    h->vec.buf = dbt; h->vec.flags = dft; h->vec.counter = cnt; h->vec.nranks = g; h->vec.rank = me;
+    h->vec.n2 = 2 * h->n; h->vec.timeout_ticks = h->peer.timeout_ticks;
+    return FOS_OK;
+}
+
 // switch the sharded sums to the peer mailboxes (collective: all ranks make the same choice after the self test)
 int fos_peer_enable(fos_handle h, int32_t on) {
     if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
     if (on && !h->peer.box) { set_error("fos_peer_enable before fos_peer_open"); return FOS_EINVAL; }
+    if (on && h->row_sharded && !h->vec.buf) { set_error("row-sharded handle: fos_peer_vec_export / fos_peer_vec_open before fos_peer_enable"); return FOS_EINVAL; }
     if (on && h->ls_interval > 0) { set_error("switch the LineSearchWrapper off before sharding the handle (fos_set_linesearch(h, 0))"); return FOS_EUNSUPPORTED; }
     FOS_HIP(hipSetDevice(h->device));
     FOS_HIP(hipStreamSynchronize(h->stream));

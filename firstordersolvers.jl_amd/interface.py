@@ -449,6 +449,17 @@ class HipHSDE:
         buf = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
         _lib.check(self._lib.fos_peer_open(self._h, nranks, rank, buf, float(timeout_s)))
 
+    def peer_vec_export(self) -> bytes:
+        """row-sharded handles: the exchange buffer of the n-vector A'y (after peer_open)"""
+        buf = (C.c_ubyte * 64)()
+        _lib.check(self._lib.fos_peer_vec_export(self._h, buf))
+        return bytes(buf)
+
+    def peer_vec_open(self, handles):
+        blob = b"".join(handles)
+        buf = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
+        _lib.check(self._lib.fos_peer_vec_open(self._h, buf))
+
     def peer_selftest(self, rounds=32) -> bool:
         ok = C.c_int32(0)
         _lib.check(self._lib.fos_peer_selftest(self._h, rounds, C.byref(ok)))

@@ -107,7 +107,7 @@ int fos_create(int64_t m, int64_t n,
  * holds the ROWS of A that belong to its K1 cones (m = local rows, b local, K1 local) and ALL n columns (c, K2 whole).  x, r,
  * tau, kappa are replicated on every rank, y and s are local.  Per Q apply the n-vector A'y = sum over ranks of A_g'y_g is
  * all-reduced in stream (RCCL; HSDEAffine.jl:51), every scalar sum counts the replicated entries once (rank 0).  Follow with
- * fos_comm_init on every rank; without a communicator the handle behaves as the only rank.  No peer mailboxes, no dual tiles. */
+ * fos_comm_init on every rank (or the peer mailboxes + fos_peer_vec_*); without a communicator the handle behaves as the only rank.  No dual tiles. */
 #define FOS_CREATE_ROW_SHARDED 1
 int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
                 const double* b, const double* c,
@@ -149,6 +149,12 @@ int fos_comm_init_host(fos_handle h, int nranks, int rank, fos_allreduce_fn fn, 
 int fos_peer_export(fos_handle h, void* handle64);
 int fos_peer_open(fos_handle h, int nranks, int rank, const void* handles, double timeout_s);
 int fos_peer_selftest(fos_handle h, int rounds, int32_t* ok);
+/* Row-sharded handles (FOS_CREATE_ROW_SHARDED) over the mailboxes: the n-vector A'y = sum over ranks of A_g'y_g (HSDEAffine.jl:51)
+ * also crosses the ranks through peer-mapped memory -- every rank pushes its 2n partial sums into every peer's exchange buffer and
+ * adds what it received in rank order, in stream, no collective library.  After fos_peer_open: fos_peer_vec_export(h, handle64),
+ * the host all-gathers the handles, fos_peer_vec_open(h, handles: nranks x 64 bytes in rank order), then fos_peer_enable. */
+int fos_peer_vec_export(fos_handle h, void* handle64);
+int fos_peer_vec_open(fos_handle h, const void* handles);
 int fos_peer_enable(fos_handle h, int32_t on);
 
 /* ---- algorithm state: replaces init_algorithm!(alg, model) data structs ---------------------------
