@@ -332,8 +332,10 @@ def test_row_sharded_single_rank_matches_unsharded(pkg, oracle):
     d1.close()
 
 
-def _worker_rows(rank, world, port, algname, iters, q):
-    """One rank of a row-sharded solve; both processes share cuda:0, the cross-rank sums go through gloo (fos_comm_init_host)."""
+def _worker_rows(rank, world, port, algname, iters, q, transport="host"):
+    """One rank of a row-sharded solve; both processes share cuda:0.  transport = "host": the cross-rank sums go through gloo
+    (fos_comm_init_host); "peer": through peer-mapped memory, in stream -- the scalars through the mailboxes, the n-vector A'y
+    through the exchange buffers of fos_peer_vec_* (gloo only carries the IPC handles)."""
     import os
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -353,7 +355,19 @@ def _worker_rows(rank, world, port, algname, iters, q):
         def allreduce_sum(a):
             calls[0] += 1
             dist.all_reduce(torch.from_numpy(a))
-        dev.comm_init_host(world, rank, allreduce_sum)
+        if transport == "host":
+            dev.comm_init_host(world, rank, allreduce_sum)
+        else:
+            handles = [None] * world
+            dist.all_gather_object(handles, dev.peer_export())
+            dev.peer_open(world, rank, handles, timeout_s=30.0)
+            vh = [None] * world
+            dist.all_gather_object(vh, dev.peer_vec_export())
+            dev.peer_vec_open(vh)
+            dist.barrier()
+            assert dev.peer_selftest(16)
+            dev.peer_enable(True)
+            calls[0] = 1
         rng = np.random.default_rng(5)
         zg = rng.standard_normal(2 * (prob.n + prob.m + 1))          # a global vector, restricted to this rank's rows
         zl = pkg.sharding.rows_global_to_local(zg, sh)
@@ -379,14 +393,16 @@ def _worker_rows(rank, world, port, algname, iters, q):
         q.put((rank, "error: " + repr(exc) + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("algname", ["DR", "GAPA"])
-def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname):
+@pytest.mark.parametrize("algname,transport", [("DR", "host"), ("GAPA", "host"), ("DR", "peer"), ("GAPA", "peer")])
+def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname, transport):
     """SURVEY 8(f2) with TWO ranks on the one GPU of the test box: each process holds the rows of half of the K1 cones of a
     problem whose A couples everything (workloads.small_mixed), the n-vector A'y and every scalar sum cross the processes
     through the caller's collective (fos_comm_init_host, here gloo).  Replicated parts bitwise identical on both ranks; the
     KKT operator and the status sums on a common vector equal the unsharded handle's to rounding; the first outer iteration
     (one CG solve) reproduces the unsharded handle with the same CG count; ten iterations follow it to 1e-3 (as the oracle's
-    own sharded-vs-unsharded comparison, tests/test_sharding_gloo.py)."""
+    own sharded-vs-unsharded comparison, tests/test_sharding_gloo.py).  transport = "peer": the same with every cross-rank sum IN
+    STREAM -- scalars through the peer mailboxes (folded into the CG kernels), the n-vector through the peer-mapped exchange
+    buffers (vec_push_kernel / vec_sum_kernel) -- no collective library, no host round trip."""
     import multiprocessing as mp
     import socket
     iters, world = 10, 2
@@ -396,7 +412,7 @@ def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_rows, args=(r, world, port, algname, iters, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_rows, args=(r, world, port, algname, iters, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
