@@ -87,6 +87,35 @@ def test_merged_cg_matches_dense_solve_and_oracle(pkg, variant):
         d.close()
 
 
+@pytest.mark.parametrize("variant", ["reference"] + VARIANTS)
+def test_cg_variants_on_window_panel_storage(pkg, variant, monkeypatch):
+    """The same solves with the operator forced into window-panel storage (FOS_WINDOWS=1; the format of C5-class operators, whose
+    sweep kernel carries its own closing prologue and tau stash): every recurrence against the dense solution and its host twin."""
+    monkeypatch.setenv("FOS_WINDOWS", "1")
+    rng = np.random.default_rng(15)
+    A = sp.random(700, 900, density=0.02, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    m, n = A.shape
+    b, c = rng.standard_normal(m), rng.standard_normal(n)
+    d = pkg.HipHSDE(A, b, c, [("Free", m)], [("Free", n)])
+    assert d.operator_stats()["win_panels"] > 0
+    d.set_cg_variant(variant)
+    Q = orc.HSDEMatrixQ(A, b, c)
+    M = orc.KKTMatrix(Q)
+    rhs, x0 = rng.standard_normal(d.N), rng.standard_normal(d.N)
+    ofn = orc.conjugategradient if variant == "reference" else orc.conjugategradient_merged
+    for k in (1, 3):
+        xk, it = d.cg_kkt(x0, rhs, 1e-300, k)
+        xo, ito = _ocg(ofn, M, x0, rhs, 1e-300, k)
+        assert it == ito == k and relerr(xk, xo) < 1e-12, (variant, k)
+    x, it = d.cg_kkt(x0, rhs, 1e-6, 10000)
+    y = np.empty(d.N)
+    M.mul(y, x)
+    assert np.linalg.norm(y - rhs) <= 1e-6 * (1 + 1e-3)
+    _, it_o = _ocg(ofn, M, x0, rhs, 1e-6, 10000)
+    assert abs(it - it_o) <= 6 + it_o // 20
+    d.close()
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_prox_affine_sequence_merged(pkg, variant):
     """prox!(y, S1::AffinePlusLinear, x) with the merged recurrence: call counter, tolerance schedule, warm start
