@@ -95,6 +95,10 @@ def build_problem(pkg, workload, nranks, rank, small, weak=False, c4_scale=None)
     return prob, alg, desc, glob
 
 
+class PeerTransportFailed(RuntimeError):
+    """raised by every rank together (after a collective vote) when the warm-up over the peer mailboxes ended in an error"""
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,7 +241,21 @@ def main():
         warm = max(args.warmup, i_floor)
         it = 0
         if warm > 0:
-            done, _, _ = dev.step(1, warm, BIG, 1e-8)
+            try:
+                if os.environ.get("FOS_BENCH_INJECT") == "peer_warmup_fail" and reduction.startswith("peer"):   # tests only
+                    raise pkg.lib.FosError(-5, "injected: peer exchange timed out")
+                done, _, _ = dev.step(1, warm, BIG, 1e-8)
+                dev.sync()
+                ok = True
+            except pkg.lib.FosError as exc:                   # e.g. FOS_ECOMM: a mailbox word that never arrived
+                if dist is None or not reduction.startswith("peer"):
+                    raise
+                print("rank %d: warm-up failed on the peer mailboxes (%s)" % (rank, exc), file=sys.stderr, flush=True)
+                done, ok = 0, False
+            if dist is not None and reduction.startswith("peer") and not agree(ok):
+                # a rank that waits for a silent peer runs into the mailbox time-out too, so every rank arrives here
+                dev.close()
+                raise PeerTransportFailed()
             it += done
         # ---- timed: exactly K outer iterations
         PROF_PERIOD = 4        # HIP events around every 4th launch group of each class (an event pair per launch costs ~5 % of a C4 step)
@@ -405,7 +423,14 @@ def main():
         return out, dev, prob, alg, it
 
     weak_main = args.scaling == "weak"
-    out, dev, prob, alg, it = run_case(weak_main)
+    try:
+        out, dev, prob, alg, it = run_case(weak_main)
+    except PeerTransportFailed:
+        # the self test passed but the first real exchanges did not: the same job over the in-stream RCCL all-reduce
+        if host_gloo or os.environ.get("FOS_REDUCTION") == "peer":
+            raise SystemExit("peer mailboxes failed during the warm-up and no other transport is allowed")
+        os.environ["FOS_REDUCTION"] = "rccl"
+        out, dev, prob, alg, it = run_case(weak_main)
     if world > 1 and not weak_main and not args.no_weak_extra and args.workload == "C4":
         # the same job once more with 512 blocks PER RANK: weak scaling, reported beside the strong-scaling headline
         dev.close()

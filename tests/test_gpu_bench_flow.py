@@ -73,3 +73,20 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     # a failing child must fail the call: an unknown workload makes every rank exit non-zero
     bad = subprocess.run(cmd + ["--workload", "nope"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0
+
+
+def test_bench_falls_back_to_rccl_when_the_mailboxes_fail_in_the_warmup():
+    """The mailbox self test can pass and the first real exchanges still fail (a transport that has never run between two
+    devices): every rank votes after the warm-up, and the job runs again over the in-stream RCCL all-reduce.  One rank in a
+    RCCL group of its own (`FOS_FORCE_DIST=1`), the failure injected."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "FOS_BENCH_BACKEND")}
+    env.update(FOS_FORCE_DIST="1", FOS_BENCH_INJECT="peer_warmup_fail", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "2", "--small", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert "RCCL" in out["config"]["parallelism"] and out["value"] > 0
+    assert "warm-up failed on the peer mailboxes" in r.stderr
+    # with only the mailboxes allowed the same failure must end the run
+    bad = subprocess.run(cmd, cwd=str(ROOT), env=dict(env, FOS_REDUCTION="peer"), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0
