@@ -216,13 +216,24 @@ __device__ __forceinline__ void cg_signal_stop(DevState* st, int jd, int maxit, 
     }
 }
 
-__device__ __forceinline__ CgClose cg_close_iteration(DevState* st, const double* __restrict__ rr_partials, int count,
+// (two pieces: everything cg_close_iteration reads -- all of it stored by EARLIER launches -- can be requested together with a
+// kernel's gate and first elements, one memory round trip for the whole prologue)
+struct CgCloseIn { d2 rt; double rnold, tol, s; int maxit; };
+__device__ __forceinline__ CgCloseIn cg_close_request(DevState* st, const double* __restrict__ rr_partials, int count,
                                                       const double* __restrict__ reduced, int from_reduced,
-                                                      const d2* __restrict__ r, int64_t l, int jd, const PeerBox& pb, uint32_t seq_base) {
-    const d2 rt = r[l - 1];
-    const double rnold = st->rn2[(jd - 1) & 1], tol = st->tol;
-    const int maxit = st->maxit;
-    double s = from_reduced ? reduced[0] : wave_sum_records(rr_partials, count);
+                                                      const d2* __restrict__ r, int64_t l, int jd) {
+    CgCloseIn in;
+    in.rt = r[l - 1];
+    in.rnold = st->rn2[(jd - 1) & 1]; in.tol = st->tol;
+    in.maxit = st->maxit;
+    in.s = from_reduced ? reduced[0] : wave_sum_records(rr_partials, count);
+    return in;
+}
+__device__ __forceinline__ CgClose cg_close_finish(DevState* st, const CgCloseIn& in, int jd, const PeerBox& pb, uint32_t seq_base) {
+    const d2 rt = in.rt;
+    const double rnold = in.rnold, tol = in.tol;
+    const int maxit = in.maxit;
+    double s = in.s;
     CgClose c{0.0, true, true};
     if (pb.nranks > 0) {
         __shared__ double sums[1];
@@ -247,6 +258,13 @@ __device__ __forceinline__ CgClose cg_close_iteration(DevState* st, const double
         }
     }
     return c;
+}
+
+__device__ __forceinline__ CgClose cg_close_iteration(DevState* st, const double* __restrict__ rr_partials, int count,
+                                                      const double* __restrict__ reduced, int from_reduced,
+                                                      const d2* __restrict__ r, int64_t l, int jd, const PeerBox& pb, uint32_t seq_base) {
+    const CgCloseIn in = cg_close_request(st, rr_partials, count, reduced, from_reduced, r, l, jd);
+    return cg_close_finish(st, in, jd, pb, seq_base);
 }
 
 // Merged-reduction CG, single GPU (CgmIter::close_in_update == false): the SWEEP behind the update of iteration jd closes it --

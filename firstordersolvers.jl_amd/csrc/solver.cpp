@@ -1187,8 +1187,8 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     // ---- scalars
     FOS_TRY(dev_alloc(h, &h->st, 1));
     FOS_HIP(hipMemset(h->st, 0, sizeof(DevState)));
-    FOS_TRY(dev_alloc(h, &h->pre_sums, 3 * 16 + 16));
-    FOS_HIP(hipMemset(h->pre_sums, 0, sizeof(double) * (3 * 16 + 16)));
+    FOS_TRY(dev_alloc(h, &h->pre_sums, 128));           // 16 producers x 3 sums x 2 self-validating words (sweep_sums3)
+    FOS_HIP(hipMemset(h->pre_sums, 0, sizeof(double) * 128));
     h->pre_on = !(getenv("FOS_CG_PRE") && atoi(getenv("FOS_CG_PRE")) == 0);
     {
         void* dp = nullptr;

@@ -66,42 +66,80 @@ __global__ __launch_bounds__(FIN_THREADS) void cg_init_finalize_kernel(const dou
 }
 
 // The sweep's three sums (Ap.p without the tau rows, [c;b].p1, [c;b].p2) -> sums[0..2] (shared), the same bits in every workgroup.
+// Two pieces, so that a kernel can request the records together with everything else it needs and add them later:
+// SweepRecs::request (loads only) and SweepRecs::finish.
+struct SweepRecs {
+    PartialRegs<3> regs;
+    const double* src;
+    int cnt;
+    bool producer, plain;
+    __device__ __forceinline__ void request(const double* __restrict__ kkt_partials, int nkkt, int from_reduced, const double* pre) {
+        plain = !from_reduced && pre == nullptr;
+        producer = !from_reduced && pre != nullptr && blockIdx.x < PRE_NPROD;
+        src = kkt_partials; cnt = nkkt;
+        if (producer) {
+            const int per = (nkkt + PRE_NPROD - 1) / PRE_NPROD;
+            const int lo = min((int)blockIdx.x * per, nkkt);
+            src = kkt_partials + 3 * (size_t)lo; cnt = min(per, nkkt - lo);
+        }
+        if (plain || producer) regs.load(src, cnt);
+    }
+    __device__ __forceinline__ void finish(double* sums, const double* __restrict__ reduced, int from_reduced, double* __restrict__ pre,
+                                           uint32_t pre_seq, DevState* st) {
+        if (from_reduced) { if (threadIdx.x < 3) sums[threadIdx.x] = reduced[threadIdx.x]; __syncthreads(); }
+        else if (pre != nullptr) {
+            // Thousands of sweep records (C4: 4 224): every workgroup adding them all again cost ~6 us of this kernel.  Instead the
+            // first PRE_NPROD workgroups -- always dispatched first, so a waiting workgroup can never keep them from running --
+            // add a slice each and publish their three sums; everybody waits for those (cache-bypassing loads: no atomics, nothing
+            // serialises) and adds the PRE_NPROD partial results in order.  Fixed order, same bits in every workgroup.
+            // The partial results travel as self-validating words, (launch number << 32) | half a double -- the idea of the peer
+            // mailboxes: no separate flag, no wait for the data's acknowledgement in front of it, and the consumers' polls ARE
+            // the data loads.  Chain: producer's records (one round trip) -> its stores -> a consumer's poll; it was five hops.
+            unsigned long long* words = reinterpret_cast<unsigned long long*>(pre);
+            __shared__ uint32_t pre_halves[6 * PRE_NPROD];
+            if (producer) {
+                double acc[3];
+                regs.sum(src, cnt, acc);
+                partials_combine<3>(acc, sums);
+                if (threadIdx.x < 6) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(sums[threadIdx.x >> 1]);
+                    const uint32_t half = (threadIdx.x & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+                    __hip_atomic_store(words + 6 * blockIdx.x + threadIdx.x, ((unsigned long long)pre_seq << 32) | half, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (threadIdx.x < 6 * PRE_NPROD) {
+                const long long t0 = wall_clock64();
+                unsigned long long w;
+                while ((uint32_t)((w = __hip_atomic_load(words + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != pre_seq) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (wall_clock64() - t0 > 500000000LL) { st->bar_failed = 1; st->done = 1; break; }      // 5 s of the 100 MHz clock: give up, flag the state
+                }
+                pre_halves[threadIdx.x] = (uint32_t)w;
+            }
+            __syncthreads();
+            if (threadIdx.x < 3) {
+                double sum = 0.0;
+                for (int b = 0; b < PRE_NPROD; ++b) {
+                    const unsigned long long lo = pre_halves[6 * b + 2 * threadIdx.x], hi = pre_halves[6 * b + 2 * threadIdx.x + 1];
+                    sum += __longlong_as_double((long long)((hi << 32) | lo));
+                }
+                sums[threadIdx.x] = sum;
+            }
+            __syncthreads();
+        }
+        else {
+            double acc[3];
+            regs.sum(src, cnt, acc);
+            partials_combine<3>(acc, sums);
+        }
+    }
+};
 __device__ __forceinline__ void sweep_sums3(double* sums, const double* __restrict__ kkt_partials, int nkkt, const double* __restrict__ reduced,
                                             int from_reduced, double* __restrict__ pre, uint32_t pre_seq, DevState* st) {
-    if (from_reduced) { if (threadIdx.x < 3) sums[threadIdx.x] = reduced[threadIdx.x]; __syncthreads(); }
-    else if (pre != nullptr) {
-        // Thousands of sweep records (C4: 4 224): every workgroup adding them all again cost ~6 us of this kernel.  Instead the
-        // first PRE_NPROD workgroups -- always dispatched first, so a waiting workgroup can never keep them from running --
-        // add a slice each, publish the three sums (written through to memory) and raise a flag carrying this launch's
-        // number; everybody waits for the flags (cache-bypassing loads: no atomics, nothing serialises) and adds the
-        // PRE_NPROD partial results in order.  Fixed order, same bits in every workgroup.
-        uint32_t* flags = reinterpret_cast<uint32_t*>(pre + 3 * PRE_NPROD);
-        if (blockIdx.x < PRE_NPROD) {
-            const int per = (nkkt + PRE_NPROD - 1) / PRE_NPROD;
-            const int lo = min((int)blockIdx.x * per, nkkt), cnt = min(per, nkkt - lo);
-            reduce_partials<3>(kkt_partials + 3 * (size_t)lo, cnt, sums);
-            if (threadIdx.x < 3) st_coh(pre + 3 * blockIdx.x + threadIdx.x, sums[threadIdx.x]);
-            __builtin_amdgcn_s_waitcnt(0);                       // the three write-through stores have been acknowledged by memory ...
-            __syncthreads();                                     // ... before thread 0 raises the flag (an agent-scope release would
-                                                                 // write back the whole L2: 20-70 us, DESIGN.md "measured dead ends")
-            if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, pre_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (threadIdx.x < PRE_NPROD) {
-            const long long t0 = wall_clock64();
-            while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pre_seq) {
-                __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > 500000000LL) { st->bar_failed = 1; st->done = 1; break; }      // 5 s of the 100 MHz clock: give up, flag the state
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 3) {
-            double sum = 0.0;
-            for (int b = 0; b < PRE_NPROD; ++b) sum += ld_coh(pre + 3 * b + threadIdx.x);
-            sums[threadIdx.x] = sum;
-        }
-        __syncthreads();
-    }
-    else reduce_partials<3>(kkt_partials, nkkt, sums);
+    SweepRecs rec;
+    rec.request(kkt_partials, nkkt, from_reduced, pre);
+    rec.finish(sums, reduced, from_reduced, pre, pre_seq, st);
 }
 
 // Second launch of a CG iteration.  EVERY workgroup reduces the sweep's 3 x nkkt partial sums in the same fixed order, finishes
@@ -131,23 +169,45 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
     // barriers): on small operators the prologue's latency, not bandwidth, is what this kernel costs
     const int64_t stride = (int64_t)nsblk * VEC_THREADS;
     const int64_t i0 = sblk * (int64_t)VEC_THREADS + threadIdx.x;
-    bool have0 = !def_role && i0 < l;
-    if constexpr (DEF) { if (have0 && ((def_mask[i0 >> 5] >> (i0 & 31)) & 1u)) have0 = false; }
-    d2 p0 = make_double2(0.0, 0.0), a0 = p0, x0 = p0, r0 = p0;
-    if (have0) { a0 = Ap[i0]; r0 = r[i0]; if constexpr (XUPD) { p0 = p[i0]; x0 = x[i0]; } }
-    if (st->done) return;
-    if (FOLD && st->xchg_failed) return;
+    // Everything the scalar prologue needs is requested FIRST and together -- the gate, the tau element of p, r.r of the previous
+    // iteration (all stored by EARLIER launches) and the sweep's records: one round trip where there were three -- and behind it
+    // the first elements of the thread's slice with their mask words (a slot-spread row's elements are read for nothing, but no
+    // element waits for a mask word: with the mask tested first every trip of the stream was two dependent round trips).
+    SweepRecs rec;
+    rec.request(kkt_partials, nkkt, from_reduced, pre);
+    const int done = st->done, xfail = FOLD ? st->xchg_failed : 0;
+    const d2 pt = p[l - 1];
+    const double rn_prev = st->rn2[(j - 1) & 1];
+    constexpr int NPF = 4;                               // elements requested in front of the prologue (at most)
+    const int npf = ((S.dbg_flags >> 8) & 7) ? ((S.dbg_flags >> 8) & 7) : NPF;
+    bool eh[NPF];
+    uint32_t em[NPF];
+    d2 ea[NPF], er[NPF], ep[NPF], ex[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+        const int64_t ik = i0 + k * stride;
+        eh[k] = !def_role && k < npf && ik < l;
+        ea[k] = er[k] = ep[k] = ex[k] = make_double2(0.0, 0.0);
+        em[k] = 0u;
+        if (eh[k]) {
+            if constexpr (DEF) em[k] = def_mask[ik >> 5];
+            ea[k] = Ap[ik]; er[k] = r[ik];
+            if constexpr (XUPD) { ep[k] = p[ik]; ex[k] = x[ik]; }
+        }
+    }
+    if (done) return;
+    if (xfail) return;
     __shared__ double sums[3];
-    sweep_sums3(sums, kkt_partials, nkkt, reduced, from_reduced, pre, pre_seq, st);
+    rec.finish(sums, reduced, from_reduced, pre, pre_seq, st);
     if constexpr (FOLD) {
         if (!peer_fold_sum<3>(pb, seq_base + 2u * (uint32_t)j, sums, st)) return;
     }
-    const d2 pt = p[l - 1];
     const double S1 = sums[0], T1 = sums[1], T2 = sums[2];
+    if ((S.dbg_flags & 16) && blockIdx.x != 0) return;                                                                   // (timing experiment)
     const double at1 = pt.x + T2;            // p1_tau - (Q p2)_tau ,  (Q v)_tau = -[c;b].v        HSDEAffine.jl:57
     const double at2 = -T1 - pt.y;           // (Q p1)_tau - p2_tau
     const double pAp = S1 + (at1 * pt.x + at2 * pt.y);
-    const double alpha = st->rn2[(j - 1) & 1] / pAp;
+    const double alpha = rn_prev / pAp;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         Ap[l - 1] = make_double2(at1, at2);
         st->pAp = pAp;
@@ -162,6 +222,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
         const int lig = threadIdx.x & (lpr - 1);
         const int npass = (S.ndef + rows_per_pass - 1) / rows_per_pass;       // uniform trip count: the DPP sums need full waves
         int q = (blockIdx.x * VEC_THREADS + threadIdx.x) >> sh;
+        if (S.dbg_flags & 4) { block_reduce_store<1>(acc, partials + blockIdx.x); return; }      // (timing experiment: rows left unfinished)
         for (int pass = 0; pass < npass; ++pass, q += rows_per_pass) {
             const bool ok = q < S.ndef;
             DefRow dr{};
@@ -189,28 +250,47 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
       }
     }
     if (def_role) { block_reduce_store<1>(acc, partials + blockIdx.x); return; }
-    if (have0) {
-        if (i0 == l - 1) a0 = make_double2(at1, at2);
-        if constexpr (XUPD) { x0.x += alpha * p0.x; x0.y += alpha * p0.y; x[i0] = x0; }
-        r0.x -= alpha * a0.x; r0.y -= alpha * a0.y;
-        r[i0] = r0;
-        if (i0 != l - 1) acc[0] += r0.x * r0.x + r0.y * r0.y;
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+        const int64_t ik = i0 + k * stride;
+        if (!eh[k] || ((em[k] >> (ik & 31)) & 1u)) continue;
+        if (ik == l - 1) ea[k] = make_double2(at1, at2);
+        if constexpr (XUPD) { ex[k].x += alpha * ep[k].x; ex[k].y += alpha * ep[k].y; x[ik] = ex[k]; }
+        er[k].x -= alpha * ea[k].x; er[k].y -= alpha * ea[k].y;
+        r[ik] = er[k];
+        if (ik != l - 1) acc[0] += er[k].x * er[k].x + er[k].y * er[k].y;
     }
-    for (int64_t i = i0 + stride; i < l; i += stride) {
-        if constexpr (DEF) { if ((def_mask[i >> 5] >> (i & 31)) & 1u) continue; }
-        const d2 ai = (i == l - 1) ? make_double2(at1, at2) : Ap[i];
-        d2 ri = r[i];
-        if constexpr (XUPD) {
-            const d2 pi = p[i];
-            d2 xi = x[i];
-            xi.x += alpha * pi.x; xi.y += alpha * pi.y;
-            x[i] = xi;
+    for (int64_t i = i0 + npf * stride; i < l; i += 2 * stride) {           // two elements per trip, every request of a trip in flight at once
+        const int64_t ie[2] = {i, i + stride};
+        bool on[2] = {true, ie[1] < l};
+        uint32_t mw[2] = {0u, 0u};
+        d2 ai[2], ri[2], pi[2], xi[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            ai[q] = ri[q] = pi[q] = xi[q] = make_double2(0.0, 0.0);
+            if (on[q]) {
+                if constexpr (DEF) mw[q] = def_mask[ie[q] >> 5];
+                ai[q] = Ap[ie[q]];
+                ri[q] = r[ie[q]];
+                if constexpr (XUPD) { pi[q] = p[ie[q]]; xi[q] = x[ie[q]]; }
+            }
         }
-        ri.x -= alpha * ai.x; ri.y -= alpha * ai.y;
-        r[i] = ri;
-        if (i != l - 1) acc[0] += ri.x * ri.x + ri.y * ri.y;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if ((mw[q] >> (ie[q] & 31)) & 1u) on[q] = false;
+            if (!on[q]) continue;
+            if (ie[q] == l - 1) ai[q] = make_double2(at1, at2);
+            if constexpr (XUPD) { xi[q].x += alpha * pi[q].x; xi[q].y += alpha * pi[q].y; x[ie[q]] = xi[q]; }
+            ri[q].x -= alpha * ai[q].x; ri[q].y -= alpha * ai[q].y;
+            r[ie[q]] = ri[q];
+            if (ie[q] != l - 1) acc[0] += ri[q].x * ri[q].x + ri[q].y * ri[q].y;
+        }
     }
     block_reduce_store<1>(acc, partials + blockIdx.x);
+}
+static int pre_min_records() {
+    static const int v = getenv("FOS_PRE_MIN") ? atoi(getenv("FOS_PRE_MIN")) : 2048;
+    return v;
 }
 void launch_cg_update(const LaunchCtx& c, const CgIter& it, double2* x, double2* r, double2* Ap, int kkt_from_reduced) {
     // r.r partials go behind the KKT partials (both live in c.partials); inside a CG iteration the sweep leaves c.S.nwg records at 0
@@ -218,12 +298,13 @@ void launch_cg_update(const LaunchCtx& c, const CgIter& it, double2* x, double2*
     const PeerBox pb = it.fold ? *it.fold : PeerBox{};
     dim3 grid(c.cg_blocks), block(VEC_THREADS);
     // many sweep records and enough workgroups: the first PRE_NPROD of them add the records for all (cg_update_kernel)
-    double* pre = (c.pre && !it.fold && !kkt_from_reduced && c.S.nwg >= 2048 && c.cg_blocks >= 4 * PRE_NPROD) ? c.pre : nullptr;
+    double* pre = (c.pre && !it.fold && !kkt_from_reduced && c.S.nwg >= pre_min_records() && c.cg_blocks >= 4 * PRE_NPROD) ? c.pre : nullptr;
     // roles (cg_update_kernel): a quarter of the grid at most for the slot-spread rows, with as many lanes per row as that allows
     int ndb = 0, dlpr = 1;
     static const bool split_env = !(getenv("FOS_UPD_SPLIT") && atoi(getenv("FOS_UPD_SPLIT")) == 0);
     if (split_env && c.S.ndef > 0 && c.l >= 8 * (int64_t)c.S.ndef && c.cg_blocks >= 64) {
-        const int64_t target = c.cg_blocks / 4;
+        static const int div_env = getenv("FOS_UPD_DIV") ? atoi(getenv("FOS_UPD_DIV")) : 4;
+        const int64_t target = c.cg_blocks / (div_env > 0 ? div_env : 4);
         while (dlpr < c.S.def_lpr && ((int64_t)c.S.ndef * (2 * dlpr) + VEC_THREADS - 1) / VEC_THREADS <= target) dlpr *= 2;
         ndb = (int)(((int64_t)c.S.ndef * dlpr + VEC_THREADS - 1) / VEC_THREADS);
         if (ndb < 1 || ndb > c.cg_blocks / 2) ndb = 0;
@@ -252,21 +333,24 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_pupdate_kernel(int64_t l, d2* 
     const int64_t i0 = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x;
     d2 p0 = make_double2(0.0, 0.0), r0 = p0, x0 = p0;
     if (i0 < l) { p0 = pcur[i0]; r0 = r[i0]; x0 = x[i0]; }     // requested before the scalar prologue (latency)
+    // ... and with them everything the prologue reads (stored by earlier launches, none of it written by this one): the gate below
+    // then costs no round trip of its own
+    const double alpha = st->alpha;
+    const int xfail = pb.nranks > 0 ? st->xchg_failed : 0;
+    const CgCloseIn cin = cg_close_request(st, partials, count, reduced, from_reduced, r, l, j);
+    unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&st->iter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (st->dbg_delay > 0 && blockIdx.x != 0) {                // test hook: let workgroup 0 finish first (tests/test_gpu_parity.py)
         const long long t0 = wall_clock64();
         while (wall_clock64() - t0 < st->dbg_delay) __builtin_amdgcn_s_sleep(8);
+        w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&st->iter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // The entry gate must not be the live `done` alone: workgroup 0 of THIS launch sets it (cg_close_iteration) when CG stops at
     // iteration j, and a workgroup that starts after that store would skip the x update of iteration j.  A stop recorded by an
     // earlier launch has iter < j; one recorded by this launch has iter == j (stored before `done`, one 8-byte word with it, so
     // a single load sees a consistent pair) -- then this workgroup goes on, takes the same stop decision and applies x += alpha p.
-    {
-        const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&st->iter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(w >> 32) != 0u && (int32_t)(uint32_t)w != j) return;
-    }
-    if (pb.nranks > 0 && st->xchg_failed) return;
-    const double alpha = st->alpha;
-    const CgClose cl = cg_close_iteration(st, partials, count, reduced, from_reduced, r, l, j, pb, seq_base);
+    if ((uint32_t)(w >> 32) != 0u && (int32_t)(uint32_t)w != j) return;
+    if (xfail) return;
+    const CgClose cl = cg_close_finish(st, cin, j, pb, seq_base);
     if (!cl.ok) return;
     const double beta = cl.beta;
     const bool go_on = !cl.stop;
@@ -332,13 +416,15 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
     const bool first = i == 0;
     DevState* st = a.st;
     bool have0 = i0 < l && !a.close_only;
-    if constexpr (DEF) { if (have0 && ((a.def_mask[i0 >> 5] >> (i0 & 31)) & 1u)) have0 = false; }
+    uint32_t mw0 = 0u;                                   // (mask word and elements requested together: cg_update_kernel)
+    if constexpr (DEF) { if (have0) mw0 = a.def_mask[i0 >> 5]; }
     // ---- everything this launch needs from memory is requested in STAGES, each stage's loads issued together, before the first
     // use: the kernel is a chain of memory latencies on small operators (a shard of a multi-GPU run steps through 17 x 2 of them)
     // stage 1: the thread's first element; the scalars (stored by EARLIER launches: nothing below races them) and the r.r records;
     //          the sweep's records; the slot-spread row this lane works on in the first pass (its list bounds and row number)
     d2 w0 = make_double2(0.0, 0.0), r0 = w0, x0 = w0, p0 = w0, s0 = w0;
     if (have0) { w0 = a.w[i0]; r0 = a.r[i0]; x0 = a.x[i0]; if (!first) { p0 = a.p[i0]; s0 = a.s[i0]; } }
+    if ((mw0 >> (i0 & 31)) & 1u) have0 = false;
     const bool closing = a.close_here != 0;      // (i = 0: g_0 from the start kernel's records, no stop test -- at least one iteration runs)
     const int done = st->done, xfail = st->xchg_failed, maxit = st->maxit;
     const double vtx = st->vtau[0], vty = st->vtau[1];           // tau element of r_i (stashed by the sweep that applied M to it)
@@ -470,11 +556,14 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
         if (i0 != l - 1) acc[0] += rr;
     }
     for (int64_t k = i0 + stride; k < l; k += stride) {
-        if constexpr (DEF) { if ((a.def_mask[k >> 5] >> (k & 31)) & 1u) continue; }
-        const d2 wi = (k == l - 1) ? make_double2(wt1, wt2) : a.w[k];
+        uint32_t mw = 0u;
+        if constexpr (DEF) mw = a.def_mask[k >> 5];
+        d2 wi = a.w[k];
         const d2 ri = a.r[k], xi = a.x[k];
         d2 pi = make_double2(0.0, 0.0), si = pi;
         if (!first) { pi = a.p[k]; si = a.s[k]; }
+        if ((mw >> (k & 31)) & 1u) continue;
+        if (k == l - 1) wi = make_double2(wt1, wt2);
         const double rr = upd(k, wi, ri, pi, si, xi);
         if (k != l - 1) acc[0] += rr;
     }
@@ -505,9 +594,11 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_start_kernel(CgmStartArgs a, 
     const int64_t i0 = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x;
     DevState* st = a.st;
     bool have0 = i0 < l;
-    if constexpr (DEF) { if (have0 && ((a.def_mask[i0 >> 5] >> (i0 & 31)) & 1u)) have0 = false; }
+    uint32_t mw0 = 0u;
+    if constexpr (DEF) { if (have0) mw0 = a.def_mask[i0 >> 5]; }
     d2 w0 = make_double2(0.0, 0.0), b0 = w0;
     if (have0) { w0 = a.w[i0]; b0 = a.rhs[i0]; }
+    if ((mw0 >> (i0 & 31)) & 1u) have0 = false;
     const double vtx = st->vtau[0], vty = st->vtau[1];           // tau element of v (stashed by the sweep)
     if (FOLD && st->xchg_failed) return;
     __shared__ double sums[3];
@@ -561,9 +652,12 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_start_kernel(CgmStartArgs a, 
         if (i0 != l - 1) acc[0] += ri.x * ri.x + ri.y * ri.y;
     }
     for (int64_t k = i0 + stride; k < l; k += stride) {
-        if constexpr (DEF) { if ((a.def_mask[k >> 5] >> (k & 31)) & 1u) continue; }
-        const d2 wi = (k == l - 1) ? make_double2(wt1, wt2) : a.w[k];
+        uint32_t mw = 0u;
+        if constexpr (DEF) mw = a.def_mask[k >> 5];
+        d2 wi = a.w[k];
         const d2 bi = a.rhs[k];
+        if ((mw >> (k & 31)) & 1u) continue;
+        if (k == l - 1) wi = make_double2(wt1, wt2);
         const d2 ri = make_double2(bi.x - wi.x, bi.y - wi.y);
         a.r[k] = ri;
         if (a.p) a.p[k] = ri;
@@ -600,7 +694,7 @@ void launch_cgm_update(const LaunchCtx& c, const CgmIter& it, bool close_only) {
     a.j = it.j; a.close_here = it.close_in_update ? 1 : 0; a.close_only = close_only ? 1 : 0;
     a.cb = c.cb; a.n = (int)c.n; a.def_mask = c.def_mask;
     a.pb = it.fold ? *it.fold : PeerBox{}; a.seq_base = it.seq_base; a.count_repl = (int)c.count_repl;
-    a.pre = (c.pre && !it.fold && !it.from_reduced && !close_only && c.S.nwg >= 2048 && c.cg_blocks >= 4 * PRE_NPROD) ? c.pre : nullptr;
+    a.pre = (c.pre && !it.fold && !it.from_reduced && !close_only && c.S.nwg >= pre_min_records() && c.cg_blocks >= 4 * PRE_NPROD) ? c.pre : nullptr;
     a.pre_seq = (uint32_t)(it.seq_base + 2u * (uint32_t)it.j + 1u);
     a.batch_mark = it.batch_mark;
     dim3 grid(close_only ? 1 : c.cg_blocks), block(VEC_THREADS);
