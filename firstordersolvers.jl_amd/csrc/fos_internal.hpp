@@ -146,7 +146,9 @@ struct DevBlkCsr {
     const int32_t* wave_blk0;
     const BlkDesc* wave_first;         // [nwaves] copy of each wavefront's first descriptor (requested together with wave_blk0)
     int32_t resident;                  // 1: the whole operator stays in the caches from sweep to sweep -- ordinary loads for the matrix stream
-    int32_t dbg_flags;                 // timing experiments only (WRONG results): bit 0 = dual tiles skip the column-sum butterflies
+    int32_t dbg_flags;                 // timing experiments only (FOS_DBG_FLAGS; WRONG results): 1 = dual tiles skip the column-sum butterflies;
+                                       // cg_update_kernel: 4 = slot-spread rows left unfinished, 16 = scalar prologue only, 32 = no prologue
+                                       // (sums taken from the first record); bits 8-10 = elements requested in front of its prologue (1..4)
     int32_t nblk, nwg, nwaves;
     // dual tiles / deferred rows (ndef == 0: none)
     double* slots;                     // [nslots][2]   written by the sweeps

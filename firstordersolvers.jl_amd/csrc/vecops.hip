@@ -303,8 +303,7 @@ void launch_cg_update(const LaunchCtx& c, const CgIter& it, double2* x, double2*
     int ndb = 0, dlpr = 1;
     static const bool split_env = !(getenv("FOS_UPD_SPLIT") && atoi(getenv("FOS_UPD_SPLIT")) == 0);
     if (split_env && c.S.ndef > 0 && c.l >= 8 * (int64_t)c.S.ndef && c.cg_blocks >= 64) {
-        static const int div_env = getenv("FOS_UPD_DIV") ? atoi(getenv("FOS_UPD_DIV")) : 4;
-        const int64_t target = c.cg_blocks / (div_env > 0 ? div_env : 4);
+        const int64_t target = c.cg_blocks / 4;
         while (dlpr < c.S.def_lpr && ((int64_t)c.S.ndef * (2 * dlpr) + VEC_THREADS - 1) / VEC_THREADS <= target) dlpr *= 2;
         ndb = (int)(((int64_t)c.S.ndef * dlpr + VEC_THREADS - 1) / VEC_THREADS);
         if (ndb < 1 || ndb > c.cg_blocks / 2) ndb = 0;
@@ -407,8 +406,10 @@ struct CgmArgs {
     double* pre; uint32_t pre_seq;
     int32_t batch_mark;
 };
+// (three wavefronts per SIMD: at two -- above 168 VGPRs -- the 512 workgroups of one launch fill the device, and two ranks that
+// share ONE GPU, as the tests' ranks do, can then wait for each other's mailbox words for ever: the peer's kernel finds no slot)
 template <bool DEF, bool FOLD>
-__global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevBlkCsr S) {
+__global__ __launch_bounds__(VEC_THREADS, 3) void cgm_update_kernel(CgmArgs a, DevBlkCsr S) {
     const int64_t l = a.l;
     const int64_t stride = (int64_t)gridDim.x * VEC_THREADS;
     const int64_t i0 = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x;
@@ -424,13 +425,12 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
     //          the sweep's records; the slot-spread row this lane works on in the first pass (its list bounds and row number)
     d2 w0 = make_double2(0.0, 0.0), r0 = w0, x0 = w0, p0 = w0, s0 = w0;
     if (have0) { w0 = a.w[i0]; r0 = a.r[i0]; x0 = a.x[i0]; if (!first) { p0 = a.p[i0]; s0 = a.s[i0]; } }
-    if ((mw0 >> (i0 & 31)) & 1u) have0 = false;
     const bool closing = a.close_here != 0;      // (i = 0: g_0 from the start kernel's records, no stop test -- at least one iteration runs)
     const int done = st->done, xfail = st->xchg_failed, maxit = st->maxit;
     const double vtx = st->vtau[0], vty = st->vtau[1];           // tau element of r_i (stashed by the sweep that applied M to it)
     const double g_cur = st->rn2[i & 1], g_prev = st->rn2[(i + 1) & 1], a_prev = st->alpha2[(i + 1) & 1], tol = st->tol;
     const bool plain_sums = !a.from_reduced && a.pre == nullptr;
-    PartialRegs<3> kreg;
+    PartialRegs<3, 6> kreg;                        // (6 x 256 records per round trip; 8 would cost a spill at three wavefronts per SIMD)
     if (plain_sums) kreg.load(a.kkt_partials, a.nkkt);
     const int lpr = DEF ? S.def_lpr : 1, sh = 31 - __clz(lpr);
     const int rows_per_pass = (gridDim.x * VEC_THREADS) >> sh;
@@ -454,6 +454,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_update_kernel(CgmArgs a, DevB
     }
     if (done) return;
     if (FOLD && xfail) return;
+    if ((mw0 >> (i0 & 31)) & 1u) have0 = false;         // a slot-spread row: finished below, its elements were read for nothing
     // stage 3: those slots (the rest of a longer list follows by the ordinary chunks)
     double du1 = 0.0, du2 = 0.0;
     if constexpr (DEF) {

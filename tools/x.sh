@@ -1,6 +1,9 @@
 cd "$GRAFT_REPO_ROOT"
-timeout 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_certificates.py tests/test_gpu_edge_cases.py -q -m gpu -x -k "psd or PSD or cert or cone" 2>&1 | grep -v "^HIP\|^ROCm\|^Hostname\|^Librccl\|^$\|^RCCL" | tail -4
-python3 bench.py --workload C4 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json
-for l in sys.stdin:
-    l=l.strip()
-    if l.startswith('{'): d=json.loads(l); print('C4', d['value'], d['ms_per_step'], json.dumps(d['roofline_psd']), d['time_shares'], d['config']['residuals_after_run'])"
+python3 -m pytest tests -q -m gpu -x 2>&1 | grep -v "^HIP\|^ROCm\|^Hostname\|^Librccl\|^$\|^RCCL" | tail -6
+run() { tag=$1; shift; envs=""; while [ "$1" != "--" ]; do envs="$envs $1"; shift; done; shift
+  env $envs python3 bench.py "$@" 2>/dev/null | tail -1 | python3 -c "import sys,json
+d=json.loads(sys.stdin.read()); print('$tag', d['value'], d['ms_per_step'], d['config'].get('cg_iters_per_step'), d['config'].get('cg_variant'))"; }
+run shard A=1 -- --small --no-cpu-baseline
+run shard_dist FOS_FORCE_DIST=1 -- --small --no-cpu-baseline
+run shard_dist2 FOS_FORCE_DIST=1 -- --small --no-cpu-baseline
+run c4 A=1 -- --no-cpu-baseline
