@@ -99,6 +99,18 @@ PROTOTYPES = {
     "fos_set_cg_variant": (C.c_int, [_h, C.c_int32]),
     "fos_get_cg_variant": (C.c_int, [_h, _i32p]),
     "fos_debug_set": (C.c_int, [_h, C.c_int32, C.c_int64]),
+    # Feasibility form (src/problemforms/Feasibility/*.jl)
+    "fos_feas_create": (C.c_int, [C.c_int64, C.c_int32, C.POINTER(_h)]),
+    "fos_feas_destroy": (C.c_int, [_h]),
+    "fos_feas_set_affine": (C.c_int, [_h, C.c_int32, C.c_int64, _dp, _dp]),
+    "fos_feas_set_box": (C.c_int, [_h, C.c_int32, C.c_double, C.c_double]),
+    "fos_feas_set_alg": (C.c_int, [_h, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "fos_feas_set_iterate": (C.c_int, [_h, _dp]),
+    "fos_feas_step": (C.c_int, [_h, C.c_int64, C.c_int64, C.c_int64, C.c_double, _i64p, _i32p, _dp, _i32p]),
+    "fos_feas_getsol": (C.c_int, [_h, _dp, C.c_int32, C.c_double, _i32p, _dp]),
+    "fos_feas_get_iterate": (C.c_int, [_h, _dp]),
+    "fos_feas_prox": (C.c_int, [_h, C.c_int32, _dp, _dp]),
+    "fos_feas_info": (C.c_int, [_h, _dp, _i32p, _dp]),
 }
 
 _lib = None

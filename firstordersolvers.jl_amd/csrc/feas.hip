@@ -1,0 +1,450 @@
+// Feasibility form on the device: find a point of S1 n S2 with the solvers' own steps.
+//   reference: src/problemforms/Feasibility/Feasibility.jl (model, zeros(n) start, populate_solution),
+//              src/problemforms/Feasibility/FeasibilityStatus.jl:32-72 (err = norm(prev - z) every checki-th iteration),
+//              src/solvers/{gap,gapa,fista,dykstra}.jl (the steps: the same files the HSDE path follows).
+// The reference takes ANY two ProximalOperators objects (host callbacks); here the two sets are device objects, the two its own
+// test uses (test/testfeasibility.jl:9-10): IndAffine(A, b) -- dense A with full row rank, an exact projection through a one-time
+// inverse of A A' (Newton-Schulz on the fp64 MFMA GEMM of vecops.hip, as fos_enable_direct does for the HSDE) -- and
+// IndBox(lo, hi).  Vectors are plain n-vectors in HBM; every iteration is a handful of streaming kernels plus, for IndAffine,
+// one dense symmetric matrix-vector product (n^2 x 8 bytes: the kernel that bounds the path, HBM).  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "dev_common.hpp"
+#include "fos_internal.hpp"
+
+namespace fos {
+
+constexpr int FEAS_THREADS = 256;
+constexpr int FEAS_PARTS = 256;               // partial sums per reduction (fixed: results do not depend on the device)
+
+#define FEAS_STRIDE(i, n) for (int64_t i = blockIdx.x * (int64_t)FEAS_THREADS + threadIdx.x; i < (n); i += (int64_t)gridDim.x * FEAS_THREADS)
+
+__global__ __launch_bounds__(FEAS_THREADS) void feas_fill_kernel(int64_t n, double* __restrict__ y, double v) { FEAS_STRIDE(i, n) y[i] = v; }
+__global__ __launch_bounds__(FEAS_THREADS) void feas_copy_kernel(int64_t n, double* __restrict__ y, const double* __restrict__ x) { FEAS_STRIDE(i, n) y[i] = x[i]; }
+// y = x - P x + q      IndAffine: x - A'(A A')^-1 (A x - b) with P = A'(A A')^-1 A, q = A'(A A')^-1 b
+__global__ __launch_bounds__(FEAS_THREADS) void feas_affine_finish_kernel(int64_t n, double* __restrict__ y, const double* __restrict__ x,
+                                                                          const double* __restrict__ Px, const double* __restrict__ q) {
+    FEAS_STRIDE(i, n) y[i] = (x[i] - Px[i]) + q[i];
+}
+// y = clamp(x, lo, hi)      IndBox
+__global__ __launch_bounds__(FEAS_THREADS) void feas_box_kernel(int64_t n, double* __restrict__ y, const double* __restrict__ x, double lo, double hi) {
+    FEAS_STRIDE(i, n) y[i] = fmin(fmax(x[i], lo), hi);
+}
+// y = a y + (1 - a) x       gap.jl:48,58 ; gapa.jl:67,77 (a = alpha12, a device scalar) ; fista.jl:37
+__global__ __launch_bounds__(FEAS_THREADS) void feas_relax_kernel(int64_t n, double* __restrict__ y, const double* __restrict__ x, double a,
+                                                                  const double* __restrict__ a_dev) {
+    const double aa = a_dev ? *a_dev : a;
+    FEAS_STRIDE(i, n) y[i] = aa * y[i] + (1.0 - aa) * x[i];
+}
+// out = a + b ; p = a - b
+__global__ __launch_bounds__(FEAS_THREADS) void feas_add_kernel(int64_t n, double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b) {
+    FEAS_STRIDE(i, n) out[i] = a[i] + b[i];
+}
+__global__ __launch_bounds__(FEAS_THREADS) void feas_sub_kernel(int64_t n, double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b) {
+    FEAS_STRIDE(i, n) out[i] = a[i] - b[i];
+}
+// y = x + coef (x - xold)      fista.jl:46
+__global__ __launch_bounds__(FEAS_THREADS) void feas_extrap_kernel(int64_t n, double* __restrict__ y, const double* __restrict__ x,
+                                                                   const double* __restrict__ xold, double coef) {
+    FEAS_STRIDE(i, n) y[i] = x[i] + coef * (x[i] - xold[i]);
+}
+
+template <int NACC>
+__device__ __forceinline__ void feas_block_store(const double (&acc)[NACC], double* __restrict__ partials) {
+    __shared__ double sm[4 * NACC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        const double v = wave_sum(acc[a]);
+        if (lane == 0) sm[wave * NACC + a] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double s = 0.0;
+        for (int w = 0; w < FEAS_THREADS / 64; ++w) s += sm[w * NACC + threadIdx.x];
+        partials[(size_t)blockIdx.x * NACC + threadIdx.x] = s;
+    }
+}
+// partial sums of |a - b|^2      FeasibilityStatus.jl:40
+__global__ __launch_bounds__(FEAS_THREADS) void feas_normdiff_kernel(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                                                     double* __restrict__ partials) {
+    double acc[1] = {0.0};
+    FEAS_STRIDE(i, n) { const double d = a[i] - b[i]; acc[0] += d * d; }
+    feas_block_store<1>(acc, partials);
+}
+// normedScalar(t2, t1, t1, x): partial sums of <d1, d2>, |d1|^2, |d2|^2 with d1 = t2 - t1, d2 = t1 - x      gapa.jl:36-47,96
+__global__ __launch_bounds__(FEAS_THREADS) void feas_triple_kernel(int64_t n, const double* __restrict__ t2, const double* __restrict__ t1,
+                                                                   const double* __restrict__ x, double* __restrict__ partials) {
+    double acc[3] = {0.0, 0.0, 0.0};
+    FEAS_STRIDE(i, n) {
+        const double d1 = t2[i] - t1[i], d2 = t1[i] - x[i];
+        acc[0] += d1 * d2; acc[1] += d1 * d1; acc[2] += d2 * d2;
+    }
+    feas_block_store<3>(acc, partials);
+}
+// alpha12 = (1 - beta) 2 / (1 + sqrt(1 - scl^2)) + 2 beta,  scl = clamp(|s| / sqrt(n1 n2), 0, 1), NaN -> 0      gapa.jl:96-101
+__global__ void feas_alpha12_kernel(const double* __restrict__ partials, int nparts, double beta, double* __restrict__ a12) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0, n1 = 0.0, n2 = 0.0;
+    for (int b = 0; b < nparts; ++b) { s += partials[3 * b]; n1 += partials[3 * b + 1]; n2 += partials[3 * b + 2]; }
+    double scl = fabs(s) / sqrt(n1 * n2);
+    if (scl != scl) scl = 0.0;
+    scl = fmin(fmax(scl, 0.0), 1.0);
+    const double aopt = 2.0 / (1.0 + sqrt(1.0 - scl * scl));
+    *a12 = (1.0 - beta) * aopt + beta * 2.0;
+}
+// x = alpha t2 + (1 - alpha) x      gap.jl:78, gapa.jl:103
+__global__ __launch_bounds__(FEAS_THREADS) void feas_combine_kernel(int64_t n, double* __restrict__ x, const double* __restrict__ t2, double alpha) {
+    FEAS_STRIDE(i, n) x[i] = alpha * t2[i] + (1.0 - alpha) * x[i];
+}
+// set-up: E[i + i L] = 1 for i >= m (the padding of G = A A' + E keeps it positive definite)
+__global__ __launch_bounds__(FEAS_THREADS) void feas_pad_identity_kernel(int64_t L, int64_t m, double* __restrict__ E) {
+    FEAS_STRIDE(i, L) if (i >= m) E[i + i * L] = 1.0;
+}
+
+struct FeasSet {
+    int kind = 0;                   // 0 unset, 1 IndAffine, 2 IndBox
+    double* P = nullptr;            // [L x L] A'(A A')^-1 A, column-major
+    double* q = nullptr;            // [L]     A'(A A')^-1 b
+    double lo = 0.0, hi = 0.0;
+    int ns_iters = 0;               // Newton-Schulz steps of the set-up
+    double ns_resid = 0.0;          // max |G X - I| it ended with
+};
+
+}  // namespace fos
+
+using namespace fos;
+
+struct fos_feas {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t n = 0, L = 0;
+    FeasSet S[2];
+    int alg = FOS_ALG_GAP;
+    double alpha = 0.8, alpha1 = 1.8, alpha2 = 1.8, beta = 0.0;
+    double fista_t = 1.0;
+    // vectors of length L (zero padded)
+    double *x = nullptr, *t1 = nullptr, *t2 = nullptr, *y = nullptr, *xold = nullptr, *p = nullptr, *q = nullptr, *prev = nullptr, *tmp = nullptr, *px = nullptr;
+    double* partials = nullptr;     // [3 x FEAS_PARTS]
+    double* a12 = nullptr;          // device scalar alpha12 (GAPA)
+    int grid = 1;
+    int status = FOS_STATUS_CONTINUE;
+    int checked = 0;
+    double err = NAN;
+    std::vector<void*> owned;
+};
+
+namespace {
+
+int feas_check_launch(const char* where) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("%s: a kernel launch failed: %s", where, hipGetErrorString(e)); return FOS_EHIP; }
+    return FOS_OK;
+}
+
+int feas_alloc(fos_feas* h, double** out, size_t count) {
+    void* q = nullptr;
+    const hipError_t e = hipMalloc(&q, sizeof(double) * std::max<size_t>(count, 1));
+    if (e != hipSuccess) { set_error("feasibility form: hipMalloc of %zu doubles failed: %s", count, hipGetErrorString(e)); return FOS_ENOMEM; }
+    if (hipMemsetAsync(q, 0, sizeof(double) * std::max<size_t>(count, 1), h->stream) != hipSuccess) { (void)hipFree(q); set_error("hipMemsetAsync failed"); return FOS_EHIP; }
+    h->owned.push_back(q);
+    *out = static_cast<double*>(q);
+    return FOS_OK;
+}
+
+#define FEAS_K(kernel, ...) hipLaunchKernelGGL(kernel, dim3(h->grid), dim3(FEAS_THREADS), 0, h->stream, __VA_ARGS__)
+
+LaunchCtx feas_ctx(const fos_feas* h, int64_t l) {
+    LaunchCtx c{};
+    c.stream = h->stream;
+    c.l = l;
+    return c;
+}
+
+// prox!(y, S, x): the projection onto set `which`; y must not alias x
+int feas_prox(fos_feas* h, int which, double* y, const double* x) {
+    const FeasSet& s = h->S[which];
+    if (s.kind == 1) {
+        launch_dense_symv(feas_ctx(h, h->n), h->L, s.P, x, h->px);        // P is symmetric: column dots = P x
+        FEAS_K(feas_affine_finish_kernel, h->n, y, x, h->px, s.q);
+    } else if (s.kind == 2) {
+        FEAS_K(feas_box_kernel, h->n, y, x, s.lo, s.hi);
+    } else { set_error("feasibility form: set %d has not been defined", which + 1); return FOS_EINVAL; }
+    return FOS_OK;
+}
+
+// checkstatus(stat, z) at iteration i      FeasibilityStatus.jl:32-72
+int feas_check(fos_feas* h, const double* z, int64_t i, int64_t checki, double eps, bool override_) {
+    if (override_ || (checki > 0 && i % checki == 0)) {
+        FEAS_K(feas_normdiff_kernel, h->n, (const double*)h->prev, z, h->partials);
+        std::vector<double> part((size_t)h->grid);
+        FOS_HIP(hipMemcpyAsync(part.data(), h->partials, sizeof(double) * h->grid, hipMemcpyDeviceToHost, h->stream));
+        FOS_HIP(hipStreamSynchronize(h->stream));
+        double s = 0.0;
+        for (double v : part) s += v;
+        h->err = std::sqrt(s);
+        h->status = (h->err <= eps) ? FOS_STATUS_OPTIMAL : FOS_STATUS_CONTINUE;       // :57 (NaN <= eps is false)
+        h->checked = 1;
+    } else h->checked = 0;
+    FEAS_K(feas_copy_kernel, h->n, h->prev, z);                                        // :61,69: every call
+    return FOS_OK;
+}
+
+int feas_step_once(fos_feas* h, int64_t i, int64_t checki, double eps) {
+    const int64_t n = h->n;
+    switch (h->alg) {
+    case FOS_ALG_GAP:
+    case FOS_ALG_GAPA: {
+        const bool ad = h->alg == FOS_ALG_GAPA;
+        const double* a12 = ad ? h->a12 : nullptr;
+        FOS_TRY(feas_prox(h, 0, h->t1, h->x));                                         // S1!  gap.jl:42-51, gapa.jl:61-70
+        FEAS_K(feas_relax_kernel, n, h->t1, (const double*)h->x, h->alpha1, a12);
+        FOS_TRY(feas_prox(h, 1, h->t2, h->t1));                                        // S2!  gap.jl:53-59, gapa.jl:72-78
+        FOS_TRY(feas_check(h, h->t2, i, checki, eps, false));
+        FEAS_K(feas_relax_kernel, n, h->t2, (const double*)h->t1, h->alpha2, a12);
+        if (ad) {                                                                      // gapa.jl:96-101 (relaxed t1, t2 and the old x)
+            FEAS_K(feas_triple_kernel, n, (const double*)h->t2, (const double*)h->t1, (const double*)h->x, h->partials);
+            hipLaunchKernelGGL(feas_alpha12_kernel, dim3(1), dim3(64), 0, h->stream, (const double*)h->partials, h->grid, h->beta, h->a12);
+        }
+        FEAS_K(feas_combine_kernel, n, h->x, (const double*)h->t2, h->alpha);          // gap.jl:78, gapa.jl:103
+        break;
+    }
+    case FOS_ALG_FISTA: {                                                              // fista.jl:28-48
+        if (i == 1) FEAS_K(feas_copy_kernel, n, h->y, (const double*)h->x);
+        FOS_TRY(feas_prox(h, 0, h->t1, h->y));
+        FEAS_K(feas_relax_kernel, n, h->t1, (const double*)h->y, h->alpha, (const double*)nullptr);
+        FEAS_K(feas_copy_kernel, n, h->xold, (const double*)h->x);
+        FOS_TRY(feas_prox(h, 1, h->x, h->t1));
+        FOS_TRY(feas_check(h, h->x, i, checki, eps, false));
+        const double told = h->fista_t;
+        h->fista_t = (1.0 + std::sqrt(1.0 + 4.0 * told * told)) / 2.0;
+        FEAS_K(feas_extrap_kernel, n, h->y, (const double*)h->x, (const double*)h->xold, (told - 1.0) / h->fista_t);
+        break;
+    }
+    case FOS_ALG_DYKSTRA: {                                                            // dykstra.jl:25-36
+        FEAS_K(feas_add_kernel, n, h->tmp, (const double*)h->x, (const double*)h->p);
+        FOS_TRY(feas_prox(h, 0, h->y, h->tmp));
+        FEAS_K(feas_sub_kernel, n, h->p, (const double*)h->tmp, (const double*)h->y);
+        FEAS_K(feas_add_kernel, n, h->tmp, (const double*)h->y, (const double*)h->q);
+        FOS_TRY(feas_prox(h, 1, h->x, h->tmp));
+        FOS_TRY(feas_check(h, h->x, i, checki, eps, false));
+        FEAS_K(feas_sub_kernel, n, h->q, (const double*)h->tmp, (const double*)h->x);
+        break;
+    }
+    default: set_error("feasibility form: unknown algorithm %d", h->alg); return FOS_EINVAL;
+    }
+    return FOS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fos_feas_create(int64_t n, int32_t device, fos_feas_handle* out) {
+    if (!out || n < 1) { set_error("fos_feas_create: n >= 1 and a handle pointer are required"); return FOS_EINVAL; }
+    if (n > 46000) { set_error("feasibility form: the dense affine projector holds %lld x %lld doubles: supported up to n = 46000", (long long)n, (long long)n); return FOS_EUNSUPPORTED; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device is visible: the HIP path has no CPU fallback"); return FOS_ENODEVICE; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (0..%d)", device, ndev - 1); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(device));
+    fos_feas* h = new fos_feas();
+    h->device = device; h->n = n; h->L = (n + 63) / 64 * 64;
+    h->grid = (int)std::min<int64_t>(FEAS_PARTS, (n + FEAS_THREADS - 1) / FEAS_THREADS);
+    if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; set_error("hipStreamCreate failed"); return FOS_EHIP; }
+    int rc = FOS_OK;
+    double** vecs[] = {&h->x, &h->t1, &h->t2, &h->y, &h->xold, &h->p, &h->q, &h->prev, &h->tmp, &h->px};
+    for (double** v : vecs) { rc = feas_alloc(h, v, (size_t)h->L); if (rc != FOS_OK) break; }
+    if (rc == FOS_OK) rc = feas_alloc(h, &h->partials, 3 * (size_t)FEAS_PARTS);
+    if (rc == FOS_OK) rc = feas_alloc(h, &h->a12, 8);
+    if (rc != FOS_OK) { fos_feas_destroy(h); return rc; }
+    *out = h;
+    return fos_feas_set_iterate(h, nullptr);
+}
+
+int fos_feas_destroy(fos_feas_handle h) {
+    if (!h) return FOS_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void* q : h->owned) (void)hipFree(q);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return FOS_OK;
+}
+
+// IndAffine(A, b): A is m x n, ROW-major (C order), full row rank.  One-time set-up on the device:
+//   G = A A' (+ identity on the padding), X = G^-1 by Newton-Schulz  X <- 2 X - X (G X)  from X_0 = I / (1.25 |A|_F^2),
+//   P = A' X A,  q = A' X b.
+int fos_feas_set_affine(fos_feas_handle h, int32_t which, int64_t m, const double* A, const double* b) {
+    if (!h || !A || !b || which < 1 || which > 2 || m < 1 || m > h->n) { set_error("fos_feas_set_affine: bad argument (1 <= m <= n, which = 1 | 2)"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    const int64_t n = h->n, L = h->L;
+    const size_t L2 = (size_t)L * (size_t)L;
+    std::vector<double> Ah(L2, 0.0), At(L2, 0.0), bp((size_t)L, 0.0);
+    double fro2 = 0.0;
+    for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = 0; j < n; ++j) {
+            const double v = A[i * n + j];
+            if (!(v == v) || std::fabs(v) > 1e300) { set_error("IndAffine: A has non-finite entries"); return FOS_EINVAL; }
+            Ah[(size_t)i + (size_t)j * L] = v;                   // column-major L x L, rows 0..m-1
+            At[(size_t)j + (size_t)i * L] = v;                   // its transpose
+            fro2 += v * v;
+        }
+    for (int64_t i = 0; i < m; ++i) bp[(size_t)i] = b[i];
+    if (!(fro2 > 0.0)) { set_error("IndAffine: A is zero"); return FOS_EINVAL; }
+    double *dA = nullptr, *dAt = nullptr, *G = nullptr, *B0 = nullptr, *B1 = nullptr, *B2 = nullptr, *db = nullptr, *dt = nullptr;
+    auto cleanup = [&]() { for (double* q : {dA, dAt, G, B0, B1, B2, db, dt}) (void)hipFree(q); };
+    hipError_t e = hipSuccess;
+    for (double** q : {&dA, &dAt, &G, &B0, &B1, &B2}) if (e == hipSuccess) e = hipMalloc((void**)q, sizeof(double) * L2);
+    for (double** q : {&db, &dt}) if (e == hipSuccess) e = hipMalloc((void**)q, sizeof(double) * (size_t)L);
+    if (e != hipSuccess) { cleanup(); set_error("IndAffine set-up: hipMalloc of six %lld x %lld buffers failed: %s", (long long)L, (long long)L, hipGetErrorString(e)); return FOS_ENOMEM; }
+    auto fail = [&](int code) { cleanup(); return code; };
+#define FEAS_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("IndAffine set-up: %s -> %s", #expr, hipGetErrorString(_e)); return fail(FOS_EHIP); } } while (0)
+    FEAS_HIP(hipMemcpyAsync(dA, Ah.data(), sizeof(double) * L2, hipMemcpyHostToDevice, h->stream));
+    FEAS_HIP(hipMemcpyAsync(dAt, At.data(), sizeof(double) * L2, hipMemcpyHostToDevice, h->stream));
+    FEAS_HIP(hipMemcpyAsync(db, bp.data(), sizeof(double) * (size_t)L, hipMemcpyHostToDevice, h->stream));
+    FEAS_HIP(hipMemsetAsync(B0, 0, sizeof(double) * L2, h->stream));
+    FEAS_HIP(hipMemsetAsync(B1, 0, sizeof(double) * L2, h->stream));
+    const LaunchCtx c = feas_ctx(h, L);
+    FEAS_K(feas_pad_identity_kernel, L, m, B0);                                        // E
+    launch_dense_gemm(c, (int)L, 1.0, dA, dAt, 1.0, B0, G);                            // G = A A' + E   (block diagonal, positive definite)
+    launch_dense_scale_identity(c, L, B1, 1.0 / (1.25 * std::max(fro2, 1.0)));         // X_0: lambda_max(G) <= max(|A|_F^2, 1)
+    double *X = B1, *Xn = B2;
+    std::vector<double> part(256);
+    double resid = 1.0, prev_resid = 2.0;
+    int it = 0;
+    for (; it < 120; ++it) {
+        launch_dense_gemm(c, (int)L, 1.0, G, X, 0.0, nullptr, B0);                     // Y = G X
+        launch_dense_resid(c, L, B0, h->partials, 256);
+        FEAS_HIP(hipMemcpyAsync(part.data(), h->partials, sizeof(double) * 256, hipMemcpyDeviceToHost, h->stream));
+        FEAS_HIP(hipStreamSynchronize(h->stream));
+        resid = 0.0;
+        for (double r : part) resid = (r > resid || r != r) ? r : resid;
+        if (resid != resid) { set_error("IndAffine set-up: the inverse of A A' produced NaN"); return fail(FOS_EINVAL); }
+        if (resid <= 2e-14 || (resid <= 1e-10 && resid >= 0.5 * prev_resid)) break;   // rounding level: the residual no longer squares
+        prev_resid = resid;
+        launch_dense_gemm(c, (int)L, -1.0, X, B0, 2.0, X, Xn);                         // X <- 2 X - X Y
+        std::swap(X, Xn);
+    }
+    if (!(resid <= 1e-10)) {
+        set_error("IndAffine set-up: the inverse of A A' did not converge (max |G X - I| = %.3e after %d Newton-Schulz steps): A needs full row rank and a moderate condition number", resid, it);
+        return fail(FOS_EINVAL);
+    }
+    FeasSet& s = h->S[which - 1];
+    int rc = FOS_OK;
+    if (!s.P) rc = feas_alloc(h, &s.P, L2);
+    if (rc == FOS_OK && !s.q) rc = feas_alloc(h, &s.q, (size_t)L);
+    if (rc != FOS_OK) return fail(rc);
+    launch_dense_gemm(c, (int)L, 1.0, X, dA, 0.0, nullptr, B0);                        // B0 = X A
+    launch_dense_gemm(c, (int)L, 1.0, dAt, B0, 0.0, nullptr, s.P);                     // P = A' X A
+    launch_dense_symv(c, L, X, db, dt);                                                // t = X b   (X symmetric)
+    launch_dense_symv(c, L, dA, dt, s.q);                                              // q[col] = A[:, col] . t = (A' t)[col]
+    FEAS_HIP(hipStreamSynchronize(h->stream));
+#undef FEAS_HIP
+    rc = feas_check_launch("IndAffine set-up");
+    cleanup();
+    if (rc != FOS_OK) return rc;
+    s.kind = 1; s.ns_iters = it; s.ns_resid = resid;
+    return FOS_OK;
+}
+
+int fos_feas_set_box(fos_feas_handle h, int32_t which, double lo, double hi) {
+    if (!h || which < 1 || which > 2 || !(lo <= hi)) { set_error("fos_feas_set_box: which = 1 | 2 and lo <= hi are required"); return FOS_EINVAL; }
+    FeasSet& s = h->S[which - 1];
+    s.kind = 2; s.lo = lo; s.hi = hi;
+    return FOS_OK;
+}
+
+int fos_feas_set_alg(fos_feas_handle h, int32_t alg, double alpha, double alpha1, double alpha2, double beta) {
+    if (!h || alg < FOS_ALG_GAP || alg > FOS_ALG_DYKSTRA) { set_error("fos_feas_set_alg: unknown algorithm"); return FOS_EINVAL; }
+    h->alg = alg; h->alpha = alpha; h->alpha1 = alpha1; h->alpha2 = alpha2; h->beta = beta;
+    return FOS_OK;
+}
+
+// x = x0 (NULL: zeros(n), Feasibility.jl:58) and the state of a fresh init_algorithm!: alpha12 = 2 (gapa.jl:29), t = 1, y = xold = 0
+// (fista.jl:22-24), p = q = 0 (dykstra.jl:21-22), prev = NaN (Feasibility.jl:78)
+int fos_feas_set_iterate(fos_feas_handle h, const double* x0) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    const size_t bytes = sizeof(double) * (size_t)h->L;
+    for (double* v : {h->x, h->t1, h->t2, h->y, h->xold, h->p, h->q, h->tmp, h->px}) FOS_HIP(hipMemsetAsync(v, 0, bytes, h->stream));
+    if (x0) FOS_HIP(hipMemcpyAsync(h->x, x0, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+    FEAS_K(feas_fill_kernel, h->n, h->prev, (double)NAN);
+    const double two = 2.0;
+    FOS_HIP(hipMemcpyAsync(h->a12, &two, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    h->fista_t = 1.0; h->status = FOS_STATUS_CONTINUE; h->checked = 0; h->err = NAN;
+    return feas_check_launch("fos_feas_set_iterate");
+}
+
+// iterations first_iter .. first_iter + niter - 1 of `iterate` (solverwrapper.jl:23-29): stops behind the iteration whose check
+// found err <= eps.  done = iterations run; status / err / checked describe the LAST iteration (FeasibilityStatus fields).
+int fos_feas_step(fos_feas_handle h, int64_t first_iter, int64_t niter, int64_t checki, double eps, int64_t* done, int32_t* status, double* err,
+                  int32_t* checked) {
+    if (!h || first_iter < 1 || niter < 0) { set_error("fos_feas_step: bad argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    int64_t k = 0;
+    for (; k < niter; ++k) {
+        FOS_TRY(feas_step_once(h, first_iter + k, checki, eps));
+        if (h->status != FOS_STATUS_CONTINUE) { ++k; break; }
+    }
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    if (done) *done = k;
+    if (status) *status = h->status;
+    if (err) *err = h->err;
+    if (checked) *checked = h->checked;
+    return feas_check_launch("fos_feas_step");
+}
+
+// getsol (gap.jl:82-87, gapa.jl:107-112, fista.jl:50-56, dykstra.jl:38-44): P_S2(P_S1(x)); force_check = the `checkstatus(...,
+// override = true)` of solverwrapper.jl:31-33 on that point
+int fos_feas_getsol(fos_feas_handle h, double* sol, int32_t force_check, double eps, int32_t* status, double* err) {
+    if (!h || !sol) { set_error("fos_feas_getsol: NULL argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FOS_TRY(feas_prox(h, 0, h->t1, h->x));
+    FOS_TRY(feas_prox(h, 1, h->tmp, h->t1));
+    if (force_check) FOS_TRY(feas_check(h, h->tmp, 0, 0, eps, true));
+    FOS_HIP(hipMemcpyAsync(sol, h->tmp, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    if (status) *status = h->status;
+    if (err) *err = h->err;
+    return feas_check_launch("fos_feas_getsol");
+}
+
+int fos_feas_get_iterate(fos_feas_handle h, double* x) {
+    if (!h || !x) { set_error("fos_feas_get_iterate: NULL argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FOS_HIP(hipMemcpyAsync(x, h->x, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    return FOS_OK;
+}
+
+// prox!(y, S_which, x) on host vectors (tests; the reference's prox! protocol)
+int fos_feas_prox(fos_feas_handle h, int32_t which, const double* x, double* y) {
+    if (!h || !x || !y || which < 1 || which > 2) { set_error("fos_feas_prox: bad argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FOS_HIP(hipMemcpyAsync(h->tmp, x, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+    FOS_TRY(feas_prox(h, which - 1, h->t2, h->tmp));
+    FOS_HIP(hipMemcpyAsync(y, h->t2, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    return feas_check_launch("fos_feas_prox");
+}
+
+// diagnostics: alpha12 (GAPA), Newton-Schulz steps / final residual of an IndAffine set-up (0 when the set is not affine)
+int fos_feas_info(fos_feas_handle h, double* alpha12, int32_t* ns_iters, double* ns_resid) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    if (alpha12) { FOS_HIP(hipMemcpyAsync(alpha12, h->a12, sizeof(double), hipMemcpyDeviceToHost, h->stream)); FOS_HIP(hipStreamSynchronize(h->stream)); }
+    for (int k = 0; k < 2; ++k) {
+        if (ns_iters) ns_iters[k] = h->S[k].ns_iters;
+        if (ns_resid) ns_resid[k] = h->S[k].ns_resid;
+    }
+    return FOS_OK;
+}
+
+}  // extern "C"

@@ -666,3 +666,195 @@ def solve(problem, alg, device=0, out=None):
     model.loadproblem(problem.c, problem.A, problem.b, problem.K1, problem.K2)
     model.optimize()
     return model
+
+
+# ---------------------------------------------------------------------------------------------- Feasibility form
+# src/problemforms/Feasibility/Feasibility.jl, FeasibilityStatus.jl.  The reference takes any two
+# ProximalOperators objects; the device path takes the two set types below (the ones test/testfeasibility.jl uses).
+
+class IndAffine:
+    """ProximalOperators.IndAffine(A, b): {x : A x = b}, dense A (m x n, full row rank)."""
+
+    def __init__(self, A, b):
+        self.A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
+        self.b = np.ascontiguousarray(np.asarray(b, dtype=np.float64))
+        if self.A.ndim != 2 or self.b.shape != (self.A.shape[0],):
+            raise ValueError("IndAffine(A, b): A must be m x n and b of length m")
+
+
+class IndBox:
+    """ProximalOperators.IndBox(lo, hi): {x : lo <= x <= hi}, scalar bounds (+-inf allowed)."""
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi = float(lo), float(hi)
+
+
+class Feasibility:
+    """struct Feasibility{T1,T2}(S1, S2, n)   Feasibility.jl:2-6"""
+
+    def __init__(self, S1, S2, n):
+        self.S1, self.S2, self.n = S1, S2, int(n)
+
+
+class FeasibilitySolution:
+    """mutable struct FeasibilitySolution   Feasibility.jl:8-11"""
+
+    def __init__(self, x, status):
+        self.x, self.status = x, status
+
+
+class HipFeasibility:
+    """The device handle of a Feasibility problem (fos_feas_*): both sets, the algorithm's vectors and the status state."""
+
+    def __init__(self, problem: Feasibility, device=0):
+        self._lib = _lib.load()
+        self.n = problem.n
+        h = C.c_void_p()
+        _lib.check(self._lib.fos_feas_create(self.n, device, C.byref(h)))
+        self._h = h
+        for which, S in ((1, problem.S1), (2, problem.S2)):
+            if isinstance(S, IndAffine):
+                if S.A.shape[1] != self.n:
+                    raise ValueError("IndAffine: A has %d columns, the problem has n = %d" % (S.A.shape[1], self.n))
+                _lib.check(self._lib.fos_feas_set_affine(self._h, which, S.A.shape[0], _lib.dptr(S.A), _lib.dptr(S.b)))
+            elif isinstance(S, IndBox):
+                _lib.check(self._lib.fos_feas_set_box(self._h, which, S.lo, S.hi))
+            else:
+                raise _lib.FosError(-4, "Feasibility on the device: set %d must be IndAffine or IndBox (host callbacks are not "
+                                        "supported: there is no CPU path), got %s" % (which, type(S).__name__))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fos_feas_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_alg(self, alg: FOSAlgorithm):
+        if isinstance(alg, LineSearchWrapper):
+            raise _lib.FosError(-4, "LineSearchWrapper is not available on the Feasibility form of the device path")
+        _lib.check(self._lib.fos_feas_set_alg(self._h, *alg._alg_args()))
+
+    def set_iterate(self, x0=None):
+        if x0 is None:
+            _lib.check(self._lib.fos_feas_set_iterate(self._h, None))
+        else:
+            x0 = np.ascontiguousarray(x0, dtype=np.float64)
+            assert x0.shape == (self.n,)
+            _lib.check(self._lib.fos_feas_set_iterate(self._h, _lib.dptr(x0)))
+
+    def step(self, i_first, count, checki, eps):
+        """-> (iterations run, status name, err of the last check or nan, checked flag of the last iteration)"""
+        done, st, err, chk = C.c_int64(0), C.c_int32(0), C.c_double(float("nan")), C.c_int32(0)
+        _lib.check(self._lib.fos_feas_step(self._h, i_first, count, checki, eps, C.byref(done), C.byref(st), C.byref(err), C.byref(chk)))
+        return done.value, _lib.STATUS_NAMES[st.value], err.value, bool(chk.value)
+
+    def getsol(self, force_check=False, eps=1e-5):
+        sol = np.empty(self.n)
+        st, err = C.c_int32(0), C.c_double(float("nan"))
+        _lib.check(self._lib.fos_feas_getsol(self._h, _lib.dptr(sol), 1 if force_check else 0, eps, C.byref(st), C.byref(err)))
+        return sol, _lib.STATUS_NAMES[st.value], err.value
+
+    def get_iterate(self):
+        x = np.empty(self.n)
+        _lib.check(self._lib.fos_feas_get_iterate(self._h, _lib.dptr(x)))
+        return x
+
+    def prox(self, which, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty(self.n)
+        _lib.check(self._lib.fos_feas_prox(self._h, which, _lib.dptr(x), _lib.dptr(y)))
+        return y
+
+    def info(self):
+        a12 = C.c_double(0.0)
+        its = (C.c_int32 * 2)()
+        res = (C.c_double * 2)()
+        _lib.check(self._lib.fos_feas_info(self._h, C.byref(a12), its, res))
+        return {"alpha12": a12.value, "ns_iters": list(its), "ns_resid": list(res)}
+
+
+class FeasibilityModel:
+    """mutable struct FeasibilityModel   Feasibility.jl:15-50: problem + algorithm + merged options, solve_stat, history."""
+
+    def __init__(self, problem: Feasibility, alg: FOSAlgorithm, device=0, **kwargs):
+        self.S1, self.S2, self.n, self.alg = problem.S1, problem.S2, problem.n, alg
+        self.options = dict(alg.options)
+        self.options.update(kwargs)                                    # kwargs of solve! override the algorithm's   :37-41
+        self.solve_stat = "NotSolved"
+        self.obj_val = 0.0
+        self.enditr = -1
+        self.history = {}
+        self.out = None
+        t1 = time.perf_counter_ns()
+        self.dev = HipFeasibility(problem, device=device)              # init_algorithm!   :46
+        self.dev.set_alg(alg)
+        self.init_duration = time.perf_counter_ns() - t1
+
+    def _println(self, s):
+        if self.out is not None:
+            self.out.append(s)
+        else:
+            print(s)
+
+    def solve(self):
+        """solve!(model)   solverwrapper.jl:2-41 with FeasibilityStatus (FeasibilityStatus.jl:32-91)."""
+        o = self.options
+        max_iters, verbose, debug = o.get("max_iters", 10000), o.get("verbose", 1), o.get("debug", 1)
+        eps, checki = o.get("eps", 1e-5), o.get("checki", 100)
+        dev = self.dev
+        dev.set_iterate(o.get("initx"))
+        t0 = time.perf_counter_ns()
+        if verbose > 0:                                                # printstatusheader :74-84 (direct = true: no cg column)
+            self._println("Time to initialize: %ss" % julia_float(self.init_duration / 1e9))
+            self._println("-" * 22)
+            self._println(" Iter | res | time")
+            self._println("-" * 22)
+        i, status, checked, err = 0, "Continue", False, float("nan")
+        while i < max_iters and status == "Continue":
+            nxt = min(max_iters, (i // checki + 1) * checki) if checki > 0 else max_iters
+            done, status, err, checked = dev.step(i + 1, nxt - i, checki, eps)
+            i += done
+            if checked:
+                t = time.perf_counter_ns() - t0
+                if debug > 0:                                          # savedata :95-103
+                    self.history.setdefault("err", []).append((i, err))
+                    self.history.setdefault("t", []).append((i, t))
+                if verbose > 0:                                        # printstatusiter :86-88
+                    self._println("%6d|%s % .1es" % (i, _jl_e9(err), t / 1e9))
+                    if status == "Optimal":
+                        self._println("Found solution i=%d" % i)
+        guess, st2, err2 = dev.getsol(force_check=not checked, eps=eps)            # solverwrapper.jl:30-34
+        if not checked:
+            status, err = st2, err2
+            if debug > 0:
+                self.history.setdefault("err", []).append((i, err))
+            if verbose > 0:
+                self._println("%6d|%s % .1es" % (i, _jl_e9(err), (time.perf_counter_ns() - t0) / 1e9))
+                if status == "Optimal":
+                    self._println("Found solution i=%d" % i)
+        if verbose > 0:                                                # solverwrapper.jl:35-39
+            self._println("Time for iterations: ")
+            self._println("%s s" % julia_float((time.perf_counter_ns() - t0) / 1e9))
+        self.enditr = i
+        endstatus = "Indeterminate" if status == "Continue" else status            # populate_solution :61-68
+        self.solve_stat = endstatus
+        sol = FeasibilitySolution(guess, endstatus)
+        sol.iterations, sol.err = i, err
+        return sol
+
+
+def _jl_e9(v):
+    """@printf("% 9.2e", v)"""
+    return "% 9.2e" % v
+
+
+def solve_feasibility(problem: Feasibility, alg: FOSAlgorithm, device=0, out=None, **kwargs):
+    """solve!(problem::Feasibility, alg; kwargs...) -> (solution, model)   Feasibility.jl:52-56"""
+    model = FeasibilityModel(problem, alg, device=device, **kwargs)
+    model.out = out
+    return model.solve(), model

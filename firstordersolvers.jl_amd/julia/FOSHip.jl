@@ -246,4 +246,87 @@ function getsol(alg::FOSAlgorithm, data::HipData, x)
     return guess
 end
 
+# ---- Feasibility form [problemforms/Feasibility/Feasibility.jl, FeasibilityStatus.jl]: solve!(Feasibility(S1, S2, n), alg; gpu=true)
+#      with S1, S2 among ProximalOperators.IndAffine (dense A) and IndBox (scalar bounds) -- the sets of test/testfeasibility.jl.
+#      init_algorithm! returns a HipFeasData; iterate dispatches on it; FeasibilityModel, populate_solution and the printed table
+#      stay the reference's own code.
+import ..FirstOrderSolvers: FeasibilityModel, FeasibilityStatus
+
+mutable struct HipFeasData <: FOSSolverData
+    handle::Ptr{Cvoid}
+    function HipFeasData(model::FeasibilityModel, device::Integer)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:fos_feas_create, libfoship), Cint, (Int64, Int32, Ref{Ptr{Cvoid}}), Int64(model.n), Int32(device), h))
+        d = new(h[])
+        finalizer(x -> ccall((:fos_feas_destroy, libfoship), Cint, (Ptr{Cvoid},), x.handle), d)
+        for (which, S) in ((Int32(1), model.S1), (Int32(2), model.S2))
+            if S isa ProximalOperators.IndBox
+                check(ccall((:fos_feas_set_box, libfoship), Cint, (Ptr{Cvoid}, Int32, Cdouble, Cdouble), d.handle, which, Float64(S.lb), Float64(S.ub)))
+            else                                            # IndAffine(A, b), dense: the C ABI takes A row-major
+                At = Matrix{Float64}(transpose(S.A))        # column-major A' = row-major A
+                b = Vector{Float64}(S.b)
+                GC.@preserve At b check(ccall((:fos_feas_set_affine, libfoship), Cint, (Ptr{Cvoid}, Int32, Int64, Ptr{Cdouble}, Ptr{Cdouble}),
+                                              d.handle, which, Int64(size(S.A, 1)), At, b))
+            end
+        end
+        return d
+    end
+end
+
+getcgiter(::HipFeasData) = 0
+
+for T in (:GAP, :GAPA, :FISTA, :Dykstra)
+    @eval function init_algorithm!(alg::$T, model::FeasibilityModel)
+        if get(model.options, :gpu, false) === true
+            data = HipFeasData(model, get(model.options, :device, 0))
+            check(ccall((:fos_feas_set_alg, libfoship), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cdouble, Cdouble), data.handle, algargs(alg)...))
+            status_generator = (mo, checki, eps, verbose, debug) ->            # Feasibility.jl:76-78
+                FeasibilityStatus(mo.n, 0, mo, fill(NaN, mo.n), Array{Array{Float64,1},1}(), :Continue, checki, eps, verbose, false, true,
+                                  time_ns(), mo.init_duration, debug)
+            return data, status_generator
+        end
+        return invoke(init_algorithm!, Tuple{$T,FirstOrderSolvers.AbstractFOSModel}, alg, model)
+    end
+end
+
+function iterate(alg::FOSAlgorithm, data::HipFeasData, status::FeasibilityStatus, x, max_iters)
+    t1 = time()
+    printstatusheader(status)
+    check(ccall((:fos_feas_set_iterate, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, x))
+    i = 0
+    done, st, err, checked = Ref{Int64}(0), Ref{Int32}(0), Ref{Cdouble}(NaN), Ref{Int32}(0)
+    report = function ()
+        t = time_ns() - status.init_time
+        status.debug > 0 && savedata(status.i, err[], x, t, status.model, status.extra, min(status.debug, 1))     # FeasibilityStatus.jl:42-45
+        status.verbose > 0 && printstatusiter(status.i, err[], t)                                              # :46-54 (direct: no cg column)
+        status.status = STATUS_SYMBOLS[st[] + 1]
+        status.verbose > 0 && status.status == :Optimal && println("Found solution i=$(status.i)")
+        status.checked = true
+    end
+    while i < max_iters
+        count = min(max_iters - i, status.checki - (i % status.checki))
+        check(ccall((:fos_feas_step, libfoship), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Int64, Cdouble, Ref{Int64}, Ref{Int32}, Ref{Cdouble}, Ref{Int32}),
+                    data.handle, i + 1, count, status.checki, status.eps, done, st, err, checked))
+        i += done[]
+        status.i = i
+        if checked[] != 0
+            report()
+            status.status != :Continue && break
+        else
+            status.checked = false
+        end
+    end
+    guess = Vector{Float64}(undef, length(x))
+    force = status.checked ? Int32(0) : Int32(1)                                   # solverwrapper.jl:31-34
+    check(ccall((:fos_feas_getsol, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int32, Cdouble, Ref{Int32}, Ref{Cdouble}),
+                data.handle, guess, force, status.eps, st, err))
+    force != 0 && report()
+    if status.verbose > 0
+        println("Time for iterations: ")
+        println("$(time() - t1) s")
+    end
+    return guess
+end
+
 end # module

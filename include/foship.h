@@ -314,6 +314,36 @@ int fos_get_cg_variant(fos_handle h, int32_t* variant);   /* the variant the nex
 #define FOS_DEBUG_PUPDATE_DELAY 1
 int fos_debug_set(fos_handle h, int32_t what, int64_t value);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Feasibility form: `Feasibility(S1, S2, n)` -- find a point of S1 n S2 with the same algorithms.
+ * Replaces, for device-resident sets, src/problemforms/Feasibility/Feasibility.jl:2-6,52-68 (problem, solve!, zeros(n) start,
+ * populate_solution) and FeasibilityStatus.jl:32-72 (checkstatus: err = norm(prev - z) every checki-th iteration, :Optimal when
+ * err <= eps; prev is refreshed at EVERY iteration and starts as NaN).  The reference accepts any two ProximalOperators objects
+ * (host callbacks); the device path offers the two its own test uses (test/testfeasibility.jl:9-10):
+ *   fos_feas_set_affine  IndAffine(A, b): A m x n ROW-major, full row rank, n <= 46 000; exact projection x - A'(A A')^-1 (A x - b)
+ *                        through a one-time dense inverse formed on the device (Newton-Schulz on the fp64 MFMA GEMM);
+ *   fos_feas_set_box     IndBox(lo, hi), scalar bounds, +-INFINITY allowed.
+ * `which` = 1 | 2 (S1, S2).  Steps: gap.jl:42-87 (GAP / DR / AP), gapa.jl:61-112, fista.jl:28-56, dykstra.jl:25-44. */
+typedef struct fos_feas* fos_feas_handle;
+int fos_feas_create(int64_t n, int32_t device, fos_feas_handle* out);
+int fos_feas_destroy(fos_feas_handle h);
+int fos_feas_set_affine(fos_feas_handle h, int32_t which, int64_t m, const double* A, const double* b);
+int fos_feas_set_box(fos_feas_handle h, int32_t which, double lo, double hi);
+int fos_feas_set_alg(fos_feas_handle h, int32_t alg, double alpha, double alpha1, double alpha2, double beta);
+/* x = x0 (NULL: zeros(n), Feasibility.jl:58) and the algorithm state of a fresh init_algorithm! */
+int fos_feas_set_iterate(fos_feas_handle h, const double* x0);
+/* iterations first_iter .. first_iter + niter - 1 of `iterate` (solverwrapper.jl:23-29); stops behind the iteration whose check
+ * found err <= eps.  done = iterations run; status (FOS_STATUS_CONTINUE | FOS_STATUS_OPTIMAL), err and checked describe the last one. */
+int fos_feas_step(fos_feas_handle h, int64_t first_iter, int64_t niter, int64_t checki, double eps, int64_t* done, int32_t* status, double* err,
+                  int32_t* checked);
+/* getsol = P_S2(P_S1(x)) (gap.jl:82-87 ...); force_check: checkstatus(status, guess, override = true) of solverwrapper.jl:31-33 */
+int fos_feas_getsol(fos_feas_handle h, double* sol, int32_t force_check, double eps, int32_t* status, double* err);
+int fos_feas_get_iterate(fos_feas_handle h, double* x);
+/* prox!(y, S_which, x) on host vectors (the ProximableFunction protocol; test entry) */
+int fos_feas_prox(fos_feas_handle h, int32_t which, const double* x, double* y);
+/* diagnostics: GAPA's alpha12; per set the Newton-Schulz steps and the final max |G X - I| of an IndAffine set-up (arrays of 2) */
+int fos_feas_info(fos_feas_handle h, double* alpha12, int32_t* ns_iters, double* ns_resid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -800,7 +800,10 @@ class IndAffineDirect:
 
 
 def hsde_sets(model, direct=False):
-    """HSDE(model; direct=false)   HSDE.jl:7-29  ->  (S1, S2, N)."""
+    """get_sets_and_status: HSDE(model; direct=false)   HSDE.jl:7-29  ->  (S1, S2, N); a FeasibilityModel hands over its own two
+    sets (Feasibility.jl:73-80 -- the method of the same generic function for that model type)."""
+    if isinstance(model, FeasibilityModel):
+        return model.S1, model.S2, model.n
     Q = HSDEMatrixQ(model.A, model.b, model.c, space=model.space)           # :17
     l = Q.shape[0]
     if direct:
@@ -1270,3 +1273,133 @@ def solve(model, alg, out=None):
     sol.status_obj = status
     sol.z = guess
     return sol
+
+
+# ----------------------------------------------------------------------------------------
+# Feasibility form      src/problemforms/Feasibility/Feasibility.jl, FeasibilityStatus.jl
+# (SURVEY 8(f) rank 4).  The two sets are ProximalOperators objects in the reference; restated here: the two its own test uses
+# (test/testfeasibility.jl:9-10), IndAffine(A, b) and IndBox(lo, hi).  Their projections are unique, so "what the package computes"
+# is pinned by the definition: x - A'(A A')^-1 (A x - b) and clamp(x, lo, hi).
+# ----------------------------------------------------------------------------------------
+class IndAffine:
+    """ProximalOperators.IndAffine(A, b): indicator of {x : A x = b}, A with full row rank (dense: QR in the package)."""
+
+    def __init__(self, A, b):
+        import scipy.linalg
+        self.A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
+        self.b = np.asarray(b, dtype=np.float64).copy()
+        assert self.A.ndim == 2 and self.A.shape[0] == self.b.shape[0]
+        self.chol = scipy.linalg.cho_factor(self.A @ self.A.T)
+
+    def prox(self, y, x):
+        import scipy.linalg
+        y[:] = x - self.A.T @ scipy.linalg.cho_solve(self.chol, self.A @ x - self.b)
+        return 0.0
+
+
+class IndBox:
+    """ProximalOperators.IndBox(lo, hi): indicator of {x : lo <= x <= hi} (scalars or vectors; +-inf allowed)."""
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi = lo, hi
+
+    def prox(self, y, x):
+        y[:] = np.minimum(np.maximum(x, self.lo), self.hi)
+        return 0.0
+
+
+class Feasibility:
+    """struct Feasibility   Feasibility.jl:2-6."""
+
+    def __init__(self, S1, S2, n):
+        self.S1, self.S2, self.n = S1, S2, int(n)
+
+
+class FeasibilitySolution:
+    """FeasibilitySolution   Feasibility.jl:8-11."""
+
+    def __init__(self, x, status):
+        self.x, self.status = x, status
+
+
+class FeasibilityModel:
+    """FeasibilityModel   Feasibility.jl:15-50 (the fields the path reads)."""
+
+    def __init__(self, problem, alg, **kwargs):
+        self.S1, self.S2, self.n = problem.S1, problem.S2, problem.n
+        self.alg = alg
+        self.options = dict(alg.options)
+        self.options.update(kwargs)                           # kwargs of solve! override the algorithm's   :37-41
+        self.solve_stat = "NotSolved"
+        self.history = {}
+        alg.init(self)                                        # init_algorithm!   :46
+
+
+class FeasibilityStatus:
+    """FeasibilityStatus + checkstatus   FeasibilityStatus.jl:1-72."""
+
+    def __init__(self, model, checki, eps, verbose, debug, out=None):
+        self.n, self.i, self.model = model.n, 0, model
+        self.prev = np.full(model.n, np.nan)                  # Feasibility.jl:78  fill(NaN, n)
+        self.status = "Continue"
+        self.checki, self.eps, self.verbose, self.debug = checki, eps, verbose, debug
+        self.checked = False
+        self.direct = True                                    # Feasibility.jl:74
+        self.out = out
+        self.err = float("nan")
+
+    def _println(self, s):
+        if self.out is not None:
+            self.out.append(s)
+        else:
+            print(s)
+
+    def printstatusheader(self):                              # :74-84
+        if self.verbose > 0:
+            self._println("Time to initialize: s")
+            width = 22 + (0 if self.direct else 5)
+            self._println("-" * width)
+            self._println(" Iter | res" + ("" if self.direct else " | cg ") + " | time")
+            self._println("-" * width)
+
+    def checkstatus(self, z, override=False):                 # :32-72
+        if self.i % self.checki == 0 or override:
+            err = float(np.linalg.norm(self.prev - z))        # :40
+            self.err = err
+            if self.debug > 0:                                # savedata :95-103
+                self.model.history.setdefault("err", []).append((self.i, err))
+            if self.verbose > 0:
+                self._println("%6d|%s" % (self.i, _jl_e(err)))
+            status = "Continue"
+            if err <= self.eps:                               # :57 (NaN <= eps is false: the first check can never stop the solve)
+                if self.verbose > 0:
+                    self._println("Found solution i=%d" % self.i)
+                status = "Optimal"
+            self.status = status
+            self.checked = True
+            self.prev[:] = z
+            return True
+        self.checked = False
+        self.prev[:] = z                                      # :69 (every call)
+        return False
+
+
+def feasibility_solve(problem, alg, out=None, **kwargs):
+    """solve!(problem::Feasibility, alg; kwargs...)   Feasibility.jl:52-56 -> (solution, model); the loop is solve!(model) of
+    solverwrapper.jl:2-17 with getinitialvalue = zeros(n) (Feasibility.jl:58) and populate_solution of :61-68."""
+    model = FeasibilityModel(problem, alg, **kwargs)
+    opts = model.options
+    max_iters = opts.get("max_iters", 10000)
+    verbose = opts.get("verbose", 1)
+    debug = opts.get("debug", 1)
+    eps = opts.get("eps", 1e-5)
+    checki = opts.get("checki", 100)
+    x = np.zeros(model.n)
+    status = FeasibilityStatus(model, checki, eps, verbose, debug, out=out)
+    guess = iterate(alg, status, x, max_iters)
+    endstatus = "Indeterminate" if status.status == "Continue" else status.status
+    model.solve_stat = endstatus
+    sol = FeasibilitySolution(np.array(guess, copy=True), endstatus)
+    sol.iterations = status.i
+    sol.err = status.err
+    return sol, model

@@ -1,0 +1,21 @@
+"""Seeded instances of the reference's Feasibility test (test/testfeasibility.jl:4-12: IndAffine(A, b) n IndBox(0, Inf) with
+b = A xsol; the reference's literal data is bound to Julia's RNG, so the shape is kept and the numbers are numpy's)."""
+import numpy as np
+
+
+def affine_box_instance(seed=2, m=50, n=100, boundary=True):
+    rng = np.random.default_rng(seed)
+    xs = rng.standard_normal(n)
+    xs = np.maximum(xs, 0.0) if boundary else np.abs(xs)       # a point of the intersection (on its boundary / inside)
+    A = rng.standard_normal((m, n))
+    return A, A @ xs
+
+
+ALGS = {
+    "DR": lambda M, **kw: M.DR(**kw),
+    "AP": lambda M, **kw: M.AP(**kw),
+    "GAP": lambda M, **kw: M.GAP(0.8, 1.5, 1.6, **kw),
+    "GAPA": lambda M, **kw: M.GAPA(0.9, 0.3, **kw),
+    "FISTA": lambda M, **kw: M.FISTA(**kw),
+    "Dykstra": lambda M, **kw: M.Dykstra(**kw),
+}

@@ -1,0 +1,120 @@
+"""
+GPU: the Feasibility form on the device (fos_feas_* through the Python mirror; src/problemforms/Feasibility/*.jl) against the
+oracle's restatement: the two set projections, the first iterations of every algorithm, whole solves (status, iteration count,
+solution), the assertions of the reference's own test (test/testfeasibility.jl), the printed table, and the error paths.
+"""
+import numpy as np
+import pytest
+
+from feasibility_cases import ALGS, affine_box_instance
+
+pytestmark = pytest.mark.gpu
+
+
+def _problems(pkg, orc, **kw):
+    A, b = affine_box_instance(**kw)
+    n = A.shape[1]
+    return A, b, pkg.Feasibility(pkg.IndAffine(A, b), pkg.IndBox(0.0, np.inf), n), orc.Feasibility(orc.IndAffine(A, b), orc.IndBox(0.0, np.inf), n)
+
+
+@pytest.mark.parametrize("m,n", [(50, 100), (80, 100), (3, 7), (120, 257)])
+def test_set_projections_match_oracle(pkg, oracle, m, n):
+    orc = oracle
+    A, b, hp, op = _problems(pkg, orc, seed=m + n, m=m, n=n)
+    d = pkg.HipFeasibility(hp)
+    info = d.info()
+    assert info["ns_iters"][0] > 0 and info["ns_resid"][0] <= 1e-10 and info["ns_iters"][1] == 0
+    rng = np.random.default_rng(1)
+    for scale in (1.0, 1e3):
+        x = scale * rng.standard_normal(n)
+        y = np.empty(n)
+        op.S1.prox(y, x)
+        yd = d.prox(1, x)
+        assert np.abs(yd - y).max() <= 1e-11 * max(1.0, np.abs(x).max())
+        assert np.abs(A @ yd - b).max() <= 1e-10 * max(1.0, np.abs(x).max())
+        op.S2.prox(y, x)
+        assert np.array_equal(d.prox(2, x), y)                 # elementwise: bit exact
+    # a two-sided box
+    d2 = pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(-0.5, 0.25), pkg.IndBox(-np.inf, 1.0), n))
+    x = rng.standard_normal(n)
+    assert np.array_equal(d2.prox(1, x), np.clip(x, -0.5, 0.25)) and np.array_equal(d2.prox(2, x), np.minimum(x, 1.0))
+
+
+@pytest.mark.parametrize("algname", sorted(ALGS))
+def test_first_iterations_match_oracle(pkg, oracle, algname):
+    orc = oracle
+    A, b, hp, op = _problems(pkg, orc, m=80, n=100)
+    oalg = ALGS[algname](orc, verbose=0)
+    omodel = orc.FeasibilityModel(op, oalg)
+    ost = orc.FeasibilityStatus(omodel, 4, 1e-30, 0, 1)
+    d = pkg.HipFeasibility(hp)
+    d.set_alg(ALGS[algname](pkg))
+    d.set_iterate(None)
+    xo = np.zeros(op.n)
+    for i in range(1, 41):
+        ost.i = i
+        oalg.step(xo, i, ost)
+        done, status, err, checked = d.step(i, 1, 4, 1e-30)
+        assert done == 1 and status == "Continue" and checked == (i % 4 == 0)
+        z = d.get_iterate()
+        assert np.abs(z - xo).max() <= 1e-11 * max(1.0, np.abs(xo).max()), (algname, i)
+        if checked and i > 4:
+            assert err == pytest.approx(ost.err, rel=1e-6, abs=1e-13)
+        if checked and i == 4:
+            assert np.isfinite(err) == np.isfinite(ost.err)    # prev refreshed at every iteration: only i = 1 would see the NaN start
+    if algname == "GAPA":
+        assert d.info()["alpha12"] == pytest.approx(oalg.alpha12, rel=1e-9)
+    g, _, _ = d.getsol()
+    assert np.abs(g - oalg.getsol(xo)).max() <= 1e-11 * max(1.0, np.abs(xo).max())
+
+
+@pytest.mark.parametrize("algname,kw", [("DR", dict(checki=10)), ("AP", dict(checki=1)), ("GAP", {}), ("GAPA", {}), ("FISTA", {}), ("Dykstra", {})])
+def test_whole_solves_match_oracle(pkg, oracle, algname, kw):
+    """test/testfeasibility.jl:15-44 on the seeded instance: status and iteration count of the oracle, the same point, and the
+    reference's own assertions wherever the oracle ends :Optimal."""
+    orc = oracle
+    A, b, hp, op = _problems(pkg, orc)
+    osol, _ = orc.feasibility_solve(op, ALGS[algname](orc, eps=1e-8, verbose=0), **kw)
+    sol, model = pkg.solve_feasibility(hp, ALGS[algname](pkg, eps=1e-8, verbose=0), **kw)
+    assert sol.status == osol.status == model.solve_stat
+    assert abs(sol.iterations - osol.iterations) <= max(kw.get("checki", 100), osol.iterations // 20)     # err crosses eps at a slightly different check
+    assert np.abs(sol.x - osol.x).max() <= 1e-6
+    if sol.status == "Optimal":
+        assert sol.x.min() > -1e-12 or algname in ("AP", "FISTA", "Dykstra")
+        assert np.abs(A @ sol.x - b).max() < (1e-12 if algname == "DR" else 1e-6)
+    assert model.history["err"][-1][0] == sol.iterations
+
+
+def test_max_iters_forced_check_and_table(pkg, oracle):
+    orc = oracle
+    A, b, hp, op = _problems(pkg, orc)
+    lines = []
+    sol, model = pkg.solve_feasibility(hp, pkg.AP(eps=1e-14), out=lines, max_iters=7, checki=5)
+    osol, omodel = orc.feasibility_solve(op, orc.AP(eps=1e-14, verbose=0), max_iters=7, checki=5)
+    assert sol.status == "Indeterminate" and sol.iterations == 7
+    assert [i for i, _ in model.history["err"]] == [5, 7]
+    for (i1, e1), (i2, e2) in zip(model.history["err"], omodel.history["err"]):
+        assert i1 == i2 and e1 == pytest.approx(e2, rel=1e-8)
+    assert lines[0].startswith("Time to initialize: ") and lines[1] == "-" * 22 and lines[2] == " Iter | res | time" and lines[3] == "-" * 22
+    assert lines[4].startswith("     5|") and lines[4].endswith("s")
+    # initx (solverwrapper.jl:12-16) and a second solve on the same model: a fresh init_algorithm! state
+    x0 = np.full(hp.n, 0.5)
+    sol2, _ = pkg.solve_feasibility(hp, pkg.DR(eps=1e-8, verbose=0), checki=10, initx=x0)
+    assert sol2.status == "Optimal" and np.abs(A @ sol2.x - b).max() < 1e-12
+
+
+def test_error_paths(pkg):
+    A, b = affine_box_instance()
+    n = A.shape[1]
+    with pytest.raises(pkg.lib.FosError):                      # host callbacks cannot be sets of the device path
+        pkg.HipFeasibility(pkg.Feasibility(object(), pkg.IndBox(0.0, 1.0), n))
+    with pytest.raises(pkg.lib.FosError):                      # rank-deficient A: A A' is singular
+        A2 = np.vstack([A[:5], A[:5]])
+        pkg.HipFeasibility(pkg.Feasibility(pkg.IndAffine(A2, np.ones(10)), pkg.IndBox(0.0, 1.0), n))
+    with pytest.raises(pkg.lib.FosError):                      # the dense projector is bounded
+        pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(0.0, 1.0), pkg.IndBox(0.0, 1.0), 50000))
+    with pytest.raises(pkg.lib.FosError):
+        pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(1.0, 0.0), pkg.IndBox(0.0, 1.0), n))
+    d = pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(0.0, 1.0), pkg.IndBox(0.0, 1.0), n))
+    with pytest.raises(pkg.lib.FosError):
+        d.set_alg(pkg.LineSearchWrapper(pkg.GAP()))

@@ -1,6 +1,6 @@
 """Static cross-check of the Julia `ccall` shim (firstordersolvers.jl_amd/julia/FOSHip.jl) against include/foship.h: there is no
 Julia in the build image, so the shim has never run -- this test at least keeps every ccall's symbol, return type, argument
-types and argument count in step with the header (which grew from 40 to 57 entries over the rounds), and the CheckResult
+types and argument count in step with the header (which grew from 40 to 68 entries over the rounds), and the CheckResult
 struct in step with fos_check_result."""
 import re
 from pathlib import Path
@@ -13,6 +13,7 @@ HDR = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "foship.h").read_text(), flag
 C2JL = {
     "int": {"Cint"}, "int32_t": {"Int32", "Cint"}, "int64_t": {"Int64"}, "double": {"Cdouble", "Float64"},
     "fos_handle": {"Ptr{Cvoid}"}, "fos_handle*": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
+    "fos_feas_handle": {"Ptr{Cvoid}"}, "fos_feas_handle*": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
     "int*": {"Ref{Cint}", "Ptr{Cint}"}, "int32_t*": {"Ref{Int32}", "Ptr{Int32}", "Ref{Cint}", "Ptr{Cint}"},
     "int64_t*": {"Ref{Int64}", "Ptr{Int64}"}, "double*": {"Ref{Cdouble}", "Ptr{Cdouble}", "Ptr{Float64}"},
     "void*": {"Ptr{Cvoid}"}, "char*": {"Ptr{UInt8}", "Cstring"},
@@ -86,7 +87,9 @@ def test_every_ccall_matches_the_header():
             assert len(args) == len(types), "%s: %d values passed for %d declared types" % (name, len(args), len(types))
     # the calls the drop-in path cannot work without
     used = {c[0] for c in calls}
-    for need in ("fos_create", "fos_destroy", "fos_set_alg", "fos_set_iterate", "fos_step", "fos_getsol", "fos_last_error"):
+    for need in ("fos_create", "fos_destroy", "fos_set_alg", "fos_set_iterate", "fos_step", "fos_getsol", "fos_last_error",
+                 "fos_feas_create", "fos_feas_destroy", "fos_feas_set_affine", "fos_feas_set_box", "fos_feas_set_alg", "fos_feas_set_iterate",
+                 "fos_feas_step", "fos_feas_getsol"):
         assert need in used, need
 
 
