@@ -248,7 +248,6 @@ extern "C" {
 
 int fos_feas_create(int64_t n, int32_t device, fos_feas_handle* out) {
     if (!out || n < 1) { set_error("fos_feas_create: n >= 1 and a handle pointer are required"); return FOS_EINVAL; }
-    if (n > 46000) { set_error("feasibility form: the dense affine projector holds %lld x %lld doubles: supported up to n = 46000", (long long)n, (long long)n); return FOS_EUNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device is visible: the HIP path has no CPU fallback"); return FOS_ENODEVICE; }
     if (device < 0 || device >= ndev) { set_error("device %d out of range (0..%d)", device, ndev - 1); return FOS_EINVAL; }
@@ -282,6 +281,7 @@ int fos_feas_destroy(fos_feas_handle h) {
 //   P = A' X A,  q = A' X b.
 int fos_feas_set_affine(fos_feas_handle h, int32_t which, int64_t m, const double* A, const double* b) {
     if (!h || !A || !b || which < 1 || which > 2 || m < 1 || m > h->n) { set_error("fos_feas_set_affine: bad argument (1 <= m <= n, which = 1 | 2)"); return FOS_EINVAL; }
+    if (h->n > 46000) { set_error("IndAffine: the dense projector holds %lld x %lld doubles: supported up to n = 46000", (long long)h->n, (long long)h->n); return FOS_EUNSUPPORTED; }
     FOS_HIP(hipSetDevice(h->device));
     const int64_t n = h->n, L = h->L;
     const size_t L2 = (size_t)L * (size_t)L;

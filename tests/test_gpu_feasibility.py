@@ -111,8 +111,13 @@ def test_error_paths(pkg):
     with pytest.raises(pkg.lib.FosError):                      # rank-deficient A: A A' is singular
         A2 = np.vstack([A[:5], A[:5]])
         pkg.HipFeasibility(pkg.Feasibility(pkg.IndAffine(A2, np.ones(10)), pkg.IndBox(0.0, 1.0), n))
-    with pytest.raises(pkg.lib.FosError):                      # the dense projector is bounded
-        pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(0.0, 1.0), pkg.IndBox(0.0, 1.0), 50000))
+    with pytest.raises(pkg.lib.FosError):                      # the dense projector is bounded (two boxes of that length are fine)
+        pkg.HipFeasibility(pkg.Feasibility(pkg.IndAffine(np.ones((1, 50000)), np.ones(1)), pkg.IndBox(0.0, 1.0), 50000))
+    big = pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(0.0, 1.0), pkg.IndBox(0.5, 2.0), 3_000_001))
+    big.set_alg(pkg.AP())
+    big.set_iterate(np.full(3_000_001, -1.0))
+    done, status, err, checked = big.step(1, 3, 1, 1e-12)
+    assert status == "Optimal" and done == 2 and err == 0.0 and np.array_equal(big.get_iterate(), np.full(3_000_001, 0.5))
     with pytest.raises(pkg.lib.FosError):
         pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(1.0, 0.0), pkg.IndBox(0.0, 1.0), n))
     d = pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(0.0, 1.0), pkg.IndBox(0.0, 1.0), n))
