@@ -103,6 +103,16 @@ __global__ void feas_alpha12_kernel(const double* __restrict__ partials, int npa
 __global__ __launch_bounds__(FEAS_THREADS) void feas_combine_kernel(int64_t n, double* __restrict__ x, const double* __restrict__ t2, double alpha) {
     FEAS_STRIDE(i, n) x[i] = alpha * t2[i] + (1.0 - alpha) * x[i];
 }
+// set-up: the row-major m x n matrix A as a column-major L x L array (rows 0..m-1, zero padded) and its transpose
+__global__ __launch_bounds__(FEAS_THREADS) void feas_spread_kernel(int64_t m, int64_t n, int64_t L, const double* __restrict__ A,
+                                                                   double* __restrict__ Ah, double* __restrict__ At) {
+    FEAS_STRIDE(e, m * n) {
+        const int64_t i = e / n, j = e % n;
+        const double v = A[e];
+        Ah[i + j * L] = v;
+        At[j + i * L] = v;
+    }
+}
 // set-up: E[i + i L] = 1 for i >= m (the padding of G = A A' + E keeps it positive definite)
 __global__ __launch_bounds__(FEAS_THREADS) void feas_pad_identity_kernel(int64_t L, int64_t m, double* __restrict__ E) {
     FEAS_STRIDE(i, L) if (i >= m) E[i + i * L] = 1.0;
@@ -285,28 +295,28 @@ int fos_feas_set_affine(fos_feas_handle h, int32_t which, int64_t m, const doubl
     FOS_HIP(hipSetDevice(h->device));
     const int64_t n = h->n, L = h->L;
     const size_t L2 = (size_t)L * (size_t)L;
-    std::vector<double> Ah(L2, 0.0), At(L2, 0.0), bp((size_t)L, 0.0);
+    std::vector<double> bp((size_t)L, 0.0);
     double fro2 = 0.0;
-    for (int64_t i = 0; i < m; ++i)
-        for (int64_t j = 0; j < n; ++j) {
-            const double v = A[i * n + j];
-            if (!(v == v) || std::fabs(v) > 1e300) { set_error("IndAffine: A has non-finite entries"); return FOS_EINVAL; }
-            Ah[(size_t)i + (size_t)j * L] = v;                   // column-major L x L, rows 0..m-1
-            At[(size_t)j + (size_t)i * L] = v;                   // its transpose
-            fro2 += v * v;
-        }
+    for (int64_t e = 0; e < m * n; ++e) {
+        const double v = A[e];
+        if (!(v == v) || std::fabs(v) > 1e300) { set_error("IndAffine: A has non-finite entries"); return FOS_EINVAL; }
+        fro2 += v * v;
+    }
     for (int64_t i = 0; i < m; ++i) bp[(size_t)i] = b[i];
     if (!(fro2 > 0.0)) { set_error("IndAffine: A is zero"); return FOS_EINVAL; }
-    double *dA = nullptr, *dAt = nullptr, *G = nullptr, *B0 = nullptr, *B1 = nullptr, *B2 = nullptr, *db = nullptr, *dt = nullptr;
-    auto cleanup = [&]() { for (double* q : {dA, dAt, G, B0, B1, B2, db, dt}) (void)hipFree(q); };
+    double *dA = nullptr, *dAt = nullptr, *G = nullptr, *B0 = nullptr, *B1 = nullptr, *B2 = nullptr, *db = nullptr, *dt = nullptr, *draw = nullptr;
+    auto cleanup = [&]() { for (double* q : {dA, dAt, G, B0, B1, B2, db, dt, draw}) (void)hipFree(q); };
     hipError_t e = hipSuccess;
     for (double** q : {&dA, &dAt, &G, &B0, &B1, &B2}) if (e == hipSuccess) e = hipMalloc((void**)q, sizeof(double) * L2);
     for (double** q : {&db, &dt}) if (e == hipSuccess) e = hipMalloc((void**)q, sizeof(double) * (size_t)L);
+    if (e == hipSuccess) e = hipMalloc((void**)&draw, sizeof(double) * (size_t)(m * n));
     if (e != hipSuccess) { cleanup(); set_error("IndAffine set-up: hipMalloc of six %lld x %lld buffers failed: %s", (long long)L, (long long)L, hipGetErrorString(e)); return FOS_ENOMEM; }
     auto fail = [&](int code) { cleanup(); return code; };
 #define FEAS_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("IndAffine set-up: %s -> %s", #expr, hipGetErrorString(_e)); return fail(FOS_EHIP); } } while (0)
-    FEAS_HIP(hipMemcpyAsync(dA, Ah.data(), sizeof(double) * L2, hipMemcpyHostToDevice, h->stream));
-    FEAS_HIP(hipMemcpyAsync(dAt, At.data(), sizeof(double) * L2, hipMemcpyHostToDevice, h->stream));
+    FEAS_HIP(hipMemcpyAsync(draw, A, sizeof(double) * (size_t)(m * n), hipMemcpyHostToDevice, h->stream));
+    FEAS_HIP(hipMemsetAsync(dA, 0, sizeof(double) * L2, h->stream));
+    FEAS_HIP(hipMemsetAsync(dAt, 0, sizeof(double) * L2, h->stream));
+    hipLaunchKernelGGL(feas_spread_kernel, dim3(1024), dim3(FEAS_THREADS), 0, h->stream, m, n, L, (const double*)draw, dA, dAt);
     FEAS_HIP(hipMemcpyAsync(db, bp.data(), sizeof(double) * (size_t)L, hipMemcpyHostToDevice, h->stream));
     FEAS_HIP(hipMemsetAsync(B0, 0, sizeof(double) * L2, h->stream));
     FEAS_HIP(hipMemsetAsync(B1, 0, sizeof(double) * L2, h->stream));
