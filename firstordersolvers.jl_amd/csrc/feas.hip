@@ -55,6 +55,12 @@ __global__ __launch_bounds__(FEAS_THREADS) void feas_extrap_kernel(int64_t n, do
     FEAS_STRIDE(i, n) y[i] = x[i] + coef * (x[i] - xold[i]);
 }
 
+// out = base + a dir      linesearch.jl:58,70
+__global__ __launch_bounds__(FEAS_THREADS) void feas_axpy_kernel(int64_t n, double* __restrict__ out, const double* __restrict__ base, double a,
+                                                                 const double* __restrict__ dir) {
+    FEAS_STRIDE(i, n) out[i] = base[i] + a * dir[i];
+}
+
 template <int NACC>
 __device__ __forceinline__ void feas_block_store(const double (&acc)[NACC], double* __restrict__ partials) {
     __shared__ double sm[4 * NACC];
@@ -147,6 +153,8 @@ struct fos_feas {
     int status = FOS_STATUS_CONTINUE;
     int checked = 0;
     double err = NAN;
+    int64_t ls_interval = 0;        // LineSearchWrapper (wrappers/linesearch.jl): every ls_interval-th iteration is a step-length search
+    double ls_log[34] = {0};        // normres, 31 test residuals, alpha_best, iteration (the layout of fos_linesearch_log)
     std::vector<void*> owned;
 };
 
@@ -206,8 +214,52 @@ int feas_check(fos_feas* h, const double* z, int64_t i, int64_t checki, double e
     return FOS_OK;
 }
 
+int feas_norm_of_diff(fos_feas* h, const double* a, const double* b, double* out) {
+    FEAS_K(feas_normdiff_kernel, h->n, a, b, h->partials);
+    std::vector<double> part((size_t)h->grid);
+    FOS_HIP(hipMemcpyAsync(part.data(), h->partials, sizeof(double) * h->grid, hipMemcpyDeviceToHost, h->stream));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    double s = 0.0;
+    for (double v : part) s += v;
+    *out = std::sqrt(s);
+    return FOS_OK;
+}
+
+// LineSearchWrapper(GAP / GAPA), one search iteration      wrappers/linesearch.jl:36-75
+// scratch: y = tmp1 (the iterate the search starts from), xold = res, p = tmp3 -- unused by these two algorithms
+int feas_linesearch_iteration(fos_feas* h, int64_t i, int64_t checki, double eps) {
+    const int64_t n = h->n;
+    const double* a12 = h->alg == FOS_ALG_GAPA ? h->a12 : nullptr;
+    FEAS_K(feas_copy_kernel, n, h->y, (const double*)h->x);                             // tmp1 .= x                 :41
+    FOS_TRY(feas_prox(h, 0, h->t1, h->x));                                             // S1!(tmp2, x)              :45
+    FEAS_K(feas_relax_kernel, n, h->t1, (const double*)h->x, h->alpha1, a12);
+    FOS_TRY(feas_prox(h, 1, h->x, h->t1));                                             // S2!(x, tmp2, status)      :46
+    FOS_TRY(feas_check(h, h->x, i, checki, eps, false));
+    FEAS_K(feas_relax_kernel, n, h->x, (const double*)h->t1, h->alpha2, a12);
+    FEAS_K(feas_sub_kernel, n, h->xold, (const double*)h->x, (const double*)h->y);     // res .= x .- tmp1          :49
+    FOS_TRY(feas_norm_of_diff(h, h->x, h->y, &h->ls_log[0]));                          // normres = norm(res)       :50
+    double best = INFINITY, abest = 1.0, a = 0.1;                                      // :53-55
+    for (int k = 0; k <= 30; ++k) {                                                    // :56
+        a = a * 1.8;                                                                   // :57
+        FEAS_K(feas_axpy_kernel, n, h->x, (const double*)h->y, a, (const double*)h->xold);      // x .= tmp1 .+ a.*res   :58
+        FOS_TRY(feas_prox(h, 0, h->t1, h->x));                                         // S1!(tmp2, x, nostatus)    :60
+        FEAS_K(feas_relax_kernel, n, h->t1, (const double*)h->x, h->alpha1, a12);
+        FOS_TRY(feas_prox(h, 1, h->p, h->t1));                                         // S2!(tmp3, tmp2, nostatus) :61
+        FEAS_K(feas_relax_kernel, n, h->p, (const double*)h->t1, h->alpha2, a12);
+        double tr = 0.0;
+        FOS_TRY(feas_norm_of_diff(h, h->x, h->p, &tr));                                // testres = normdiff(x, tmp3) :62
+        h->ls_log[1 + k] = tr;
+        if (tr < best) { best = tr; abest = a; }                                       // :64-67
+    }
+    FEAS_K(feas_axpy_kernel, n, h->x, (const double*)h->y, abest, (const double*)h->xold);      // x .= tmp1 .+ abest.*res :70
+    h->ls_log[32] = abest;
+    h->ls_log[33] = (double)i;
+    return FOS_OK;
+}
+
 int feas_step_once(fos_feas* h, int64_t i, int64_t checki, double eps) {
     const int64_t n = h->n;
+    if (h->ls_interval > 0 && i % h->ls_interval == 0) return feas_linesearch_iteration(h, i, checki, eps);      // linesearch.jl:39
     switch (h->alg) {
     case FOS_ALG_GAP:
     case FOS_ALG_GAPA: {
@@ -373,6 +425,23 @@ int fos_feas_set_box(fos_feas_handle h, int32_t which, double lo, double hi) {
 int fos_feas_set_alg(fos_feas_handle h, int32_t alg, double alpha, double alpha1, double alpha2, double beta) {
     if (!h || alg < FOS_ALG_GAP || alg > FOS_ALG_DYKSTRA) { set_error("fos_feas_set_alg: unknown algorithm"); return FOS_EINVAL; }
     h->alg = alg; h->alpha = alpha; h->alpha1 = alpha1; h->alpha2 = alpha2; h->beta = beta;
+    if (alg == FOS_ALG_GAPA) h->alpha1 = h->alpha2 = 2.0;              // (unused: GAPA relaxes with the device scalar alpha12)
+    h->ls_interval = 0;                                                // a fresh algorithm is unwrapped (fos_feas_set_linesearch follows)
+    return FOS_OK;
+}
+
+int fos_feas_set_linesearch(fos_feas_handle h, int64_t lsinterval) {
+    if (!h || lsinterval < 0) { set_error("bad argument"); return FOS_EINVAL; }
+    if (lsinterval > 0 && h->alg != FOS_ALG_GAP && h->alg != FOS_ALG_GAPA) {
+        set_error("this algorithm does not support line search (support_linesearch: GAP and GAPA only, solvers/defaults.jl:22)");
+        return FOS_EUNSUPPORTED;
+    }
+    h->ls_interval = lsinterval;
+    return FOS_OK;
+}
+int fos_feas_linesearch_log(fos_feas_handle h, double* out34) {
+    if (!h || !out34) { set_error("NULL argument"); return FOS_EINVAL; }
+    memcpy(out34, h->ls_log, sizeof(h->ls_log));
     return FOS_OK;
 }
 

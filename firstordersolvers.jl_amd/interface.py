@@ -735,9 +735,15 @@ class HipFeasibility:
             pass
 
     def set_alg(self, alg: FOSAlgorithm):
-        if isinstance(alg, LineSearchWrapper):
-            raise _lib.FosError(-4, "LineSearchWrapper is not available on the Feasibility form of the device path")
         _lib.check(self._lib.fos_feas_set_alg(self._h, *alg._alg_args()))
+        if isinstance(alg, LineSearchWrapper):                          # the wrapped algorithm's arguments, then the search
+            _lib.check(self._lib.fos_feas_set_linesearch(self._h, alg.lsinterval))
+
+    def linesearch_log(self):
+        """(iteration, ||res||, [31 test residuals], alpha_best) of the last search."""
+        out = np.zeros(34)
+        _lib.check(self._lib.fos_feas_linesearch_log(self._h, _lib.dptr(out)))
+        return int(out[33]), float(out[0]), out[1:32].copy(), float(out[32])
 
     def set_iterate(self, x0=None):
         if x0 is None:
@@ -815,10 +821,21 @@ class FeasibilityModel:
             self._println(" Iter | res | time")
             self._println("-" * 22)
         i, status, checked, err = 0, "Continue", False, float("nan")
+        ls = self.alg.lsinterval if isinstance(self.alg, LineSearchWrapper) else 0
         while i < max_iters and status == "Continue":
             nxt = min(max_iters, (i // checki + 1) * checki) if checki > 0 else max_iters
+            if ls > 0:
+                nxt = min(nxt, (i // ls + 1) * ls)                     # stop at every line-search iteration: its output is printed
             done, status, err, checked = dev.step(i + 1, nxt - i, checki, eps)
             i += done
+            if ls > 0 and i % ls == 0:                                 # what linesearch.jl:51,63,69 print
+                _, normres, tests, abest = dev.linesearch_log()
+                self._println("test, %s" % julia_float(normres))
+                a = 0.1
+                for tr in tests:
+                    a = a * 1.8
+                    self._println("\u03b1: %s, %s" % (julia_float(a), julia_float(tr)))
+                self._println("\u03b1: %s" % julia_float(abest))
             if checked:
                 t = time.perf_counter_ns() - t0
                 if debug > 0:                                          # savedata :95-103

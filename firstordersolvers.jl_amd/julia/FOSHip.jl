@@ -254,10 +254,11 @@ import ..FirstOrderSolvers: FeasibilityModel, FeasibilityStatus
 
 mutable struct HipFeasData <: FOSSolverData
     handle::Ptr{Cvoid}
+    lsinterval::Int64                     # > 0: LineSearchWrapper around the algorithm
     function HipFeasData(model::FeasibilityModel, device::Integer)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:fos_feas_create, libfoship), Cint, (Int64, Int32, Ref{Ptr{Cvoid}}), Int64(model.n), Int32(device), h))
-        d = new(h[])
+        d = new(h[], 0)
         finalizer(x -> ccall((:fos_feas_destroy, libfoship), Cint, (Ptr{Cvoid},), x.handle), d)
         for (which, S) in ((Int32(1), model.S1), (Int32(2), model.S2))
             if S isa ProximalOperators.IndBox
@@ -289,6 +290,29 @@ for T in (:GAP, :GAPA, :FISTA, :Dykstra)
     end
 end
 
+# LineSearchWrapper(GAP / GAPA) on the Feasibility form (test/testfeasibility.jl:36-44): the wrapped algorithm's handle with the
+# search switched on; what linesearch.jl prints during a search comes from fos_feas_linesearch_log
+function init_algorithm!(ls::LineSearchWrapper, model::FeasibilityModel)
+    if get(model.options, :gpu, false) === true
+        data, status_generator = init_algorithm!(ls.alg, model)
+        check(ccall((:fos_feas_set_linesearch, libfoship), Cint, (Ptr{Cvoid}, Int64), data.handle, ls.lsinterval))
+        data.lsinterval = ls.lsinterval
+        return data, status_generator
+    end
+    return invoke(init_algorithm!, Tuple{LineSearchWrapper,FirstOrderSolvers.AbstractFOSModel}, ls, model)
+end
+function print_linesearch(data::HipFeasData)
+    log = Vector{Float64}(undef, 34)
+    check(ccall((:fos_feas_linesearch_log, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, log))
+    println("test, $(log[1])")
+    α = 0.1
+    for k = 0:30
+        α = α * 1.8
+        println("α: $α, $(log[2+k])")
+    end
+    println("α: $(log[33])")
+end
+
 function iterate(alg::FOSAlgorithm, data::HipFeasData, status::FeasibilityStatus, x, max_iters)
     t1 = time()
     printstatusheader(status)
@@ -305,11 +329,14 @@ function iterate(alg::FOSAlgorithm, data::HipFeasData, status::FeasibilityStatus
     end
     while i < max_iters
         count = min(max_iters - i, status.checki - (i % status.checki))
+        ls = data.lsinterval
+        ls > 0 && (count = min(count, ls - (i % ls)))
         check(ccall((:fos_feas_step, libfoship), Cint,
                     (Ptr{Cvoid}, Int64, Int64, Int64, Cdouble, Ref{Int64}, Ref{Int32}, Ref{Cdouble}, Ref{Int32}),
                     data.handle, i + 1, count, status.checki, status.eps, done, st, err, checked))
         i += done[]
         status.i = i
+        ls > 0 && i % ls == 0 && print_linesearch(data)
         if checked[] != 0
             report()
             status.status != :Continue && break

@@ -121,5 +121,44 @@ def test_error_paths(pkg):
     with pytest.raises(pkg.lib.FosError):
         pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(1.0, 0.0), pkg.IndBox(0.0, 1.0), n))
     d = pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(0.0, 1.0), pkg.IndBox(0.0, 1.0), n))
-    with pytest.raises(pkg.lib.FosError):
-        d.set_alg(pkg.LineSearchWrapper(pkg.GAP()))
+    d.set_alg(pkg.FISTA())
+    with pytest.raises(pkg.lib.FosError):                      # support_linesearch: GAP and GAPA only
+        d._lib.fos_feas_set_linesearch.restype = int
+        pkg.lib.check(d._lib.fos_feas_set_linesearch(d._h, 5))
+
+
+@pytest.mark.parametrize("algname", ["DR", "GAP", "GAPA"])
+def test_linesearch_wrapper_matches_oracle(pkg, oracle, algname):
+    """LineSearchWrapper(alg; lsinterval) on the Feasibility form (test/testfeasibility.jl:36-44 runs LineSearchWrapper(GAP)):
+    iterates through two searches, the 31 test residuals and the chosen step length against the oracle; then the whole solve."""
+    orc = oracle
+    A, b, hp, op = _problems(pkg, orc, m=80, n=100)
+    ls = 5
+    lines = []
+    owrap = orc.LineSearchWrapper(ALGS[algname](orc, verbose=0), lsinterval=ls, out=lines)
+    omodel = orc.FeasibilityModel(op, owrap)
+    ost = orc.FeasibilityStatus(omodel, 10 ** 9, 1e-30, 0, 1)
+    d = pkg.HipFeasibility(hp)
+    d.set_alg(pkg.LineSearchWrapper(ALGS[algname](pkg), lsinterval=ls))
+    d.set_iterate(None)
+    xo = np.zeros(op.n)
+    for i in range(1, 2 * ls + 3):
+        ost.i = i
+        owrap.step(xo, i, ost)
+        d.step(i, 1, 10 ** 9, 1e-30)
+        z = d.get_iterate()
+        assert np.abs(z - xo).max() <= 1e-10 * max(1.0, np.abs(xo).max()), (algname, i)
+        if i % ls == 0:
+            it, normres, tests, abest = d.linesearch_log()
+            oi, onormres, otests, oabest = owrap.log[-1]
+            assert it == oi == i and abest == oabest
+            assert normres == pytest.approx(onormres, rel=1e-9)
+            assert np.allclose(tests, otests, rtol=1e-7, atol=1e-12)
+    # whole solve: the reference's test expects :Optimal with |A x - b| < 1e-6
+    out = []
+    sol, model = pkg.solve_feasibility(hp, pkg.LineSearchWrapper(ALGS[algname](pkg, eps=1e-8), lsinterval=20), out=out, checki=10)
+    osol, _ = orc.feasibility_solve(op, orc.LineSearchWrapper(ALGS[algname](orc, eps=1e-8, verbose=0), lsinterval=20, out=[]), checki=10)
+    assert sol.status == osol.status == "Optimal"
+    assert abs(sol.iterations - osol.iterations) <= 10
+    assert sol.x.min() > -1e-9 and np.abs(A @ sol.x - b).max() < 1e-6
+    assert any(l.startswith("test, ") for l in out) and sum(l.startswith("\u03b1: ") for l in out) % 32 == 0
