@@ -10,5 +10,5 @@ from . import _lib as lib          # noqa: F401
 from . import workloads            # noqa: F401
 from .interface import (AP, DR, FISTA, GAP, GAPA, Dykstra, FOSAlgorithm, FOSMathProgModel, HipHSDE, HSDEStatus,  # noqa: F401
                         LineSearchWrapper, Solution, solve, HEADER_CG, HEADER_DIRECT,
-                        Feasibility, FeasibilityModel, FeasibilitySolution, HipFeasibility, IndAffine, IndBox, solve_feasibility)
+                        ConeProduct, Feasibility, FeasibilityModel, FeasibilitySolution, HipFeasibility, IndAffine, IndBox, solve_feasibility)
 from . import sharding             # noqa: F401

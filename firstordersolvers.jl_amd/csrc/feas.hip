@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "dev_common.hpp"
@@ -109,6 +110,13 @@ __global__ void feas_alpha12_kernel(const double* __restrict__ partials, int npa
 __global__ __launch_bounds__(FEAS_THREADS) void feas_combine_kernel(int64_t n, double* __restrict__ x, const double* __restrict__ t2, double alpha) {
     FEAS_STRIDE(i, n) x[i] = alpha * t2[i] + (1.0 - alpha) * x[i];
 }
+// plain vector <-> the two-part layout of the cone kernels (part 1 = the vector, part 2 = zeros: its dual projections are of zero)
+__global__ __launch_bounds__(FEAS_THREADS) void feas_to_parts_kernel(int64_t n, double2* __restrict__ z, const double* __restrict__ x) {
+    FEAS_STRIDE(i, n) z[i] = make_double2(x[i], 0.0);
+}
+__global__ __launch_bounds__(FEAS_THREADS) void feas_from_parts_kernel(int64_t n, double* __restrict__ y, const double2* __restrict__ z) {
+    FEAS_STRIDE(i, n) y[i] = z[i].x;
+}
 // set-up: the row-major m x n matrix A as a column-major L x L array (rows 0..m-1, zero padded) and its transpose
 __global__ __launch_bounds__(FEAS_THREADS) void feas_spread_kernel(int64_t m, int64_t n, int64_t L, const double* __restrict__ A,
                                                                    double* __restrict__ Ah, double* __restrict__ At) {
@@ -131,6 +139,14 @@ struct FeasSet {
     double lo = 0.0, hi = 0.0;
     int ns_iters = 0;               // Newton-Schulz steps of the set-up
     double ns_resid = 0.0;          // max |G X - I| it ended with
+    // kind 3: ConeProduct (cones.jl:31-94) on the batched cone kernels of the HSDE path
+    uint8_t* ew_op = nullptr;       // [n] elementwise op per index (EW_SKIP inside SOC / Exp / PSD cones)
+    ConeDesc *soc = nullptr, *expc = nullptr, *psd = nullptr;
+    int nsoc = 0, nexp = 0, npsd = 0, psd_kmin = 0, psd_kmax = 0;
+    double* psd_scratch = nullptr;
+    double* psd_V[2] = {nullptr, nullptr};
+    int psd_cur = 0, psd_have_prev = 0;
+    bool psd_attr_set = false;
 };
 
 }  // namespace fos
@@ -147,6 +163,8 @@ struct fos_feas {
     double fista_t = 1.0;
     // vectors of length L (zero padded)
     double *x = nullptr, *t1 = nullptr, *t2 = nullptr, *y = nullptr, *xold = nullptr, *p = nullptr, *q = nullptr, *prev = nullptr, *tmp = nullptr, *px = nullptr;
+    double2 *zin = nullptr, *zout = nullptr;      // [n] two-part scratch of the cone kernels (allocated with the first ConeProduct set)
+    int cus = 256;
     double* partials = nullptr;     // [3 x FEAS_PARTS]
     double* a12 = nullptr;          // device scalar alpha12 (GAPA)
     int grid = 1;
@@ -193,6 +211,18 @@ int feas_prox(fos_feas* h, int which, double* y, const double* x) {
         FEAS_K(feas_affine_finish_kernel, h->n, y, x, h->px, s.q);
     } else if (s.kind == 2) {
         FEAS_K(feas_box_kernel, h->n, y, x, s.lo, s.hi);
+    } else if (s.kind == 3) {                                             // prox!(y, ::ConeProduct, x)   cones.jl:89-94
+        FeasSet& ms = h->S[which];
+        LaunchCtx c = feas_ctx(h, h->n);
+        c.vec_blocks = h->grid; c.cus = h->cus; c.psd_attr_set = &ms.psd_attr_set;
+        FEAS_K(feas_to_parts_kernel, h->n, h->zin, x);
+        launch_cones_elementwise(c, h->zout, h->zin, s.ew_op);
+        launch_cones_soc(c, h->zout, h->zin, s.soc, s.nsoc);
+        launch_cones_exp(c, h->zout, h->zin, s.expc, s.nexp);
+        FOS_TRY(launch_cones_psd(c, h->zout, h->zin, s.psd, s.npsd, s.psd_kmin, s.psd_kmax, s.psd_scratch, s.psd_V[s.psd_cur], s.psd_V[1 - s.psd_cur],
+                                 s.psd_have_prev, nullptr, 0));
+        if (s.npsd > 0 && s.psd_V[0]) { ms.psd_cur = 1 - ms.psd_cur; ms.psd_have_prev = 1; }      // warm start of the next projection
+        FEAS_K(feas_from_parts_kernel, h->n, y, (const double2*)h->zout);
     } else { set_error("feasibility form: set %d has not been defined", which + 1); return FOS_EINVAL; }
     return FOS_OK;
 }
@@ -318,6 +348,7 @@ int fos_feas_create(int64_t n, int32_t device, fos_feas_handle* out) {
     h->device = device; h->n = n; h->L = (n + 63) / 64 * 64;
     h->grid = (int)std::min<int64_t>(FEAS_PARTS, (n + FEAS_THREADS - 1) / FEAS_THREADS);
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; set_error("hipStreamCreate failed"); return FOS_EHIP; }
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->cus = prop.multiProcessorCount; }
     int rc = FOS_OK;
     double** vecs[] = {&h->x, &h->t1, &h->t2, &h->y, &h->xold, &h->p, &h->q, &h->prev, &h->tmp, &h->px};
     for (double** v : vecs) { rc = feas_alloc(h, v, (size_t)h->L); if (rc != FOS_OK) break; }
@@ -422,6 +453,82 @@ int fos_feas_set_box(fos_feas_handle h, int32_t which, double lo, double hi) {
     return FOS_OK;
 }
 
+// ConeProduct (cones.jl:31-77): ncones cones in order, contiguous from index 1, together covering all n entries
+int fos_feas_set_cones(fos_feas_handle h, int32_t which, int64_t ncones, const int32_t* type, const int64_t* len) {
+    if (!h || which < 1 || which > 2 || ncones < 1 || !type || !len) { set_error("fos_feas_set_cones: bad argument"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    const int64_t n = h->n;
+    std::vector<uint8_t> ew((size_t)n, 0);
+    std::vector<ConeDesc> soc, psd, expc;
+    int64_t pos = 0;
+    for (int64_t i = 0; i < ncones; ++i) {
+        if (len[i] < 1 || pos + len[i] > n) { set_error("ConeProduct: cone %lld (length %lld) does not fit the %lld entries (cones.jl:66-72: contiguous, gap-free ranges)", (long long)i + 1, (long long)len[i], (long long)n); return FOS_EINVAL; }
+        uint8_t prim = 0;
+        bool ewise = true;
+        switch (type[i]) {
+            case FOS_CONE_FREE: prim = EW_COPY; break;
+            case FOS_CONE_ZERO: prim = EW_ZERO; break;
+            case FOS_CONE_NONNEG: prim = EW_MAX0; break;
+            case FOS_CONE_NONPOS: prim = EW_MIN0; break;
+            case FOS_CONE_SOC: case FOS_CONE_SOCROT: case FOS_CONE_SDP: case FOS_CONE_EXPPRIMAL: case FOS_CONE_EXPDUAL: ewise = false; break;
+            default: set_error("ConeProduct: unknown cone code %d", type[i]); return FOS_EINVAL;
+        }
+        if (ewise) { for (int64_t k = 0; k < len[i]; ++k) ew[(size_t)(pos + k)] = (uint8_t)(prim | (EW_COPY << 2)); }
+        else {
+            ConeDesc cd;
+            cd.start = pos; cd.len = (int32_t)len[i]; cd.type = type[i]; cd.dual_part = 1; cd.k = 0;      // part 1 (the vector): primal
+            if (type[i] == FOS_CONE_SDP) {
+                const int64_t k = (int64_t)std::floor((std::sqrt(8.0 * (double)len[i] + 1.0) - 1.0) / 2.0 + 0.5);
+                if (k * (k + 1) / 2 != len[i]) { set_error("ConeProduct cone %lld: SDP length %lld is not k(k+1)/2", (long long)i + 1, (long long)len[i]); return FOS_EINVAL; }
+                cd.k = (int32_t)k;
+                psd.push_back(cd);
+            } else if (type[i] == FOS_CONE_EXPPRIMAL || type[i] == FOS_CONE_EXPDUAL) {
+                if (len[i] != 3) { set_error("ConeProduct cone %lld: an exponential cone has exactly 3 entries (got %lld)", (long long)i + 1, (long long)len[i]); return FOS_EINVAL; }
+                expc.push_back(cd);
+            } else {
+                if (type[i] == FOS_CONE_SOCROT && len[i] < 2) { set_error("ConeProduct cone %lld: rotated SOC needs >= 2 entries", (long long)i + 1); return FOS_EINVAL; }
+                soc.push_back(cd);
+            }
+            for (int64_t k = 0; k < len[i]; ++k) ew[(size_t)(pos + k)] = EW_SKIP;
+        }
+        pos += len[i];
+    }
+    if (pos != n) { set_error("ConeProduct: the cones cover %lld of the %lld entries", (long long)pos, (long long)n); return FOS_EINVAL; }
+    FeasSet& s = h->S[which - 1];
+    auto upload = [&](auto** dst, const auto& v) -> int {
+        using T = typename std::remove_reference<decltype(v)>::type::value_type;
+        if (v.empty()) { *dst = nullptr; return FOS_OK; }
+        void* q = nullptr;
+        if (hipMalloc(&q, sizeof(T) * v.size()) != hipSuccess) { set_error("ConeProduct: hipMalloc failed"); return FOS_ENOMEM; }
+        h->owned.push_back(q);
+        if (hipMemcpy(q, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice) != hipSuccess) { set_error("ConeProduct: upload failed"); return FOS_EHIP; }
+        *dst = static_cast<T*>(q);
+        return FOS_OK;
+    };
+    FOS_TRY(upload(&s.ew_op, ew));
+    FOS_TRY(upload(&s.soc, soc));
+    FOS_TRY(upload(&s.expc, expc));
+    FOS_TRY(upload(&s.psd, psd));
+    s.nsoc = (int)soc.size(); s.nexp = (int)expc.size(); s.npsd = (int)psd.size();
+    s.psd_kmax = 0;
+    for (auto& cd : psd) s.psd_kmax = std::max(s.psd_kmax, cd.k);
+    s.psd_kmin = s.psd_kmax;
+    for (auto& cd : psd) s.psd_kmin = std::min(s.psd_kmin, cd.k);
+    const size_t sb = psd_scratch_bytes(s.psd_kmax, s.npsd);
+    if (sb) FOS_TRY(feas_alloc(h, &s.psd_scratch, sb / sizeof(double)));
+    const size_t vb = psd_basis_doubles(s.psd_kmax, s.npsd);
+    if (vb) { FOS_TRY(feas_alloc(h, &s.psd_V[0], vb)); FOS_TRY(feas_alloc(h, &s.psd_V[1], vb)); }
+    s.psd_cur = 0; s.psd_have_prev = 0;
+    if (!h->zin) {
+        double* q = nullptr;
+        FOS_TRY(feas_alloc(h, &q, 2 * (size_t)n)); h->zin = reinterpret_cast<double2*>(q);
+        FOS_TRY(feas_alloc(h, &q, 2 * (size_t)n)); h->zout = reinterpret_cast<double2*>(q);
+    }
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    s.kind = 3;
+    return FOS_OK;
+}
+
 int fos_feas_set_alg(fos_feas_handle h, int32_t alg, double alpha, double alpha1, double alpha2, double beta) {
     if (!h || alg < FOS_ALG_GAP || alg > FOS_ALG_DYKSTRA) { set_error("fos_feas_set_alg: unknown algorithm"); return FOS_EINVAL; }
     h->alg = alg; h->alpha = alpha; h->alpha1 = alpha1; h->alpha2 = alpha2; h->beta = beta;
@@ -458,6 +565,7 @@ int fos_feas_set_iterate(fos_feas_handle h, const double* x0) {
     FOS_HIP(hipMemcpyAsync(h->a12, &two, sizeof(double), hipMemcpyHostToDevice, h->stream));
     FOS_HIP(hipStreamSynchronize(h->stream));
     h->fista_t = 1.0; h->status = FOS_STATUS_CONTINUE; h->checked = 0; h->err = NAN;
+    for (FeasSet& s : h->S) { s.psd_cur = 0; s.psd_have_prev = 0; }        // a new solve starts its PSD projections cold
     return feas_check_launch("fos_feas_set_iterate");
 }
 

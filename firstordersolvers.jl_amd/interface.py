@@ -689,6 +689,17 @@ class IndBox:
         self.lo, self.hi = float(lo), float(hi)
 
 
+class ConeProduct:
+    """FirstOrderSolvers.ConeProduct (src/cones.jl:31-94) as a set of the Feasibility form: cones = [(name, length), ...] with the
+    names of `conemap` (cones.jl:4-14: Free, Zero, NonNeg, NonPos, SOC, SOCRotated, SDP, ExpPrimal, ExpDual), in order, contiguous."""
+
+    def __init__(self, cones):
+        self.cones = [(str(k), int(l)) for k, l in cones]
+        for k, _ in self.cones:
+            if k not in _lib.CONE_CODES:
+                raise ValueError("unknown cone %r (supportedcones: %s)" % (k, ", ".join(_lib.CONE_CODES)))
+
+
 class Feasibility:
     """struct Feasibility{T1,T2}(S1, S2, n)   Feasibility.jl:2-6"""
 
@@ -719,8 +730,13 @@ class HipFeasibility:
                 _lib.check(self._lib.fos_feas_set_affine(self._h, which, S.A.shape[0], _lib.dptr(S.A), _lib.dptr(S.b)))
             elif isinstance(S, IndBox):
                 _lib.check(self._lib.fos_feas_set_box(self._h, which, S.lo, S.hi))
+            elif isinstance(S, ConeProduct):
+                types = np.ascontiguousarray([_lib.CONE_CODES[k] for k, _ in S.cones], dtype=np.int32)
+                lens = np.ascontiguousarray([l for _, l in S.cones], dtype=np.int64)
+                _lib.check(self._lib.fos_feas_set_cones(self._h, which, len(S.cones), types.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                        lens.ctypes.data_as(C.POINTER(C.c_int64))))
             else:
-                raise _lib.FosError(-4, "Feasibility on the device: set %d must be IndAffine or IndBox (host callbacks are not "
+                raise _lib.FosError(-4, "Feasibility on the device: set %d must be IndAffine, IndBox or ConeProduct (host callbacks are not "
                                         "supported: there is no CPU path), got %s" % (which, type(S).__name__))
 
     def close(self):

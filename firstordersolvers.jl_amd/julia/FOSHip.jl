@@ -247,7 +247,8 @@ function getsol(alg::FOSAlgorithm, data::HipData, x)
 end
 
 # ---- Feasibility form [problemforms/Feasibility/Feasibility.jl, FeasibilityStatus.jl]: solve!(Feasibility(S1, S2, n), alg; gpu=true)
-#      with S1, S2 among ProximalOperators.IndAffine (dense A) and IndBox (scalar bounds) -- the sets of test/testfeasibility.jl.
+#      with S1, S2 among ProximalOperators.IndAffine (dense A), IndBox (scalar bounds) -- the sets of test/testfeasibility.jl -- and
+#      FirstOrderSolvers.ConeProduct.
 #      init_algorithm! returns a HipFeasData; iterate dispatches on it; FeasibilityModel, populate_solution and the printed table
 #      stay the reference's own code.
 import ..FirstOrderSolvers: FeasibilityModel, FeasibilityStatus
@@ -263,6 +264,10 @@ mutable struct HipFeasData <: FOSSolverData
         for (which, S) in ((Int32(1), model.S1), (Int32(2), model.S2))
             if S isa ProximalOperators.IndBox
                 check(ccall((:fos_feas_set_box, libfoship), Cint, (Ptr{Cvoid}, Int32, Cdouble, Cdouble), d.handle, which, Float64(S.lb), Float64(S.ub)))
+            elseif S isa ConeProduct                        # the reference's own cone stack [cones.jl:31-94]
+                types, _, lens = conearrays(S)
+                GC.@preserve types lens check(ccall((:fos_feas_set_cones, libfoship), Cint, (Ptr{Cvoid}, Int32, Int64, Ptr{Int32}, Ptr{Int64}),
+                                                    d.handle, which, Int64(length(types)), types, lens))
             else                                            # IndAffine(A, b), dense: the C ABI takes A row-major
                 At = Matrix{Float64}(transpose(S.A))        # column-major A' = row-major A
                 b = Vector{Float64}(S.b)

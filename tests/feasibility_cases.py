@@ -19,3 +19,19 @@ ALGS = {
     "FISTA": lambda M, **kw: M.FISTA(**kw),
     "Dykstra": lambda M, **kw: M.Dykstra(**kw),
 }
+
+
+MIXED_CONES = [("NonNeg", 7), ("SOC", 6), ("SDP", 21), ("Free", 3), ("SOCRotated", 5), ("SDP", 2080), ("NonPos", 4), ("SOC", 1), ("SDP", 3),
+               ("ExpPrimal", 3), ("ExpDual", 3), ("Zero", 2)]
+
+
+def cone_instance(orc, cones=MIXED_CONES, m_frac=0.3, seed=11):
+    """A x = b with b = A x0, x0 a point of the cone product (the projection of a random vector): IndAffine n ConeProduct is non-empty."""
+    rng = np.random.default_rng(seed)
+    n = sum(l for _, l in cones)
+    K = orc.ConeProduct.from_lengths([(orc.CONE_CODES[k], l) for k, l in cones])
+    x0 = np.empty(n)
+    K.prox(x0, rng.standard_normal(n))
+    m = max(1, int(m_frac * n))
+    A = rng.standard_normal((m, n)) / np.sqrt(n)
+    return A, A @ x0, K, n

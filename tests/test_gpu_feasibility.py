@@ -6,7 +6,7 @@ solution), the assertions of the reference's own test (test/testfeasibility.jl),
 import numpy as np
 import pytest
 
-from feasibility_cases import ALGS, affine_box_instance
+from feasibility_cases import ALGS, MIXED_CONES, affine_box_instance, cone_instance
 
 pytestmark = pytest.mark.gpu
 
@@ -162,3 +162,56 @@ def test_linesearch_wrapper_matches_oracle(pkg, oracle, algname):
     assert abs(sol.iterations - osol.iterations) <= 10
     assert sol.x.min() > -1e-9 and np.abs(A @ sol.x - b).max() < 1e-6
     assert any(l.startswith("test, ") for l in out) and sum(l.startswith("\u03b1: ") for l in out) % 32 == 0
+
+
+def test_cone_product_set_matches_oracle(pkg, oracle):
+    """ConeProduct (src/cones.jl:31-94) as a set of the Feasibility form: every cone type, PSD orders 2, 6 and 64, projected by the
+    batched cone kernels of the HSDE path; cold and warm-started PSD projections."""
+    orc = oracle
+    A, b, K, n = cone_instance(orc)
+    d = pkg.HipFeasibility(pkg.Feasibility(pkg.ConeProduct(MIXED_CONES), pkg.IndBox(-np.inf, np.inf), n))
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(n)
+    y = np.empty(n)
+    for rep in range(3):                                       # rep > 0: warm-started from the previous basis, slowly moving input
+        K.prox(y, x)
+        yd = d.prox(1, x)
+        assert np.abs(yd - y).max() <= 5e-12 * max(1.0, np.abs(x).max()), rep
+        x = x + 1e-3 * rng.standard_normal(n)
+    d.set_iterate(None)                                        # a new solve starts cold again
+    K.prox(y, x)
+    assert np.abs(d.prox(1, x) - y).max() <= 5e-12
+    for bad in ([("SDP", 4), ("Free", n - 4)], [("NonNeg", n - 1)], [("ExpPrimal", 6), ("Free", n - 6)], [("NonNeg", n + 1)]):
+        with pytest.raises(pkg.lib.FosError):
+            pkg.HipFeasibility(pkg.Feasibility(pkg.ConeProduct(bad), pkg.IndBox(0.0, 1.0), n))
+
+
+@pytest.mark.parametrize("algname", ["DR", "GAPA", "FISTA", "Dykstra"])
+def test_affine_cone_feasibility_matches_oracle(pkg, oracle, algname):
+    """find x in {A x = b} n K, K a product of all cone types (the conic feasibility problem the reference's form is made for):
+    first iterations against the oracle, then the whole solve."""
+    orc = oracle
+    A, b, K, n = cone_instance(orc)
+    hp = pkg.Feasibility(pkg.IndAffine(A, b), pkg.ConeProduct(MIXED_CONES), n)
+    op = orc.Feasibility(orc.IndAffine(A, b), K, n)
+    oalg = ALGS[algname](orc, verbose=0)
+    omodel = orc.FeasibilityModel(op, oalg)
+    ost = orc.FeasibilityStatus(omodel, 10 ** 9, 1e-30, 0, 1)
+    d = pkg.HipFeasibility(hp)
+    d.set_alg(ALGS[algname](pkg))
+    d.set_iterate(None)
+    xo = np.zeros(n)
+    for i in range(1, 26):
+        ost.i = i
+        oalg.step(xo, i, ost)
+        d.step(i, 1, 10 ** 9, 1e-30)
+        assert np.abs(d.get_iterate() - xo).max() <= 1e-10 * max(1.0, np.abs(xo).max()), (algname, i)
+    sol, model = pkg.solve_feasibility(hp, ALGS[algname](pkg, eps=1e-7, verbose=0, max_iters=4000), checki=10)
+    osol, _ = orc.feasibility_solve(op, ALGS[algname](orc, eps=1e-7, verbose=0, max_iters=4000), checki=10)
+    assert sol.status == osol.status
+    assert abs(sol.iterations - osol.iterations) <= max(10, osol.iterations // 20)
+    assert np.abs(sol.x - osol.x).max() <= 1e-5
+    if sol.status == "Optimal":
+        proj = np.empty(n)
+        K.prox(proj, sol.x)
+        assert np.abs(proj - sol.x).max() <= 1e-6 and np.abs(A @ sol.x - b).max() <= 1e-5      # in the cone product and on the affine set

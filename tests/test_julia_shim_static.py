@@ -1,6 +1,6 @@
 """Static cross-check of the Julia `ccall` shim (firstordersolvers.jl_amd/julia/FOSHip.jl) against include/foship.h: there is no
 Julia in the build image, so the shim has never run -- this test at least keeps every ccall's symbol, return type, argument
-types and argument count in step with the header (which grew from 40 to 70 entries over the rounds), and the CheckResult
+types and argument count in step with the header (which grew from 40 to 71 entries over the rounds), and the CheckResult
 struct in step with fos_check_result."""
 import re
 from pathlib import Path
@@ -88,7 +88,7 @@ def test_every_ccall_matches_the_header():
     # the calls the drop-in path cannot work without
     used = {c[0] for c in calls}
     for need in ("fos_create", "fos_destroy", "fos_set_alg", "fos_set_iterate", "fos_step", "fos_getsol", "fos_last_error",
-                 "fos_feas_create", "fos_feas_destroy", "fos_feas_set_affine", "fos_feas_set_box", "fos_feas_set_alg", "fos_feas_set_iterate",
+                 "fos_feas_create", "fos_feas_destroy", "fos_feas_set_affine", "fos_feas_set_box", "fos_feas_set_cones", "fos_feas_set_alg", "fos_feas_set_iterate",
                  "fos_feas_step", "fos_feas_getsol"):
         assert need in used, need
 
