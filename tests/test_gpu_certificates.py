@@ -174,3 +174,35 @@ def test_mid_size_whole_solve_matches_oracle(pkg, algname):
         for key in ("p", "d", "g"):
             assert getattr(last, key) == pytest.approx(olast[key], rel=0.05)
         assert np.max(np.abs(model.getsolution() - sol.x)) <= 1e-3 * max(1.0, np.max(np.abs(sol.x)))
+
+
+@pytest.mark.parametrize("algname", ["DR", "GAPA"])
+def test_mid_size_solved_to_the_north_star_tolerance(pkg, algname):
+    """BASELINE north_star: residuals within 1e-8.  l ~ 1e4 solved to eps = 1e-8 on the device and judged WITHOUT the oracle (a numpy
+    oracle solve to that tolerance takes many minutes): p, d, g of HSDEStatus.jl:34-38 recomputed on the host from the returned
+    (x, y, s), cone membership of s and y, and the optimal value against the optimum the instance was built around (a strictly
+    complementary primal-dual pair, workloads.c5_mixed)."""
+    prob = pkg.workloads.mid_mixed()
+    alg = {"DR": lambda: pkg.DR(eps=1e-8, verbose=0, max_iters=20000, checki=100),
+           "GAPA": lambda: pkg.GAPA(0.8, 0.5, eps=1e-8, verbose=0, max_iters=20000, checki=100)}[algname]()     # (~10 000 iterations)
+    model = pkg.solve(prob, alg)
+    assert model.status() == "Optimal"
+    last = model.status_obj.last
+    eps = 1e-8
+    x, y, s = model.getsolution(), model.dual_sol, model.slack
+    A, b, c = prob.A, prob.b, prob.c
+    nb, nc = np.linalg.norm(b), np.linalg.norm(c)
+    p = np.linalg.norm(A @ x + s - b) / (1 + nb)
+    d = np.linalg.norm(A.T @ y + c) / (1 + nc)                 # K2 = Free: r = 0
+    ctx, bty = float(c @ x), float(b @ y)
+    g = abs(ctx + bty) / (1 + abs(ctx) + abs(bty))
+    assert p <= eps * (1 + nb) and d <= eps * (1 + nc) and g <= eps * (1 + abs(ctx) + abs(bty))      # the decision of HSDEStatus.jl:53-55
+    assert last.p <= eps * (1 + nb) and last.d <= eps * (1 + nc)            # (the device's own check, on the iterate it stopped at)
+    K1 = orc.ConeProduct.from_lengths([(orc.CONE_CODES[k], l) for k, l in prob.K1])
+    proj = np.empty_like(s)
+    K1.prox(proj, s)
+    assert np.abs(proj - s).max() <= 1e-9 * max(1.0, np.abs(s).max())       # s in K1
+    K1.prox_dual(proj, y)
+    assert np.abs(proj - y).max() <= 1e-9 * max(1.0, np.abs(y).max())       # y in K1*
+    opt = float(c @ prob.x0)
+    assert abs(ctx - opt) <= 1e-6 * (1 + abs(opt))
