@@ -258,7 +258,9 @@ def main():
                 raise PeerTransportFailed()
             it += done
         # ---- timed: exactly K outer iterations
-        PROF_PERIOD = 4        # HIP events around every 4th launch group of each class (an event pair per launch costs ~5 % of a C4 step)
+        # HIP events around every PROF_PERIOD-th launch group of each class: an event pair per launch costs ~5 % of a C4 step, every
+        # 4th 2 %, every 16th 1 % (536 / 542 / 547 it/s at periods 4 / 16 / 64); short runs keep the dense sampling for the sample count
+        PROF_PERIOD = int(os.environ.get("FOS_BENCH_PROF_PERIOD", "16" if args.steps >= 20 else "4"))
         dev.psd_debug(True, 0)
         dev.profile(PROF_PERIOD)
         dev.profile_read_classes()
