@@ -37,6 +37,11 @@ __global__ __launch_bounds__(FEAS_THREADS) void feas_affine_finish_kernel(int64_
 __global__ __launch_bounds__(FEAS_THREADS) void feas_box_kernel(int64_t n, double* __restrict__ y, const double* __restrict__ x, double lo, double hi) {
     FEAS_STRIDE(i, n) y[i] = fmin(fmax(x[i], lo), hi);
 }
+// y = clamp(x, lo[i], hi[i])      IndBox with array bounds
+__global__ __launch_bounds__(FEAS_THREADS) void feas_boxv_kernel(int64_t n, double* __restrict__ y, const double* __restrict__ x,
+                                                                 const double* __restrict__ lo, const double* __restrict__ hi) {
+    FEAS_STRIDE(i, n) y[i] = fmin(fmax(x[i], lo[i]), hi[i]);
+}
 // y = a y + (1 - a) x       gap.jl:48,58 ; gapa.jl:67,77 (a = alpha12, a device scalar) ; fista.jl:37
 __global__ __launch_bounds__(FEAS_THREADS) void feas_relax_kernel(int64_t n, double* __restrict__ y, const double* __restrict__ x, double a,
                                                                   const double* __restrict__ a_dev) {
@@ -137,6 +142,7 @@ struct FeasSet {
     double* P = nullptr;            // [L x L] A'(A A')^-1 A, column-major
     double* q = nullptr;            // [L]     A'(A A')^-1 b
     double lo = 0.0, hi = 0.0;
+    double *lov = nullptr, *hiv = nullptr;      // [n] array bounds (IndBox with vectors); nullptr: the scalars
     int ns_iters = 0;               // Newton-Schulz steps of the set-up
     double ns_resid = 0.0;          // max |G X - I| it ended with
     // kind 3: ConeProduct (cones.jl:31-94) on the batched cone kernels of the HSDE path
@@ -210,7 +216,8 @@ int feas_prox(fos_feas* h, int which, double* y, const double* x) {
         launch_dense_symv(feas_ctx(h, h->n), h->L, s.P, x, h->px);        // P is symmetric: column dots = P x
         FEAS_K(feas_affine_finish_kernel, h->n, y, x, h->px, s.q);
     } else if (s.kind == 2) {
-        FEAS_K(feas_box_kernel, h->n, y, x, s.lo, s.hi);
+        if (s.lov) FEAS_K(feas_boxv_kernel, h->n, y, x, (const double*)s.lov, (const double*)s.hiv);
+        else FEAS_K(feas_box_kernel, h->n, y, x, s.lo, s.hi);
     } else if (s.kind == 3) {                                             // prox!(y, ::ConeProduct, x)   cones.jl:89-94
         FeasSet& ms = h->S[which];
         LaunchCtx c = feas_ctx(h, h->n);
@@ -449,7 +456,21 @@ int fos_feas_set_affine(fos_feas_handle h, int32_t which, int64_t m, const doubl
 int fos_feas_set_box(fos_feas_handle h, int32_t which, double lo, double hi) {
     if (!h || which < 1 || which > 2 || !(lo <= hi)) { set_error("fos_feas_set_box: which = 1 | 2 and lo <= hi are required"); return FOS_EINVAL; }
     FeasSet& s = h->S[which - 1];
-    s.kind = 2; s.lo = lo; s.hi = hi;
+    s.kind = 2; s.lo = lo; s.hi = hi; s.lov = s.hiv = nullptr;
+    return FOS_OK;
+}
+
+// IndBox(lo, hi) with array bounds (n entries each; +-INFINITY allowed)
+int fos_feas_set_box_arrays(fos_feas_handle h, int32_t which, const double* lo, const double* hi) {
+    if (!h || which < 1 || which > 2 || !lo || !hi) { set_error("fos_feas_set_box_arrays: bad argument"); return FOS_EINVAL; }
+    for (int64_t i = 0; i < h->n; ++i) if (!(lo[i] <= hi[i])) { set_error("IndBox: lo[%lld] <= hi[%lld] is required", (long long)i + 1, (long long)i + 1); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FeasSet& s = h->S[which - 1];
+    if (!s.lov) { FOS_TRY(feas_alloc(h, &s.lov, (size_t)h->n)); FOS_TRY(feas_alloc(h, &s.hiv, (size_t)h->n)); }
+    FOS_HIP(hipMemcpyAsync(s.lov, lo, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+    FOS_HIP(hipMemcpyAsync(s.hiv, hi, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    s.kind = 2;
     return FOS_OK;
 }
 

@@ -683,10 +683,14 @@ class IndAffine:
 
 
 class IndBox:
-    """ProximalOperators.IndBox(lo, hi): {x : lo <= x <= hi}, scalar bounds (+-inf allowed)."""
+    """ProximalOperators.IndBox(lo, hi): {x : lo <= x <= hi}, scalar or array bounds (+-inf allowed)."""
 
     def __init__(self, lo, hi):
-        self.lo, self.hi = float(lo), float(hi)
+        self.arrays = np.ndim(lo) > 0 or np.ndim(hi) > 0
+        if self.arrays:
+            self.lo, self.hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+        else:
+            self.lo, self.hi = float(lo), float(hi)
 
 
 class ConeProduct:
@@ -728,6 +732,10 @@ class HipFeasibility:
                 if S.A.shape[1] != self.n:
                     raise ValueError("IndAffine: A has %d columns, the problem has n = %d" % (S.A.shape[1], self.n))
                 _lib.check(self._lib.fos_feas_set_affine(self._h, which, S.A.shape[0], _lib.dptr(S.A), _lib.dptr(S.b)))
+            elif isinstance(S, IndBox) and S.arrays:
+                lo = np.ascontiguousarray(np.broadcast_to(S.lo, (self.n,)), dtype=np.float64)
+                hi = np.ascontiguousarray(np.broadcast_to(S.hi, (self.n,)), dtype=np.float64)
+                _lib.check(self._lib.fos_feas_set_box_arrays(self._h, which, _lib.dptr(lo), _lib.dptr(hi)))
             elif isinstance(S, IndBox):
                 _lib.check(self._lib.fos_feas_set_box(self._h, which, S.lo, S.hi))
             elif isinstance(S, ConeProduct):

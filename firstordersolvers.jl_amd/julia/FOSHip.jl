@@ -262,7 +262,11 @@ mutable struct HipFeasData <: FOSSolverData
         d = new(h[], 0)
         finalizer(x -> ccall((:fos_feas_destroy, libfoship), Cint, (Ptr{Cvoid},), x.handle), d)
         for (which, S) in ((Int32(1), model.S1), (Int32(2), model.S2))
-            if S isa ProximalOperators.IndBox
+            if S isa ProximalOperators.IndBox && (S.lb isa AbstractArray || S.ub isa AbstractArray)
+                lo = S.lb isa AbstractArray ? Vector{Float64}(vec(S.lb)) : fill(Float64(S.lb), model.n)
+                hi = S.ub isa AbstractArray ? Vector{Float64}(vec(S.ub)) : fill(Float64(S.ub), model.n)
+                GC.@preserve lo hi check(ccall((:fos_feas_set_box_arrays, libfoship), Cint, (Ptr{Cvoid}, Int32, Ptr{Cdouble}, Ptr{Cdouble}), d.handle, which, lo, hi))
+            elseif S isa ProximalOperators.IndBox
                 check(ccall((:fos_feas_set_box, libfoship), Cint, (Ptr{Cvoid}, Int32, Cdouble, Cdouble), d.handle, which, Float64(S.lb), Float64(S.ub)))
             elseif S isa ConeProduct                        # the reference's own cone stack [cones.jl:31-94]
                 types, _, lens = conearrays(S)

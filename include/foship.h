@@ -322,7 +322,7 @@ int fos_debug_set(fos_handle h, int32_t what, int64_t value);
  * (host callbacks); the device path offers the two its own test uses (test/testfeasibility.jl:9-10):
  *   fos_feas_set_affine  IndAffine(A, b): A m x n ROW-major, full row rank, n <= 46 000; exact projection x - A'(A A')^-1 (A x - b)
  *                        through a one-time dense inverse formed on the device (Newton-Schulz on the fp64 MFMA GEMM);
- *   fos_feas_set_box     IndBox(lo, hi), scalar bounds, +-INFINITY allowed;
+ *   fos_feas_set_box     IndBox(lo, hi), scalar bounds (fos_feas_set_box_arrays: array bounds), +-INFINITY allowed;
  *   fos_feas_set_cones   the reference's own ConeProduct (src/cones.jl), any of its nine cone types.
  * `which` = 1 | 2 (S1, S2).  Steps: gap.jl:42-87 (GAP / DR / AP), gapa.jl:61-112, fista.jl:28-56, dykstra.jl:25-44; LineSearchWrapper. */
 typedef struct fos_feas* fos_feas_handle;
@@ -330,6 +330,7 @@ int fos_feas_create(int64_t n, int32_t device, fos_feas_handle* out);
 int fos_feas_destroy(fos_feas_handle h);
 int fos_feas_set_affine(fos_feas_handle h, int32_t which, int64_t m, const double* A, const double* b);
 int fos_feas_set_box(fos_feas_handle h, int32_t which, double lo, double hi);
+int fos_feas_set_box_arrays(fos_feas_handle h, int32_t which, const double* lo, const double* hi);     /* IndBox with array bounds (n each) */
 /* ConeProduct (src/cones.jl:31-94): ncones cones of type[i] (FOS_CONE_*) and len[i] entries, in order, contiguous, covering all n entries;
  * projected by the batched cone kernels of the HSDE path (PSD cones warm-started from one projection to the next) */
 int fos_feas_set_cones(fos_feas_handle h, int32_t which, int64_t ncones, const int32_t* type, const int64_t* len);

@@ -34,10 +34,14 @@ def test_set_projections_match_oracle(pkg, oracle, m, n):
         assert np.abs(A @ yd - b).max() <= 1e-10 * max(1.0, np.abs(x).max())
         op.S2.prox(y, x)
         assert np.array_equal(d.prox(2, x), y)                 # elementwise: bit exact
-    # a two-sided box
-    d2 = pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(-0.5, 0.25), pkg.IndBox(-np.inf, 1.0), n))
-    x = rng.standard_normal(n)
-    assert np.array_equal(d2.prox(1, x), np.clip(x, -0.5, 0.25)) and np.array_equal(d2.prox(2, x), np.minimum(x, 1.0))
+    # a two-sided box; array bounds
+    lo, hi = -np.abs(rng.standard_normal(n)), np.abs(rng.standard_normal(n))
+    hi[::7] = np.inf
+    d2 = pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(-0.5, 0.25), pkg.IndBox(lo, hi), n))
+    x = 2 * rng.standard_normal(n)
+    assert np.array_equal(d2.prox(1, x), np.clip(x, -0.5, 0.25)) and np.array_equal(d2.prox(2, x), np.minimum(np.maximum(x, lo), hi))
+    d3 = pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(-np.inf, 1.0), pkg.IndBox(lo, 3.0), n))
+    assert np.array_equal(d3.prox(1, x), np.minimum(x, 1.0)) and np.array_equal(d3.prox(2, x), np.minimum(np.maximum(x, lo), 3.0))
 
 
 @pytest.mark.parametrize("algname", sorted(ALGS))
