@@ -179,6 +179,8 @@ struct fos_feas {
     double err = NAN;
     int64_t ls_interval = 0;        // LineSearchWrapper (wrappers/linesearch.jl): every ls_interval-th iteration is a step-length search
     double ls_log[34] = {0};        // normres, 31 test residuals, alpha_best, iteration (the layout of fos_linesearch_log)
+    int64_t gapp_iproj = 100;       // GAPP (solvers/gapproj.jl): every iproj-th iteration is a projected search
+    double gapp_log[23] = {0};      // 21 test norms, alpha_best, iteration
     std::vector<void*> owned;
 };
 
@@ -294,8 +296,43 @@ int feas_linesearch_iteration(fos_feas* h, int64_t i, int64_t checki, double eps
     return FOS_OK;
 }
 
+// GAPP, one iteration      solvers/gapproj.jl:29-72      scratch: xold = res, p = tmp3, q = tmp4
+int feas_gapp_iteration(fos_feas* h, int64_t i, int64_t checki, double eps) {
+    const int64_t n = h->n;
+    FOS_TRY(feas_prox(h, 0, h->t1, h->x));                                             // prox!(tmp1, S1, x)        :33
+    if (i % h->gapp_iproj != 0) {                                                      // the GAP step              :63-70
+        FEAS_K(feas_relax_kernel, n, h->t1, (const double*)h->x, h->alpha1, (const double*)nullptr);
+        FOS_TRY(feas_prox(h, 1, h->t2, h->t1));
+        FOS_TRY(feas_check(h, h->t2, i, checki, eps, false));
+        FEAS_K(feas_relax_kernel, n, h->t2, (const double*)h->t1, h->alpha2, (const double*)nullptr);
+        FEAS_K(feas_combine_kernel, n, h->x, (const double*)h->t2, h->alpha);
+        return FOS_OK;
+    }
+    FOS_TRY(feas_prox(h, 1, h->t2, h->t1));                                            // prox!(tmp2, S2, tmp1)     :39
+    FOS_TRY(feas_prox(h, 0, h->xold, h->t2));                                          // prox!(res, S1, tmp2)      :40
+    FEAS_K(feas_sub_kernel, n, h->xold, (const double*)h->xold, (const double*)h->t1); // res .= res - tmp1         :41
+    double normbest = INFINITY, abest = -1.0;                                          // :44-45
+    for (int k = 0; k <= 20; ++k) {                                                    // :46
+        const double at = std::ldexp(1.0, k);                                          // 2.0^k
+        FEAS_K(feas_axpy_kernel, n, h->p, (const double*)h->t1, at, (const double*)h->xold);       // tmp3 .= tmp1 .+ at.*res
+        FOS_TRY(feas_prox(h, 1, h->q, h->p));                                          // prox!(tmp4, S2, tmp3)
+        double nt = 0.0;
+        FOS_TRY(feas_norm_of_diff(h, h->q, h->p, &nt));                                // norm(tmp4 - tmp3)
+        h->gapp_log[k] = nt;
+        if (nt < normbest) { abest = at; normbest = nt; }
+    }
+    h->gapp_log[21] = abest; h->gapp_log[22] = (double)i;
+    FEAS_K(feas_axpy_kernel, n, h->p, (const double*)h->t1, abest, (const double*)h->xold);        // tmp1 .= tmp1 .+ abest.*res   :58
+    FOS_TRY(feas_prox(h, 1, h->t2, h->p));                                             // prox!(tmp2, S2, tmp1)     :59
+    FOS_TRY(feas_check(h, h->t2, i, checki, eps, false));                              // :60
+    FEAS_K(feas_relax_kernel, n, h->t2, (const double*)h->p, h->alpha2, (const double*)nullptr);   // :61
+    FEAS_K(feas_copy_kernel, n, h->x, (const double*)h->t2);                           // x .= tmp2                 :62
+    return FOS_OK;
+}
+
 int feas_step_once(fos_feas* h, int64_t i, int64_t checki, double eps) {
     const int64_t n = h->n;
+    if (h->alg == FOS_ALG_GAPP) return feas_gapp_iteration(h, i, checki, eps);
     if (h->ls_interval > 0 && i % h->ls_interval == 0) return feas_linesearch_iteration(h, i, checki, eps);      // linesearch.jl:39
     switch (h->alg) {
     case FOS_ALG_GAP:
@@ -555,6 +592,19 @@ int fos_feas_set_alg(fos_feas_handle h, int32_t alg, double alpha, double alpha1
     h->alg = alg; h->alpha = alpha; h->alpha1 = alpha1; h->alpha2 = alpha2; h->beta = beta;
     if (alg == FOS_ALG_GAPA) h->alpha1 = h->alpha2 = 2.0;              // (unused: GAPA relaxes with the device scalar alpha12)
     h->ls_interval = 0;                                                // a fresh algorithm is unwrapped (fos_feas_set_linesearch follows)
+    return FOS_OK;
+}
+
+// GAPP(alpha, alpha1, alpha2; iproj)      solvers/gapproj.jl:5-13 (Feasibility form only)
+int fos_feas_set_gapp(fos_feas_handle h, double alpha, double alpha1, double alpha2, int64_t iproj) {
+    if (!h || iproj < 1) { set_error("fos_feas_set_gapp: iproj >= 1 is required"); return FOS_EINVAL; }
+    h->alg = FOS_ALG_GAPP; h->alpha = alpha; h->alpha1 = alpha1; h->alpha2 = alpha2; h->beta = 0.0; h->gapp_iproj = iproj;
+    h->ls_interval = 0;
+    return FOS_OK;
+}
+int fos_feas_gapp_log(fos_feas_handle h, double* out23) {
+    if (!h || !out23) { set_error("NULL argument"); return FOS_EINVAL; }
+    memcpy(out23, h->gapp_log, sizeof(h->gapp_log));
     return FOS_OK;
 }
 

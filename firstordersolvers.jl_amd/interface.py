@@ -81,6 +81,17 @@ class FISTA(FOSAlgorithm):
         return (_lib.ALG_FISTA, self.alpha, 0.0, 0.0, 0.0)
 
 
+class GAPP(FOSAlgorithm):
+    """GAPP(alpha=0.8, alpha1=1.8, alpha2=1.8; direct=true, iproj=100, kwargs...)   gapproj.jl:5-13 -- experimental in the reference;
+    available on the Feasibility form of the device path (test/testfeasibility.jl:36), not on the HSDE one."""
+
+    def __init__(self, alpha=0.8, alpha1=1.8, alpha2=1.8, direct=True, iproj=100, **kwargs):
+        self.alpha, self.alpha1, self.alpha2, self.direct, self.iproj, self.options = alpha, alpha1, alpha2, direct, int(iproj), kwargs
+
+    def _alg_args(self):
+        raise _lib.FosError(-4, "GAPP runs on the Feasibility form only (fos_feas_set_gapp)")
+
+
 class Dykstra(FOSAlgorithm):
     """Dykstra(; direct=false, kwargs...)   dykstra.jl:5-9"""
 
@@ -759,9 +770,18 @@ class HipFeasibility:
             pass
 
     def set_alg(self, alg: FOSAlgorithm):
+        if isinstance(alg, GAPP):
+            _lib.check(self._lib.fos_feas_set_gapp(self._h, alg.alpha, alg.alpha1, alg.alpha2, alg.iproj))
+            return
         _lib.check(self._lib.fos_feas_set_alg(self._h, *alg._alg_args()))
         if isinstance(alg, LineSearchWrapper):                          # the wrapped algorithm's arguments, then the search
             _lib.check(self._lib.fos_feas_set_linesearch(self._h, alg.lsinterval))
+
+    def gapp_log(self):
+        """(iteration, [21 test norms], alpha_best) of GAPP's last search."""
+        out = np.zeros(23)
+        _lib.check(self._lib.fos_feas_gapp_log(self._h, _lib.dptr(out)))
+        return int(out[22]), out[0:21].copy(), float(out[21])
 
     def linesearch_log(self):
         """(iteration, ||res||, [31 test residuals], alpha_best) of the last search."""
@@ -846,12 +866,20 @@ class FeasibilityModel:
             self._println("-" * 22)
         i, status, checked, err = 0, "Continue", False, float("nan")
         ls = self.alg.lsinterval if isinstance(self.alg, LineSearchWrapper) else 0
+        gp = self.alg.iproj if isinstance(self.alg, GAPP) else 0
         while i < max_iters and status == "Continue":
             nxt = min(max_iters, (i // checki + 1) * checki) if checki > 0 else max_iters
             if ls > 0:
                 nxt = min(nxt, (i // ls + 1) * ls)                     # stop at every line-search iteration: its output is printed
+            if gp > 0:
+                nxt = min(nxt, (i // gp + 1) * gp)
             done, status, err, checked = dev.step(i + 1, nxt - i, checki, eps)
             i += done
+            if gp > 0 and i % gp == 0:                                 # what gapproj.jl:51,57 print (unconditionally)
+                _, tests, abest = dev.gapp_log()
+                for nt in tests:
+                    self._println("normtest: %s" % julia_float(nt))
+                self._println("\u03b1best: %s" % julia_float(abest))
             if ls > 0 and i % ls == 0:                                 # what linesearch.jl:51,63,69 print
                 _, normres, tests, abest = dev.linesearch_log()
                 self._println("test, %s" % julia_float(normres))

@@ -256,10 +256,11 @@ import ..FirstOrderSolvers: FeasibilityModel, FeasibilityStatus
 mutable struct HipFeasData <: FOSSolverData
     handle::Ptr{Cvoid}
     lsinterval::Int64                     # > 0: LineSearchWrapper around the algorithm
+    gappinterval::Int64                   # > 0: GAPP, its search interval
     function HipFeasData(model::FeasibilityModel, device::Integer)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:fos_feas_create, libfoship), Cint, (Int64, Int32, Ref{Ptr{Cvoid}}), Int64(model.n), Int32(device), h))
-        d = new(h[], 0)
+        d = new(h[], 0, 0)
         finalizer(x -> ccall((:fos_feas_destroy, libfoship), Cint, (Ptr{Cvoid},), x.handle), d)
         for (which, S) in ((Int32(1), model.S1), (Int32(2), model.S2))
             if S isa ProximalOperators.IndBox && (S.lb isa AbstractArray || S.ub isa AbstractArray)
@@ -322,6 +323,29 @@ function print_linesearch(data::HipFeasData)
     println("α: $(log[33])")
 end
 
+# GAPP ("projected GAP", solvers/gapproj.jl) on the Feasibility form: every iproj-th iteration is a 21-point search on the device
+import ..FirstOrderSolvers: GAPP
+function init_algorithm!(alg::GAPP, model::FeasibilityModel)
+    if get(model.options, :gpu, false) === true
+        data = HipFeasData(model, get(model.options, :device, 0))
+        check(ccall((:fos_feas_set_gapp, libfoship), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Int64), data.handle, alg.α, alg.α1, alg.α2, Int64(alg.iproj)))
+        data.gappinterval = alg.iproj
+        status_generator = (mo, checki, eps, verbose, debug) ->
+            FeasibilityStatus(mo.n, 0, mo, fill(NaN, mo.n), Array{Array{Float64,1},1}(), :Continue, checki, eps, verbose, false, true,
+                              time_ns(), mo.init_duration, debug)
+        return data, status_generator
+    end
+    return invoke(init_algorithm!, Tuple{GAPP,FirstOrderSolvers.AbstractFOSModel}, alg, model)
+end
+function print_gapp(data::HipFeasData)                       # gapproj.jl:51,57
+    log = Vector{Float64}(undef, 23)
+    check(ccall((:fos_feas_gapp_log, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, log))
+    for k = 1:21
+        println("normtest: $(log[k])")
+    end
+    println("αbest: $(log[22])")
+end
+
 function iterate(alg::FOSAlgorithm, data::HipFeasData, status::FeasibilityStatus, x, max_iters)
     t1 = time()
     printstatusheader(status)
@@ -340,12 +364,15 @@ function iterate(alg::FOSAlgorithm, data::HipFeasData, status::FeasibilityStatus
         count = min(max_iters - i, status.checki - (i % status.checki))
         ls = data.lsinterval
         ls > 0 && (count = min(count, ls - (i % ls)))
+        gp = data.gappinterval
+        gp > 0 && (count = min(count, gp - (i % gp)))
         check(ccall((:fos_feas_step, libfoship), Cint,
                     (Ptr{Cvoid}, Int64, Int64, Int64, Cdouble, Ref{Int64}, Ref{Int32}, Ref{Cdouble}, Ref{Int32}),
                     data.handle, i + 1, count, status.checki, status.eps, done, st, err, checked))
         i += done[]
         status.i = i
         ls > 0 && i % ls == 0 && print_linesearch(data)
+        gp > 0 && i % gp == 0 && print_gapp(data)
         if checked[] != 0
             report()
             status.status != :Continue && break

@@ -54,6 +54,7 @@ extern "C" {
 #define FOS_ALG_GAPA    1   /* GAPA(alpha, beta)                                                              */
 #define FOS_ALG_FISTA   2   /* FISTA(alpha)                                                                   */
 #define FOS_ALG_DYKSTRA 3   /* Dykstra()                                                                      */
+#define FOS_ALG_GAPP    4   /* GAPP(alpha, alpha1, alpha2; iproj): Feasibility form only (fos_feas_set_gapp)   */
 
 /* status codes <-> Symbols of HSDEStatus.status (src/problemforms/HSDE/HSDEStatus.jl:53-63) */
 #define FOS_STATUS_CONTINUE   0
@@ -335,6 +336,10 @@ int fos_feas_set_box_arrays(fos_feas_handle h, int32_t which, const double* lo, 
  * projected by the batched cone kernels of the HSDE path (PSD cones warm-started from one projection to the next) */
 int fos_feas_set_cones(fos_feas_handle h, int32_t which, int64_t ncones, const int32_t* type, const int64_t* len);
 int fos_feas_set_alg(fos_feas_handle h, int32_t alg, double alpha, double alpha1, double alpha2, double beta);
+/* GAPP ("projected GAP", src/solvers/gapproj.jl:5-81; test/testfeasibility.jl:36): GAP whose every iproj-th iteration searches 21 step
+ * lengths 2^k along P_S1(P_S2(P_S1 x)) - P_S1 x.  out23 = the 21 test norms, alpha_best, iteration of the last search. */
+int fos_feas_set_gapp(fos_feas_handle h, double alpha, double alpha1, double alpha2, int64_t iproj);
+int fos_feas_gapp_log(fos_feas_handle h, double* out23);
 /* LineSearchWrapper(GAP | GAPA; lsinterval) around the algorithm set last (wrappers/linesearch.jl:36-75; 0 switches it off), and what
  * the reference prints during the last search: out34 = normres, 31 test residuals, alpha_best, iteration (as fos_linesearch_log) */
 int fos_feas_set_linesearch(fos_feas_handle h, int64_t lsinterval);

@@ -1099,6 +1099,64 @@ class FISTA:
         return tmp2
 
 
+class GAPP:
+    """GAPP(alpha=0.8, alpha1=1.8, alpha2=1.8; direct=true, iproj=100)   gapproj.jl:5-13 -- "projected GAP": GAP whose every iproj-th
+    iteration searches 21 step lengths 2^k along P_S1(P_S2(P_S1 x)) - P_S1 x (gapproj.jl:29-79).  Experimental in the reference
+    (it prints inside the loop); used by test/testfeasibility.jl:36-44, restated for the Feasibility form."""
+
+    def __init__(self, alpha=0.8, alpha1=1.8, alpha2=1.8, iproj=100, direct=True, out=None, **options):
+        self.alpha, self.alpha1, self.alpha2, self.iproj, self.direct = alpha, alpha1, alpha2, iproj, direct
+        self.options, self.out = options, out
+        self.log = []
+
+    def _println(self, s):
+        if self.out is None:
+            print(s)
+        else:
+            self.out.append(s)
+
+    def init(self, model):                                  # :22-26
+        self.S1, self.S2, n = hsde_sets(model, self.direct)
+        self.tmp1, self.tmp2 = np.empty(n), np.empty(n)
+
+    def step(self, x, i, status):                           # :29-72
+        tmp1, tmp2 = self.tmp1, self.tmp2
+        self.S1.prox(tmp1, x)                               # :33
+        if i % self.iproj == 0:                             # :34
+            tmp3, tmp4, res = np.empty_like(tmp1), np.empty_like(tmp1), np.empty_like(tmp1)
+            self.S2.prox(tmp2, tmp1)                        # :39
+            self.S1.prox(res, tmp2)                         # :40
+            res[:] = res - tmp1                             # :41
+            normbest, abest, tests = math.inf, -1.0, []
+            for k in range(21):                             # :46
+                atest = 2.0 ** k
+                tmp3[:] = tmp1 + atest * res
+                self.S2.prox(tmp4, tmp3)
+                normtest = float(np.linalg.norm(tmp4 - tmp3))
+                tests.append(normtest)
+                self._println("normtest: %s" % julia_float(normtest))
+                if normtest < normbest:
+                    abest, normbest = atest, normtest
+            self._println("\u03b1best: %s" % julia_float(abest))
+            tmp1[:] = tmp1 + abest * res                    # :58
+            self.S2.prox(tmp2, tmp1)                        # :59
+            status.checkstatus(tmp2)
+            tmp2[:] = self.alpha2 * tmp2 + (1 - self.alpha2) * tmp1
+            x[:] = tmp2                                     # :62
+            self.log.append((i, tests, abest))
+        else:
+            tmp1[:] = self.alpha1 * tmp1 + (1 - self.alpha1) * x        # :64
+            self.S2.prox(tmp2, tmp1)
+            status.checkstatus(tmp2)
+            tmp2[:] = self.alpha2 * tmp2 + (1 - self.alpha2) * tmp1
+            x[:] = self.alpha * tmp2 + (1 - self.alpha) * x             # :70
+
+    def getsol(self, x):                                    # :76-81
+        self.S1.prox(self.tmp1, x)
+        self.S2.prox(self.tmp2, self.tmp1)
+        return self.tmp2
+
+
 class Dykstra:
     """Dykstra()   dykstra.jl:5-9."""
 

@@ -19,6 +19,7 @@ ALGS = {
     "FISTA": lambda M, **kw: M.FISTA(**kw),
     "Dykstra": lambda M, **kw: M.Dykstra(**kw),
 }
+GAPP = lambda M, **kw: M.GAPP(0.8, 1.5, 1.6, **kw)
 
 
 MIXED_CONES = [("NonNeg", 7), ("SOC", 6), ("SDP", 21), ("Free", 3), ("SOCRotated", 5), ("SDP", 2080), ("NonPos", 4), ("SOC", 1), ("SDP", 3),

@@ -5,7 +5,7 @@ reference's own test (test/testfeasibility.jl): the assertions that test makes, 
 import numpy as np
 import pytest
 
-from feasibility_cases import ALGS, affine_box_instance
+from feasibility_cases import ALGS, GAPP, affine_box_instance
 
 
 def _problem(orc, **kw):
@@ -79,3 +79,23 @@ def test_every_algorithm_reaches_the_intersection(oracle, algname):
     sol, _ = orc.feasibility_solve(prob, ALGS[algname](orc, eps=1e-9, verbose=0, max_iters=20000), checki=10)
     assert sol.status == "Optimal"
     assert sol.x.min() > -1e-7 and np.abs(A @ sol.x - b).max() < 1e-6
+
+
+def test_gapp_on_the_reference_test(oracle):
+    """testfeasibility.jl:36-44 runs GAPP(eps=1e-8, verbose=0, proji=50) -- `proji` is not the keyword (`iproj`), so the search interval stays
+    100 -- and expects :Optimal with |A x - b| < 1e-6; the search prints 21 test norms and the chosen step (gapproj.jl:51,57)."""
+    orc = oracle
+    A, b, prob = _problem(orc, m=80, n=100)
+    lines = []
+    sol, _ = orc.feasibility_solve(prob, orc.GAPP(eps=1e-8, verbose=0, proji=50, out=lines))
+    assert sol.status == "Optimal" and sol.x.min() > -1e-9 and np.abs(A @ sol.x - b).max() < 1e-6
+    assert sum(l.startswith("normtest: ") for l in lines) == 21 * (sol.iterations // 100)
+    # a search step never leaves the affine set: x_new = P_S2-relaxed point built from tmp1 + a res with tmp1, res in S1 - S1
+    alg = GAPP(orc, iproj=3, out=[])
+    model = orc.FeasibilityModel(prob, alg)
+    st = orc.FeasibilityStatus(model, 10 ** 9, 0.0, 0, 0)
+    x = np.zeros(prob.n)
+    for i in (1, 2, 3):
+        st.i = i
+        alg.step(x, i, st)
+    assert alg.log and alg.log[0][0] == 3 and len(alg.log[0][1]) == 21 and alg.log[0][2] in [2.0 ** k for k in range(21)]

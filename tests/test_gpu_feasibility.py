@@ -6,7 +6,7 @@ solution), the assertions of the reference's own test (test/testfeasibility.jl),
 import numpy as np
 import pytest
 
-from feasibility_cases import ALGS, MIXED_CONES, affine_box_instance, cone_instance
+from feasibility_cases import ALGS, GAPP, MIXED_CONES, affine_box_instance, cone_instance
 
 pytestmark = pytest.mark.gpu
 
@@ -219,3 +219,35 @@ def test_affine_cone_feasibility_matches_oracle(pkg, oracle, algname):
         proj = np.empty(n)
         K.prox(proj, sol.x)
         assert np.abs(proj - sol.x).max() <= 1e-6 and np.abs(A @ sol.x - b).max() <= 1e-5      # in the cone product and on the affine set
+
+
+def test_gapp_matches_oracle(pkg, oracle):
+    """GAPP (solvers/gapproj.jl) on the Feasibility form: GAP steps and two projected searches against the oracle (iterates, the 21 test
+    norms, the chosen step), then the whole solve of test/testfeasibility.jl:36-44."""
+    orc = oracle
+    A, b, hp, op = _problems(pkg, orc, m=80, n=100)
+    oalg = GAPP(orc, iproj=4, out=[])
+    omodel = orc.FeasibilityModel(op, oalg)
+    ost = orc.FeasibilityStatus(omodel, 10 ** 9, 1e-30, 0, 1)
+    d = pkg.HipFeasibility(hp)
+    d.set_alg(GAPP(pkg, iproj=4))
+    d.set_iterate(None)
+    xo = np.zeros(op.n)
+    for i in range(1, 11):
+        ost.i = i
+        oalg.step(xo, i, ost)
+        d.step(i, 1, 10 ** 9, 1e-30)
+        assert np.abs(d.get_iterate() - xo).max() <= 1e-10 * max(1.0, np.abs(xo).max()), i
+        if i % 4 == 0:
+            it, tests, abest = d.gapp_log()
+            oi, otests, oabest = oalg.log[-1]
+            assert it == oi == i and abest == oabest and np.allclose(tests, otests, rtol=1e-7, atol=1e-11)
+    out = []
+    sol, model = pkg.solve_feasibility(hp, pkg.GAPP(eps=1e-8, verbose=0), out=out)
+    osol, _ = orc.feasibility_solve(op, orc.GAPP(eps=1e-8, verbose=0, out=[]))
+    assert sol.status == osol.status == "Optimal" and abs(sol.iterations - osol.iterations) <= 100
+    assert sol.x.min() > -1e-9 and np.abs(A @ sol.x - b).max() < 1e-6
+    assert sum(l.startswith("normtest: ") for l in out) == 21 * (sol.iterations // 100)
+    with pytest.raises(pkg.lib.FosError):                      # not an algorithm of the HSDE path
+        prob = pkg.workloads.small_mixed()
+        pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2).set_alg(pkg.GAPP())
