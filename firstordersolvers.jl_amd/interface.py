@@ -687,6 +687,8 @@ class IndAffine:
     """ProximalOperators.IndAffine(A, b): {x : A x = b}, dense A (m x n, full row rank)."""
 
     def __init__(self, A, b):
+        if sp.issparse(A):                                              # (a sparse A is handed over dense: the projector is dense anyway)
+            A = A.toarray()
         self.A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
         self.b = np.ascontiguousarray(np.asarray(b, dtype=np.float64))
         if self.A.ndim != 2 or self.b.shape != (self.A.shape[0],):
