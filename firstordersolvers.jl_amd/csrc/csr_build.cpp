@@ -192,9 +192,11 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
 
     const int64_t nrows = n + m;
     const bool compress = getenv("FOS_NO_INDEX_COMPRESSION") == nullptr;
-    // row-sharded operators (fos_internal.hpp): every row of A' is finished from ONE partial slot that is summed over the ranks
-    // first, so those rows use the deferred-row machinery; no dual tiles, no window panels
-    const bool tiles_on = compress && getenv("FOS_NO_TILES") == nullptr && !row_sharded;
+    // row-sharded operators (fos_internal.hpp): every row of A' is finished from its partial sum over the ranks, so those rows use
+    // the deferred-row machinery -- ONE slot per row without dual tiles; with them (dense rectangles of A stored once) the row's local
+    // slot list is added up first (slots_compact_kernel) and the n sums cross the ranks.  No window panels.
+    const bool tiles_on = compress && getenv("FOS_NO_TILES") == nullptr &&
+                          (!row_sharded || !(getenv("FOS_ROW_SHARDED_TILES") && atoi(getenv("FOS_ROW_SHARDED_TILES")) == 0));
     if (row_sharded) window_mode = 0;
 
     // ---- rows of A: length, first column, and whether the columns are consecutive ("run": dense blocks, banded rows)
@@ -321,7 +323,7 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     std::vector<int32_t> ndef_slots;                        // per row: slots it will sum (0: not deferred)
     std::vector<uint8_t> skip(nrows, 0);                    // rows the ordinary row blocks do not contain
     S.row_sharded = row_sharded;
-    if (row_sharded) {
+    if (row_sharded && !have_tiles) {
         S.row_defer.assign(nrows, -1);
         ndef_slots.assign(nrows, 0);
         for (int64_t j = 0; j < n; ++j) {
@@ -345,7 +347,7 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             }
         }
         for (int64_t j = 0; j < n; ++j) {
-            if (ndef_slots[j] == 0) continue;
+            if (ndef_slots[j] == 0 && !row_sharded) continue;    // (row-sharded: EVERY row of A' waits for the other ranks' shares)
             if (rp[j + 1] == rp[j]) { S.row_defer[j] = -2; skip[j] = 1; }
             else { S.row_defer[j] = 0; ndef_slots[j] += 1; }      // slot number assigned below
         }
@@ -581,7 +583,7 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             }
         }
     }
-    if (row_sharded) {
+    if (row_sharded && !have_tiles) {
         S.def_ptr.push_back(0);
         for (int64_t j = 0; j < n; ++j) {
             S.def_rows.push_back((int32_t)j);
@@ -613,7 +615,7 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         }
         S.def_ptr.push_back(0);
         for (int64_t q = 0; q < nrows; ++q) {
-            if (ndef_slots[q] == 0) continue;
+            if (ndef_slots[q] == 0 && !(row_sharded && q < n)) continue;      // (row-sharded: a row of A' without local entries has an empty list)
             if (cur[q] != lp[q + 1]) { set_error("internal: slot list of row %lld incomplete", (long long)q); return FOS_EINVAL; }
             S.def_rows.push_back((int32_t)q);
             S.def_idx.insert(S.def_idx.end(), idx.begin() + lp[q], idx.begin() + lp[q + 1]);

@@ -271,6 +271,8 @@ struct VecBox {
     int64_t timeout_ticks;
 };
 void launch_vec_exchange(const LaunchCtx& c, const VecBox& vb, uint32_t seq, const double* slots, double* slots_rd);
+// row-sharded + dual tiles: the local slot lists of the rows of A' -> one partial sum per row (kernels.hip)
+void launch_slots_compact(const LaunchCtx& c, int nrows, const DefRow* rec, const int32_t* idx, int lpr, const double* slots, double* out);
 
 // ---------------------------------------------------------------------------------- kernel launchers (kernels.hip / psd.hip)
 struct LaunchCtx {

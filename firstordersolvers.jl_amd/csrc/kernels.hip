@@ -674,6 +674,9 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
 //   so whoever WRITES a slot adds its term (park), and the slot-free part is added once per deferred row by kkt_deferred_local.
 template <class G, bool FOLD>
 struct EpiKkt {
+    struct AccKeep { double v[3]; };
+    __device__ __forceinline__ AccKeep acc_copy() const { AccKeep k; for (int a = 0; a < 3; ++a) k.v[a] = acc[a]; return k; }
+    __device__ __forceinline__ void acc_restore(const AccKeep& k) { for (int a = 0; a < 3; ++a) acc[a] = k.v[a]; }
     static constexpr bool FOLDDEF = FOLD;
     G gat;
     d2* out;
@@ -738,7 +741,8 @@ struct KktArgs {
     int j;                     // FUSEP: this iteration (>= 2)
     PeerBox pb;                // FUSEP: nranks > 0 -> the r.r exchange happens here (peer mailboxes)
     uint32_t seq_base;
-    int count_repl;            // FOLD: 0 = the slot-free part of the slot-spread rows is counted by another rank (row-sharded)
+    int count_repl;            // FOLD: 0 = the slot-free part of the replicated slot-spread rows is counted by another rank (row-sharded)
+    int n_repl;                // rows below it are replicated (row-sharded: the n rows of A'; else 0)
     // merged-reduction CG (fos_internal.hpp, CgmIter): the sweep applies M to r
     double* vt_out;            // non-null: workgroup 0 stashes the applied vector's tau element here (DevState.vtau)
     int close_j;               // >= 0: close iteration close_j first (r.r records of its update, stop test) and return when CG has stopped (plain_args: -1)
@@ -774,8 +778,12 @@ __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBl
         if (blockIdx.x == 0 && threadIdx.x == 0) a.pnew[a.nm] = epi.wt;          // the tau element has no row in S
     }
     if constexpr (FOLD) {
-        if (a.count_repl) {
-            for (int q = blockIdx.x * SPMV_THREADS + threadIdx.x; q < S.ndef; q += gridDim.x * SPMV_THREADS) epi.deferred_local(S.def_rows[q]);
+        if (a.count_repl || S.ndef > a.n_repl) {          // (row-sharded: the replicated rows' slot-free part is counted by one rank)
+            for (int q = blockIdx.x * SPMV_THREADS + threadIdx.x; q < S.ndef; q += gridDim.x * SPMV_THREADS) {
+                const int i = S.def_rows[q];
+                if (a.count_repl || i >= a.n_repl) epi.deferred_local(i);
+                else if constexpr (FUSEP) a.pnew[i] = gat.load(i);
+            }
         } else if constexpr (FUSEP) {            // (p_new of those rows must still be stored)
             for (int q = blockIdx.x * SPMV_THREADS + threadIdx.x; q < S.ndef; q += gridDim.x * SPMV_THREADS) { const int i = S.def_rows[q]; a.pnew[i] = gat.load(i); }
         }
@@ -814,8 +822,10 @@ static void launch_kkt2_win(const LaunchCtx& c, const KktArgs& a) {
 // row's slots in list order, then the fixed DPP butterfly -- long slot lists (a dense LP: one partial per 64-row tile) are
 // latency bound with one thread per row.  Used by the stand-alone applies (CG start, rhs build, status, test entries); inside
 // a CG iteration cg_update_kernel does the same sums itself.
+// (row-sharded: rows below n_repl -- the rows of A' -- are replicated and counted in the scalar sums by ONE rank (count != 0); the
+// rows of A that are spread over column chunks are local and always counted)
 template <class Epi>
-__device__ __forceinline__ void deferred_rows(const DevBlkCsr& S, Epi& epi) {
+__device__ __forceinline__ void deferred_rows(const DevBlkCsr& S, Epi& epi, int n_repl = 0, int count = 1) {
     const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots_rd);
     const int lpr = S.def_lpr, sh = 31 - __clz(lpr);
     const int rows_per_pass = (gridDim.x * DEF_THREADS) >> sh;
@@ -833,7 +843,14 @@ __device__ __forceinline__ void deferred_rows(const DevBlkCsr& S, Epi& epi) {
         if (ok) slot_list_sum(slots, S.def_idx, dr, lig, lpr, u1, u2);
         u1 = group_sum(u1, lpr);
         u2 = group_sum(u2, lpr);
-        if (ok && lig == 0) epi.row(row, u1, u2, pr);
+        if (ok && lig == 0) {
+            if (count || row >= n_repl) epi.row(row, u1, u2, pr);
+            else {                                       // finished, but its share of the sums belongs to another rank
+                auto keep = epi.acc_copy();
+                epi.row(row, u1, u2, pr);
+                epi.acc_restore(keep);
+            }
+        }
     }
 }
 // The sweep left nwg partial-sum records; the deferred-row kernel runs after it anyway, so each of its nwg_def workgroups
@@ -854,10 +871,35 @@ __global__ __launch_bounds__(DEF_THREADS) void kkt2_deferred_kernel(DevBlkCsr S,
     EpiKkt<GatherW, false> epi;
     epi.gat.w = w; epi.out = out; epi.pnew = nullptr; epi.cb = cb; epi.n = n; epi.wt = w[nm];
     epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
-    deferred_rows(S, epi);
-    if (!count) epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;      // row-sharded: these rows are replicated, another rank counts them
+    deferred_rows(S, epi, n, count);
     fold_sweep_records<3>(S, partials, epi.acc);
     block_reduce_store<3, DEF_THREADS>(epi.acc, red, partials + 3 * (int64_t)(S.nwg + blockIdx.x));
+}
+
+// Row-sharded operators with dual tiles: the LOCAL slot list of every row of A' (its own partial + the column sums of the tiles
+// above it, list order) -> one partial sum per row, the n-vector that crosses the ranks (solver.cpp, sum_slots_over_ranks).
+__global__ __launch_bounds__(DEF_THREADS) void slots_compact_kernel(int nrows, const DefRow* __restrict__ rec, const int32_t* __restrict__ idx,
+                                                                    const d2* __restrict__ slots, d2* __restrict__ out, int lpr) {
+    const int sh = 31 - __clz(lpr);
+    const int rows_per_pass = (gridDim.x * DEF_THREADS) >> sh;
+    const int lig = threadIdx.x & (lpr - 1);
+    const int npass = (nrows + rows_per_pass - 1) / rows_per_pass;            // uniform trip count: the DPP sums need full waves
+    int q = (blockIdx.x * DEF_THREADS + threadIdx.x) >> sh;
+    for (int pass = 0; pass < npass; ++pass, q += rows_per_pass) {
+        const bool ok = q < nrows;
+        DefRow dr{};
+        if (ok) dr = ld_defrow(rec + q);
+        double u1 = 0.0, u2 = 0.0;
+        if (ok) slot_list_sum(slots, idx, dr, lig, lpr, u1, u2);
+        u1 = group_sum(u1, lpr);
+        u2 = group_sum(u2, lpr);
+        if (ok && lig == 0) out[dr.row] = make_double2(u1, u2);
+    }
+}
+void launch_slots_compact(const LaunchCtx& c, int nrows, const DefRow* rec, const int32_t* idx, int lpr, const double* slots, double* out) {
+    const int grid = (int)std::min<int64_t>(DEF_MAX_WG, ((int64_t)nrows * lpr + DEF_THREADS - 1) / DEF_THREADS);
+    hipLaunchKernelGGL(slots_compact_kernel, dim3(std::max(grid, 1)), dim3(DEF_THREADS), 0, c.stream, nrows, rec, idx, reinterpret_cast<const d2*>(slots),
+                       reinterpret_cast<d2*>(out), lpr);
 }
 
 constexpr int FIN_THREADS = 1024;
@@ -1008,7 +1050,7 @@ __global__ __launch_bounds__(SPMV_THREADS) void cg_stop_check_kernel(KktArgs a) 
 static KktArgs plain_args(const LaunchCtx& c, const double2* w, double2* out, int gate) {
     KktArgs a{};
     a.w = w; a.out = out; a.cb = c.cb; a.n = (int)c.n; a.nm = (int)(c.n + c.m); a.partials = c.partials; a.st = c.st; a.gate = gate;
-    a.count_repl = c.count_repl;
+    a.count_repl = c.count_repl; a.n_repl = (int)c.n_repl;
     a.close_j = -1;
     return a;
 }
@@ -1108,6 +1150,9 @@ void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int
 // ------------------------------------------------------------------------------------------------ single RHS Q apply
 
 struct EpiQPlain {
+    struct AccKeep { double v[1]; };
+    __device__ __forceinline__ AccKeep acc_copy() const { AccKeep k; for (int a = 0; a < 1; ++a) k.v[a] = acc[a]; return k; }
+    __device__ __forceinline__ void acc_restore(const AccKeep& k) { for (int a = 0; a < 1; ++a) acc[a] = k.v[a]; }
     static constexpr bool FOLDDEF = false;
     __device__ __forceinline__ void park(int, double, double, const d2&) {}     // out_plain[i] = sign * (Q v)_i ; acc[0] = [c;b].v
     const double* vcomp; double* out; const double* cb; int n; double vt, sign; double acc[1];
@@ -1121,6 +1166,9 @@ struct EpiQPlain {
     }
 };
 struct EpiQRhs {
+    struct AccKeep { double v[1]; };
+    __device__ __forceinline__ AccKeep acc_copy() const { AccKeep k; for (int a = 0; a < 1; ++a) k.v[a] = acc[a]; return k; }
+    __device__ __forceinline__ void acc_restore(const AccKeep& k) { for (int a = 0; a < 1; ++a) acc[a] = k.v[a]; }
     static constexpr bool FOLDDEF = false;
     __device__ __forceinline__ void park(int, double, double, const d2&) {}       // out[i] = (x1_i - (Q x2)_i, 0)      affinepluslinear.jl:94-95 (beta = 1, q = 0, rhs2 = b = 0)
     const d2* x; d2* out; const double* cb; int n; double vt; double acc[1];
@@ -1135,6 +1183,9 @@ struct EpiQRhs {
     }
 };
 struct EpiQVfromU {
+    struct AccKeep { double v[1]; };
+    __device__ __forceinline__ AccKeep acc_copy() const { AccKeep k; for (int a = 0; a < 1; ++a) k.v[a] = acc[a]; return k; }
+    __device__ __forceinline__ void acc_restore(const AccKeep& k) { for (int a = 0; a < 1; ++a) acc[a] = k.v[a]; }
     static constexpr bool FOLDDEF = false;
     __device__ __forceinline__ void park(int, double, double, const d2&) {}    // out[i] = (y_i.x, (Q y.x)_i)        HSDEAffine.jl:122-124  v = Q u
     const d2* y; d2* out; const double* cb; int n; double vt; double acc[1];
@@ -1149,6 +1200,9 @@ struct EpiQVfromU {
     }
 };
 struct EpiQStatus {
+    struct AccKeep { double v[6]; };
+    __device__ __forceinline__ AccKeep acc_copy() const { AccKeep k; for (int a = 0; a < 6; ++a) k.v[a] = acc[a]; return k; }
+    __device__ __forceinline__ void acc_restore(const AccKeep& k) { for (int a = 0; a < 6; ++a) acc[a] = k.v[a]; }
     static constexpr bool FOLDDEF = false;
     __device__ __forceinline__ void park(int, double, double, const d2&) {}    // residual sums of checkstatus  HSDEStatus.jl:34-38,59,61  (z = [x;y;tau | r;s;kappa] interleaved)
     const d2* z; const double* cb; int n; double tau; double acc[6];
@@ -1186,16 +1240,12 @@ __global__ __launch_bounds__(SPMV_THREADS) void q1_kernel(DevBlkCsr S, const dou
 }
 template <class Epi, int NACC>
 __global__ __launch_bounds__(DEF_THREADS) void q1_deferred_kernel(DevBlkCsr S, const double* __restrict__ vcomp, Epi epi, int nm,
-                                                                  double* __restrict__ partials, int count) {
+                                                                  double* __restrict__ partials, int count, int n_repl) {
     __shared__ double red[8 * NACC > 16 ? 8 * NACC : 16];
 #pragma unroll
     for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
     epi.init(vcomp[2 * (int64_t)nm]);
-    deferred_rows(S, epi);
-    if (!count) {
-#pragma unroll
-        for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
-    }
+    deferred_rows(S, epi, n_repl, count);
     fold_sweep_records<NACC>(S, partials, epi.acc);
     block_reduce_store<NACC, DEF_THREADS>(epi.acc, red, partials + NACC * (int64_t)(S.nwg + blockIdx.x));
 }
@@ -1222,7 +1272,7 @@ static void launch_q1_kernels(const LaunchCtx& c, const double* vcomp, const Epi
     if (c.S.ndef > 0) {
         hipLaunchKernelGGL((q1_kernel<Epi, NACC, true>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
         if (c.between) (void)c.between(c.between_arg);
-        hipLaunchKernelGGL((q1_deferred_kernel<Epi, NACC>), dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, vcomp, e, nm, c.partials, (int)c.count_repl);
+        hipLaunchKernelGGL((q1_deferred_kernel<Epi, NACC>), dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, vcomp, e, nm, c.partials, (int)c.count_repl, (int)c.n_repl);
     } else {
         hipLaunchKernelGGL((q1_kernel<Epi, NACC, false>), grid, block, 0, c.stream, c.S, vcomp, e, nm, c.partials);
     }

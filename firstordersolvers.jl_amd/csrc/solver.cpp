@@ -226,6 +226,13 @@ struct fos_solver {
     static constexpr size_t PROF_CAP = 16384;
 
     static int sum_slots_over_ranks(void* self);      // defined below (needs the RCCL table)
+    // row-sharded WITH dual tiles: the sweep fills local slot lists (S.slots = slots_rd + 2n doubles); between sweep and consumers the
+    // lists of the n rows of A' are added up (cmp_rec / cmp_idx -> cmp_local) and THAT n-vector crosses the ranks into slots_rd[0..n);
+    // the consumers' records (S.def_rec) name slot j for row j < n and the local lists, shifted by n, for the rows of A
+    DefRow* cmp_rec = nullptr;
+    int32_t* cmp_idx = nullptr;
+    double* cmp_local = nullptr;
+    int cmp_lpr = 1;
 
     LaunchCtx ctx() const {
         LaunchCtx c;
@@ -256,15 +263,20 @@ static int host_allreduce(fos_solver* h, const double* src, double* dst, size_t 
 
 int fos_solver::sum_slots_over_ranks(void* self) {
     fos_solver* h = static_cast<fos_solver*>(self);
-    if (h->host_fn) return host_allreduce(h, h->S.slots, h->slots_rd, (size_t)2 * (size_t)h->n);
+    const double* src = h->S.slots;            // one slot per row of A' ...
+    if (h->cmp_local) {                        // ... or, with dual tiles, the rows' local slot lists added up first
+        launch_slots_compact(h->ctx(), (int)h->n, h->cmp_rec, h->cmp_idx, h->cmp_lpr, h->S.slots, h->cmp_local);
+        src = h->cmp_local;
+    }
+    if (h->host_fn) return host_allreduce(h, src, h->slots_rd, (size_t)2 * (size_t)h->n);
     if (h->peer_on && h->vec.buf) {            // peer-mapped memory: push + sum, in stream, no library call
-        launch_vec_exchange(h->ctx(), h->vec, ++h->vec_seq, h->S.slots, h->slots_rd);
+        launch_vec_exchange(h->ctx(), h->vec, ++h->vec_seq, src, h->slots_rd);
         return FOS_OK;
     }
     if (!h->comm) {            // no communicator yet (set-up calls before fos_comm_init, or a single process): the sum is the copy
-        return hipMemcpyAsync(h->slots_rd, h->S.slots, sizeof(double) * 2 * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream) == hipSuccess ? FOS_OK : FOS_EHIP;
+        return hipMemcpyAsync(h->slots_rd, src, sizeof(double) * 2 * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream) == hipSuccess ? FOS_OK : FOS_EHIP;
     }
-    return g_rccl.AllReduce(h->S.slots, h->slots_rd, (size_t)2 * (size_t)h->n, ncclDouble, ncclSum, h->comm, h->stream) == ncclSuccess ? FOS_OK : FOS_ECOMM;
+    return g_rccl.AllReduce(src, h->slots_rd, (size_t)2 * (size_t)h->n, ncclDouble, ncclSum, h->comm, h->stream) == ncclSuccess ? FOS_OK : FOS_ECOMM;
 }
 
 namespace {
@@ -1095,18 +1107,58 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
         FOS_TRY(dev_upload(h, &ddp, hs.def_ptr));
         FOS_TRY(dev_upload(h, &ddi, hs.def_idx));
         DefRow* ddrec = nullptr;
-        FOS_TRY(dev_upload(h, &ddrec, hs.def_rec));
-        h->S.def_rec = ddrec;
-        FOS_TRY(dev_alloc(h, &dsl, (size_t)2 * hs.nslots));
-        FOS_HIP(hipMemset(dsl, 0, sizeof(double) * 2 * hs.nslots));
-        h->S.slots = dsl; h->S.slots_rd = dsl; h->S.row_defer = drd; h->S.def_rows = ddr; h->S.def_ptr = ddp; h->S.def_idx = ddi;
-        if (h->row_sharded) {                      // the all-reduced copy the slot-list sums read
-            FOS_TRY(dev_alloc(h, &h->slots_rd, (size_t)2 * hs.nslots));
-            FOS_HIP(hipMemset(h->slots_rd, 0, sizeof(double) * 2 * hs.nslots));
+        double avg_list = (double)hs.def_ptr.back() / (double)h->S.ndef;
+        const bool rs_tiles = h->row_sharded && hs.ntiles > 0;
+        if (!rs_tiles) {
+            FOS_TRY(dev_upload(h, &ddrec, hs.def_rec));
+            h->S.def_rec = ddrec;
+            FOS_TRY(dev_alloc(h, &dsl, (size_t)2 * hs.nslots));
+            FOS_HIP(hipMemset(dsl, 0, sizeof(double) * 2 * hs.nslots));
+            h->S.slots = dsl; h->S.slots_rd = dsl; h->S.row_defer = drd; h->S.def_rows = ddr; h->S.def_ptr = ddp; h->S.def_idx = ddi;
+            if (h->row_sharded) {                      // the all-reduced copy the slot-list sums read
+                FOS_TRY(dev_alloc(h, &h->slots_rd, (size_t)2 * hs.nslots));
+                FOS_HIP(hipMemset(h->slots_rd, 0, sizeof(double) * 2 * hs.nslots));
+                h->S.slots_rd = h->slots_rd;
+            }
+        } else {
+            // Two views of the builder's lists (fos_solver::cmp_rec).  The builder lists the n rows of A' first (rows ascending).
+            const size_t nn = (size_t)h->n;
+            if (hs.def_rows.size() < nn || hs.def_rows[nn - 1] != (int32_t)(nn - 1)) { set_error("internal: row-sharded tile operator without all rows of A' deferred"); return FOS_EINVAL; }
+            // (1) what slots_compact_kernel adds up: the records of rows 0..n-1 as built, over the sweep's slot array
+            std::vector<DefRow> crec(hs.def_rec.begin(), hs.def_rec.begin() + nn);
+            FOS_TRY(dev_upload(h, &h->cmp_rec, crec));
+            h->cmp_idx = ddi;
+            double lsum = 0.0;
+            for (size_t q = 0; q < nn; ++q) lsum += (double)(hs.def_ptr[q + 1] - hs.def_ptr[q]);
+            int clpr = 1;
+            while (clpr < 64 && 4.0 * clpr < lsum / (double)nn) clpr <<= 1;
+            h->cmp_lpr = clpr;
+            FOS_TRY(dev_alloc(h, &h->cmp_local, 2 * nn));
+            FOS_HIP(hipMemset(h->cmp_local, 0, sizeof(double) * 2 * nn));
+            // (2) what the consumers read, over slots_rd = [n summed rows | the sweep's slot array]: row j < n -> the single slot j;
+            //     rows of A spread over column chunks -> their local lists, shifted by n
+            std::vector<DefRow> vrec(hs.def_rec);
+            std::vector<int32_t> vidx(hs.def_idx.size() + nn);
+            for (size_t k = 0; k < hs.def_idx.size(); ++k) vidx[k] = hs.def_idx[k] + (int32_t)nn;
+            for (size_t j = 0; j < nn; ++j) vidx[hs.def_idx.size() + j] = (int32_t)j;
+            for (size_t q = 0; q < vrec.size(); ++q) {
+                DefRow& d = vrec[q];
+                if (q < nn) { d.own = -1; d.count = 1; d.base = (int32_t)q; d.stride = getenv("FOS_DEF_EXPLICIT") ? DEF_EXPLICIT : 0; d.kidx = (int32_t)(hs.def_idx.size() + q); }
+                else { if (d.own >= 0) d.own += (int32_t)nn; d.base += (int32_t)nn; }
+            }
+            FOS_TRY(dev_upload(h, &ddrec, vrec));
+            h->S.def_rec = ddrec;
+            int32_t* dvi = nullptr;
+            FOS_TRY(dev_upload(h, &dvi, vidx));
+            FOS_TRY(dev_alloc(h, &h->slots_rd, 2 * (nn + (size_t)hs.nslots)));
+            FOS_HIP(hipMemset(h->slots_rd, 0, sizeof(double) * 2 * (nn + (size_t)hs.nslots)));
             h->S.slots_rd = h->slots_rd;
+            h->S.slots = h->slots_rd + 2 * nn;
+            h->S.row_defer = drd; h->S.def_rows = ddr; h->S.def_ptr = ddp; h->S.def_idx = dvi;
+            // consumers: one slot per row of A', the lists of the rows of A
+            avg_list = ((double)nn + ((double)hs.def_ptr.back() - lsum)) / (double)h->S.ndef;
         }
         // lanes per deferred row: about a quarter of the average slot-list length (C4: 33 slots -> 8 lanes, dense LP: 80 -> 16)
-        const double avg_list = (double)hs.def_ptr.back() / (double)h->S.ndef;
         int lpr = 1;
         while (lpr < 64 && 4.0 * lpr < avg_list) lpr <<= 1;
         if (getenv("FOS_DEF_LPR")) lpr = std::max(1, std::min(64, atoi(getenv("FOS_DEF_LPR"))));
@@ -2015,7 +2067,8 @@ int fos_host_stacked_spmv_mode(int64_t m, int64_t n, const int64_t* colptr, cons
                                const double* v, double* out, int32_t window_mode, int64_t* stats16) {
     if (!colptr || !v || !out || m < 0 || n < 0) { set_error("bad argument"); return FOS_EINVAL; }
     HostBlkCsr S;
-    FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, 1024, &S, 0, window_mode));
+    const bool rs = getenv("FOS_HOST_SPMV_ROW_SHARDED") && atoi(getenv("FOS_HOST_SPMV_ROW_SHARDED")) != 0;      // (tests: the row-sharded builder)
+    FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, 1024, &S, 0, window_mode, rs));
     std::string why;
     int rc = host_stacked_spmv(S, v, out, &why);
     if (rc != FOS_OK) { set_error("operator format check failed: %s", why.c_str()); return rc; }

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cg_update_kernel(int64_t l, d2* _
                 if constexpr (XUPD) { xi.x += alpha * pi.x; xi.y += alpha * pi.y; x[row] = xi; }
                 ri.x -= alpha * a1; ri.y -= alpha * a2;
                 r[row] = ri;
-                if (count_repl) acc[0] += ri.x * ri.x + ri.y * ri.y;       // (row-sharded: replicated rows are counted by one rank)
+                if (count_repl || row >= n) acc[0] += ri.x * ri.x + ri.y * ri.y;       // (row-sharded: the replicated rows -- those of A' -- are counted by one rank)
             }
         }
       }
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(VEC_THREADS, 3) void cgm_update_kernel(CgmArgs a, D
                 else { q1 = -(u1 - vtx * c); q2 = -(u2 - vty * c); }
                 const d2 wi = make_double2(ri.x - q2, q1 - ri.y);
                 const double rr = upd(row, wi, ri, pi, si, xi);
-                if (a.count_repl) acc[0] += rr;                  // (row-sharded: replicated rows are counted by one rank)
+                if (a.count_repl || row >= a.n) acc[0] += rr;    // (row-sharded: the replicated rows -- those of A' -- are counted by one rank)
             }
         }
     }
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(VEC_THREADS) void cgm_start_kernel(CgmStartArgs a, 
                 const d2 ri = make_double2(bi.x - (vi.x - q2), bi.y - (q1 - vi.y));       // r = b - Ap      :33
                 a.r[row] = ri;
                 if (a.p) a.p[row] = ri;
-                if (a.count_repl) acc[0] += ri.x * ri.x + ri.y * ri.y;
+                if (a.count_repl || row >= a.n) acc[0] += ri.x * ri.x + ri.y * ri.y;
             }
         }
     }

@@ -287,19 +287,38 @@ def test_missing_peer_times_out_with_error(pkg):
         ghost.close()
 
 
-def test_row_sharded_single_rank_matches_unsharded(pkg, oracle):
+def _rows_problem(pkg, name):
+    """"mixed": sparse A that couples everything (row blocks, one slot per row of A'); "dense": dense rows of A (dual tiles: A stored
+    once, every row of A' finished from its local slot list summed first) under a mix of cones."""
+    if name == "mixed":
+        return pkg.workloads.small_mixed()
+    import scipy.sparse as sp
+    rng = np.random.default_rng(21)
+    K1 = [("NonNeg", 70), ("SOC", 24), ("SOC", 30), ("NonNeg", 40), ("SDP", 36), ("Zero", 20)]
+    m, n = sum(l for _, l in K1), 150
+    A = rng.standard_normal((m, n)) / 10.0
+    A[:, 140:] = 0.0
+    A[200:, :] = A[200:, :] * (rng.random((m - 200, n)) < 0.2)       # the last rows sparse: row blocks next to the tiles
+    return pkg.workloads.from_complementary_pair("dense-rows", sp.csc_matrix(A), K1, [("Free", 100), ("NonNeg", 50)], rng)
+
+
+@pytest.mark.parametrize("pname", ["mixed", "dense"])
+def test_row_sharded_single_rank_matches_unsharded(pkg, oracle, pname):
     """SURVEY 8(f2) plumbing on ONE rank (what a one-GPU box can run): a row-sharded handle -- every row of A' finished from a
     partial slot that passes through the all-reduce buffer, replicated-entry counting, RCCL communicator of size 1 -- must
     reproduce the ordinary handle: operators to rounding, whole solves to the same status / iteration count / solution.
     (The multi-rank sums are checked at the oracle level by tests/test_sharding_gloo.py::test_row_sharded_oracle_matches_unsharded;
     the row-sharded HIP path has never run on two GPUs.)"""
-    prob = pkg.workloads.small_mixed()
+    prob = _rows_problem(pkg, pname)
     d0 = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     d1 = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2, row_sharded=True)
     for d in (d0, d1):
         d.set_cg_variant("merged_update")        # what a sharded handle runs by default; d1 has no communicator in the first stage
     st = d1.operator_stats()
-    assert st["deferred"] == prob.n and st["tiles"] == 0
+    if pname == "mixed":
+        assert st["deferred"] == prob.n and st["tiles"] == 0
+    else:                                        # dual tiles: A stored once, all n rows of A' (+ rows of A cut into column chunks) deferred
+        assert st["tiles"] > 0 and st["deferred"] >= prob.n and st["slots"] > prob.n and st["vals"] < 1.2 * prob.A.nnz
     rng = np.random.default_rng(3)
     z = rng.standard_normal(d0.N)
     for stage in ("no communicator", "1-rank RCCL communicator"):
@@ -332,7 +351,7 @@ def test_row_sharded_single_rank_matches_unsharded(pkg, oracle):
     d1.close()
 
 
-def _worker_rows(rank, world, port, algname, iters, q, transport="host"):
+def _worker_rows(rank, world, port, algname, iters, q, transport="host", pname="mixed"):
     """One rank of a row-sharded solve; both processes share cuda:0.  transport = "host": the cross-rank sums go through gloo
     (fos_comm_init_host); "peer": through peer-mapped memory, in stream -- the scalars through the mailboxes, the n-vector A'y
     through the exchange buffers of fos_peer_vec_* (gloo only carries the IPC handles)."""
@@ -346,7 +365,7 @@ def _worker_rows(rank, world, port, algname, iters, q, transport="host"):
     pkg = ge.load_package()
     try:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        prob = pkg.workloads.small_mixed()
+        prob = _rows_problem(pkg, pname)
         sh = pkg.sharding.shard_rows(prob, world, rank)
         lp = sh.problem
         dev = pkg.HipHSDE(lp.A, lp.b, lp.c, lp.K1, lp.K2, row_sharded=True)
@@ -393,8 +412,9 @@ def _worker_rows(rank, world, port, algname, iters, q, transport="host"):
         q.put((rank, "error: " + repr(exc) + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("algname,transport", [("DR", "host"), ("GAPA", "host"), ("DR", "peer"), ("GAPA", "peer")])
-def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname, transport):
+@pytest.mark.parametrize("algname,transport,pname", [("DR", "host", "mixed"), ("GAPA", "host", "mixed"), ("DR", "peer", "mixed"), ("GAPA", "peer", "mixed"),
+                                                     ("DR", "host", "dense"), ("GAPA", "peer", "dense")])
+def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname, transport, pname):
     """SURVEY 8(f2) with TWO ranks on the one GPU of the test box: each process holds the rows of half of the K1 cones of a
     problem whose A couples everything (workloads.small_mixed), the n-vector A'y and every scalar sum cross the processes
     through the caller's collective (fos_comm_init_host, here gloo).  Replicated parts bitwise identical on both ranks; the
@@ -412,7 +432,7 @@ def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname, transport
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_rows, args=(r, world, port, algname, iters, q, transport)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_rows, args=(r, world, port, algname, iters, q, transport, pname)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -428,7 +448,7 @@ def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname, transport
         for p in procs:
             if p.is_alive():
                 p.kill()
-    prob = pkg.workloads.small_mixed()
+    prob = _rows_problem(pkg, pname)
     shards = [pkg.sharding.shard_rows(prob, world, r) for r in range(world)]
     n = prob.n
     ls = [sh.problem.m + n + 1 for sh in shards]

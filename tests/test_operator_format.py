@@ -242,3 +242,33 @@ def test_tall_dual_tiles_stack_vertically_adjacent_groups(pkg, monkeypatch):
     assert seen[4]["tiles"] == 3 * 2 + 3 and seen[8]["tiles"] == 3 * 1 + 3
     slots = [seen[t]["slots"] for t in (1, 2, 3, 4, 8, 16)]
     assert all(a >= b for a, b in zip(slots, slots[1:])) and slots[0] > slots[3] > 0
+
+
+# ------------------------------------------------------------------------------------------------ row-sharded builder with dual tiles
+@pytest.mark.parametrize("seed", range(12))
+def test_row_sharded_builder_with_dual_tiles(pkg, monkeypatch, seed):
+    """a row-sharded rank stores the dense rectangles of its rows of A ONCE (dual tiles); every row of A' is then a
+    deferred row whose list -- own partial + tile column sums, possibly empty -- is what the device adds up before the n-vector
+    crosses the ranks.  The host emulation walks the same blocks and lists: out = S v, every row of A' deferred."""
+    monkeypatch.setenv("FOS_HOST_SPMV_ROW_SHARDED", "1")
+    rng = np.random.default_rng(2000 + seed)
+    A = _random_structured(rng)
+    m, n = A.shape
+    v = rng.standard_normal(n + m)
+    out, st = _host_spmv_mode(pkg, A, v, 0)
+    assert np.allclose(out, reference(A, v), rtol=1e-12, atol=1e-12), seed
+    monkeypatch.setenv("FOS_ROW_SHARDED_TILES", "0")            # the one-slot-per-row form of round 2
+    out0, st0 = _host_spmv_mode(pkg, A, v, 0)
+    assert np.allclose(out0, reference(A, v), rtol=1e-12, atol=1e-12) and st0[8] == 0 and st0[9] == n
+    if st[8] > 0:                                               # tiles: more slots than rows of A', fewer stored values
+        assert st[9] >= st0[9] - n and st[5] < st0[5]
+
+
+def test_row_sharded_dense_operator_uses_tiles(pkg, monkeypatch):
+    monkeypatch.setenv("FOS_HOST_SPMV_ROW_SHARDED", "1")
+    rng = np.random.default_rng(7)
+    A = sp.csc_matrix(rng.standard_normal((200, 300)))
+    v = rng.standard_normal(500)
+    out, st = _host_spmv_mode(pkg, A, v, 0)
+    assert np.allclose(out, reference(A, v), rtol=1e-12, atol=1e-12)
+    assert st[8] > 0 and st[5] <= 1.1 * A.nnz                   # A stored once (plus padding), not twice
