@@ -1012,8 +1012,102 @@ __global__ __launch_bounds__(VEC_X_THREADS) void vec_sum_kernel(VecBox vb, uint3
         slots_rd[k] = sacc;
     }
 }
+// ---- the same exchange as reduce-scatter + all-gather (three or more ranks: 2 (g-1) n / g doubles leave a rank instead of (g-1) n).
+// Rank o owns the slice [o chunk, (o+1) chunk) of the 2n doubles.  Stage 1: every rank writes its partial sums OF THAT SLICE into
+// o's buffer (region [parity][sender]); o adds them in rank order.  Stage 2: o writes the summed slice into every peer's buffer -- the
+// same region [parity][o], whose entries of o's slice stage 1 never touches -- and raises the stage-2 flag; everybody copies the
+// slices it does not own.  One sum per entry, made by its owner: the same bits on every rank, and the bits of the direct scheme.
+__device__ __forceinline__ void vec_slice(const VecBox& vb, int o, int64_t& k0, int64_t& k1) {
+    const int64_t chunk = (vb.n2 + vb.nranks - 1) / vb.nranks;
+    k0 = std::min<int64_t>(vb.n2, (int64_t)o * chunk);
+    k1 = std::min<int64_t>(vb.n2, k0 + chunk);
+}
+// raise flag `which` (0: stage 1, 1: stage 2) in every peer's flag array once the whole grid's stores have left
+__device__ __forceinline__ void vec_raise_flags(const VecBox& vb, uint32_t seq, size_t half, int which) {
+    __threadfence_system();
+    __syncthreads();
+    __shared__ int last;
+    if (threadIdx.x == 0) last = (atomicAdd(vb.counter, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (last) {
+        __threadfence_system();
+        if ((int)threadIdx.x < vb.nranks && (int)threadIdx.x != vb.rank)
+            __hip_atomic_store(vb.flags[threadIdx.x] + (size_t)which * 2 * vb.nranks + half + vb.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) *vb.counter = 0u;
+    }
+}
+// wait until every peer's flag `which` of this exchange has arrived; false (and the solve is stopped) on a time-out
+__device__ __forceinline__ bool vec_wait_flags(const VecBox& vb, uint32_t seq, size_t half, int which, DevState* st) {
+    __shared__ int failed;
+    if (threadIdx.x == 0) failed = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < vb.nranks && (int)threadIdx.x != vb.rank) {
+        const uint32_t* f = vb.flags[vb.rank] + (size_t)which * 2 * vb.nranks + half + threadIdx.x;
+        const long long t0 = wall_clock64();
+        bool ok;
+        do { ok = __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == seq; } while (!ok && (wall_clock64() - t0) < vb.timeout_ticks);
+        if (!ok) failed = 1;
+    }
+    __syncthreads();
+    if (failed) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->xchg_failed = 1; st->done = 1; } return false; }
+    return true;
+}
+__global__ __launch_bounds__(VEC_X_THREADS) void vec_rs_push_kernel(VecBox vb, uint32_t seq, const double* __restrict__ slots, DevState* st) {
+    if (st->xchg_failed) return;
+    const size_t half = (size_t)(seq & 1u) * (size_t)vb.nranks;
+    for (int o = 0; o < vb.nranks; ++o) {
+        if (o == vb.rank) continue;
+        int64_t k0, k1;
+        vec_slice(vb, o, k0, k1);
+        double* dst = vb.buf[o] + (half + (size_t)vb.rank) * (size_t)vb.n2;
+        for (int64_t k = k0 + blockIdx.x * (int64_t)VEC_X_THREADS + threadIdx.x; k < k1; k += (int64_t)gridDim.x * VEC_X_THREADS)
+            __builtin_nontemporal_store(slots[k], dst + k);
+    }
+    vec_raise_flags(vb, seq, half, 0);
+}
+__global__ __launch_bounds__(VEC_X_THREADS) void vec_rs_sum_kernel(VecBox vb, uint32_t seq, const double* __restrict__ slots,
+                                                                   double* __restrict__ slots_rd, DevState* st) {
+    if (st->xchg_failed) return;
+    const size_t half = (size_t)(seq & 1u) * (size_t)vb.nranks;
+    if (!vec_wait_flags(vb, seq, half, 0, st)) return;
+    int64_t k0, k1;
+    vec_slice(vb, vb.rank, k0, k1);
+    const double* own = vb.buf[vb.rank] + half * (size_t)vb.n2;
+    for (int64_t k = k0 + blockIdx.x * (int64_t)VEC_X_THREADS + threadIdx.x; k < k1; k += (int64_t)gridDim.x * VEC_X_THREADS) {
+        double sacc = 0.0;
+        for (int r = 0; r < vb.nranks; ++r)                  // rank order: the bits of the direct scheme
+            sacc += (r == vb.rank) ? slots[k] : __builtin_nontemporal_load(own + (size_t)r * (size_t)vb.n2 + k);
+        slots_rd[k] = sacc;
+        for (int p = 0; p < vb.nranks; ++p)
+            if (p != vb.rank) __builtin_nontemporal_store(sacc, vb.buf[p] + (half + (size_t)vb.rank) * (size_t)vb.n2 + k);
+    }
+    vec_raise_flags(vb, seq, half, 1);
+}
+__global__ __launch_bounds__(VEC_X_THREADS) void vec_ag_copy_kernel(VecBox vb, uint32_t seq, double* __restrict__ slots_rd, DevState* st) {
+    if (st->xchg_failed) return;
+    const size_t half = (size_t)(seq & 1u) * (size_t)vb.nranks;
+    if (!vec_wait_flags(vb, seq, half, 1, st)) return;
+    const double* own = vb.buf[vb.rank] + half * (size_t)vb.n2;
+    for (int o = 0; o < vb.nranks; ++o) {
+        if (o == vb.rank) continue;
+        int64_t k0, k1;
+        vec_slice(vb, o, k0, k1);
+        for (int64_t k = k0 + blockIdx.x * (int64_t)VEC_X_THREADS + threadIdx.x; k < k1; k += (int64_t)gridDim.x * VEC_X_THREADS)
+            slots_rd[k] = __builtin_nontemporal_load(own + (size_t)o * (size_t)vb.n2 + k);
+    }
+}
 void launch_vec_exchange(const LaunchCtx& c, const VecBox& vb, uint32_t seq, const double* slots, double* slots_rd) {
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (vb.n2 + VEC_X_THREADS - 1) / VEC_X_THREADS));
+    // two ranks move the same bytes either way (and the direct scheme has one hop less); FOS_VEC_RSAG=0/1 forces
+    static const int rsag_env = getenv("FOS_VEC_RSAG") ? atoi(getenv("FOS_VEC_RSAG")) : -1;
+    const bool rsag = rsag_env >= 0 ? rsag_env != 0 : vb.nranks >= 3;
+    if (rsag) {
+        const int g1 = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (vb.n2 / vb.nranks + VEC_X_THREADS) / VEC_X_THREADS));
+        hipLaunchKernelGGL(vec_rs_push_kernel, dim3(g1), dim3(VEC_X_THREADS), 0, c.stream, vb, seq, slots, c.st);
+        hipLaunchKernelGGL(vec_rs_sum_kernel, dim3(g1), dim3(VEC_X_THREADS), 0, c.stream, vb, seq, slots, slots_rd, c.st);
+        hipLaunchKernelGGL(vec_ag_copy_kernel, dim3(g1), dim3(VEC_X_THREADS), 0, c.stream, vb, seq, slots_rd, c.st);
+        return;
+    }
     hipLaunchKernelGGL(vec_push_kernel, dim3(grid), dim3(VEC_X_THREADS), 0, c.stream, vb, seq, slots, c.st);
     hipLaunchKernelGGL(vec_sum_kernel, dim3(grid), dim3(VEC_X_THREADS), 0, c.stream, vb, seq, slots, slots_rd, c.st);
 }

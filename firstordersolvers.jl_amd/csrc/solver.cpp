@@ -1434,7 +1434,7 @@ int fos_peer_vec_export(fos_handle h, void* handle64) {
     if (!h->vec_buf) {
         const int g = h->peer.nranks;
         const size_t doubles = (size_t)2 * g * 2 * (size_t)h->n;
-        const size_t bytes = doubles * sizeof(double) + (size_t)2 * g * sizeof(uint32_t) + 64;
+        const size_t bytes = doubles * sizeof(double) + (size_t)4 * g * sizeof(uint32_t) + 64;       // flags: [stage 1 | stage 2][parity][rank]
         void* q = nullptr;
         hipError_t e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached);
         if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained); }

@@ -365,6 +365,9 @@ def _worker_rows(rank, world, port, algname, iters, q, transport="host", pname="
     pkg = ge.load_package()
     try:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        if transport == "peer-rsag":                 # the n-vector as reduce-scatter + all-gather (the default from three ranks on)
+            os.environ["FOS_VEC_RSAG"] = "1"
+            transport = "peer"
         prob = _rows_problem(pkg, pname)
         sh = pkg.sharding.shard_rows(prob, world, rank)
         lp = sh.problem
@@ -413,7 +416,7 @@ def _worker_rows(rank, world, port, algname, iters, q, transport="host", pname="
 
 
 @pytest.mark.parametrize("algname,transport,pname", [("DR", "host", "mixed"), ("GAPA", "host", "mixed"), ("DR", "peer", "mixed"), ("GAPA", "peer", "mixed"),
-                                                     ("DR", "host", "dense"), ("GAPA", "peer", "dense")])
+                                                     ("DR", "host", "dense"), ("GAPA", "peer", "dense"), ("GAPA", "peer-rsag", "mixed"), ("DR", "peer-rsag", "dense")])
 def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname, transport, pname):
     """SURVEY 8(f2) with TWO ranks on the one GPU of the test box: each process holds the rows of half of the K1 cones of a
     problem whose A couples everything (workloads.small_mixed), the n-vector A'y and every scalar sum cross the processes
@@ -512,3 +515,63 @@ def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname, transport
     oalg.step(xo, 1, st1)
     assert abs(g0["cg"][0] - oalg.S1.getcgiter()) <= 1
     assert np.linalg.norm(zz1 - xo) <= 1e-7 * max(1.0, np.linalg.norm(xo))
+
+
+def test_row_sharded_three_ranks_reduce_scatter_all_gather(pkg):
+    """Three processes on the one GPU, rows of a dense-row problem split three ways, every cross-rank sum in stream through peer-mapped
+    memory; with three ranks the n-vector A'y crosses as reduce-scatter + all-gather (each entry summed once, by its owner, in rank
+    order).  Replicated parts bitwise identical on all ranks, the operator and the status sums equal to the ordinary handle's, the same
+    CG counts, the first outer iteration to 1e-7."""
+    import multiprocessing as mp
+    import socket
+    iters, world = 4, 3
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_rows, args=(r, world, port, "DR", iters, q, "peer", "dense")) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            r, payload = q.get(timeout=300)
+            assert not isinstance(payload, str), payload
+            got[r] = payload
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    prob = _rows_problem(pkg, "dense")
+    shards = [pkg.sharding.shard_rows(prob, world, r) for r in range(world)]
+    n = prob.n
+    ls = [sh.problem.m + n + 1 for sh in shards]
+    for r in (1, 2):
+        for key in ("z", "z1", "kk"):
+            a, b = got[0][key], got[r][key]
+            assert np.array_equal(a[:n], b[:n]) and np.array_equal(a[ls[0]:ls[0] + n], b[ls[r]:ls[r] + n]), (key, r)
+            assert a[ls[0] - 1] == b[ls[r] - 1] and a[-1] == b[-1], (key, r)
+        assert got[0]["cg"] == got[r]["cg"]
+        for key in got[0]["res"]:
+            assert got[0]["res"][key] == got[r]["res"][key], key
+    d0 = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    rng = np.random.default_rng(5)
+    zg = rng.standard_normal(d0.N)
+    kk = pkg.sharding.rows_local_to_global([got[r]["kk"] for r in range(world)], shards)
+    assert np.allclose(kk, d0.kkt_apply(zg), rtol=1e-12, atol=1e-12)
+    chk = d0.check(zg, 1e-6)
+    for key in ("p", "d", "g", "ctx", "bty"):
+        assert got[0]["chk"][key] == pytest.approx(getattr(chk, key), rel=1e-11), key
+    d0.set_cg_variant("merged_update")
+    d0.set_alg(pkg.DR())
+    d0.set_iterate(None)
+    d0.step(1, 1, 10 ** 9, 1e-9)
+    assert got[0]["cg"][0] == d0.cgiter()
+    z1 = d0.get_iterate()
+    zz1 = pkg.sharding.rows_local_to_global([got[r]["z1"] for r in range(world)], shards)
+    assert np.linalg.norm(zz1 - z1) <= 1e-7 * max(1.0, np.linalg.norm(z1))
