@@ -90,3 +90,25 @@ def test_bench_falls_back_to_rccl_when_the_mailboxes_fail_in_the_warmup():
     # with only the mailboxes allowed the same failure must end the run
     bad = subprocess.run(cmd, cwd=str(ROOT), env=dict(env, FOS_REDUCTION="peer"), capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0
+
+
+@pytest.mark.parametrize("nranks", [4, 8])
+def test_bench_four_and_eight_ranks_on_one_gpu(nranks):
+    """The rank counts the driver launches (2, 4, 8), here sharing the one GPU: cone shards of 1/N of the blocks, every CG iteration's
+    sums through N peer mailboxes.  Same iteration count and residuals as one rank on the same problem (timing is meaningless here)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(FOS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "3", "--small"]
+    rn = subprocess.run(base + ["--gpus", str(nranks), "--no-weak-extra"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    assert rn.returncode == 0, rn.stdout[-3000:] + rn.stderr[-3000:]
+    outn = _last_json(rn.stdout)
+    r1 = subprocess.run(base + ["--no-cpu-baseline"], cwd=str(ROOT), env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stdout[-3000:] + r1.stderr[-3000:]
+    out1 = _last_json(r1.stdout)
+    assert outn["n_gpus"] == nranks and "peer mailboxes" in outn["config"]["parallelism"]
+    assert nranks * outn["config"]["local_m"] == out1["config"]["local_m"]
+    ra, rb = out1["config"]["residuals_after_run"], outn["config"]["residuals_after_run"]
+    assert ra["iteration"] == rb["iteration"]
+    for k in ("p", "d", "g"):
+        assert rb[k] == pytest.approx(ra[k], rel=1e-4), k
+    assert outn["config"]["cg_iters_per_step"] == pytest.approx(out1["config"]["cg_iters_per_step"], abs=1.5)
