@@ -108,7 +108,8 @@ int fos_create(int64_t m, int64_t n,
  * holds the ROWS of A that belong to its K1 cones (m = local rows, b local, K1 local) and ALL n columns (c, K2 whole).  x, r,
  * tau, kappa are replicated on every rank, y and s are local.  Per Q apply the n-vector A'y = sum over ranks of A_g'y_g is
  * all-reduced in stream (RCCL; HSDEAffine.jl:51), every scalar sum counts the replicated entries once (rank 0).  Follow with
- * fos_comm_init on every rank (or the peer mailboxes + fos_peer_vec_*); without a communicator the handle behaves as the only rank.  No dual tiles. */
+ * fos_comm_init on every rank (or the peer mailboxes + fos_peer_vec_*); without a communicator the handle behaves as the only rank.  Dense
+ * rectangles of the rank's rows are stored once (dual tiles); their column sums are added up locally before the n-vector crosses the ranks. */
 #define FOS_CREATE_ROW_SHARDED 1
 int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
                 const double* b, const double* c,
