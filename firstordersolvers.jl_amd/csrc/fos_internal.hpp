@@ -127,7 +127,7 @@ struct HostBlkCsr {
     std::vector<int32_t> def_ptr;      // [ndef+1] their slot lists
     std::vector<int32_t> def_idx;      // slot indices, in summation order
     std::vector<DefRow> def_rec;       // [ndef]   the same lists in the form the kernels read (progressions where they are ones)
-    bool row_sharded = false;          // every row of A' is deferred with the single slot `row` (summed over the ranks before use)
+    bool row_sharded = false;          // every row of A' is deferred: the single slot `row`, or -- with dual tiles -- its local slot list (summed over the ranks before use)
     // window panels (empty unless the operator is stored that way; then blk is empty and val/col are unused)
     std::vector<WinPanel> wpanel;
     std::vector<WinSeg> wseg;
@@ -153,6 +153,7 @@ struct DevBlkCsr {
     // dual tiles / deferred rows (ndef == 0: none)
     double* slots;                     // [nslots][2]   written by the sweeps
     const double* slots_rd;            // what the slot-list sums read: == slots, or -- row-sharded operators -- the all-reduced copy
+                                       // (with dual tiles: [n summed rows of A' | the sweep's slot array], solver.cpp cmp_rec)
     const int32_t* row_defer;          // nullptr when ndef == 0
     const int32_t* def_rows;
     const int32_t* def_ptr;
