@@ -412,6 +412,8 @@ void launch_get_plain(const LaunchCtx& c, double* plain_l, const double2* in, in
 
 // cones (cones.jl:122-142)
 void launch_cones_elementwise(const LaunchCtx& c, double2* out, const double2* in, const uint8_t* ew_op);
+// t1 = a sol + (1 - a) x (a, or alpha12 of the device state) and t2 = P(t1) on the elementwise cones' indices, one pass (vecops.hip)
+void launch_relax_ew(const LaunchCtx& c, double2* t1, double2* t2, const double2* sol, const double2* x, double a, bool use_a12, const uint8_t* ew_op);
 void launch_cones_soc(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones);
 void launch_cones_exp(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones);
 int  launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones,

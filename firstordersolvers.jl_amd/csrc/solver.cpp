@@ -646,11 +646,12 @@ int prox_affine(fos_solver* h, const d2* x, const PostFn* post = nullptr, bool* 
 }
 
 // prox!(y, S2::DualConeProduct, x)                                        cones.jl:122-142
-int prox_cones(fos_solver* h, d2* out, const d2* in, const int32_t* gate = nullptr) {
+// ew_done: the elementwise cones were projected by the kernel that wrote `in` (launch_relax_ew)
+int prox_cones(fos_solver* h, d2* out, const d2* in, const int32_t* gate = nullptr, bool ew_done = false) {
     RoctxRange range("fos:prox_cones (elementwise + SOC + Exp + batched PSD)");
     LaunchCtx c = h->ctx();
     c.gate = gate;
-    launch_cones_elementwise(c, out, in, h->ew_op);
+    if (!ew_done) launch_cones_elementwise(c, out, in, h->ew_op);
     launch_cones_soc(c, out, in, h->soc, h->nsoc);
     launch_cones_exp(c, out, in, h->expc, h->nexp);
     const int pe = h->npsd > 0 ? prof_begin(h, FOS_PROF_PSD, 0, h->prof_seen[FOS_PROF_PSD]++) : -1;
@@ -788,9 +789,15 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bo
             // gated, so that the GPU does not wait for the host to learn the iteration count
             const bool gapa = h->alg == FOS_ALG_GAPA;
             const PostFn post = [h, gapa, will_check](const LaunchCtx& cg) -> int {
+                static const bool fuse_ew = !(getenv("FOS_RELAX_EW") && atoi(getenv("FOS_RELAX_EW")) == 0);
+                if (fuse_ew) {                       // the relaxation and the elementwise cones of S2! in one pass
+                    launch_relax_ew(cg, h->T1, h->T2, h->SOL, h->X, h->alpha1, gapa, h->ew_op);
+                    FOS_TRY(prox_cones(h, h->T2, h->T1, cg.gate, true));
+                } else {
                 if (gapa) launch_relax_a12(cg, h->T1, h->SOL, h->X);                          // gapa.jl:67
                 else launch_axpby(cg, h->T1, h->alpha1, h->SOL, 1 - h->alpha1, h->X);          //   y = a1 y + (1-a1) x     :48
                 FOS_TRY(prox_cones(h, h->T2, h->T1, cg.gate));                                // S2!: prox!(y,S2,x)  :55
+                }
                 if (!will_check) FOS_TRY(step_finish_launch(h, cg));
                 return FOS_OK;
             };

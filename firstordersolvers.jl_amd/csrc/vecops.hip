@@ -740,6 +740,32 @@ __global__ __launch_bounds__(VEC_THREADS) void relax_a12_kernel(int64_t l, d2* _
         out[i] = make_double2(a * yi.x + b * xi.x, a * yi.y + b * xi.y);
     }
 }
+// elementwise cone operations (cones.jl:97-102; used by relax_ew_kernel here and by cones_elementwise_kernel below)
+__device__ __forceinline__ double ew_apply(int op, double v) {
+    switch (op) {
+        case EW_COPY: return v;               // IndFree / dual of IndZero           cones.jl:98
+        case EW_ZERO: return 0.0;             // IndZero / dual of IndFree (IndPoint) cones.jl:100
+        // comparisons, not fmax/fmin: a NaN must stay a NaN as it does in the reference (Julia's max(NaN,0) is NaN)
+        case EW_MAX0: return v < 0.0 ? 0.0 : v;   // IndNonnegative (self dual)       cones.jl:101 ; tau, kappa :138,141
+        default:      return v > 0.0 ? 0.0 : v;   // IndNonpositive                   cones.jl:102
+    }
+}
+// The relaxation behind S1 and the elementwise share of the cone projection in ONE pass (one launch less per outer iteration):
+//   t1 = a sol + (1 - a) x   (a: the argument, or alpha12 from the device state -- the arithmetic of axpby_kernel / relax_a12_kernel)
+//   t2 = P(t1) on the indices of Free / Zero / NonNeg / NonPos cones and the (tau, kappa) element (cones_elementwise_kernel)
+__global__ __launch_bounds__(VEC_THREADS) void relax_ew_kernel(int64_t l, d2* __restrict__ t1, d2* __restrict__ t2, const d2* __restrict__ sol,
+                                                               const d2* __restrict__ x, double a_arg, int use_a12, const DevState* st,
+                                                               const uint8_t* __restrict__ ew_op, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;                  // speculatively enqueued behind a CG batch that did not converge: no-op
+    const double a = use_a12 ? st->alpha12 : a_arg, b = 1 - a;
+    GRID_STRIDE(i, l) {
+        const d2 si = sol[i], xi = x[i];
+        const uint8_t op = ew_op[i];
+        const d2 v = make_double2(a * si.x + b * xi.x, a * si.y + b * xi.y);
+        t1[i] = v;
+        if (op != EW_SKIP) t2[i] = make_double2(ew_apply(op & 3, v.x), ew_apply((op >> 2) & 3, v.y));
+    }
+}
 // tmp2 = a2 tmp2 + (1-a2) tmp1 ; x = a tmp2 + (1-a) x           gap.jl:58,78
 // shift_out (optional): also the vector the NEXT affine projection's CG start applies M to, sol - [0; x2_new] (shift_part2_kernel),
 // so that projection needs no pass of its own for it
@@ -856,6 +882,9 @@ void launch_normdiff(const LaunchCtx& c, const double2* x, const double2* y) {
 }
 void launch_axpby(const LaunchCtx& c, double2* out, double a, const double2* x, double b, const double2* y) {
     hipLaunchKernelGGL(axpby_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, a, x, b, y, c.gate);
+}
+void launch_relax_ew(const LaunchCtx& c, double2* t1, double2* t2, const double2* sol, const double2* x, double a, bool use_a12, const uint8_t* ew_op) {
+    hipLaunchKernelGGL(relax_ew_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, t1, t2, sol, x, a, use_a12 ? 1 : 0, (const DevState*)c.st, ew_op, c.gate);
 }
 void launch_relax_a12(const LaunchCtx& c, double2* out, const double2* y, const double2* x) {
     hipLaunchKernelGGL(relax_a12_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, out, y, x, c.st, c.gate);
@@ -1064,15 +1093,6 @@ void launch_get_plain(const LaunchCtx& c, double* plain_l, const double2* in, in
 
 // ------------------------------------------------------------------------------------------------ cones
 
-__device__ __forceinline__ double ew_apply(int op, double v) {
-    switch (op) {
-        case EW_COPY: return v;               // IndFree / dual of IndZero           cones.jl:98
-        case EW_ZERO: return 0.0;             // IndZero / dual of IndFree (IndPoint) cones.jl:100
-        // comparisons, not fmax/fmin: a NaN must stay a NaN as it does in the reference (Julia's max(NaN,0) is NaN)
-        case EW_MAX0: return v < 0.0 ? 0.0 : v;   // IndNonnegative (self dual)       cones.jl:101 ; tau, kappa :138,141
-        default:      return v > 0.0 ? 0.0 : v;   // IndNonpositive                   cones.jl:102
-    }
-}
 // every index whose cone is Free/Zero/NonNeg/NonPos, plus the (tau,kappa) element; op byte: part1 | part2 << 2
 __global__ __launch_bounds__(VEC_THREADS) void cones_elementwise_kernel(int64_t l, d2* __restrict__ out, const d2* __restrict__ in,
                                                                         const uint8_t* __restrict__ ew_op, const int32_t* __restrict__ gate) {
