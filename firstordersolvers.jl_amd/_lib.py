@@ -8,7 +8,7 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "csrc" / "libfoship.so"
+LIB_PATH = Path(os.environ["FOSHIP_LIB"]) if os.environ.get("FOSHIP_LIB") else _HERE / "csrc" / "libfoship.so"      # (FOSHIP_LIB: as in julia/FOSHip.jl)
 
 # error codes / enums (mirror of include/foship.h)
 FOS_OK = 0
