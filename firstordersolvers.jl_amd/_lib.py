@@ -99,6 +99,8 @@ PROTOTYPES = {
     "fos_set_cg_variant": (C.c_int, [_h, C.c_int32]),
     "fos_get_cg_variant": (C.c_int, [_h, _i32p]),
     "fos_debug_set": (C.c_int, [_h, C.c_int32, C.c_int64]),
+    "fos_set_gapp": (C.c_int, [_h, C.c_int64]),
+    "fos_gapp_log": (C.c_int, [_h, _dp]),
     # Feasibility form (src/problemforms/Feasibility/*.jl)
     "fos_feas_create": (C.c_int, [C.c_int64, C.c_int32, C.POINTER(_h)]),
     "fos_feas_destroy": (C.c_int, [_h]),

@@ -185,6 +185,10 @@ struct fos_solver {
     bool in_step = false;
     int64_t ls_interval = 0;
     bool ls_now = false;                       // the iteration in flight is a line-search iteration (between step_once and step_finish)
+    // GAPP ("projected GAP", solvers/gapproj.jl): GAP whose every gapp_iproj-th iteration is a 21-point projected search
+    int64_t gapp_iproj = 0;
+    bool gapp_now = false;
+    double gapp_log[23] = {0};                 // 21 test norms, alpha_best, iteration
     double ls_log[34] = {0};                   // last search: ||res||, the 31 test residuals, the chosen alpha, the iteration
     int cg_same_run = 0;                       // consecutive solves that took exactly last_cg_pred iterations
     const d2* last_checked = nullptr;          // vector the last checkstatus was evaluated on
@@ -754,6 +758,37 @@ int ls_finish(fos_solver* h, int64_t i) {
     return FOS_OK;
 }
 
+// ---- GAPP, a search iteration                                       solvers/gapproj.jl:29-62
+// scratch: Y = tmp1 = P_S1(x), XOLD = res, W = tmp3 / the new tmp1, T1 = tmp4 -- Y, XOLD, W are unused by GAP
+int gapp_begin(fos_solver* h, int64_t i, const d2** check_on) {
+    LaunchCtx c = h->ctx();
+    FOS_TRY(prox_affine(h, h->X));                                                                  // prox!(tmp1, S1, x)        :33
+    FOS_HIP(hipMemcpyAsync(h->Y, h->SOL, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));
+    FOS_TRY(prox_cones(h, h->T2, h->Y));                                                            // prox!(tmp2, S2, tmp1)     :39
+    FOS_TRY(prox_affine(h, h->T2));                                                                 // prox!(res, S1, tmp2)      :40
+    launch_axpby(c, h->XOLD, 1.0, h->SOL, -1.0, h->Y);                                              // res .= res - tmp1         :41
+    double normbest = INFINITY, abest = -1.0;                                                       // :44-45
+    for (int k = 0; k <= 20; ++k) {                                                                 // :46
+        const double at = std::ldexp(1.0, k);                                                       // 2.0^k
+        launch_axpby(c, h->W, 1.0, h->Y, at, h->XOLD);                                              // tmp3 .= tmp1 .+ at.*res
+        FOS_TRY(prox_cones(h, h->T1, h->W));                                                        // prox!(tmp4, S2, tmp3)
+        double nt = 0.0;
+        FOS_TRY(ls_normdiff(h, c, h->T1, h->W, &nt));                                               // norm(tmp4 - tmp3)
+        h->gapp_log[k] = nt;
+        if (nt < normbest) { abest = at; normbest = nt; }
+    }
+    h->gapp_log[21] = abest; h->gapp_log[22] = (double)i;
+    launch_axpby(c, h->W, 1.0, h->Y, abest, h->XOLD);                                               // tmp1 .= tmp1 .+ abest.*res :58
+    FOS_TRY(prox_cones(h, h->T2, h->W));                                                            // prox!(tmp2, S2, tmp1)     :59
+    *check_on = h->T2;                                                                              // checkstatus(status, tmp2) :60
+    return FOS_OK;
+}
+int gapp_finish(fos_solver* h) {
+    LaunchCtx c = h->ctx();
+    launch_axpby(c, h->X, h->alpha2, h->T2, 1 - h->alpha2, h->W);                                   // x .= a2 tmp2 + (1-a2) tmp1 :61-62
+    return FOS_OK;
+}
+
 // one outer iteration; *check_on receives the vector checkstatus is evaluated on (the cone-feasible point)
 int step_finish_launch(fos_solver* h, const LaunchCtx& c);
 
@@ -781,6 +816,8 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bo
     *finish_done = false;
     h->ls_now = h->ls_interval > 0 && (i % h->ls_interval) == 0;                                    // linesearch.jl:39
     if (h->ls_now) return ls_begin(h, check_on);
+    h->gapp_now = h->gapp_iproj > 0 && (i % h->gapp_iproj) == 0;                                     // gapproj.jl:34
+    if (h->gapp_now) return gapp_begin(h, i, check_on);
     switch (h->alg) {
         case FOS_ALG_GAP:                                                // gap.jl:61-80
         case FOS_ALG_GAPA: {                                             // gapa.jl:80-105
@@ -843,6 +880,7 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bo
 int step_finish(fos_solver* h, int64_t i) {
     LaunchCtx c = h->ctx();
     if (h->ls_now) { h->ls_now = false; return ls_finish(h, i); }
+    if (h->gapp_now) { h->gapp_now = false; return gapp_finish(h); }
     return step_finish_launch(h, c);
 }
 int step_finish_launch(fos_solver* h, const LaunchCtx& c) {
@@ -1307,7 +1345,7 @@ int fos_comm_get_unique_id(void* id128) {
 
 int fos_comm_init(fos_handle h, int nranks, int rank, const void* id128) {
     if (!h || nranks < 1 || rank < 0 || rank >= nranks) { set_error("bad comm arguments"); return FOS_EINVAL; }
-    if (h->ls_interval > 0) { set_error("switch the LineSearchWrapper off before sharding the handle (fos_set_linesearch(h, 0))"); return FOS_EUNSUPPORTED; }
+    if (h->ls_interval > 0 || h->gapp_iproj > 0) { set_error("switch the LineSearchWrapper / GAPP off before sharding the handle (fos_set_linesearch(h, 0), fos_set_gapp(h, 0))"); return FOS_EUNSUPPORTED; }
     FOS_TRY(rccl_load());
     FOS_HIP(hipSetDevice(h->device));
     ncclUniqueId id;
@@ -1323,7 +1361,7 @@ int fos_comm_init(fos_handle h, int nranks, int rank, const void* id128) {
 // processes (tests/test_gpu_peer_mailbox.py::test_row_sharded_two_processes_host_exchange).
 int fos_comm_init_host(fos_handle h, int nranks, int rank, fos_allreduce_fn fn, void* user) {
     if (!h || !fn || nranks < 1 || rank < 0 || rank >= nranks) { set_error("bad comm arguments"); return FOS_EINVAL; }
-    if (h->ls_interval > 0) { set_error("switch the LineSearchWrapper off before sharding the handle (fos_set_linesearch(h, 0))"); return FOS_EUNSUPPORTED; }
+    if (h->ls_interval > 0 || h->gapp_iproj > 0) { set_error("switch the LineSearchWrapper / GAPP off before sharding the handle (fos_set_linesearch(h, 0), fos_set_gapp(h, 0))"); return FOS_EUNSUPPORTED; }
     if (h->comm || h->peer_on) { set_error("this handle already has a communicator"); return FOS_EINVAL; }
     FOS_HIP(hipSetDevice(h->device));
     if (!h->host_buf) {
@@ -1498,7 +1536,7 @@ int fos_peer_enable(fos_handle h, int32_t on) {
     if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
     if (on && !h->peer.box) { set_error("fos_peer_enable before fos_peer_open"); return FOS_EINVAL; }
     if (on && h->row_sharded && !h->vec.buf) { set_error("row-sharded handle: fos_peer_vec_export / fos_peer_vec_open before fos_peer_enable"); return FOS_EINVAL; }
-    if (on && h->ls_interval > 0) { set_error("switch the LineSearchWrapper off before sharding the handle (fos_set_linesearch(h, 0))"); return FOS_EUNSUPPORTED; }
+    if (on && (h->ls_interval > 0 || h->gapp_iproj > 0)) { set_error("switch the LineSearchWrapper / GAPP off before sharding the handle (fos_set_linesearch(h, 0), fos_set_gapp(h, 0))"); return FOS_EUNSUPPORTED; }
     FOS_HIP(hipSetDevice(h->device));
     FOS_HIP(hipStreamSynchronize(h->stream));
     h->peer_on = on != 0;
@@ -1513,6 +1551,7 @@ int fos_set_alg(fos_handle h, int alg, double alpha, double alpha1, double alpha
     FOS_HIP(hipSetDevice(h->device));
     h->alg = alg; h->alpha = alpha; h->alpha1 = alpha1; h->alpha2 = alpha2; h->beta = beta;
     h->ls_interval = 0; h->ls_now = false;                              // a fresh algorithm is unwrapped (fos_set_linesearch follows)
+    h->gapp_iproj = 0; h->gapp_now = false;                             // ... and plain (fos_set_gapp follows)
     h->fista_t = 1.0;                                                   // fista.jl:24
     // fresh *Data: alpha12 = 2.0 (gapa.jl:29); y = xold = 0 (fista.jl:24); p = q = 0 (dykstra.jl:21)
     DevState z;
@@ -1706,6 +1745,21 @@ int fos_set_linesearch(fos_handle h, int64_t lsinterval) {
         return FOS_EUNSUPPORTED;
     }
     h->ls_interval = lsinterval;
+    return FOS_OK;
+}
+// GAPP(alpha, alpha1, alpha2; iproj) (solvers/gapproj.jl, README solver table): fos_set_alg(FOS_ALG_GAP, alpha, alpha1, alpha2) and then
+// fos_set_gapp(iproj > 0): iterations i with i % iproj == 0 search 21 step lengths 2^k along P_S1(P_S2(P_S1 x)) - P_S1 x.
+int fos_set_gapp(fos_handle h, int64_t iproj) {
+    if (!h || iproj < 0) { set_error("bad argument"); return FOS_EINVAL; }
+    if (iproj > 0 && h->alg != FOS_ALG_GAP) { set_error("GAPP is GAP with a projected search: fos_set_alg(FOS_ALG_GAP, ...) first"); return FOS_EUNSUPPORTED; }
+    if (iproj > 0 && (h->sharded() || h->row_sharded)) { set_error("GAPP is built for single-GPU handles only (its test norms are global norms)"); return FOS_EUNSUPPORTED; }
+    if (iproj > 0 && h->ls_interval > 0) { set_error("GAPP and the LineSearchWrapper exclude each other"); return FOS_EUNSUPPORTED; }
+    h->gapp_iproj = iproj;
+    return FOS_OK;
+}
+int fos_gapp_log(fos_handle h, double* out23) {
+    if (!h || !out23) { set_error("NULL argument"); return FOS_EINVAL; }
+    memcpy(out23, h->gapp_log, sizeof(h->gapp_log));
     return FOS_OK;
 }
 int fos_linesearch_log(fos_handle h, double* out34) {

@@ -82,14 +82,15 @@ class FISTA(FOSAlgorithm):
 
 
 class GAPP(FOSAlgorithm):
-    """GAPP(alpha=0.8, alpha1=1.8, alpha2=1.8; direct=true, iproj=100, kwargs...)   gapproj.jl:5-13 -- experimental in the reference;
-    available on the Feasibility form of the device path (test/testfeasibility.jl:36), not on the HSDE one."""
+    """GAPP(alpha=0.8, alpha1=1.8, alpha2=1.8; direct=true, iproj=100, kwargs...)   gapproj.jl:5-13, the last row of the reference's
+    solver table (README.md:32-40): GAP whose every iproj-th iteration is a 21-point projected search.  On the HSDE path
+    (fos_set_gapp) and on the Feasibility form (fos_feas_set_gapp); `direct` defaults to true as in the reference (dense, l <= 46 000)."""
 
     def __init__(self, alpha=0.8, alpha1=1.8, alpha2=1.8, direct=True, iproj=100, **kwargs):
         self.alpha, self.alpha1, self.alpha2, self.direct, self.iproj, self.options = alpha, alpha1, alpha2, direct, int(iproj), kwargs
 
     def _alg_args(self):
-        raise _lib.FosError(-4, "GAPP runs on the Feasibility form only (fos_feas_set_gapp)")
+        return (_lib.ALG_GAP, self.alpha, self.alpha1, self.alpha2, 0.0)         # + fos_set_gapp(iproj)
 
 
 class Dykstra(FOSAlgorithm):
@@ -215,6 +216,14 @@ class HipHSDE:
         _lib.check(self._lib.fos_set_alg(self._h, code, a, a1, a2, beta))
         if isinstance(alg, LineSearchWrapper):
             self.set_linesearch(alg.lsinterval)
+        if isinstance(alg, GAPP):
+            _lib.check(self._lib.fos_set_gapp(self._h, alg.iproj))
+
+    def gapp_log(self):
+        """(iteration, [21 test norms], alpha_best) of GAPP's last search."""
+        out = np.zeros(23)
+        _lib.check(self._lib.fos_gapp_log(self._h, _lib.dptr(out)))
+        return int(out[22]), out[0:21].copy(), float(out[21])
 
     def set_linesearch(self, lsinterval):
         """LineSearchWrapper around the current algorithm (0: off); fos_set_linesearch."""
@@ -631,13 +640,21 @@ class FOSMathProgModel:
         status.printstatusheader()
         i = 0
         ls = self.alg.lsinterval if isinstance(self.alg, LineSearchWrapper) else 0
+        gp = self.alg.iproj if isinstance(self.alg, GAPP) else 0
         while i < max_iters:                                       # for i = 1:max_iters   :23
             count = min(max_iters - i, checki - (i % checki))
             if ls > 0:
                 count = min(count, ls - (i % ls))                  # stop at every line-search iteration: its output is printed
+            if gp > 0:
+                count = min(count, gp - (i % gp))
             done, checked, res = dev.step(i + 1, count, checki, eps)
             i += done
             status.i = i
+            if gp > 0 and i % gp == 0:                             # what gapproj.jl:51,57 print (unconditionally)
+                _, tests, abest = dev.gapp_log()
+                for nt in tests:
+                    status._println("normtest: %s" % julia_float(nt))
+                status._println("\u03b1best: %s" % julia_float(abest))
             if ls > 0 and i % ls == 0:                             # what linesearch.jl:51,63,69 print
                 _, normres, tests, abest = dev.linesearch_log()
                 status._println("test, %s" % julia_float(normres))

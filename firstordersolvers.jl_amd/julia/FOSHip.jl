@@ -67,6 +67,7 @@ mutable struct HipData <: FOSSolverData
     n::Int
     cgiter::Int64
     lsinterval::Int64                     # > 0: LineSearchWrapper around the algorithm [wrappers/linesearch.jl]
+    gappinterval::Int64                   # > 0: GAPP, its search interval [solvers/gapproj.jl]
     function HipData(model::FOSMathProgModel, device::Integer)
         A = model.A                       # SparseMatrixCSC{Float64,Int}: colptr/rowval are Int64 and 1-based, as the ABI wants
         m, n = size(A)
@@ -83,7 +84,7 @@ mutable struct HipData <: FOSSolverData
                         m, n, A.colptr, A.rowval, A.nzval, b, c,
                         length(t1), t1, s1, l1, length(t2), t2, s2, l2, Cint(device), h))
         end
-        d = new(h[], m, n, 0, 0)
+        d = new(h[], m, n, 0, 0, 0)
         finalizer(x -> (x.handle != C_NULL && ccall((:fos_destroy, libfoship), Cint, (Ptr{Cvoid},), x.handle); x.handle = C_NULL), d)
         return d
     end
@@ -93,6 +94,7 @@ algargs(a::GAP) = (FOS_ALG_GAP, a.α, a.α1, a.α2, 0.0)              # gap.jl:6
 algargs(a::GAPA) = (FOS_ALG_GAPA, a.α, 0.0, 0.0, a.β)              # gapa.jl:9-15
 algargs(a::FISTA) = (FOS_ALG_FISTA, a.α, 0.0, 0.0, 0.0)            # fista.jl:6-11
 algargs(a::Dykstra) = (FOS_ALG_DYKSTRA, 0.0, 0.0, 0.0, 0.0)        # dykstra.jl:5-9
+algargs(a::FirstOrderSolvers.GAPP) = (FOS_ALG_GAP, a.α, a.α1, a.α2, 0.0)   # gapproj.jl:5-13: GAP + fos_set_gapp(iproj)
 
 set_alg!(d::HipData, alg) = check(ccall((:fos_set_alg, libfoship), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cdouble, Cdouble),
                                         d.handle, algargs(alg)...))
@@ -100,7 +102,7 @@ set_alg!(d::HipData, alg) = check(ccall((:fos_set_alg, libfoship), Cint, (Ptr{Cv
 usegpu(model::FOSMathProgModel) = get(model.options, :gpu, false) === true
 
 # ---- init_algorithm!: return HipData when gpu=true, otherwise fall through to the reference method --------------
-for T in (:GAP, :GAPA, :FISTA, :Dykstra)
+for T in (:GAP, :GAPA, :FISTA, :Dykstra, :(FirstOrderSolvers.GAPP))
     @eval function init_algorithm!(alg::$T, model::FOSMathProgModel)
         if usegpu(model)
             # the reference's closure [HSDE.jl:24-27], built directly: get_sets_and_status would also construct the host-side
@@ -113,6 +115,10 @@ for T in (:GAP, :GAPA, :FISTA, :Dykstra)
             set_alg!(data, alg)
             if haskey(model.options, :cg_variant)      # device-side key: which CG recurrence the affine projection runs (FOS_CG_* of foship.h)
                 check(ccall((:fos_set_cg_variant, libfoship), Cint, (Ptr{Cvoid}, Int32), data.handle, Int32(model.options[:cg_variant])))
+            end
+            if alg isa FirstOrderSolvers.GAPP            # "projected GAP": every iproj-th iteration is a 21-point search on the device
+                check(ccall((:fos_set_gapp, libfoship), Cint, (Ptr{Cvoid}, Int64), data.handle, Int64(alg.iproj)))
+                data.gappinterval = alg.iproj
             end
             if alg.direct            # HSDE.jl:12-15: S1 = IndAffine([Q -I], 0) -> exact projection, (I + Q Q')^-1 formed once on the device
                 A = model.A
@@ -138,6 +144,14 @@ function init_algorithm!(ls::LineSearchWrapper, model::FOSMathProgModel)
 end
 
 # what linesearch.jl:51,63,69 print during a search, from the device's record of the last one
+function print_gapp(data::HipData)                       # gapproj.jl:51,57
+    log = Vector{Float64}(undef, 23)
+    check(ccall((:fos_gapp_log, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, log))
+    for k = 1:21
+        println("normtest: $(log[k])")
+    end
+    println("αbest: $(log[22])")
+end
 function print_linesearch(data::HipData)
     log = Vector{Float64}(undef, 34)
     check(ccall((:fos_linesearch_log, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, log))
@@ -193,12 +207,15 @@ function iterate(alg::FOSAlgorithm, data::HipData, status::HSDEStatus, x, max_it
         count = min(max_iters - i, status.checki - (i % status.checki))
         ls = data.lsinterval
         ls > 0 && (count = min(count, ls - (i % ls)))                 # stop at every line-search iteration: its output is printed
+        gp = data.gappinterval
+        gp > 0 && (count = min(count, gp - (i % gp)))
         check(ccall((:fos_step, libfoship), Cint,
                     (Ptr{Cvoid}, Int64, Int64, Int64, Cdouble, Ref{Int64}, Ref{Int32}, Ref{CheckResult}),
                     data.handle, i + 1, count, status.checki, status.eps, done, checked, res))
         i += done[]
         status.i = i
         ls > 0 && i % ls == 0 && print_linesearch(data)
+        gp > 0 && i % gp == 0 && print_gapp(data)
         if checked[] != 0
             record!(status, data, res[])
             status.status != :Continue && break

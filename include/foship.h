@@ -204,6 +204,12 @@ int fos_step(fos_handle h, int64_t i_first, int64_t count, int64_t checki, doubl
  * prints with its println calls (linesearch.jl:51,63,69). */
 int fos_set_linesearch(fos_handle h, int64_t lsinterval);
 int fos_linesearch_log(fos_handle h, double* out34);
+/* GAPP(alpha, alpha1, alpha2; iproj) -- "projected GAP", src/solvers/gapproj.jl:5-81, the last row of the reference's solver table
+ * (README.md:32-40): fos_set_alg(FOS_ALG_GAP, alpha, alpha1, alpha2, 0) and then fos_set_gapp(iproj > 0).  Iterations i with
+ * i % iproj == 0 search 21 step lengths 2^k along P_S1(P_S2(P_S1 x)) - P_S1 x (gapproj.jl:34-62); out23 = the 21 test norms,
+ * alpha_best, iteration of the last search (what gapproj.jl:51,57 print).  Single-GPU handles. */
+int fos_set_gapp(fos_handle h, int64_t iproj);
+int fos_gapp_log(fos_handle h, double* out23);
 
 /* getsol(alg, data, x): one more S1 prox + S2 prox (gap.jl:82-87, gapa.jl:107-112, fista.jl:50-56); advances
  * the CG call counter like the reference.  z_out (N doubles) receives `guess`.  If force_check != 0 the

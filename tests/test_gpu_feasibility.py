@@ -248,6 +248,3 @@ def test_gapp_matches_oracle(pkg, oracle):
     assert sol.status == osol.status == "Optimal" and abs(sol.iterations - osol.iterations) <= 100
     assert sol.x.min() > -1e-9 and np.abs(A @ sol.x - b).max() < 1e-6
     assert sum(l.startswith("normtest: ") for l in out) == 21 * (sol.iterations // 100)
-    with pytest.raises(pkg.lib.FosError):                      # not an algorithm of the HSDE path
-        prob = pkg.workloads.small_mixed()
-        pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2).set_alg(pkg.GAPP())

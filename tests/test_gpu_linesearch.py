@@ -106,3 +106,59 @@ def test_linesearch_is_refused_on_sharded_handles(pkg):
     with pytest.raises(pkg.lib.FosError):
         d.set_linesearch(10)
     d.close()
+
+
+@pytest.mark.parametrize("direct", [False, True])
+def test_gapp_on_the_hsde_path_matches_oracle(pkg, oracle, direct):
+    """GAPP ("projected GAP", src/solvers/gapproj.jl -- the last row of the reference's solver table) on the device: GAP steps and two
+    projected searches against the oracle's restatement -- iterates, the 21 test norms, the chosen step length, the CG tolerance
+    counter (S1 is applied twice in a search iteration) -- with the CG projection and with direct=true (GAPP's default)."""
+    orc = oracle
+    prob = pkg.workloads.small_mixed()
+    ip = 4
+    lines = []
+    oalg = orc.GAPP(0.8, 1.5, 1.6, iproj=ip, direct=direct, out=lines)
+    mo = _omodel(orc, prob)
+    oalg.init(mo)
+    xo = orc.hsde_initialvalue(mo)
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    if direct:
+        d.enable_direct(prob.A)
+    d.set_alg(pkg.GAPP(0.8, 1.5, 1.6, iproj=ip, direct=direct))
+    d.set_iterate(None)
+    st = orc.HSDEStatus(mo, 10 ** 9, 1e-9, 0, 1, S1=oalg.S1)
+    for i in range(1, 2 * ip + 2):
+        st.i = i
+        oalg.step(xo, i, st)
+        d.step(i, 1, 10 ** 9, 1e-9)
+        z = d.get_iterate()
+        scale = max(1.0, np.linalg.norm(xo))
+        tol = 1e-9 if direct else 5e-2                      # (CG: the first iterations solve S1 to the loose tolerance 0.2^sqrt(i))
+        assert np.linalg.norm(z - xo) <= tol * scale, (i, np.linalg.norm(z - xo))
+        if i % ip == 0 and direct:
+            it, tests, abest = d.gapp_log()
+            oi, otests, oabest = oalg.log[-1]
+            assert it == oi == i and abest == oabest and np.allclose(tests, otests, rtol=1e-6, atol=1e-10)
+    if not direct:
+        _, pi, _ = d.get_affine_state()
+        assert pi == oalg.S1.i                               # two S1 applications per search iteration
+
+
+def test_gapp_whole_solve_and_refusals(pkg, oracle):
+    orc = oracle
+    prob = pkg.workloads.small_mixed()
+    out = []
+    # (direct = true, GAPP's default: both sides project exactly, so the whole trajectory is comparable; 450 iterations = four searches)
+    model = pkg.FOSMathProgModel(pkg.GAPP(eps=1e-7, verbose=0, max_iters=450, checki=50, iproj=100))
+    model.out = out
+    model.loadproblem(prob.c, prob.A, prob.b, prob.K1, prob.K2)
+    model.optimize()
+    osol = orc.solve(_omodel(orc, prob), orc.GAPP(eps=1e-7, verbose=0, max_iters=450, checki=50, iproj=100, out=[]))
+    assert model.status() == osol.status
+    assert model.iterations == osol.iterations
+    assert np.max(np.abs(model.getsolution() - osol.x)) <= 1e-6 * max(1.0, np.max(np.abs(osol.x)))
+    assert sum(l.startswith("normtest: ") for l in out) == 21 * (model.iterations // 100)
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d.set_alg(pkg.FISTA())
+    with pytest.raises(pkg.lib.FosError):                     # GAPP is GAP with a search
+        pkg.lib.check(d._lib.fos_set_gapp(d._h, 10))
