@@ -430,7 +430,7 @@ __global__ __launch_bounds__(VEC_THREADS, 3) void cgm_update_kernel(CgmArgs a, D
     const double vtx = st->vtau[0], vty = st->vtau[1];           // tau element of r_i (stashed by the sweep that applied M to it)
     const double g_cur = st->rn2[i & 1], g_prev = st->rn2[(i + 1) & 1], a_prev = st->alpha2[(i + 1) & 1], tol = st->tol;
     const bool plain_sums = !a.from_reduced && a.pre == nullptr;
-    PartialRegs<3, 6> kreg;                        // (6 x 256 records per round trip; 8 would cost a spill at three wavefronts per SIMD)
+    PartialRegs<3, 4> kreg;                        // (4 x 256 records per round trip; more would cost spills at three wavefronts per SIMD)
     if (plain_sums) kreg.load(a.kkt_partials, a.nkkt);
     const int lpr = DEF ? S.def_lpr : 1, sh = 31 - __clz(lpr);
     const int rows_per_pass = (gridDim.x * VEC_THREADS) >> sh;
@@ -440,31 +440,32 @@ __global__ __launch_bounds__(VEC_THREADS, 3) void cgm_update_kernel(CgmArgs a, D
     DefRow dr0{};
     if (ok0) dr0 = ld_defrow(S.def_rec + q0);
     const int drow0 = dr0.row, dn0 = dr0.count + (dr0.own >= 0 ? 1 : 0);
-    const double rs = !closing ? 0.0 : (a.from_reduced ? a.reduced[3] : wave_sum_records(a.rr_in, a.nrr));
-    // stage 2: the first four slot indices of that row's list; the row's vector elements
-    int did[4] = {-1, -1, -1, -1};
+    // (only the first wavefront's sum is used -- thread 0 hands it on below: the others leave the 4 KB of records alone)
+    const double rs = (!closing || threadIdx.x >= 64) ? 0.0 : (a.from_reduced ? a.reduced[3] : wave_sum_records(a.rr_in, a.nrr));
+    // stage 2: the first NDV slot indices of that row's list; the row's vector elements
+    constexpr int NDV = 5;                               // (C4: 33 slots per row on 8 lanes -- five for the first lane)
+    int did[NDV];
+#pragma unroll
+    for (int q = 0; q < NDV; ++q) did[q] = -1;
     d2 dri = make_double2(0.0, 0.0), dpi = dri, dsi = dri, dxi = dri;
     double dc = 0.0;
     if constexpr (DEF) {
         if (ok0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) did[q] = (lig + q * lpr < dn0) ? defrow_slot(dr0, S.def_idx, lig + q * lpr) : -1;
+            for (int q = 0; q < NDV; ++q) did[q] = (lig + q * lpr < dn0) ? defrow_slot(dr0, S.def_idx, lig + q * lpr) : -1;
             if (lig == 0) { dri = a.r[drow0]; dxi = a.x[drow0]; dc = a.cb[drow0]; if (!first) { dpi = a.p[drow0]; dsi = a.s[drow0]; } }
         }
     }
     if (done) return;
     if (FOLD && xfail) return;
     if ((mw0 >> (i0 & 31)) & 1u) have0 = false;         // a slot-spread row: finished below, its elements were read for nothing
-    // stage 3: those slots (the rest of a longer list follows by the ordinary chunks)
-    double du1 = 0.0, du2 = 0.0;
+    // stage 3: those slots are REQUESTED here and added behind the scalar part (the sums' reduction and the mailbox hop run while
+    // they are on their way; the rest of a longer list follows there by the ordinary chunks)
+    d2 dv[NDV];
     if constexpr (DEF) {
         const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots_rd);
-        d2 dv[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dv[q] = did[q] >= 0 ? slots[did[q]] : make_double2(0.0, 0.0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) if (did[q] >= 0) { du1 += dv[q].x; du2 += dv[q].y; }
-        if (ok0) slot_list_sum(slots, S.def_idx, dr0, lig + 4 * lpr, lpr, du1, du2);
+        for (int q = 0; q < NDV; ++q) dv[q] = did[q] >= 0 ? slots[did[q]] : make_double2(0.0, 0.0);
     }
     __shared__ double sums[4];
     if (plain_sums) {
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(VEC_THREADS, 3) void cgm_update_kernel(CgmArgs a, D
         __syncthreads();
     }
     if constexpr (FOLD) {
+        if (!(S.dbg_flags & 128))                                                                        // (timing experiment, one rank: no mailbox hop)
         if (!peer_fold_sum<4>(a.pb, a.seq_base + (uint32_t)a.j, sums, st)) return;
     }
     const double S1 = sums[0], T1 = sums[1], T2 = sums[2];
@@ -508,6 +510,13 @@ __global__ __launch_bounds__(VEC_THREADS, 3) void cgm_update_kernel(CgmArgs a, D
             __hip_atomic_store(&reinterpret_cast<HostMark*>(st->hostmark)->batch, a.batch_mark, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (a.close_only) return;
+    if ((S.dbg_flags & 64) && blockIdx.x != 0) return;                                                    // (timing experiment: scalar prologue only)
+    double du1 = 0.0, du2 = 0.0;
+    if constexpr (DEF) {
+#pragma unroll
+        for (int q = 0; q < NDV; ++q) if (did[q] >= 0) { du1 += dv[q].x; du2 += dv[q].y; }
+        if (ok0) slot_list_sum(reinterpret_cast<const d2*>(S.slots_rd), S.def_idx, dr0, lig + NDV * lpr, lpr, du1, du2);
+    }
     double acc[1] = {0.0};
     // one element: (w, r, p, s, x) -> (p, s, x, r); returns r.r of the element
     auto upd = [&](int64_t idx, d2 wi, d2 ri, d2 pi, d2 si, d2 xi) -> double {
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(VEC_THREADS, 3) void cgm_update_kernel(CgmArgs a, D
     };
     if constexpr (DEF) {
         const d2* __restrict__ slots = reinterpret_cast<const d2*>(S.slots_rd);
-        const int npass = (S.ndef + rows_per_pass - 1) / rows_per_pass;       // uniform trip count: the DPP sums need full waves
+        const int npass = (S.dbg_flags & 4) ? 0 : (S.ndef + rows_per_pass - 1) / rows_per_pass;       // uniform trip count: the DPP sums need full waves
         int q = q0;
         for (int pass = 0; pass < npass; ++pass, q += rows_per_pass) {
             const bool ok = q < S.ndef;
