@@ -301,6 +301,10 @@ struct LaunchCtx {
     bool psd_narrow = false, psd_wide = false;
     int32_t psd_wide_threads = 512;
     bool* psd_attr_set = nullptr;    // the handle's "LDS opt-in done" flag
+    bool* psd_attr_set_r = nullptr;  // the same for the refinement kernel
+    int32_t psd_refine = -1;         // FOS_PSD_REFINE: -1 by batch size, 0 / 1 never / always (order 64, warm)
+    bool psd_extrapolate = true;     // FOS_PSD_EXTRAPOLATE=0: the refinement starts from the previous basis only
+    double psd_theta = 0.0;          // FOS_PSD_THETA: rotation threshold of the refinement (0: the built-in value)
     int32_t count_repl;         // 1: this rank counts the replicated entries in scalar sums (always 1 when not row-sharded)
     int64_t n_repl;             // replicated leading entries of every vector (0 when not row-sharded)
 };
@@ -417,7 +421,8 @@ void launch_relax_ew(const LaunchCtx& c, double2* t1, double2* t2, const double2
 void launch_cones_soc(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones);
 void launch_cones_exp(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones);
 int  launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones,
-                      int kmin, int kmax, double* gscratch, const double* vin, double* vout, int have_prev, int* stats, int phase_limit);
+                      int kmin, int kmax, double* gscratch, const double* vin, double* vout, int have_prev, int* stats, int phase_limit,
+                      int32_t* redo = nullptr);
 size_t psd_scratch_bytes(int kmax, int ncones);
 size_t psd_basis_doubles(int kmax, int ncones);
 

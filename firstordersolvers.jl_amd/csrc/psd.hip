@@ -169,13 +169,11 @@ template <int NW>
 __device__ __forceinline__ int jacobi64_regs(double* __restrict__ G, const int ld, const int tid, const double tol2, double* scratch);
 
 template <bool USE_LDS, bool WARM, int THREADS>
-__global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, const d2* __restrict__ in,
-                                                          const ConeDesc* __restrict__ cones,
-                                                          double* __restrict__ gscratch, size_t scratch_stride,
-                                                          const double* __restrict__ vin, double* __restrict__ vout,
-                                                          size_t vstride, int have_prev, int* __restrict__ stats, int phase_limit, const int32_t* __restrict__ gate) {
-    if (gate && !*gate) return;                  // speculatively enqueued behind a CG batch that did not converge: no-op
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+__device__ __forceinline__ void psd_block(d2* __restrict__ out, const d2* __restrict__ in,
+                                          const ConeDesc* __restrict__ cones,
+                                          double* __restrict__ gscratch, size_t scratch_stride,
+                                          const double* __restrict__ vin, double* __restrict__ vout,
+                                          size_t vstride, int have_prev, int* __restrict__ stats, int phase_limit, double* __restrict__ smem) {
     const int tid = threadIdx.x;
     const int cone = blockIdx.x >> 1, part = blockIdx.x & 1;
     const ConeDesc cd = cones[cone];
@@ -426,6 +424,17 @@ __global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, cons
         if (dual) s = x[2 * (int64_t)idx] + s;
         y[2 * (int64_t)idx] = s;
     }
+}
+
+template <bool USE_LDS, bool WARM, int THREADS>
+__global__ __launch_bounds__(THREADS) void psd_kernel(d2* __restrict__ out, const d2* __restrict__ in,
+                                                          const ConeDesc* __restrict__ cones,
+                                                          double* __restrict__ gscratch, size_t scratch_stride,
+                                                          const double* __restrict__ vin, double* __restrict__ vout,
+                                                          size_t vstride, int have_prev, int* __restrict__ stats, int phase_limit, const int32_t* __restrict__ gate) {
+    if (gate && !*gate) return;                  // speculatively enqueued behind a CG batch that did not converge: no-op
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    psd_block<USE_LDS, WARM, THREADS>(out, in, cones, gscratch, scratch_stride, vin, vout, vstride, have_prev, stats, phase_limit, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -801,6 +810,442 @@ __global__ __launch_bounds__(64) void psd64_wave_kernel(d2* __restrict__ out, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Order 64, WARM: the projection by eigenvector REFINEMENT -- matrix products only, no serial chain of Jacobi steps.
+//
+// The warm-started Jacobi iteration above is a chain of 64 barrier-separated steps per sweep (0.46 us each with four wavefronts
+// per matrix) however few matrices there are: a shard of a multi-GPU run (at most one matrix per CU) spends 100 of its 118 us
+// there.  But a basis V that nearly diagonalises M can be corrected by first-order perturbation theory, quadratically convergent
+// and all of it 64 x 64 x 64 products on the matrix cores (the iteration of Ogita & Aishima, "Iterative refinement for symmetric
+// eigenvalue decomposition", 2018, restated with ONE product for both correction terms):
+//     G = M V;   d_j = (v_j . g_j) / (v_j . v_j);   N = V' (G - V diag d)      [ N_ij = (V'MV)_ij - (V'V)_ij d_j , N_jj = 0 ]
+//     E_ij = N_ij / (d_j - d_i)  (i != j),   E_jj = (1 - v_j . v_j) / 2;       V <- V + V E
+// (three products per iteration; the second term of N_ij is what pulls V back to orthonormal columns), until ||E||_F <= 1e-6; then
+// ONE Newton-Schulz step V <- V (I + (I - V'V) / 2) -- the part of the orthogonality defect of a pair with a tiny gap that is below
+// the rounding level of N (defect x gap < eps ||M||) is invisible to the iteration, and a defect of 1e-10 would be an error of 1e-10
+// in the projection -- and P = V max(diag d, 0) V'.  3 it + 3 products.
+// START: the solver's iterates move smoothly, so the basis is EXTRAPOLATED from the last two, V0 = 2 V_prev - V_pp (the two
+// ping-pong buffers): in C4's steady state the first ||E||_F drops from 2e-2 to 1e-3 (outer iteration 200) ... 1e-4 (350), and
+// two or three iterations do where the plain start needs four.  If the extrapolated start does not converge (a jump of the
+// iterate), the kernel starts again from V_prev.
+// Pairs whose coupling is NOT small against their gap (|N_ij| > RF_THETA |d_j - d_i|: eigenvalues that nearly coincide or have
+// just crossed) are turned first by an exact two-sided Jacobi rotation of S = N + diag d and of the two columns of V -- a rare,
+// slow path through LDS; couplings below the rounding level of the products (RF_NOISE ||M||_F) are left alone whatever the gap
+// (a cluster is an invariant subspace: any basis of it gives the same projection).  A matrix that needs more than RF_MAX_ROT
+// rotations or RF_MAX_IT iterations (a cold basis, a jump of the iterate, a cluster split by the change) is FLAGGED (record 1) and
+// left to the Jacobi kernel, which the launcher runs behind this one for the flagged matrices only, from a cold start.  Record 2:
+// accepted, but columns were rotated -- the next call must not extrapolate across that.
+// One workgroup of four wavefronts per matrix; wavefront w owns the 16-column block w of every product (operand and result
+// layouts of v_mfma_f64_16x16x4_f64 chain without data movement: a result tile IS the B operand of the next product); M and V
+// live in LDS (leading dimension 66; the rotation path borrows M's array and unpacks M again afterwards).
+constexpr int RF_LD = 66;
+constexpr int RF_MAX_IT = 7;
+constexpr int RF_MAX_ROT = 12;
+constexpr double RF_THETA = 0.2;
+constexpr double RF_ACCEPT2 = 1e-12;          // ||E||_F <= 1e-6 at the last update: error of the projection < 1e-13 ||M|| (measured on the oracle)
+constexpr double RF_NOISE = 16.0 * 2.220446049250313e-16;
+__host__ inline size_t psd64r_lds_bytes() {
+    const size_t own = (size_t)(2 * 64 * RF_LD + 64 + 64) * sizeof(double);
+    return own > psd_lds_bytes(64) ? own : psd_lds_bytes(64);      // (the Jacobi path of a flagged matrix runs in the same workgroup)
+}
+// per-matrix record between calls: int32 code [nmat] (0 accepted, 1 left to Jacobi), then uint64 mask [nmat] of the columns that were
+// rotated (the next call does not extrapolate those)
+__host__ __device__ inline size_t psd64r_record_ints(int nmat) { return (size_t)nmat * 4; }
+
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * (2.0 - x * y);
+    y = y * (2.0 - x * y);
+    return y;
+}
+// sum over the four lanes l, l^16, l^32, l^48 (the four row groups of a tile column): the same bits in each
+__device__ __forceinline__ double colgroup_sum(double v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+// the packed input of a thread (9 entries) -> M in LDS (both triangles, diagonal scaled by sqrt(2)); returns the thread's share of ||M||_F^2
+__device__ __forceinline__ void rf_fetch_m(double (&v)[9], const double* __restrict__ x, int tid) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int idx = q * 256 + tid;
+        v[q] = idx < P64_LEN ? x[2 * (int64_t)idx] : 0.0;
+    }
+}
+__device__ __forceinline__ double rf_store_m(double* __restrict__ Ml, const double (&v)[9], double sgn, int tid) {
+    double fro = 0.0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int idx = q * 256 + tid;
+        const unsigned ij = psd64_index.ij[idx < P64_LEN ? idx : 0];
+        const int i = ij & 0xFF, j = ij >> 8;
+        double m = sgn * v[q];
+        if (idx < P64_LEN) {
+            if (i == j) { m *= SQRT2; fro += m * m; }
+            else fro += 2.0 * m * m;
+            Ml[i + j * RF_LD] = m;
+            Ml[j + i * RF_LD] = m;
+        }
+    }
+    return fro;
+}
+// acc[ib] += sum_kk A(ib, kk) B(kk) for the four row tiles ib of a column block: A(ib, kk) = base[ib SI + kk SK] (LDS), B(kk) = b[kk >> 2][kk & 3].
+// The A fragments of four k-steps are requested while the matrix cores work on the previous four (the compiler, left alone, requests
+// each step's fragments behind the previous step's last MFMA and exposes the LDS latency sixteen times per product).
+template <int SI, int SK>
+__device__ __forceinline__ void rf_gemm(v4d (&acc)[4], const double* __restrict__ base, const v4d (&b)[4]) {
+    double a0[16], a1[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a0[q] = base[(q & 3) * SI + (q >> 2) * SK];
+#pragma unroll
+    for (int c = 0; c < 4; c += 2) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a1[q] = base[(q & 3) * SI + (4 * (c + 1) + (q >> 2)) * SK];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b[c][q >> 2], acc[q & 3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < 4) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a0[q] = base[(q & 3) * SI + (4 * (c + 2) + (q >> 2)) * SK];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b[c + 1][q >> 2], acc[q & 3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ __launch_bounds__(256) void psd64_refine_kernel(d2* __restrict__ out, const d2* __restrict__ in, const ConeDesc* __restrict__ cones,
+                                                           const double* __restrict__ vin, double* __restrict__ vout, int have_prev,
+                                                           int* __restrict__ stats, int32_t* __restrict__ rec, int phase_limit,
+                                                           const int32_t* __restrict__ gate, const double theta) {
+    if (gate && !*gate) return;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int LD = RF_LD;
+    double* Ml = smem;                      // M, column-major (symmetric); S = N + diag d in the rotation path; P at the end
+    double* Vl = Ml + 64 * LD;              // V, column-major: V[k][j] at k + LD j
+    double* dl = Vl + 64 * LD;              // [64] eigenvalue estimates
+    double* red = dl + 64;                  // [64] reductions / broadcast
+    int* ired = reinterpret_cast<int*>(red + 32);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const int jcol = 16 * w + lr;
+    const int cone = blockIdx.x >> 1, part = blockIdx.x & 1;
+    const ConeDesc cd = cones[cone];
+    const bool dual = (cd.dual_part == part);
+    const double sgn = dual ? -1.0 : 1.0;
+    const double* __restrict__ x = reinterpret_cast<const double*>(in + cd.start) + part;
+    double* __restrict__ y = reinterpret_cast<double*>(out + cd.start) + part;
+    const d2* __restrict__ Vp = reinterpret_cast<const d2*>(vin + (size_t)blockIdx.x * 4096);
+    d2* __restrict__ Vn = reinterpret_cast<d2*>(vout + (size_t)blockIdx.x * 4096);
+    int32_t* __restrict__ code = rec + blockIdx.x;
+    unsigned long long* __restrict__ cmask = reinterpret_cast<unsigned long long*>(rec + 2 * gridDim.x) + blockIdx.x;
+    // extrapolation needs the bases of the last TWO projections, the second a continuation of the first (accepted by this kernel);
+    // columns that were rotated then are not extrapolated
+    int attempt = (have_prev >= 2 && *code == 0) ? 0 : 1;
+    const unsigned long long skip = attempt == 0 ? *cmask : 0ull;
+
+    // ---- everything the start needs is requested at once: the packed matrix and the two bases
+    double fro;
+    {
+        double xv[9];
+        rf_fetch_m(xv, x, tid);
+        d2 vv[8], vo[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) vv[q] = Vp[tid + 256 * q];
+        if (attempt == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) vo[q] = Vn[tid + 256 * q];
+        }
+        fro = rf_store_m(Ml, xv, sgn, tid);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = 2 * (tid + 256 * q);           // rows k, k + 1 of column j = e >> 6
+            if (attempt == 0 && !((skip >> (e >> 6)) & 1ull)) { vv[q].x = 2.0 * vv[q].x - vo[q].x; vv[q].y = 2.0 * vv[q].y - vo[q].y; }
+            *reinterpret_cast<d2*>(Vl + (e & 63) + (e >> 6) * LD) = vv[q];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
+    if (lane == 0) red[w] = fro;
+    __syncthreads();
+    const double scale = sqrt((red[0] + red[1]) + (red[2] + red[3]));
+    const double noise = RF_NOISE * scale;
+    if (phase_limit == 11) return;
+
+    v4d Vb[4];                              // this wavefront's column block: Vb[ib][r] = V[16 ib + 4 r + lk][16 w + lr] (B operand of k-step 4 ib + r)
+    int it = 0, nrot = 0, fail = 0, total_it = 0;
+    unsigned long long rmask = 0ull;
+    double dj = 0.0;
+    for (;; ++attempt) {
+        if (attempt == 1 && total_it > 0) {
+            // the extrapolated start did not converge: again from the previous basis
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = 2 * (tid + 256 * q);
+                *reinterpret_cast<d2*>(Vl + (e & 63) + (e >> 6) * LD) = Vp[tid + 256 * q];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Vb[ib][r] = Vl[16 * ib + 4 * r + lk + jcol * LD];
+        fail = 0; nrot = 0; rmask = 0ull;
+        for (it = 0;; ++it) {
+            if (it >= RF_MAX_IT) { fail = 1; break; }
+            ++total_it;
+            // ---- G = M V (column block w)
+            v4d acc[4];
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) acc[ib] = v4d{0.0, 0.0, 0.0, 0.0};
+            rf_gemm<16, 4 * LD>(acc, Ml + lr + lk * LD, Vb);
+            if (phase_limit == 12) return;
+            // ---- Rayleigh quotients of the block's columns; G' = G - V diag d
+            double vv = 0.0, vg = 0.0;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { vv += Vb[ib][r] * Vb[ib][r]; vg += Vb[ib][r] * acc[ib][r]; }
+            vv = colgroup_sum(vv); vg = colgroup_sum(vg);
+            dj = vv > 0.0 ? vg / vv : 0.0;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ib][r] -= Vb[ib][r] * dj;
+            if (lk == 0) dl[jcol] = dj;
+            // ---- N = V' G' (column block w): A operand = columns of V read as rows
+            v4d nac[4];
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) nac[ib] = v4d{0.0, 0.0, 0.0, 0.0};
+            rf_gemm<16 * LD, 4>(nac, Vl + lk + lr * LD, acc);
+            __syncthreads();                                   // d of all blocks visible
+            if (phase_limit == 13) return;
+            // ---- E from N; pairs that need a rotation first
+            double conv2 = 0.0;
+            int bad = 0;
+            v4d ev[4];
+            auto make_e = [&]() {
+                conv2 = 0.0; bad = 0;
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * ib + 4 * r + lk;
+                        const double n = nac[ib][r];
+                        const double den = dj - dl[i];
+                        const double an = fabs(n), ad = fabs(den);
+                        double e;
+                        if (i == jcol) e = 0.5 * (1.0 - vv);
+                        else if (an <= noise) e = 0.0;             // rounding level: never chased, whatever the gap (a quotient of two
+                                                                   // rounding errors would be an O(theta) "rotation" that is not even skew)
+                        else if (an <= theta * ad) e = n * fast_rcp(den);
+                        else { e = 0.0; bad = 1; }
+                        conv2 += e * e;
+                        ev[ib][r] = e;
+                    }
+            };
+            make_e();
+            if (__syncthreads_or(bad)) {
+                // ---- rare: exact rotations of the offending pairs on S = N + diag d (in M's array) and on the columns of V
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * ib + 4 * r + lk;
+                        Ml[i + jcol * LD] = (i == jcol) ? dj : nac[ib][r];
+                    }
+                __syncthreads();
+                for (;;) {
+                    // worst pair: the largest coupling among the pairs that are neither small against their gap nor below the noise
+                    double best = 0.0; int bidx = -1;
+                    {
+                        const int j = tid & 63, i0 = (tid >> 6) * 16;
+                        const double djj = Ml[j + j * LD];
+#pragma unroll 4
+                        for (int q = 0; q < 16; ++q) {
+                            const int i = i0 + q;
+                            if (i == j) continue;
+                            const double an = fabs(Ml[i + j * LD]), ad = fabs(djj - Ml[i + i * LD]);
+                            if (!(an <= theta * ad) && !(an <= noise) && !(an <= best)) { best = an; bidx = i | (j << 8); }
+                        }
+                    }
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const double ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bidx, off, 64);
+                        if (ob > best || (ob == best && oi > bidx)) { best = ob; bidx = oi; }
+                    }
+                    if (lane == 0) { red[w] = best; ired[w] = bidx; }
+                    __syncthreads();
+                    double gb = red[0]; int gi = ired[0];
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) if (red[q] > gb || (red[q] == gb && ired[q] > gi)) { gb = red[q]; gi = ired[q]; }
+                    __syncthreads();
+                    if (gi < 0) break;
+                    if (++nrot > RF_MAX_ROT) { fail = 1; break; }
+                    const int pi = gi & 0xFF, pj = gi >> 8;
+                    rmask |= (1ull << pi) | (1ull << pj);
+                    const double a = Ml[pi + pi * LD], b = Ml[pj + pj * LD], g = 0.5 * (Ml[pi + pj * LD] + Ml[pj + pi * LD]);
+                    double cs = 1.0, sn = 0.0;
+                    if (g != 0.0) {
+                        const double zeta = (b - a) / (2.0 * g);
+                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        cs = 1.0 / sqrt(1.0 + t * t); sn = t * cs;
+                    }
+                    __syncthreads();
+                    if (tid < 64) {                         // columns pi, pj of S
+                        const double ti = Ml[tid + pi * LD], tj = Ml[tid + pj * LD];
+                        Ml[tid + pi * LD] = cs * ti - sn * tj; Ml[tid + pj * LD] = sn * ti + cs * tj;
+                    } else if (tid < 128) {                 // columns pi, pj of V
+                        const int rr = tid - 64;
+                        const double ti = Vl[rr + pi * LD], tj = Vl[rr + pj * LD];
+                        Vl[rr + pi * LD] = cs * ti - sn * tj; Vl[rr + pj * LD] = sn * ti + cs * tj;
+                    }
+                    __syncthreads();
+                    if (tid < 64) {                         // rows pi, pj of S
+                        const double ti = Ml[pi + tid * LD], tj = Ml[pj + tid * LD];
+                        Ml[pi + tid * LD] = cs * ti - sn * tj; Ml[pj + tid * LD] = sn * ti + cs * tj;
+                    }
+                    __syncthreads();
+                    if (tid == 0) { Ml[pi + pj * LD] = 0.0; Ml[pj + pi * LD] = 0.0; }
+                    __syncthreads();
+                }
+                if (!fail) {
+                    // back to registers: d, N, this block's columns of V
+                    dj = Ml[jcol + jcol * LD];
+#pragma unroll
+                    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 16 * ib + 4 * r + lk;
+                            nac[ib][r] = Ml[i + jcol * LD];
+                            Vb[ib][r] = Vl[i + jcol * LD];
+                        }
+                    if (lk == 0) dl[jcol] = dj;
+                }
+                __syncthreads();
+                {                                              // M back into its array
+                    double xv[9];
+                    rf_fetch_m(xv, x, tid);
+                    rf_store_m(Ml, xv, sgn, tid);
+                }
+                __syncthreads();
+                if (fail) break;
+                make_e();      // (a pair can still be flagged here only through the difference between (N_ij + N_ji) / 2 and N_ij: left to the next iteration)
+            }
+            // ---- ||E||_F^2 over the workgroup
+            for (int off = 32; off > 0; off >>= 1) conv2 += __shfl_xor(conv2, off, 64);
+            if (lane == 0) red[8 + w] = conv2;
+            if (phase_limit == 14) return;
+            // ---- V <- V + V E (column block w); A operand = rows of V
+            v4d vn[4];
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) vn[ib] = Vb[ib];
+            rf_gemm<16, 4 * LD>(vn, Vl + lr + lk * LD, ev);
+            __syncthreads();                                   // every wavefront has read the old V
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                Vb[ib] = vn[ib];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Vl[16 * ib + 4 * r + lk + jcol * LD] = vn[ib][r];
+            }
+            const double c2 = (red[8] + red[9]) + (red[10] + red[11]);
+            __syncthreads();
+            if (phase_limit == 15) return;
+            if (c2 <= RF_ACCEPT2) { ++it; break; }
+            if (!(c2 < 1e300)) { fail = 1; break; }            // NaN / overflow: not ours
+        }
+        if (!fail || attempt >= 1) break;
+    }
+    if (fail) {
+        // the basis does not fit this matrix: Jacobi from a cold start, in this workgroup
+        if (tid == 0) { *code = 1; *cmask = 0ull; }
+        __syncthreads();
+        psd_block<true, true, 256>(out, in, cones, nullptr, 0, vin, vout, 4096, 0, stats, 0, smem);
+        return;
+    }
+    if (tid == 0) { *code = 0; *cmask = rmask; if (stats) stats[blockIdx.x] = 100 + 1000 * (attempt == 0) + 16 * nrot + total_it; }
+    if (phase_limit == 16) return;
+
+    // ---- one Newton-Schulz step: V <- V (I + (I - V'V) / 2)
+    {
+        v4d g[4];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) g[ib] = v4d{0.0, 0.0, 0.0, 0.0};
+        rf_gemm<16 * LD, 4>(g, Vl + lk + lr * LD, Vb);
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[ib][r] = ((16 * ib + 4 * r + lk == jcol) ? 0.5 : 0.0) - 0.5 * g[ib][r];
+        v4d vn[4];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) vn[ib] = Vb[ib];
+        rf_gemm<16, 4 * LD>(vn, Vl + lr + lk * LD, g);
+        __syncthreads();
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Vl[16 * ib + 4 * r + lk + jcol * LD] = vn[ib][r];
+        __syncthreads();
+    }
+    if (phase_limit == 17) return;
+    // ---- P = V max(diag d, 0) V': the 10 tiles on and below the diagonal, round-robin over the wavefronts, into M's array
+    {
+        constexpr int NT = 3;
+        v4d acc[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int tt = w + 4 * q;
+            acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+            if (tt < 10) {
+                const int jb = tt < 4 ? 0 : (tt < 7 ? 1 : (tt < 9 ? 2 : 3));
+                const int ib = tt < 4 ? tt : (tt < 7 ? tt - 3 : (tt < 9 ? tt - 5 : 3));
+                const double* __restrict__ va = Vl + 16 * ib + lr + lk * LD;
+                const double* __restrict__ vb = Vl + 16 * jb + lr + lk * LD;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const double f = fmax(dl[kk * 4 + lk], 0.0);
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk * 4 * LD], f * vb[kk * 4 * LD], acc[q], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int tt = w + 4 * q;
+            if (tt < 10) {
+                const int jb = tt < 4 ? 0 : (tt < 7 ? 1 : (tt < 9 ? 2 : 3));
+                const int ib = tt < 4 ? tt : (tt < 7 ? tt - 3 : (tt < 9 ? tt - 5 : 3));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ml[ib * 16 + lk + 4 * r + (jb * 16 + lr) * LD] = acc[q][r];
+            }
+        }
+    }
+    // the new basis (coalesced, from LDS)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = 2 * (tid + 256 * q);
+        Vn[tid + 256 * q] = *reinterpret_cast<const d2*>(Vl + (e & 63) + (e >> 6) * LD);
+    }
+    __syncthreads();
+    {
+        double xv[9]; unsigned short ij[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int idx = q * 256 + tid;
+            ij[q] = psd64_index.ij[idx < P64_LEN ? idx : 0];
+            xv[q] = (dual && idx < P64_LEN) ? x[2 * (int64_t)idx] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int idx = q * 256 + tid;
+            const int i = ij[q] & 0xFF, j = ij[q] >> 8;
+            double v = Ml[i + j * LD];
+            if (i == j) v *= INV_SQRT2;
+            if (idx < P64_LEN) y[2 * (int64_t)idx] = xv[q] + v;
+        }
+    }
+}
+
 size_t psd_scratch_bytes(int kmax, int ncones) {
     if (ncones <= 0) return 0;
     if (psd_lds_bytes(kmax) <= 160 * 1024 - 256) return 0;
@@ -813,7 +1258,7 @@ size_t psd_basis_doubles(int kmax, int ncones) {       // one warm-start basis b
 }
 
 int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones, int kmin, int kmax, double* gscratch,
-                     const double* vin, double* vout, int have_prev, int* stats, int phase_limit) {
+                     const double* vin, double* vout, int have_prev, int* stats, int phase_limit, int32_t* redo) {
     if (ncones <= 0) return FOS_OK;
     // per-handle configuration (fos_create reads the device's CU count and the FOS_PSD_* switches ONCE: two host threads driving
     // handles on different devices share nothing here, and the kernel choice cannot change between a speculative enqueue and its re-run)
@@ -823,6 +1268,21 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     // (psd_kernel<.., 256>, jacobi64_regs) below that (a shard of a multi-GPU run; 128 / 256 / 512 matrices: 118 / 127 / 179 us
     // against 173 / 182 / 190).  FOS_PSD_WAVE=0 / 1 forces the workgroup / the wavefront form.
     const int wave_env = c.psd_wave;
+    // warm, every cone of order 64, a basis from the previous projection: refinement by matrix products (psd64_refine_kernel) with the
+    // Jacobi workgroup kernel behind it for the matrices it flags.  FOS_PSD_REFINE=0 / 1 switches it off / on for every batch size;
+    // by default it runs where the workgroup kernel would (at most two matrices per CU: the shard of a multi-GPU run).
+    const bool refine_ok = kmin == 64 && kmax == 64 && vin && vout && have_prev && redo && (phase_limit == 0 || phase_limit >= 11);
+    if (refine_ok && (c.psd_refine == 1 || (c.psd_refine < 0 && wave_env != 1 && ncones <= cus))) {
+        const size_t rl = psd64r_lds_bytes();
+        if (!*c.psd_attr_set_r) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd64_refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);
+            if (e != hipSuccess) { set_error("hipFuncSetAttribute(psd64_refine_kernel): %s", hipGetErrorString(e)); return FOS_EHIP; }
+            *c.psd_attr_set_r = true;
+        }
+        hipLaunchKernelGGL(psd64_refine_kernel, dim3(2 * ncones), dim3(256), rl, c.stream, out, in, cones, vin, vout, c.psd_extrapolate ? have_prev : 1, stats, redo,
+                           phase_limit, c.gate, c.psd_theta > 0.0 ? c.psd_theta : RF_THETA);
+        return FOS_OK;
+    }
     if (kmin == 64 && kmax == 64 && wave_env != 0 && (wave_env == 1 || ncones > cus)) {
         const size_t wl = psd64w_lds_bytes();
         const size_t vs = (size_t)64 * 64;

@@ -141,7 +141,11 @@ struct fos_solver {
     int psd_phase_limit = 0;                   // diagnostic: stop the PSD kernel after a phase (wrong results!)
     int cus = 256;                             // compute units of `device`
     int psd_wave = -1; bool psd_narrow = false, psd_wide = false; int psd_wide_threads = 512;      // FOS_PSD_* (read at fos_create)
-    mutable bool psd_attr_set = false;
+    mutable bool psd_attr_set = false, psd_attr_set_r = false;
+    int32_t* psd_redo = nullptr;               // per (cone, copy): 1 = the refinement kernel left the matrix to the Jacobi kernel
+    int psd_refine = -1;                       // FOS_PSD_REFINE
+    bool psd_extrapolate = true;               // FOS_PSD_EXTRAPOLATE
+    double psd_theta = 0.0;                    // FOS_PSD_THETA
 
     // scalars
     DevState* st = nullptr;
@@ -247,7 +251,7 @@ struct fos_solver {
         c.pre = pre_on ? pre_sums : nullptr;
         c.between = nullptr; c.between_arg = nullptr;
         c.cus = cus; c.psd_wave = psd_wave; c.psd_narrow = psd_narrow; c.psd_wide = psd_wide; c.psd_wide_threads = psd_wide_threads;
-        c.psd_attr_set = &psd_attr_set;
+        c.psd_attr_set = &psd_attr_set; c.psd_attr_set_r = &psd_attr_set_r; c.psd_refine = psd_refine; c.psd_extrapolate = psd_extrapolate; c.psd_theta = psd_theta;
         c.count_repl = (!row_sharded || rank == 0) ? 1 : 0;
         c.n_repl = row_sharded ? n : 0;
         if (row_sharded) { c.between = &fos_solver::sum_slots_over_ranks; c.between_arg = const_cast<fos_solver*>(this); }
@@ -660,10 +664,10 @@ int prox_cones(fos_solver* h, d2* out, const d2* in, const int32_t* gate = nullp
     launch_cones_exp(c, out, in, h->expc, h->nexp);
     const int pe = h->npsd > 0 ? prof_begin(h, FOS_PROF_PSD, 0, h->prof_seen[FOS_PROF_PSD]++) : -1;
     FOS_TRY(launch_cones_psd(c, out, in, h->psd, h->npsd, h->psd_kmin, h->psd_kmax, h->psd_scratch,
-                             h->psd_V[h->psd_cur], h->psd_V[1 - h->psd_cur], h->psd_have_prev, h->psd_stats, h->psd_phase_limit));
+                             h->psd_V[h->psd_cur], h->psd_V[1 - h->psd_cur], h->psd_have_prev, h->psd_stats, h->psd_phase_limit, h->psd_redo));
     prof_end(h, pe);
     // (a diagnostic launch truncated before the basis store leaves the previous basis current)
-    if (h->npsd > 0 && h->psd_V[0] && (h->psd_phase_limit == 0 || h->psd_phase_limit >= 4)) { h->psd_cur = 1 - h->psd_cur; h->psd_have_prev = 1; }
+    if (h->npsd > 0 && h->psd_V[0] && (h->psd_phase_limit == 0 || (h->psd_phase_limit >= 4 && h->psd_phase_limit < 11))) { h->psd_cur = 1 - h->psd_cur; h->psd_have_prev = std::min(h->psd_have_prev + 1, 2); }
     return check_launch("cone projection");
 }
 
@@ -1055,6 +1059,9 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->cus = cus;
     if (const char* e = getenv("FOS_PSD_WAVE")) h->psd_wave = atoi(e);
+    if (const char* e = getenv("FOS_PSD_REFINE")) h->psd_refine = atoi(e);
+    if (const char* e = getenv("FOS_PSD_EXTRAPOLATE")) h->psd_extrapolate = atoi(e) != 0;
+    if (const char* e = getenv("FOS_PSD_THETA")) h->psd_theta = atof(e);
     h->psd_narrow = getenv("FOS_PSD_NARROW") != nullptr;
     h->psd_wide = getenv("FOS_PSD_WIDE") != nullptr;
     if (const char* e = getenv("FOS_PSD_THREADS")) h->psd_wide_threads = atoi(e);
@@ -1279,6 +1286,10 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     if (!getenv("FOS_PSD_COLD")) {
         const size_t vb = psd_basis_doubles(h->psd_kmax, h->npsd);
         if (vb) { FOS_TRY(dev_alloc(h, &h->psd_V[0], vb)); FOS_TRY(dev_alloc(h, &h->psd_V[1], vb)); }
+        if (vb && h->psd_kmin == 64 && h->psd_kmax == 64) {
+            FOS_TRY(dev_alloc(h, &h->psd_redo, (size_t)8 * h->npsd));          // code [2 npsd] + 64-bit column mask [2 npsd]
+            FOS_HIP(hipMemset(h->psd_redo, 0, sizeof(int32_t) * 8 * h->npsd));
+        }
     }
 
     // ---- scalars

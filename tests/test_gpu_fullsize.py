@@ -229,3 +229,26 @@ def test_c5_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle):
     lives on the device only -- outer iteration 241 from the device's state at iteration 240, against the oracle."""
     prob = pkg.workloads.c5_mixed()
     _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 240, 1e-9)
+
+
+def test_c4_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle):
+    """C4 (DR, 512 x PSD(64): dual tiles, 17 CG iterations at the tolerance floor, the batched 1024-matrix PSD projection), outer
+    iteration 201 from the device's state at iteration 200 against the oracle's step (solverwrapper.jl:23-29, gap.jl:61-80) --
+    relative 1e-9 (BASELINE tolerance 1e-8).  The numpy oracle needs ~2 s for this step."""
+    prob = pkg.workloads.c4_block_sdp()
+    _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 200, 1e-9)
+
+
+def test_c4_shard_one_steady_state_iteration_vs_oracle(pkg, oracle):
+    """What one of eight ranks holds of C4 (64 blocks, 128 matrices per projection: the small-batch PSD path -- refinement by matrix
+    products from an extrapolated basis, psd64_refine_kernel), outer iterations 201 and 231 against the oracle's step, 1e-9."""
+    prob = pkg.workloads.c4_block_sdp(nblocks=512, block_range=(0, 64))
+    _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 200, 1e-9)
+    _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 230, 1e-9)
+
+
+def test_c2_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle):
+    """C2 (DR, dense 5000 x 10000 LP in tall dual tiles, ~45 CG iterations at the tolerance floor), outer iteration 301 from the
+    device's state at iteration 300 against the oracle's step, relative 1e-9.  The numpy oracle needs ~5 s for this step."""
+    prob = pkg.workloads.c2_lp()
+    _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 300, 1e-9)

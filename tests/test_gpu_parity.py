@@ -256,11 +256,13 @@ PSD_KNOWN = np.array([[0.03909044662082823, -0.00823811392936668],
                       [-0.00823811392936668, 0.00173614084718757]])
 
 
-@pytest.fixture(params=["wave", "workgroup"])
+@pytest.fixture(params=["wave", "workgroup", "refine"])
 def psd64_kernel(request, monkeypatch):
-    """Order-64 cones have two kernels (one wavefront per matrix / one workgroup per matrix; the library picks by batch size):
-    the PSD tests run both."""
+    """Order-64 cones have three kernels (Jacobi with one wavefront per matrix / one workgroup per matrix, and -- warm, behind a
+    previous projection -- refinement by matrix products with the Jacobi kernel behind it; the library picks by batch size):
+    the PSD tests run all of them."""
     monkeypatch.setenv("FOS_PSD_WAVE", "1" if request.param == "wave" else "0")
+    monkeypatch.setenv("FOS_PSD_REFINE", "1" if request.param == "refine" else "0")
     return request.param
 
 
@@ -336,6 +338,84 @@ def test_psd_warm_start_drift_and_clustered_spectra(pkg, dev_ops, psd64_kernel):
             S2.prox(ref, z)
             out = d.prox_cones(z)
             assert np.linalg.norm(out - ref) <= 1e-12 * max(1e-300, np.linalg.norm(z)), (k, it)
+
+
+def test_psd_refinement_path(pkg, dev_ops, monkeypatch):
+    """psd64_refine_kernel (warm order-64 projections by matrix products: three per iteration, quadratic convergence) against
+    LAPACK (oracle) on sequences built to take each of its paths -- the kernel's own record says which one ran:
+    100 (+ 1000 if the extrapolated start was accepted) + 16 rotations + iterations = accepted, otherwise the sweeps of the
+    Jacobi kernel it handed the matrix to."""
+    monkeypatch.setenv("FOS_PSD_REFINE", "1")
+    monkeypatch.setenv("FOS_PSD_WAVE", "0")
+    rng = np.random.default_rng(77)
+    k, ncone = 64, 3
+    ln = k * (k + 1) // 2
+    K1 = [("SDP", ln)] * ncone
+    d, _, _ = dev_ops(sp.random(ncone * ln, 3, density=0.01, format="csc", random_state=rng), None, None, K1, [("Free", 3)])
+    d.psd_debug(True, 0)
+    S2 = orc.DualConeProduct(orc.ConeProduct.from_lengths([(orc.CONE_SDP, ln)] * ncone), orc.ConeProduct.from_lengths([(orc.CONE_FREE, 3)]))
+    sym = lambda B: (B + B.T) / 2
+
+    def project(mats):
+        z = np.zeros(d.N)
+        for c_, M in enumerate(mats):
+            sv = pkg.workloads._svec(sym(M))
+            z[3 + c_ * ln:3 + (c_ + 1) * ln] = sv * (1.0 + 0.25 * c_)       # the dual copy sees a scaled matrix: six different ones
+            z[d.l + 3 + c_ * ln:d.l + 3 + (c_ + 1) * ln] = sv
+        ref = np.empty(d.N)
+        S2.prox(ref, z)
+        out = d.prox_cones(z)
+        err = np.linalg.norm(out - ref) / max(1e-300, np.linalg.norm(z))
+        st = d.psd_sweeps().copy()
+        st[st >= 1100] -= 1000
+        return err, st
+
+    base = [sym(rng.standard_normal((k, k))) for _ in range(ncone)]
+    drift = [sym(rng.standard_normal((k, k))) for _ in range(ncone)]
+    err, st = project(base)                                   # cold: no basis yet -> Jacobi
+    assert err <= 5e-13 and (st < 100).all() and (st > 0).all(), (err, st)
+    # (1) steady drift, 1e-3 relative per call: accepted after 3-5 iterations, no rotation as a rule
+    for t in range(1, 6):
+        err, st = project([B + 1e-3 * t * D for B, D in zip(base, drift)])
+        assert err <= 5e-13, (t, err, st)
+        assert (st >= 100).all() and ((st - 100) % 16 <= 8).all(), (t, st)
+    # (2) no change at all, then a change at rounding level: one iteration
+    cur = [B + 5e-3 * D for B, D in zip(base, drift)]
+    err, st = project(cur)
+    assert err <= 5e-13 and (st >= 100).all() and ((st - 100) % 16 <= 4).all(), (err, st)
+    # (3) two eigenvalues that nearly coincide and are coupled by the change: the rotation path
+    Q, _ = np.linalg.qr(rng.standard_normal((k, k)))
+    lam = np.linspace(-1.0, 1.0, k)
+    lam[20] = lam[21] + 1e-7                                  # same sign pair
+    lam[31] = -2e-7; lam[32] = 3e-7                           # a pair straddling zero
+    M1 = Q @ np.diag(lam) @ Q.T
+    err, st = project([M1] * ncone)                           # a jump: flagged, Jacobi
+    assert err <= 5e-13 and (st < 100).all(), (err, st)
+    C = np.zeros((k, k))
+    C[20, 21] = C[21, 20] = 3e-6
+    C[31, 32] = C[32, 31] = 2e-6
+    M2 = M1 + Q @ C @ Q.T + 1e-5 * drift[0]
+    err, st = project([M2] * ncone)
+    assert err <= 5e-13, (err, st)
+    assert (st >= 100).all() and ((st - 100) // 16 >= 1).any(), st          # accepted, with rotations
+    # (4) exactly repeated eigenvalues (two clusters), then the same matrix again and a small drift: couplings inside a cluster
+    #     are at rounding level and must not be chased
+    half = k // 2
+    M3 = Q @ np.diag([1.0] * half + [-1.0] * (k - half)) @ Q.T
+    project([M3] * ncone)
+    for t in range(3):
+        err, st = project([M3 + 1e-6 * t * drift[1]] * ncone)
+        assert err <= 5e-13, (t, err, st)
+    # (5) zero matrix, identity, rank one, a jump back: whatever path, the projection is right
+    v = rng.standard_normal(k)
+    for M in (np.zeros((k, k)), np.eye(k), np.outer(v, v), -np.outer(v, v), base[0], np.zeros((k, k)), base[1]):
+        err, st = project([M] * ncone)
+        assert err <= 5e-13, (err, st)
+    # (6) huge change of scale with the same eigenvectors: the basis still fits
+    err, st = project([1e6 * B for B in base])
+    err, st = project([1e6 * (B + 1e-4 * D) for B, D in zip(base, drift)])
+    assert err <= 5e-13 and (st >= 100).all(), (err, st)
+    d.psd_debug(False, 0)
 
 
 # ---------------------------------------------------------------------------------------------- status
