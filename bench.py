@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--workload", default="C4")
     ap.add_argument("--small", action="store_true", help="reduced sizes (smoke / CI); not a valid benchmark number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-raw-instance", action="store_true",
+                    help="N = 1, C4: skip the additional timing of the instance as SURVEY 8(d) writes it (A_j not divided by 32)")
     ap.add_argument("--spmv-wg", type=int, default=0)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1, C4: strong = the 512-block problem split over the ranks (default, the metric's definition); "
@@ -177,6 +179,7 @@ def main():
     def run_case(weak):
         """Build the (shard of the) problem, warm up to the steady state, time exactly --steps outer iterations."""
         reduction = "in-stream RCCL all-reduce"
+        peer_reason = None             # why the peer mailboxes are NOT the transport (None: they are, or there is one rank)
         t0 = time.time()
         prob, alg, desc, glob = build_problem(pkg, args.workload, world, rank, args.small, weak=weak, c4_scale=args.c4_scale)
         t_gen = time.time() - t0
@@ -192,12 +195,25 @@ def main():
             # scalar sums: peer mailboxes (one xGMI write latency per exchange) when every rank's self test passes,
             # otherwise the in-stream RCCL all-reduce set up above.  FOS_REDUCTION=rccl|peer|auto (default auto).
             want = "peer" if host_gloo else os.environ.get("FOS_REDUCTION", "auto")
+            if want == "rccl":
+                peer_reason = os.environ.get("FOS_PEER_FALLBACK_NOTE", "FOS_REDUCTION=rccl")
             if want != "rccl":
+                # first contact between DIFFERENT devices: can this device map its peers' memory at all?  (the IPC mapping below can
+                # succeed where loads and stores over the link do not)  Asked of the runtime, not assumed; a "no" names the pair.
+                why = None
                 try:
-                    mine = dev.peer_export()
+                    if not host_gloo:
+                        for g in range(torch.cuda.device_count()):
+                            if g != local_rank and g < world and not torch.cuda.can_device_access_peer(local_rank, g):
+                                why = "hipDeviceCanAccessPeer(%d, %d) = 0" % (local_rank, g)
+                                break
+                except Exception as exc:
+                    why = "peer-access query failed: %s" % exc
+                try:
+                    mine = dev.peer_export() if why is None else None
                 except Exception as exc:                      # no uncached allocation / IPC export on this device
                     print("rank %d: peer mailbox export failed (%s)" % (rank, exc), file=sys.stderr, flush=True)
-                    mine = None
+                    mine, why = None, "export: %s" % exc
                 handles = [None] * world
                 dist.all_gather_object(handles, mine)
                 ok = all(h is not None for h in handles)
@@ -207,17 +223,24 @@ def main():
                         dev.sync()
                     except Exception as exc:                  # IPC mapping not available between these devices
                         print("rank %d: peer mailboxes unavailable (%s)" % (rank, exc), file=sys.stderr, flush=True)
-                        ok = False
+                        ok, why = False, "open: %s" % exc
                 if agree(ok):
                     dist.barrier()
                     try:
                         ok = dev.peer_selftest(64)
+                        if not ok:
+                            why = "self test: wrong sums"
                     except Exception as exc:
                         print("rank %d: peer mailbox self test raised (%s)" % (rank, exc), file=sys.stderr, flush=True)
-                        ok = False
+                        ok, why = False, "self test: %s" % exc
                     if agree(ok):
                         dev.peer_enable(True)
                         reduction = "peer mailboxes over xGMI (HIP IPC)"
+                if not reduction.startswith("peer"):
+                    # every rank learns every rank's reason (the vote only says that SOME rank failed)
+                    whys = [None] * world
+                    dist.all_gather_object(whys, why)
+                    peer_reason = "; ".join("rank %d: %s" % (g, w) for g, w in enumerate(whys) if w) or "a peer failed"
                 if want == "peer" and not reduction.startswith("peer"):
                     raise SystemExit("FOS_REDUCTION=peer but the peer mailboxes are not usable")
         if args.spmv_wg:
@@ -273,7 +296,12 @@ def main():
         t2 = time.perf_counter()
         it += done
         elapsed = t2 - t1
+        per_rank_ms = None
         if dist is not None:
+            mine_t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+            every = [torch.zeros_like(mine_t) for _ in range(world)]
+            dist.all_gather(every, mine_t)                    # a straggler shows in the line, not only in the maximum
+            per_rank_ms = [round(1e3 * float(t.item()) / max(1, args.steps), 4) for t in every]
             tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
@@ -317,13 +345,21 @@ def main():
         npsd_mats = int(sweeps.size)
         psd_n, psd_ms = cls["psd"]
         avg_psd_ms = psd_ms / max(1, psd_n)
-        mean_sweeps = float(sweeps.mean()) if npsd_mats else 0.0
+        # records of the last launch: >= 100 = refinement by matrix products (100 + 1000 [extrapolated start accepted] + 16 rotations +
+        # iterations), otherwise the sweeps of the Jacobi kernel
+        rec = np.asarray(sweeps, dtype=np.int64)
+        refined = rec >= 100
+        rf_it = np.where(refined, ((rec % 1000) - 100) % 16, 0)
+        rf_rot = np.where(refined, ((rec % 1000) - 100) // 16, 0)
+        mean_sweeps = float(rec[~refined].mean()) if (~refined).any() else 0.0
         kk = 64
         # per sweep: 64 steps x 32 pairs x (one dot product + the rotation of 2 columns); the wave kernel carries the column norms
         # along instead of recomputing them, so this is fewer flops per sweep than the 3-dot-product workgroup kernel did
         flop_sweep = kk * (kk // 2) * (2 * kk + 2 * kk * 3)
         flop_fixed = 2 * kk ** 3 + 10 * 16 * 16 * kk * 2 + 2 * kk * kk         # warm-start product, rebuild (10 tiles), weights
-        psd_flops = npsd_mats * (mean_sweeps * flop_sweep + flop_fixed)
+        # refinement: three 64^3 products per iteration, two for the Newton-Schulz step, 10 of 16 tiles for P
+        flop_refine = float(np.sum((3.0 * rf_it + 2.0 + 10.0 / 16.0) * 2.0 * kk ** 3))
+        psd_flops = int((~refined).sum()) * (mean_sweeps * flop_sweep + flop_fixed) + flop_refine
         psd_tflops = psd_flops / (avg_psd_ms * 1e-3) / 1e12 if psd_n and avg_psd_ms > 0 else 0.0
         vec_n, vec_ms = cls["cgvec"]
         avg_vec_ms = vec_ms / max(1, vec_n)
@@ -357,6 +393,12 @@ def main():
             "traffic": traffic,
             "stored_bytes_per_launch_model": stored_bytes,
             "survey_model_bytes_per_launch": survey_bytes,
+            "algorithmic_bytes_per_launch": survey_bytes if not ost["tiles"] else stored_bytes,
+            "algorithmic_bytes_basis": ("SURVEY 8(d): B_kkt,min = 24 nnz + 4 (m+n+2) + 32 (m+n)" if not ost["tiles"] else
+                                        "dense rectangles stored once (dual tiles, 8 B per non-zero for both products): the stored-format model; "
+                                        "SURVEY 8(d)'s two-stream CSR formula is `survey_model_bytes_per_launch`"),
+            "traffic_over_algorithmic": (round(traffic / (survey_bytes if not ost["tiles"] else stored_bytes), 4) if traffic else None),
+            "frac_on_algorithmic_bytes": round((survey_bytes if not ost["tiles"] else stored_bytes) / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if launches else None,
             "frac_vs_survey_model": round(survey_gbs / HBM_PEAK_GBS, 4),
             "survey_model_note": "SURVEY 8(d) counts A and A' as two CSR streams (24 B per non-zero of A per dual-RHS apply); dual tiles "
                                  "store a dense rectangle of A once for both products (8 B), so this ratio can exceed 1 -- it is NOT a "
@@ -371,21 +413,42 @@ def main():
         }
         roof_psd = None
         if psd_n:
-            roof_psd = {
-                "bound": "mfma",
-                "kernel": "psd64_wave_kernel: batched order-64 PSD projection, one wavefront per matrix, one-sided Jacobi (odd-even ordering) in registers with warm start; warm-start product and rebuild on v_mfma_f64_16x16x4",
-                "achieved": round(psd_tflops, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(psd_tflops / FP64_PEAK_TFLOPS, 4),
-                "flops_per_launch": psd_flops,
-                "flops_model": "matrices x (sweeps x 64 steps x 32 pairs x 512 + 2 x 64^3 + 10 x 16 x 16 x 64 x 2 + 2 x 64^2); sweeps counted by the kernel",
-                "matrices_per_launch": npsd_mats, "mean_jacobi_sweeps": round(mean_sweeps, 3),
-                "sweeps_histogram_last_launch": {int(k): int(v) for k, v in zip(*np.unique(sweeps, return_counts=True))},
-                "avg_kernel_ms": round(avg_psd_ms, 5), "launches_timed": psd_n,
-                "note": "issue bound: one wavefront per SIMD issues an fp64 VALU op every 7.5 cycles and a DPP move every 9 (measured; "
-                        "4 waves per SIMD reach ~5), and 1024 matrices are one wavefront per SIMD; the two dense contractions are "
-                        "12 % of its time (profiles/r02_psd_phases_wave.json; the kernel is unchanged since)",
-                "kernel_share_of_step": shares["psd_projection"],
-            }
+            n_ref = int(refined.sum())
+            if n_ref * 2 >= npsd_mats:
+                roof_psd = {
+                    "bound": "mfma",
+                    "kernel": "psd64_refine_kernel: batched order-64 PSD projection by eigenvector refinement -- three 64^3 products per "
+                              "iteration on v_mfma_f64_16x16x4 from a basis extrapolated over the last two projections, one Newton-Schulz "
+                              "step, P = V max(D, 0) V'; one workgroup of four wavefronts per matrix; Jacobi kernel for flagged matrices",
+                    "achieved": round(psd_tflops, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(psd_tflops / FP64_PEAK_TFLOPS, 4),
+                    "flops_per_launch": psd_flops,
+                    "flops_model": "refined matrices x (3 iterations + 2 + 10/16) x 2 x 64^3 (iterations counted by the kernel) + Jacobi matrices "
+                                   "x (sweeps x 64 steps x 32 pairs x 512 + 2 x 64^3 + ...)",
+                    "matrices_per_launch": npsd_mats, "refined": n_ref, "left_to_jacobi": npsd_mats - n_ref,
+                    "iterations_histogram_last_launch": {int(k): int(v) for k, v in zip(*np.unique(rf_it[refined], return_counts=True))},
+                    "matrices_with_rotations": int((rf_rot > 0).sum()), "extrapolated_starts_accepted": int((rec >= 1100).sum()),
+                    "avg_kernel_ms": round(avg_psd_ms, 5), "launches_timed": psd_n,
+                    "note": "the launch lasts as long as its slowest matrix (the largest iteration count); a 64^3 product is 64 MFMAs of "
+                            "64 cycles per wavefront, measured 2.5-3.2 us of a 10 us iteration (tools/psd_time.py, profiles/r04_psd_time.json)",
+                    "kernel_share_of_step": shares["psd_projection"],
+                }
+            else:
+                roof_psd = {
+                    "bound": "valu-issue",
+                    "kernel": "psd64_wave_kernel: batched order-64 PSD projection, one wavefront per matrix, one-sided Jacobi (odd-even ordering) in registers with warm start; warm-start product and rebuild on v_mfma_f64_16x16x4 (12 % of its time)",
+                    "achieved": round(psd_tflops, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(psd_tflops / FP64_PEAK_TFLOPS, 4),
+                    "flops_per_launch": psd_flops,
+                    "flops_model": "matrices x (sweeps x 64 steps x 32 pairs x 512 + 2 x 64^3 + 10 x 16 x 16 x 64 x 2 + 2 x 64^2); sweeps counted by the kernel",
+                    "matrices_per_launch": npsd_mats, "mean_jacobi_sweeps": round(mean_sweeps, 3),
+                    "sweeps_histogram_last_launch": {int(k): int(v) for k, v in zip(*np.unique(rec, return_counts=True))},
+                    "avg_kernel_ms": round(avg_psd_ms, 5), "launches_timed": psd_n,
+                    "note": "fp64 VALU issue bound, not MFMA bound: 88 % of the kernel is the Jacobi sweeps on the vector ALUs (one wavefront per "
+                            "SIMD issues an fp64 op every 7.5 cycles and a DPP move every 9, measured); the two dense contractions on the "
+                            "matrix cores are 12 % of its time (profiles/r02_psd_phases_wave.json)",
+                    "kernel_share_of_step": shares["psd_projection"],
+                }
         out = {
             "metric": "GAP/DR outer iterations/sec (+ achieved HBM GB/s of the CG SpMV in `roofline`)",
             "value": round(value, 4),
@@ -410,6 +473,8 @@ def main():
                 "cg_variant": dev.cg_variant_name(),
                 "cg_launches_per_iteration": 3 if dev.cg_variant_name() == "reference" else 2,
                 "parallelism": "cone-sharded x%d (scalar sums: %s)" % (world, reduction) if dist is not None else "single GPU",
+                "peer_fallback_reason": peer_reason,
+                "all_ranks_ms_per_step": per_rank_ms,
                 "residuals_after_run": {"p": chk.p, "d": chk.d, "g": chk.g, "iteration": it},
                 "setup_s": round(t_setup, 2), "generate_s": round(t_gen, 2),
                 "instance_note": ("data scaled as BASELINE.md 3 records (||b|| = ||c|| = 10, A_j / 32): a well-conditioned instance, 17 CG "
@@ -432,6 +497,7 @@ def main():
         if host_gloo or os.environ.get("FOS_REDUCTION") == "peer":
             raise SystemExit("peer mailboxes failed during the warm-up and no other transport is allowed")
         os.environ["FOS_REDUCTION"] = "rccl"
+        os.environ["FOS_PEER_FALLBACK_NOTE"] = "the self test passed, but an exchange of the warm-up timed out on the peer mailboxes (FOS_ECOMM)"
         out, dev, prob, alg, it = run_case(weak_main)
     if world > 1 and not weak_main and not args.no_weak_extra and args.workload == "C4":
         # the same job once more with 512 blocks PER RANK: weak scaling, reported beside the strong-scaling headline
@@ -526,6 +592,25 @@ def main():
                 "gpu_cg_iters_same_step": dev.cgiter(),
             }
             out["cpu_baseline"] = cpu
+    # ---- the C4 instance as SURVEY 8(d) writes it (A_j as drawn, not divided by 32): same size, same code path, twice the CG
+    #      iterations per outer iteration -- timed here so that the driver's line carries it beside the headline
+    if world == 1 and args.workload == "C4" and args.c4_scale is None and not args.small and not args.no_raw_instance:
+        args.c4_scale = 1.0
+        try:
+            rout, rdev, _, _, _ = run_case(False)
+            rdev.close()
+            rr = rout["roofline_kkt"] if isinstance(rout["roofline_kkt"], dict) else rout["roofline"]
+            out["raw_instance"] = {
+                "workload": rout["config"]["workload"], "value": rout["value"], "unit": rout["unit"], "ms_per_step": rout["ms_per_step"],
+                "steps": rout["steps"], "warmup_effective": rout["warmup_effective"],
+                "cg_iters_per_step": rout["config"]["cg_iters_per_step"],
+                "roofline": {k: rr[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_kernel_ms", "bytes_per_launch")},
+                "time_shares": rout["time_shares"], "residuals_after_run": rout["config"]["residuals_after_run"],
+                "note": "SURVEY 8(d)'s C4 without the data scaling of the headline instance (BASELINE.md 3): the same operator format, "
+                        "kernels and sizes; the KKT matrix is worse conditioned, so CG needs about twice the iterations per outer iteration",
+            }
+        finally:
+            args.c4_scale = None
     if dist is not None:
         # librccl prints its version banner through C stdio, which a pipe buffers until exit: flush it now so the
         # JSON line below is the last thing on stdout

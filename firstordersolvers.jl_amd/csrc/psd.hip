@@ -916,7 +916,8 @@ __device__ __forceinline__ void rf_gemm(v4d (&acc)[4], const double* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void psd64_refine_kernel(d2* __restrict__ out, const d2* __restrict__ in, const ConeDesc* __restrict__ cones,
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__ out, const d2* __restrict__ in, const ConeDesc* __restrict__ cones,
                                                            const double* __restrict__ vin, double* __restrict__ vout, int have_prev,
                                                            int* __restrict__ stats, int32_t* __restrict__ rec, int phase_limit,
                                                            const int32_t* __restrict__ gate, const double theta) {
@@ -1270,17 +1271,23 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     const int wave_env = c.psd_wave;
     // warm, every cone of order 64, a basis from the previous projection: refinement by matrix products (psd64_refine_kernel) with the
     // Jacobi workgroup kernel behind it for the matrices it flags.  FOS_PSD_REFINE=0 / 1 switches it off / on for every batch size;
-    // by default it runs where the workgroup kernel would (at most two matrices per CU: the shard of a multi-GPU run).
+    // by default it runs at every batch size (128 / 256 / 512 / 1024 matrices: 55 / 58 / 92 / 154 us against 121 / 128 / 178 / 201 for Jacobi).
     const bool refine_ok = kmin == 64 && kmax == 64 && vin && vout && have_prev && redo && (phase_limit == 0 || phase_limit >= 11);
-    if (refine_ok && (c.psd_refine == 1 || (c.psd_refine < 0 && wave_env != 1 && ncones <= cus))) {
+    if (refine_ok && (c.psd_refine == 1 || (c.psd_refine < 0 && wave_env != 1))) {
         const size_t rl = psd64r_lds_bytes();
         if (!*c.psd_attr_set_r) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd64_refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd64_refine_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd64_refine_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);
             if (e != hipSuccess) { set_error("hipFuncSetAttribute(psd64_refine_kernel): %s", hipGetErrorString(e)); return FOS_EHIP; }
             *c.psd_attr_set_r = true;
         }
-        hipLaunchKernelGGL(psd64_refine_kernel, dim3(2 * ncones), dim3(256), rl, c.stream, out, in, cones, vin, vout, c.psd_extrapolate ? have_prev : 1, stats, redo,
-                           phase_limit, c.gate, c.psd_theta > 0.0 ? c.psd_theta : RF_THETA);
+        // more matrices than CUs: two workgroups per CU (256 registers per lane), so that one's vector phases run beside the other's products
+        if (2 * ncones > cus)
+            hipLaunchKernelGGL(psd64_refine_kernel<2>, dim3(2 * ncones), dim3(256), rl, c.stream, out, in, cones, vin, vout, c.psd_extrapolate ? have_prev : 1, stats, redo,
+                               phase_limit, c.gate, c.psd_theta > 0.0 ? c.psd_theta : RF_THETA);
+        else
+            hipLaunchKernelGGL(psd64_refine_kernel<1>, dim3(2 * ncones), dim3(256), rl, c.stream, out, in, cones, vin, vout, c.psd_extrapolate ? have_prev : 1, stats, redo,
+                               phase_limit, c.gate, c.psd_theta > 0.0 ? c.psd_theta : RF_THETA);
         return FOS_OK;
     }
     if (kmin == 64 && kmax == 64 && wave_env != 0 && (wave_env == 1 || ncones > cus)) {

@@ -2,7 +2,8 @@
 """Generates tests/golden/*.npz from the oracle (oracle/fos_oracle.py).  The Julia reference cannot be executed in
 the build container, so these vectors pin the ORACLE's outputs (which tests/test_oracle_reference.py ties to the
 reference's own tests); the GPU tests compare the HIP path against them without importing the oracle.
-Run from the repo root:  python tests/golden/make_golden.py"""
+Run from the repo root:  python tests/golden/make_golden.py   (and `... make_golden.py mid` for the three whole solves of the
+l ~ 1e4 problem, ~5 minutes)"""
 import sys
 from pathlib import Path
 
@@ -61,7 +62,44 @@ def solve(name, prob, mk, **opts):
                         opts=np.array([opts["eps"], opts["checki"], opts["max_iters"]]))
 
 
+def mid_size_solves():
+    """The whole solves of the l ~ 1e4 mixed-cone problem (workloads.mid_mixed) that tests/test_gpu_certificates.py compares the device
+    with: the numpy oracle needs 1-2 minutes for each, so its results are kept here instead of being recomputed on the GPU box at
+    every run (the problem itself is regenerated from its seed, not stored).  tests/test_golden.py re-derives the stored end-point
+    residuals with the oracle's formulas (cheap) to tie the file to the oracle."""
+    prob = pkg.workloads.mid_mixed()
+    mks = {"DR": lambda **o: orc.DR(**o), "GAPA": lambda **o: orc.GAPA(0.8, 0.5, **o), "FISTA": lambda **o: orc.FISTA(**o)}
+    out = {}
+    checked = {}
+    inner = orc.HSDEStatus.checkstatus
+
+    def keep(self, z, override=False):                 # the point of the LAST evaluated check (the one `last` belongs to)
+        done = inner(self, z, override=override)
+        if self.checked:
+            checked["z"] = np.array(z, copy=True)
+        return done
+    orc.HSDEStatus.checkstatus = keep
+    for name, mk in mks.items():
+        opts = dict(eps={"DR": 1e-6, "GAPA": 1e-5, "FISTA": 1e-6}[name], verbose=0, max_iters=2500 if name != "FISTA" else 300, checki=100)
+        mo = orc.Model(prob.A, prob.b, prob.c, codes(prob.K1), codes(prob.K2))
+        sol = orc.solve(mo, mk(**opts), out=[])
+        last = sol.status_obj.last
+        out[name + "_x"] = sol.x
+        out[name + "_zchecked"] = checked["z"]
+        out[name + "_status"] = np.array([sol.status])
+        out[name + "_iterations"] = sol.iterations
+        out[name + "_obj"] = sol.obj_val
+        out[name + "_pdg"] = np.array([last["p"], last["d"], last["g"]])
+        out[name + "_opts"] = np.array([opts["eps"], opts["checki"], opts["max_iters"]])
+        print("mid_mixed", name, sol.status, sol.iterations, out[name + "_pdg"])
+    orc.HSDEStatus.checkstatus = inner
+    np.savez_compressed(OUT / "mid_mixed_solves.npz", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "mid":
+        mid_size_solves()
+        raise SystemExit(0)
     operators("small_mixed", pkg.workloads.small_mixed(), 100)
     operators("c4_tiny", pkg.workloads.c4_block_sdp(nblocks=3, k=6, p=4), 101)
     operators("c1_nnls", pkg.workloads.c1_readme_nnls(seed=2), 102)

@@ -86,3 +86,21 @@ def test_hip_reproduces_solve_goldens(name, pkg):
     # the first recorded check (iteration `checki`) agrees closely: before the two trajectories drift apart
     assert model.history["p"][0][0] == int(z["hist_iter"][0])
     assert model.history["p"][0][1] == pytest.approx(float(z["hist_p"][0]), rel=0.05)
+
+
+def test_mid_size_solve_fixture_is_the_oracles(pkg, oracle):
+    """tests/golden/mid_mixed_solves.npz (the three whole solves the GPU suite compares the device with at l ~ 1e4) against the oracle,
+    without repeating the solves: the stored end points evaluated with the oracle's residual formulas and status decision
+    (HSDEStatus.jl:27-63) give the stored p, d, g and status."""
+    orc = oracle
+    gold = np.load(GOLD / "mid_mixed_solves.npz")
+    prob = pkg.workloads.mid_mixed()
+    mo = orc.Model(prob.A, prob.b, prob.c, [(orc.CONE_CODES[k], l) for k, l in prob.K1], [(orc.CONE_CODES[k], l) for k, l in prob.K2])
+    for name in ("DR", "GAPA", "FISTA"):
+        z = gold[name + "_zchecked"]                    # the point of the last check of the solve
+        eps = float(gold[name + "_opts"][0])
+        res = orc.residuals(mo, z)
+        assert np.allclose([res["p"], res["d"], res["g"]], gold[name + "_pdg"], rtol=1e-9, atol=1e-15), name
+        status = orc.decide_status(res, eps)
+        assert ("Indeterminate" if status == "Continue" else status) == str(gold[name + "_status"][0])
+        assert gold[name + "_x"].shape == (prob.n,) and np.isfinite(gold[name + "_x"]).all()

@@ -41,7 +41,10 @@ def test_bench_two_ranks_on_one_gpu_matches_single_rank():
     assert out2["n_gpus"] == 2 and out2["steps"] == 6 and out2["warmup"] == 3 and out2["scaling"] == "strong"
     assert out2["unit"] == "iterations/s" and out2["value"] > 0 and out2["higher_is_better"] is True and out2["dtype"] == "f64"
     assert out2["warmup_effective"] >= out2["warmup"] and out2["warmup_effective"] == out1["warmup_effective"]   # same global l
-    assert "peer mailboxes" in out2["config"]["parallelism"]
+    assert "peer mailboxes" in out2["config"]["parallelism"] and out2["config"]["peer_fallback_reason"] is None
+    per_rank = out2["config"]["all_ranks_ms_per_step"]                   # a straggler would show here, not only in the maximum
+    assert len(per_rank) == 2 and max(per_rank) == pytest.approx(out2["ms_per_step"], rel=1e-3) and min(per_rank) > 0
+    assert out1["config"]["peer_fallback_reason"] is None
     assert out2["roofline"]["all_ranks"]["achieved_all_ranks"] >= out2["roofline"]["achieved"]
     assert "cpu_baseline" not in out2                       # N = 1 only
     # each rank holds half of the blocks
@@ -86,6 +89,7 @@ def test_bench_falls_back_to_rccl_when_the_mailboxes_fail_in_the_warmup():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = _last_json(r.stdout)
     assert "RCCL" in out["config"]["parallelism"] and out["value"] > 0
+    assert "timed out on the peer mailboxes" in out["config"]["peer_fallback_reason"]
     assert "warm-up failed on the peer mailboxes" in r.stderr
     # with only the mailboxes allowed the same failure must end the run
     bad = subprocess.run(cmd, cwd=str(ROOT), env=dict(env, FOS_REDUCTION="peer"), capture_output=True, text=True, timeout=600)
@@ -106,6 +110,7 @@ def test_bench_four_and_eight_ranks_on_one_gpu(nranks):
     assert r1.returncode == 0, r1.stdout[-3000:] + r1.stderr[-3000:]
     out1 = _last_json(r1.stdout)
     assert outn["n_gpus"] == nranks and "peer mailboxes" in outn["config"]["parallelism"]
+    assert outn["config"]["peer_fallback_reason"] is None and len(outn["config"]["all_ranks_ms_per_step"]) == nranks
     assert nranks * outn["config"]["local_m"] == out1["config"]["local_m"]
     ra, rb = out1["config"]["residuals_after_run"], outn["config"]["residuals_after_run"]
     assert ra["iteration"] == rb["iteration"]

@@ -152,28 +152,33 @@ def test_c2_dr_driven_to_iteration_cap_full_size(pkg):
 
 @pytest.mark.parametrize("algname", ["DR", "GAPA", "FISTA"])
 def test_mid_size_whole_solve_matches_oracle(pkg, algname):
-    """l ~ 1e4 (NonNeg + SOC + PSD, sparse A): the whole solve against the oracle -- same status, iteration count within one
-    check interval, p / d / g at the end within 1e-8 of the oracle's (BASELINE north_star), same solution."""
+    """l ~ 1e4 (NonNeg + SOC + PSD, sparse A): the whole solve against the oracle's -- same status, iteration count within one
+    check interval, p / d / g at the end within 1e-8 of the oracle's (BASELINE north_star), same solution.  The oracle's three solves
+    (1-2 minutes each in numpy) are kept in tests/golden/mid_mixed_solves.npz (tests/golden/make_golden.py mid; tests/test_golden.py
+    ties the file to the oracle); the problem is regenerated from its seed."""
+    from pathlib import Path
+    gold = np.load(Path(__file__).resolve().parent / "golden" / "mid_mixed_solves.npz")
     prob = pkg.workloads.mid_mixed()
     assert 8000 < prob.m + prob.n + 1 < 12000
     mk = {"DR": lambda M, **o: M.DR(**o), "GAPA": lambda M, **o: M.GAPA(0.8, 0.5, **o), "FISTA": lambda M, **o: M.FISTA(**o)}[algname]
-    # (the numpy oracle needs ~0.07-0.1 s per outer iteration at this size: tolerances chosen so that each solve ends in < 1 min)
     opts = dict(eps={"DR": 1e-6, "GAPA": 1e-5, "FISTA": 1e-6}[algname], verbose=0, max_iters=2500 if algname != "FISTA" else 300, checki=100)
+    assert np.array_equal(gold[algname + "_opts"], np.array([opts["eps"], opts["checki"], opts["max_iters"]]))
     model = pkg.solve(prob, mk(pkg, **opts))
-    sol = orc.solve(_omodel(prob), mk(orc, **opts), out=[])
-    assert model.status() == sol.status
-    assert abs(model.iterations - sol.iterations) <= 100
-    last, olast = model.status_obj.last, sol.status_obj.last
-    if sol.status == "Optimal":
+    o_status, o_iter, o_x = str(gold[algname + "_status"][0]), int(gold[algname + "_iterations"]), gold[algname + "_x"]
+    o_pdg = dict(zip(("p", "d", "g"), gold[algname + "_pdg"]))
+    assert model.status() == o_status
+    assert abs(model.iterations - o_iter) <= 100
+    last = model.status_obj.last
+    if o_status == "Optimal":
         for key in ("p", "d", "g"):
-            assert abs(getattr(last, key) - olast[key]) < 1e-6             # both below eps (1 + norm); CG stop decisions differ
-        assert model.getobjval() == pytest.approx(sol.obj_val, abs=1e-4)
-        ref_err = np.max(np.abs(sol.x - prob.x0))
+            assert abs(getattr(last, key) - o_pdg[key]) < 1e-6             # both below eps (1 + norm); CG stop decisions differ
+        assert model.getobjval() == pytest.approx(float(gold[algname + "_obj"]), abs=1e-4)
+        ref_err = np.max(np.abs(o_x - prob.x0))
         assert np.max(np.abs(model.getsolution() - prob.x0)) <= 3 * ref_err + 1e-8
     else:                                                               # FISTA at the cap: the same trajectory end point
         for key in ("p", "d", "g"):
-            assert getattr(last, key) == pytest.approx(olast[key], rel=0.05)
-        assert np.max(np.abs(model.getsolution() - sol.x)) <= 1e-3 * max(1.0, np.max(np.abs(sol.x)))
+            assert getattr(last, key) == pytest.approx(o_pdg[key], rel=0.05)
+        assert np.max(np.abs(model.getsolution() - o_x)) <= 1e-3 * max(1.0, np.max(np.abs(o_x)))
 
 
 @pytest.mark.parametrize("algname", ["DR", "GAPA"])
