@@ -2199,11 +2199,12 @@ int fos_get_cg_variant(fos_handle h, int32_t* variant) {
     if (!h || !variant) { set_error("NULL argument"); return FOS_EINVAL; }
     static const bool fold_env = !(getenv("FOS_PEER_FOLD") && atoi(getenv("FOS_PEER_FOLD")) == 0);
     // default: the reference's recurrence -- except where a CG iteration is bound by its launches, not its bytes: sharded handles (one
-    // exchange per iteration instead of two) and cache-resident gather-type operators (C3: two launches per iteration instead of three,
-    // 370 -> 385 iterations/s; the streamed operators C2 / C4 / C5 are faster on the reference recurrence).  Same Krylov iterates, same
+    // exchange per iteration instead of two) and cache-resident gather-type operators of 32 768 rows or more (C3: two launches per iteration
+    // instead of three, 370 -> 385 iterations/s; the streamed operators C2 / C4 / C5 are faster on the reference recurrence; small problems
+    // keep the reference's arithmetic).  Same Krylov iterates, same
     // iteration counting and stop test; FOS_CG_VARIANT=0 / fos_set_cg_variant restore the reference recurrence everywhere.
     int v = h->cg_variant >= 0 ? h->cg_variant
-            : (h->fuse_p ? FOS_CG_FUSED_P : ((h->sharded() || (h->S.resident && !h->row_sharded)) ? FOS_CG_MERGED_UPDATE : FOS_CG_REFERENCE));
+            : (h->fuse_p ? FOS_CG_FUSED_P : ((h->sharded() || (h->S.resident && !h->row_sharded && h->l >= 32768)) ? FOS_CG_MERGED_UPDATE : FOS_CG_REFERENCE));
     if (v == FOS_CG_MERGED_SWEEP && h->sharded()) v = FOS_CG_MERGED_UPDATE;
     if (v == FOS_CG_MERGED_UPDATE && h->peer_on && !fold_env) v = FOS_CG_REFERENCE;
     *variant = v;
