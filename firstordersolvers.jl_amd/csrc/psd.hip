@@ -976,6 +976,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
 
     v4d Vb[4];                              // this wavefront's column block: Vb[ib][r] = V[16 ib + 4 r + lk][16 w + lr] (B operand of k-step 4 ib + r)
     int it = 0, nrot = 0, fail = 0, total_it = 0;
+    int dbg_c1 = 0, dbg_c2 = 0;
     unsigned long long rmask = 0ull;
     double dj = 0.0;
     for (;; ++attempt) {
@@ -1029,6 +1030,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
             v4d ev[4];
             auto make_e = [&]() {
                 conv2 = 0.0; bad = 0;
+                const double ediag = 0.5 * (1.0 - vv);
 #pragma unroll
                 for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
@@ -1037,12 +1039,13 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
                         const double n = nac[ib][r];
                         const double den = dj - dl[i];
                         const double an = fabs(n), ad = fabs(den);
-                        double e;
-                        if (i == jcol) e = 0.5 * (1.0 - vv);
-                        else if (an <= noise) e = 0.0;             // rounding level: never chased, whatever the gap (a quotient of two
-                                                                   // rounding errors would be an O(theta) "rotation" that is not even skew)
-                        else if (an <= theta * ad) e = n * fast_rcp(den);
-                        else { e = 0.0; bad = 1; }
+                        // rounding level (an <= noise): never chased, whatever the gap -- a quotient of two rounding errors would be an
+                        // O(theta) "rotation" that is not even skew; small against the gap: first-order correction; else: a rotation first
+                        const bool isdiag = i == jcol, small = an <= noise, ok = an <= theta * ad;
+                        double rc = __builtin_amdgcn_rcp(den);
+                        rc = rc * (2.0 - den * rc);                  // (E needs a few digits only: the iteration corrects itself)
+                        const double e = isdiag ? ediag : ((small || !ok) ? 0.0 : n * rc);
+                        bad |= (!isdiag && !small && !ok) ? 1 : 0;
                         conv2 += e * e;
                         ev[ib][r] = e;
                     }
@@ -1135,7 +1138,9 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
                 make_e();      // (a pair can still be flagged here only through the difference between (N_ij + N_ji) / 2 and N_ij: left to the next iteration)
             }
             // ---- ||E||_F^2 over the workgroup
-            for (int off = 32; off > 0; off >>= 1) conv2 += __shfl_xor(conv2, off, 64);
+            conv2 = group16_sum(conv2);                        // (DPP inside the 16-lane rows, then two cross-row exchanges)
+            conv2 += __shfl_xor(conv2, 16, 64);
+            conv2 += __shfl_xor(conv2, 32, 64);
             if (lane == 0) red[8 + w] = conv2;
             if (phase_limit == 14) return;
             // ---- V <- V + V E (column block w); A operand = rows of V
@@ -1151,6 +1156,8 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
                 for (int r = 0; r < 4; ++r) Vl[16 * ib + 4 * r + lk + jcol * LD] = vn[ib][r];
             }
             const double c2 = (red[8] + red[9]) + (red[10] + red[11]);
+            if (it == 0) dbg_c1 = c2 > 0.0 ? min(9, max(0, (int)(-0.5 * log10(c2)))) : 9;
+            if (it == 1) dbg_c2 = c2 > 0.0 ? min(9, max(0, (int)(-0.5 * log10(c2)))) : 9;
             __syncthreads();
             if (phase_limit == 15) return;
             if (c2 <= RF_ACCEPT2) { ++it; break; }
@@ -1165,7 +1172,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
         psd_block<true, true, 256>(out, in, cones, nullptr, 0, vin, vout, 4096, 0, stats, 0, smem);
         return;
     }
-    if (tid == 0) { *code = 0; *cmask = rmask; if (stats) stats[blockIdx.x] = 100 + 1000 * (attempt == 0) + 16 * nrot + total_it; }
+    if (tid == 0) { *code = 0; *cmask = rmask; if (stats) stats[blockIdx.x] = 100 + 1000 * (attempt == 0) + 16 * nrot + total_it + (rec[4 * gridDim.x] == 77 ? 10000 * dbg_c1 + 100000 * dbg_c2 + 1000000 * (skip != 0ull) : 0); }
     if (phase_limit == 16) return;
 
     // ---- one Newton-Schulz step: V <- V (I + (I - V'V) / 2)

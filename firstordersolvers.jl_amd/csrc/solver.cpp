@@ -1287,8 +1287,9 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
         const size_t vb = psd_basis_doubles(h->psd_kmax, h->npsd);
         if (vb) { FOS_TRY(dev_alloc(h, &h->psd_V[0], vb)); FOS_TRY(dev_alloc(h, &h->psd_V[1], vb)); }
         if (vb && h->psd_kmin == 64 && h->psd_kmax == 64) {
-            FOS_TRY(dev_alloc(h, &h->psd_redo, (size_t)8 * h->npsd));          // code [2 npsd] + 64-bit column mask [2 npsd]
-            FOS_HIP(hipMemset(h->psd_redo, 0, sizeof(int32_t) * 8 * h->npsd));
+            FOS_TRY(dev_alloc(h, &h->psd_redo, (size_t)8 * h->npsd + 16));     // code [2 npsd] + 64-bit column mask [2 npsd] + a diagnostics switch
+            FOS_HIP(hipMemset(h->psd_redo, 0, sizeof(int32_t) * (8 * h->npsd + 16)));
+            if (getenv("FOS_PSD_DEBUG_REC")) { const int32_t v = 77; FOS_HIP(hipMemcpy(h->psd_redo + 8 * h->npsd, &v, sizeof(v), hipMemcpyHostToDevice)); }
         }
     }
 
@@ -1430,6 +1431,18 @@ int fos_peer_open(fos_handle h, int nranks, int rank, const void* handles, doubl
         }
         h->peer_opened.push_back(q);
         tab[r] = reinterpret_cast<unsigned long long*>(q);
+        // first contact between DIFFERENT devices: the mapping can succeed where loads and stores over the link cannot -- ask the
+        // runtime, and say which pair it is (the caller falls back to its collective: bench.py `peer_fallback_reason`)
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, q) == hipSuccess && attr.device >= 0 && attr.device != h->device) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, h->device, attr.device) == hipSuccess && !can) {
+                for (void* o : h->peer_opened) (void)hipIpcCloseMemHandle(o);
+                h->peer_opened.clear();
+                set_error("device %d cannot access the memory of device %d, rank %d's (hipDeviceCanAccessPeer = 0)", h->device, attr.device, r);
+                return FOS_ECOMM;
+            }
+        } else (void)hipGetLastError();
     }
     unsigned long long** dtab = nullptr;
     FOS_TRY(dev_upload(h, &dtab, tab));
