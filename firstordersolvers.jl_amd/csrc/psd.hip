@@ -892,26 +892,29 @@ __device__ __forceinline__ double rf_store_m(double* __restrict__ Ml, const doub
 // acc[ib] += sum_kk A(ib, kk) B(kk) for the four row tiles ib of a column block: A(ib, kk) = base[ib SI + kk SK] (LDS), B(kk) = b[kk >> 2][kk & 3].
 // The A fragments of four k-steps are requested while the matrix cores work on the previous four (the compiler, left alone, requests
 // each step's fragments behind the previous step's last MFMA and exposes the LDS latency sixteen times per product).
-template <int SI, int SK>
+template <int SI, int SK, int KC = 4>
 __device__ __forceinline__ void rf_gemm(v4d (&acc)[4], const double* __restrict__ base, const v4d (&b)[4]) {
-    double a0[16], a1[16];
+    // KC k-steps (4 KC fragments) per request group; two groups alternate (KC = 4: 64 registers of fragments, KC = 2: 32 -- the form for two
+    // workgroups per CU, which has 256 registers per lane)
+    constexpr int NQ = 4 * KC, NC = 16 / KC;
+    double a0[NQ], a1[NQ];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) a0[q] = base[(q & 3) * SI + (q >> 2) * SK];
+    for (int q = 0; q < NQ; ++q) a0[q] = base[(q & 3) * SI + (q >> 2) * SK];
 #pragma unroll
-    for (int c = 0; c < 4; c += 2) {
+    for (int c = 0; c < NC; c += 2) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) a1[q] = base[(q & 3) * SI + (4 * (c + 1) + (q >> 2)) * SK];
+        for (int q = 0; q < NQ; ++q) a1[q] = base[(q & 3) * SI + (KC * (c + 1) + (q >> 2)) * SK];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b[c][q >> 2], acc[q & 3], 0, 0, 0);
+        for (int q = 0; q < NQ; ++q) { const int kk = KC * c + (q >> 2); acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b[kk >> 2][kk & 3], acc[q & 3], 0, 0, 0); }
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 2 < 4) {
+        if (c + 2 < NC) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) a0[q] = base[(q & 3) * SI + (4 * (c + 2) + (q >> 2)) * SK];
+            for (int q = 0; q < NQ; ++q) a0[q] = base[(q & 3) * SI + (KC * (c + 2) + (q >> 2)) * SK];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b[c + 1][q >> 2], acc[q & 3], 0, 0, 0);
+        for (int q = 0; q < NQ; ++q) { const int kk = KC * (c + 1) + (q >> 2); acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b[kk >> 2][kk & 3], acc[q & 3], 0, 0, 0); }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -1002,7 +1005,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
             v4d acc[4];
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) acc[ib] = v4d{0.0, 0.0, 0.0, 0.0};
-            rf_gemm<16, 4 * LD>(acc, Ml + lr + lk * LD, Vb);
+            rf_gemm<16, 4 * LD, WPS == 2 ? 2 : 4>(acc, Ml + lr + lk * LD, Vb);
             if (phase_limit == 12) return;
             // ---- Rayleigh quotients of the block's columns; G' = G - V diag d
             double vv = 0.0, vg = 0.0;
@@ -1021,7 +1024,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
             v4d nac[4];
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) nac[ib] = v4d{0.0, 0.0, 0.0, 0.0};
-            rf_gemm<16 * LD, 4>(nac, Vl + lk + lr * LD, acc);
+            rf_gemm<16 * LD, 4, WPS == 2 ? 2 : 4>(nac, Vl + lk + lr * LD, acc);
             __syncthreads();                                   // d of all blocks visible
             if (phase_limit == 13) return;
             // ---- E from N; pairs that need a rotation first
@@ -1147,7 +1150,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
             v4d vn[4];
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) vn[ib] = Vb[ib];
-            rf_gemm<16, 4 * LD>(vn, Vl + lr + lk * LD, ev);
+            rf_gemm<16, 4 * LD, WPS == 2 ? 2 : 4>(vn, Vl + lr + lk * LD, ev);
             __syncthreads();                                   // every wavefront has read the old V
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) {
@@ -1180,7 +1183,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
         v4d g[4];
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) g[ib] = v4d{0.0, 0.0, 0.0, 0.0};
-        rf_gemm<16 * LD, 4>(g, Vl + lk + lr * LD, Vb);
+        rf_gemm<16 * LD, 4, WPS == 2 ? 2 : 4>(g, Vl + lk + lr * LD, Vb);
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
@@ -1188,7 +1191,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
         v4d vn[4];
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) vn[ib] = Vb[ib];
-        rf_gemm<16, 4 * LD>(vn, Vl + lr + lk * LD, g);
+        rf_gemm<16, 4 * LD, WPS == 2 ? 2 : 4>(vn, Vl + lr + lk * LD, g);
         __syncthreads();
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib)

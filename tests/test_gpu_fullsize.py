@@ -245,6 +245,8 @@ def test_c4_shard_one_steady_state_iteration_vs_oracle(pkg, oracle):
     prob = pkg.workloads.c4_block_sdp(nblocks=512, block_range=(0, 64))
     _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 200, 1e-9)
     _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 230, 1e-9)
+    # GAPA: another sequence of matrices for the basis extrapolation (alpha12 changes from step to step)
+    _same_step_vs_oracle(pkg, prob, pkg.GAPA(), oracle.GAPA(), 200, 1e-9)
 
 
 def test_c2_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle):
