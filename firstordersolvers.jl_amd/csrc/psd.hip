@@ -844,8 +844,9 @@ constexpr int RF_MAX_ROT = 12;
 constexpr double RF_THETA = 0.2;
 constexpr double RF_ACCEPT2 = 1e-12;          // ||E||_F <= 1e-6 at the last update: error of the projection < 1e-13 ||M|| (measured on the oracle)
 constexpr double RF_NOISE = 16.0 * 2.220446049250313e-16;
-__host__ inline size_t psd64r_lds_bytes() {
-    const size_t own = (size_t)(2 * 64 * RF_LD + 64 + 64) * sizeof(double);
+__host__ inline size_t psd64r_lds_bytes(int wps) {
+    // one workgroup per CU: a third array for the rotation path (S = N + diag d); two per CU: that path borrows M's array and unpacks M again
+    const size_t own = (size_t)((wps == 1 ? 3 : 2) * 64 * RF_LD + 64 + 64) * sizeof(double);
     return own > psd_lds_bytes(64) ? own : psd_lds_bytes(64);      // (the Jacobi path of a flagged matrix runs in the same workgroup)
 }
 // per-matrix record between calls: int32 code [nmat] (0 accepted, 1 left to Jacobi), then uint64 mask [nmat] of the columns that were
@@ -932,6 +933,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
     double* dl = Vl + 64 * LD;              // [64] eigenvalue estimates
     double* red = dl + 64;                  // [64] reductions / broadcast
     int* ired = reinterpret_cast<int*>(red + 32);
+    double* Sl = WPS == 1 ? red + 64 : Ml;  // the rotation path's S = N + diag d: an array of its own, or M's (M is unpacked again afterwards)
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
     const int jcol = 16 * w + lr;
@@ -1061,7 +1063,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = 16 * ib + 4 * r + lk;
-                        Ml[i + jcol * LD] = (i == jcol) ? dj : nac[ib][r];
+                        Sl[i + jcol * LD] = (i == jcol) ? dj : nac[ib][r];
                     }
                 __syncthreads();
                 for (;;) {
@@ -1069,12 +1071,12 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
                     double best = 0.0; int bidx = -1;
                     {
                         const int j = tid & 63, i0 = (tid >> 6) * 16;
-                        const double djj = Ml[j + j * LD];
+                        const double djj = Sl[j + j * LD];
 #pragma unroll 4
                         for (int q = 0; q < 16; ++q) {
                             const int i = i0 + q;
                             if (i == j) continue;
-                            const double an = fabs(Ml[i + j * LD]), ad = fabs(djj - Ml[i + i * LD]);
+                            const double an = fabs(Sl[i + j * LD]), ad = fabs(djj - Sl[i + i * LD]);
                             if (!(an <= theta * ad) && !(an <= noise) && !(an <= best)) { best = an; bidx = i | (j << 8); }
                         }
                     }
@@ -1092,7 +1094,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
                     if (++nrot > RF_MAX_ROT) { fail = 1; break; }
                     const int pi = gi & 0xFF, pj = gi >> 8;
                     rmask |= (1ull << pi) | (1ull << pj);
-                    const double a = Ml[pi + pi * LD], b = Ml[pj + pj * LD], g = 0.5 * (Ml[pi + pj * LD] + Ml[pj + pi * LD]);
+                    const double a = Sl[pi + pi * LD], b = Sl[pj + pj * LD], g = 0.5 * (Sl[pi + pj * LD] + Sl[pj + pi * LD]);
                     double cs = 1.0, sn = 0.0;
                     if (g != 0.0) {
                         const double zeta = (b - a) / (2.0 * g);
@@ -1101,8 +1103,8 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
                     }
                     __syncthreads();
                     if (tid < 64) {                         // columns pi, pj of S
-                        const double ti = Ml[tid + pi * LD], tj = Ml[tid + pj * LD];
-                        Ml[tid + pi * LD] = cs * ti - sn * tj; Ml[tid + pj * LD] = sn * ti + cs * tj;
+                        const double ti = Sl[tid + pi * LD], tj = Sl[tid + pj * LD];
+                        Sl[tid + pi * LD] = cs * ti - sn * tj; Sl[tid + pj * LD] = sn * ti + cs * tj;
                     } else if (tid < 128) {                 // columns pi, pj of V
                         const int rr = tid - 64;
                         const double ti = Vl[rr + pi * LD], tj = Vl[rr + pj * LD];
@@ -1110,33 +1112,33 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
                     }
                     __syncthreads();
                     if (tid < 64) {                         // rows pi, pj of S
-                        const double ti = Ml[pi + tid * LD], tj = Ml[pj + tid * LD];
-                        Ml[pi + tid * LD] = cs * ti - sn * tj; Ml[pj + tid * LD] = sn * ti + cs * tj;
+                        const double ti = Sl[pi + tid * LD], tj = Sl[pj + tid * LD];
+                        Sl[pi + tid * LD] = cs * ti - sn * tj; Sl[pj + tid * LD] = sn * ti + cs * tj;
                     }
                     __syncthreads();
-                    if (tid == 0) { Ml[pi + pj * LD] = 0.0; Ml[pj + pi * LD] = 0.0; }
+                    if (tid == 0) { Sl[pi + pj * LD] = 0.0; Sl[pj + pi * LD] = 0.0; }
                     __syncthreads();
                 }
                 if (!fail) {
                     // back to registers: d, N, this block's columns of V
-                    dj = Ml[jcol + jcol * LD];
+                    dj = Sl[jcol + jcol * LD];
 #pragma unroll
                     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int i = 16 * ib + 4 * r + lk;
-                            nac[ib][r] = Ml[i + jcol * LD];
+                            nac[ib][r] = Sl[i + jcol * LD];
                             Vb[ib][r] = Vl[i + jcol * LD];
                         }
                     if (lk == 0) dl[jcol] = dj;
                 }
                 __syncthreads();
-                {                                              // M back into its array
+                if constexpr (WPS != 1) {                      // M back into its array
                     double xv[9];
                     rf_fetch_m(xv, x, tid);
                     rf_store_m(Ml, xv, sgn, tid);
+                    __syncthreads();
                 }
-                __syncthreads();
                 if (fail) break;
                 make_e();      // (a pair can still be flagged here only through the difference between (N_ij + N_ji) / 2 and N_ij: left to the next iteration)
             }
@@ -1284,19 +1286,19 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     // by default it runs at every batch size (128 / 256 / 512 / 1024 matrices: 55 / 58 / 92 / 154 us against 121 / 128 / 178 / 201 for Jacobi).
     const bool refine_ok = kmin == 64 && kmax == 64 && vin && vout && have_prev && redo && (phase_limit == 0 || phase_limit >= 11);
     if (refine_ok && (c.psd_refine == 1 || (c.psd_refine < 0 && wave_env != 1))) {
-        const size_t rl = psd64r_lds_bytes();
+        const size_t rl1 = psd64r_lds_bytes(1), rl2 = psd64r_lds_bytes(2);
         if (!*c.psd_attr_set_r) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd64_refine_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd64_refine_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd64_refine_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl1);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd64_refine_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl2);
             if (e != hipSuccess) { set_error("hipFuncSetAttribute(psd64_refine_kernel): %s", hipGetErrorString(e)); return FOS_EHIP; }
             *c.psd_attr_set_r = true;
         }
         // more matrices than CUs: two workgroups per CU (256 registers per lane), so that one's vector phases run beside the other's products
         if (2 * ncones > cus)
-            hipLaunchKernelGGL(psd64_refine_kernel<2>, dim3(2 * ncones), dim3(256), rl, c.stream, out, in, cones, vin, vout, c.psd_extrapolate ? have_prev : 1, stats, redo,
+            hipLaunchKernelGGL(psd64_refine_kernel<2>, dim3(2 * ncones), dim3(256), rl2, c.stream, out, in, cones, vin, vout, c.psd_extrapolate ? have_prev : 1, stats, redo,
                                phase_limit, c.gate, c.psd_theta > 0.0 ? c.psd_theta : RF_THETA);
         else
-            hipLaunchKernelGGL(psd64_refine_kernel<1>, dim3(2 * ncones), dim3(256), rl, c.stream, out, in, cones, vin, vout, c.psd_extrapolate ? have_prev : 1, stats, redo,
+            hipLaunchKernelGGL(psd64_refine_kernel<1>, dim3(2 * ncones), dim3(256), rl1, c.stream, out, in, cones, vin, vout, c.psd_extrapolate ? have_prev : 1, stats, redo,
                                phase_limit, c.gate, c.psd_theta > 0.0 ? c.psd_theta : RF_THETA);
         return FOS_OK;
     }
