@@ -53,6 +53,17 @@ def tolerance_floor_iteration(l_global):
 
 
 
+def decode_psd_records(rec):
+    """Per-matrix records of the last batched PSD(64) projection (fos_psd_stats): >= 100 = accepted by the refinement kernel,
+    100 + 1000 [the extrapolated start was the one accepted] + 16 x rotations + iterations (both starts counted; further decimal digits
+    only with FOS_PSD_DEBUG_REC); below 100 = sweeps of the Jacobi kernel.  Returns (refined mask, iterations, rotations, extrapolated mask)."""
+    import numpy as np
+    rec = np.asarray(rec, dtype=np.int64) % 10000
+    refined = rec >= 100
+    body = np.where(refined, (rec % 1000) - 100, 0)
+    return refined, body % 16, body // 16, refined & (rec >= 1100)
+
+
 def build_problem(pkg, workload, nranks, rank, small, weak=False, c4_scale=None):
     w = pkg.workloads
     if workload == "C4":
@@ -348,9 +359,7 @@ def main():
         # records of the last launch: >= 100 = refinement by matrix products (100 + 1000 [extrapolated start accepted] + 16 rotations +
         # iterations), otherwise the sweeps of the Jacobi kernel
         rec = np.asarray(sweeps, dtype=np.int64)
-        refined = rec >= 100
-        rf_it = np.where(refined, ((rec % 1000) - 100) % 16, 0)
-        rf_rot = np.where(refined, ((rec % 1000) - 100) // 16, 0)
+        refined, rf_it, rf_rot, rf_extrap = decode_psd_records(rec)
         mean_sweeps = float(rec[~refined].mean()) if (~refined).any() else 0.0
         kk = 64
         # per sweep: 64 steps x 32 pairs x (one dot product + the rotation of 2 columns); the wave kernel carries the column norms
@@ -427,7 +436,7 @@ def main():
                                    "x (sweeps x 64 steps x 32 pairs x 512 + 2 x 64^3 + ...)",
                     "matrices_per_launch": npsd_mats, "refined": n_ref, "left_to_jacobi": npsd_mats - n_ref,
                     "iterations_histogram_last_launch": {int(k): int(v) for k, v in zip(*np.unique(rf_it[refined], return_counts=True))},
-                    "matrices_with_rotations": int((rf_rot > 0).sum()), "extrapolated_starts_accepted": int((rec >= 1100).sum()),
+                    "matrices_with_rotations": int((rf_rot > 0).sum()), "extrapolated_starts_accepted": int(rf_extrap.sum()),
                     "avg_kernel_ms": round(avg_psd_ms, 5), "launches_timed": psd_n,
                     "note": "the launch lasts as long as its slowest matrix (the largest iteration count); a 64^3 product is 64 MFMAs of "
                             "64 cycles per wavefront, measured 2.5-3.2 us of a 10 us iteration (tools/psd_time.py, profiles/r04_psd_time.json)",
