@@ -420,9 +420,20 @@ void launch_cones_elementwise(const LaunchCtx& c, double2* out, const double2* i
 void launch_relax_ew(const LaunchCtx& c, double2* t1, double2* t2, const double2* sol, const double2* x, double a, bool use_a12, const uint8_t* ew_op);
 void launch_cones_soc(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones);
 void launch_cones_exp(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones);
+// Fusion of the GAP / DR step around the batched PSD(64) projection (psd64_refine_kernel): the kernel's input is not read from a vector t1
+// but FORMED, t1 = a1 sol + (1 - a1) x (the relaxation behind S1, gap.jl:48), and its output is not written to t2 but taken on to the step's
+// last pass, x = alpha (alpha2 t2 + (1 - alpha2) t1) + (1 - alpha) x (gap.jl:58,78), with the vector the next CG start applies M to
+// (sol - [0; x2]) -- for the entries of the PSD cones; the other entries (elementwise cones) are done by extra workgroups of the same launch.
+struct PsdFuse {
+    int on;
+    const double2* sol; double2* xv; double2* shift;     // shift: nullptr when the next projection is not a CG solve inside fos_step
+    double a1, alpha, alpha2;
+    const uint8_t* ew_op; int64_t l; int nmat;           // elementwise entries: workgroups nmat.. of the grid
+};
+bool psd_fuse_possible(const LaunchCtx& c, int ncones, int kmin, int kmax, const double* vin, const double* vout, int have_prev, const int32_t* redo, int phase_limit);
 int  launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones,
                       int kmin, int kmax, double* gscratch, const double* vin, double* vout, int have_prev, int* stats, int phase_limit,
-                      int32_t* redo = nullptr);
+                      int32_t* redo = nullptr, const PsdFuse* fuse = nullptr);
 size_t psd_scratch_bytes(int kmax, int ncones);
 size_t psd_basis_doubles(int kmax, int ncones);
 

@@ -866,11 +866,26 @@ __device__ __forceinline__ double colgroup_sum(double v) {
     return v;
 }
 // the packed input of a thread (9 entries) -> M in LDS (both triangles, diagonal scaled by sqrt(2)); returns the thread's share of ||M||_F^2
-__device__ __forceinline__ void rf_fetch_m(double (&v)[9], const double* __restrict__ x, int tid) {
+// Fusion of the GAP / DR step around the projection (PsdFuse::on): the kernel's input is not read from a vector t1 but FORMED,
+// t1 = a1 sol + (1 - a1) x (the relaxation behind S1, gap.jl:48), and its output is not written to t2 but taken on to the step's last pass,
+// x = alpha (alpha2 t2 + (1 - alpha2) t1) + (1 - alpha) x (gap.jl:58,78), with the vector the next CG start applies M to (sol - [0; x2]) --
+// for the entries of the PSD cones; the other entries (elementwise cones) are done by the extra workgroups of the same launch.
+__device__ __forceinline__ void rf_fetch_m(double (&v)[9], const double* __restrict__ x, int tid, const PsdFuse& fz, const double* __restrict__ solc,
+                                           const double* __restrict__ xc) {
+    const double b1 = 1.0 - fz.a1;
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
         const int idx = q * 256 + tid;
-        v[q] = idx < P64_LEN ? x[2 * (int64_t)idx] : 0.0;
+        if (fz.on) v[q] = idx < P64_LEN ? fz.a1 * solc[2 * (int64_t)idx] + b1 * xc[2 * (int64_t)idx] : 0.0;
+        else v[q] = idx < P64_LEN ? x[2 * (int64_t)idx] : 0.0;
+    }
+}
+__device__ __forceinline__ double ew_apply_psd(int op, double v) {       // (= ew_apply of vecops.hip)
+    switch (op) {
+        case EW_COPY: return v;
+        case EW_ZERO: return 0.0;
+        case EW_MAX0: return v < 0.0 ? 0.0 : v;
+        default:      return v > 0.0 ? 0.0 : v;
     }
 }
 __device__ __forceinline__ double rf_store_m(double* __restrict__ Ml, const double (&v)[9], double sgn, int tid) {
@@ -924,8 +939,26 @@ template <int WPS>
 __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__ out, const d2* __restrict__ in, const ConeDesc* __restrict__ cones,
                                                            const double* __restrict__ vin, double* __restrict__ vout, int have_prev,
                                                            int* __restrict__ stats, int32_t* __restrict__ rec, int phase_limit,
-                                                           const int32_t* __restrict__ gate, const double theta) {
+                                                           const int32_t* __restrict__ gate, const double theta, const PsdFuse fz) {
     if (gate && !*gate) return;
+    if (fz.on && (int)blockIdx.x >= fz.nmat) {
+        // the step's two passes on the entries of the elementwise cones (relax_ew_kernel + gap_final_kernel of vecops.hip, same arithmetic)
+        const double b1 = 1.0 - fz.a1, b2 = 1.0 - fz.alpha2, b = 1.0 - fz.alpha;
+        for (int64_t i = ((int64_t)blockIdx.x - fz.nmat) * 256 + threadIdx.x; i < fz.l; i += (int64_t)(gridDim.x - fz.nmat) * 256) {
+            const uint8_t op = fz.ew_op[i];
+            if (op == EW_SKIP) continue;
+            const d2 si = fz.sol[i];
+            d2 xi = fz.xv[i];
+            const d2 v = make_double2(fz.a1 * si.x + b1 * xi.x, fz.a1 * si.y + b1 * xi.y);
+            const d2 u = make_double2(ew_apply_psd(op & 3, v.x), ew_apply_psd((op >> 2) & 3, v.y));
+            const double rx = fz.alpha2 * u.x + b2 * v.x, ry = fz.alpha2 * u.y + b2 * v.y;
+            xi.x = fz.alpha * rx + b * xi.x;
+            xi.y = fz.alpha * ry + b * xi.y;
+            fz.xv[i] = xi;
+            if (fz.shift) fz.shift[i] = make_double2(si.x, si.y - xi.y);
+        }
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int LD = RF_LD;
     double* Ml = smem;                      // M, column-major (symmetric); S = N + diag d in the rotation path; P at the end
@@ -945,8 +978,11 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
     double* __restrict__ y = reinterpret_cast<double*>(out + cd.start) + part;
     const d2* __restrict__ Vp = reinterpret_cast<const d2*>(vin + (size_t)blockIdx.x * 4096);
     d2* __restrict__ Vn = reinterpret_cast<d2*>(vout + (size_t)blockIdx.x * 4096);
+    const int nmat = fz.on ? fz.nmat : (int)gridDim.x;
     int32_t* __restrict__ code = rec + blockIdx.x;
-    unsigned long long* __restrict__ cmask = reinterpret_cast<unsigned long long*>(rec + 2 * gridDim.x) + blockIdx.x;
+    unsigned long long* __restrict__ cmask = reinterpret_cast<unsigned long long*>(rec + 2 * nmat) + blockIdx.x;
+    const double* __restrict__ solc = fz.on ? reinterpret_cast<const double*>(fz.sol + cd.start) + part : nullptr;      // this copy's component of sol, x
+    double* __restrict__ xcomp = fz.on ? reinterpret_cast<double*>(fz.xv + cd.start) + part : nullptr;
     // extrapolation needs the bases of the last TWO projections, the second a continuation of the first (accepted by this kernel);
     // columns that were rotated then are not extrapolated
     int attempt = (have_prev >= 2 && *code == 0) ? 0 : 1;
@@ -956,7 +992,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
     double fro;
     {
         double xv[9];
-        rf_fetch_m(xv, x, tid);
+        rf_fetch_m(xv, x, tid, fz, solc, xcomp);
         d2 vv[8], vo[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) vv[q] = Vp[tid + 256 * q];
@@ -1135,7 +1171,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
                 __syncthreads();
                 if constexpr (WPS != 1) {                      // M back into its array
                     double xv[9];
-                    rf_fetch_m(xv, x, tid);
+                    rf_fetch_m(xv, x, tid, fz, solc, xcomp);
                     rf_store_m(Ml, xv, sgn, tid);
                     __syncthreads();
                 }
@@ -1173,11 +1209,32 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
     if (fail) {
         // the basis does not fit this matrix: Jacobi from a cold start, in this workgroup
         if (tid == 0) { *code = 1; *cmask = 0ull; }
+        if (fz.on) {                                       // (the Jacobi code reads t1 and writes t2: form t1 first ...)
+            double t1v[9];
+            rf_fetch_m(t1v, x, tid, fz, solc, xcomp);
+            double* __restrict__ t1c = const_cast<double*>(x);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { const int idx = q * 256 + tid; if (idx < P64_LEN) t1c[2 * (int64_t)idx] = t1v[q]; }
+        }
         __syncthreads();
         psd_block<true, true, 256>(out, in, cones, nullptr, 0, vin, vout, 4096, 0, stats, 0, smem);
+        if (fz.on) {                                       // (... and take t2 on to the step's last pass)
+            __syncthreads();
+            const double b2 = 1.0 - fz.alpha2, b = 1.0 - fz.alpha;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int idx = q * 256 + tid;
+                if (idx < P64_LEN) {
+                    const double t1 = x[2 * (int64_t)idx], t2 = y[2 * (int64_t)idx];
+                    const double xn = fz.alpha * (fz.alpha2 * t2 + b2 * t1) + b * xcomp[2 * (int64_t)idx];
+                    xcomp[2 * (int64_t)idx] = xn;
+                    if (fz.shift) (reinterpret_cast<double*>(fz.shift + cd.start) + part)[2 * (int64_t)idx] = part == 1 ? solc[2 * (int64_t)idx] - xn : solc[2 * (int64_t)idx];
+                }
+            }
+        }
         return;
     }
-    if (tid == 0) { *code = 0; *cmask = rmask; if (stats) stats[blockIdx.x] = 100 + 1000 * (attempt == 0) + 16 * nrot + total_it + (rec[4 * gridDim.x] == 77 ? 10000 * dbg_c1 + 100000 * dbg_c2 + 1000000 * (skip != 0ull) : 0); }
+    if (tid == 0) { *code = 0; *cmask = rmask; if (stats) stats[blockIdx.x] = 100 + 1000 * (attempt == 0) + 16 * nrot + total_it + (rec[4 * nmat] == 77 ? 10000 * dbg_c1 + 100000 * dbg_c2 + 1000000 * (skip != 0ull) : 0); }
     if (phase_limit == 16) return;
 
     // ---- one Newton-Schulz step: V <- V (I + (I - V'V) / 2)
@@ -1240,6 +1297,33 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
         Vn[tid + 256 * q] = *reinterpret_cast<const d2*>(Vl + (e & 63) + (e >> 6) * LD);
     }
     __syncthreads();
+    if (fz.on) {
+        double sv[9], xo[9]; unsigned short ij[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int idx = q * 256 + tid;
+            ij[q] = psd64_index.ij[idx < P64_LEN ? idx : 0];
+            sv[q] = idx < P64_LEN ? solc[2 * (int64_t)idx] : 0.0;
+            xo[q] = idx < P64_LEN ? xcomp[2 * (int64_t)idx] : 0.0;
+        }
+        const double b1 = 1.0 - fz.a1, b2 = 1.0 - fz.alpha2, b = 1.0 - fz.alpha;
+        double* __restrict__ shc = fz.shift ? reinterpret_cast<double*>(fz.shift + cd.start) + part : nullptr;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int idx = q * 256 + tid;
+            const int i = ij[q] & 0xFF, j = ij[q] >> 8;
+            double v = Ml[i + j * LD];
+            if (i == j) v *= INV_SQRT2;
+            const double t1 = fz.a1 * sv[q] + b1 * xo[q];              // (the same expression the input was formed with)
+            const double t2 = (dual ? t1 : 0.0) + v;
+            const double xn = fz.alpha * (fz.alpha2 * t2 + b2 * t1) + b * xo[q];
+            if (idx < P64_LEN) {
+                xcomp[2 * (int64_t)idx] = xn;
+                if (shc) shc[2 * (int64_t)idx] = part == 1 ? sv[q] - xn : sv[q];
+            }
+        }
+        return;
+    }
     {
         double xv[9]; unsigned short ij[9];
 #pragma unroll
@@ -1270,9 +1354,15 @@ size_t psd_basis_doubles(int kmax, int ncones) {       // one warm-start basis b
     return (size_t)2 * ncones * (size_t)kmax * kmax;
 }
 
+// whether launch_cones_psd would take the refinement kernel (the only one the step fusion is built into)
+bool psd_fuse_possible(const LaunchCtx& c, int ncones, int kmin, int kmax, const double* vin, const double* vout, int have_prev, const int32_t* redo, int phase_limit) {
+    const bool refine_ok = ncones > 0 && kmin == 64 && kmax == 64 && vin && vout && have_prev && redo && phase_limit == 0;
+    return refine_ok && (c.psd_refine == 1 || (c.psd_refine < 0 && c.psd_wave != 1));
+}
+
 int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones, int kmin, int kmax, double* gscratch,
-                     const double* vin, double* vout, int have_prev, int* stats, int phase_limit, int32_t* redo) {
-    if (ncones <= 0) return FOS_OK;
+                     const double* vin, double* vout, int have_prev, int* stats, int phase_limit, int32_t* redo, const PsdFuse* fuse) {
+    if (ncones <= 0) return fuse ? FOS_EINVAL : FOS_OK;
     // per-handle configuration (fos_create reads the device's CU count and the FOS_PSD_* switches ONCE: two host threads driving
     // handles on different devices share nothing here, and the kernel choice cannot change between a speculative enqueue and its re-run)
     const int cus = c.cus > 0 ? c.cus : 256;
@@ -1294,14 +1384,18 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
             *c.psd_attr_set_r = true;
         }
         // more matrices than CUs: two workgroups per CU (256 registers per lane), so that one's vector phases run beside the other's products
+        PsdFuse fz{};
+        int grid = 2 * ncones;
+        if (fuse) { fz = *fuse; fz.on = 1; fz.nmat = 2 * ncones; grid += std::max(16, std::min(256, (int)((fz.l + 16383) / 16384))); }
+        const int have = c.psd_extrapolate ? have_prev : 1;
+        const double theta = c.psd_theta > 0.0 ? c.psd_theta : RF_THETA;
         if (2 * ncones > cus)
-            hipLaunchKernelGGL(psd64_refine_kernel<2>, dim3(2 * ncones), dim3(256), rl2, c.stream, out, in, cones, vin, vout, c.psd_extrapolate ? have_prev : 1, stats, redo,
-                               phase_limit, c.gate, c.psd_theta > 0.0 ? c.psd_theta : RF_THETA);
+            hipLaunchKernelGGL(psd64_refine_kernel<2>, dim3(grid), dim3(256), rl2, c.stream, out, in, cones, vin, vout, have, stats, redo, phase_limit, c.gate, theta, fz);
         else
-            hipLaunchKernelGGL(psd64_refine_kernel<1>, dim3(2 * ncones), dim3(256), rl1, c.stream, out, in, cones, vin, vout, c.psd_extrapolate ? have_prev : 1, stats, redo,
-                               phase_limit, c.gate, c.psd_theta > 0.0 ? c.psd_theta : RF_THETA);
+            hipLaunchKernelGGL(psd64_refine_kernel<1>, dim3(grid), dim3(256), rl1, c.stream, out, in, cones, vin, vout, have, stats, redo, phase_limit, c.gate, theta, fz);
         return FOS_OK;
     }
+    if (fuse) { set_error("launch_cones_psd: the fused step needs the refinement kernel"); return FOS_EINVAL; }
     if (kmin == 64 && kmax == 64 && wave_env != 0 && (wave_env == 1 || ncones > cus)) {
         const size_t wl = psd64w_lds_bytes();
         const size_t vs = (size_t)64 * 64;

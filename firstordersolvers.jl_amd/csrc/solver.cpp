@@ -831,6 +831,26 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bo
             const bool gapa = h->alg == FOS_ALG_GAPA;
             const PostFn post = [h, gapa, will_check](const LaunchCtx& cg) -> int {
                 static const bool fuse_ew = !(getenv("FOS_RELAX_EW") && atoi(getenv("FOS_RELAX_EW")) == 0);
+                static const bool fuse_psd = !(getenv("FOS_PSD_FUSE") && atoi(getenv("FOS_PSD_FUSE")) == 0);
+                // GAP / DR, no status check in this step, every non-elementwise cone a PSD(64) cone with a basis from the last projection:
+                // relaxation, projection and the step's last pass are ONE launch (PsdFuse, fos_internal.hpp)
+                if (fuse_psd && !gapa && !will_check && h->nsoc == 0 && h->nexp == 0 && !h->ls_interval && !h->gapp_iproj &&
+                    psd_fuse_possible(cg, h->npsd, h->psd_kmin, h->psd_kmax, h->psd_V[h->psd_cur], h->psd_V[1 - h->psd_cur], h->psd_have_prev, h->psd_redo,
+                                      h->psd_phase_limit)) {
+                    RoctxRange range("fos:relaxation + PSD projection + final pass (one launch)");
+                    const bool sh = h->in_step && h->shift_fuse && !h->direct;
+                    PsdFuse fz{};
+                    fz.sol = h->SOL; fz.xv = h->X; fz.shift = sh ? h->RHS : nullptr;
+                    fz.a1 = h->alpha1; fz.alpha = h->alpha; fz.alpha2 = h->alpha2;
+                    fz.ew_op = h->ew_op; fz.l = h->l;
+                    const int pe = prof_begin(h, FOS_PROF_PSD, 0, h->prof_seen[FOS_PROF_PSD]++);
+                    FOS_TRY(launch_cones_psd(cg, h->T2, h->T1, h->psd, h->npsd, h->psd_kmin, h->psd_kmax, h->psd_scratch, h->psd_V[h->psd_cur],
+                                             h->psd_V[1 - h->psd_cur], h->psd_have_prev, h->psd_stats, 0, h->psd_redo, &fz));
+                    prof_end(h, pe);
+                    h->psd_cur = 1 - h->psd_cur; h->psd_have_prev = std::min(h->psd_have_prev + 1, 2);
+                    h->shift_ready = sh;
+                    return check_launch("fused relaxation + PSD projection + final pass");
+                }
                 if (fuse_ew) {                       // the relaxation and the elementwise cones of S2! in one pass
                     launch_relax_ew(cg, h->T1, h->T2, h->SOL, h->X, h->alpha1, gapa, h->ew_op);
                     FOS_TRY(prox_cones(h, h->T2, h->T1, cg.gate, true));
