@@ -305,6 +305,7 @@ struct LaunchCtx {
     int32_t psd_refine = -1;         // FOS_PSD_REFINE: -1 by batch size, 0 / 1 never / always (order 64, warm)
     bool psd_extrapolate = true;     // FOS_PSD_EXTRAPOLATE=0: the refinement starts from the previous basis only
     double psd_theta = 0.0;          // FOS_PSD_THETA: rotation threshold of the refinement (0: the built-in value)
+    int32_t psd_refine_max_mats = 0; // > 0: peer ranks share THIS device (tests): the refinement kernel only for batches this small (psd.hip)
     int32_t count_repl;         // 1: this rank counts the replicated entries in scalar sums (always 1 when not row-sharded)
     int64_t n_repl;             // replicated leading entries of every vector (0 when not row-sharded)
 };

@@ -1355,9 +1355,19 @@ size_t psd_basis_doubles(int kmax, int ncones) {       // one warm-start basis b
 }
 
 // whether launch_cones_psd would take the refinement kernel (the only one the step fusion is built into)
+// Whether a warm order-64 batch goes to the refinement kernel (FOS_PSD_REFINE=0 / 1 switches it off / on for every batch size; by default it
+// runs at every size: 128 / 256 / 512 / 1024 matrices 55 / 58 / 89 / 146 us against 121 / 128 / 178 / 201 for Jacobi).  One exception: when peer
+// ranks share THIS device (several ranks on one GPU: tests only) a workgroup of it -- a whole CU's registers and 100 KB of LDS -- finds no CU
+// while a peer's CG kernel is resident there SPINNING for this rank's mailbox words, which this rank writes only after its projection:
+// two ranks of the full C4 on one GPU dead-locked until the exchange timed out.  Then only batches small enough to fit beside everything.
+static bool psd_refine_chosen(const LaunchCtx& c, int ncones) {
+    if (c.psd_refine == 0 || (c.psd_refine < 0 && c.psd_wave == 1)) return false;
+    if (c.psd_refine_max_mats > 0 && 2 * ncones > c.psd_refine_max_mats) return false;
+    return true;
+}
 bool psd_fuse_possible(const LaunchCtx& c, int ncones, int kmin, int kmax, const double* vin, const double* vout, int have_prev, const int32_t* redo, int phase_limit) {
     const bool refine_ok = ncones > 0 && kmin == 64 && kmax == 64 && vin && vout && have_prev && redo && phase_limit == 0;
-    return refine_ok && (c.psd_refine == 1 || (c.psd_refine < 0 && c.psd_wave != 1));
+    return refine_ok && psd_refine_chosen(c, ncones);
 }
 
 int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones, int kmin, int kmax, double* gscratch,
@@ -1372,10 +1382,9 @@ int launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const 
     // against 173 / 182 / 190).  FOS_PSD_WAVE=0 / 1 forces the workgroup / the wavefront form.
     const int wave_env = c.psd_wave;
     // warm, every cone of order 64, a basis from the previous projection: refinement by matrix products (psd64_refine_kernel) with the
-    // Jacobi workgroup kernel behind it for the matrices it flags.  FOS_PSD_REFINE=0 / 1 switches it off / on for every batch size;
-    // by default it runs at every batch size (128 / 256 / 512 / 1024 matrices: 55 / 58 / 92 / 154 us against 121 / 128 / 178 / 201 for Jacobi).
+    // Jacobi code in the same workgroup for the matrices it flags (psd_refine_chosen above: when)
     const bool refine_ok = kmin == 64 && kmax == 64 && vin && vout && have_prev && redo && (phase_limit == 0 || phase_limit >= 11);
-    if (refine_ok && (c.psd_refine == 1 || (c.psd_refine < 0 && wave_env != 1))) {
+    if (refine_ok && psd_refine_chosen(c, ncones)) {
         const size_t rl1 = psd64r_lds_bytes(1), rl2 = psd64r_lds_bytes(2);
         if (!*c.psd_attr_set_r) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(psd64_refine_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl1);

@@ -146,6 +146,7 @@ struct fos_solver {
     int psd_refine = -1;                       // FOS_PSD_REFINE
     bool psd_extrapolate = true;               // FOS_PSD_EXTRAPOLATE
     double psd_theta = 0.0;                    // FOS_PSD_THETA
+    bool peer_same_device = false;             // a peer rank's mailbox lives on THIS device (several ranks on one GPU: tests)
 
     // scalars
     DevState* st = nullptr;
@@ -252,6 +253,7 @@ struct fos_solver {
         c.between = nullptr; c.between_arg = nullptr;
         c.cus = cus; c.psd_wave = psd_wave; c.psd_narrow = psd_narrow; c.psd_wide = psd_wide; c.psd_wide_threads = psd_wide_threads;
         c.psd_attr_set = &psd_attr_set; c.psd_attr_set_r = &psd_attr_set_r; c.psd_refine = psd_refine; c.psd_extrapolate = psd_extrapolate; c.psd_theta = psd_theta;
+        c.psd_refine_max_mats = (peer_same_device && nranks > 1) ? std::max(1, cus / nranks) : 0;
         c.count_repl = (!row_sharded || rank == 0) ? 1 : 0;
         c.n_repl = row_sharded ? n : 0;
         if (row_sharded) { c.between = &fos_solver::sum_slots_over_ranks; c.between_arg = const_cast<fos_solver*>(this); }
@@ -1454,6 +1456,7 @@ int fos_peer_open(fos_handle h, int nranks, int rank, const void* handles, doubl
         // first contact between DIFFERENT devices: the mapping can succeed where loads and stores over the link cannot -- ask the
         // runtime, and say which pair it is (the caller falls back to its collective: bench.py `peer_fallback_reason`)
         hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, q) == hipSuccess && attr.device == h->device) h->peer_same_device = true;
         if (hipPointerGetAttributes(&attr, q) == hipSuccess && attr.device >= 0 && attr.device != h->device) {
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, h->device, attr.device) == hipSuccess && !can) {

@@ -19,6 +19,11 @@ run c4_shard64_dist1rank FOS_FORCE_DIST=1 -- --small --no-cpu-baseline
 run c4_shard64_dist1rank_rccl FOS_FORCE_DIST=1 FOS_REDUCTION=rccl -- --small --no-cpu-baseline
 run c4_shard64_jacobi FOS_FORCE_DIST=1 FOS_PSD_REFINE=0 -- --small --no-cpu-baseline
 run c3_reference FOS_CG_VARIANT=0 -- --workload C3 --no-cpu-baseline
+run c4_shard64_dist1rank_unfused FOS_FORCE_DIST=1 FOS_PSD_FUSE=0 -- --small --no-cpu-baseline
+# two ranks of the full C4 on the ONE GPU of the box (host coordination over gloo, sums through the peer mailboxes): residuals of the single-rank run.
+# (Eight ranks of the full problem cannot share one GPU: a rank's update kernel spins for its peers' mailbox words, and eight such grids do not fit the
+# device together -- the exchange times out, as it must; eight ranks run on the reduced problem: tests/test_gpu_bench_flow.py.)
+FOS_BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --no-weak-extra 2> $OUT/bench_c4_two_ranks_one_gpu.err | tail -1 > $OUT/bench_c4_two_ranks_one_gpu.json
 for W in c4 c2 c3 c5; do
   extra=""; [ $W != c4 ] && extra="--workload ${W^^}"
   bash tools/r04_trace.sh $W "" $extra > /dev/null 2>&1
