@@ -107,15 +107,19 @@ static bool build_window_panels(int64_t m, int64_t n, const int64_t* colptr, con
         for (int64_t q = rp[r] + 1; q < rp[r + 1]; ++q)
             if (ci[q] <= ci[q - 1]) return false;
     HostBlkCsr& S = *out;
+    static_assert(WIN_USL <= 4, "a WinDesc holds the step counts of four slices");
     const int64_t npanel = (nrows + WIN_ROWS - 1) / WIN_ROWS;
     int64_t staged = 0;                                   // vector elements the tiles stage
     std::vector<int32_t> cnt(WIN_ROWS), order(WIN_ROWS), cursor(WIN_ROWS);
+    struct SegRow { int32_t i, cnt; int64_t q0; };        // an active row of a segment: local row, entries inside the window, first of them
+    struct SegTmp { int32_t win; std::vector<SegRow> rows; };      // rows in descending entry count: slice j = rows 64 j ..
+    std::vector<SegTmp> segs;
     int64_t pos = 0;
     for (int64_t p = 0; p < npanel; ++p) {
         const int64_t r0 = p * WIN_ROWS, R = std::min<int64_t>(WIN_ROWS, nrows - r0);
-        WinPanel wp;
-        wp.row0 = (int32_t)r0; wp.nrows = (int32_t)R; wp.seg0 = (int32_t)S.wseg.size(); wp.nseg = 0;
-        // the windows this panel touches, ascending: every row's entries are sorted by column, so walk them window by window
+        // ---- pass 1: the windows this panel touches, ascending (every row's entries are sorted by column), and per window the
+        //      active rows sorted by their entry count (SELL-sigma)
+        segs.clear();
         for (int64_t i = 0; i < R; ++i) cursor[i] = 0;
         while (true) {
             int64_t wmin = -1;                            // the smallest window with an unconsumed entry
@@ -133,40 +137,54 @@ static bool build_window_panels(int64_t m, int64_t n, const int64_t* colptr, con
                 if (k > 0) order[nact++] = (int32_t)i;
             }
             std::stable_sort(order.begin(), order.begin() + nact, [&](int32_t a, int32_t b) { return cnt[a] > cnt[b]; });
-            WinSeg sg;
-            sg.col0 = (int32_t)c0; sg.ncols = (int32_t)(c1 - c0); sg.slice0 = (int32_t)S.wslice.size(); sg.nslice = 0;
-            for (int64_t s0 = 0; s0 < nact; s0 += 64) {
-                const int64_t ns = std::min<int64_t>(64, nact - s0);
-                const int32_t T = cnt[order[s0]];
-                WinSlice sl;
-                sl.off = pos; sl.steps = T; sl.pad = 0;
-                S.wval.resize((size_t)(pos + 64 * (int64_t)T), 0.0);
-                S.wcol.resize((size_t)(pos + 64 * (int64_t)T), 0);
-                const size_t rbase = S.wrow.size();
-                S.wrow.resize(rbase + 64, (uint16_t)0xFFFF);
-                for (int64_t l = 0; l < ns; ++l) {
-                    const int32_t i = order[s0 + l];
-                    S.wrow[rbase + l] = (uint16_t)i;
-                    const int64_t q0 = rp[r0 + i] + cursor[i];
-                    for (int32_t t = 0; t < cnt[i]; ++t) {
-                        S.wval[(size_t)(pos + 64 * (int64_t)t + l)] = vv[q0 + t];
-                        S.wcol[(size_t)(pos + 64 * (int64_t)t + l)] = (uint16_t)(ci[q0 + t] - c0);
-                    }
-                }
-                pos += 64 * (int64_t)T;
-                S.wslice.push_back(sl);
-                sg.nslice += 1;
-            }
+            segs.emplace_back();
+            SegTmp& sg = segs.back();
+            sg.win = (int32_t)wmin;
+            sg.rows.resize((size_t)nact);
+            for (int64_t l = 0; l < nact; ++l) { const int32_t i = order[l]; sg.rows[l] = SegRow{i, cnt[i], rp[r0 + i] + cursor[i]}; }
             for (int64_t i = 0; i < R; ++i) cursor[i] += cnt[i];
-            S.wseg.push_back(sg);
-            wp.nseg += 1;
             staged += c1 - c0;
+        }
+        // ---- pass 2: one stream per wavefront: segment after segment, its slices j = w, w + WIN_WAVES, ...
+        WinPanel wp;
+        wp.row0 = (int32_t)r0; wp.nrows = (int32_t)R; wp.seg0 = (int32_t)S.wdesc.size(); wp.nseg = (int32_t)segs.size();
+        if (S.wdesc.size() + (size_t)WIN_WAVES * segs.size() >= ((size_t)1 << 31)) return false;
+        for (int w = 0; w < WIN_WAVES; ++w) {
+            WinWave ww;
+            ww.off = pos; ww.slice0 = (int32_t)(S.wrow.size() / 64); ww.pad = 0;
+            S.wwave.push_back(ww);
+            for (const SegTmp& sg : segs) {
+                const int64_t nact = (int64_t)sg.rows.size();
+                uint32_t T4[4] = {0, 0, 0, 0};
+                for (int u = 0; u < WIN_USL; ++u) {
+                    const int64_t s0 = 64 * (int64_t)(w + WIN_WAVES * u);
+                    if (s0 >= nact) break;
+                    const int64_t ns = std::min<int64_t>(64, nact - s0);
+                    const int32_t T = sg.rows[s0].cnt;
+                    T4[u] = (uint32_t)T;
+                    S.wval.resize((size_t)(pos + 64 * (int64_t)T), 0.0);
+                    S.wcol.resize((size_t)(pos + 64 * (int64_t)T), 0);
+                    const size_t rbase = S.wrow.size();
+                    S.wrow.resize(rbase + 64, (uint16_t)0xFFFF);
+                    for (int64_t l = 0; l < ns; ++l) {
+                        const SegRow& sr = sg.rows[s0 + l];
+                        S.wrow[rbase + l] = (uint16_t)sr.i;
+                        for (int32_t t = 0; t < sr.cnt; ++t) {
+                            S.wval[(size_t)(pos + 64 * (int64_t)t + l)] = vv[sr.q0 + t];
+                            S.wcol[(size_t)(pos + 64 * (int64_t)t + l)] = (uint16_t)(ci[sr.q0 + t] - (int64_t)sg.win * WIN_COLS);
+                        }
+                    }
+                    pos += 64 * (int64_t)T;
+                    S.wnslice += 1;
+                }
+                S.wdesc.push_back(WinDesc{(uint32_t)sg.win, T4[0] | (T4[1] << 16), T4[2] | (T4[3] << 16), 0u});
+            }
         }
         S.wpanel.push_back(wp);
     }
     const bool worth = 2 * nnz >= staged / 2 && npanel >= 64;
     if (!worth && !force) {
-        S.wpanel.clear(); S.wseg.clear(); S.wslice.clear(); S.wval.clear(); S.wcol.clear(); S.wrow.clear();
+        S.wpanel.clear(); S.wwave.clear(); S.wdesc.clear(); S.wnslice = 0; S.wval.clear(); S.wcol.clear(); S.wrow.clear();
         std::vector<double>().swap(S.wval);
         return false;
     }
@@ -649,42 +667,63 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
 // without a GPU.
 int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::string* why) {
     if (!S.wpanel.empty()) {
-        // window panels: per panel the row sums accumulate window by window, inside a window slice by slice, lane by lane
+        // window panels: per panel the row sums accumulate window by window; inside a window every wavefront takes its slices from
+        // its own stream (running offsets, as the kernel walks them), lane by lane
         auto failw = [&](const char* msg, long long a) { if (why) *why = std::string(msg) + " " + std::to_string(a); return FOS_EINVAL; };
         std::vector<int> covered(S.nrows, 0);
         int64_t next_row = 0;
+        if (S.wwave.size() != S.wpanel.size() * WIN_WAVES) return failw("wave table size", (long long)S.wwave.size());
+        int64_t slices_seen = 0, values_seen = 0;
         for (size_t p = 0; p < S.wpanel.size(); ++p) {
             const WinPanel& wp = S.wpanel[p];
             if (wp.row0 != next_row || wp.nrows < 1 || wp.nrows > WIN_ROWS) return failw("bad panel", (long long)p);
+            if (wp.seg0 < 0 || wp.nseg < 0 || (size_t)wp.seg0 + (size_t)WIN_WAVES * wp.nseg > S.wdesc.size()) return failw("bad record range in panel", (long long)p);
             next_row += wp.nrows;
             std::vector<double> acc(wp.nrows, 0.0);
-            int32_t prev_col0 = -1;
-            for (int32_t sgi = wp.seg0; sgi < wp.seg0 + wp.nseg; ++sgi) {
-                const WinSeg& sg = S.wseg[sgi];
-                if (sg.col0 <= prev_col0 || sg.col0 % WIN_COLS || sg.ncols < 1 || sg.ncols > WIN_COLS || sg.col0 + sg.ncols > S.nrows) return failw("bad window in panel", (long long)p);
-                prev_col0 = sg.col0;
+            int64_t off[WIN_WAVES]; int64_t rs[WIN_WAVES];
+            for (int w = 0; w < WIN_WAVES; ++w) { off[w] = S.wwave[p * WIN_WAVES + w].off; rs[w] = S.wwave[p * WIN_WAVES + w].slice0; }
+            int64_t prev_win = -1;
+            for (int32_t k = 0; k < wp.nseg; ++k) {
+                const int64_t win = S.wdesc[(size_t)wp.seg0 + k].win;
+                const int64_t col0 = win * WIN_COLS, ncols = std::min<int64_t>(WIN_COLS, S.nrows - col0);
+                if (win <= prev_win || ncols < 1) return failw("bad window in panel", (long long)p);
+                prev_win = win;
                 std::vector<int> used(wp.nrows, 0);
-                for (int32_t sl = sg.slice0; sl < sg.slice0 + sg.nslice; ++sl) {
-                    const WinSlice& ws = S.wslice[sl];
-                    if (ws.off % 64 || ws.steps < 1 || ws.off + 64 * (int64_t)ws.steps > (int64_t)S.wval.size()) return failw("bad slice", sl);
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const uint16_t rid = S.wrow[(size_t)sl * 64 + lane];
-                        double a = 0.0;
-                        for (int t = 0; t < ws.steps; ++t) {
-                            const size_t e = (size_t)(ws.off + 64 * (int64_t)t + lane);
-                            const int c = S.wcol[e];
-                            if (c >= sg.ncols) return failw("column outside the window in slice", sl);
-                            if (rid == 0xFFFF && S.wval[e] != 0.0) return failw("padding lane with a value in slice", sl);
-                            a += S.wval[e] * v[sg.col0 + c];
+                for (int w = 0; w < WIN_WAVES; ++w) {
+                    const WinDesc& d = S.wdesc[(size_t)wp.seg0 + (size_t)w * wp.nseg + k];
+                    if ((int64_t)d.win != win) return failw("wavefronts disagree on the window in panel", (long long)p);
+                    const uint32_t T4[4] = {d.t01 & 0xFFFFu, d.t01 >> 16, d.t23 & 0xFFFFu, d.t23 >> 16};
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t T = T4[u];
+                        if (T == 0) { for (int u2 = u + 1; u2 < 4; ++u2) if (T4[u2]) return failw("slice after an empty one in panel", (long long)p); break; }
+                        if (u >= WIN_USL || off[w] % 64 || off[w] + 64 * T > (int64_t)S.wval.size() || (size_t)(rs[w] + 1) * 64 > S.wrow.size()) return failw("bad slice in panel", (long long)p);
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const uint16_t rid = S.wrow[(size_t)rs[w] * 64 + lane];
+                            double a = 0.0;
+                            for (int64_t t = 0; t < T; ++t) {
+                                const size_t e = (size_t)(off[w] + 64 * t + lane);
+                                const int c = S.wcol[e];
+                                if (c >= ncols) return failw("column outside the window in panel", (long long)p);
+                                if (rid == 0xFFFF && S.wval[e] != 0.0) return failw("padding lane with a value in panel", (long long)p);
+                                a += S.wval[e] * v[col0 + c];
+                            }
+                            if (rid == 0xFFFF) continue;
+                            if (rid >= wp.nrows || used[rid]++) return failw("row listed twice in a window, panel", (long long)p);
+                            acc[rid] += a;
                         }
-                        if (rid == 0xFFFF) continue;
-                        if (rid >= wp.nrows || used[rid]++) return failw("row listed twice in a window, slice", sl);
-                        acc[rid] += a;
+                        off[w] += 64 * T; rs[w] += 1; slices_seen += 1; values_seen += 64 * T;
                     }
                 }
             }
+            for (int w = 0; w < WIN_WAVES; ++w) {           // every stream ends where the next one starts
+                const size_t nx = p * WIN_WAVES + w + 1;
+                const int64_t end_off = nx < S.wwave.size() ? S.wwave[nx].off : S.nnz_padded;
+                const int64_t end_rs = nx < S.wwave.size() ? S.wwave[nx].slice0 : S.wnslice;
+                if (off[w] != end_off || rs[w] != end_rs) return failw("stream of a wavefront does not end at the next one, panel", (long long)p);
+            }
             for (int32_t i = 0; i < wp.nrows; ++i) { out[wp.row0 + i] = acc[i]; covered[wp.row0 + i]++; }
         }
+        if (slices_seen != S.wnslice || values_seen != S.nnz_padded) return failw("slices walked:", slices_seen);
         if (next_row != S.nrows) return failw("panels do not cover all rows:", next_row);
         for (int64_t r = 0; r < S.nrows; ++r) if (covered[r] != 1) return failw("row not covered exactly once:", r);
         return FOS_OK;

@@ -77,9 +77,18 @@ constexpr int WIN_ROWS = 2016;      // panel: 31.5 KB of row sums in LDS
 constexpr int WIN_NSL = 3;          // slices per wavefront and segment whose first WIN_PRE steps are requested with the window
 constexpr int WIN_WG_PER_CU = 2;    // two workgroups per CU (2 x 80 KB of LDS): each hides the other's memory latency
 constexpr int WIN_THREADS = 512;    // 8 wavefronts share the window
-struct WinPanel { int32_t row0, nrows, seg0, nseg; };
-struct WinSeg { int32_t col0, ncols, slice0, nslice; };
-struct WinSlice { int64_t off; int32_t steps, pad; };       // values/columns at off + 64 t + lane (off a multiple of 64)
+constexpr int WIN_WAVES = WIN_THREADS / 64;
+constexpr int WIN_USL = (WIN_ROWS + 64 * WIN_WAVES - 1) / (64 * WIN_WAVES);      // slices one wavefront can get in a segment (4)
+// Storage = WAVE STREAMS (round 4).  Slice j of a segment (slices in descending step count) belongs to wavefront j % WIN_WAVES; everything
+// one wavefront reads of a panel -- its slices' values / column offsets / row words, segment after segment -- is CONTIGUOUS, so the
+// wavefront walks it with a running offset, and what it has to be told per segment (the window and the step counts of its <= WIN_USL
+// slices) is one 16-byte record, all records of a panel loaded in ONE request at the panel's start (lane k holds segment k's record,
+// read back by v_readlane): no dependent descriptor load sits in front of a segment's memory requests any more (the round-3 form paid
+// two scalar round trips -- segment, then slice descriptor -- before the slice loads of EVERY segment could be issued).
+struct WinPanel { int32_t row0, nrows, seg0, nseg; };      // seg0: first record of wavefront 0 in wdesc; wavefront w: seg0 + w * nseg
+struct WinWave { int64_t off; int32_t slice0, pad; };       // per (panel, wavefront): first value / column offset (multiple of 64), first row-word slice
+struct WinDesc { uint32_t win, t01, t23, pad; };            // per (panel, wavefront, segment): window number; steps of the wavefront's slices u = 0..3
+                                                            // (16 bits each, 0: no such slice; descending).  Values at off + 64 t + lane, then the next slice.
 
 
 // One slot-spread row and its list of partial-sum slots, in summation order: [its own partial `own` (>= 0) from the sweep] followed
@@ -130,8 +139,9 @@ struct HostBlkCsr {
     bool row_sharded = false;          // every row of A' is deferred: the single slot `row`, or -- with dual tiles -- its local slot list (summed over the ranks before use)
     // window panels (empty unless the operator is stored that way; then blk is empty and val/col are unused)
     std::vector<WinPanel> wpanel;
-    std::vector<WinSeg> wseg;
-    std::vector<WinSlice> wslice;
+    std::vector<WinWave> wwave;        // [npanel * WIN_WAVES]
+    std::vector<WinDesc> wdesc;        // [sum over panels of WIN_WAVES * nseg]
+    int64_t wnslice = 0;               // slices stored
     std::vector<double> wval;
     std::vector<uint16_t> wcol;        // column offset inside the window, per stored entry
     std::vector<uint16_t> wrow;        // [nslice * 64] local row of each lane (0xFFFF: no row)
@@ -166,9 +176,10 @@ struct DevBlkCsr {
                                        // sweep's records into its own nwg_def, stored behind them)
     // window panels (npanel == 0: row-block storage)
     int32_t npanel;
+    int32_t win_temporal_pct;          // share (%) of a panel's segments whose matrix stream is read with ordinary loads (stays in the Infinity Cache)
     const WinPanel* wpanel;
-    const WinSeg* wseg;
-    const WinSlice* wslice;
+    const WinWave* wwave;
+    const WinDesc* wdesc;
     const double* wval;
     const uint16_t* wcol;
     const uint16_t* wrow;

@@ -538,8 +538,17 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
 // runs once per row at the end, over consecutive rows (coalesced).
 constexpr size_t win_lds_bytes(int nrhs) { return (size_t)(WIN_COLS + WIN_ROWS) * 8 * nrhs + 64 * sizeof(double); }
 
-// What a wavefront holds of one 64-row slice while the window is being staged: the first WIN_PRE steps of its lane's values
-// and window offsets, requested BEFORE the barriers of the segment so that one memory latency covers the window and the matrix.
+// In-kernel time stamps of the window walk (timing experiments; compiled in with -DFOS_WIN_STAMPS): workgroup FOS_WIN_STAMP_WG, every
+// wavefront, segment k, phase ph -> g_win_stamps[(wave * 64 + k) * 8 + ph], in ticks of the 100 MHz clock.
+#ifdef FOS_WIN_STAMPS
+__device__ long long g_win_stamps[8 * 64 * 8];
+#define WIN_STAMP(ph) do { if (stamp_on && k0 + k < 64) { __builtin_amdgcn_sched_barrier(0); g_win_stamps[((size_t)wv * 64 + k0 + k) * 8 + (ph)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define WIN_STAMP(ph) do { } while (0)
+#endif
+
+// What a wavefront holds of its slices while the window is being staged: the first WIN_PRE steps of each lane's values and window
+// offsets, requested BEFORE the barriers of the segment so that one memory latency covers the window and the matrix.
 constexpr int WIN_PRE = 6;
 struct WinSliceRegs {
     double v[WIN_PRE];
@@ -548,15 +557,10 @@ struct WinSliceRegs {
     int T;                 // steps of the slice, wave-uniform (0: no slice)
     int64_t off;
 };
-__device__ __forceinline__ void win_slice_desc(const DevBlkCsr& S, int sl, bool have, WinSliceRegs& r) {
-    // wave-uniform descriptor through the constant address space (scalar loads)
-    typedef const __attribute__((address_space(4))) WinSlice* cptr_slice;
-    r.T = 0; r.off = 0;
-    if (have) { const cptr_slice d = (cptr_slice)(S.wslice + sl); r.off = d->off; r.T = d->steps; }
-}
-// The value / offset loads depend only on the (scalar) slice descriptor, NOT on the per-lane row word (a second dependent
+// The value / offset loads depend only on the (wave-uniform) step count and running offset, NOT on the per-lane row word (a second dependent
 // memory round trip per segment costs more than the padding it would avoid reading: per-lane-count predication measured
 // 210-260 us per C5 sweep).  Steps beyond a lane's count hold value 0 / offset 0.
+template <bool MNT>
 __device__ __forceinline__ void win_slice_issue(const DevBlkCsr& S, int sl, int lane, WinSliceRegs& r) {
     r.rid = 0xFFFFu;
 #pragma unroll
@@ -567,10 +571,10 @@ __device__ __forceinline__ void win_slice_issue(const DevBlkCsr& S, int sl, int 
         const uint16_t* __restrict__ col = S.wcol + r.off + lane;
 #pragma unroll
         for (int t = 0; t < WIN_PRE; ++t)
-            if (t < r.T) { r.v[t] = nt_load(val + 64 * t); r.c[t] = nt_load(col + 64 * t); }
+            if (t < r.T) { r.v[t] = mload<MNT>(val + 64 * t); r.c[t] = mload<MNT>(col + 64 * t); }
     }
 }
-template <int NRHS, class E>
+template <bool MNT, int NRHS, class E>
 __device__ __forceinline__ void win_slice_compute(const DevBlkCsr& S, const WinSliceRegs& r, const E* __restrict__ win, E* __restrict__ acc, int lane) {
     if (r.T <= 0) return;
     double a1 = 0.0, a2 = 0.0;
@@ -583,8 +587,8 @@ __device__ __forceinline__ void win_slice_compute(const DevBlkCsr& S, const WinS
         const double* __restrict__ val = S.wval + r.off + lane;
         const uint16_t* __restrict__ col = S.wcol + r.off + lane;
         for (int t = WIN_PRE; t < r.T; ++t) {
-            const double v = nt_load(val + 64 * t);
-            const E x = win[nt_load(col + 64 * t)];
+            const double v = mload<MNT>(val + 64 * t);
+            const E x = win[mload<MNT>(col + 64 * t)];
             if constexpr (NRHS == 2) { a1 += v * x.x; a2 += v * x.y; } else a1 += v * x;
         }
     }
@@ -595,62 +599,91 @@ __device__ __forceinline__ void win_slice_compute(const DevBlkCsr& S, const WinS
 }
 
 // One segment = one (panel, window) tile.  EVERYTHING the segment needs from memory -- the window's vector elements and the
-// first WIN_PRE steps of WIN_NSL slices per wavefront -- is requested before the first barrier, so a segment costs one memory
-// latency, two barriers and the LDS work.  The walk is LATENCY bound: its time is (segments a workgroup slot runs one after the
-// other) x (latency of one); with the sweep's parts switched off in turn, of 112 us per C5 sweep 63 were that skeleton, 20
-// the window gathers, 30 the slice loads and the multiply.  So what pays is more workgroup slots without proportionally more
-// segments: TWO workgroups of 512 threads per CU (2 x 80 KB of LDS: 3072-column windows, 2016-row panels, three slices per
-// wavefront in registers) run 20.7 segments per slot where one workgroup of 1024 threads (4096 x 2048, 96 KB) ran 32.
-// Measured per C5 sweep (MI355X): row blocks 155 us; 1 x 1024 threads, 2048 x 4096 tiles 112-116 us; 2 x 512 threads,
-// 2016 x 3072 tiles 93 us (kept).  Slower: 4096 x 4096 tiles with 1024 threads 139-160 us (a third / fourth slice per wavefront
-// falls into the dependent-load path); 2048 x 2048 tiles with a register-double-buffered software pipeline across segments
-// 136-145 us (twice the barriers); per-lane-count predicated loads 210-260 us; next segment's descriptors requested one segment
-// ahead by scalar loads 111.6 us (they share the LDS counter, so the LDS accesses wait for them anyway), by vector loads from a
-// flat per-(segment, wavefront) table 127 us.
-template <class G, class Epi>
+// first WIN_PRE steps of WIN_NSL slices per wavefront -- is requested before the first barrier, and (round 4: wave streams,
+// fos_internal.hpp) NOTHING of it waits for a descriptor: the panel's records sit in a register (lane k = segment k, one request
+// per panel), the addresses are running offsets.  A segment costs one memory latency, two barriers and the LDS work.
+// In-kernel stamps (round 4, tools/win_stamps.py, C5: 21-23 segments per panel, 4.0 us each): ISSUING the segment's ~18 loads per
+// wavefront takes 1.6-2.2 us -- the wavefronts stall in the issue of their memory instructions --, the first barrier 0.1-1.0 (the
+// wavefronts that issued first wait for the last), the wait for the data and the window's LDS stores 0.4-0.5, the second barrier
+// 0.1-0.2, the multiply out of LDS and the row sums 0.7-1.0.  ONE workgroup per CU runs a segment in 3.0 us, two in 4.0 each.
+// What was measured on this walk (per C5 sweep, MI355X): row blocks 155 us; 1 x 1024 threads, 2048 x 4096 tiles 112-116 us;
+// 2 x 512 threads, 2016 x 3072 tiles 93-97 us (kept).  Slower or equal: 4096 x 4096 tiles with 1024 threads 139-160; 2048 x 2048
+// tiles with a register-double-buffered pipeline across segments 136-145 (twice the barriers); per-lane-count predicated loads
+// 210-260; next segment's descriptors requested one segment ahead by scalar loads 111.6, by vector loads 127; round 4: NO
+// descriptor loads per segment at all (this form) 96.9 against 97.4 -- the two scalar round trips were not on the critical path;
+// a body with one nest of wave-uniform step tests for the three slices, unpredicated whole-window loads / stores and a dummy
+// row-sum element for padding lanes (a third fewer scalar instructions) 99-102: its LDS reads wait step by step; the same with
+// per-step tests only 119; the matrix stream by ordinary loads (to keep it in the Infinity Cache) 102.6 against 101.2 and 51.8
+// against 54.3 FISTA it/s; the second workgroup of every CU started 1-4 us late (out of phase) 101-103 against 99; the slice loads issued in front of the window loads 98-99 against 95-96.
+template <bool MNT, class G, class Epi>
 __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& epi, double* lds) {
     constexpr int NRHS = G::NRHS;
-    constexpr int NWAVES = WIN_THREADS / 64;
+    constexpr int NWAVES = WIN_WAVES;
     constexpr int WPT = (WIN_COLS + WIN_THREADS - 1) / WIN_THREADS;      // window elements per thread
     using E = typename std::conditional<NRHS == 2, d2, double>::type;
-    typedef const __attribute__((address_space(4))) WinSeg* cptr_seg;
     E* win = reinterpret_cast<E*>(lds);
     E* acc = win + WIN_COLS;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef FOS_WIN_STAMPS
+    const bool stamp_on = blockIdx.x == 100 && lane == 0;
+#endif
     for (int p = xcd_remap(blockIdx.x, gridDim.x); p < S.npanel; p += gridDim.x) {
         const WinPanel wp = S.wpanel[p];
+        const WinWave ww = S.wwave[(size_t)p * NWAVES + wv];
+        int64_t off = ww.off;                              // running position of this wavefront in the value / column streams
+        int rs = ww.slice0;                                // ... and in the row words
+        const WinDesc* __restrict__ drec = S.wdesc + wp.seg0 + (size_t)wv * wp.nseg;
         for (int i = tid; i < wp.nrows; i += WIN_THREADS) {
             if constexpr (NRHS == 2) acc[i] = make_double2(0.0, 0.0); else acc[i] = 0.0;
         }
-        for (int sgi = wp.seg0; sgi < wp.seg0 + wp.nseg; ++sgi) {
-            const cptr_seg sgp = (cptr_seg)(S.wseg + sgi);
-            const int col0 = sgp->col0, ncols = sgp->ncols, slice0 = sgp->slice0, nslice = sgp->nslice;
-            // ---- everything this segment needs from memory is requested here, in one go
-            WinSliceRegs r[WIN_NSL];
+        for (int k0 = 0; k0 < wp.nseg; k0 += 64) {         // (one chunk unless a panel touches more than 64 windows)
+            const int nk = min(64, wp.nseg - k0);
+            uint4 dv = make_uint4(0u, 0u, 0u, 0u);
+            if (lane < nk) dv = *reinterpret_cast<const uint4*>(drec + k0 + lane);
+            for (int k = 0; k < nk; ++k) {
+                WIN_STAMP(0);
+                const unsigned dwin = (unsigned)__builtin_amdgcn_readlane((int)dv.x, k);
+                const unsigned t01 = (unsigned)__builtin_amdgcn_readlane((int)dv.y, k);
+                const unsigned t23 = (unsigned)__builtin_amdgcn_readlane((int)dv.z, k);
+                const int col0 = (int)dwin * WIN_COLS;
+                const int ncols = min(WIN_COLS, (int)S.nrows - col0);
+                const int T4[4] = {(int)(t01 & 0xFFFFu), (int)(t01 >> 16), (int)(t23 & 0xFFFFu), (int)(t23 >> 16)};
+                // ---- everything this segment needs from memory is requested here, in one go
+                WinSliceRegs r[WIN_NSL];
 #pragma unroll
-            for (int u = 0; u < WIN_NSL; ++u) win_slice_desc(S, slice0 + wv + u * NWAVES, wv + u * NWAVES < nslice, r[u]);
-            d2 wreg[WPT];
+                for (int u = 0; u < WIN_NSL; ++u) { r[u].T = T4[u]; r[u].off = off; off += 64 * (int64_t)T4[u]; }
+                d2 wreg[WPT];
 #pragma unroll
-            for (int q = 0; q < WPT; ++q) {
-                const int i = tid + q * WIN_THREADS;
-                wreg[q] = (i < ncols) ? gat.load(col0 + i) : make_double2(0.0, 0.0);
-            }
+                for (int q = 0; q < WPT; ++q) {
+                    const int i = tid + q * WIN_THREADS;
+                    wreg[q] = (i < ncols) ? gat.load(col0 + i) : make_double2(0.0, 0.0);
+                }
 #pragma unroll
-            for (int u = 0; u < WIN_NSL; ++u) win_slice_issue(S, slice0 + wv + u * NWAVES, lane, r[u]);
-            __syncthreads();                               // the previous window's readers are done (first pass: acc is zeroed)
+                for (int u = 0; u < WIN_NSL; ++u) win_slice_issue<MNT>(S, rs + u, lane, r[u]);
+                WIN_STAMP(1);
+                __syncthreads();                           // the previous window's readers are done (first pass: acc is zeroed)
+                WIN_STAMP(2);
 #pragma unroll
-            for (int q = 0; q < WPT; ++q) {
-                const int i = tid + q * WIN_THREADS;
-                if (i < ncols) { if constexpr (NRHS == 2) win[i] = wreg[q]; else win[i] = wreg[q].x; }
-            }
-            __syncthreads();
+                for (int q = 0; q < WPT; ++q) {
+                    const int i = tid + q * WIN_THREADS;
+                    if (i < ncols) { if constexpr (NRHS == 2) win[i] = wreg[q]; else win[i] = wreg[q].x; }
+                }
+                WIN_STAMP(3);
+                __syncthreads();
+                WIN_STAMP(4);
 #pragma unroll
-            for (int u = 0; u < WIN_NSL; ++u) win_slice_compute<NRHS>(S, r[u], win, acc, lane);
-            for (int sl = slice0 + wv + WIN_NSL * NWAVES; sl < slice0 + nslice; sl += NWAVES) {      // (more slices than the registers hold: rare)
-                WinSliceRegs t;
-                win_slice_desc(S, sl, true, t);
-                win_slice_issue(S, sl, lane, t);
-                win_slice_compute<NRHS>(S, t, win, acc, lane);
+                for (int u = 0; u < WIN_NSL; ++u) { win_slice_compute<MNT, NRHS>(S, r[u], win, acc, lane); rs += T4[u] > 0; }
+#pragma unroll
+                for (int u = WIN_NSL; u < WIN_USL; ++u) {  // (more slices than the registers hold: more than 3/4 of the panel's rows active in one window)
+                    if (T4[u] > 0) {
+                        WinSliceRegs t;
+                        t.T = T4[u]; t.off = off; off += 64 * (int64_t)T4[u];
+                        win_slice_issue<MNT>(S, rs, lane, t);
+                        win_slice_compute<MNT, NRHS>(S, t, win, acc, lane);
+                        rs += 1;
+                    }
+                }
+                WIN_STAMP(5);
             }
         }
         __syncthreads();
@@ -793,6 +826,7 @@ __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBl
 }
 
 // window-panel form of the sweep (stand-alone applies and CG iterations alike: no dual tiles, the p update is a kernel of its own)
+template <bool MNT>
 __global__ __launch_bounds__(WIN_THREADS, 4) void kkt2_win_kernel(DevBlkCsr S, KktArgs a) {
     if (a.gate && a.close_j < 0 && a.st->done) return;
     extern __shared__ __attribute__((aligned(16))) double wlds[];
@@ -803,9 +837,19 @@ __global__ __launch_bounds__(WIN_THREADS, 4) void kkt2_win_kernel(DevBlkCsr S, K
     epi.gat = gat; epi.out = a.out; epi.pnew = nullptr; epi.cb = a.cb; epi.n = a.n; epi.wt = gat.load_u(a.nm);
     epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
     if (a.vt_out && blockIdx.x == 0 && threadIdx.x == 0) { a.vt_out[0] = epi.wt.x; a.vt_out[1] = epi.wt.y; }
-    win_walk(S, gat, epi, wlds);
+    win_walk<MNT>(S, gat, epi, wlds);
     block_reduce_store<3, WIN_THREADS>(epi.acc, wlds + (size_t)(WIN_COLS + WIN_ROWS) * 2, a.partials + 3 * (int64_t)blockIdx.x);
 }
+}  // namespace fos
+extern "C" int fos_debug_win_stamps(long long* out, int n) {      // (not part of the ABI: timing experiments, tools/win_stamps.py)
+#ifdef FOS_WIN_STAMPS
+    if (n > 8 * 64 * 8) n = 8 * 64 * 8;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fos::g_win_stamps), sizeof(long long) * (size_t)n);
+#else
+    (void)out; (void)n; return -1;
+#endif
+}
+namespace fos {
 // dynamic LDS above 64 KB needs an opt-in per kernel and device
 template <class K>
 static bool win_lds_optin(K kernel, size_t bytes) {
@@ -814,8 +858,13 @@ static bool win_lds_optin(K kernel, size_t bytes) {
     return true;
 }
 static void launch_kkt2_win(const LaunchCtx& c, const KktArgs& a) {
-    (void)win_lds_optin(kkt2_win_kernel, win_lds_bytes(2));       // cheap (a table update); a failure surfaces through check_launch
-    hipLaunchKernelGGL(kkt2_win_kernel, dim3(c.S.nwg), dim3(WIN_THREADS), win_lds_bytes(2), c.stream, c.S, a);
+    if (c.S.win_temporal_pct >= 50) {
+        (void)win_lds_optin(kkt2_win_kernel<false>, win_lds_bytes(2));       // cheap (a table update); a failure surfaces through check_launch
+        hipLaunchKernelGGL(kkt2_win_kernel<false>, dim3(c.S.nwg), dim3(WIN_THREADS), win_lds_bytes(2), c.stream, c.S, a);
+    } else {
+        (void)win_lds_optin(kkt2_win_kernel<true>, win_lds_bytes(2));
+        hipLaunchKernelGGL(kkt2_win_kernel<true>, dim3(c.S.nwg), dim3(WIN_THREADS), win_lds_bytes(2), c.stream, c.S, a);
+    }
 }
 
 // Deferred rows (dual tiles): `lpr` lanes (a power of two <= 64, S.def_lpr) share a row: lane-strided partial sums of the
@@ -1351,7 +1400,7 @@ __global__ __launch_bounds__(WIN_THREADS, 4) void q1_win_kernel(DevBlkCsr S, con
     for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
     epi.init(vcomp[2 * (int64_t)nm]);
     Gather1 gat{vcomp};
-    win_walk(S, gat, epi, wlds);
+    win_walk<true>(S, gat, epi, wlds);
     block_reduce_store<NACC, WIN_THREADS>(epi.acc, wlds + (size_t)(WIN_COLS + WIN_ROWS), partials + NACC * (int64_t)blockIdx.x);
 }
 template <class Epi, int NACC>
