@@ -81,7 +81,9 @@ void partition_workgroups(HostBlkCsr* S, int nwg_target) {
 // back to row blocks): fewer entries inside the panel-window tiles than half the vector elements the tiles stage (the window
 // loads would then cost more than the gathers they replace), or too few panels to fill the GPU.
 static bool build_window_panels(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
-                                bool force, HostBlkCsr* out) {
+                                bool force, const WinGeomRt& G, HostBlkCsr* out) {
+    const int64_t WIN_ROWS = G.rows, WIN_COLS = G.cols;
+    const int WIN_WAVES = G.waves, WIN_USL = (int)((WIN_ROWS + 64 * WIN_WAVES - 1) / (64 * WIN_WAVES));
     const int64_t nrows = n + m, nnz = colptr[n] - 1;
     if (nrows >= (int64_t)1 << 31 || 2 * nnz >= ((int64_t)1 << 40)) return false;
     // ---- CSR of S: rows 0..n-1 = columns of A (entries at stacked column n + i), rows n.. = rows of A (stacked column j)
@@ -107,28 +109,78 @@ static bool build_window_panels(int64_t m, int64_t n, const int64_t* colptr, con
         for (int64_t q = rp[r] + 1; q < rp[r + 1]; ++q)
             if (ci[q] <= ci[q - 1]) return false;
     HostBlkCsr& S = *out;
-    static_assert(WIN_USL <= 4, "a WinDesc holds the step counts of four slices");
-    const int64_t npanel = (nrows + WIN_ROWS - 1) / WIN_ROWS;
+    S.wgeom = G;
+    // ---- the panels' row ranges.  A panel whose rows reach into two column ranges that have nothing to do with each other -- the y part
+    // and the x part of the stacked vector (rows of A' / rows of A), or two diagonal blocks of a block-diagonal A -- walks the windows
+    // of both: twice the segments of its neighbours, and the sweep lasts as long as its slowest panel (C5, 8 blocks: every 16th panel).
+    // So the rows are first cut into GROUPS at such boundaries (inside each half of S: row r starts a group when every later row of
+    // the half lies to the right of all rows of the current group), consecutive groups are packed into panels while they fit, and a
+    // group larger than a panel is cut into equal panels of its own (C5: 16 blocks x 16 tall panels of 3907 rows = one per CU).
+    std::vector<std::pair<int64_t, int64_t>> pranges;      // (first row, rows)
+    for (int half = 0; half < 2; ++half) {
+        const int64_t h0 = half == 0 ? 0 : n, h1 = half == 0 ? n : nrows;
+        if (h1 <= h0) continue;
+        std::vector<int64_t> smin((size_t)(h1 - h0 + 1), INT64_MAX);      // smallest column of rows >= r of this half
+        for (int64_t r = h1 - 1; r >= h0; --r) {
+            smin[r - h0] = smin[r - h0 + 1];
+            if (rp[r] < rp[r + 1]) smin[r - h0] = std::min<int64_t>(smin[r - h0], ci[rp[r]]);
+        }
+        std::vector<int64_t> gstart;                      // group starts
+        gstart.push_back(h0);
+        int64_t pmax = -1;
+        for (int64_t r = h0; r < h1; ++r) {
+            if (r > gstart.back() && pmax >= 0 && smin[r - h0] != INT64_MAX && pmax < smin[r - h0]) { gstart.push_back(r); pmax = -1; }
+            if (rp[r] < rp[r + 1]) pmax = std::max<int64_t>(pmax, ci[rp[r + 1] - 1]);
+        }
+        gstart.push_back(h1);
+        int64_t cur0 = h0, cur = 0;                       // the open panel: rows [cur0, cur0 + cur)
+        auto close = [&]() { if (cur > 0) pranges.emplace_back(cur0, cur); cur0 += cur; cur = 0; };
+        for (size_t g = 0; g + 1 < gstart.size(); ++g) {
+            const int64_t len = gstart[g + 1] - gstart[g];
+            if (cur + len <= WIN_ROWS) { cur += len; continue; }
+            close();
+            if (len <= WIN_ROWS) { cur = len; continue; }
+            const int64_t np = (len + WIN_ROWS - 1) / WIN_ROWS, per = (len + np - 1) / np;
+            for (int64_t q = 0; q < len; q += per) { cur = std::min<int64_t>(per, len - q); close(); }
+        }
+        close();
+    }
+    const int64_t npanel = (int64_t)pranges.size();
     int64_t staged = 0;                                   // vector elements the tiles stage
     std::vector<int32_t> cnt(WIN_ROWS), order(WIN_ROWS), cursor(WIN_ROWS);
     struct SegRow { int32_t i, cnt; int64_t q0; };        // an active row of a segment: local row, entries inside the window, first of them
-    struct SegTmp { int32_t win; std::vector<SegRow> rows; };      // rows in descending entry count: slice j = rows 64 j ..
+    struct SegTmp { int64_t col0; int32_t ncols; std::vector<SegRow> rows; };      // rows in descending entry count: slice j = rows 64 j ..
     std::vector<SegTmp> segs;
     int64_t pos = 0;
     for (int64_t p = 0; p < npanel; ++p) {
-        const int64_t r0 = p * WIN_ROWS, R = std::min<int64_t>(WIN_ROWS, nrows - r0);
-        // ---- pass 1: the windows this panel touches, ascending (every row's entries are sorted by column), and per window the
-        //      active rows sorted by their entry count (SELL-sigma)
+        const int64_t r0 = pranges[p].first, R = pranges[p].second;
+        // ---- pass 1: the panel's windows -- the span of its columns cut into equal parts of at most WIN_COLS columns (multiples of 8) --,
+        //      ascending (every row's entries are sorted by column), and per window that holds entries the active rows sorted by
+        //      their entry count (SELL-sigma)
         segs.clear();
-        for (int64_t i = 0; i < R; ++i) cursor[i] = 0;
-        while (true) {
+        int64_t cmin = -1, cmax = -1;
+        for (int64_t i = 0; i < R; ++i) {
+            cursor[i] = 0;
+            if (rp[r0 + i] < rp[r0 + i + 1]) {
+                const int64_t a = ci[rp[r0 + i]], b = ci[rp[r0 + i + 1] - 1];
+                if (cmin < 0 || a < cmin) cmin = a;
+                if (b > cmax) cmax = b;
+            }
+        }
+        int64_t wwidth = WIN_COLS;
+        if (cmin >= 0) {
+            cmin -= cmin % 8;                              // (16-byte elements: 128-byte aligned window starts)
+            const int64_t span = cmax - cmin + 1, nwin = (span + WIN_COLS - 1) / WIN_COLS;
+            wwidth = std::min<int64_t>(WIN_COLS, ((span + nwin - 1) / nwin + 7) / 8 * 8);
+        }
+        while (cmin >= 0) {
             int64_t wmin = -1;                            // the smallest window with an unconsumed entry
             for (int64_t i = 0; i < R; ++i) {
                 const int64_t q = rp[r0 + i] + cursor[i];
-                if (q < rp[r0 + i + 1]) { const int64_t w = ci[q] / WIN_COLS; if (wmin < 0 || w < wmin) wmin = w; }
+                if (q < rp[r0 + i + 1]) { const int64_t w = (ci[q] - cmin) / wwidth; if (wmin < 0 || w < wmin) wmin = w; }
             }
             if (wmin < 0) break;
-            const int64_t c0 = wmin * WIN_COLS, c1 = std::min<int64_t>(c0 + WIN_COLS, nrows);
+            const int64_t c0 = cmin + wmin * wwidth, c1 = std::min<int64_t>(c0 + wwidth, nrows);
             int64_t nact = 0;
             for (int64_t i = 0; i < R; ++i) {
                 int32_t k = 0;
@@ -139,7 +191,7 @@ static bool build_window_panels(int64_t m, int64_t n, const int64_t* colptr, con
             std::stable_sort(order.begin(), order.begin() + nact, [&](int32_t a, int32_t b) { return cnt[a] > cnt[b]; });
             segs.emplace_back();
             SegTmp& sg = segs.back();
-            sg.win = (int32_t)wmin;
+            sg.col0 = c0; sg.ncols = (int32_t)(c1 - c0);
             sg.rows.resize((size_t)nact);
             for (int64_t l = 0; l < nact; ++l) { const int32_t i = order[l]; sg.rows[l] = SegRow{i, cnt[i], rp[r0 + i] + cursor[i]}; }
             for (int64_t i = 0; i < R; ++i) cursor[i] += cnt[i];
@@ -171,13 +223,13 @@ static bool build_window_panels(int64_t m, int64_t n, const int64_t* colptr, con
                         S.wrow[rbase + l] = (uint16_t)sr.i;
                         for (int32_t t = 0; t < sr.cnt; ++t) {
                             S.wval[(size_t)(pos + 64 * (int64_t)t + l)] = vv[sr.q0 + t];
-                            S.wcol[(size_t)(pos + 64 * (int64_t)t + l)] = (uint16_t)(ci[sr.q0 + t] - (int64_t)sg.win * WIN_COLS);
+                            S.wcol[(size_t)(pos + 64 * (int64_t)t + l)] = (uint16_t)(ci[sr.q0 + t] - sg.col0);
                         }
                     }
                     pos += 64 * (int64_t)T;
                     S.wnslice += 1;
                 }
-                S.wdesc.push_back(WinDesc{(uint32_t)sg.win, T4[0] | (T4[1] << 16), T4[2] | (T4[3] << 16), 0u});
+                S.wdesc.push_back(WinDesc{(uint32_t)sg.col0, T4[0] | (T4[1] << 16), T4[2] | (T4[3] << 16), (uint32_t)sg.ncols});
             }
         }
         S.wpanel.push_back(wp);
@@ -275,7 +327,6 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         //   C2 (dense LP, 79 groups x 157 column chunks):        196 / 203 / - / 193 / - / - / 212 (16: 159) -- a quarter of the sweep's
         //      slot traffic and of the update kernel's list entries goes away: K = 8.
         // So: stack only operators whose rows are cut into several column chunks (their slot arrays are large), eight high.
-        (void)tall_target;
         bool multi_chunk = false;
         for (const Group& g : groups) multi_chunk = multi_chunk || g.nchunk > 1;
         int kmax = multi_chunk ? 8 : 1;
@@ -303,12 +354,20 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
         if (const char* e = getenv("FOS_WINDOWS")) mode = atoi(e);
         int64_t runA = 0;
         for (int64_t i = 0; i < m; ++i) runA += (is_run[n + i] && alen[i] > 1) ? 1 : 0;
-        const bool candidate = !have_tiles && nnz >= 4 * nrows / 2 && runA < m / 10 && nrows >= 64 * (int64_t)WIN_ROWS;
-        if (mode == 1 || (mode != 0 && candidate)) {
+        const bool candidate = !have_tiles && nnz >= 4 * nrows / 2 && runA < m / 10 && nrows >= 64 * (int64_t)WinStd::ROWS;
+        if (mode == 1 || mode == 2 || (mode != 0 && candidate)) {
+            // geometry, from what a panel's walk was measured to take on C5 (in-kernel stamps, tools/win_stamps.py): a standard panel 84 us
+            // beside a second one on its CU and 63 us alone, a tall one (twice the rows, one per CU) 66 us -- times the rounds of workgroups
+            const int cus = tall_target > 0 ? tall_target / 16 : 256;
+            const int64_t np_std = (nrows + WIN_GEOM_STD.rows - 1) / WIN_GEOM_STD.rows, np_tall = (nrows + WIN_GEOM_TALL.rows - 1) / WIN_GEOM_TALL.rows;
+            const double cost_std = (double)((np_std + 2 * cus - 1) / (2 * cus)) * (np_std > cus ? 84.0 : 63.0);
+            const double cost_tall = (double)((np_tall + cus - 1) / cus) * 66.0;
+            bool tall = mode == 2 || (mode != 1 && cost_tall < cost_std);
+            if (const char* e = getenv("FOS_WIN_GEOM")) tall = atoi(e) == 2;
             *out = HostBlkCsr();
             out->nrows = nrows;
             out->nnz = 2 * nnz;
-            if (build_window_panels(m, n, colptr, rowval, nzval, mode == 1, out)) {
+            if (build_window_panels(m, n, colptr, rowval, nzval, mode == 1 || mode == 2, tall ? WIN_GEOM_TALL : WIN_GEOM_STD, out)) {
                 out->nblk = 0; out->nwg = (int32_t)std::min<size_t>(out->wpanel.size(), 16384); out->nwaves = 0;
                 out->wave_blk0.assign(1, 0);
                 return FOS_OK;
@@ -672,6 +731,9 @@ int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::st
         auto failw = [&](const char* msg, long long a) { if (why) *why = std::string(msg) + " " + std::to_string(a); return FOS_EINVAL; };
         std::vector<int> covered(S.nrows, 0);
         int64_t next_row = 0;
+        const int64_t WIN_ROWS = S.wgeom.rows, WIN_COLS = S.wgeom.cols;
+        const int WIN_WAVES = S.wgeom.waves, WIN_USL = (int)((WIN_ROWS + 64 * WIN_WAVES - 1) / (64 * WIN_WAVES));
+        if (WIN_WAVES < 1 || WIN_WAVES > 16 || WIN_USL > 4) return failw("bad geometry, wavefronts:", WIN_WAVES);
         if (S.wwave.size() != S.wpanel.size() * WIN_WAVES) return failw("wave table size", (long long)S.wwave.size());
         int64_t slices_seen = 0, values_seen = 0;
         for (size_t p = 0; p < S.wpanel.size(); ++p) {
@@ -680,18 +742,17 @@ int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::st
             if (wp.seg0 < 0 || wp.nseg < 0 || (size_t)wp.seg0 + (size_t)WIN_WAVES * wp.nseg > S.wdesc.size()) return failw("bad record range in panel", (long long)p);
             next_row += wp.nrows;
             std::vector<double> acc(wp.nrows, 0.0);
-            int64_t off[WIN_WAVES]; int64_t rs[WIN_WAVES];
+            int64_t off[16]; int64_t rs[16];
             for (int w = 0; w < WIN_WAVES; ++w) { off[w] = S.wwave[p * WIN_WAVES + w].off; rs[w] = S.wwave[p * WIN_WAVES + w].slice0; }
-            int64_t prev_win = -1;
+            int64_t prev_end = 0;
             for (int32_t k = 0; k < wp.nseg; ++k) {
-                const int64_t win = S.wdesc[(size_t)wp.seg0 + k].win;
-                const int64_t col0 = win * WIN_COLS, ncols = std::min<int64_t>(WIN_COLS, S.nrows - col0);
-                if (win <= prev_win || ncols < 1) return failw("bad window in panel", (long long)p);
-                prev_win = win;
+                const int64_t col0 = S.wdesc[(size_t)wp.seg0 + k].col0, ncols = S.wdesc[(size_t)wp.seg0 + k].ncols;
+                if (col0 < prev_end || col0 % 8 || ncols < 1 || ncols > WIN_COLS || col0 + ncols > S.nrows) return failw("bad window in panel", (long long)p);
+                prev_end = col0 + ncols;
                 std::vector<int> used(wp.nrows, 0);
                 for (int w = 0; w < WIN_WAVES; ++w) {
                     const WinDesc& d = S.wdesc[(size_t)wp.seg0 + (size_t)w * wp.nseg + k];
-                    if ((int64_t)d.win != win) return failw("wavefronts disagree on the window in panel", (long long)p);
+                    if ((int64_t)d.col0 != col0 || (int64_t)d.ncols != ncols) return failw("wavefronts disagree on the window in panel", (long long)p);
                     const uint32_t T4[4] = {d.t01 & 0xFFFFu, d.t01 >> 16, d.t23 & 0xFFFFu, d.t23 >> 16};
                     for (int u = 0; u < 4; ++u) {
                         const int64_t T = T4[u];

@@ -72,23 +72,39 @@ constexpr int TILE_TALL_MAX = 16;   // sub-tiles a tall tile may stack (5 bits i
 // the windows.  Inside a (panel, window) SEGMENT the rows that have entries there are sorted by their entry count (SELL-sigma)
 // and cut into SLICES of 64 rows stored lane-major (lane = row, step = entry; padded to the slice's longest row: ~10 %, not the
 // 40-50 % of panel-wide ELL), with 16-bit column offsets inside the window and a 16-bit local row id per lane.
-constexpr int WIN_COLS = 3072;      // window: 48 KB of double2 in LDS
-constexpr int WIN_ROWS = 2016;      // panel: 31.5 KB of row sums in LDS
-constexpr int WIN_NSL = 3;          // slices per wavefront and segment whose first WIN_PRE steps are requested with the window
-constexpr int WIN_WG_PER_CU = 2;    // two workgroups per CU (2 x 80 KB of LDS): each hides the other's memory latency
-constexpr int WIN_THREADS = 512;    // 8 wavefronts share the window
-constexpr int WIN_WAVES = WIN_THREADS / 64;
-constexpr int WIN_USL = (WIN_ROWS + 64 * WIN_WAVES - 1) / (64 * WIN_WAVES);      // slices one wavefront can get in a segment (4)
+// Two geometries (round 4), chosen per operator at fos_create (csr_build.cpp, window_geometry):
+//   WinStd   2016-row panels, windows of <= 3072 columns, 512 threads, TWO workgroups per CU (2 x 80 KB of LDS);
+//   WinTall  4032-row panels, windows of <= 6144 columns, 1024 threads, ONE workgroup per CU (160 KB): four times the entries per
+//            segment against the same fixed cost of a segment (its memory latency, two barriers) and half the window bytes per entry
+//            -- C5 sweep 96.6 -> 89.2 us -- for operators with enough rows to give (nearly) every CU a panel.
+struct WinStd {
+    static constexpr int COLS = 3072, ROWS = 2016, THREADS = 512, WG_PER_CU = 2, WAVES = THREADS / 64;
+    // steps of a wavefront's slice u (descending step counts) requested with the window, so that one memory latency covers the window
+    // and the matrix; the rest -- and, here, a fourth slice -- is streamed behind the barriers
+    static constexpr int PRE0 = 6, PRE1 = 6, PRE2 = 6, PRE3 = 0;
+};
+struct WinTall {
+    static constexpr int COLS = 6144, ROWS = 4032, THREADS = 1024, WG_PER_CU = 1, WAVES = THREADS / 64;
+    static constexpr int PRE0 = 8, PRE1 = 4, PRE2 = 2, PRE3 = 2;
+};
+static_assert((WinStd::ROWS + 64 * WinStd::WAVES - 1) / (64 * WinStd::WAVES) <= 4 && (WinTall::ROWS + 64 * WinTall::WAVES - 1) / (64 * WinTall::WAVES) <= 4,
+              "a WinDesc holds the step counts of four slices per wavefront");
+struct WinGeomRt { int32_t rows, cols, waves, wg_per_cu; };       // the same numbers for the host-side builder / emulation
+constexpr WinGeomRt WIN_GEOM_STD = {WinStd::ROWS, WinStd::COLS, WinStd::WAVES, WinStd::WG_PER_CU};
+constexpr WinGeomRt WIN_GEOM_TALL = {WinTall::ROWS, WinTall::COLS, WinTall::WAVES, WinTall::WG_PER_CU};
 // Storage = WAVE STREAMS (round 4).  Slice j of a segment (slices in descending step count) belongs to wavefront j % WIN_WAVES; everything
 // one wavefront reads of a panel -- its slices' values / column offsets / row words, segment after segment -- is CONTIGUOUS, so the
-// wavefront walks it with a running offset, and what it has to be told per segment (the window and the step counts of its <= WIN_USL
+// wavefront walks it with a running offset, and what it has to be told per segment (the window and the step counts of its <= 4
 // slices) is one 16-byte record, all records of a panel loaded in ONE request at the panel's start (lane k holds segment k's record,
 // read back by v_readlane): no dependent descriptor load sits in front of a segment's memory requests any more (the round-3 form paid
 // two scalar round trips -- segment, then slice descriptor -- before the slice loads of EVERY segment could be issued).
 struct WinPanel { int32_t row0, nrows, seg0, nseg; };      // seg0: first record of wavefront 0 in wdesc; wavefront w: seg0 + w * nseg
 struct WinWave { int64_t off; int32_t slice0, pad; };       // per (panel, wavefront): first value / column offset (multiple of 64), first row-word slice
-struct WinDesc { uint32_t win, t01, t23, pad; };            // per (panel, wavefront, segment): window number; steps of the wavefront's slices u = 0..3
-                                                            // (16 bits each, 0: no such slice; descending).  Values at off + 64 t + lane, then the next slice.
+struct WinDesc { uint32_t col0, t01, t23, ncols; };         // per (panel, wavefront, segment): the window [col0, col0 + ncols) of the stacked vector; steps of the
+                                                            // wavefront's slices u = 0..3 (16 bits each, 0: no such slice; descending).  Values at off + 64 t + lane,
+                                                            // then the next slice.  Windows are cut PER PANEL: the span of the panel's columns in equal parts of at most
+                                                            // COLS columns (C5: every panel of a block gets 21 -- tall: 11 -- equally filled segments; a global grid gave
+                                                            // some panels one more, nearly empty one, and the sweep lasts as long as its slowest panel).
 
 
 // One slot-spread row and its list of partial-sum slots, in summation order: [its own partial `own` (>= 0) from the sweep] followed
@@ -139,8 +155,9 @@ struct HostBlkCsr {
     bool row_sharded = false;          // every row of A' is deferred: the single slot `row`, or -- with dual tiles -- its local slot list (summed over the ranks before use)
     // window panels (empty unless the operator is stored that way; then blk is empty and val/col are unused)
     std::vector<WinPanel> wpanel;
-    std::vector<WinWave> wwave;        // [npanel * WIN_WAVES]
-    std::vector<WinDesc> wdesc;        // [sum over panels of WIN_WAVES * nseg]
+    WinGeomRt wgeom = WIN_GEOM_STD;    // geometry the panels were built for
+    std::vector<WinWave> wwave;        // [npanel * waves]
+    std::vector<WinDesc> wdesc;        // [sum over panels of waves * nseg]
     int64_t wnslice = 0;               // slices stored
     std::vector<double> wval;
     std::vector<uint16_t> wcol;        // column offset inside the window, per stored entry
@@ -176,6 +193,7 @@ struct DevBlkCsr {
                                        // sweep's records into its own nwg_def, stored behind them)
     // window panels (npanel == 0: row-block storage)
     int32_t npanel;
+    int32_t win_tall;                  // 1: WinTall geometry (else WinStd)
     int32_t win_temporal_pct;          // share (%) of a panel's segments whose matrix stream is read with ordinary loads (stays in the Infinity Cache)
     const WinPanel* wpanel;
     const WinWave* wwave;
@@ -187,7 +205,7 @@ struct DevBlkCsr {
 
 // Builds S = [[0, A'],[A, 0]] from Julia CSC (1-based).  Returns FOS_EINVAL on malformed input.
 int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
-                      int nwg_target, HostBlkCsr* out, int resident_waves = 0, int window_mode = -1,   // -1: decide from the operator, 0 / 1: force
+                      int nwg_target, HostBlkCsr* out, int resident_waves = 0, int window_mode = -1,   // -1: decide from the operator, 0: no window panels, 1 / 2: force WinStd / WinTall
                       bool row_sharded = false, int tall_target = 0);   // tall_target: tile blocks that fit one resident round (0: 4096)
 void partition_workgroups(HostBlkCsr* S, int nwg_target);
 int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::string* why);

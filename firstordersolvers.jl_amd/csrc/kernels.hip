@@ -531,28 +531,30 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
 }
 
 // ------------------------------------------------------------------------------------------------ window panels
-// Gather-bound operators (fos_internal.hpp, WinPanel): ONE WORKGROUP per panel of WIN_ROWS rows.  Per column window the panel
+// Gather-bound operators (fos_internal.hpp, WinPanel): ONE WORKGROUP per panel of GEO::ROWS rows.  Per column window the panel
 // touches: stage the window of the vector in LDS (coalesced 16-byte loads), then every wavefront takes whole 64-row slices --
 // lane = row, lane-major values and 16-bit window offsets streamed non-temporally, the vector element read from LDS -- and adds
 // its lanes' sums to the panel's row sums in LDS (a row appears once per window: no conflict, fixed order).  The row epilogue
 // runs once per row at the end, over consecutive rows (coalesced).
-constexpr size_t win_lds_bytes(int nrhs) { return (size_t)(WIN_COLS + WIN_ROWS) * 8 * nrhs + 64 * sizeof(double); }
+template <class GEO> constexpr size_t win_lds_bytes(int nrhs) { return (size_t)(GEO::COLS + GEO::ROWS) * 8 * nrhs + 64 * sizeof(double); }
 
 // In-kernel time stamps of the window walk (timing experiments; compiled in with -DFOS_WIN_STAMPS): workgroup FOS_WIN_STAMP_WG, every
 // wavefront, segment k, phase ph -> g_win_stamps[(wave * 64 + k) * 8 + ph], in ticks of the 100 MHz clock.
 #ifdef FOS_WIN_STAMPS
-__device__ long long g_win_stamps[8 * 64 * 8];
+__device__ long long g_win_stamps[16 * 64 * 8];
 #define WIN_STAMP(ph) do { if (stamp_on && k0 + k < 64) { __builtin_amdgcn_sched_barrier(0); g_win_stamps[((size_t)wv * 64 + k0 + k) * 8 + (ph)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define WIN_STAMP_G(ph) do { if (blockIdx.x == 100 && (threadIdx.x & 63) == 0) { __builtin_amdgcn_sched_barrier(0); g_win_stamps[((size_t)(threadIdx.x >> 6) * 64 + 63) * 8 + (ph)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define WIN_STAMP(ph) do { } while (0)
+#define WIN_STAMP_G(ph) do { } while (0)
 #endif
 
-// What a wavefront holds of its slices while the window is being staged: the first WIN_PRE steps of each lane's values and window
+// What a wavefront holds of one of its slices while the window is being staged: the first PRE steps of its lane's values and window
 // offsets, requested BEFORE the barriers of the segment so that one memory latency covers the window and the matrix.
-constexpr int WIN_PRE = 6;
+template <int PRE>
 struct WinSliceRegs {
-    double v[WIN_PRE];
-    unsigned c[WIN_PRE];
+    double v[PRE > 0 ? PRE : 1];
+    unsigned c[PRE > 0 ? PRE : 1];
     unsigned rid;          // local row of this lane, 0xFFFF: none
     int T;                 // steps of the slice, wave-uniform (0: no slice)
     int64_t off;
@@ -560,33 +562,33 @@ struct WinSliceRegs {
 // The value / offset loads depend only on the (wave-uniform) step count and running offset, NOT on the per-lane row word (a second dependent
 // memory round trip per segment costs more than the padding it would avoid reading: per-lane-count predication measured
 // 210-260 us per C5 sweep).  Steps beyond a lane's count hold value 0 / offset 0.
-template <bool MNT>
-__device__ __forceinline__ void win_slice_issue(const DevBlkCsr& S, int sl, int lane, WinSliceRegs& r) {
+template <bool MNT, int PRE>
+__device__ __forceinline__ void win_slice_issue(const DevBlkCsr& S, int sl, int lane, WinSliceRegs<PRE>& r) {
     r.rid = 0xFFFFu;
 #pragma unroll
-    for (int t = 0; t < WIN_PRE; ++t) { r.v[t] = 0.0; r.c[t] = 0u; }
+    for (int t = 0; t < PRE; ++t) { r.v[t] = 0.0; r.c[t] = 0u; }
     if (r.T > 0) {
         r.rid = S.wrow[(size_t)sl * 64 + lane];
         const double* __restrict__ val = S.wval + r.off + lane;
         const uint16_t* __restrict__ col = S.wcol + r.off + lane;
 #pragma unroll
-        for (int t = 0; t < WIN_PRE; ++t)
+        for (int t = 0; t < PRE; ++t)
             if (t < r.T) { r.v[t] = mload<MNT>(val + 64 * t); r.c[t] = mload<MNT>(col + 64 * t); }
     }
 }
-template <bool MNT, int NRHS, class E>
-__device__ __forceinline__ void win_slice_compute(const DevBlkCsr& S, const WinSliceRegs& r, const E* __restrict__ win, E* __restrict__ acc, int lane) {
+template <bool MNT, int NRHS, int PRE, class E>
+__device__ __forceinline__ void win_slice_compute(const DevBlkCsr& S, const WinSliceRegs<PRE>& r, const E* __restrict__ win, E* __restrict__ acc, int lane) {
     if (r.T <= 0) return;
     double a1 = 0.0, a2 = 0.0;
 #pragma unroll
-    for (int t = 0; t < WIN_PRE; ++t) {                    // (steps beyond T hold value 0, offset 0)
+    for (int t = 0; t < PRE; ++t) {                        // (steps beyond T hold value 0, offset 0)
         const E x = win[r.c[t]];
         if constexpr (NRHS == 2) { a1 += r.v[t] * x.x; a2 += r.v[t] * x.y; } else a1 += r.v[t] * x;
     }
-    if (r.T > WIN_PRE) {                                   // a row with many entries inside one window: the rest is streamed here
+    if (r.T > PRE) {                                       // more steps than the slot holds (a row with many entries inside one window; PRE == 0: a slice without a register slot): streamed here
         const double* __restrict__ val = S.wval + r.off + lane;
         const uint16_t* __restrict__ col = S.wcol + r.off + lane;
-        for (int t = WIN_PRE; t < r.T; ++t) {
+        for (int t = PRE; t < r.T; ++t) {
             const double v = mload<MNT>(val + 64 * t);
             const E x = win[mload<MNT>(col + 64 * t)];
             if constexpr (NRHS == 2) { a1 += v * x.x; a2 += v * x.y; } else a1 += v * x;
@@ -599,7 +601,7 @@ __device__ __forceinline__ void win_slice_compute(const DevBlkCsr& S, const WinS
 }
 
 // One segment = one (panel, window) tile.  EVERYTHING the segment needs from memory -- the window's vector elements and the
-// first WIN_PRE steps of WIN_NSL slices per wavefront -- is requested before the first barrier, and (round 4: wave streams,
+// first GEO::PRE0..3 steps of the slices of the wavefront -- is requested before the first barrier, and (round 4: wave streams,
 // fos_internal.hpp) NOTHING of it waits for a descriptor: the panel's records sit in a register (lane k = segment k, one request
 // per panel), the addresses are running offsets.  A segment costs one memory latency, two barriers and the LDS work.
 // In-kernel stamps (round 4, tools/win_stamps.py, C5: 21-23 segments per panel, 4.0 us each): ISSUING the segment's ~18 loads per
@@ -615,10 +617,10 @@ __device__ __forceinline__ void win_slice_compute(const DevBlkCsr& S, const WinS
 // row-sum element for padding lanes (a third fewer scalar instructions) 99-102: its LDS reads wait step by step; the same with
 // per-step tests only 119; the matrix stream by ordinary loads (to keep it in the Infinity Cache) 102.6 against 101.2 and 51.8
 // against 54.3 FISTA it/s; the second workgroup of every CU started 1-4 us late (out of phase) 101-103 against 99; the slice loads issued in front of the window loads 98-99 against 95-96.
-template <bool MNT, class G, class Epi>
+template <class GEO, bool MNT, class G, class Epi>
 __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& epi, double* lds) {
     constexpr int NRHS = G::NRHS;
-    constexpr int NWAVES = WIN_WAVES;
+    constexpr int NWAVES = GEO::WAVES, WIN_COLS = GEO::COLS, WIN_THREADS = GEO::THREADS;
     constexpr int WPT = (WIN_COLS + WIN_THREADS - 1) / WIN_THREADS;      // window elements per thread
     using E = typename std::conditional<NRHS == 2, d2, double>::type;
     E* win = reinterpret_cast<E*>(lds);
@@ -636,30 +638,35 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
         for (int i = tid; i < wp.nrows; i += WIN_THREADS) {
             if constexpr (NRHS == 2) acc[i] = make_double2(0.0, 0.0); else acc[i] = 0.0;
         }
+        WIN_STAMP_G(1);
         for (int k0 = 0; k0 < wp.nseg; k0 += 64) {         // (one chunk unless a panel touches more than 64 windows)
             const int nk = min(64, wp.nseg - k0);
             uint4 dv = make_uint4(0u, 0u, 0u, 0u);
             if (lane < nk) dv = *reinterpret_cast<const uint4*>(drec + k0 + lane);
             for (int k = 0; k < nk; ++k) {
                 WIN_STAMP(0);
-                const unsigned dwin = (unsigned)__builtin_amdgcn_readlane((int)dv.x, k);
+                const int col0 = __builtin_amdgcn_readlane((int)dv.x, k);
                 const unsigned t01 = (unsigned)__builtin_amdgcn_readlane((int)dv.y, k);
                 const unsigned t23 = (unsigned)__builtin_amdgcn_readlane((int)dv.z, k);
-                const int col0 = (int)dwin * WIN_COLS;
-                const int ncols = min(WIN_COLS, (int)S.nrows - col0);
-                const int T4[4] = {(int)(t01 & 0xFFFFu), (int)(t01 >> 16), (int)(t23 & 0xFFFFu), (int)(t23 >> 16)};
+                const int ncols = __builtin_amdgcn_readlane((int)dv.w, k);
                 // ---- everything this segment needs from memory is requested here, in one go
-                WinSliceRegs r[WIN_NSL];
-#pragma unroll
-                for (int u = 0; u < WIN_NSL; ++u) { r[u].T = T4[u]; r[u].off = off; off += 64 * (int64_t)T4[u]; }
+                WinSliceRegs<GEO::PRE0> r0; WinSliceRegs<GEO::PRE1> r1; WinSliceRegs<GEO::PRE2> r2; WinSliceRegs<GEO::PRE3> r3;
+                r0.T = (int)(t01 & 0xFFFFu); r1.T = (int)(t01 >> 16); r2.T = (int)(t23 & 0xFFFFu); r3.T = (int)(t23 >> 16);
+                r0.off = off; off += 64 * (int64_t)r0.T;
+                r1.off = off; off += 64 * (int64_t)r1.T;
+                r2.off = off; off += 64 * (int64_t)r2.T;
+                r3.off = off; off += 64 * (int64_t)r3.T;
                 d2 wreg[WPT];
 #pragma unroll
                 for (int q = 0; q < WPT; ++q) {
                     const int i = tid + q * WIN_THREADS;
                     wreg[q] = (i < ncols) ? gat.load(col0 + i) : make_double2(0.0, 0.0);
                 }
-#pragma unroll
-                for (int u = 0; u < WIN_NSL; ++u) win_slice_issue<MNT>(S, rs + u, lane, r[u]);
+                win_slice_issue<MNT>(S, rs, lane, r0);
+                win_slice_issue<MNT>(S, rs + 1, lane, r1);
+                win_slice_issue<MNT>(S, rs + 2, lane, r2);
+                win_slice_issue<MNT>(S, rs + 3, lane, r3);
+                rs += (r0.T > 0) + (r1.T > 0) + (r2.T > 0) + (r3.T > 0);
                 WIN_STAMP(1);
                 __syncthreads();                           // the previous window's readers are done (first pass: acc is zeroed)
                 WIN_STAMP(2);
@@ -671,28 +678,31 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
                 WIN_STAMP(3);
                 __syncthreads();
                 WIN_STAMP(4);
-#pragma unroll
-                for (int u = 0; u < WIN_NSL; ++u) { win_slice_compute<MNT, NRHS>(S, r[u], win, acc, lane); rs += T4[u] > 0; }
-#pragma unroll
-                for (int u = WIN_NSL; u < WIN_USL; ++u) {  // (more slices than the registers hold: more than 3/4 of the panel's rows active in one window)
-                    if (T4[u] > 0) {
-                        WinSliceRegs t;
-                        t.T = T4[u]; t.off = off; off += 64 * (int64_t)T4[u];
-                        win_slice_issue<MNT>(S, rs, lane, t);
-                        win_slice_compute<MNT, NRHS>(S, t, win, acc, lane);
-                        rs += 1;
-                    }
-                }
+                win_slice_compute<MNT, NRHS>(S, r0, win, acc, lane);
+                win_slice_compute<MNT, NRHS>(S, r1, win, acc, lane);
+                win_slice_compute<MNT, NRHS>(S, r2, win, acc, lane);
+                win_slice_compute<MNT, NRHS>(S, r3, win, acc, lane);
                 WIN_STAMP(5);
             }
         }
+        WIN_STAMP_G(2);
         __syncthreads();
-        for (int i = tid; i < wp.nrows; i += WIN_THREADS) {
-            const int row = wp.row0 + i;
-            const RowPre pr = epi.pre(row);
-            if constexpr (NRHS == 2) { const d2 a = acc[i]; epi.row(row, a.x, a.y, pr); }
-            else epi.row(row, acc[i], 0.0, pr);
+        WIN_STAMP_G(3);
+        // row epilogue, two rows of a thread at a time: what they need from memory is requested together (all four at once spills)
+        for (int i = tid; i < wp.nrows; i += 2 * WIN_THREADS) {
+            const int i2 = i + WIN_THREADS;
+            const bool h2 = i2 < wp.nrows;
+            const RowPre pa = epi.pre(wp.row0 + i);
+            RowPre pb = pa;
+            if (h2) pb = epi.pre(wp.row0 + i2);
+            if constexpr (NRHS == 2) { const d2 a = acc[i]; epi.row(wp.row0 + i, a.x, a.y, pa); }
+            else epi.row(wp.row0 + i, acc[i], 0.0, pa);
+            if (h2) {
+                if constexpr (NRHS == 2) { const d2 a = acc[i2]; epi.row(wp.row0 + i2, a.x, a.y, pb); }
+                else epi.row(wp.row0 + i2, acc[i2], 0.0, pb);
+            }
         }
+        WIN_STAMP_G(4);
         __syncthreads();                                   // before the next panel zeroes acc
     }
 }
@@ -826,8 +836,9 @@ __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBl
 }
 
 // window-panel form of the sweep (stand-alone applies and CG iterations alike: no dual tiles, the p update is a kernel of its own)
-template <bool MNT>
-__global__ __launch_bounds__(WIN_THREADS, 4) void kkt2_win_kernel(DevBlkCsr S, KktArgs a) {
+template <class GEO, bool MNT>
+__global__ __launch_bounds__(GEO::THREADS, 4) void kkt2_win_kernel(DevBlkCsr S, KktArgs a) {
+    WIN_STAMP_G(0);
     if (a.gate && a.close_j < 0 && a.st->done) return;
     extern __shared__ __attribute__((aligned(16))) double wlds[];
     GatherW gat;
@@ -837,13 +848,14 @@ __global__ __launch_bounds__(WIN_THREADS, 4) void kkt2_win_kernel(DevBlkCsr S, K
     epi.gat = gat; epi.out = a.out; epi.pnew = nullptr; epi.cb = a.cb; epi.n = a.n; epi.wt = gat.load_u(a.nm);
     epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
     if (a.vt_out && blockIdx.x == 0 && threadIdx.x == 0) { a.vt_out[0] = epi.wt.x; a.vt_out[1] = epi.wt.y; }
-    win_walk<MNT>(S, gat, epi, wlds);
-    block_reduce_store<3, WIN_THREADS>(epi.acc, wlds + (size_t)(WIN_COLS + WIN_ROWS) * 2, a.partials + 3 * (int64_t)blockIdx.x);
+    win_walk<GEO, MNT>(S, gat, epi, wlds);
+    block_reduce_store<3, GEO::THREADS>(epi.acc, wlds + (size_t)(GEO::COLS + GEO::ROWS) * 2, a.partials + 3 * (int64_t)blockIdx.x);
+    WIN_STAMP_G(5);
 }
 }  // namespace fos
 extern "C" int fos_debug_win_stamps(long long* out, int n) {      // (not part of the ABI: timing experiments, tools/win_stamps.py)
 #ifdef FOS_WIN_STAMPS
-    if (n > 8 * 64 * 8) n = 8 * 64 * 8;
+    if (n > 16 * 64 * 8) n = 16 * 64 * 8;
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fos::g_win_stamps), sizeof(long long) * (size_t)n);
 #else
     (void)out; (void)n; return -1;
@@ -857,14 +869,15 @@ static bool win_lds_optin(K kernel, size_t bytes) {
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(window kernel, %zu bytes of LDS): %s", bytes, hipGetErrorString(e)); return false; }
     return true;
 }
+template <class GEO, bool MNT>
+static void launch_kkt2_win_as(const LaunchCtx& c, const KktArgs& a) {
+    (void)win_lds_optin(kkt2_win_kernel<GEO, MNT>, win_lds_bytes<GEO>(2));       // cheap (a table update); a failure surfaces through check_launch
+    hipLaunchKernelGGL((kkt2_win_kernel<GEO, MNT>), dim3(c.S.nwg), dim3(GEO::THREADS), win_lds_bytes<GEO>(2), c.stream, c.S, a);
+}
 static void launch_kkt2_win(const LaunchCtx& c, const KktArgs& a) {
-    if (c.S.win_temporal_pct >= 50) {
-        (void)win_lds_optin(kkt2_win_kernel<false>, win_lds_bytes(2));       // cheap (a table update); a failure surfaces through check_launch
-        hipLaunchKernelGGL(kkt2_win_kernel<false>, dim3(c.S.nwg), dim3(WIN_THREADS), win_lds_bytes(2), c.stream, c.S, a);
-    } else {
-        (void)win_lds_optin(kkt2_win_kernel<true>, win_lds_bytes(2));
-        hipLaunchKernelGGL(kkt2_win_kernel<true>, dim3(c.S.nwg), dim3(WIN_THREADS), win_lds_bytes(2), c.stream, c.S, a);
-    }
+    const bool nt = c.S.win_temporal_pct < 50;
+    if (c.S.win_tall) { if (nt) launch_kkt2_win_as<WinTall, true>(c, a); else launch_kkt2_win_as<WinTall, false>(c, a); }
+    else { if (nt) launch_kkt2_win_as<WinStd, true>(c, a); else launch_kkt2_win_as<WinStd, false>(c, a); }
 }
 
 // Deferred rows (dual tiles): `lpr` lanes (a power of two <= 64, S.def_lpr) share a row: lane-strided partial sums of the
@@ -1392,24 +1405,30 @@ __global__ __launch_bounds__(DEF_THREADS) void q1_deferred_kernel(DevBlkCsr S, c
     fold_sweep_records<NACC>(S, partials, epi.acc);
     block_reduce_store<NACC, DEF_THREADS>(epi.acc, red, partials + NACC * (int64_t)(S.nwg + blockIdx.x));
 }
-template <class Epi, int NACC>
-__global__ __launch_bounds__(WIN_THREADS, 4) void q1_win_kernel(DevBlkCsr S, const double* __restrict__ vcomp, Epi epi, int nm,
+template <class GEO, class Epi, int NACC>
+__global__ __launch_bounds__(GEO::THREADS, 4) void q1_win_kernel(DevBlkCsr S, const double* __restrict__ vcomp, Epi epi, int nm,
                                                              double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) double wlds[];
 #pragma unroll
     for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
     epi.init(vcomp[2 * (int64_t)nm]);
     Gather1 gat{vcomp};
-    win_walk<true>(S, gat, epi, wlds);
-    block_reduce_store<NACC, WIN_THREADS>(epi.acc, wlds + (size_t)(WIN_COLS + WIN_ROWS), partials + NACC * (int64_t)blockIdx.x);
+    win_walk<GEO, true>(S, gat, epi, wlds);
+    block_reduce_store<NACC, GEO::THREADS>(epi.acc, wlds + (size_t)(GEO::COLS + GEO::ROWS), partials + NACC * (int64_t)blockIdx.x);
 }
 template <class Epi, int NACC>
 static void launch_q1_kernels(const LaunchCtx& c, const double* vcomp, const Epi& e, int nm) {
     dim3 grid(c.S.nwg), block(SPMV_THREADS);
     if (c.S.npanel > 0) {
-        const size_t lds = win_lds_bytes(1) + 16 * NACC * sizeof(double);
-        (void)win_lds_optin(q1_win_kernel<Epi, NACC>, lds);
-        hipLaunchKernelGGL((q1_win_kernel<Epi, NACC>), grid, dim3(WIN_THREADS), lds, c.stream, c.S, vcomp, e, nm, c.partials);
+        if (c.S.win_tall) {
+            const size_t lds = win_lds_bytes<WinTall>(1) + 16 * NACC * sizeof(double);
+            (void)win_lds_optin(q1_win_kernel<WinTall, Epi, NACC>, lds);
+            hipLaunchKernelGGL((q1_win_kernel<WinTall, Epi, NACC>), grid, dim3(WinTall::THREADS), lds, c.stream, c.S, vcomp, e, nm, c.partials);
+        } else {
+            const size_t lds = win_lds_bytes<WinStd>(1) + 16 * NACC * sizeof(double);
+            (void)win_lds_optin(q1_win_kernel<WinStd, Epi, NACC>, lds);
+            hipLaunchKernelGGL((q1_win_kernel<WinStd, Epi, NACC>), grid, dim3(WinStd::THREADS), lds, c.stream, c.S, vcomp, e, nm, c.partials);
+        }
         return;
     }
     if (c.S.ndef > 0) {

@@ -1131,12 +1131,13 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     if (windowed) {
         // window panels: persistent workgroups, one per CU (96 KB of LDS each), walking the panels (measured on C5: 116 us per
         // sweep with 256 workgroups, 122 us with one workgroup per panel)
-        int nwg = std::min<int>((int)hs.wpanel.size(), cus * WIN_WG_PER_CU);
+        int nwg = std::min<int>((int)hs.wpanel.size(), cus * hs.wgeom.wg_per_cu);
         if (const char* e = getenv("FOS_SPMV_WG")) nwg = std::max(1, std::min<int>(atoi(e), (int)hs.wpanel.size()));
         if (nwg >= 8) nwg -= nwg % 8;
         hs.nwg = nwg;
     }
     h->S.npanel = (int32_t)hs.wpanel.size();
+    h->S.win_tall = hs.wgeom.rows == WinTall::ROWS ? 1 : 0;
     h->S.win_temporal_pct = getenv("FOS_WIN_TEMPORAL") ? std::max(0, std::min(100, atoi(getenv("FOS_WIN_TEMPORAL")))) : 0;
     h->S.wpanel = nullptr; h->S.wwave = nullptr; h->S.wdesc = nullptr; h->S.wval = nullptr; h->S.wcol = nullptr; h->S.wrow = nullptr;
     if (h->S.npanel > 0) {
@@ -1148,7 +1149,7 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
         FOS_TRY(dev_upload(h, &dwc, hs.wcol));
         FOS_TRY(dev_upload(h, &dwr, hs.wrow));
         h->S.wpanel = dp; h->S.wwave = dsg; h->S.wdesc = dsl; h->S.wval = dwv2; h->S.wcol = dwc; h->S.wrow = dwr;
-        h->win_stats[0] = (int64_t)hs.wpanel.size(); h->win_stats[1] = (int64_t)hs.wdesc.size() / WIN_WAVES; h->win_stats[2] = hs.wnslice;
+        h->win_stats[0] = (int64_t)hs.wpanel.size(); h->win_stats[1] = (int64_t)hs.wdesc.size() / hs.wgeom.waves; h->win_stats[2] = hs.wnslice;
         h->win_stats[3] = (int64_t)hs.wval.size();
         std::vector<double>().swap(hs.wval);
         std::vector<uint16_t>().swap(hs.wcol);
@@ -2184,7 +2185,7 @@ int fos_host_stacked_spmv_mode(int64_t m, int64_t n, const int64_t* colptr, cons
     if (stats16) {
         for (int k = 0; k < 16; ++k) stats16[k] = 0;
         stats16[0] = S.nblk; stats16[5] = S.nnz_padded; stats16[6] = S.ncol_stored; stats16[8] = S.ntiles; stats16[9] = S.nslots;
-        stats16[12] = (int64_t)S.wpanel.size(); stats16[13] = (int64_t)S.wdesc.size() / WIN_WAVES; stats16[14] = S.wnslice; stats16[15] = (int64_t)S.wval.size();
+        stats16[12] = (int64_t)S.wpanel.size(); stats16[13] = (int64_t)S.wdesc.size() / S.wgeom.waves; stats16[14] = S.wnslice; stats16[15] = (int64_t)S.wval.size();
     }
     return FOS_OK;
 }

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-WIN_ROWS = 2016          # rows per window panel (csrc/fos_internal.hpp)
+WIN_ROWS = 2016          # rows per window panel (csrc/fos_internal.hpp, WinStd)
+WIN_ROWS_TALL = 4032     # ... of the tall geometry (WinTall)
 
 
 def host_spmv(pkg, A, v, wg=0, waves=0):
@@ -172,7 +173,8 @@ def _host_spmv_mode(pkg, A, v, mode):
 
 @pytest.mark.parametrize("shape,density,seed", [((300, 260), 0.05, 1), ((5000, 4100), 0.004, 2), ((9000, 200), 0.03, 3), ((70, 9000), 0.02, 4),
                                                  ((4097, 4096), 0.002, 5), ((1, 1), 1.0, 6), ((3000, 2500), 0.0, 7)])
-def test_window_panels_host_emulation(pkg, shape, density, seed):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_window_panels_host_emulation(pkg, shape, density, seed, mode):
     """Forced window-panel storage (fos_internal.hpp, WinPanel): the host walk of the panels / windows / slices -- the traversal
     the kernel performs -- reproduces S v = [A'vy; A vx]; rows without entries, empty operators, windows cut at the end of the
     vector, panels with fewer than 64 rows and rows longer than a window are all covered."""
@@ -185,10 +187,11 @@ def test_window_panels_host_emulation(pkg, shape, density, seed):
         A[:, 1] = rng.standard_normal((m, 1))
         A = A.tocsc()
     v = rng.standard_normal(n + m)
-    out, st = _host_spmv_mode(pkg, A, v, 1)
+    out, st = _host_spmv_mode(pkg, A, v, mode)                      # 1: standard geometry, 2: tall panels (one workgroup per CU)
     ref = np.concatenate([A.T @ v[n:], A @ v[:n]])
     assert np.allclose(out, ref, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(ref).max()))
-    assert st[12] == -(-(n + m) // WIN_ROWS) and st[0] == 0        # panels of WIN_ROWS rows, no row blocks
+    R = WIN_ROWS if mode == 1 else WIN_ROWS_TALL
+    assert st[12] == -(-n // R) + -(-m // R) and st[0] == 0        # panels of <= R rows (the rows of A' and of A apart), no row blocks
     assert st[15] >= 2 * A.nnz                                      # stored entries (padding included)
     out0, st0 = _host_spmv_mode(pkg, A, v, 0)                       # the same operator in row blocks / tiles
     assert np.allclose(out0, ref, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(ref).max())) and st0[12] == 0
@@ -204,8 +207,15 @@ def test_window_panels_chosen_for_large_random_sparse_only(pkg):
     out, st = _host_spmv_mode(pkg, A, v, -1)
     ref = np.concatenate([A.T @ v[n:], A @ v[:n]])
     assert np.allclose(out, ref, rtol=1e-12, atol=1e-11)
-    assert st[12] == -(-(n + m) // WIN_ROWS) and st[0] == 0
+    assert st[12] == 2 * -(-n // WIN_ROWS) and st[0] == 0           # (too few rows for the tall geometry to fill the CUs)
     assert st[15] <= 1.25 * 2 * A.nnz, (st[15], 2 * A.nnz)          # SELL-sigma slices: padding well under the 40-50 % of panel-wide ELL
+    m = n = 500000                                                  # 10^6 stacked rows: 249 tall panels fill the 256 CUs in one round
+    A = sp.block_diag([sp.random(62500, 62500, density=10.0 / 62500, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+                       for _ in range(8)], format="csc")            # (C5's structure: 8 blocks; a panel's windows span its block only)
+    v = rng.standard_normal(n + m)
+    out, st = _host_spmv_mode(pkg, A, v, -1)
+    assert np.allclose(out, np.concatenate([A.T @ v[n:], A @ v[:n]]), rtol=1e-12, atol=1e-11)
+    assert st[12] == 256 and st[0] == 0                             # 16 column ranges (8 blocks of A', 8 of A) x 16 equal panels: none straddles two blocks
     small = sp.random(3000, 2500, density=0.01, format="csc", random_state=rng, data_rvs=rng.standard_normal)
     assert _host_spmv_mode(pkg, small, rng.standard_normal(5500), -1)[1][12] == 0
     dense = sp.csc_matrix(rng.standard_normal((128, 96)))
