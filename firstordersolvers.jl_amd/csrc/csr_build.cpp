@@ -77,11 +77,32 @@ void partition_workgroups(HostBlkCsr* S, int nwg_target) {
     S->nwaves = nwaves;
 }
 
+// The slot lists in the form the kernels read: own partial first, then a progression of tile partials where it is one.
+static void build_def_records(HostBlkCsr& S) {
+    S.def_rec.resize(S.def_rows.size());
+    for (size_t q = 0; q < S.def_rows.size(); ++q) {
+        DefRow& d = S.def_rec[q];
+        d = DefRow{};
+        d.row = S.def_rows[q];
+        int32_t k0 = S.def_ptr[q];
+        const int32_t k1 = S.def_ptr[q + 1];
+        d.own = -1;
+        if (!S.row_defer.empty() && S.row_defer[d.row] >= 0 && k0 < k1 && S.def_idx[k0] == S.row_defer[d.row]) { d.own = S.def_idx[k0]; ++k0; }
+        d.count = k1 - k0;
+        d.kidx = k0;
+        d.base = d.count > 0 ? S.def_idx[k0] : 0;
+        d.stride = d.count > 1 ? S.def_idx[k0 + 1] - S.def_idx[k0] : 0;
+        for (int32_t k = k0 + 1; k < k1 && d.stride != DEF_EXPLICIT; ++k)
+            if (S.def_idx[k] - S.def_idx[k - 1] != d.stride) d.stride = DEF_EXPLICIT;
+        if (getenv("FOS_DEF_EXPLICIT")) d.stride = DEF_EXPLICIT;
+    }
+}
+
 // Window-panel storage of S (fos_internal.hpp, WinPanel).  Returns true when built; false = "not worth it" (the caller falls
 // back to row blocks): fewer entries inside the panel-window tiles than half the vector elements the tiles stage (the window
 // loads would then cost more than the gathers they replace), or too few panels to fill the GPU.
 static bool build_window_panels(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
-                                bool force, const WinGeomRt& G, HostBlkCsr* out) {
+                                bool force, const WinGeomRt& G, bool row_sharded, HostBlkCsr* out) {
     const int64_t WIN_ROWS = G.rows, WIN_COLS = G.cols;
     const int WIN_WAVES = G.waves, WIN_USL = (int)((WIN_ROWS + 64 * WIN_WAVES - 1) / (64 * WIN_WAVES));
     const int64_t nrows = n + m, nnz = colptr[n] - 1;
@@ -242,6 +263,21 @@ static bool build_window_panels(int64_t m, int64_t n, const int64_t* colptr, con
     }
     S.nnz_padded = pos;
     S.ncol_stored = pos;
+    if (row_sharded) {
+        // rows of A' are summed over the ranks: the sweep parks its share of row j in slot j (the all-reduce buffer is indexed by column),
+        // the deferred-row kernel finishes all n of them from the summed slots (a row without local entries keeps its zero)
+        S.row_sharded = true;
+        S.row_defer.assign((size_t)nrows, -1);
+        S.def_ptr.push_back(0);
+        for (int64_t j = 0; j < n; ++j) {
+            S.row_defer[j] = rp[j + 1] == rp[j] ? -2 : (int32_t)j;
+            S.def_rows.push_back((int32_t)j);
+            S.def_idx.push_back((int32_t)j);
+            S.def_ptr.push_back((int32_t)S.def_idx.size());
+        }
+        S.nslots = n;
+        build_def_records(S);
+    }
     // the kernel's prefetch reads a fixed number of steps per slice, present or not (masked afterwards): one slice of slack
     S.wval.resize((size_t)pos + 64 * 8, 0.0);
     S.wcol.resize((size_t)pos + 64 * 8, 0);
@@ -267,7 +303,6 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
     // slot list is added up first (slots_compact_kernel) and the n sums cross the ranks.  No window panels.
     const bool tiles_on = compress && getenv("FOS_NO_TILES") == nullptr &&
                           (!row_sharded || !(getenv("FOS_ROW_SHARDED_TILES") && atoi(getenv("FOS_ROW_SHARDED_TILES")) == 0));
-    if (row_sharded) window_mode = 0;
 
     // ---- rows of A: length, first column, and whether the columns are consecutive ("run": dense blocks, banded rows)
     std::vector<uint8_t> is_run(nrows, 1);
@@ -367,7 +402,7 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             *out = HostBlkCsr();
             out->nrows = nrows;
             out->nnz = 2 * nnz;
-            if (build_window_panels(m, n, colptr, rowval, nzval, mode == 1 || mode == 2, tall ? WIN_GEOM_TALL : WIN_GEOM_STD, out)) {
+            if (build_window_panels(m, n, colptr, rowval, nzval, mode == 1 || mode == 2, tall ? WIN_GEOM_TALL : WIN_GEOM_STD, row_sharded, out)) {
                 out->nblk = 0; out->nwg = (int32_t)std::min<size_t>(out->wpanel.size(), 16384); out->nwaves = 0;
                 out->wave_blk0.assign(1, 0);
                 return FOS_OK;
@@ -699,24 +734,7 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             S.def_ptr.push_back((int32_t)S.def_idx.size());
         }
     }
-    // ---- the lists in the form the kernels read: own partial first, then a progression of tile partials where it is one
-    S.def_rec.resize(S.def_rows.size());
-    for (size_t q = 0; q < S.def_rows.size(); ++q) {
-        DefRow& d = S.def_rec[q];
-        d = DefRow{};
-        d.row = S.def_rows[q];
-        int32_t k0 = S.def_ptr[q];
-        const int32_t k1 = S.def_ptr[q + 1];
-        d.own = -1;
-        if (!S.row_defer.empty() && S.row_defer[d.row] >= 0 && k0 < k1 && S.def_idx[k0] == S.row_defer[d.row]) { d.own = S.def_idx[k0]; ++k0; }
-        d.count = k1 - k0;
-        d.kidx = k0;
-        d.base = d.count > 0 ? S.def_idx[k0] : 0;
-        d.stride = d.count > 1 ? S.def_idx[k0 + 1] - S.def_idx[k0] : 0;
-        for (int32_t k = k0 + 1; k < k1 && d.stride != DEF_EXPLICIT; ++k)
-            if (S.def_idx[k] - S.def_idx[k - 1] != d.stride) d.stride = DEF_EXPLICIT;
-        if (getenv("FOS_DEF_EXPLICIT")) d.stride = DEF_EXPLICIT;
-    }
+    build_def_records(S);
     partition_workgroups(&S, nwg_target);
     return FOS_OK;
 }
@@ -736,6 +754,8 @@ int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::st
         if (WIN_WAVES < 1 || WIN_WAVES > 16 || WIN_USL > 4) return failw("bad geometry, wavefronts:", WIN_WAVES);
         if (S.wwave.size() != S.wpanel.size() * WIN_WAVES) return failw("wave table size", (long long)S.wwave.size());
         int64_t slices_seen = 0, values_seen = 0;
+        std::vector<double> wslots((size_t)std::max<int64_t>(S.nslots, 1), 0.0);
+        std::vector<int> wslot_written((size_t)std::max<int64_t>(S.nslots, 1), 0);
         for (size_t p = 0; p < S.wpanel.size(); ++p) {
             const WinPanel& wp = S.wpanel[p];
             if (wp.row0 != next_row || wp.nrows < 1 || wp.nrows > WIN_ROWS) return failw("bad panel", (long long)p);
@@ -782,7 +802,19 @@ int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::st
                 const int64_t end_rs = nx < S.wwave.size() ? S.wwave[nx].slice0 : S.wnslice;
                 if (off[w] != end_off || rs[w] != end_rs) return failw("stream of a wavefront does not end at the next one, panel", (long long)p);
             }
-            for (int32_t i = 0; i < wp.nrows; ++i) { out[wp.row0 + i] = acc[i]; covered[wp.row0 + i]++; }
+            for (int32_t i = 0; i < wp.nrows; ++i) {
+                const int64_t row = wp.row0 + i;
+                covered[row]++;
+                const int32_t ds = S.row_defer.empty() ? -1 : S.row_defer[row];
+                if (ds >= 0) { if (ds >= S.nslots || wslot_written[ds]++) return failw("slot written twice, row", row); wslots[ds] = acc[i]; }
+                else if (ds == -2) { if (acc[i] != 0.0) return failw("row marked as having no local entries has some:", row); }
+                else out[row] = acc[i];
+            }
+        }
+        for (size_t q = 0; q < S.def_rows.size(); ++q) {    // deferred rows: their slot lists, in list order (one rank: the sum over the ranks is the slot itself)
+            double a = 0.0;
+            for (int32_t k = S.def_ptr[q]; k < S.def_ptr[q + 1]; ++k) a += wslots[S.def_idx[k]];
+            out[S.def_rows[q]] = a;
         }
         if (slices_seen != S.wnslice || values_seen != S.nnz_padded) return failw("slices walked:", slices_seen);
         if (next_row != S.nrows) return failw("panels do not cover all rows:", next_row);

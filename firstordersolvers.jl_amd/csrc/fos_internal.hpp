@@ -194,7 +194,6 @@ struct DevBlkCsr {
     // window panels (npanel == 0: row-block storage)
     int32_t npanel;
     int32_t win_tall;                  // 1: WinTall geometry (else WinStd)
-    int32_t win_temporal_pct;          // share (%) of a panel's segments whose matrix stream is read with ordinary loads (stays in the Infinity Cache)
     const WinPanel* wpanel;
     const WinWave* wwave;
     const WinDesc* wdesc;

@@ -580,10 +580,18 @@ template <bool MNT, int NRHS, int PRE, class E>
 __device__ __forceinline__ void win_slice_compute(const DevBlkCsr& S, const WinSliceRegs<PRE>& r, const E* __restrict__ win, E* __restrict__ acc, int lane) {
     if (r.T <= 0) return;
     double a1 = 0.0, a2 = 0.0;
+    // (steps beyond T hold value 0, offset 0: the LDS reads of a group of steps go out together; a slot of four or more steps skips
+    //  the groups of two its slice does not reach -- wave-uniform)
+    constexpr int GRP = PRE >= 4 ? 2 : (PRE > 0 ? PRE : 1);
 #pragma unroll
-    for (int t = 0; t < PRE; ++t) {                        // (steps beyond T hold value 0, offset 0)
-        const E x = win[r.c[t]];
-        if constexpr (NRHS == 2) { a1 += r.v[t] * x.x; a2 += r.v[t] * x.y; } else a1 += r.v[t] * x;
+    for (int g = 0; g < PRE; g += GRP) {
+        if (g == 0 || g < r.T) {
+#pragma unroll
+            for (int t = g; t < g + GRP && t < PRE; ++t) {
+                const E x = win[r.c[t]];
+                if constexpr (NRHS == 2) { a1 += r.v[t] * x.x; a2 += r.v[t] * x.y; } else a1 += r.v[t] * x;
+            }
+        }
     }
     if (r.T > PRE) {                                       // more steps than the slot holds (a row with many entries inside one window; PRE == 0: a slice without a register slot): streamed here
         const double* __restrict__ val = S.wval + r.off + lane;
@@ -598,6 +606,14 @@ __device__ __forceinline__ void win_slice_compute(const DevBlkCsr& S, const WinS
         if constexpr (NRHS == 2) { const d2 o = acc[r.rid]; acc[r.rid] = make_double2(o.x + a1, o.y + a2); }
         else acc[r.rid] += a1;
     }
+}
+
+// A panel holds EVERY row of its range, also the rows of a row-sharded operator that have no local entries (row_defer -2: the
+// deferred-row kernel finishes them from the other ranks' shares): those are skipped here, the others go the way of finish_row.
+template <bool DEFER, class Epi>
+__device__ __forceinline__ void win_finish_row(const DevBlkCsr& S, Epi& epi, int row, double a1, double a2, const RowPre& pr) {
+    if constexpr (DEFER) { if (S.row_defer[row] == -2) return; }
+    finish_row<DEFER>(S, epi, row, a1, a2, pr);
 }
 
 // One segment = one (panel, window) tile.  EVERYTHING the segment needs from memory -- the window's vector elements and the
@@ -617,7 +633,7 @@ __device__ __forceinline__ void win_slice_compute(const DevBlkCsr& S, const WinS
 // row-sum element for padding lanes (a third fewer scalar instructions) 99-102: its LDS reads wait step by step; the same with
 // per-step tests only 119; the matrix stream by ordinary loads (to keep it in the Infinity Cache) 102.6 against 101.2 and 51.8
 // against 54.3 FISTA it/s; the second workgroup of every CU started 1-4 us late (out of phase) 101-103 against 99; the slice loads issued in front of the window loads 98-99 against 95-96.
-template <class GEO, bool MNT, class G, class Epi>
+template <class GEO, bool MNT, bool DEFER, class G, class Epi>
 __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& epi, double* lds) {
     constexpr int NRHS = G::NRHS;
     constexpr int NWAVES = GEO::WAVES, WIN_COLS = GEO::COLS, WIN_THREADS = GEO::THREADS;
@@ -695,11 +711,11 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
             const RowPre pa = epi.pre(wp.row0 + i);
             RowPre pb = pa;
             if (h2) pb = epi.pre(wp.row0 + i2);
-            if constexpr (NRHS == 2) { const d2 a = acc[i]; epi.row(wp.row0 + i, a.x, a.y, pa); }
-            else epi.row(wp.row0 + i, acc[i], 0.0, pa);
+            if constexpr (NRHS == 2) { const d2 a = acc[i]; win_finish_row<DEFER>(S, epi, wp.row0 + i, a.x, a.y, pa); }
+            else win_finish_row<DEFER>(S, epi, wp.row0 + i, acc[i], 0.0, pa);
             if (h2) {
-                if constexpr (NRHS == 2) { const d2 a = acc[i2]; epi.row(wp.row0 + i2, a.x, a.y, pb); }
-                else epi.row(wp.row0 + i2, acc[i2], 0.0, pb);
+                if constexpr (NRHS == 2) { const d2 a = acc[i2]; win_finish_row<DEFER>(S, epi, wp.row0 + i2, a.x, a.y, pb); }
+                else win_finish_row<DEFER>(S, epi, wp.row0 + i2, acc[i2], 0.0, pb);
             }
         }
         WIN_STAMP_G(4);
@@ -836,32 +852,31 @@ __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBl
 }
 
 // window-panel form of the sweep (stand-alone applies and CG iterations alike: no dual tiles, the p update is a kernel of its own)
-template <class GEO, bool MNT>
+template <class GEO, bool DEFER, bool FOLD>
 __global__ __launch_bounds__(GEO::THREADS, 4) void kkt2_win_kernel(DevBlkCsr S, KktArgs a) {
+    static_assert(!FOLD || DEFER, "FOLD is about deferred rows");
     WIN_STAMP_G(0);
     if (a.gate && a.close_j < 0 && a.st->done) return;
     extern __shared__ __attribute__((aligned(16))) double wlds[];
     GatherW gat;
     gat.w = a.w;
     if (a.close_j >= 0 && cgm_close_in_sweep(a.st, a.rr_partials, a.rr_count, a.w, (int64_t)a.nm + 1, a.close_j, a.seq_base >> 11, a.batch_mark)) return;
-    EpiKkt<GatherW, false> epi;
+    EpiKkt<GatherW, FOLD> epi;
     epi.gat = gat; epi.out = a.out; epi.pnew = nullptr; epi.cb = a.cb; epi.n = a.n; epi.wt = gat.load_u(a.nm);
     epi.acc[0] = epi.acc[1] = epi.acc[2] = 0.0;
     if (a.vt_out && blockIdx.x == 0 && threadIdx.x == 0) { a.vt_out[0] = epi.wt.x; a.vt_out[1] = epi.wt.y; }
-    win_walk<GEO, MNT>(S, gat, epi, wlds);
+    if constexpr (FOLD) {                                 // (as kkt2_kernel: the slot-free part of the slot-spread rows' share of the sums)
+        if (a.count_repl || S.ndef > a.n_repl) {
+            for (int q = blockIdx.x * GEO::THREADS + threadIdx.x; q < S.ndef; q += gridDim.x * GEO::THREADS) {
+                const int i = S.def_rows[q];
+                if (a.count_repl || i >= a.n_repl) epi.deferred_local(i);
+            }
+        }
+    }
+    win_walk<GEO, true, DEFER>(S, gat, epi, wlds);
     block_reduce_store<3, GEO::THREADS>(epi.acc, wlds + (size_t)(GEO::COLS + GEO::ROWS) * 2, a.partials + 3 * (int64_t)blockIdx.x);
     WIN_STAMP_G(5);
 }
-}  // namespace fos
-extern "C" int fos_debug_win_stamps(long long* out, int n) {      // (not part of the ABI: timing experiments, tools/win_stamps.py)
-#ifdef FOS_WIN_STAMPS
-    if (n > 16 * 64 * 8) n = 16 * 64 * 8;
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fos::g_win_stamps), sizeof(long long) * (size_t)n);
-#else
-    (void)out; (void)n; return -1;
-#endif
-}
-namespace fos {
 // dynamic LDS above 64 KB needs an opt-in per kernel and device
 template <class K>
 static bool win_lds_optin(K kernel, size_t bytes) {
@@ -869,15 +884,23 @@ static bool win_lds_optin(K kernel, size_t bytes) {
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(window kernel, %zu bytes of LDS): %s", bytes, hipGetErrorString(e)); return false; }
     return true;
 }
-template <class GEO, bool MNT>
+template <class GEO, bool DEFER, bool FOLD>
 static void launch_kkt2_win_as(const LaunchCtx& c, const KktArgs& a) {
-    (void)win_lds_optin(kkt2_win_kernel<GEO, MNT>, win_lds_bytes<GEO>(2));       // cheap (a table update); a failure surfaces through check_launch
-    hipLaunchKernelGGL((kkt2_win_kernel<GEO, MNT>), dim3(c.S.nwg), dim3(GEO::THREADS), win_lds_bytes<GEO>(2), c.stream, c.S, a);
+    (void)win_lds_optin(kkt2_win_kernel<GEO, DEFER, FOLD>, win_lds_bytes<GEO>(2));       // cheap (a table update); a failure surfaces through check_launch
+    hipLaunchKernelGGL((kkt2_win_kernel<GEO, DEFER, FOLD>), dim3(c.S.nwg), dim3(GEO::THREADS), win_lds_bytes<GEO>(2), c.stream, c.S, a);
 }
-static void launch_kkt2_win(const LaunchCtx& c, const KktArgs& a) {
-    const bool nt = c.S.win_temporal_pct < 50;
-    if (c.S.win_tall) { if (nt) launch_kkt2_win_as<WinTall, true>(c, a); else launch_kkt2_win_as<WinTall, false>(c, a); }
-    else { if (nt) launch_kkt2_win_as<WinStd, true>(c, a); else launch_kkt2_win_as<WinStd, false>(c, a); }
+// window-panel sweep; fold: the slot-spread rows' share of the sums is added by the sweep (row-sharded operators: the rows of A')
+static void launch_kkt2_win(const LaunchCtx& c, const KktArgs& a, bool fold) {
+    const bool defer = c.S.ndef > 0;
+    if (c.S.win_tall) {
+        if (!defer) launch_kkt2_win_as<WinTall, false, false>(c, a);
+        else if (fold) launch_kkt2_win_as<WinTall, true, true>(c, a);
+        else launch_kkt2_win_as<WinTall, true, false>(c, a);
+    } else {
+        if (!defer) launch_kkt2_win_as<WinStd, false, false>(c, a);
+        else if (fold) launch_kkt2_win_as<WinStd, true, true>(c, a);
+        else launch_kkt2_win_as<WinStd, true, false>(c, a);
+    }
 }
 
 // Deferred rows (dual tiles): `lpr` lanes (a power of two <= 64, S.def_lpr) share a row: lane-strided partial sums of the
@@ -1213,6 +1236,7 @@ static KktArgs plain_args(const LaunchCtx& c, const double2* w, double2* out, in
 // the plain (not fused-p) sweep in the form the operator wants: FOLD = slot-spread rows' share of the sums added by the sweep;
 // resident operators read their matrix stream with ordinary (cache-retaining) loads
 static void launch_plain_sweep(const LaunchCtx& c, const KktArgs& a, bool fold) {
+    if (c.S.npanel > 0) { launch_kkt2_win(c, a, fold); return; }
     dim3 grid(c.S.nwg), block(SPMV_THREADS);
     if (c.S.ndef > 0) {
         if (fold) {
@@ -1230,7 +1254,6 @@ static void launch_plain_sweep(const LaunchCtx& c, const KktArgs& a, bool fold) 
 // stand-alone apply: sweep (+ deferred-row kernel when the operator has dual tiles); leaves c.S.npart records at c.S.part_off
 void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
     const KktArgs a = plain_args(c, w, out, gate);
-    if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
     if (c.S.ndef > 0) {
         launch_plain_sweep(c, a, false);
         if (c.between) (void)c.between(c.between_arg);        // row-sharded: the slots are summed over the ranks here
@@ -1256,9 +1279,8 @@ void launch_kkt2_cg(const LaunchCtx& c, const CgIter& it, double2* Ap) {
         a.close_j = 0; a.seq_base = it.seq_base;
         a.rr_partials = c.partials + 3 * (size_t)PART_CAP; a.rr_count = c.cg_blocks;
     }
-    if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }       // (fuse_p is never set for window-panel operators)
+    if (!fused || c.S.npanel > 0) { launch_plain_sweep(c, a, true); return; }       // (fuse_p is never set for window-panel operators)
     dim3 grid(c.S.nwg), block(SPMV_THREADS);
-    if (!fused) { launch_plain_sweep(c, a, true); return; }
     if (c.S.ndef > 0) hipLaunchKernelGGL((kkt2_kernel<true, true, true>), grid, block, 0, c.stream, c.S, a);
     else hipLaunchKernelGGL((kkt2_kernel<false, true, false>), grid, block, 0, c.stream, c.S, a);
 }
@@ -1272,7 +1294,6 @@ void launch_cgm_sweep(const LaunchCtx& c, const CgmIter& it, int closes) {
         a.close_j = closes; a.batch_mark = it.batch_mark;
         a.rr_partials = c.partials + 3 * (size_t)PART_CAP + (size_t)(closes & 1) * CGM_RR_STRIDE; a.rr_count = c.cg_blocks;
     }
-    if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
     launch_plain_sweep(c, a, true);
 }
 // merged-reduction CG, start of a solve: it.w = M v, every row but tau, slot-spread rows left in their slots (the start kernel
@@ -1280,7 +1301,6 @@ void launch_cgm_sweep(const LaunchCtx& c, const CgmIter& it, int closes) {
 void launch_cgm_apply(const LaunchCtx& c, const CgmIter& it, const double2* v) {
     KktArgs a = plain_args(c, v, it.w, 0);
     a.vt_out = c.st->vtau;
-    if (c.S.npanel > 0) { launch_kkt2_win(c, a); return; }
     launch_plain_sweep(c, a, true);
 }
 void launch_cg_stop_check(const LaunchCtx& c, const CgIter& it) {
@@ -1405,7 +1425,7 @@ __global__ __launch_bounds__(DEF_THREADS) void q1_deferred_kernel(DevBlkCsr S, c
     fold_sweep_records<NACC>(S, partials, epi.acc);
     block_reduce_store<NACC, DEF_THREADS>(epi.acc, red, partials + NACC * (int64_t)(S.nwg + blockIdx.x));
 }
-template <class GEO, class Epi, int NACC>
+template <class GEO, class Epi, int NACC, bool DEFER>
 __global__ __launch_bounds__(GEO::THREADS, 4) void q1_win_kernel(DevBlkCsr S, const double* __restrict__ vcomp, Epi epi, int nm,
                                                              double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) double wlds[];
@@ -1413,21 +1433,25 @@ __global__ __launch_bounds__(GEO::THREADS, 4) void q1_win_kernel(DevBlkCsr S, co
     for (int a = 0; a < NACC; ++a) epi.acc[a] = 0.0;
     epi.init(vcomp[2 * (int64_t)nm]);
     Gather1 gat{vcomp};
-    win_walk<GEO, true>(S, gat, epi, wlds);
+    win_walk<GEO, true, DEFER>(S, gat, epi, wlds);
     block_reduce_store<NACC, GEO::THREADS>(epi.acc, wlds + (size_t)(GEO::COLS + GEO::ROWS), partials + NACC * (int64_t)blockIdx.x);
+}
+template <class GEO, class Epi, int NACC, bool DEFER>
+static void launch_q1_win_as(const LaunchCtx& c, const double* vcomp, const Epi& e, int nm) {
+    const size_t lds = win_lds_bytes<GEO>(1) + 16 * NACC * sizeof(double);
+    (void)win_lds_optin(q1_win_kernel<GEO, Epi, NACC, DEFER>, lds);
+    hipLaunchKernelGGL((q1_win_kernel<GEO, Epi, NACC, DEFER>), dim3(c.S.nwg), dim3(GEO::THREADS), lds, c.stream, c.S, vcomp, e, nm, c.partials);
 }
 template <class Epi, int NACC>
 static void launch_q1_kernels(const LaunchCtx& c, const double* vcomp, const Epi& e, int nm) {
     dim3 grid(c.S.nwg), block(SPMV_THREADS);
     if (c.S.npanel > 0) {
-        if (c.S.win_tall) {
-            const size_t lds = win_lds_bytes<WinTall>(1) + 16 * NACC * sizeof(double);
-            (void)win_lds_optin(q1_win_kernel<WinTall, Epi, NACC>, lds);
-            hipLaunchKernelGGL((q1_win_kernel<WinTall, Epi, NACC>), grid, dim3(WinTall::THREADS), lds, c.stream, c.S, vcomp, e, nm, c.partials);
+        if (c.S.ndef > 0) {
+            if (c.S.win_tall) launch_q1_win_as<WinTall, Epi, NACC, true>(c, vcomp, e, nm); else launch_q1_win_as<WinStd, Epi, NACC, true>(c, vcomp, e, nm);
+            if (c.between) (void)c.between(c.between_arg);
+            hipLaunchKernelGGL((q1_deferred_kernel<Epi, NACC>), dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, vcomp, e, nm, c.partials, (int)c.count_repl, (int)c.n_repl);
         } else {
-            const size_t lds = win_lds_bytes<WinStd>(1) + 16 * NACC * sizeof(double);
-            (void)win_lds_optin(q1_win_kernel<WinStd, Epi, NACC>, lds);
-            hipLaunchKernelGGL((q1_win_kernel<WinStd, Epi, NACC>), grid, dim3(WinStd::THREADS), lds, c.stream, c.S, vcomp, e, nm, c.partials);
+            if (c.S.win_tall) launch_q1_win_as<WinTall, Epi, NACC, false>(c, vcomp, e, nm); else launch_q1_win_as<WinStd, Epi, NACC, false>(c, vcomp, e, nm);
         }
         return;
     }

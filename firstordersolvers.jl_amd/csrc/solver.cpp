@@ -1138,7 +1138,6 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     }
     h->S.npanel = (int32_t)hs.wpanel.size();
     h->S.win_tall = hs.wgeom.rows == WinTall::ROWS ? 1 : 0;
-    h->S.win_temporal_pct = getenv("FOS_WIN_TEMPORAL") ? std::max(0, std::min(100, atoi(getenv("FOS_WIN_TEMPORAL")))) : 0;
     h->S.wpanel = nullptr; h->S.wwave = nullptr; h->S.wdesc = nullptr; h->S.wval = nullptr; h->S.wcol = nullptr; h->S.wrow = nullptr;
     if (h->S.npanel > 0) {
         WinPanel* dp; WinWave* dsg; WinDesc* dsl; double* dwv2; uint16_t *dwc, *dwr;

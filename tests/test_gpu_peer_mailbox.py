@@ -368,10 +368,14 @@ def _worker_rows(rank, world, port, algname, iters, q, transport="host", pname="
         if transport == "peer-rsag":                 # the n-vector as reduce-scatter + all-gather (the default from three ranks on)
             os.environ["FOS_VEC_RSAG"] = "1"
             transport = "peer"
+        if pname.endswith("-win"):                   # the rank's rows stored as window panels (the format of large random-sparse operators), forced
+            os.environ["FOS_WINDOWS"] = "1"
+            pname = pname[:-4]
         prob = _rows_problem(pkg, pname)
         sh = pkg.sharding.shard_rows(prob, world, rank)
         lp = sh.problem
         dev = pkg.HipHSDE(lp.A, lp.b, lp.c, lp.K1, lp.K2, row_sharded=True)
+        assert ("FOS_WINDOWS" in os.environ) == (dev.operator_stats()["win_panels"] > 0)
         calls = [0]
 
         def allreduce_sum(a):
@@ -416,7 +420,8 @@ def _worker_rows(rank, world, port, algname, iters, q, transport="host", pname="
 
 
 @pytest.mark.parametrize("algname,transport,pname", [("DR", "host", "mixed"), ("GAPA", "host", "mixed"), ("DR", "peer", "mixed"), ("GAPA", "peer", "mixed"),
-                                                     ("DR", "host", "dense"), ("GAPA", "peer", "dense"), ("GAPA", "peer-rsag", "mixed"), ("DR", "peer-rsag", "dense")])
+                                                     ("DR", "host", "dense"), ("GAPA", "peer", "dense"), ("GAPA", "peer-rsag", "mixed"), ("DR", "peer-rsag", "dense"),
+                                                     ("DR", "host", "mixed-win"), ("GAPA", "peer", "mixed-win")])
 def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname, transport, pname):
     """SURVEY 8(f2) with TWO ranks on the one GPU of the test box: each process holds the rows of half of the K1 cones of a
     problem whose A couples everything (workloads.small_mixed), the n-vector A'y and every scalar sum cross the processes
@@ -451,7 +456,7 @@ def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname, transport
         for p in procs:
             if p.is_alive():
                 p.kill()
-    prob = _rows_problem(pkg, pname)
+    prob = _rows_problem(pkg, pname[:-4] if pname.endswith("-win") else pname)
     shards = [pkg.sharding.shard_rows(prob, world, r) for r in range(world)]
     n = prob.n
     ls = [sh.problem.m + n + 1 for sh in shards]

@@ -282,3 +282,19 @@ def test_row_sharded_dense_operator_uses_tiles(pkg, monkeypatch):
     out, st = _host_spmv_mode(pkg, A, v, 0)
     assert np.allclose(out, reference(A, v), rtol=1e-12, atol=1e-12)
     assert st[8] > 0 and st[5] <= 1.1 * A.nnz                   # A stored once (plus padding), not twice
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("seed", range(4))
+def test_row_sharded_builder_with_window_panels(pkg, monkeypatch, seed, mode):
+    """SURVEY 8(f2), random-sparse rows: a row-sharded rank may store its rows as window panels (both geometries).  Every row of A'
+    is then a deferred row -- the panel's walk parks its share in slot j, rows without local entries are skipped -- and the host
+    emulation (same traversal, same lists) gives S v."""
+    monkeypatch.setenv("FOS_HOST_SPMV_ROW_SHARDED", "1")
+    rng = np.random.default_rng(3000 + seed)
+    m, n = int(rng.integers(50, 6000)), int(rng.integers(50, 5000))
+    A = sp.random(m, n, density=float(rng.choice([0.002, 0.01, 0.05])), format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    v = rng.standard_normal(n + m)
+    out, st = _host_spmv_mode(pkg, A, v, mode)
+    assert np.allclose(out, reference(A, v), rtol=1e-12, atol=1e-12), seed
+    assert st[12] > 0 and st[9] == n                               # window panels, one slot per row of A'
