@@ -108,6 +108,7 @@ PROTOTYPES = {
     "fos_feas_set_box": (C.c_int, [_h, C.c_int32, C.c_double, C.c_double]),
     "fos_feas_set_box_arrays": (C.c_int, [_h, C.c_int32, _dp, _dp]),
     "fos_feas_set_cones": (C.c_int, [_h, C.c_int32, C.c_int64, _i32p, _i64p]),
+    "fos_feas_set_callback": (C.c_int, [_h, C.c_int32, C.c_void_p, C.c_void_p]),
     "fos_feas_set_alg": (C.c_int, [_h, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]),
     "fos_feas_set_gapp": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, C.c_int64]),
     "fos_feas_gapp_log": (C.c_int, [_h, _dp]),

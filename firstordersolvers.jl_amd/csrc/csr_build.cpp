@@ -102,7 +102,7 @@ static void build_def_records(HostBlkCsr& S) {
 // back to row blocks): fewer entries inside the panel-window tiles than half the vector elements the tiles stage (the window
 // loads would then cost more than the gathers they replace), or too few panels to fill the GPU.
 static bool build_window_panels(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
-                                bool force, const WinGeomRt& G, bool row_sharded, HostBlkCsr* out) {
+                                bool force, const WinGeomRt& G, bool row_sharded, int cus, HostBlkCsr* out) {
     const int64_t WIN_ROWS = G.rows, WIN_COLS = G.cols;
     const int WIN_WAVES = G.waves, WIN_USL = (int)((WIN_ROWS + 64 * WIN_WAVES - 1) / (64 * WIN_WAVES));
     const int64_t nrows = n + m, nnz = colptr[n] - 1;
@@ -255,7 +255,16 @@ static bool build_window_panels(int64_t m, int64_t n, const int64_t* colptr, con
         }
         S.wpanel.push_back(wp);
     }
-    const bool worth = 2 * nnz >= staged / 2 && npanel >= 64;
+    // worth it?  (i) bytes: the windows the panels stage must not outweigh the gathers they replace; (ii) time, from what the walks were
+    // measured to take on MI355X (C5, in-kernel stamps): a sweep lasts as long as its longest panel -- segments x (3.0 us alone on a CU,
+    // 4.0 beside a second workgroup, 6.0 for a tall panel's four-times-larger segments) + ~8 us around the walk --, per round of
+    // workgroups; the row-block form it competes with ran C5's 2 x 10^7 stored entries in 155 us (gather-bound: time ~ entries).
+    int64_t maxseg = 0;
+    for (const WinPanel& wp : S.wpanel) maxseg = std::max<int64_t>(maxseg, wp.nseg);
+    const int64_t slots = (int64_t)std::max(1, cus) * G.wg_per_cu, rounds = (npanel + slots - 1) / slots;
+    const double tseg = G.wg_per_cu == 1 ? 6.0 : (npanel > cus ? 4.0 : 3.0);
+    const double t_win = (double)rounds * ((double)maxseg * tseg + 8.0), t_blocks = 2.0 * (double)nnz * (155.0 / 2.0e7);
+    const bool worth = 2 * nnz >= staged / 2 && npanel >= 64 && t_win < t_blocks;
     if (!worth && !force) {
         S.wpanel.clear(); S.wwave.clear(); S.wdesc.clear(); S.wnslice = 0; S.wval.clear(); S.wcol.clear(); S.wrow.clear();
         std::vector<double>().swap(S.wval);
@@ -402,7 +411,7 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             *out = HostBlkCsr();
             out->nrows = nrows;
             out->nnz = 2 * nnz;
-            if (build_window_panels(m, n, colptr, rowval, nzval, mode == 1 || mode == 2, tall ? WIN_GEOM_TALL : WIN_GEOM_STD, row_sharded, out)) {
+            if (build_window_panels(m, n, colptr, rowval, nzval, mode == 1 || mode == 2, tall ? WIN_GEOM_TALL : WIN_GEOM_STD, row_sharded, cus, out)) {
                 out->nblk = 0; out->nwg = (int32_t)std::min<size_t>(out->wpanel.size(), 16384); out->nwaves = 0;
                 out->wave_blk0.assign(1, 0);
                 return FOS_OK;

@@ -138,7 +138,10 @@ __global__ __launch_bounds__(FEAS_THREADS) void feas_pad_identity_kernel(int64_t
 }
 
 struct FeasSet {
-    int kind = 0;                   // 0 unset, 1 IndAffine, 2 IndBox
+    int kind = 0;                   // 0 unset, 1 IndAffine, 2 IndBox, 3 ConeProduct, 4 host callback
+    fos_prox_fn cb = nullptr;       // kind 4: prox!(y, S, x) evaluated by the caller on pinned host vectors
+    void* cb_ctx = nullptr;
+    double *cb_x = nullptr, *cb_y = nullptr;
     double* P = nullptr;            // [L x L] A'(A A')^-1 A, column-major
     double* q = nullptr;            // [L]     A'(A A')^-1 b
     double lo = 0.0, hi = 0.0;
@@ -232,6 +235,12 @@ int feas_prox(fos_feas* h, int which, double* y, const double* x) {
                                  s.psd_have_prev, nullptr, 0));
         if (s.npsd > 0 && s.psd_V[0]) { ms.psd_cur = 1 - ms.psd_cur; ms.psd_have_prev = 1; }      // warm start of the next projection
         FEAS_K(feas_from_parts_kernel, h->n, y, (const double2*)h->zout);
+    } else if (s.kind == 4) {                                             // any other ProximableFunction: the caller's prox! on host vectors
+        FOS_HIP(hipMemcpyAsync(s.cb_x, x, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+        FOS_HIP(hipStreamSynchronize(h->stream));
+        const int32_t rc = s.cb(s.cb_ctx, h->n, s.cb_x, s.cb_y);
+        if (rc != 0) { set_error("feasibility form: the prox callback of set %d returned %d", which + 1, (int)rc); return FOS_EINVAL; }
+        FOS_HIP(hipMemcpyAsync(y, s.cb_y, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
     } else { set_error("feasibility form: set %d has not been defined", which + 1); return FOS_EINVAL; }
     return FOS_OK;
 }
@@ -408,6 +417,7 @@ int fos_feas_destroy(fos_feas_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* q : h->owned) (void)hipFree(q);
+    for (FeasSet& s : h->S) { if (s.cb_x) (void)hipHostFree(s.cb_x); if (s.cb_y) (void)hipHostFree(s.cb_y); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return FOS_OK;
@@ -584,6 +594,24 @@ int fos_feas_set_cones(fos_feas_handle h, int32_t which, int64_t ncones, const i
     }
     FOS_HIP(hipStreamSynchronize(h->stream));
     s.kind = 3;
+    return FOS_OK;
+}
+
+int fos_feas_set_callback(fos_feas_handle h, int32_t which, fos_prox_fn fn, void* ctx) {
+    if (!h || (which != 1 && which != 2) || !fn) { set_error("fos_feas_set_callback: NULL handle / callback or which not in {1, 2}"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FeasSet& s = h->S[which - 1];
+    if (!s.cb_x) {
+        void *px = nullptr, *py = nullptr;
+        if (hipHostMalloc(&px, sizeof(double) * std::max<int64_t>(h->n, 1)) != hipSuccess || hipHostMalloc(&py, sizeof(double) * std::max<int64_t>(h->n, 1)) != hipSuccess) {
+            if (px) (void)hipHostFree(px);
+            set_error("fos_feas_set_callback: pinned host buffers of %lld doubles could not be allocated", (long long)h->n);
+            return FOS_ENOMEM;
+        }
+        s.cb_x = static_cast<double*>(px); s.cb_y = static_cast<double*>(py);
+    }
+    s.cb = fn; s.cb_ctx = ctx;
+    s.kind = 4;
     return FOS_OK;
 }
 

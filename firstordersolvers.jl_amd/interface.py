@@ -734,8 +734,12 @@ class ConeProduct:
                 raise ValueError("unknown cone %r (supportedcones: %s)" % (k, ", ".join(_lib.CONE_CODES)))
 
 
+PROX_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double))     # fos_prox_fn
+
+
 class Feasibility:
-    """struct Feasibility{T1,T2}(S1, S2, n)   Feasibility.jl:2-6"""
+    """struct Feasibility{T1,T2}(S1, S2, n)   Feasibility.jl:2-6.  S1, S2: IndAffine, IndBox, ConeProduct (device resident) or any
+    object with a `prox(y, x)` method filling y = prox_S(x) in place (the ProximableFunction protocol; evaluated on the host)."""
 
     def __init__(self, S1, S2, n):
         self.S1, self.S2, self.n = S1, S2, int(n)
@@ -757,6 +761,8 @@ class HipFeasibility:
         h = C.c_void_p()
         _lib.check(self._lib.fos_feas_create(self.n, device, C.byref(h)))
         self._h = h
+        self._callbacks = []
+        self.callback_error = None
         for which, S in ((1, problem.S1), (2, problem.S2)):
             if isinstance(S, IndAffine):
                 if S.A.shape[1] != self.n:
@@ -773,9 +779,37 @@ class HipFeasibility:
                 lens = np.ascontiguousarray([l for _, l in S.cones], dtype=np.int64)
                 _lib.check(self._lib.fos_feas_set_cones(self._h, which, len(S.cones), types.ctypes.data_as(C.POINTER(C.c_int32)),
                                                         lens.ctypes.data_as(C.POINTER(C.c_int64))))
+            elif callable(getattr(S, "prox", None)):                    # any other ProximableFunction: prox!(y, S, x) as a host callback
+                cb = PROX_FN(self._make_prox_callback(S))
+                self._callbacks.append(cb)                              # (the library keeps the pointer: it must outlive the handle)
+                _lib.check(self._lib.fos_feas_set_callback(self._h, which, C.cast(cb, C.c_void_p), None))
             else:
-                raise _lib.FosError(-4, "Feasibility on the device: set %d must be IndAffine, IndBox or ConeProduct (host callbacks are not "
-                                        "supported: there is no CPU path), got %s" % (which, type(S).__name__))
+                raise _lib.FosError(-4, "Feasibility: set %d must be IndAffine, IndBox, ConeProduct or an object with a prox(y, x) method "
+                                        "(evaluated on the host through fos_feas_set_callback), got %s" % (which, type(S).__name__))
+
+    def _make_prox_callback(self, S):
+        n = self.n
+
+        def call(ctx, nn, xp, yp):
+            try:
+                x = np.ctypeslib.as_array(xp, shape=(n,))
+                y = np.ctypeslib.as_array(yp, shape=(n,))
+                S.prox(y, x)                                            # prox!(y, S, x): fills y in place
+                return 0
+            except Exception as exc:  # noqa: BLE001  (an exception must not unwind through the C frames)
+                self.callback_error = exc
+                return 1
+        return call
+
+    def _check(self, rc):
+        """_lib.check, with the exception a prox callback raised (if that is what stopped the call) as the cause"""
+        try:
+            _lib.check(rc)
+        except _lib.FosError as err:
+            exc, self.callback_error = self.callback_error, None
+            if exc is not None:
+                raise err from exc
+            raise
 
     def close(self):
         if getattr(self, "_h", None):
@@ -819,13 +853,13 @@ class HipFeasibility:
     def step(self, i_first, count, checki, eps):
         """-> (iterations run, status name, err of the last check or nan, checked flag of the last iteration)"""
         done, st, err, chk = C.c_int64(0), C.c_int32(0), C.c_double(float("nan")), C.c_int32(0)
-        _lib.check(self._lib.fos_feas_step(self._h, i_first, count, checki, eps, C.byref(done), C.byref(st), C.byref(err), C.byref(chk)))
+        self._check(self._lib.fos_feas_step(self._h, i_first, count, checki, eps, C.byref(done), C.byref(st), C.byref(err), C.byref(chk)))
         return done.value, _lib.STATUS_NAMES[st.value], err.value, bool(chk.value)
 
     def getsol(self, force_check=False, eps=1e-5):
         sol = np.empty(self.n)
         st, err = C.c_int32(0), C.c_double(float("nan"))
-        _lib.check(self._lib.fos_feas_getsol(self._h, _lib.dptr(sol), 1 if force_check else 0, eps, C.byref(st), C.byref(err)))
+        self._check(self._lib.fos_feas_getsol(self._h, _lib.dptr(sol), 1 if force_check else 0, eps, C.byref(st), C.byref(err)))
         return sol, _lib.STATUS_NAMES[st.value], err.value
 
     def get_iterate(self):
@@ -836,7 +870,7 @@ class HipFeasibility:
     def prox(self, which, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.empty(self.n)
-        _lib.check(self._lib.fos_feas_prox(self._h, which, _lib.dptr(x), _lib.dptr(y)))
+        self._check(self._lib.fos_feas_prox(self._h, which, _lib.dptr(x), _lib.dptr(y)))
         return y
 
     def info(self):

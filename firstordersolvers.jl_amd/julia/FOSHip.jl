@@ -264,20 +264,33 @@ function getsol(alg::FOSAlgorithm, data::HipData, x)
 end
 
 # ---- Feasibility form [problemforms/Feasibility/Feasibility.jl, FeasibilityStatus.jl]: solve!(Feasibility(S1, S2, n), alg; gpu=true)
-#      with S1, S2 among ProximalOperators.IndAffine (dense A), IndBox (scalar bounds) -- the sets of test/testfeasibility.jl -- and
-#      FirstOrderSolvers.ConeProduct.
+#      with S1, S2 among ProximalOperators.IndAffine (dense A), IndBox -- the sets of test/testfeasibility.jl -- and
+#      FirstOrderSolvers.ConeProduct on the device; any other ProximableFunction through a host callback (fos_feas_set_callback).
 #      init_algorithm! returns a HipFeasData; iterate dispatches on it; FeasibilityModel, populate_solution and the printed table
 #      stay the reference's own code.
 import ..FirstOrderSolvers: FeasibilityModel, FeasibilityStatus
+
+# fos_prox_fn: int32 fn(void* ctx, int64 n, const double* x, double* y) -- ctx is the set (boxed in a Ref), y = prox_S(x)
+function prox_trampoline(ctx::Ptr{Cvoid}, n::Int64, x::Ptr{Cdouble}, y::Ptr{Cdouble})::Int32
+    try
+        S = unsafe_pointer_to_objref(ctx)[]
+        ProximalOperators.prox!(unsafe_wrap(Array, y, n), S, unsafe_wrap(Array, x, n))
+        return Int32(0)
+    catch
+        return Int32(1)                                     # (an exception must not unwind through the C frames)
+    end
+end
+const PROX_TRAMPOLINE = Ref{Ptr{Cvoid}}(C_NULL)             # @cfunction pointers are made at run time (__init__)
 
 mutable struct HipFeasData <: FOSSolverData
     handle::Ptr{Cvoid}
     lsinterval::Int64                     # > 0: LineSearchWrapper around the algorithm
     gappinterval::Int64                   # > 0: GAPP, its search interval
+    sets::Vector{Base.RefValue{Any}}      # callback sets, kept alive as long as the handle
     function HipFeasData(model::FeasibilityModel, device::Integer)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:fos_feas_create, libfoship), Cint, (Int64, Int32, Ref{Ptr{Cvoid}}), Int64(model.n), Int32(device), h))
-        d = new(h[], 0, 0)
+        d = new(h[], 0, 0, Base.RefValue{Any}[])
         finalizer(x -> ccall((:fos_feas_destroy, libfoship), Cint, (Ptr{Cvoid},), x.handle), d)
         for (which, S) in ((Int32(1), model.S1), (Int32(2), model.S2))
             if S isa ProximalOperators.IndBox && (S.lb isa AbstractArray || S.ub isa AbstractArray)
@@ -290,11 +303,15 @@ mutable struct HipFeasData <: FOSSolverData
                 types, _, lens = conearrays(S)
                 GC.@preserve types lens check(ccall((:fos_feas_set_cones, libfoship), Cint, (Ptr{Cvoid}, Int32, Int64, Ptr{Int32}, Ptr{Int64}),
                                                     d.handle, which, Int64(length(types)), types, lens))
-            else                                            # IndAffine(A, b), dense: the C ABI takes A row-major
-                At = Matrix{Float64}(transpose(S.A))        # column-major A' = row-major A
+            elseif S isa ProximalOperators.IndAffine && S.A isa AbstractMatrix && !(S.A isa SparseArrays.AbstractSparseMatrix)
+                At = Matrix{Float64}(transpose(S.A))        # IndAffine(A, b), dense: the C ABI takes A row-major = column-major A'
                 b = Vector{Float64}(S.b)
                 GC.@preserve At b check(ccall((:fos_feas_set_affine, libfoship), Cint, (Ptr{Cvoid}, Int32, Int64, Ptr{Cdouble}, Ptr{Cdouble}),
                                               d.handle, which, Int64(size(S.A, 1)), At, b))
+            else                                            # any other ProximableFunction: prox!(y, S, x) on host vectors [Feasibility.jl:2-6]
+                push!(d.sets, Ref{Any}(S))                  # (rooted: the library keeps a pointer to it)
+                check(ccall((:fos_feas_set_callback, libfoship), Cint, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
+                            d.handle, which, PROX_TRAMPOLINE[], pointer_from_objref(d.sets[end])))
             end
         end
         return d
@@ -407,6 +424,10 @@ function iterate(alg::FOSAlgorithm, data::HipFeasData, status::FeasibilityStatus
         println("$(time() - t1) s")
     end
     return guess
+end
+
+function __init__()
+    PROX_TRAMPOLINE[] = @cfunction(prox_trampoline, Int32, (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}))
 end
 
 end # module

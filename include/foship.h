@@ -326,8 +326,9 @@ int fos_debug_set(fos_handle h, int32_t what, int64_t value);
  * Feasibility form: `Feasibility(S1, S2, n)` -- find a point of S1 n S2 with the same algorithms.
  * Replaces, for device-resident sets, src/problemforms/Feasibility/Feasibility.jl:2-6,52-68 (problem, solve!, zeros(n) start,
  * populate_solution) and FeasibilityStatus.jl:32-72 (checkstatus: err = norm(prev - z) every checki-th iteration, :Optimal when
- * err <= eps; prev is refreshed at EVERY iteration and starts as NaN).  The reference accepts any two ProximalOperators objects
- * (host callbacks); the device path offers the two its own test uses (test/testfeasibility.jl:9-10):
+ * err <= eps; prev is refreshed at EVERY iteration and starts as NaN).  The reference accepts any two ProximalOperators objects;
+ * device-resident are the two its own test uses (test/testfeasibility.jl:9-10) and its cone stack, anything else is a host callback
+ * (fos_feas_set_callback):
  *   fos_feas_set_affine  IndAffine(A, b): A m x n ROW-major, full row rank, n <= 46 000; exact projection x - A'(A A')^-1 (A x - b)
  *                        through a one-time dense inverse formed on the device (Newton-Schulz on the fp64 MFMA GEMM);
  *   fos_feas_set_box     IndBox(lo, hi), scalar bounds (fos_feas_set_box_arrays: array bounds), +-INFINITY allowed;
@@ -342,6 +343,12 @@ int fos_feas_set_box_arrays(fos_feas_handle h, int32_t which, const double* lo, 
 /* ConeProduct (src/cones.jl:31-94): ncones cones of type[i] (FOS_CONE_*) and len[i] entries, in order, contiguous, covering all n entries;
  * projected by the batched cone kernels of the HSDE path (PSD cones warm-started from one projection to the next) */
 int fos_feas_set_cones(fos_feas_handle h, int32_t which, int64_t ncones, const int32_t* type, const int64_t* len);
+/* Any OTHER ProximableFunction (Feasibility.jl:2-6 takes any two; the reference's step calls prox!(y, S, x), gap.jl:47,56): evaluated by
+ * the CALLER on host vectors -- fn(ctx, n, x, y) fills y = prox_S(x), returns 0 (anything else aborts the step with FOS_EINVAL).  The
+ * iterate crosses the host link twice per projection (2 x 8n bytes through pinned buffers, one stream synchronisation); everything else
+ * of the iteration -- the other set, the relaxations, the status test -- stays on the device.  fn and ctx must outlive the handle. */
+typedef int32_t (*fos_prox_fn)(void* ctx, int64_t n, const double* x, double* y);
+int fos_feas_set_callback(fos_feas_handle h, int32_t which, fos_prox_fn fn, void* ctx);
 int fos_feas_set_alg(fos_feas_handle h, int32_t alg, double alpha, double alpha1, double alpha2, double beta);
 /* GAPP ("projected GAP", src/solvers/gapproj.jl:5-81; test/testfeasibility.jl:36): GAP whose every iproj-th iteration searches 21 step
  * lengths 2^k along P_S1(P_S2(P_S1 x)) - P_S1 x.  out23 = the 21 test norms, alpha_best, iteration of the last search. */

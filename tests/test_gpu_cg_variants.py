@@ -87,13 +87,15 @@ def test_merged_cg_matches_dense_solve_and_oracle(pkg, variant):
         d.close()
 
 
-@pytest.mark.parametrize("variant", ["reference"] + VARIANTS)
-def test_cg_variants_on_window_panel_storage(pkg, variant, monkeypatch):
-    """The same solves with the operator forced into window-panel storage (FOS_WINDOWS=1; the format of C5-class operators, whose
-    sweep kernel carries its own closing prologue and tau stash): every recurrence against the dense solution and its host twin."""
-    monkeypatch.setenv("FOS_WINDOWS", "1")
+@pytest.mark.parametrize("variant,geom", [(v, "1") for v in ["reference"] + VARIANTS] + [("reference", "2"), (VARIANTS[-1], "2")])
+def test_cg_variants_on_window_panel_storage(pkg, variant, geom, monkeypatch):
+    """The same solves with the operator forced into window-panel storage (FOS_WINDOWS=1: 2016-row panels, two workgroups per CU;
+    2: the tall geometry of C5, 4032-row panels, one 1024-thread workgroup per CU; the sweep kernel carries its own closing prologue
+    and tau stash): every recurrence against the dense solution and its host twin."""
+    monkeypatch.setenv("FOS_WINDOWS", geom)
     rng = np.random.default_rng(15)
-    A = sp.random(700, 900, density=0.02, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    shape = (700, 900) if geom == "1" else (5200, 4700)            # (tall: more than one panel per half, slices for every wavefront)
+    A = sp.random(*shape, density=0.02 if geom == "1" else 0.004, format="csc", random_state=rng, data_rvs=rng.standard_normal)
     m, n = A.shape
     b, c = rng.standard_normal(m), rng.standard_normal(n)
     d = pkg.HipHSDE(A, b, c, [("Free", m)], [("Free", n)])

@@ -248,3 +248,90 @@ def test_gapp_matches_oracle(pkg, oracle):
     assert sol.status == osol.status == "Optimal" and abs(sol.iterations - osol.iterations) <= 100
     assert sol.x.min() > -1e-9 and np.abs(A @ sol.x - b).max() < 1e-6
     assert sum(l.startswith("normtest: ") for l in out) == 21 * (sol.iterations // 100)
+
+
+class IndBallL2:
+    """A ProximableFunction the device has no kernel for (ProximalOperators.IndBallL2): projection onto the Euclidean ball of radius r
+    -- the protocol object of both the oracle and, through fos_feas_set_callback, the device path."""
+
+    def __init__(self, r, center):
+        self.r, self.c = float(r), np.array(center, dtype=np.float64)
+        self.calls = 0
+
+    def prox(self, y, x):
+        self.calls += 1
+        d = x - self.c
+        nd = float(np.linalg.norm(d))
+        y[:] = x if nd <= self.r else self.c + d * (self.r / nd)
+
+
+@pytest.mark.parametrize("algname", ["DR", "GAPA", "FISTA", "Dykstra"])
+def test_host_callback_set_matches_oracle(pkg, oracle, algname):
+    """Feasibility.jl:2-6 takes ANY two ProximableFunctions: a set without a device kernel is evaluated by the caller (fos_feas_set_callback:
+    the iterate crosses the host link per projection, the other set / relaxations / status stay on the device).  Same iterates as the
+    oracle running the same object; the callback is really called; whole solve reaches the oracle's status and point."""
+    orc = oracle
+    A, b = affine_box_instance(m=30, n=100)
+    n = A.shape[1]
+    x_ls = np.linalg.lstsq(A, b, rcond=None)[0]                 # a point of the affine set; the ball around a point 2 away from it, radius 2.2,
+    u = np.random.default_rng(9).standard_normal(n)             # meets the set without containing the start: the projection is active
+    center = x_ls + 2.0 * u / np.linalg.norm(u)
+    ball_d, ball_o = IndBallL2(2.2, center), IndBallL2(2.2, center)
+    hp = pkg.Feasibility(pkg.IndAffine(A, b), ball_d, n)
+    op = orc.Feasibility(orc.IndAffine(A, b), ball_o, n)
+    oalg = ALGS[algname](orc, verbose=0)
+    omodel = orc.FeasibilityModel(op, oalg)
+    ost = orc.FeasibilityStatus(omodel, 4, 1e-30, 0, 1)
+    d = pkg.HipFeasibility(hp)
+    d.set_alg(ALGS[algname](pkg))
+    d.set_iterate(None)
+    xo = np.zeros(n)
+    # (GAPA's step-length estimate is ill-conditioned against a curved set: a relative perturbation of 1e-15 after the first iteration
+    #  moves the ORACLE's own alpha12 of the second by 1e-3 -- its iterates are compared for two iterations, its solve for the result)
+    nsame = 2 if algname == "GAPA" else 30
+    for i in range(1, nsame + 1):
+        ost.i = i
+        oalg.step(xo, i, ost)
+        done, status, err, checked = d.step(i, 1, 4, 1e-30)
+        assert done == 1                                       # (Dykstra's iterate becomes exactly stationary here: err = 0 is Optimal even at eps = 1e-30)
+        assert np.abs(d.get_iterate() - xo).max() <= 1e-11 * max(1.0, np.abs(xo).max()), (algname, i)
+    assert ball_d.calls == ball_o.calls > 0
+    if algname in ("DR", "GAPA"):                              # the whole solve ends in the intersection
+        done, status, err, checked = d.step(nsame + 1, 3000, 10, 1e-9)
+        assert status == "Optimal", (status, err)
+        g, _, _ = d.getsol()
+        assert np.abs(A @ g - b).max() <= 1e-6 and np.linalg.norm(g - center) <= 2.2 * (1 + 1e-6)
+    x = np.random.default_rng(3).standard_normal(n) * 50
+    y = np.empty(n)
+    ball_o.prox(y, x)
+    assert np.array_equal(d.prox(2, x), y)                     # the callback's own arithmetic, untouched by the two copies
+
+
+def test_host_callback_on_both_sets_and_errors(pkg, oracle):
+    """Both sets as callbacks (the oracle's IndBox / IndAffine objects handed to the device path): bit-identical to the oracle for the
+    elementwise set; an exception inside a callback stops the step with FosError (cause = the exception) instead of unwinding through C."""
+    orc = oracle
+    A, b = affine_box_instance(m=20, n=60)
+    n = A.shape[1]
+    d = pkg.HipFeasibility(pkg.Feasibility(orc.IndAffine(A, b), orc.IndBox(0.0, np.inf), n))
+    dd = pkg.HipFeasibility(pkg.Feasibility(pkg.IndAffine(A, b), pkg.IndBox(0.0, np.inf), n))
+    x = np.random.default_rng(0).standard_normal(n)
+    assert np.array_equal(d.prox(2, x), dd.prox(2, x))
+    assert np.abs(d.prox(1, x) - dd.prox(1, x)).max() <= 1e-11
+    for h in (d, dd):
+        h.set_alg(pkg.DR())
+        h.set_iterate(None)
+        h.step(1, 50, 10, 1e-30)
+    assert np.abs(d.get_iterate() - dd.get_iterate()).max() <= 1e-10
+
+    class Broken:
+        def prox(self, y, x):
+            raise ZeroDivisionError("boom")
+    e = pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(0.0, 1.0), Broken(), n))
+    e.set_alg(pkg.DR())
+    e.set_iterate(None)
+    with pytest.raises(pkg.lib.FosError) as ei:
+        e.step(1, 1, 1, 1e-6)
+    assert isinstance(ei.value.__cause__, ZeroDivisionError) and "callback" in str(ei.value)
+    with pytest.raises(pkg.lib.FosError):
+        pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(0.0, 1.0), object(), n))

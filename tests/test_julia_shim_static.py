@@ -1,6 +1,6 @@
 """Static cross-check of the Julia `ccall` shim (firstordersolvers.jl_amd/julia/FOSHip.jl) against include/foship.h: there is no
 Julia in the build image, so the shim has never run -- this test at least keeps every ccall's symbol, return type, argument
-types and argument count in step with the header (which grew from 40 to 76 entries over the rounds), and the CheckResult
+types and argument count in step with the header (which grew from 40 to 77 entries over the rounds), and the CheckResult
 struct in step with fos_check_result."""
 import re
 from pathlib import Path
@@ -17,7 +17,7 @@ C2JL = {
     "int*": {"Ref{Cint}", "Ptr{Cint}"}, "int32_t*": {"Ref{Int32}", "Ptr{Int32}", "Ref{Cint}", "Ptr{Cint}"},
     "int64_t*": {"Ref{Int64}", "Ptr{Int64}"}, "double*": {"Ref{Cdouble}", "Ptr{Cdouble}", "Ptr{Float64}"},
     "void*": {"Ptr{Cvoid}"}, "char*": {"Ptr{UInt8}", "Cstring"},
-    "fos_check_result*": {"Ref{CheckResult}", "Ptr{CheckResult}"}, "fos_allreduce_fn": {"Ptr{Cvoid}"},
+    "fos_check_result*": {"Ref{CheckResult}", "Ptr{CheckResult}"}, "fos_allreduce_fn": {"Ptr{Cvoid}"}, "fos_prox_fn": {"Ptr{Cvoid}"},
 }
 
 

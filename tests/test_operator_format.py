@@ -198,24 +198,29 @@ def test_window_panels_host_emulation(pkg, shape, density, seed, mode):
 
 
 def test_window_panels_chosen_for_large_random_sparse_only(pkg):
-    """fos_create's choice (window_mode -1): a C5-like random-sparse operator with >= 64 panels goes to window panels with little
-    padding; a small one, a dense LP (dual tiles) and a banded (run-compressed) one keep their row-block formats."""
+    """fos_create's choice (window_mode -1): a C5-like random-sparse operator (10^6 stacked rows in 8 diagonal blocks) goes to window
+    panels -- the tall geometry, one panel per CU, none straddling two blocks, little padding; a random-sparse operator too small for
+    its panels' walks to beat the row-block form (by the builder's time model), a small one, a dense LP (dual tiles) and a banded
+    (run-compressed) one keep their row-block formats."""
     rng = np.random.default_rng(11)
-    m = n = 70000                                                   # 140 000 stacked rows = 70 panels
+    m = n = 70000                                                   # 140 000 stacked rows = 70 panels of ~23 windows each: row blocks are faster
     A = sp.random(m, n, density=20.0 / n, format="csc", random_state=rng, data_rvs=rng.standard_normal)
     v = rng.standard_normal(n + m)
     out, st = _host_spmv_mode(pkg, A, v, -1)
     ref = np.concatenate([A.T @ v[n:], A @ v[:n]])
     assert np.allclose(out, ref, rtol=1e-12, atol=1e-11)
-    assert st[12] == 2 * -(-n // WIN_ROWS) and st[0] == 0           # (too few rows for the tall geometry to fill the CUs)
-    assert st[15] <= 1.25 * 2 * A.nnz, (st[15], 2 * A.nnz)          # SELL-sigma slices: padding well under the 40-50 % of panel-wide ELL
-    m = n = 500000                                                  # 10^6 stacked rows: 249 tall panels fill the 256 CUs in one round
-    A = sp.block_diag([sp.random(62500, 62500, density=10.0 / 62500, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    assert st[12] == 0 and st[0] > 0
+    out, st = _host_spmv_mode(pkg, A, v, 1)                         # forced: SELL-sigma slices, padding well under the 40-50 % of panel-wide ELL
+    assert np.allclose(out, ref, rtol=1e-12, atol=1e-11)
+    assert st[12] == 2 * -(-n // WIN_ROWS) and st[15] <= 1.25 * 2 * A.nnz, (st[15], 2 * A.nnz)
+    m = n = 500000                                                  # 10^6 stacked rows: 256 tall panels fill the 256 CUs in one round
+    A = sp.block_diag([sp.random(62500, 62500, density=20.0 / 62500, format="csc", random_state=rng, data_rvs=rng.standard_normal)
                        for _ in range(8)], format="csc")            # (C5's structure: 8 blocks; a panel's windows span its block only)
     v = rng.standard_normal(n + m)
     out, st = _host_spmv_mode(pkg, A, v, -1)
     assert np.allclose(out, np.concatenate([A.T @ v[n:], A @ v[:n]]), rtol=1e-12, atol=1e-11)
     assert st[12] == 256 and st[0] == 0                             # 16 column ranges (8 blocks of A', 8 of A) x 16 equal panels: none straddles two blocks
+    assert st[15] <= 1.25 * 2 * A.nnz, (st[15], 2 * A.nnz)
     small = sp.random(3000, 2500, density=0.01, format="csc", random_state=rng, data_rvs=rng.standard_normal)
     assert _host_spmv_mode(pkg, small, rng.standard_normal(5500), -1)[1][12] == 0
     dense = sp.csc_matrix(rng.standard_normal((128, 96)))
