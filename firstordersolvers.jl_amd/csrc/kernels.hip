@@ -538,6 +538,14 @@ __device__ __forceinline__ void spmv_walk(const DevBlkCsr& S, const G& gat, Epi&
 // runs once per row at the end, over consecutive rows (coalesced).
 template <class GEO> constexpr size_t win_lds_bytes(int nrhs) { return (size_t)(GEO::COLS + GEO::ROWS) * 8 * nrhs + 64 * sizeof(double); }
 
+// Start / end stamps of every workgroup of the row-block sweep (timing experiments; -DFOS_KKT_STAMPS; tools/kkt_stamps.py)
+#ifdef FOS_KKT_STAMPS
+__device__ long long g_kkt_stamps[2 * 16384];
+#define KKT_STAMP(which) do { if (threadIdx.x == 0 && blockIdx.x < 16384) { __builtin_amdgcn_sched_barrier(0); g_kkt_stamps[2 * blockIdx.x + (which)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define KKT_STAMP(which) do { } while (0)
+#endif
+
 // In-kernel time stamps of the window walk (timing experiments; compiled in with -DFOS_WIN_STAMPS): workgroup FOS_WIN_STAMP_WG, every
 // wavefront, segment k, phase ph -> g_win_stamps[(wave * 64 + k) * 8 + ph], in ticks of the 100 MHz clock.
 #ifdef FOS_WIN_STAMPS
@@ -812,6 +820,7 @@ template <bool DEFER, bool FUSEP, bool FOLD, bool NT = true>
 __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBlkCsr S, KktArgs a) {
     static_assert(NT || !FUSEP, "the resident-operator form exists for the plain sweeps only");
     static_assert(!FOLD || DEFER, "FOLD is about deferred rows");
+    KKT_STAMP(0);
     WaveWork ww;                             // requested before the gate / the closing prologue: their round trip covers it
     if constexpr (!FUSEP) ww = wave_work(S);
     if ((FUSEP || a.gate) && a.close_j < 0 && a.st->done) return;        // (close_j > 0: cgm_close_in_sweep below tests `done` with its other loads)
@@ -849,6 +858,7 @@ __global__ __launch_bounds__(SPMV_THREADS, FUSEP ? 4 : 1) void kkt2_kernel(DevBl
     }
     spmv_walk<DEFER>(S, gat, epi, prod, ww);
     block_reduce_store<3, SPMV_THREADS>(epi.acc, red, a.partials + 3 * (int64_t)blockIdx.x);
+    KKT_STAMP(1);
 }
 
 // window-panel form of the sweep (stand-alone applies and CG iterations alike: no dual tiles, the p update is a kernel of its own)
@@ -877,6 +887,25 @@ __global__ __launch_bounds__(GEO::THREADS, 4) void kkt2_win_kernel(DevBlkCsr S, 
     block_reduce_store<3, GEO::THREADS>(epi.acc, wlds + (size_t)(GEO::COLS + GEO::ROWS) * 2, a.partials + 3 * (int64_t)blockIdx.x);
     WIN_STAMP_G(5);
 }
+}  // namespace fos
+// (not part of the ABI: timing experiments -- tools/win_stamps.py, tools/kkt_stamps.py; -1 unless compiled with the matching -DFOS_*_STAMPS)
+extern "C" int fos_debug_win_stamps(long long* out, int n) {
+#ifdef FOS_WIN_STAMPS
+    if (n > 16 * 64 * 8) n = 16 * 64 * 8;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fos::g_win_stamps), sizeof(long long) * (size_t)n);
+#else
+    (void)out; (void)n; return -1;
+#endif
+}
+extern "C" int fos_debug_kkt_stamps(long long* out, int n) {
+#ifdef FOS_KKT_STAMPS
+    if (n > 2 * 16384) n = 2 * 16384;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fos::g_kkt_stamps), sizeof(long long) * (size_t)n);
+#else
+    (void)out; (void)n; return -1;
+#endif
+}
+namespace fos {
 // dynamic LDS above 64 KB needs an opt-in per kernel and device
 template <class K>
 static bool win_lds_optin(K kernel, size_t bytes) {
