@@ -388,9 +388,13 @@ def main():
             agg = {"achieved_all_ranks": round(float(tt[0]), 1),
                    "frac_of_n_gpus_peak": round(float(tt[0]) / (HBM_PEAK_GBS * world), 4),
                    "note": "this rank's KKT sweep on its shard is what `achieved` prices; the sum over the ranks is the job's rate"}
+        kname = "kkt2_kernel"
+        if ost.get("win_panels", 0):                        # window panels; more than 2016 rows per panel = the tall geometry (fos_internal.hpp, WinTall)
+            tall = nmr / ost["win_panels"] > 2016
+            kname = "kkt2_win_kernel (window panels, %s)" % ("4032-row panels, one 1024-thread workgroup per CU" if tall else "2016-row panels, two 512-thread workgroups per CU")
         roof_kkt = {
             "bound": "hbm",
-            "kernel": "kkt2_kernel: fused dual-RHS KKT sweep of a CG iteration (4 reference SpMV sweeps + epilogue + 3 reductions)",
+            "kernel": kname + ": fused dual-RHS KKT sweep of a CG iteration (4 reference SpMV sweeps + epilogue + 3 reductions)",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
