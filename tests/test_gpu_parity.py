@@ -117,6 +117,40 @@ def test_kkt_apply(pkg, dev_ops):
         assert relerr(d.kkt_apply(x), y_ref) < 1e-13, name
 
 
+@pytest.mark.parametrize("geom", ["1", "2"])
+def test_operators_on_forced_window_panels(pkg, geom, monkeypatch):
+    """The same Q, Q', KKT and status products with the operator forced into window panels (FOS_WINDOWS = 1: 2016-row panels, 2: the tall
+    geometry): shapes with rows longer than a window's register slots, empty rows and columns, a dense row and column, panels with fewer
+    than 64 rows, a panel that touches MORE THAN 64 windows (the record chunks of the walk), a last window cut by the end of the vector."""
+    monkeypatch.setenv("FOS_WINDOWS", geom)
+    rng = np.random.default_rng(77)
+    wide = sp.random(150, 420000, density=2.5e-5, format="csc", random_state=rng, data_rvs=rng.standard_normal)   # its rows' panel spans > 64 windows of 6144
+    tall_ = sp.random(9000, 300, density=0.01, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    mid = sp.random(5000, 4100, density=0.004, format="csc", random_state=rng, data_rvs=rng.standard_normal).tolil()
+    mid[3, :] = rng.standard_normal(4100) * (rng.random(4100) < 0.5)                 # a row with ~2000 entries: far beyond the register slots
+    mid[:, 1] = rng.standard_normal((5000, 1))
+    for name, A in (("wide", wide), ("tall", tall_), ("mid", sp.csc_matrix(mid)), ("tiny", sp.random(3, 5, density=0.5, format="csc", random_state=rng))):
+        m, n = A.shape
+        b, c = rng.standard_normal(m), rng.standard_normal(n)
+        d = pkg.HipHSDE(A, b, c, [("Free", m)], [("Free", n)])
+        st = d.operator_stats()
+        assert st["win_panels"] > 0 and st["blocks"] == 0, name
+        if name == "wide":
+            assert st["win_segments"] > 64
+        Q = orc.HSDEMatrixQ(A, b, c)
+        x = rng.standard_normal(d.l)
+        y_ref = np.empty(d.l)
+        Q.mul(y_ref, x)
+        assert relerr(d.q_apply(x), y_ref) < 1e-13, name
+        Q.mul_t(y_ref, x)
+        assert relerr(d.q_apply(x, transpose=True), y_ref) < 1e-13, name
+        z = rng.standard_normal(d.N)
+        z_ref = np.empty(d.N)
+        orc.KKTMatrix(Q).mul(z_ref, z)
+        assert relerr(d.kkt_apply(z), z_ref) < 1e-13, name
+        d.close()
+
+
 def test_cg_kkt_matches_dense_solve_and_oracle_count(pkg, dev_ops):
     """conjugategradient! on the indefinite KKT system (conjugategradients.jl:31-55)."""
     rng = np.random.default_rng(5)
