@@ -9,6 +9,6 @@ fallback: every compute call goes through the library and fails loudly if it is 
 from . import _lib as lib          # noqa: F401
 from . import workloads            # noqa: F401
 from .interface import (AP, DR, FISTA, GAP, GAPA, GAPP, Dykstra, FOSAlgorithm, FOSMathProgModel, HipHSDE, HSDEStatus,  # noqa: F401
-                        LineSearchWrapper, Solution, solve, HEADER_CG, HEADER_DIRECT,
+                        LineSearchWrapper, LongstepWrapper, Solution, solve, HEADER_CG, HEADER_DIRECT,
                         ConeProduct, Feasibility, FeasibilityModel, FeasibilitySolution, HipFeasibility, IndAffine, IndBox, solve_feasibility)
 from . import sharding             # noqa: F401

@@ -55,6 +55,8 @@ PROTOTYPES = {
     "fos_comm_get_unique_id": (C.c_int, [C.c_void_p]),
     "fos_set_linesearch": (C.c_int, [_h, C.c_int64]),
     "fos_linesearch_log": (C.c_int, [_h, _dp]),
+    "fos_set_longstep": (C.c_int, [_h, C.c_int64, C.c_int64]),
+    "fos_longstep_log": (C.c_int, [_h, _dp]),
     "fos_comm_init": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
     "fos_comm_init_host": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "fos_peer_export": (C.c_int, [_h, C.c_void_p]),

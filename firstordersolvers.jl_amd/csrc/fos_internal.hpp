@@ -413,6 +413,10 @@ void launch_cg_init_finalize(const LaunchCtx& c, const double2* r, double tol, i
 void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate, int off = 0);   // partials[off.. +count][nacc] -> reduced[nacc] (+ peer exchange)
 
 // outer-loop vector kernels (gap.jl:48,58,78; gapa.jl:67,77,96-103; fista.jl:31-46; dykstra.jl)
+constexpr int LONG_KMAX_ROWS = 32;   // saved planes of a LongstepWrapper: 2 (nsave + 1) <= 32
+void launch_long_plane(const LaunchCtx& c, double2* row, const double2* x, const double2* y, double* bpart);          // row = x - y; bpart[blocks]: partial sums of (x - y).y
+void launch_long_dots(const LaunchCtx& c, const double2* P, int K, int a, const double2* x, double* out);              // out[blocks][33]: row_a . row_{a+k}, k < 32; [32]: row_a . x
+void launch_long_apply(const LaunchCtx& c, double2* x, const double2* P, int K, const double* nu);                     // x += sum_k nu[k] row_k
 void launch_normdiff(const LaunchCtx& c, const double2* x, const double2* y);   // c.partials[0 .. vec_blocks) = partial sums of |x - y|^2
 void launch_shift_part2(const LaunchCtx& c, double2* out, const double2* y, const double2* x);   // out = (y.x, y.y - x.y)
 void launch_axpby(const LaunchCtx& c, double2* out, double a, const double2* x, double b, const double2* y);          // out = a x + b y

@@ -195,6 +195,16 @@ struct fos_solver {
     bool gapp_now = false;
     double gapp_log[23] = {0};                 // 21 test norms, alpha_best, iteration
     double ls_log[34] = {0};                   // last search: ||res||, the 31 test residuals, the chosen alpha, the iteration
+    // LongstepWrapper (wrappers/longstep.jl, saveplanes.jl): the last nsave + 1 iterations of every long_interval save the two half-planes of
+    // their projections; the iterate is then projected onto the saved planes
+    int64_t long_interval = 0, long_nsave = 0;
+    int64_t long_savepos = 0;                  // LongstepWrapperData.savepos (0 at the start, -1 after a projection)
+    bool long_now = false;                     // the iteration in flight saves planes (between step_once and step_finish)
+    d2* long_P = nullptr;                      // [2 (nsave + 1)][l] saved rows x - y, in the reference's row order (equality, inequality, equality, ...)
+    double* long_bpart = nullptr;              // [rows][vec_blocks] partial sums of the offsets (x - y).y
+    double* long_dots = nullptr;               // [vec_blocks][33] scratch of the Gram products
+    double* long_nu = nullptr;                 // [rows] multipliers, device copy
+    double long_log[8] = {0};                  // last projection: iteration, active inequalities, KKT violation, |x_new - x|, rows, enumerated subsets
     int cg_same_run = 0;                       // consecutive solves that took exactly last_cg_pred iterations
     const d2* last_checked = nullptr;          // vector the last checkstatus was evaluated on
 
@@ -795,8 +805,177 @@ int gapp_finish(fos_solver* h) {
     return FOS_OK;
 }
 
-// one outer iteration; *check_on receives the vector checkstatus is evaluated on (the cone-feasible point)
+// ---- LongstepWrapper                                                 wrappers/longstep.jl:41-101, saveplanes.jl:13-35
 int step_finish_launch(fos_solver* h, const LaunchCtx& c);
+// addprojeq (which = 0) / addprojineq (which = 1): row i = (savepos - 1) (neq + nineq) + eqi (+ uneqi) + 1 with neq = nineq = 1     longstep.jl:69,88
+void long_save(fos_solver* h, const LaunchCtx& c, int which, const d2* y, const d2* x) {
+    const int64_t row = 2 * (h->long_savepos - 1) + which;
+    launch_long_plane(c, h->long_P + row * h->l, x, y, h->long_bpart + row * c.vec_blocks);
+}
+// a saving iteration: the step of the wrapped algorithm, unfused, with the two planes taken where the reference's step calls addprojeq /
+// addprojineq (gap.jl:47,57  gapa.jl:66,76  fista.jl:36,42  dykstra.jl:30,34)
+int long_begin(fos_solver* h, int64_t i, const d2** check_on) {
+    LaunchCtx c = h->ctx();
+    switch (h->alg) {
+        case FOS_ALG_GAP:
+        case FOS_ALG_GAPA:
+            FOS_TRY(prox_affine(h, h->X));                                       // prox!(y, S1, x)
+            long_save(h, c, 0, h->SOL, h->X);                                    // addprojeq(longstep, y, x)
+            ls_relax(h, c, h->T1, h->SOL, h->X, 1);                              // y .= a1 y + (1 - a1) x
+            FOS_TRY(prox_cones(h, h->T2, h->T1));                                // prox!(y, S2, x); checkstatus(status, y)
+            *check_on = h->T2;
+            return FOS_OK;
+        case FOS_ALG_FISTA:
+            if (i == 1) FOS_HIP(hipMemcpyAsync(h->Y, h->X, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));
+            FOS_TRY(prox_affine(h, h->Y));                                       // prox!(tmp1, S1, y)
+            long_save(h, c, 0, h->SOL, h->Y);                                    // addprojeq(longstep, tmp1, y)
+            launch_axpby(c, h->T1, h->alpha, h->SOL, 1 - h->alpha, h->Y);
+            launch_copy(c, h->XOLD, h->X);
+            FOS_TRY(prox_cones(h, h->X, h->T1));
+            *check_on = h->X;
+            return FOS_OK;
+        case FOS_ALG_DYKSTRA:
+            launch_add(c, h->W, h->X, h->Y);                                     // x .+ p
+            FOS_TRY(prox_affine(h, h->W));                                       // prox!(y, S1, x .+ p)
+            long_save(h, c, 0, h->SOL, h->W);                                    // addprojeq(longstep, y, x .+ p)
+            launch_dykstra_corr(c, h->Y, h->X, h->SOL);                          // p .= x .+ p .- y
+            launch_add(c, h->W, h->SOL, h->XOLD);                                // y .+ q
+            FOS_TRY(prox_cones(h, h->X, h->W));                                  // prox!(x, S2, y .+ q)
+            *check_on = h->X;
+            return FOS_OK;
+    }
+    return FOS_EINVAL;
+}
+// The projection of x onto {v : A v = b, C v >= d}, A = the first nsave + 1 saved rows, C = the others (saveplanes.jl:17-28 -- the rows are
+// saved equality, inequality, equality, ... and split here into halves: the reference's behaviour, kept).  The reference hands the n-variable
+// problem to QPDAS in BigFloat; the solution is v = x + P' nu with nu = (lambda, mu >= 0) the minimiser of the SMALL dual
+//     1/2 nu' G nu - nu' (beta - P x),  G = P P'  (K = 2 (nsave + 1) <= 32 unknowns),
+// solved on the host: the inequality multipliers by enumeration of their support (<= 2^16 candidate supports; each a K x K symmetric system
+// by eigen-decomposition, singular ones -- parallel planes -- through the pseudo-inverse); a support is accepted when its multipliers are
+// non-negative and the inequalities outside it hold.  Only G, P x and beta leave the device; x += P' nu runs there.
+static void sym_eig_jacobi(int n, std::vector<double>& A, std::vector<double>& V) {      // A (n x n, row-major) -> eigenvalues on its diagonal, eigenvectors in the columns of V
+    V.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; ++i) { diag += A[(size_t)i * n + i] * A[(size_t)i * n + i]; for (int j = i + 1; j < n; ++j) off += A[(size_t)i * n + j] * A[(size_t)i * n + j]; }
+        if (off <= 1e-60 + 1e-32 * diag) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[(size_t)p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[(size_t)q * n + q] - A[(size_t)p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+                    A[(size_t)k * n + p] = cs * akp - sn * akq; A[(size_t)k * n + q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+                    A[(size_t)p * n + k] = cs * apk - sn * aqk; A[(size_t)q * n + k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+                    V[(size_t)k * n + p] = cs * vkp - sn * vkq; V[(size_t)k * n + q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+}
+// nu_F = pinv(G_FF) c_F on the index set F, zero elsewhere
+static void long_solve_support(int K, const std::vector<double>& G, const std::vector<double>& cvec, const std::vector<int>& F, std::vector<double>& nu) {
+    const int nf = (int)F.size();
+    nu.assign((size_t)K, 0.0);
+    if (nf == 0) return;
+    std::vector<double> A((size_t)nf * nf), V;
+    double tr = 0.0;
+    for (int i = 0; i < nf; ++i) { for (int j = 0; j < nf; ++j) A[(size_t)i * nf + j] = G[(size_t)F[i] * K + F[j]]; tr += A[(size_t)i * nf + i]; }
+    sym_eig_jacobi(nf, A, V);
+    const double cut = 1e-13 * std::max(tr, 1e-300);
+    for (int e = 0; e < nf; ++e) {
+        const double lam = A[(size_t)e * nf + e];
+        if (!(lam > cut)) continue;
+        double proj = 0.0;
+        for (int i = 0; i < nf; ++i) proj += V[(size_t)i * nf + e] * cvec[(size_t)F[i]];
+        for (int i = 0; i < nf; ++i) nu[(size_t)F[i]] += V[(size_t)i * nf + e] * proj / lam;
+    }
+}
+int long_project(fos_solver* h, int64_t i) {
+    LaunchCtx c = h->ctx();
+    const int K = (int)(2 * (h->long_nsave + 1)), neq = (int)(h->long_nsave + 1), nin = K - neq;
+    const int nb = c.vec_blocks;
+    std::vector<double> G((size_t)K * K, 0.0), Px((size_t)K, 0.0), beta((size_t)K, 0.0);
+    std::vector<double> part((size_t)nb * (LONG_KMAX_ROWS + 1)), bp((size_t)K * nb);
+    for (int a = 0; a < K; ++a) {
+        launch_long_dots(c, h->long_P, K, a, h->X, h->long_dots);
+        FOS_HIP(hipMemcpyAsync(part.data(), h->long_dots, sizeof(double) * part.size(), hipMemcpyDeviceToHost, h->stream));
+        FOS_HIP(hipStreamSynchronize(h->stream));
+        for (int k = 0; a + k < K; ++k) {
+            double sacc = 0.0;
+            for (int b = 0; b < nb; ++b) sacc += part[(size_t)b * (LONG_KMAX_ROWS + 1) + k];
+            G[(size_t)a * K + a + k] = G[(size_t)(a + k) * K + a] = sacc;
+        }
+        double sx = 0.0;
+        for (int b = 0; b < nb; ++b) sx += part[(size_t)b * (LONG_KMAX_ROWS + 1) + LONG_KMAX_ROWS];
+        Px[(size_t)a] = sx;
+    }
+    FOS_HIP(hipMemcpyAsync(bp.data(), h->long_bpart, sizeof(double) * bp.size(), hipMemcpyDeviceToHost, h->stream));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    for (int a = 0; a < K; ++a) { double sacc = 0.0; for (int b = 0; b < nb; ++b) sacc += bp[(size_t)a * nb + b]; beta[(size_t)a] = sacc; }
+    std::vector<double> cvec((size_t)K);
+    for (int a = 0; a < K; ++a) cvec[(size_t)a] = beta[(size_t)a] - Px[(size_t)a];
+    double scale = 0.0;
+    for (int a = 0; a < K; ++a) scale = std::max(scale, std::fabs(cvec[(size_t)a]) + std::sqrt(G[(size_t)a * K + a]));
+    std::vector<double> nu, best_nu((size_t)K, 0.0);
+    double best_viol = INFINITY;
+    int best_active = 0;
+    int64_t tried = 0;
+    std::vector<int> F;
+    for (uint32_t mask = 0; mask < (1u << nin); ++mask) {
+        F.clear();
+        for (int a = 0; a < neq; ++a) F.push_back(a);
+        for (int j = 0; j < nin; ++j) if (mask & (1u << j)) F.push_back(neq + j);
+        long_solve_support(K, G, cvec, F, nu);
+        ++tried;
+        // violation: equality residuals, negative multipliers inside the support, violated inequalities outside it
+        double viol = 0.0;
+        for (int a = 0; a < K; ++a) {
+            double g = -cvec[(size_t)a];                                      // (G nu - c)_a = P_a v - beta_a
+            for (int b2 = 0; b2 < K; ++b2) g += G[(size_t)a * K + b2] * nu[(size_t)b2];
+            if (a < neq) viol = std::max(viol, std::fabs(g));
+            else if (mask & (1u << (a - neq))) viol = std::max(viol, std::max(std::fabs(g), -nu[(size_t)a] * std::sqrt(std::max(G[(size_t)a * K + a], 1e-300))));
+            else viol = std::max(viol, -g);
+        }
+        if (viol < best_viol) { best_viol = viol; best_nu = nu; best_active = __builtin_popcount(mask); }
+        if (best_viol <= 1e-12 * std::max(scale, 1e-300)) break;
+    }
+    double step2 = 0.0;                                                       // |P' nu|^2 = nu' G nu
+    for (int a = 0; a < K; ++a) for (int b2 = 0; b2 < K; ++b2) step2 += best_nu[(size_t)a] * G[(size_t)a * K + b2] * best_nu[(size_t)b2];
+    FOS_HIP(hipMemcpyAsync(h->long_nu, best_nu.data(), sizeof(double) * K, hipMemcpyHostToDevice, h->stream));
+    launch_long_apply(c, h->X, h->long_P, K, h->long_nu);                     // x .= longstep.tmp      longstep.jl:57
+    FOS_HIP(hipStreamSynchronize(h->stream));                                 // (best_nu leaves scope)
+    h->long_log[0] = (double)i; h->long_log[1] = (double)best_active; h->long_log[2] = best_viol; h->long_log[3] = std::sqrt(std::max(step2, 0.0));
+    h->long_log[4] = (double)K; h->long_log[5] = (double)tried;
+    h->shift_ready = false;                                                   // (the iterate changed behind the step's last kernel)
+    return FOS_OK;
+}
+int long_finish(fos_solver* h, int64_t i) {
+    LaunchCtx c = h->ctx();
+    switch (h->alg) {
+        case FOS_ALG_GAP:
+        case FOS_ALG_GAPA: long_save(h, c, 1, h->T2, h->T1); break;           // addprojineq(longstep, y, x)
+        case FOS_ALG_FISTA: long_save(h, c, 1, h->X, h->T1); break;           // addprojineq(longstep, x, tmp1)
+        case FOS_ALG_DYKSTRA: long_save(h, c, 1, h->X, h->W); break;          // addprojineq(longstep, x, y .+ q)
+    }
+    FOS_TRY(step_finish_launch(h, c));
+    if (h->long_savepos == h->long_nsave + 1) {                               // longstep.jl:53-58
+        FOS_TRY(long_project(h, i));
+        h->long_savepos = -1;
+    }
+    return FOS_OK;
+}
+
+// one outer iteration; *check_on receives the vector checkstatus is evaluated on (the cone-feasible point)
 
 // prox!(.., S1, in) followed by `post` -- everything of the step behind the CG solve (relaxation, cone projection and, when no
 // status check sits in between, the step's last pass).  `post` is handed to the solve, which enqueues it behind the first CG
@@ -824,6 +1003,13 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bo
     if (h->ls_now) return ls_begin(h, check_on);
     h->gapp_now = h->gapp_iproj > 0 && (i % h->gapp_iproj) == 0;                                     // gapproj.jl:34
     if (h->gapp_now) return gapp_begin(h, i, check_on);
+    h->long_now = false;
+    if (h->long_interval > 0) {                                                                      // longstep.jl:44-49
+        const int64_t savepos = (i - 1) % h->long_interval - h->long_interval + h->long_nsave + 2;
+        if (savepos > 0) h->long_savepos = savepos;
+        h->long_now = h->long_savepos > 0;
+        if (h->long_now) return long_begin(h, i, check_on);
+    }
     switch (h->alg) {
         case FOS_ALG_GAP:                                                // gap.jl:61-80
         case FOS_ALG_GAPA: {                                             // gapa.jl:80-105
@@ -836,7 +1022,7 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bo
                 static const bool fuse_psd = !(getenv("FOS_PSD_FUSE") && atoi(getenv("FOS_PSD_FUSE")) == 0);
                 // GAP / DR, no status check in this step, every non-elementwise cone a PSD(64) cone with a basis from the last projection:
                 // relaxation, projection and the step's last pass are ONE launch (PsdFuse, fos_internal.hpp)
-                if (fuse_psd && !gapa && !will_check && h->nsoc == 0 && h->nexp == 0 && !h->ls_interval && !h->gapp_iproj &&
+                if (fuse_psd && !gapa && !will_check && h->nsoc == 0 && h->nexp == 0 && !h->ls_interval && !h->gapp_iproj && !h->long_interval &&
                     psd_fuse_possible(cg, h->npsd, h->psd_kmin, h->psd_kmax, h->psd_V[h->psd_cur], h->psd_V[1 - h->psd_cur], h->psd_have_prev, h->psd_redo,
                                       h->psd_phase_limit)) {
                     RoctxRange range("fos:relaxation + PSD projection + final pass (one launch)");
@@ -907,6 +1093,7 @@ int step_finish(fos_solver* h, int64_t i) {
     LaunchCtx c = h->ctx();
     if (h->ls_now) { h->ls_now = false; return ls_finish(h, i); }
     if (h->gapp_now) { h->gapp_now = false; return gapp_finish(h); }
+    if (h->long_now) { h->long_now = false; return long_finish(h, i); }
     return step_finish_launch(h, c);
 }
 int step_finish_launch(fos_solver* h, const LaunchCtx& c) {
@@ -1600,6 +1787,7 @@ int fos_set_alg(fos_handle h, int alg, double alpha, double alpha1, double alpha
     h->alg = alg; h->alpha = alpha; h->alpha1 = alpha1; h->alpha2 = alpha2; h->beta = beta;
     h->ls_interval = 0; h->ls_now = false;                              // a fresh algorithm is unwrapped (fos_set_linesearch follows)
     h->gapp_iproj = 0; h->gapp_now = false;                             // ... and plain (fos_set_gapp follows)
+    h->long_interval = 0; h->long_savepos = 0; h->long_now = false;     // ... (fos_set_longstep follows)
     h->fista_t = 1.0;                                                   // fista.jl:24
     // fresh *Data: alpha12 = 2.0 (gapa.jl:29); y = xold = 0 (fista.jl:24); p = q = 0 (dykstra.jl:21)
     DevState z;
@@ -1792,6 +1980,7 @@ int fos_set_linesearch(fos_handle h, int64_t lsinterval) {
         set_error("LineSearchWrapper is built for single-GPU handles only (its step-length scores are global norms)");
         return FOS_EUNSUPPORTED;
     }
+    if (lsinterval > 0 && h->long_interval > 0) { set_error("LineSearchWrapper inside a LongstepWrapper is not supported"); return FOS_EUNSUPPORTED; }
     h->ls_interval = lsinterval;
     return FOS_OK;
 }
@@ -1808,6 +1997,31 @@ int fos_set_gapp(fos_handle h, int64_t iproj) {
 int fos_gapp_log(fos_handle h, double* out23) {
     if (!h || !out23) { set_error("NULL argument"); return FOS_EINVAL; }
     memcpy(out23, h->gapp_log, sizeof(h->gapp_log));
+    return FOS_OK;
+}
+// LongstepWrapper(alg; longinterval, nsave) around the algorithm set last (wrappers/longstep.jl:22-40): 0 switches it off
+int fos_set_longstep(fos_handle h, int64_t longinterval, int64_t nsave) {
+    if (!h || longinterval < 0 || nsave < 0) { set_error("bad argument"); return FOS_EINVAL; }
+    if (longinterval == 0) { h->long_interval = 0; h->long_savepos = 0; return FOS_OK; }
+    if (2 * (nsave + 1) > LONG_KMAX_ROWS) { set_error("LongstepWrapper: nsave <= %d (2 (nsave + 1) saved planes, small dual QP solved by enumeration)", LONG_KMAX_ROWS / 2 - 1); return FOS_EUNSUPPORTED; }
+    if (longinterval < nsave + 1) { set_error("LongstepWrapper: longinterval must be at least nsave + 1 (every plane is written before it is read)"); return FOS_EINVAL; }
+    if (h->sharded() || h->row_sharded) { set_error("LongstepWrapper is built for single-GPU handles only (the planes' products are global sums)"); return FOS_EUNSUPPORTED; }
+    if (h->ls_interval > 0 || h->gapp_iproj > 0) { set_error("LongstepWrapper around a LineSearchWrapper / GAPP is not supported"); return FOS_EUNSUPPORTED; }
+    FOS_HIP(hipSetDevice(h->device));
+    const int64_t K = 2 * (nsave + 1);
+    if (!h->long_P || h->long_nsave != nsave) {
+        FOS_TRY(dev_alloc(h, &h->long_P, (size_t)K * h->l));
+        FOS_TRY(dev_alloc(h, &h->long_bpart, (size_t)K * h->vec_blocks));
+        FOS_TRY(dev_alloc(h, &h->long_dots, (size_t)h->vec_blocks * (LONG_KMAX_ROWS + 1)));
+        FOS_TRY(dev_alloc(h, &h->long_nu, (size_t)K));
+    }
+    h->long_interval = longinterval; h->long_nsave = nsave; h->long_savepos = 0; h->long_now = false;
+    return FOS_OK;
+}
+// last projection of the LongstepWrapper: out8 = iteration, active inequalities, largest KKT violation of the small dual, |x_new - x|, rows, supports tried
+int fos_longstep_log(fos_handle h, double* out8) {
+    if (!h || !out8) { set_error("NULL argument"); return FOS_EINVAL; }
+    memcpy(out8, h->long_log, sizeof(h->long_log));
     return FOS_OK;
 }
 int fos_linesearch_log(fos_handle h, double* out34) {

@@ -886,6 +886,55 @@ __global__ __launch_bounds__(VEC_THREADS) void normdiff_kernel(int64_t l, const 
     }
     block_reduce_store<1>(acc, partials + blockIdx.x);
 }
+// ---- LongstepWrapper (wrappers/longstep.jl): the saved half-planes
+// addprojeq / addprojineq (longstep.jl:65-101): row = x - y, its offset b = (x - y).y as partial sums per workgroup
+__global__ __launch_bounds__(VEC_THREADS) void long_plane_kernel(int64_t l, d2* __restrict__ row, const d2* __restrict__ x, const d2* __restrict__ y,
+                                                                 double* __restrict__ bpart) {
+    double acc[1] = {0.0};
+    for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
+        const d2 a = x[i], b = y[i];
+        const d2 d = make_double2(a.x - b.x, a.y - b.y);
+        row[i] = d;
+        acc[0] += d.x * b.x + d.y * b.y;
+    }
+    block_reduce_store<1>(acc, bpart + blockIdx.x);
+}
+// partial sums of row_a . row_b for b = a .. K-1 and of row_a . x: out[blockIdx][K - a + 1] (what the small dual QP of the projection needs)
+constexpr int LONG_KMAX = 32;
+__global__ __launch_bounds__(VEC_THREADS) void long_dots_kernel(int64_t l, const d2* __restrict__ P, int K, int a, const d2* __restrict__ x,
+                                                                double* __restrict__ out) {
+    double acc[LONG_KMAX + 1];
+#pragma unroll
+    for (int k = 0; k <= LONG_KMAX; ++k) acc[k] = 0.0;
+    const d2* __restrict__ pa = P + (int64_t)a * l;
+    for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
+        const d2 va = pa[i];
+#pragma unroll
+        for (int k = 0; k < LONG_KMAX; ++k) {
+            if (a + k < K) { const d2 vb = P[(int64_t)(a + k) * l + i]; acc[k] += va.x * vb.x + va.y * vb.y; }
+        }
+        const d2 xi = x[i];
+        acc[LONG_KMAX] += va.x * xi.x + va.y * xi.y;
+    }
+    block_reduce_store<LONG_KMAX + 1>(acc, out + (int64_t)blockIdx.x * (LONG_KMAX + 1));
+}
+// x += sum_k nu[k] row_k  (the projection onto the saved planes, written back: longstep.jl:57)
+__global__ __launch_bounds__(VEC_THREADS) void long_apply_kernel(int64_t l, d2* __restrict__ x, const d2* __restrict__ P, int K, const double* __restrict__ nu) {
+    GRID_STRIDE(i, l) {
+        d2 v = x[i];
+        for (int k = 0; k < K; ++k) { const double w = nu[k]; const d2 r = P[(int64_t)k * l + i]; v.x += w * r.x; v.y += w * r.y; }
+        x[i] = v;
+    }
+}
+void launch_long_plane(const LaunchCtx& c, double2* row, const double2* x, const double2* y, double* bpart) {
+    hipLaunchKernelGGL(long_plane_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, row, x, y, bpart);
+}
+void launch_long_dots(const LaunchCtx& c, const double2* P, int K, int a, const double2* x, double* out) {
+    hipLaunchKernelGGL(long_dots_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, P, K, a, x, out);
+}
+void launch_long_apply(const LaunchCtx& c, double2* x, const double2* P, int K, const double* nu) {
+    hipLaunchKernelGGL(long_apply_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, P, K, nu);
+}
 void launch_normdiff(const LaunchCtx& c, const double2* x, const double2* y) {
     hipLaunchKernelGGL(normdiff_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, x, y, c.partials);
 }

@@ -149,6 +149,23 @@ class LineSearchWrapper(FOSAlgorithm):
         return self.alg._alg_args()
 
 
+class LongstepWrapper(FOSAlgorithm):
+    """LongstepWrapper(alg; longinterval=100, nsave=10, kwargs...)   wrappers/longstep.jl:5-24 -- around GAP (AP, DR), GAPA, FISTA or Dykstra
+    (support_longstep).  The last nsave + 1 iterations of every longinterval save the half-planes of their two projections (addprojeq /
+    addprojineq); the iterate is then projected onto the saved planes (projectonnormals!, saveplanes.jl:13-35).  All on the device
+    (fos_set_longstep): the planes never leave it, the projection's small dual QP is solved by the library."""
+
+    def __init__(self, alg, longinterval=100, nsave=10, **kwargs):
+        if not isinstance(alg, (GAP, GAPA, FISTA, Dykstra)) or isinstance(alg, GAPP):      # longstep.jl:28 (an @error in the reference)
+            raise ValueError("Algorithm %s does not support longstep" % type(alg).__name__)
+        self.alg, self.longinterval, self.nsave = alg, int(longinterval), int(nsave)
+        self.options = {**kwargs, **alg.options}            # [kwargs..., alg.options...]: the wrapped algorithm's options win  longstep.jl:23
+        self.direct = alg.direct
+
+    def _alg_args(self):
+        return self.alg._alg_args()
+
+
 def _normalize_cones(cones, total, what):
     """(name, length) or (name, 1-based index range/list) tuples -> (types int32, starts int64 1-based, lens int64).
     Index lists must be contiguous: toRanges, src/cones.jl:44-56."""
@@ -218,6 +235,18 @@ class HipHSDE:
             self.set_linesearch(alg.lsinterval)
         if isinstance(alg, GAPP):
             _lib.check(self._lib.fos_set_gapp(self._h, alg.iproj))
+        if isinstance(alg, LongstepWrapper):
+            self.set_longstep(alg.longinterval, alg.nsave)
+
+    def set_longstep(self, longinterval, nsave):
+        """LongstepWrapper around the current algorithm (longinterval 0: off); fos_set_longstep."""
+        _lib.check(self._lib.fos_set_longstep(self._h, int(longinterval), int(nsave)))
+
+    def longstep_log(self):
+        """last projection onto the saved planes: dict(iteration, active inequalities, KKT violation of the small dual, step length, rows, supports tried)"""
+        out = np.zeros(8)
+        _lib.check(self._lib.fos_longstep_log(self._h, _lib.dptr(out)))
+        return dict(iteration=int(out[0]), active=int(out[1]), violation=float(out[2]), step=float(out[3]), rows=int(out[4]), tried=int(out[5]))
 
     def gapp_log(self):
         """(iteration, [21 test norms], alpha_best) of GAPP's last search."""

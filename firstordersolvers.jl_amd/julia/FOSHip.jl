@@ -143,6 +143,21 @@ function init_algorithm!(ls::LineSearchWrapper, model::FOSMathProgModel)
     return invoke(init_algorithm!, Tuple{LineSearchWrapper,FirstOrderSolvers.AbstractFOSModel}, ls, model)
 end
 
+# ---- LongstepWrapper(GAP / GAPA / FISTA / Dykstra) [wrappers/longstep.jl, saveplanes.jl]: the wrapped algorithm's handle with the plane saving and the
+#      projection onto the saved planes switched on (fos_set_longstep); planes and projection stay on the device, `iterate` is the wrapped algorithm's.
+import ..FirstOrderSolvers: LongstepWrapper
+function init_algorithm!(long::LongstepWrapper, model::FOSMathProgModel)
+    if usegpu(model)
+        !FirstOrderSolvers.support_longstep(long.alg) && @error "Algorithm alg does not support longstep"        # longstep.jl:28
+        data, status_generator = init_algorithm!(long.alg, model)
+        check(ccall((:fos_set_longstep, libfoship), Cint, (Ptr{Cvoid}, Int64, Int64), data.handle, Int64(long.longinterval), Int64(long.nsave)))
+        return data, status_generator
+    end
+    return invoke(init_algorithm!, Tuple{LongstepWrapper,FirstOrderSolvers.AbstractFOSModel}, long, model)
+end
+iterate(long::LongstepWrapper, data::HipData, status::HSDEStatus, x, max_iters) = iterate(long.alg, data, status, x, max_iters)
+getsol(long::LongstepWrapper, data::HipData, x) = getsol(long.alg, data, x)
+
 # what linesearch.jl:51,63,69 print during a search, from the device's record of the last one
 function print_gapp(data::HipData)                       # gapproj.jl:51,57
     log = Vector{Float64}(undef, 23)
@@ -237,8 +252,7 @@ end
 
 # ---- single-step entry points for callers written against step/getsol (one upload, one ccall, one download per
 #      iteration: correct but PCIe bound -- `iterate` above is the path to use).  The host vector is uploaded on EVERY call, so
-#      a caller that edits x between steps is honoured.  LineSearchWrapper runs on the device through `iterate` (above);
-#      LongstepWrapper is NOT supported with gpu=true (it collects half-planes on the host and solves a BigFloat QP).
+#      a caller that edits x between steps is honoured.  LineSearchWrapper and LongstepWrapper run on the device through `iterate` (above).
 function Base.step(alg::FOSAlgorithm, data::HipData, x, i, status::HSDEStatus, longstep = nothing)
     longstep === nothing || error("longstep/linesearch wrappers are not available with gpu=true")
     check(ccall((:fos_set_iterate, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, x))

@@ -204,6 +204,16 @@ int fos_step(fos_handle h, int64_t i_first, int64_t count, int64_t checki, doubl
  * prints with its println calls (linesearch.jl:51,63,69). */
 int fos_set_linesearch(fos_handle h, int64_t lsinterval);
 int fos_linesearch_log(fos_handle h, double* out34);
+/* LongstepWrapper(alg; longinterval, nsave) around the algorithm set last -- GAP (AP, DR), GAPA, FISTA or Dykstra (support_longstep in src/solvers) --
+ * replaces src/wrappers/longstep.jl:5-63 (LongstepWrapper, init_algorithm!, step) and saveplanes.jl:5-35 (SavedPlanes, projectonnormals!): the last
+ * nsave + 1 iterations of every longinterval save, per iteration, the half-plane through P_S1(x) with normal x - P_S1(x) (addprojeq, longstep.jl:65-79) and
+ * the one of the second projection (addprojineq, :81-97), rows in the reference's order; behind the last of them the iterate is replaced by its projection onto
+ * { first nsave + 1 rows as equalities, the others as inequalities C v >= d } (saveplanes.jl:17-28).  The reference solves that QP in the n variables with QPDAS
+ * (BigFloat); here its dual in the 2 (nsave + 1) multipliers is solved (exactly, by enumeration of the active inequalities) -- the same unique point.
+ * nsave <= 15; longinterval >= nsave + 1; 0 switches the wrapper off.  out8 = iteration of the last projection, active inequalities, largest KKT violation of
+ * the small dual, |x_new - x|, rows, candidate supports tried, 0, 0. */
+int fos_set_longstep(fos_handle h, int64_t longinterval, int64_t nsave);
+int fos_longstep_log(fos_handle h, double* out8);
 /* GAPP(alpha, alpha1, alpha2; iproj) -- "projected GAP", src/solvers/gapproj.jl:5-81, the last row of the reference's solver table
  * (README.md:32-40): fos_set_alg(FOS_ALG_GAP, alpha, alpha1, alpha2, 0) and then fos_set_gapp(iproj > 0).  Iterations i with
  * i % iproj == 0 search 21 step lengths 2^k along P_S1(P_S2(P_S1 x)) - P_S1 x (gapproj.jl:34-62); out23 = the 21 test norms,

@@ -985,18 +985,20 @@ class GAP:
         self.tmp1 = np.empty(n)
         self.tmp2 = np.empty(n)
 
-    def S1_(self, y, x):                                    # gap.jl:42-51
+    def S1_(self, y, x, longstep=None):                     # gap.jl:42-51
         self.S1.prox(y, x)
+        addprojeq(longstep, y, x)                           # :47
         y[:] = self.alpha1 * y + (1 - self.alpha1) * x
 
-    def S2_(self, y, x, status):                            # gap.jl:53-59
+    def S2_(self, y, x, status, longstep=None):             # gap.jl:53-59
         self.S2.prox(y, x)
         status.checkstatus(y)
+        addprojineq(longstep, y, x)                         # :57
         y[:] = self.alpha2 * y + (1 - self.alpha2) * x
 
-    def step(self, x, i, status):                           # gap.jl:61-80
-        self.S1_(self.tmp1, x)
-        self.S2_(self.tmp2, self.tmp1, status)
+    def step(self, x, i, status, longstep=None):            # gap.jl:61-80
+        self.S1_(self.tmp1, x, longstep)
+        self.S2_(self.tmp2, self.tmp1, status, longstep)
         x[:] = self.alpha * self.tmp2 + (1 - self.alpha) * x
 
     def getsol(self, x):                                    # gap.jl:82-87
@@ -1038,20 +1040,22 @@ class GAPA:
         self.tmp1 = np.empty(n)
         self.tmp2 = np.empty(n)
 
-    def S1_(self, y, x):                                    # gapa.jl:61-70
+    def S1_(self, y, x, longstep=None):                     # gapa.jl:61-70
         a12 = self.alpha12
         self.S1.prox(y, x)
+        addprojeq(longstep, y, x)                           # :66
         y[:] = a12 * y + (1 - a12) * x
 
-    def S2_(self, y, x, status):                            # gapa.jl:72-78
+    def S2_(self, y, x, status, longstep=None):             # gapa.jl:72-78
         a12 = self.alpha12
         self.S2.prox(y, x)
         status.checkstatus(y)
+        addprojineq(longstep, y, x)                         # :76
         y[:] = a12 * y + (1 - a12) * x
 
-    def step(self, x, i, status):                           # gapa.jl:80-105
-        self.S1_(self.tmp1, x)
-        self.S2_(self.tmp2, self.tmp1, status)
+    def step(self, x, i, status, longstep=None):            # gapa.jl:80-105
+        self.S1_(self.tmp1, x, longstep)
+        self.S2_(self.tmp2, self.tmp1, status, longstep)
         scl = normed_scalar(self.tmp2, self.tmp1, self.tmp1, x, getattr(getattr(self.S1, "A", None), "space", LOCAL))     # :96
         scl = 0.0 if math.isnan(scl) else min(max(scl, 0.0), 1.0)   # :96-97 (clamp then NaN -> 0)
         s = math.sqrt(1 - scl ** 2)                         # :98
@@ -1080,14 +1084,16 @@ class FISTA:
         self.xold = np.zeros(n)
         self.tmp1 = np.empty(n)
 
-    def step(self, x, i, status):                           # fista.jl:28-48
+    def step(self, x, i, status, longstep=None):            # fista.jl:28-48
         if i == 1:
             self.y[:] = x                                   # :31-33
         self.S1.prox(self.tmp1, self.y)                     # :35
+        addprojeq(longstep, self.tmp1, self.y)              # :36
         self.tmp1[:] = self.alpha * self.tmp1 + (1 - self.alpha) * self.y   # :37
         self.xold[:] = x                                    # :39
         self.S2.prox(x, self.tmp1)                          # :40
         status.checkstatus(x)                               # :41
+        addprojineq(longstep, x, self.tmp1)                 # :42
         told = self.t
         self.t = (1 + math.sqrt(1 + 4 * self.t ** 2)) / 2   # :45
         self.y[:] = x + (told - 1) / self.t * (x - self.xold)   # :46
@@ -1170,11 +1176,13 @@ class Dykstra:
         self.q = np.zeros(n)
         self.y = np.empty(n)
 
-    def step(self, x, i, status):                           # dykstra.jl:25-36
+    def step(self, x, i, status, longstep=None):            # dykstra.jl:25-36
         self.S1.prox(self.y, x + self.p)
+        addprojeq(longstep, self.y, x + self.p)             # :30
         self.p[:] = x + self.p - self.y
         self.S2.prox(x, self.y + self.q)
         status.checkstatus(x)
+        addprojineq(longstep, x, self.y + self.q)           # :34
         self.q[:] = self.y + self.q - x
 
     def getsol(self, x):                                    # dykstra.jl:38-44
@@ -1278,6 +1286,123 @@ class LineSearchWrapper:
         self.log.append((i, normres, tests, abest))
 
     def getsol(self, x):                                    # :93-95
+        return self.alg.getsol(x)
+
+
+# ----------------------------------------------------------------------------------------
+# LongstepWrapper        src/wrappers/longstep.jl, src/wrappers/saveplanes.jl
+# ----------------------------------------------------------------------------------------
+
+
+class SavedPlanes:
+    """mutable struct SavedPlanes (saveplanes.jl:5-11) and its constructor (:30-33): (n + 1) neq + (n + 1) nineq rows (uninitialised in the
+    reference; every row is written before the first projection reads it when longinterval >= nsave + 1)."""
+
+    def __init__(self, x, n, neq, nineq):
+        total = (n + 1) * neq + (n + 1) * nineq
+        self.A = np.full((total, x.size), np.nan)
+        self.b = np.full(total, np.nan)
+        self.n, self.neq, self.nineq = n, neq, nineq
+
+
+def project_onto_planes(A, b, C, d, x, tol=1e-12):
+    """argmin 1/2 |v|^2 - x'v  s.t.  A v = b, C v >= d  -- what saveplanes.jl:24-26 hands to QPDAS (a package outside the checkout) as
+    QuadraticProgram(A, b, -C, -d, -x, I) in BigFloat.  The problem is the projection of x onto a polyhedron: its solution is unique, whatever
+    solves it.  Here: v = x + A'lam + C'mu, mu >= 0; the support of mu is found by enumeration (smallest KKT violation), each candidate by a
+    least-squares solve.  Test infrastructure: tests/test_longstep_oracle.py checks it against scipy's SLSQP on the primal."""
+    import itertools
+    P = np.vstack([A, C])
+    neq, nin = A.shape[0], C.shape[0]
+    beta = np.concatenate([b, d])
+    G = P @ P.T
+    c = beta - P @ x
+    scale = max(1e-300, float(np.max(np.abs(c) + np.sqrt(np.diag(G)))))
+    best = (math.inf, None)
+    for r in range(nin + 1):
+        for S in itertools.combinations(range(nin), r):
+            F = list(range(neq)) + [neq + j for j in S]
+            nu = np.zeros(neq + nin)
+            if F:
+                nu[F] = np.linalg.lstsq(G[np.ix_(F, F)], c[F], rcond=1e-13)[0]
+            g = G @ nu - c                                  # P v - beta
+            viol = float(np.max(np.abs(g[:neq]))) if neq else 0.0
+            for j in range(nin):
+                if j in S:
+                    viol = max(viol, abs(g[neq + j]), -nu[neq + j] * math.sqrt(max(G[neq + j, neq + j], 1e-300)))
+                else:
+                    viol = max(viol, -g[neq + j])
+            if viol < best[0]:
+                best = (viol, nu)
+            if best[0] <= tol * scale:
+                return x + P.T @ best[1], best[0]
+    return x + P.T @ best[1], best[0]
+
+
+def projectonnormals(s, x, y):
+    """projectonnormals!(s, x, y)   saveplanes.jl:13-28 -- the FIRST neq (n + 1) rows are taken as equalities and the rest as inequalities,
+    although the rows were saved equality, inequality, equality, ... (longstep.jl:69,88): the reference's behaviour, kept."""
+    ne = s.neq * (s.n + 1)
+    A, b = s.A[:ne], s.b[:ne]
+    C, d = s.A[ne:(s.neq + s.nineq) * (s.n + 1)], s.b[ne:(s.neq + s.nineq) * (s.n + 1)]
+    y[:], viol = project_onto_planes(A, b, C, d, x)
+    return False, viol
+
+
+def addprojeq(long, y, x):                                  # longstep.jl:62,65-79
+    if long is None:
+        return
+    if long.savepos > 0:
+        s = long.saved
+        i = (long.savepos - 1) * (s.neq + s.nineq * long.saveineq) + long.eqi       # (0-based; the reference's i is this + 1)
+        s.A[i, :] = x - y
+        s.b[i] = float(np.dot(x - y, y))
+        long.eqi += 1
+
+
+def addprojineq(long, y, x):                                # longstep.jl:63,81-97
+    if long is None:
+        return
+    if long.savepos > 0 and (long.saveineq or long.savepos == long.nsave + 1):
+        s = long.saved
+        i = (long.savepos - 1) * (s.neq + s.nineq * long.saveineq) + long.eqi + long.uneqi
+        s.A[i, :] = x - y
+        s.b[i] = float(np.dot(x - y, y))
+        long.uneqi += 1
+
+
+class LongstepWrapper:
+    """LongstepWrapper(alg; longinterval=100, nsave=10, kwargs...)   longstep.jl:5-24 (+ LongstepWrapperData :12-22 in the same object)."""
+
+    def __init__(self, alg, longinterval=100, nsave=10, **options):
+        if not isinstance(alg, (GAP, GAPA, FISTA, Dykstra)) or isinstance(alg, GAPP):      # support_longstep: gap.jl:91, gapa.jl:114, fista.jl:58, dykstra.jl:47
+            raise ValueError("Algorithm alg does not support longstep")                    # longstep.jl:28 (@error)
+        self.alg, self.longinterval, self.nsave = alg, longinterval, nsave
+        self.options = {**options, **alg.options}           # [kwargs..., alg.options...]   :23
+        self.direct = alg.direct
+        self.log = []                                        # (i, KKT violation of the projection) per projection
+
+    def init(self, model):                                  # longstep.jl:26-38
+        self.alg.init(model)
+        self.S1, self.S2 = self.alg.S1, self.alg.S2          # (what solve() hands to the status object)
+        neq, nineq = 1, 1                                   # projections_per_step: (1, 1) for the four algorithms
+        x = hsde_initialvalue(model) if not isinstance(model, FeasibilityModel) else np.zeros(model.n)
+        self.saved = SavedPlanes(x, self.nsave, neq, nineq)
+        self.saveineq, self.savepos, self.eqi, self.uneqi = True, 0, 1, 1
+        self.tmp = np.empty_like(x)
+
+    def step(self, x, i, status):                           # longstep.jl:41-59
+        savepos = (i - 1) % self.longinterval - self.longinterval + self.nsave + 2     # :45
+        if 0 < savepos:                                     # :47-50
+            self.savepos = savepos
+            self.eqi, self.uneqi = 0, 0
+        self.alg.step(x, i, status, self)                   # :51
+        if self.savepos == self.nsave + 1:                  # :53-58
+            _, viol = projectonnormals(self.saved, x, self.tmp)
+            self.savepos = -1
+            x[:] = self.tmp
+            self.log.append((i, viol))
+
+    def getsol(self, x):                                    # :61-63
         return self.alg.getsol(x)
 
 

@@ -1,0 +1,80 @@
+"""
+GPU test of the LongstepWrapper (src/wrappers/longstep.jl, saveplanes.jl) on the device -- fos_set_longstep / fos_longstep_log through the
+Python mirror -- against the oracle's restatement on the same problem: the iterates of the saving iterations, of the projection onto the
+saved planes and of the steps around them, for the four algorithms with support_longstep; the error paths.
+(direct = true, as in the reference's own use of the wrapper, test/testspecific.jl:8,23: with the exact S1 projection device and oracle
+agree to rounding; with CG the first iterations are solved to 0.2^sqrt(i) only.)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ALGS = {"DR": lambda M: M.DR(direct=True), "GAP": lambda M: M.GAP(0.8, 1.5, 1.6, direct=True), "GAPA": lambda M: M.GAPA(0.8, 0.5, direct=True),
+        "FISTA": lambda M: M.FISTA(direct=True), "Dykstra": lambda M: M.Dykstra(direct=True)}
+
+
+def _omodel(orc, prob):
+    codes = lambda cs: [(orc.CONE_CODES[k], l) for k, l in cs]
+    return orc.Model(prob.A, prob.b, prob.c, codes(prob.K1), codes(prob.K2))
+
+
+@pytest.mark.parametrize("algname", sorted(ALGS))
+@pytest.mark.parametrize("longinterval,nsave", [(7, 2), (9, 4)])
+def test_longstep_iterates_match_oracle(pkg, oracle, algname, longinterval, nsave):
+    orc = oracle
+    prob = pkg.workloads.small_mixed()
+    owrap = orc.LongstepWrapper(ALGS[algname](orc), longinterval=longinterval, nsave=nsave)
+    mo = _omodel(orc, prob)
+    owrap.init(mo)
+    xo = orc.hsde_initialvalue(mo)
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d.enable_direct(prob.A)
+    d.set_alg(pkg.LongstepWrapper(ALGS[algname](pkg), longinterval=longinterval, nsave=nsave))
+    d.set_iterate(None)
+    st = orc.HSDEStatus(mo, 10 ** 9, 1e-9, 0, 1, S1=owrap.alg.S1)
+    worst = 0.0
+    for i in range(1, 3 * longinterval + 2):                      # three projections and the steps around them
+        st.i = i
+        owrap.step(xo, i, st)
+        d.step(i, 1, 10 ** 9, 1e-9)
+        z = d.get_iterate()
+        err = np.linalg.norm(z - xo) / max(1.0, np.linalg.norm(xo))
+        worst = max(worst, err)
+        # GAPA's step-length estimate amplifies rounding (tests/test_gpu_feasibility.py): its iterates are followed more loosely
+        assert err <= (1e-6 if algname == "GAPA" else 2e-8), (algname, i, err)       # (projections onto nearly parallel planes amplify rounding: 1e-9 after three of them)
+        if i % longinterval == 0:
+            log = d.longstep_log()
+            assert log["iteration"] == i == owrap.log[-1][0]
+            assert log["rows"] == 2 * (nsave + 1) and log["violation"] <= 1e-9 * max(1.0, log["step"])
+    assert len(owrap.log) == 3
+    d.close()
+
+
+def test_longstep_solve_and_error_paths(pkg, oracle):
+    """Whole solve through FOSMathProgModel with the wrapper (CG projections): same status as the oracle's wrapped solve and an objective
+    within the solve's own tolerance; what the reference refuses is refused; so is what this build does not support."""
+    orc = oracle
+    prob = pkg.workloads.c1_readme_nnls(seed=2)
+    opts = dict(eps=1e-6, verbose=0, checki=10, max_iters=600, direct=True)
+    model = pkg.FOSMathProgModel(pkg.LongstepWrapper(pkg.DR(**opts), longinterval=50, nsave=3))
+    model.loadproblem(prob.c, prob.A, prob.b, prob.K1, prob.K2)
+    model.optimize()
+    ow = orc.LongstepWrapper(orc.DR(**opts), longinterval=50, nsave=3)
+    sol = orc.solve(_omodel(orc, prob), ow)
+    assert model.status() == sol.status
+    assert model.getobjval() == pytest.approx(sol.obj_val, rel=1e-5)
+    with pytest.raises(ValueError):
+        pkg.LongstepWrapper(pkg.GAPP())                           # support_longstep(::GAPP) = false   gapproj.jl:83
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d.set_alg(pkg.DR())
+    with pytest.raises(pkg.lib.FosError):
+        d.set_longstep(100, 16)                                   # 2 (nsave + 1) > 32 planes
+    with pytest.raises(pkg.lib.FosError):
+        d.set_longstep(3, 5)                                      # longinterval < nsave + 1: a plane would be read before it is written
+    d.set_longstep(20, 2)
+    d.set_longstep(0, 0)                                          # off again
+    d.set_linesearch(10)
+    with pytest.raises(pkg.lib.FosError):
+        d.set_longstep(20, 2)                                     # not around a LineSearchWrapper
+    d.close()
