@@ -116,6 +116,8 @@ PROTOTYPES = {
     "fos_feas_gapp_log": (C.c_int, [_h, _dp]),
     "fos_feas_set_linesearch": (C.c_int, [_h, C.c_int64]),
     "fos_feas_linesearch_log": (C.c_int, [_h, _dp]),
+    "fos_feas_set_longstep": (C.c_int, [_h, C.c_int64, C.c_int64]),
+    "fos_feas_longstep_log": (C.c_int, [_h, _dp]),
     "fos_feas_set_iterate": (C.c_int, [_h, _dp]),
     "fos_feas_step": (C.c_int, [_h, C.c_int64, C.c_int64, C.c_int64, C.c_double, _i64p, _i32p, _dp, _i32p]),
     "fos_feas_getsol": (C.c_int, [_h, _dp, C.c_int32, C.c_double, _i32p, _dp]),

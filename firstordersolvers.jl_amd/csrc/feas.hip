@@ -182,6 +182,7 @@ struct fos_feas {
     double err = NAN;
     int64_t ls_interval = 0;        // LineSearchWrapper (wrappers/linesearch.jl): every ls_interval-th iteration is a step-length search
     double ls_log[34] = {0};        // normres, 31 test residuals, alpha_best, iteration (the layout of fos_linesearch_log)
+    LongPlanes lp;                  // LongstepWrapper (wrappers/longstep.jl): planes saved in the last nsave + 1 iterations of every interval (vectors viewed as L/2 double2)
     int64_t gapp_iproj = 100;       // GAPP (solvers/gapproj.jl): every iproj-th iteration is a projected search
     double gapp_log[23] = {0};      // 21 test norms, alpha_best, iteration
     std::vector<void*> owned;
@@ -212,6 +213,16 @@ LaunchCtx feas_ctx(const fos_feas* h, int64_t l) {
     c.stream = h->stream;
     c.l = l;
     return c;
+}
+
+// the LongstepWrapper's kernels see the zero-padded vectors of L doubles as L / 2 double2
+LaunchCtx feas_long_ctx(const fos_feas* h) {
+    LaunchCtx c = feas_ctx(h, h->L / 2);
+    c.vec_blocks = h->grid;
+    return c;
+}
+inline void feas_long_save(fos_feas* h, int which, const double* y, const double* x) {
+    if (h->lp.now) long_save_plane(feas_long_ctx(h), h->lp, which, reinterpret_cast<const double2*>(y), reinterpret_cast<const double2*>(x));
 }
 
 // prox!(y, S, x): the projection onto set `which`; y must not alias x
@@ -343,15 +354,23 @@ int feas_step_once(fos_feas* h, int64_t i, int64_t checki, double eps) {
     const int64_t n = h->n;
     if (h->alg == FOS_ALG_GAPP) return feas_gapp_iteration(h, i, checki, eps);
     if (h->ls_interval > 0 && i % h->ls_interval == 0) return feas_linesearch_iteration(h, i, checki, eps);      // linesearch.jl:39
+    h->lp.now = false;
+    if (h->lp.interval > 0) {                                                           // longstep.jl:44-49
+        const int64_t savepos = (i - 1) % h->lp.interval - h->lp.interval + h->lp.nsave + 2;
+        if (savepos > 0) h->lp.savepos = savepos;
+        h->lp.now = h->lp.savepos > 0;
+    }
     switch (h->alg) {
     case FOS_ALG_GAP:
     case FOS_ALG_GAPA: {
         const bool ad = h->alg == FOS_ALG_GAPA;
         const double* a12 = ad ? h->a12 : nullptr;
         FOS_TRY(feas_prox(h, 0, h->t1, h->x));                                         // S1!  gap.jl:42-51, gapa.jl:61-70
+        feas_long_save(h, 0, h->t1, h->x);                                             // addprojeq(longstep, y, x)
         FEAS_K(feas_relax_kernel, n, h->t1, (const double*)h->x, h->alpha1, a12);
         FOS_TRY(feas_prox(h, 1, h->t2, h->t1));                                        // S2!  gap.jl:53-59, gapa.jl:72-78
         FOS_TRY(feas_check(h, h->t2, i, checki, eps, false));
+        feas_long_save(h, 1, h->t2, h->t1);                                            // addprojineq(longstep, y, x)
         FEAS_K(feas_relax_kernel, n, h->t2, (const double*)h->t1, h->alpha2, a12);
         if (ad) {                                                                      // gapa.jl:96-101 (relaxed t1, t2 and the old x)
             FEAS_K(feas_triple_kernel, n, (const double*)h->t2, (const double*)h->t1, (const double*)h->x, h->partials);
@@ -363,10 +382,12 @@ int feas_step_once(fos_feas* h, int64_t i, int64_t checki, double eps) {
     case FOS_ALG_FISTA: {                                                              // fista.jl:28-48
         if (i == 1) FEAS_K(feas_copy_kernel, n, h->y, (const double*)h->x);
         FOS_TRY(feas_prox(h, 0, h->t1, h->y));
+        feas_long_save(h, 0, h->t1, h->y);                                             // addprojeq(longstep, tmp1, y)      fista.jl:36
         FEAS_K(feas_relax_kernel, n, h->t1, (const double*)h->y, h->alpha, (const double*)nullptr);
         FEAS_K(feas_copy_kernel, n, h->xold, (const double*)h->x);
         FOS_TRY(feas_prox(h, 1, h->x, h->t1));
         FOS_TRY(feas_check(h, h->x, i, checki, eps, false));
+        feas_long_save(h, 1, h->x, h->t1);                                             // addprojineq(longstep, x, tmp1)    fista.jl:42
         const double told = h->fista_t;
         h->fista_t = (1.0 + std::sqrt(1.0 + 4.0 * told * told)) / 2.0;
         FEAS_K(feas_extrap_kernel, n, h->y, (const double*)h->x, (const double*)h->xold, (told - 1.0) / h->fista_t);
@@ -375,15 +396,22 @@ int feas_step_once(fos_feas* h, int64_t i, int64_t checki, double eps) {
     case FOS_ALG_DYKSTRA: {                                                            // dykstra.jl:25-36
         FEAS_K(feas_add_kernel, n, h->tmp, (const double*)h->x, (const double*)h->p);
         FOS_TRY(feas_prox(h, 0, h->y, h->tmp));
+        feas_long_save(h, 0, h->y, h->tmp);                                            // addprojeq(longstep, y, x .+ p)    dykstra.jl:30
         FEAS_K(feas_sub_kernel, n, h->p, (const double*)h->tmp, (const double*)h->y);
         FEAS_K(feas_add_kernel, n, h->tmp, (const double*)h->y, (const double*)h->q);
         FOS_TRY(feas_prox(h, 1, h->x, h->tmp));
         FOS_TRY(feas_check(h, h->x, i, checki, eps, false));
+        feas_long_save(h, 1, h->x, h->tmp);                                            // addprojineq(longstep, x, y .+ q)  dykstra.jl:34
         FEAS_K(feas_sub_kernel, n, h->q, (const double*)h->tmp, (const double*)h->x);
         break;
     }
     default: set_error("feasibility form: unknown algorithm %d", h->alg); return FOS_EINVAL;
     }
+    if (h->lp.now && h->lp.savepos == h->lp.nsave + 1) {                                // longstep.jl:53-58: projectonnormals!, x .= tmp
+        FOS_TRY(long_project_planes(feas_long_ctx(h), h->lp, reinterpret_cast<double2*>(h->x), i));
+        h->lp.savepos = -1;
+    }
+    h->lp.now = false;
     return FOS_OK;
 }
 
@@ -620,6 +648,7 @@ int fos_feas_set_alg(fos_feas_handle h, int32_t alg, double alpha, double alpha1
     h->alg = alg; h->alpha = alpha; h->alpha1 = alpha1; h->alpha2 = alpha2; h->beta = beta;
     if (alg == FOS_ALG_GAPA) h->alpha1 = h->alpha2 = 2.0;              // (unused: GAPA relaxes with the device scalar alpha12)
     h->ls_interval = 0;                                                // a fresh algorithm is unwrapped (fos_feas_set_linesearch follows)
+    h->lp.interval = 0; h->lp.savepos = 0; h->lp.now = false;          // ... (fos_feas_set_longstep follows)
     return FOS_OK;
 }
 
@@ -643,6 +672,31 @@ int fos_feas_set_linesearch(fos_feas_handle h, int64_t lsinterval) {
         return FOS_EUNSUPPORTED;
     }
     h->ls_interval = lsinterval;
+    return FOS_OK;
+}
+// LongstepWrapper on the Feasibility form (as fos_set_longstep)
+int fos_feas_set_longstep(fos_feas_handle h, int64_t longinterval, int64_t nsave) {
+    if (!h || longinterval < 0 || nsave < 0) { set_error("bad argument"); return FOS_EINVAL; }
+    if (longinterval == 0) { h->lp.interval = 0; h->lp.savepos = 0; h->lp.now = false; return FOS_OK; }
+    if (h->alg == FOS_ALG_GAPP) { set_error("Algorithm alg does not support longstep (support_longstep(::GAPP) = false, gapproj.jl:83)"); return FOS_EUNSUPPORTED; }
+    if (2 * (nsave + 1) > LONG_KMAX_ROWS) { set_error("LongstepWrapper: nsave <= %d", LONG_KMAX_ROWS / 2 - 1); return FOS_EUNSUPPORTED; }
+    if (longinterval < nsave + 1) { set_error("LongstepWrapper: longinterval must be at least nsave + 1"); return FOS_EINVAL; }
+    if (h->ls_interval > 0) { set_error("LongstepWrapper around a LineSearchWrapper is not supported"); return FOS_EUNSUPPORTED; }
+    FOS_HIP(hipSetDevice(h->device));
+    const int64_t K = 2 * (nsave + 1);
+    if (!h->lp.P || h->lp.nsave != nsave) {
+        double* q = nullptr;
+        FOS_TRY(feas_alloc(h, &q, (size_t)K * h->L)); h->lp.P = reinterpret_cast<double2*>(q);
+        FOS_TRY(feas_alloc(h, &h->lp.bpart, (size_t)K * h->grid));
+        FOS_TRY(feas_alloc(h, &h->lp.dots, (size_t)h->grid * (LONG_KMAX_ROWS + 1)));
+        FOS_TRY(feas_alloc(h, &h->lp.nu, (size_t)K));
+    }
+    h->lp.interval = longinterval; h->lp.nsave = nsave; h->lp.savepos = 0; h->lp.now = false;
+    return FOS_OK;
+}
+int fos_feas_longstep_log(fos_feas_handle h, double* out8) {
+    if (!h || !out8) { set_error("NULL argument"); return FOS_EINVAL; }
+    memcpy(out8, h->lp.log, sizeof(h->lp.log));
     return FOS_OK;
 }
 int fos_feas_linesearch_log(fos_feas_handle h, double* out34) {

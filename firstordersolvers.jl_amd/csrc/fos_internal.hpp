@@ -414,6 +414,20 @@ void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate, int off =
 
 // outer-loop vector kernels (gap.jl:48,58,78; gapa.jl:67,77,96-103; fista.jl:31-46; dykstra.jl)
 constexpr int LONG_KMAX_ROWS = 32;   // saved planes of a LongstepWrapper: 2 (nsave + 1) <= 32
+// LongstepWrapper state of a handle (wrappers/longstep.jl:12-22 LongstepWrapperData + saveplanes.jl:5-11 SavedPlanes), device resident
+struct LongPlanes {
+    int64_t interval = 0, nsave = 0;
+    int64_t savepos = 0;               // LongstepWrapperData.savepos (0 at the start, -1 after a projection)
+    bool now = false;                  // the iteration in flight saves planes
+    double2* P = nullptr;              // [2 (nsave + 1)][l] saved rows x - y, in the reference's row order (equality, inequality, equality, ...)
+    double* bpart = nullptr;           // [rows][vec_blocks] partial sums of the offsets (x - y).y
+    double* dots = nullptr;            // [vec_blocks][33] scratch of the Gram products
+    double* nu = nullptr;              // [rows] multipliers, device copy
+    double log[8] = {0};               // last projection: iteration, active inequalities, KKT violation, |x_new - x|, rows, supports tried
+};
+struct LaunchCtx;
+void long_save_plane(const LaunchCtx& c, LongPlanes& lp, int which, const double2* y, const double2* x);      // addprojeq (0) / addprojineq (1) at lp.savepos
+int long_project_planes(const LaunchCtx& c, LongPlanes& lp, double2* X, int64_t i);                          // projectonnormals! + x .= tmp   (solver.cpp)
 void launch_long_plane(const LaunchCtx& c, double2* row, const double2* x, const double2* y, double* bpart);          // row = x - y; bpart[blocks]: partial sums of (x - y).y
 void launch_long_dots(const LaunchCtx& c, const double2* P, int K, int a, const double2* x, double* out);              // out[blocks][33]: row_a . row_{a+k}, k < 32; [32]: row_a . x
 void launch_long_apply(const LaunchCtx& c, double2* x, const double2* P, int K, const double* nu);                     // x += sum_k nu[k] row_k

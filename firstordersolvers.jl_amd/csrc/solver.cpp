@@ -197,14 +197,7 @@ struct fos_solver {
     double ls_log[34] = {0};                   // last search: ||res||, the 31 test residuals, the chosen alpha, the iteration
     // LongstepWrapper (wrappers/longstep.jl, saveplanes.jl): the last nsave + 1 iterations of every long_interval save the two half-planes of
     // their projections; the iterate is then projected onto the saved planes
-    int64_t long_interval = 0, long_nsave = 0;
-    int64_t long_savepos = 0;                  // LongstepWrapperData.savepos (0 at the start, -1 after a projection)
-    bool long_now = false;                     // the iteration in flight saves planes (between step_once and step_finish)
-    d2* long_P = nullptr;                      // [2 (nsave + 1)][l] saved rows x - y, in the reference's row order (equality, inequality, equality, ...)
-    double* long_bpart = nullptr;              // [rows][vec_blocks] partial sums of the offsets (x - y).y
-    double* long_dots = nullptr;               // [vec_blocks][33] scratch of the Gram products
-    double* long_nu = nullptr;                 // [rows] multipliers, device copy
-    double long_log[8] = {0};                  // last projection: iteration, active inequalities, KKT violation, |x_new - x|, rows, enumerated subsets
+    LongPlanes lp;                             // (fos_internal.hpp)
     int cg_same_run = 0;                       // consecutive solves that took exactly last_cg_pred iterations
     const d2* last_checked = nullptr;          // vector the last checkstatus was evaluated on
 
@@ -808,10 +801,7 @@ int gapp_finish(fos_solver* h) {
 // ---- LongstepWrapper                                                 wrappers/longstep.jl:41-101, saveplanes.jl:13-35
 int step_finish_launch(fos_solver* h, const LaunchCtx& c);
 // addprojeq (which = 0) / addprojineq (which = 1): row i = (savepos - 1) (neq + nineq) + eqi (+ uneqi) + 1 with neq = nineq = 1     longstep.jl:69,88
-void long_save(fos_solver* h, const LaunchCtx& c, int which, const d2* y, const d2* x) {
-    const int64_t row = 2 * (h->long_savepos - 1) + which;
-    launch_long_plane(c, h->long_P + row * h->l, x, y, h->long_bpart + row * c.vec_blocks);
-}
+void long_save(fos_solver* h, const LaunchCtx& c, int which, const d2* y, const d2* x) { fos::long_save_plane(c, h->lp, which, y, x); }
 // a saving iteration: the step of the wrapped algorithm, unfused, with the two planes taken where the reference's step calls addprojeq /
 // addprojineq (gap.jl:47,57  gapa.jl:66,76  fista.jl:36,42  dykstra.jl:30,34)
 int long_begin(fos_solver* h, int64_t i, const d2** check_on) {
@@ -901,61 +891,7 @@ static void long_solve_support(int K, const std::vector<double>& G, const std::v
     }
 }
 int long_project(fos_solver* h, int64_t i) {
-    LaunchCtx c = h->ctx();
-    const int K = (int)(2 * (h->long_nsave + 1)), neq = (int)(h->long_nsave + 1), nin = K - neq;
-    const int nb = c.vec_blocks;
-    std::vector<double> G((size_t)K * K, 0.0), Px((size_t)K, 0.0), beta((size_t)K, 0.0);
-    std::vector<double> part((size_t)nb * (LONG_KMAX_ROWS + 1)), bp((size_t)K * nb);
-    for (int a = 0; a < K; ++a) {
-        launch_long_dots(c, h->long_P, K, a, h->X, h->long_dots);
-        FOS_HIP(hipMemcpyAsync(part.data(), h->long_dots, sizeof(double) * part.size(), hipMemcpyDeviceToHost, h->stream));
-        FOS_HIP(hipStreamSynchronize(h->stream));
-        for (int k = 0; a + k < K; ++k) {
-            double sacc = 0.0;
-            for (int b = 0; b < nb; ++b) sacc += part[(size_t)b * (LONG_KMAX_ROWS + 1) + k];
-            G[(size_t)a * K + a + k] = G[(size_t)(a + k) * K + a] = sacc;
-        }
-        double sx = 0.0;
-        for (int b = 0; b < nb; ++b) sx += part[(size_t)b * (LONG_KMAX_ROWS + 1) + LONG_KMAX_ROWS];
-        Px[(size_t)a] = sx;
-    }
-    FOS_HIP(hipMemcpyAsync(bp.data(), h->long_bpart, sizeof(double) * bp.size(), hipMemcpyDeviceToHost, h->stream));
-    FOS_HIP(hipStreamSynchronize(h->stream));
-    for (int a = 0; a < K; ++a) { double sacc = 0.0; for (int b = 0; b < nb; ++b) sacc += bp[(size_t)a * nb + b]; beta[(size_t)a] = sacc; }
-    std::vector<double> cvec((size_t)K);
-    for (int a = 0; a < K; ++a) cvec[(size_t)a] = beta[(size_t)a] - Px[(size_t)a];
-    double scale = 0.0;
-    for (int a = 0; a < K; ++a) scale = std::max(scale, std::fabs(cvec[(size_t)a]) + std::sqrt(G[(size_t)a * K + a]));
-    std::vector<double> nu, best_nu((size_t)K, 0.0);
-    double best_viol = INFINITY;
-    int best_active = 0;
-    int64_t tried = 0;
-    std::vector<int> F;
-    for (uint32_t mask = 0; mask < (1u << nin); ++mask) {
-        F.clear();
-        for (int a = 0; a < neq; ++a) F.push_back(a);
-        for (int j = 0; j < nin; ++j) if (mask & (1u << j)) F.push_back(neq + j);
-        long_solve_support(K, G, cvec, F, nu);
-        ++tried;
-        // violation: equality residuals, negative multipliers inside the support, violated inequalities outside it
-        double viol = 0.0;
-        for (int a = 0; a < K; ++a) {
-            double g = -cvec[(size_t)a];                                      // (G nu - c)_a = P_a v - beta_a
-            for (int b2 = 0; b2 < K; ++b2) g += G[(size_t)a * K + b2] * nu[(size_t)b2];
-            if (a < neq) viol = std::max(viol, std::fabs(g));
-            else if (mask & (1u << (a - neq))) viol = std::max(viol, std::max(std::fabs(g), -nu[(size_t)a] * std::sqrt(std::max(G[(size_t)a * K + a], 1e-300))));
-            else viol = std::max(viol, -g);
-        }
-        if (viol < best_viol) { best_viol = viol; best_nu = nu; best_active = __builtin_popcount(mask); }
-        if (best_viol <= 1e-12 * std::max(scale, 1e-300)) break;
-    }
-    double step2 = 0.0;                                                       // |P' nu|^2 = nu' G nu
-    for (int a = 0; a < K; ++a) for (int b2 = 0; b2 < K; ++b2) step2 += best_nu[(size_t)a] * G[(size_t)a * K + b2] * best_nu[(size_t)b2];
-    FOS_HIP(hipMemcpyAsync(h->long_nu, best_nu.data(), sizeof(double) * K, hipMemcpyHostToDevice, h->stream));
-    launch_long_apply(c, h->X, h->long_P, K, h->long_nu);                     // x .= longstep.tmp      longstep.jl:57
-    FOS_HIP(hipStreamSynchronize(h->stream));                                 // (best_nu leaves scope)
-    h->long_log[0] = (double)i; h->long_log[1] = (double)best_active; h->long_log[2] = best_viol; h->long_log[3] = std::sqrt(std::max(step2, 0.0));
-    h->long_log[4] = (double)K; h->long_log[5] = (double)tried;
+    FOS_TRY(fos::long_project_planes(h->ctx(), h->lp, h->X, i));
     h->shift_ready = false;                                                   // (the iterate changed behind the step's last kernel)
     return FOS_OK;
 }
@@ -968,9 +904,9 @@ int long_finish(fos_solver* h, int64_t i) {
         case FOS_ALG_DYKSTRA: long_save(h, c, 1, h->X, h->W); break;          // addprojineq(longstep, x, y .+ q)
     }
     FOS_TRY(step_finish_launch(h, c));
-    if (h->long_savepos == h->long_nsave + 1) {                               // longstep.jl:53-58
+    if (h->lp.savepos == h->lp.nsave + 1) {                               // longstep.jl:53-58
         FOS_TRY(long_project(h, i));
-        h->long_savepos = -1;
+        h->lp.savepos = -1;
     }
     return FOS_OK;
 }
@@ -1003,12 +939,12 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bo
     if (h->ls_now) return ls_begin(h, check_on);
     h->gapp_now = h->gapp_iproj > 0 && (i % h->gapp_iproj) == 0;                                     // gapproj.jl:34
     if (h->gapp_now) return gapp_begin(h, i, check_on);
-    h->long_now = false;
-    if (h->long_interval > 0) {                                                                      // longstep.jl:44-49
-        const int64_t savepos = (i - 1) % h->long_interval - h->long_interval + h->long_nsave + 2;
-        if (savepos > 0) h->long_savepos = savepos;
-        h->long_now = h->long_savepos > 0;
-        if (h->long_now) return long_begin(h, i, check_on);
+    h->lp.now = false;
+    if (h->lp.interval > 0) {                                                                      // longstep.jl:44-49
+        const int64_t savepos = (i - 1) % h->lp.interval - h->lp.interval + h->lp.nsave + 2;
+        if (savepos > 0) h->lp.savepos = savepos;
+        h->lp.now = h->lp.savepos > 0;
+        if (h->lp.now) return long_begin(h, i, check_on);
     }
     switch (h->alg) {
         case FOS_ALG_GAP:                                                // gap.jl:61-80
@@ -1022,7 +958,7 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bo
                 static const bool fuse_psd = !(getenv("FOS_PSD_FUSE") && atoi(getenv("FOS_PSD_FUSE")) == 0);
                 // GAP / DR, no status check in this step, every non-elementwise cone a PSD(64) cone with a basis from the last projection:
                 // relaxation, projection and the step's last pass are ONE launch (PsdFuse, fos_internal.hpp)
-                if (fuse_psd && !gapa && !will_check && h->nsoc == 0 && h->nexp == 0 && !h->ls_interval && !h->gapp_iproj && !h->long_interval &&
+                if (fuse_psd && !gapa && !will_check && h->nsoc == 0 && h->nexp == 0 && !h->ls_interval && !h->gapp_iproj && !h->lp.interval &&
                     psd_fuse_possible(cg, h->npsd, h->psd_kmin, h->psd_kmax, h->psd_V[h->psd_cur], h->psd_V[1 - h->psd_cur], h->psd_have_prev, h->psd_redo,
                                       h->psd_phase_limit)) {
                     RoctxRange range("fos:relaxation + PSD projection + final pass (one launch)");
@@ -1093,7 +1029,7 @@ int step_finish(fos_solver* h, int64_t i) {
     LaunchCtx c = h->ctx();
     if (h->ls_now) { h->ls_now = false; return ls_finish(h, i); }
     if (h->gapp_now) { h->gapp_now = false; return gapp_finish(h); }
-    if (h->long_now) { h->long_now = false; return long_finish(h, i); }
+    if (h->lp.now) { h->lp.now = false; return long_finish(h, i); }
     return step_finish_launch(h, c);
 }
 int step_finish_launch(fos_solver* h, const LaunchCtx& c) {
@@ -1200,6 +1136,70 @@ void add_cones(int64_t offset, bool is_K1, int64_t nK, const int32_t* type, cons
 }
 
 }  // namespace
+
+namespace fos {
+int long_project_planes(const LaunchCtx& c, LongPlanes& lp, d2* X, int64_t i) {
+    const int K = (int)(2 * (lp.nsave + 1)), neq = (int)(lp.nsave + 1), nin = K - neq;
+    const int nb = c.vec_blocks;
+    std::vector<double> G((size_t)K * K, 0.0), Px((size_t)K, 0.0), beta((size_t)K, 0.0);
+    std::vector<double> part((size_t)nb * (LONG_KMAX_ROWS + 1)), bp((size_t)K * nb);
+    for (int a = 0; a < K; ++a) {
+        launch_long_dots(c, lp.P, K, a, X, lp.dots);
+        FOS_HIP(hipMemcpyAsync(part.data(), lp.dots, sizeof(double) * part.size(), hipMemcpyDeviceToHost, c.stream));
+        FOS_HIP(hipStreamSynchronize(c.stream));
+        for (int k = 0; a + k < K; ++k) {
+            double sacc = 0.0;
+            for (int b = 0; b < nb; ++b) sacc += part[(size_t)b * (LONG_KMAX_ROWS + 1) + k];
+            G[(size_t)a * K + a + k] = G[(size_t)(a + k) * K + a] = sacc;
+        }
+        double sx = 0.0;
+        for (int b = 0; b < nb; ++b) sx += part[(size_t)b * (LONG_KMAX_ROWS + 1) + LONG_KMAX_ROWS];
+        Px[(size_t)a] = sx;
+    }
+    FOS_HIP(hipMemcpyAsync(bp.data(), lp.bpart, sizeof(double) * bp.size(), hipMemcpyDeviceToHost, c.stream));
+    FOS_HIP(hipStreamSynchronize(c.stream));
+    for (int a = 0; a < K; ++a) { double sacc = 0.0; for (int b = 0; b < nb; ++b) sacc += bp[(size_t)a * nb + b]; beta[(size_t)a] = sacc; }
+    std::vector<double> cvec((size_t)K);
+    for (int a = 0; a < K; ++a) cvec[(size_t)a] = beta[(size_t)a] - Px[(size_t)a];
+    double scale = 0.0;
+    for (int a = 0; a < K; ++a) scale = std::max(scale, std::fabs(cvec[(size_t)a]) + std::sqrt(G[(size_t)a * K + a]));
+    std::vector<double> nu, best_nu((size_t)K, 0.0);
+    double best_viol = INFINITY;
+    int best_active = 0;
+    int64_t tried = 0;
+    std::vector<int> F;
+    for (uint32_t mask = 0; mask < (1u << nin); ++mask) {
+        F.clear();
+        for (int a = 0; a < neq; ++a) F.push_back(a);
+        for (int j = 0; j < nin; ++j) if (mask & (1u << j)) F.push_back(neq + j);
+        long_solve_support(K, G, cvec, F, nu);
+        ++tried;
+        // violation: equality residuals, negative multipliers inside the support, violated inequalities outside it
+        double viol = 0.0;
+        for (int a = 0; a < K; ++a) {
+            double g = -cvec[(size_t)a];                                      // (G nu - c)_a = P_a v - beta_a
+            for (int b2 = 0; b2 < K; ++b2) g += G[(size_t)a * K + b2] * nu[(size_t)b2];
+            if (a < neq) viol = std::max(viol, std::fabs(g));
+            else if (mask & (1u << (a - neq))) viol = std::max(viol, std::max(std::fabs(g), -nu[(size_t)a] * std::sqrt(std::max(G[(size_t)a * K + a], 1e-300))));
+            else viol = std::max(viol, -g);
+        }
+        if (viol < best_viol) { best_viol = viol; best_nu = nu; best_active = __builtin_popcount(mask); }
+        if (best_viol <= 1e-12 * std::max(scale, 1e-300)) break;
+    }
+    double step2 = 0.0;                                                       // |P' nu|^2 = nu' G nu
+    for (int a = 0; a < K; ++a) for (int b2 = 0; b2 < K; ++b2) step2 += best_nu[(size_t)a] * G[(size_t)a * K + b2] * best_nu[(size_t)b2];
+    FOS_HIP(hipMemcpyAsync(lp.nu, best_nu.data(), sizeof(double) * K, hipMemcpyHostToDevice, c.stream));
+    launch_long_apply(c, X, lp.P, K, lp.nu);                     // x .= longstep.tmp      longstep.jl:57
+    FOS_HIP(hipStreamSynchronize(c.stream));                                 // (best_nu leaves scope)
+    lp.log[0] = (double)i; lp.log[1] = (double)best_active; lp.log[2] = best_viol; lp.log[3] = std::sqrt(std::max(step2, 0.0));
+    lp.log[4] = (double)K; lp.log[5] = (double)tried;
+    return FOS_OK;
+}
+void long_save_plane(const LaunchCtx& c, LongPlanes& lp, int which, const d2* y, const d2* x) {
+    const int64_t row = 2 * (lp.savepos - 1) + which;
+    launch_long_plane(c, lp.P + row * c.l, x, y, lp.bpart + row * c.vec_blocks);
+}
+}  // namespace fos
 
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" {
@@ -1787,7 +1787,7 @@ int fos_set_alg(fos_handle h, int alg, double alpha, double alpha1, double alpha
     h->alg = alg; h->alpha = alpha; h->alpha1 = alpha1; h->alpha2 = alpha2; h->beta = beta;
     h->ls_interval = 0; h->ls_now = false;                              // a fresh algorithm is unwrapped (fos_set_linesearch follows)
     h->gapp_iproj = 0; h->gapp_now = false;                             // ... and plain (fos_set_gapp follows)
-    h->long_interval = 0; h->long_savepos = 0; h->long_now = false;     // ... (fos_set_longstep follows)
+    h->lp.interval = 0; h->lp.savepos = 0; h->lp.now = false;     // ... (fos_set_longstep follows)
     h->fista_t = 1.0;                                                   // fista.jl:24
     // fresh *Data: alpha12 = 2.0 (gapa.jl:29); y = xold = 0 (fista.jl:24); p = q = 0 (dykstra.jl:21)
     DevState z;
@@ -1980,7 +1980,7 @@ int fos_set_linesearch(fos_handle h, int64_t lsinterval) {
         set_error("LineSearchWrapper is built for single-GPU handles only (its step-length scores are global norms)");
         return FOS_EUNSUPPORTED;
     }
-    if (lsinterval > 0 && h->long_interval > 0) { set_error("LineSearchWrapper inside a LongstepWrapper is not supported"); return FOS_EUNSUPPORTED; }
+    if (lsinterval > 0 && h->lp.interval > 0) { set_error("LineSearchWrapper inside a LongstepWrapper is not supported"); return FOS_EUNSUPPORTED; }
     h->ls_interval = lsinterval;
     return FOS_OK;
 }
@@ -2002,26 +2002,26 @@ int fos_gapp_log(fos_handle h, double* out23) {
 // LongstepWrapper(alg; longinterval, nsave) around the algorithm set last (wrappers/longstep.jl:22-40): 0 switches it off
 int fos_set_longstep(fos_handle h, int64_t longinterval, int64_t nsave) {
     if (!h || longinterval < 0 || nsave < 0) { set_error("bad argument"); return FOS_EINVAL; }
-    if (longinterval == 0) { h->long_interval = 0; h->long_savepos = 0; return FOS_OK; }
+    if (longinterval == 0) { h->lp.interval = 0; h->lp.savepos = 0; return FOS_OK; }
     if (2 * (nsave + 1) > LONG_KMAX_ROWS) { set_error("LongstepWrapper: nsave <= %d (2 (nsave + 1) saved planes, small dual QP solved by enumeration)", LONG_KMAX_ROWS / 2 - 1); return FOS_EUNSUPPORTED; }
     if (longinterval < nsave + 1) { set_error("LongstepWrapper: longinterval must be at least nsave + 1 (every plane is written before it is read)"); return FOS_EINVAL; }
     if (h->sharded() || h->row_sharded) { set_error("LongstepWrapper is built for single-GPU handles only (the planes' products are global sums)"); return FOS_EUNSUPPORTED; }
     if (h->ls_interval > 0 || h->gapp_iproj > 0) { set_error("LongstepWrapper around a LineSearchWrapper / GAPP is not supported"); return FOS_EUNSUPPORTED; }
     FOS_HIP(hipSetDevice(h->device));
     const int64_t K = 2 * (nsave + 1);
-    if (!h->long_P || h->long_nsave != nsave) {
-        FOS_TRY(dev_alloc(h, &h->long_P, (size_t)K * h->l));
-        FOS_TRY(dev_alloc(h, &h->long_bpart, (size_t)K * h->vec_blocks));
-        FOS_TRY(dev_alloc(h, &h->long_dots, (size_t)h->vec_blocks * (LONG_KMAX_ROWS + 1)));
-        FOS_TRY(dev_alloc(h, &h->long_nu, (size_t)K));
+    if (!h->lp.P || h->lp.nsave != nsave) {
+        FOS_TRY(dev_alloc(h, &h->lp.P, (size_t)K * h->l));
+        FOS_TRY(dev_alloc(h, &h->lp.bpart, (size_t)K * h->vec_blocks));
+        FOS_TRY(dev_alloc(h, &h->lp.dots, (size_t)h->vec_blocks * (LONG_KMAX_ROWS + 1)));
+        FOS_TRY(dev_alloc(h, &h->lp.nu, (size_t)K));
     }
-    h->long_interval = longinterval; h->long_nsave = nsave; h->long_savepos = 0; h->long_now = false;
+    h->lp.interval = longinterval; h->lp.nsave = nsave; h->lp.savepos = 0; h->lp.now = false;
     return FOS_OK;
 }
 // last projection of the LongstepWrapper: out8 = iteration, active inequalities, largest KKT violation of the small dual, |x_new - x|, rows, supports tried
 int fos_longstep_log(fos_handle h, double* out8) {
     if (!h || !out8) { set_error("NULL argument"); return FOS_EINVAL; }
-    memcpy(out8, h->long_log, sizeof(h->long_log));
+    memcpy(out8, h->lp.log, sizeof(h->lp.log));
     return FOS_OK;
 }
 int fos_linesearch_log(fos_handle h, double* out34) {

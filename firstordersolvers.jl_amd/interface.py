@@ -858,6 +858,13 @@ class HipFeasibility:
         _lib.check(self._lib.fos_feas_set_alg(self._h, *alg._alg_args()))
         if isinstance(alg, LineSearchWrapper):                          # the wrapped algorithm's arguments, then the search
             _lib.check(self._lib.fos_feas_set_linesearch(self._h, alg.lsinterval))
+        if isinstance(alg, LongstepWrapper):
+            _lib.check(self._lib.fos_feas_set_longstep(self._h, alg.longinterval, alg.nsave))
+
+    def longstep_log(self):
+        out = np.zeros(8)
+        _lib.check(self._lib.fos_feas_longstep_log(self._h, _lib.dptr(out)))
+        return dict(iteration=int(out[0]), active=int(out[1]), violation=float(out[2]), step=float(out[3]), rows=int(out[4]), tried=int(out[5]))
 
     def gapp_log(self):
         """(iteration, [21 test norms], alpha_best) of GAPP's last search."""

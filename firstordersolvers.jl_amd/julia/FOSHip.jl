@@ -350,6 +350,17 @@ end
 
 # LineSearchWrapper(GAP / GAPA) on the Feasibility form (test/testfeasibility.jl:36-44): the wrapped algorithm's handle with the
 # search switched on; what linesearch.jl prints during a search comes from fos_feas_linesearch_log
+function init_algorithm!(long::LongstepWrapper, model::FeasibilityModel)      # [wrappers/longstep.jl] on the Feasibility form: fos_feas_set_longstep
+    if usegpu(model)
+        !FirstOrderSolvers.support_longstep(long.alg) && @error "Algorithm alg does not support longstep"
+        data, status_generator = init_algorithm!(long.alg, model)
+        check(ccall((:fos_feas_set_longstep, libfoship), Cint, (Ptr{Cvoid}, Int64, Int64), data.handle, Int64(long.longinterval), Int64(long.nsave)))
+        return data, status_generator
+    end
+    return invoke(init_algorithm!, Tuple{LongstepWrapper,FirstOrderSolvers.AbstractFOSModel}, long, model)
+end
+iterate(long::LongstepWrapper, data::HipFeasData, status::FeasibilityStatus, x, max_iters) = iterate(long.alg, data, status, x, max_iters)
+getsol(long::LongstepWrapper, data::HipFeasData, x) = getsol(long.alg, data, x)
 function init_algorithm!(ls::LineSearchWrapper, model::FeasibilityModel)
     if get(model.options, :gpu, false) === true
         data, status_generator = init_algorithm!(ls.alg, model)

@@ -367,6 +367,9 @@ int fos_feas_gapp_log(fos_feas_handle h, double* out23);
 /* LineSearchWrapper(GAP | GAPA; lsinterval) around the algorithm set last (wrappers/linesearch.jl:36-75; 0 switches it off), and what
  * the reference prints during the last search: out34 = normres, 31 test residuals, alpha_best, iteration (as fos_linesearch_log) */
 int fos_feas_set_linesearch(fos_feas_handle h, int64_t lsinterval);
+/* LongstepWrapper on this form (fos_set_longstep above: same planes, same projection) */
+int fos_feas_set_longstep(fos_feas_handle h, int64_t longinterval, int64_t nsave);
+int fos_feas_longstep_log(fos_feas_handle h, double* out8);
 int fos_feas_linesearch_log(fos_feas_handle h, double* out34);
 /* x = x0 (NULL: zeros(n), Feasibility.jl:58) and the algorithm state of a fresh init_algorithm! */
 int fos_feas_set_iterate(fos_feas_handle h, const double* x0);

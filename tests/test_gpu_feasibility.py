@@ -335,3 +335,28 @@ def test_host_callback_on_both_sets_and_errors(pkg, oracle):
     assert isinstance(ei.value.__cause__, ZeroDivisionError) and "callback" in str(ei.value)
     with pytest.raises(pkg.lib.FosError):
         pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(0.0, 1.0), object(), n))
+
+
+@pytest.mark.parametrize("algname", ["DR", "FISTA", "Dykstra"])
+def test_longstep_on_the_feasibility_form_matches_oracle(pkg, oracle, algname):
+    """LongstepWrapper (wrappers/longstep.jl) around an algorithm on the Feasibility form (fos_feas_set_longstep): saving iterations,
+    the projection onto the saved planes and the steps around them against the oracle's restatement."""
+    orc = oracle
+    A, b, hp, op = _problems(pkg, orc, m=60, n=100)
+    oalg = orc.LongstepWrapper(ALGS[algname](orc, verbose=0), longinterval=8, nsave=3)
+    omodel = orc.FeasibilityModel(op, oalg)
+    ost = orc.FeasibilityStatus(omodel, 4, 1e-30, 0, 1)
+    d = pkg.HipFeasibility(hp)
+    d.set_alg(pkg.LongstepWrapper(ALGS[algname](pkg), longinterval=8, nsave=3))
+    d.set_iterate(None)
+    xo = np.zeros(op.n)
+    for i in range(1, 27):
+        ost.i = i
+        oalg.step(xo, i, ost)
+        d.step(i, 1, 4, 1e-30)
+        z = d.get_iterate()
+        assert np.abs(z - xo).max() <= 1e-8 * max(1.0, np.abs(xo).max()), (algname, i)
+        if i % 8 == 0:
+            log = d.longstep_log()
+            assert log["iteration"] == i == oalg.log[-1][0] and log["rows"] == 8
+    assert len(oalg.log) == 3

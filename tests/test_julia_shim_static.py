@@ -1,6 +1,6 @@
 """Static cross-check of the Julia `ccall` shim (firstordersolvers.jl_amd/julia/FOSHip.jl) against include/foship.h: there is no
 Julia in the build image, so the shim has never run -- this test at least keeps every ccall's symbol, return type, argument
-types and argument count in step with the header (which grew from 40 to 79 entries over the rounds), and the CheckResult
+types and argument count in step with the header (which grew from 40 to 81 entries over the rounds), and the CheckResult
 struct in step with fos_check_result."""
 import re
 from pathlib import Path
