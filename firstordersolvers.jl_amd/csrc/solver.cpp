@@ -172,6 +172,7 @@ struct fos_solver {
 
     // direct = true (HSDE.jl:12-15): S1 = IndAffine([Q -I], 0), an exact projection through a one-time dense factorisation
     bool direct = false;
+    bool direct_cg = false;                    // direct = true on an operator too large for the dense inverse: the same projection by CG at its tolerance floor from the first call on
     double* Ginv = nullptr;                    // (I + Q Q')^-1, symmetric, column-major, leading dimension Gld (l padded to 64)
     int64_t Gld = 0;
     int direct_iters = 0;                      // Newton-Schulz iterations the set-up took
@@ -649,11 +650,12 @@ int prox_affine(fos_solver* h, const d2* x, const PostFn* post = nullptr, bool* 
     h->shift_ready = false;                                             // (SOL changes below)
     // :108-112   tol = max(0.2^sqrt(i), size(A,2)*eps())
     const double eps = 2.220446049250313e-16;
-    double tol = std::max(std::pow(0.2, std::sqrt((double)h->prox_i)), (double)h->l_global * eps);
+    double tol = std::max(h->direct_cg ? 0.0 : std::pow(0.2, std::sqrt((double)h->prox_i)), (double)h->l_global * eps);
     h->prox_i += 1;                                                     // :114
     int64_t it = 0;
-    if (fused_rhs) FOS_TRY(cg_solve(h, h->SOL, x, tol, 1000, &it, h->RHS, post, post_ran));
-    else FOS_TRY(cg_solve(h, h->SOL, h->RHS, tol, 1000, &it, nullptr, post, post_ran));          // :115-117 ; y aliases xinit (:106,:122)
+    const int64_t cap = h->direct_cg ? 10000 : 1000;                   // (:115: 1000; the exact projection is given the default cap of conjugategradients.jl:31)
+    if (fused_rhs) FOS_TRY(cg_solve(h, h->SOL, x, tol, cap, &it, h->RHS, post, post_ran));
+    else FOS_TRY(cg_solve(h, h->SOL, h->RHS, tol, cap, &it, nullptr, post, post_ran));          // :115-117 ; y aliases xinit (:106,:122)
     h->cgiter = it;                                                     // :121
     return FOS_OK;                                                      // :124 y2 .*= beta with beta = 1
 }
@@ -1812,7 +1814,11 @@ int fos_enable_direct(fos_handle h, const int64_t* colptr, const int64_t* rowval
     if (h->sharded()) { set_error("direct=true is a single-GPU mode"); return FOS_EUNSUPPORTED; }
     if (h->Ginv) { h->direct = true; return FOS_OK; }
     const int64_t l = h->l, nnz = colptr[h->n] - 1;
-    if (l > 46000) { set_error("direct=true holds dense %lld x %lld matrices: supported up to l = 46000", (long long)l, (long long)l); return FOS_EUNSUPPORTED; }
+    // beyond what a dense l x l inverse can hold, S1 = IndAffine([Q -I], 0) and S1 = AffinePlusLinear(Q, 0, 0, 1) are still the SAME set (HSDE.jl:12-15 / :22): the
+    // exact projection is what the warm-started CG converges to, so "direct" becomes CG run to its tolerance floor l eps from the first call on
+    // (no 0.2^sqrt(i) schedule: affinepluslinear.jl:108-112 is what direct = true switches off) -- the reference's sparse factorisation is not rebuilt.
+    const int64_t dense_max = getenv("FOS_DIRECT_DENSE_MAX") ? atoll(getenv("FOS_DIRECT_DENSE_MAX")) : 46000;
+    if (l > dense_max) { h->direct_cg = true; h->direct = false; return FOS_OK; }
     if (nnz != h->nnz) { set_error("fos_enable_direct: A has %lld non-zeros, the handle was created with %lld", (long long)nnz, (long long)h->nnz); return FOS_EINVAL; }
     FOS_HIP(hipSetDevice(h->device));
     LaunchCtx c = h->ctx();
@@ -1898,7 +1904,7 @@ int fos_enable_direct(fos_handle h, const int64_t* colptr, const int64_t* rowval
 
 int fos_disable_direct(fos_handle h) {
     if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
-    h->direct = false;
+    h->direct = false; h->direct_cg = false;
     return FOS_OK;
 }
 

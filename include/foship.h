@@ -175,7 +175,10 @@ int fos_reset_affine(fos_handle h);
  * four times that during set-up, ~(2 log2(lambda_max) + 14) l x l x l products) and a projection is two Q sweeps and one
  * dense symmetric matrix-vector product.  A (the arrays fos_create was given) is passed
  * again: the handle keeps only its device format.  No CG runs: fos_check_result.cgiter stays 0 and the host prints the table
- * without the cg column (HSDEStatus.jl:44-50,79).  Single-GPU handles only.  fos_disable_direct returns to CG. */
+ * without the cg column (HSDEStatus.jl:44-50,79).  Single-GPU handles only.  fos_disable_direct returns to CG.
+ * l > 46000 (C3, C4, C5): the dense inverse does not fit; IndAffine([Q -I], 0) and AffinePlusLinear(Q, 0, 0, 1) being the same set (HSDE.jl:12-15 / :22), the
+ * exact projection is then computed by the warm-started CG run to its tolerance floor l eps from the first call on (no 0.2^sqrt(i) schedule) -- the reference's
+ * sparse factorisation is not rebuilt; fos_check_result.cgiter reports the CG iterations of that projection. */
 int fos_enable_direct(fos_handle h, const int64_t* colptr, const int64_t* rowval, const double* nzval);
 int fos_disable_direct(fos_handle h);
 

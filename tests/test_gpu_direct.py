@@ -86,10 +86,47 @@ def test_direct_on_dense_lp_is_faster_than_cg_and_reaches_the_optimum(pkg):
     assert md.getobjval() == pytest.approx(float(prob.c @ prob.x0), rel=1e-2, abs=1e-4)
 
 
-def test_direct_refuses_what_it_cannot_hold(pkg):
-    prob = pkg.workloads.c3_socp()                        # l = 70 001: a dense 39 GB matrix is past the stated limit
+def test_direct_beyond_the_dense_size_is_the_same_projection_by_cg(pkg, monkeypatch):
+    """l > 46 000 (here forced: FOS_DIRECT_DENSE_MAX = 10): direct = true keeps its meaning -- the EXACT projection onto {Q u = v} from the
+    first call on -- computed by the warm-started CG at its tolerance floor instead of the 0.2^sqrt(i) schedule.  Against the oracle's
+    IndAffineDirect from the FIRST call (the scheduled CG is five orders of magnitude off there), and on C3 itself (l = 70 001)."""
+    monkeypatch.setenv("FOS_DIRECT_DENSE_MAX", "10")
+    prob = pkg.workloads.small_mixed()
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
-    with pytest.raises(pkg.lib.FosError) as e:
-        d.enable_direct(prob.A)
-    assert "46000" in str(e.value)
+    d.enable_direct(prob.A)
+    S1 = orc.IndAffineDirect(orc.HSDEMatrixQ(prob.A, prob.b, prob.c))
+    rng = np.random.default_rng(4)
+    for k in range(3):
+        x = rng.standard_normal(d.N) * (1.0 if k < 2 else 1e3)
+        ref = np.empty(d.N)
+        S1.prox(ref, x)
+        y = d.prox_affine(x)
+        assert np.linalg.norm(y - ref) <= 1e-9 * np.linalg.norm(ref), k
+        assert d.cgiter() > 0
+    # first iterations of a solve follow the oracle's direct = true solve
+    oalg = orc.DR(direct=True)
+    mo = _omodel(prob)
+    oalg.init(mo)
+    xo = orc.hsde_initialvalue(mo)
+    st = orc.HSDEStatus(mo, 10 ** 9, 1e-9, 0, 1, S1=oalg.S1)
+    d.set_alg(pkg.DR(direct=True))
+    d.set_iterate(None)
+    d.reset_affine()
+    for i in range(1, 11):
+        st.i = i
+        oalg.step(xo, i, st)
+        d.step(i, 1, 10 ** 9, 1e-9)
+        assert np.linalg.norm(d.get_iterate() - xo) <= 1e-8 * max(1.0, np.linalg.norm(xo)), i
+    d.close()
+    monkeypatch.delenv("FOS_DIRECT_DENSE_MAX")
+    prob = pkg.workloads.c3_socp()                        # l = 70 001: a dense 39 GB inverse is past the limit -> CG at the floor
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d.enable_direct(prob.A)
+    x = np.random.default_rng(1).standard_normal(d.N)
+    y = d.prox_affine(x)
+    l = d.l
+    assert np.linalg.norm(d.q_apply(y[:l]) - y[l:]) <= 1e-9 * np.linalg.norm(y)                      # on the set
+    u = np.random.default_rng(2).standard_normal(l)
+    t = np.concatenate([u, d.q_apply(u)])
+    assert abs((x - y) @ t) <= 1e-8 * np.linalg.norm(t) * np.linalg.norm(x)                          # displacement orthogonal to it
     d.close()
