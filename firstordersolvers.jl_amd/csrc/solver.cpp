@@ -1322,7 +1322,9 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
         // sweep with 256 workgroups, 122 us with one workgroup per panel)
         int nwg = std::min<int>((int)hs.wpanel.size(), cus * hs.wgeom.wg_per_cu);
         if (const char* e = getenv("FOS_SPMV_WG")) nwg = std::max(1, std::min<int>(atoi(e), (int)hs.wpanel.size()));
-        if (nwg >= 8) nwg -= nwg % 8;
+        // (a multiple of 8 lets xcd_remap give every XCD a contiguous run of panels -- but never at the price of a workgroup walking two
+        //  panels while others walk one: with fewer panels than slots every panel gets its own workgroup, remapped or not)
+        if (nwg >= 8 && (int)hs.wpanel.size() > nwg) nwg -= nwg % 8;
         hs.nwg = nwg;
     }
     h->S.npanel = (int32_t)hs.wpanel.size();
