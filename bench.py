@@ -192,7 +192,15 @@ def main():
         reduction = "in-stream RCCL all-reduce"
         peer_reason = None             # why the peer mailboxes are NOT the transport (None: they are, or there is one rank)
         t0 = time.time()
-        prob, alg, desc, glob = build_problem(pkg, args.workload, world, rank, args.small, weak=weak, c4_scale=args.c4_scale)
+        # FOS_BENCH_SHARD="k/N" (with FOS_FORCE_DIST=1, one process): rank k's shard of an N-rank run on this GPU, in the sharded code path -- what an N-GPU
+        # run's ranks would each step (no hop between devices is paid: a projection, labelled as such in config.workload)
+        emu = os.environ.get("FOS_BENCH_SHARD") if world == 1 else None
+        if emu:
+            ek, en = (int(v) for v in emu.split("/"))
+            prob, alg, desc, glob = build_problem(pkg, args.workload, en, ek, args.small, weak=weak, c4_scale=args.c4_scale)
+            desc += " [shard %d of %d, alone on this GPU]" % (ek, en)
+        else:
+            prob, alg, desc, glob = build_problem(pkg, args.workload, world, rank, args.small, weak=weak, c4_scale=args.c4_scale)
         t_gen = time.time() - t0
         t0 = time.time()
         dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2, device=local_rank)
