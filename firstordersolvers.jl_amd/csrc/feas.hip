@@ -90,16 +90,6 @@ __global__ __launch_bounds__(FEAS_THREADS) void feas_normdiff_kernel(int64_t n, 
     FEAS_STRIDE(i, n) { const double d = a[i] - b[i]; acc[0] += d * d; }
     feas_block_store<1>(acc, partials);
 }
-// normedScalar(t2, t1, t1, x): partial sums of <d1, d2>, |d1|^2, |d2|^2 with d1 = t2 - t1, d2 = t1 - x      gapa.jl:36-47,96
-__global__ __launch_bounds__(FEAS_THREADS) void feas_triple_kernel(int64_t n, const double* __restrict__ t2, const double* __restrict__ t1,
-                                                                   const double* __restrict__ x, double* __restrict__ partials) {
-    double acc[3] = {0.0, 0.0, 0.0};
-    FEAS_STRIDE(i, n) {
-        const double d1 = t2[i] - t1[i], d2 = t1[i] - x[i];
-        acc[0] += d1 * d2; acc[1] += d1 * d1; acc[2] += d2 * d2;
-    }
-    feas_block_store<3>(acc, partials);
-}
 // alpha12 = (1 - beta) 2 / (1 + sqrt(1 - scl^2)) + 2 beta,  scl = clamp(|s| / sqrt(n1 n2), 0, 1), NaN -> 0      gapa.jl:96-101
 __global__ void feas_alpha12_kernel(const double* __restrict__ partials, int nparts, double beta, double* __restrict__ a12) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -110,6 +100,36 @@ __global__ void feas_alpha12_kernel(const double* __restrict__ partials, int npa
     scl = fmin(fmax(scl, 0.0), 1.0);
     const double aopt = 2.0 / (1.0 + sqrt(1.0 - scl * scl));
     *a12 = (1.0 - beta) * aopt + beta * 2.0;
+}
+// checkstatus in ONE pass (FeasibilityStatus.jl:40,61,69): partial sums of |prev - z|^2 when this iteration checks, and prev = z -- every call
+__global__ __launch_bounds__(FEAS_THREADS) void feas_check_kernel(int64_t n, double* __restrict__ prev, const double* __restrict__ z, int do_norm,
+                                                                  double* __restrict__ partials) {
+    double acc[1] = {0.0};
+    if (do_norm) {
+        FEAS_STRIDE(i, n) { const double zi = z[i], d = prev[i] - zi; acc[0] += d * d; prev[i] = zi; }
+        feas_block_store<1>(acc, partials);
+    } else {
+        FEAS_STRIDE(i, n) prev[i] = z[i];
+    }
+}
+// the tail of a GAP / GAPA step in ONE pass: t2 = a2 t2 + (1 - a2) t1 (gap.jl:58, gapa.jl:77; a2 = alpha12 from the device for GAPA), for GAPA the
+// partial sums of normedScalar(t2, t1, t1, x) on the relaxed t2 and the OLD x (gapa.jl:96), then x = alpha t2 + (1 - alpha) x (gap.jl:78, gapa.jl:103)
+template <bool GAPA>
+__global__ __launch_bounds__(FEAS_THREADS) void feas_gap_tail_kernel(int64_t n, double* __restrict__ x, double* __restrict__ t2, const double* __restrict__ t1,
+                                                                     double a2, const double* __restrict__ a_dev, double alpha, double* __restrict__ partials) {
+    const double aa = a_dev ? *a_dev : a2;
+    double acc[3] = {0.0, 0.0, 0.0};
+    FEAS_STRIDE(i, n) {
+        const double t1i = t1[i], xi = x[i];
+        const double t2i = aa * t2[i] + (1.0 - aa) * t1i;
+        t2[i] = t2i;
+        if constexpr (GAPA) {
+            const double d1 = t2i - t1i, d2 = t1i - xi;
+            acc[0] += d1 * d2; acc[1] += d1 * d1; acc[2] += d2 * d2;
+        }
+        x[i] = alpha * t2i + (1.0 - alpha) * xi;
+    }
+    if constexpr (GAPA) feas_block_store<3>(acc, partials);
 }
 // x = alpha t2 + (1 - alpha) x      gap.jl:78, gapa.jl:103
 __global__ __launch_bounds__(FEAS_THREADS) void feas_combine_kernel(int64_t n, double* __restrict__ x, const double* __restrict__ t2, double alpha) {
@@ -259,7 +279,7 @@ int feas_prox(fos_feas* h, int which, double* y, const double* x) {
 // checkstatus(stat, z) at iteration i      FeasibilityStatus.jl:32-72
 int feas_check(fos_feas* h, const double* z, int64_t i, int64_t checki, double eps, bool override_) {
     if (override_ || (checki > 0 && i % checki == 0)) {
-        FEAS_K(feas_normdiff_kernel, h->n, (const double*)h->prev, z, h->partials);
+        FEAS_K(feas_check_kernel, h->n, h->prev, z, 1, h->partials);                   // |prev - z|^2 and prev = z in one pass
         std::vector<double> part((size_t)h->grid);
         FOS_HIP(hipMemcpyAsync(part.data(), h->partials, sizeof(double) * h->grid, hipMemcpyDeviceToHost, h->stream));
         FOS_HIP(hipStreamSynchronize(h->stream));
@@ -268,8 +288,10 @@ int feas_check(fos_feas* h, const double* z, int64_t i, int64_t checki, double e
         h->err = std::sqrt(s);
         h->status = (h->err <= eps) ? FOS_STATUS_OPTIMAL : FOS_STATUS_CONTINUE;       // :57 (NaN <= eps is false)
         h->checked = 1;
-    } else h->checked = 0;
-    FEAS_K(feas_copy_kernel, h->n, h->prev, z);                                        // :61,69: every call
+    } else {
+        h->checked = 0;
+        FEAS_K(feas_check_kernel, h->n, h->prev, z, 0, h->partials);                   // :61,69: prev = z at every call
+    }
     return FOS_OK;
 }
 
@@ -371,12 +393,12 @@ int feas_step_once(fos_feas* h, int64_t i, int64_t checki, double eps) {
         FOS_TRY(feas_prox(h, 1, h->t2, h->t1));                                        // S2!  gap.jl:53-59, gapa.jl:72-78
         FOS_TRY(feas_check(h, h->t2, i, checki, eps, false));
         feas_long_save(h, 1, h->t2, h->t1);                                            // addprojineq(longstep, y, x)
-        FEAS_K(feas_relax_kernel, n, h->t2, (const double*)h->t1, h->alpha2, a12);
-        if (ad) {                                                                      // gapa.jl:96-101 (relaxed t1, t2 and the old x)
-            FEAS_K(feas_triple_kernel, n, (const double*)h->t2, (const double*)h->t1, (const double*)h->x, h->partials);
-            hipLaunchKernelGGL(feas_alpha12_kernel, dim3(1), dim3(64), 0, h->stream, (const double*)h->partials, h->grid, h->beta, h->a12);
+        if (ad) {                                                                      // relaxation, the sums of gapa.jl:96 (relaxed t1, t2 and the old x) and x's update: one pass
+            FEAS_K(feas_gap_tail_kernel<true>, n, h->x, h->t2, (const double*)h->t1, h->alpha2, a12, h->alpha, h->partials);
+            hipLaunchKernelGGL(feas_alpha12_kernel, dim3(1), dim3(64), 0, h->stream, (const double*)h->partials, h->grid, h->beta, h->a12);    // gapa.jl:96-101
+        } else {
+            FEAS_K(feas_gap_tail_kernel<false>, n, h->x, h->t2, (const double*)h->t1, h->alpha2, a12, h->alpha, h->partials);                  // gap.jl:58,78
         }
-        FEAS_K(feas_combine_kernel, n, h->x, (const double*)h->t2, h->alpha);          // gap.jl:78, gapa.jl:103
         break;
     }
     case FOS_ALG_FISTA: {                                                              // fista.jl:28-48
