@@ -18,7 +18,7 @@ rc = lib.fos_debug_win_stamps(buf, NW * 64 * 8)
 if rc != 0:
     sys.exit("library built without -DFOS_WIN_STAMPS (rc %d)" % rc)
 st = np.array(buf[:], dtype=np.int64).reshape(NW, 64, 8)
-nseg = int((st[0, :, 0] > 0).sum())
+nseg = int((st[0, :63, 0] > 0).sum())                       # (slot 63 holds the kernel-level stamps)
 print("segments stamped:", nseg)
 names = ["issue loads", "barrier 1", "wait + window -> LDS", "barrier 2", "multiply + row sums", "loop tail -> next"]
 for w in range(NW):
