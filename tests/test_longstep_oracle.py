@@ -85,3 +85,17 @@ def test_wrapped_solve_runs_the_projection_every_interval(pkg, oracle):
     sol = orc.solve(mo, w)
     assert sol.status in ("Optimal", "Indeterminate")
     assert [i for i, _ in w.log] == list(range(50, 601, 50)) and max(v for _, v in w.log) <= 1e-10
+
+
+def test_python_mirror_wrapper_class(pkg):
+    """The host mirror's LongstepWrapper (interface.py): what the reference's constructor does (longstep.jl:22-24, 28) -- options merged with the
+    wrapped algorithm's winning, the algorithm's code and relaxation parameters handed on, GAPP refused."""
+    w = pkg.LongstepWrapper(pkg.GAPA(0.8, 0.5, eps=1e-7, checki=10), longinterval=50, nsave=3, eps=1e-3, verbose=0)
+    assert (w.longinterval, w.nsave) == (50, 3)
+    assert w.options["eps"] == 1e-7 and w.options["checki"] == 10 and w.options["verbose"] == 0      # [kwargs..., alg.options...]: the algorithm's win
+    assert w._alg_args() == w.alg._alg_args() and w.direct == w.alg.direct
+    for bad in (pkg.GAPP(),):
+        with pytest.raises(ValueError):
+            pkg.LongstepWrapper(bad)
+    for ok in (pkg.DR(), pkg.AP(), pkg.GAP(), pkg.FISTA(), pkg.Dykstra()):
+        pkg.LongstepWrapper(ok)

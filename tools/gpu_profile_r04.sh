@@ -19,6 +19,9 @@ run c4_shard64_dist1rank FOS_FORCE_DIST=1 -- --small --no-cpu-baseline
 run c4_shard64_dist1rank_rccl FOS_FORCE_DIST=1 FOS_REDUCTION=rccl -- --small --no-cpu-baseline
 run c4_shard64_jacobi FOS_FORCE_DIST=1 FOS_PSD_REFINE=0 -- --small --no-cpu-baseline
 run c3_reference FOS_CG_VARIANT=0 -- --workload C3 --no-cpu-baseline
+# one rank's shard of an N-rank run of C5 alone on the GPU, in the sharded code path (a projection: no hop between devices is paid)
+run c5_shard1of2_dist1rank FOS_FORCE_DIST=1 FOS_BENCH_SHARD=0/2 -- --workload C5 --no-cpu-baseline
+run c5_shard1of8_dist1rank FOS_FORCE_DIST=1 FOS_BENCH_SHARD=0/8 -- --workload C5 --no-cpu-baseline
 run c4_shard64_dist1rank_unfused FOS_FORCE_DIST=1 FOS_PSD_FUSE=0 -- --small --no-cpu-baseline
 # two ranks of the full C4 on the ONE GPU of the box (host coordination over gloo, sums through the peer mailboxes): residuals of the single-rank run.
 # (Eight ranks of the full problem cannot share one GPU: a rank's update kernel spins for its peers' mailbox words, and eight such grids do not fit the
