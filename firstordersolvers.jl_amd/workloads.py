@@ -148,13 +148,19 @@ def from_complementary_pair(name, A, K1, K2, rng, meta=None, normalize=True):
 # ---------------------------------------------------------------------------- configs
 
 
-def c1_readme_nnls(seed=0, m=40, n=50):
+def c1_readme_nnls(seed=0, m=40, n=50, data=None):
     """C1: README least squares  min ||Ax-b||^2 s.t. x >= 0  (README.md:21-26, test/testDRandGAPA.jl:4-8),
     emitted directly in conic form: vars (x, t, w), min w,
-    (t, Ax-b) in SOC(m+1), (w+1, w-1, 2t) in SOC(3), x in NonNeg(n); K2 = Free."""
-    rng = np.random.default_rng(seed)
-    Ad = rng.standard_normal((m, n))
-    bd = rng.standard_normal(m)
+    (t, Ax-b) in SOC(m+1), (w+1, w-1, 2t) in SOC(3), x in NonNeg(n); K2 = Free.
+    `data=(A, b)` takes the dense data from the caller (the reference's own draws, tests/golden/reference_test_inputs.npz)."""
+    if data is not None:
+        Ad = np.asarray(data[0], dtype=np.float64)
+        bd = np.asarray(data[1], dtype=np.float64).reshape(-1)
+        m, n = Ad.shape
+    else:
+        rng = np.random.default_rng(seed)
+        Ad = rng.standard_normal((m, n))
+        bd = rng.standard_normal(m)
     nv = n + 2
     it, iw = n, n + 1
     rows, cols, vals = [], [], []

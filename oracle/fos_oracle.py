@@ -24,14 +24,19 @@ ProximalOperators.jl (Project.toml:10, version UNPINNED, no Manifest).  They are
 here from that package's published algorithm (IndFree/IndZero/IndPoint/IndNonnegative/
 IndNonpositive/IndSOC/IndRotatedSOC/IndPSD(scaling=true)/IndExpPrimal/IndExpDual).  Pinning status:
   * IndPSD: pinned by the reference's RNG-free known answer test/testPSD.jl:3-4,14-25.
-  * IndNonnegative / Zero / Free: pinned through the DR/GAPA solves of test/testDRandGAPA.jl
-    (problem shape; Julia's RNG stream is unavailable, optimum checked with scipy nnls).
-  * IndSOC / IndRotatedSOC / IndExpPrimal / IndExpDual: PARITY UNPINNED -- no reference test touches them
+  * IndNonnegative / Zero / Free / IndSOC (the two second-order cones of the NNLS epigraph form): pinned through the
+    DR/GAPA solves of test/testDRandGAPA.jl ON THE REFERENCE'S OWN DATA -- oracle/julia_random.py restates Julia's
+    MersenneTwister + randn, the regenerated `Random.seed!(2)` inputs reproduce the file's literal optima
+    (12.38418747141913 to 3e-15), and the solves meet every assertion and threshold of that file
+    (tests/test_reference_known_answers.py).  IndAffine / IndBox and the Feasibility form's stopping rule: pinned the
+    same way by the seven data-dependent outcomes of test/testfeasibility.jl.
+  * IndRotatedSOC / IndExpPrimal / IndExpDual: PARITY UNPINNED -- no reference test touches them
     (the exponential cone follows the SCS-style bisection + Newton projection; checked here only through the
     projection's optimality conditions).
 The Julia reference itself cannot be executed in the build container (no julia binary), so
 the oracle is pinned against the reference's own tests restated in tests/test_oracle_*.py
-(identities vs dense linear algebra, CG property test, PSD known answer, print formats).
+(identities vs dense linear algebra, CG property test, PSD known answer, print formats) and, for whole solves,
+against the literals and outcomes those tests hold for seeded data (tests/test_reference_known_answers.py).
 
 Indices are 0-based here; the z layout is the reference's  [x(n); y(m); tau; r(n); s(m); kappa]
 (src/cones.jl:126-141, src/problemforms/HSDE/HSDEStatus.jl:93-101).

@@ -1,5 +1,6 @@
 """Seeded instances of the reference's Feasibility test (test/testfeasibility.jl:4-12: IndAffine(A, b) n IndBox(0, Inf) with
-b = A xsol; the reference's literal data is bound to Julia's RNG, so the shape is kept and the numbers are numpy's)."""
+b = A xsol) with numpy's numbers; the reference's literal draw and its outcomes are in tests/test_reference_known_answers.py
+and tests/test_gpu_known_answers.py)."""
 import numpy as np
 
 

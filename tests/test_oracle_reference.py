@@ -1,8 +1,9 @@
 """
 Pins the oracle (oracle/fos_oracle.py) against the reference's OWN tests, restated.
 Every test cites the reference test file it follows (paths under /root/reference).
-Julia's RNG stream is not reproducible here, so where the reference test is an identity or a
-property (any seed), it is run on numpy data; RNG-free literals are used verbatim.
+Where the reference test is an identity or a property (any seed) it is run on numpy data; RNG-free literals are
+used verbatim.  The literals that depend on Julia's seeded draws (the NNLS optima, the feasibility test's outcomes)
+are in tests/test_reference_known_answers.py, on the regenerated draws.
 CPU only (no gpu marker).
 """
 import math
@@ -231,7 +232,8 @@ def nnls(pkg):
 
 def test_readme_nnls_dr(nnls):
     """test/testDRandGAPA.jl:9-23: DR(eps=1e-8) -> :Optimal, optval, min(x) > -10 eps.
-    (The literal optimum depends on Julia's randn stream; scipy.optimize.nnls is the oracle here.)"""
+    (numpy data, scipy.optimize.nnls as the optimum; the reference's literal optimum on the reference's own draw is
+    checked in tests/test_reference_known_answers.py.)"""
     prob, model, xs, opt = nnls
     eps = 1e-8
     lines = []
