@@ -30,9 +30,11 @@ IndNonpositive/IndSOC/IndRotatedSOC/IndPSD(scaling=true)/IndExpPrimal/IndExpDual
     (12.38418747141913 to 3e-15), and the solves meet every assertion and threshold of that file
     (tests/test_reference_known_answers.py).  IndAffine / IndBox and the Feasibility form's stopping rule: pinned the
     same way by the seven data-dependent outcomes of test/testfeasibility.jl.
-  * IndRotatedSOC / IndExpPrimal / IndExpDual: PARITY UNPINNED -- no reference test touches them
-    (the exponential cone follows the SCS-style bisection + Newton projection; checked here only through the
-    projection's optimality conditions).
+  * IndRotatedSOC / IndExpPrimal / IndExpDual: PARITY UNPINNED upstream -- no reference test touches them
+    (the exponential cone follows the SCS-style bisection + Newton projection).  What is checked instead, both
+    independent of this file: the projections' optimality conditions (tests/cone_certificates.py) and CLOSED-FORM optima
+    of textbook programs over these cones in MathProgBase's conventions (entry order, 2pq, the e of the dual cone:
+    tests/analytic_cases.py, reached by this oracle and by the HIP path to 1e-8).
 The Julia reference itself cannot be executed in the build container (no julia binary), so
 the oracle is pinned against the reference's own tests restated in tests/test_oracle_*.py
 (identities vs dense linear algebra, CG property test, PSD known answer, print formats) and, for whole solves,

@@ -73,3 +73,22 @@ def test_testfeasibility_outcomes_on_the_hip_path(pkg):
         assert sol.status == "Optimal", type(alg).__name__                              # :41
         assert sol.x.min() > -1e-12                                                     # :42
         assert np.abs(A @ sol.x - b).max() < 1e-6                                       # :43
+
+
+def _analytic_cases():
+    from analytic_cases import cases
+    return cases()
+
+
+@pytest.mark.parametrize("cs", _analytic_cases(), ids=[c["name"] for c in _analytic_cases()])
+def test_closed_form_optima_on_the_hip_path(pkg, cs):
+    """Textbook conic programs with closed-form optima (tests/analytic_cases.py): second-order, ROTATED second-order, primal and dual
+    EXPONENTIAL cones and svec'd PSD, as row cones and as variable cones, through fos_create / fos_iterate -- the cone conventions of
+    `conemap` (src/cones.jl:4-14) pinned at whole-solve level without the oracle."""
+    prob = pkg.workloads.ConicProblem(cs["name"], cs["A"], cs["b"], cs["c"], cs["K1"], cs["K2"])
+    model = pkg.solve(prob, pkg.DR(eps=1e-8, verbose=0, max_iters=20000))
+    assert model.status() == "Optimal"
+    assert abs(model.getobjval() - cs["opt"]) < 1e-8 * max(1.0, abs(cs["opt"]))
+    assert np.abs(model.getsolution() - cs["x"]).max() < 1e-7
+    for w in cs["wrong"]:
+        assert abs(model.getobjval() - w) > 1e-3
