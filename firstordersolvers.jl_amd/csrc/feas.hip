@@ -710,8 +710,8 @@ int fos_feas_set_longstep(fos_feas_handle h, int64_t longinterval, int64_t nsave
         double* q = nullptr;
         FOS_TRY(feas_alloc(h, &q, (size_t)K * h->L)); h->lp.P = reinterpret_cast<double2*>(q);
         FOS_TRY(feas_alloc(h, &h->lp.bpart, (size_t)K * h->grid));
-        FOS_TRY(feas_alloc(h, &h->lp.dots, (size_t)h->grid * (LONG_KMAX_ROWS + 1)));
-        FOS_TRY(feas_alloc(h, &h->lp.nu, (size_t)K));
+        FOS_TRY(feas_alloc(h, &h->lp.dots, (size_t)h->grid * 2 * (LONG_KMAX_ROWS + 1)));
+        FOS_TRY(feas_alloc(h, &h->lp.nu, (size_t)2 * K));
     }
     h->lp.interval = longinterval; h->lp.nsave = nsave; h->lp.savepos = 0; h->lp.now = false;
     return FOS_OK;

@@ -421,15 +421,15 @@ struct LongPlanes {
     bool now = false;                  // the iteration in flight saves planes
     double2* P = nullptr;              // [2 (nsave + 1)][l] saved rows x - y, in the reference's row order (equality, inequality, equality, ...)
     double* bpart = nullptr;           // [rows][vec_blocks] partial sums of the offsets (x - y).y
-    double* dots = nullptr;            // [vec_blocks][33] scratch of the Gram products
-    double* nu = nullptr;              // [rows] multipliers, device copy
+    double* dots = nullptr;            // [vec_blocks][33][hi, lo] scratch of the Gram products (double-double)
+    double* nu = nullptr;              // [rows][hi, lo] multipliers, device copy
     double log[8] = {0};               // last projection: iteration, active inequalities, KKT violation, |x_new - x|, rows, supports tried
 };
 struct LaunchCtx;
 void long_save_plane(const LaunchCtx& c, LongPlanes& lp, int which, const double2* y, const double2* x);      // addprojeq (0) / addprojineq (1) at lp.savepos
 int long_project_planes(const LaunchCtx& c, LongPlanes& lp, double2* X, int64_t i);                          // projectonnormals! + x .= tmp   (solver.cpp)
 void launch_long_plane(const LaunchCtx& c, double2* row, const double2* x, const double2* y, double* bpart);          // row = x - y; bpart[blocks]: partial sums of (x - y).y
-void launch_long_dots(const LaunchCtx& c, const double2* P, int K, int a, const double2* x, double* out);              // out[blocks][33]: row_a . row_{a+k}, k < 32; [32]: row_a . x
+void launch_long_dots(const LaunchCtx& c, const double2* P, int K, int a, const double2* x, double* out);              // out[blocks][33][hi, lo]: row_a . row_{a+k}, k < 32; [32]: row_a . x (double-double)
 void launch_long_apply(const LaunchCtx& c, double2* x, const double2* P, int K, const double* nu);                     // x += sum_k nu[k] row_k
 void launch_normdiff(const LaunchCtx& c, const double2* x, const double2* y);   // c.partials[0 .. vec_blocks) = partial sums of |x - y|^2
 void launch_shift_part2(const LaunchCtx& c, double2* out, const double2* y, const double2* x);   // out = (y.x, y.y - x.y)

@@ -845,51 +845,85 @@ int long_begin(fos_solver* h, int64_t i, const d2** check_on) {
 // solved on the host: the inequality multipliers by enumeration of their support (<= 2^16 candidate supports; each a K x K symmetric system
 // by eigen-decomposition, singular ones -- parallel planes -- through the pseudo-inverse); a support is accepted when its multipliers are
 // non-negative and the inequalities outside it hold.  Only G, P x and beta leave the device; x += P' nu runs there.
-static void sym_eig_jacobi(int n, std::vector<double>& A, std::vector<double>& V) {      // A (n x n, row-major) -> eigenvalues on its diagonal, eigenvectors in the columns of V
-    V.assign((size_t)n * n, 0.0);
-    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0, diag = 0.0;
+// 113-bit arithmetic for the small dual QP of the LongstepWrapper (the reference solves it in BigFloat, saveplanes.jl:24)
+typedef __float128 qreal;
+static inline qreal qabs(qreal x) { return x < 0 ? -x : x; }
+static inline qreal qsqrt(qreal x) {
+    if (!(x > 0)) return 0;
+    qreal y = (qreal)sqrtl((long double)x);
+    y = (y + x / y) / 2; y = (y + x / y) / 2;
+    return y;
+}
+static void sym_eig_jacobi(int n, std::vector<qreal>& A, std::vector<qreal>& V) {      // A (n x n, row-major) -> eigenvalues on its diagonal, eigenvectors in the columns of V
+    V.assign((size_t)n * n, (qreal)0);
+    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1;
+    for (int sweep = 0; sweep < 80; ++sweep) {
+        qreal off = 0, diag = 0;
         for (int i = 0; i < n; ++i) { diag += A[(size_t)i * n + i] * A[(size_t)i * n + i]; for (int j = i + 1; j < n; ++j) off += A[(size_t)i * n + j] * A[(size_t)i * n + j]; }
-        if (off <= 1e-60 + 1e-32 * diag) break;
+        if (off <= (qreal)1e-64 * diag || off == 0) break;
         for (int p = 0; p < n; ++p)
             for (int q = p + 1; q < n; ++q) {
-                const double apq = A[(size_t)p * n + q];
-                if (apq == 0.0) continue;
-                const double theta = (A[(size_t)q * n + q] - A[(size_t)p * n + p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                const qreal apq = A[(size_t)p * n + q];
+                if (apq == 0) continue;
+                const qreal theta = (A[(size_t)q * n + q] - A[(size_t)p * n + p]) / (2 * apq);
+                const qreal t = (theta >= 0 ? (qreal)1 : (qreal)-1) / (qabs(theta) + qsqrt(theta * theta + 1));
+                const qreal cs = 1 / qsqrt(t * t + 1), sn = t * cs;
                 for (int k = 0; k < n; ++k) {
-                    const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+                    const qreal akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
                     A[(size_t)k * n + p] = cs * akp - sn * akq; A[(size_t)k * n + q] = sn * akp + cs * akq;
                 }
                 for (int k = 0; k < n; ++k) {
-                    const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+                    const qreal apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
                     A[(size_t)p * n + k] = cs * apk - sn * aqk; A[(size_t)q * n + k] = sn * apk + cs * aqk;
                 }
                 for (int k = 0; k < n; ++k) {
-                    const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+                    const qreal vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
                     V[(size_t)k * n + p] = cs * vkp - sn * vkq; V[(size_t)k * n + q] = sn * vkp + cs * vkq;
                 }
             }
     }
 }
-// nu_F = pinv(G_FF) c_F on the index set F, zero elsewhere
-static void long_solve_support(int K, const std::vector<double>& G, const std::vector<double>& cvec, const std::vector<int>& F, std::vector<double>& nu) {
+// nu_F = pinv(G_FF) c_F on the index set F, zero elsewhere.  Cholesky first (a few thousand 113-bit operations); a pivot below 1e-26 of the
+// trace = dependent planes -> the pseudo-inverse through the eigendecomposition (eigenvalues below that cut dropped)
+static void long_solve_support(int K, const std::vector<qreal>& G, const std::vector<qreal>& cvec, const std::vector<int>& F, std::vector<qreal>& nu) {
     const int nf = (int)F.size();
-    nu.assign((size_t)K, 0.0);
+    nu.assign((size_t)K, (qreal)0);
     if (nf == 0) return;
-    std::vector<double> A((size_t)nf * nf), V;
-    double tr = 0.0;
+    std::vector<qreal> A((size_t)nf * nf), V;
+    qreal tr = 0;
     for (int i = 0; i < nf; ++i) { for (int j = 0; j < nf; ++j) A[(size_t)i * nf + j] = G[(size_t)F[i] * K + F[j]]; tr += A[(size_t)i * nf + i]; }
+    const qreal cut = (qreal)1e-26 * (tr > 0 ? tr : (qreal)1e-300);
+    {
+        std::vector<qreal> L(A);
+        bool ok = true;
+        for (int j = 0; j < nf && ok; ++j) {
+            qreal dj = L[(size_t)j * nf + j];
+            for (int k = 0; k < j; ++k) dj -= L[(size_t)j * nf + k] * L[(size_t)j * nf + k];
+            if (!(dj > cut)) { ok = false; break; }
+            const qreal ljj = qsqrt(dj);
+            L[(size_t)j * nf + j] = ljj;
+            for (int i = j + 1; i < nf; ++i) {
+                qreal v = L[(size_t)i * nf + j];
+                for (int k = 0; k < j; ++k) v -= L[(size_t)i * nf + k] * L[(size_t)j * nf + k];
+                L[(size_t)i * nf + j] = v / ljj;
+            }
+        }
+        if (ok) {
+            std::vector<qreal> y((size_t)nf);
+            for (int i = 0; i < nf; ++i) { qreal v = cvec[(size_t)F[i]]; for (int k = 0; k < i; ++k) v -= L[(size_t)i * nf + k] * y[(size_t)k]; y[(size_t)i] = v / L[(size_t)i * nf + i]; }
+            for (int i = nf - 1; i >= 0; --i) { qreal v = y[(size_t)i]; for (int k = i + 1; k < nf; ++k) v -= L[(size_t)k * nf + i] * y[(size_t)k]; y[(size_t)i] = v / L[(size_t)i * nf + i]; }
+            for (int i = 0; i < nf; ++i) nu[(size_t)F[i]] = y[(size_t)i];
+            return;
+        }
+    }
     sym_eig_jacobi(nf, A, V);
-    const double cut = 1e-13 * std::max(tr, 1e-300);
     for (int e = 0; e < nf; ++e) {
-        const double lam = A[(size_t)e * nf + e];
+        const qreal lam = A[(size_t)e * nf + e];
         if (!(lam > cut)) continue;
-        double proj = 0.0;
+        qreal proj = 0;
         for (int i = 0; i < nf; ++i) proj += V[(size_t)i * nf + e] * cvec[(size_t)F[i]];
-        for (int i = 0; i < nf; ++i) nu[(size_t)F[i]] += V[(size_t)i * nf + e] * proj / lam;
+        proj /= lam;
+        for (int i = 0; i < nf; ++i) nu[(size_t)F[i]] += V[(size_t)i * nf + e] * proj;
     }
 }
 int long_project(fos_solver* h, int64_t i) {
@@ -1143,30 +1177,33 @@ namespace fos {
 int long_project_planes(const LaunchCtx& c, LongPlanes& lp, d2* X, int64_t i) {
     const int K = (int)(2 * (lp.nsave + 1)), neq = (int)(lp.nsave + 1), nin = K - neq;
     const int nb = c.vec_blocks;
-    std::vector<double> G((size_t)K * K, 0.0), Px((size_t)K, 0.0), beta((size_t)K, 0.0);
-    std::vector<double> part((size_t)nb * (LONG_KMAX_ROWS + 1)), bp((size_t)K * nb);
+    const size_t W = 2 * (LONG_KMAX_ROWS + 1);                                // (hi, lo) pairs per workgroup
+    std::vector<qreal> G((size_t)K * K, (qreal)0), Px((size_t)K, (qreal)0), beta((size_t)K, (qreal)0);
+    std::vector<double> part((size_t)nb * W), bp((size_t)K * nb);
     for (int a = 0; a < K; ++a) {
         launch_long_dots(c, lp.P, K, a, X, lp.dots);
         FOS_HIP(hipMemcpyAsync(part.data(), lp.dots, sizeof(double) * part.size(), hipMemcpyDeviceToHost, c.stream));
         FOS_HIP(hipStreamSynchronize(c.stream));
         for (int k = 0; a + k < K; ++k) {
-            double sacc = 0.0;
-            for (int b = 0; b < nb; ++b) sacc += part[(size_t)b * (LONG_KMAX_ROWS + 1) + k];
+            qreal sacc = 0;
+            for (int b = 0; b < nb; ++b) sacc += (qreal)part[(size_t)b * W + 2 * k] + (qreal)part[(size_t)b * W + 2 * k + 1];
             G[(size_t)a * K + a + k] = G[(size_t)(a + k) * K + a] = sacc;
         }
-        double sx = 0.0;
-        for (int b = 0; b < nb; ++b) sx += part[(size_t)b * (LONG_KMAX_ROWS + 1) + LONG_KMAX_ROWS];
+        qreal sx = 0;
+        for (int b = 0; b < nb; ++b) sx += (qreal)part[(size_t)b * W + 2 * LONG_KMAX_ROWS] + (qreal)part[(size_t)b * W + 2 * LONG_KMAX_ROWS + 1];
         Px[(size_t)a] = sx;
     }
     FOS_HIP(hipMemcpyAsync(bp.data(), lp.bpart, sizeof(double) * bp.size(), hipMemcpyDeviceToHost, c.stream));
     FOS_HIP(hipStreamSynchronize(c.stream));
-    for (int a = 0; a < K; ++a) { double sacc = 0.0; for (int b = 0; b < nb; ++b) sacc += bp[(size_t)a * nb + b]; beta[(size_t)a] = sacc; }
-    std::vector<double> cvec((size_t)K);
+    // (the offsets b = (x - y).y are float64 sums in the reference too, longstep.jl:71-75: data of the QP, not part of its solution)
+    for (int a = 0; a < K; ++a) { double sacc = 0.0; for (int b = 0; b < nb; ++b) sacc += bp[(size_t)a * nb + b]; beta[(size_t)a] = (qreal)sacc; }
+    std::vector<qreal> cvec((size_t)K);
     for (int a = 0; a < K; ++a) cvec[(size_t)a] = beta[(size_t)a] - Px[(size_t)a];
-    double scale = 0.0;
-    for (int a = 0; a < K; ++a) scale = std::max(scale, std::fabs(cvec[(size_t)a]) + std::sqrt(G[(size_t)a * K + a]));
-    std::vector<double> nu, best_nu((size_t)K, 0.0);
-    double best_viol = INFINITY;
+    qreal scale = 0;
+    for (int a = 0; a < K; ++a) { const qreal v = qabs(cvec[(size_t)a]) + qsqrt(G[(size_t)a * K + a]); if (v > scale) scale = v; }
+    if (!(scale > 0)) scale = (qreal)1e-300;
+    std::vector<qreal> nu, best_nu((size_t)K, (qreal)0);
+    qreal best_viol = (qreal)INFINITY;
     int best_active = 0;
     int64_t tried = 0;
     std::vector<int> F;
@@ -1177,23 +1214,27 @@ int long_project_planes(const LaunchCtx& c, LongPlanes& lp, d2* X, int64_t i) {
         long_solve_support(K, G, cvec, F, nu);
         ++tried;
         // violation: equality residuals, negative multipliers inside the support, violated inequalities outside it
-        double viol = 0.0;
+        qreal viol = 0;
         for (int a = 0; a < K; ++a) {
-            double g = -cvec[(size_t)a];                                      // (G nu - c)_a = P_a v - beta_a
+            qreal g = -cvec[(size_t)a];                                       // (G nu - c)_a = P_a v - beta_a
             for (int b2 = 0; b2 < K; ++b2) g += G[(size_t)a * K + b2] * nu[(size_t)b2];
-            if (a < neq) viol = std::max(viol, std::fabs(g));
-            else if (mask & (1u << (a - neq))) viol = std::max(viol, std::max(std::fabs(g), -nu[(size_t)a] * std::sqrt(std::max(G[(size_t)a * K + a], 1e-300))));
-            else viol = std::max(viol, -g);
+            qreal va;
+            if (a < neq) va = qabs(g);
+            else if (mask & (1u << (a - neq))) { const qreal gd = G[(size_t)a * K + a]; const qreal m2 = -nu[(size_t)a] * qsqrt(gd > 0 ? gd : (qreal)1e-300); va = qabs(g) > m2 ? qabs(g) : m2; }
+            else va = -g;
+            if (va > viol) viol = va;
         }
         if (viol < best_viol) { best_viol = viol; best_nu = nu; best_active = __builtin_popcount(mask); }
-        if (best_viol <= 1e-12 * std::max(scale, 1e-300)) break;
+        if (best_viol <= (qreal)1e-12 * scale) break;
     }
-    double step2 = 0.0;                                                       // |P' nu|^2 = nu' G nu
+    qreal step2 = 0;                                                          // |P' nu|^2 = nu' G nu
     for (int a = 0; a < K; ++a) for (int b2 = 0; b2 < K; ++b2) step2 += best_nu[(size_t)a] * G[(size_t)a * K + b2] * best_nu[(size_t)b2];
-    FOS_HIP(hipMemcpyAsync(lp.nu, best_nu.data(), sizeof(double) * K, hipMemcpyHostToDevice, c.stream));
+    std::vector<double> nu2((size_t)2 * K);                                   // multipliers as (hi, lo) pairs for the double-double update
+    for (int a = 0; a < K; ++a) { const double hi = (double)best_nu[(size_t)a]; nu2[(size_t)2 * a] = hi; nu2[(size_t)2 * a + 1] = (double)(best_nu[(size_t)a] - (qreal)hi); }
+    FOS_HIP(hipMemcpyAsync(lp.nu, nu2.data(), sizeof(double) * 2 * K, hipMemcpyHostToDevice, c.stream));
     launch_long_apply(c, X, lp.P, K, lp.nu);                     // x .= longstep.tmp      longstep.jl:57
-    FOS_HIP(hipStreamSynchronize(c.stream));                                 // (best_nu leaves scope)
-    lp.log[0] = (double)i; lp.log[1] = (double)best_active; lp.log[2] = best_viol; lp.log[3] = std::sqrt(std::max(step2, 0.0));
+    FOS_HIP(hipStreamSynchronize(c.stream));                                 // (nu2 leaves scope)
+    lp.log[0] = (double)i; lp.log[1] = (double)best_active; lp.log[2] = (double)best_viol; lp.log[3] = (double)qsqrt(step2 > 0 ? step2 : (qreal)0);
     lp.log[4] = (double)K; lp.log[5] = (double)tried;
     return FOS_OK;
 }
@@ -2020,8 +2061,8 @@ int fos_set_longstep(fos_handle h, int64_t longinterval, int64_t nsave) {
     if (!h->lp.P || h->lp.nsave != nsave) {
         FOS_TRY(dev_alloc(h, &h->lp.P, (size_t)K * h->l));
         FOS_TRY(dev_alloc(h, &h->lp.bpart, (size_t)K * h->vec_blocks));
-        FOS_TRY(dev_alloc(h, &h->lp.dots, (size_t)h->vec_blocks * (LONG_KMAX_ROWS + 1)));
-        FOS_TRY(dev_alloc(h, &h->lp.nu, (size_t)K));
+        FOS_TRY(dev_alloc(h, &h->lp.dots, (size_t)h->vec_blocks * 2 * (LONG_KMAX_ROWS + 1)));
+        FOS_TRY(dev_alloc(h, &h->lp.nu, (size_t)2 * K));
     }
     h->lp.interval = longinterval; h->lp.nsave = nsave; h->lp.savepos = 0; h->lp.now = false;
     return FOS_OK;

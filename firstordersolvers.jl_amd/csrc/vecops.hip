@@ -899,31 +899,78 @@ __global__ __launch_bounds__(VEC_THREADS) void long_plane_kernel(int64_t l, d2* 
     }
     block_reduce_store<1>(acc, bpart + blockIdx.x);
 }
-// partial sums of row_a . row_b for b = a .. K-1 and of row_a . x: out[blockIdx][K - a + 1] (what the small dual QP of the projection needs)
+// The Gram products of the saved planes in DOUBLE-DOUBLE.  The normals of successive iterations are nearly dependent (measured on the README
+// NNLS with the default nsave = 10: cond(P) 1e8 .. 1e10), which is why the reference hands the projection to a BigFloat QP (saveplanes.jl:24);
+// G = P P' formed in float64 loses cond(P)^2 eps = everything.  Products by FMA (exact), sums by TwoSum, across the workgroup as well; the host
+// adds the workgroups' pairs and solves the small dual in 113-bit arithmetic (solver.cpp, long_project_planes).
+struct dd { double hi, lo; };
+__device__ __forceinline__ dd dd_add(dd a, dd b) {
+    const double s = __dadd_rn(a.hi, b.hi), z = __dadd_rn(s, -a.hi);
+    double e = __dadd_rn(__dadd_rn(a.hi, -__dadd_rn(s, -z)), __dadd_rn(b.hi, -z));
+    e = __dadd_rn(e, __dadd_rn(a.lo, b.lo));
+    dd r;
+    r.hi = __dadd_rn(s, e);
+    r.lo = __dadd_rn(e, -__dadd_rn(r.hi, -s));
+    return r;
+}
+__device__ __forceinline__ void dd_add_prod(dd& acc, double a, double b) {      // acc += a b
+    dd p;
+    p.hi = __dmul_rn(a, b);
+    p.lo = __fma_rn(a, b, -p.hi);
+    acc = dd_add(acc, p);
+}
+template <int NV>
+__device__ __forceinline__ void dd_block_reduce_store(dd (&acc)[NV], double* out) {      // out[2 v], out[2 v + 1] = (hi, lo) of the workgroup's sum of acc[v]
+    __shared__ double sh_hi[VEC_THREADS], sh_lo[VEC_THREADS];
+    const int tid = threadIdx.x;
+#pragma unroll 1
+    for (int v = 0; v < NV; ++v) {
+        sh_hi[tid] = acc[v].hi; sh_lo[tid] = acc[v].lo;
+        __syncthreads();
+        for (int s = VEC_THREADS / 2; s > 0; s >>= 1) {
+            if (tid < s) {
+                const dd r = dd_add(dd{sh_hi[tid], sh_lo[tid]}, dd{sh_hi[tid + s], sh_lo[tid + s]});
+                sh_hi[tid] = r.hi; sh_lo[tid] = r.lo;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) { out[2 * v] = sh_hi[0]; out[2 * v + 1] = sh_lo[0]; }
+        __syncthreads();
+    }
+}
+// partial sums of row_a . row_b for b = a .. K-1 and of row_a . x: out[blockIdx][33][hi, lo] (what the small dual QP of the projection needs)
 constexpr int LONG_KMAX = 32;
 __global__ __launch_bounds__(VEC_THREADS) void long_dots_kernel(int64_t l, const d2* __restrict__ P, int K, int a, const d2* __restrict__ x,
                                                                 double* __restrict__ out) {
-    double acc[LONG_KMAX + 1];
+    dd acc[LONG_KMAX + 1];
 #pragma unroll
-    for (int k = 0; k <= LONG_KMAX; ++k) acc[k] = 0.0;
+    for (int k = 0; k <= LONG_KMAX; ++k) acc[k] = dd{0.0, 0.0};
     const d2* __restrict__ pa = P + (int64_t)a * l;
     for (int64_t i = blockIdx.x * (int64_t)VEC_THREADS + threadIdx.x; i < l; i += (int64_t)gridDim.x * VEC_THREADS) {
         const d2 va = pa[i];
 #pragma unroll
         for (int k = 0; k < LONG_KMAX; ++k) {
-            if (a + k < K) { const d2 vb = P[(int64_t)(a + k) * l + i]; acc[k] += va.x * vb.x + va.y * vb.y; }
+            if (a + k < K) { const d2 vb = P[(int64_t)(a + k) * l + i]; dd_add_prod(acc[k], va.x, vb.x); dd_add_prod(acc[k], va.y, vb.y); }
         }
         const d2 xi = x[i];
-        acc[LONG_KMAX] += va.x * xi.x + va.y * xi.y;
+        dd_add_prod(acc[LONG_KMAX], va.x, xi.x);
+        dd_add_prod(acc[LONG_KMAX], va.y, xi.y);
     }
-    block_reduce_store<LONG_KMAX + 1>(acc, out + (int64_t)blockIdx.x * (LONG_KMAX + 1));
+    dd_block_reduce_store<LONG_KMAX + 1>(acc, out + (int64_t)blockIdx.x * 2 * (LONG_KMAX + 1));
 }
-// x += sum_k nu[k] row_k  (the projection onto the saved planes, written back: longstep.jl:57)
+// x += sum_k nu[k] row_k  (the projection onto the saved planes, written back: longstep.jl:57).  The multipliers of nearly dependent planes are
+// large and their terms cancel: nu as (hi, lo) pairs (nu[2 k], nu[2 k + 1]), the sum in double-double, rounded once.
 __global__ __launch_bounds__(VEC_THREADS) void long_apply_kernel(int64_t l, d2* __restrict__ x, const d2* __restrict__ P, int K, const double* __restrict__ nu) {
     GRID_STRIDE(i, l) {
-        d2 v = x[i];
-        for (int k = 0; k < K; ++k) { const double w = nu[k]; const d2 r = P[(int64_t)k * l + i]; v.x += w * r.x; v.y += w * r.y; }
-        x[i] = v;
+        const d2 v = x[i];
+        dd sx{v.x, 0.0}, sy{v.y, 0.0};
+        for (int k = 0; k < K; ++k) {
+            const double wh = nu[2 * k], wl = nu[2 * k + 1];
+            const d2 r = P[(int64_t)k * l + i];
+            dd_add_prod(sx, wh, r.x); dd_add_prod(sx, wl, r.x);
+            dd_add_prod(sy, wh, r.y); dd_add_prod(sy, wl, r.y);
+        }
+        x[i] = make_double2(__dadd_rn(sx.hi, sx.lo), __dadd_rn(sy.hi, sy.lo));
     }
 }
 void launch_long_plane(const LaunchCtx& c, double2* row, const double2* x, const double2* y, double* bpart) {

@@ -212,7 +212,8 @@ int fos_linesearch_log(fos_handle h, double* out34);
  * nsave + 1 iterations of every longinterval save, per iteration, the half-plane through P_S1(x) with normal x - P_S1(x) (addprojeq, longstep.jl:65-79) and
  * the one of the second projection (addprojineq, :81-97), rows in the reference's order; behind the last of them the iterate is replaced by its projection onto
  * { first nsave + 1 rows as equalities, the others as inequalities C v >= d } (saveplanes.jl:17-28).  The reference solves that QP in the n variables with QPDAS
- * (BigFloat); here its dual in the 2 (nsave + 1) multipliers is solved (exactly, by enumeration of the active inequalities) -- the same unique point.
+ * (BigFloat, because successive normals are nearly dependent); here its dual in the 2 (nsave + 1) multipliers is solved by enumeration of the active
+ * inequalities -- the same unique point -- with the Gram products formed in double-double on the device and the small systems solved in 113-bit arithmetic.
  * nsave <= 15; longinterval >= nsave + 1; 0 switches the wrapper off.  out8 = iteration of the last projection, active inequalities, largest KKT violation of
  * the small dual, |x_new - x|, rows, candidate supports tried, 0, 0. */
 int fos_set_longstep(fos_handle h, int64_t longinterval, int64_t nsave);

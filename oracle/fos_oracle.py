@@ -1314,35 +1314,61 @@ class SavedPlanes:
 
 def project_onto_planes(A, b, C, d, x, tol=1e-12):
     """argmin 1/2 |v|^2 - x'v  s.t.  A v = b, C v >= d  -- what saveplanes.jl:24-26 hands to QPDAS (a package outside the checkout) as
-    QuadraticProgram(A, b, -C, -d, -x, I) in BigFloat.  The problem is the projection of x onto a polyhedron: its solution is unique, whatever
-    solves it.  Here: v = x + A'lam + C'mu, mu >= 0; the support of mu is found by enumeration (smallest KKT violation), each candidate by a
-    least-squares solve.  Test infrastructure: tests/test_longstep_oracle.py checks it against scipy's SLSQP on the primal."""
+    QuadraticProgram(BigFloat.(A), BigFloat.(b), BigFloat.(-C), BigFloat.(-d), BigFloat.(-x), I, eps = 1e-12): the projection of x onto a polyhedron,
+    solved in EXTENDED precision because the saved normals of successive iterations are nearly dependent (measured on the README NNLS with the
+    default nsave = 10: cond(P) 1e8 .. 1e10; a float64 solve through G = P P' is then off by 1e-4, ~1 % of the step).  The solution is unique,
+    whatever solves it.  Here, in 60-digit arithmetic (mpmath) on the float64 data, as the reference: v = x + A'lam + C'mu, mu >= 0; the support
+    of mu is found by enumeration (smallest KKT violation), each candidate by the pseudo-inverse of its Gram block (eigenvalues below 1e-26 of
+    the trace dropped: dependent planes).  Test infrastructure: tests/test_longstep_oracle.py checks it against scipy's SLSQP on the primal."""
     import itertools
-    P = np.vstack([A, C])
-    neq, nin = A.shape[0], C.shape[0]
-    beta = np.concatenate([b, d])
-    G = P @ P.T
-    c = beta - P @ x
-    scale = max(1e-300, float(np.max(np.abs(c) + np.sqrt(np.diag(G)))))
-    best = (math.inf, None)
-    for r in range(nin + 1):
-        for S in itertools.combinations(range(nin), r):
-            F = list(range(neq)) + [neq + j for j in S]
-            nu = np.zeros(neq + nin)
-            if F:
-                nu[F] = np.linalg.lstsq(G[np.ix_(F, F)], c[F], rcond=1e-13)[0]
-            g = G @ nu - c                                  # P v - beta
-            viol = float(np.max(np.abs(g[:neq]))) if neq else 0.0
-            for j in range(nin):
-                if j in S:
-                    viol = max(viol, abs(g[neq + j]), -nu[neq + j] * math.sqrt(max(G[neq + j, neq + j], 1e-300)))
-                else:
-                    viol = max(viol, -g[neq + j])
-            if viol < best[0]:
-                best = (viol, nu)
+    import mpmath as mp
+    with mp.workdps(60):
+        P = np.vstack([A, C])
+        neq, nin = A.shape[0], C.shape[0]
+        K = neq + nin
+        Pm = mp.matrix(P.tolist()) if K else mp.matrix(0, len(x))
+        xm = mp.matrix([float(t) for t in x])
+        beta = mp.matrix([float(t) for t in np.concatenate([b, d])]) if K else mp.matrix(0, 1)
+        G = Pm * Pm.T
+        c = beta - Pm * xm
+        scale = max([abs(c[a]) + mp.sqrt(G[a, a]) for a in range(K)] + [mp.mpf("1e-300")])
+        best = (mp.inf, mp.zeros(K, 1))
+        for r in range(nin + 1):
+            for S in itertools.combinations(range(nin), r):
+                F = list(range(neq)) + [neq + j for j in S]
+                nu = mp.zeros(K, 1)
+                if F:
+                    nf = len(F)
+                    GF = mp.matrix(nf, nf)
+                    cF = mp.matrix(nf, 1)
+                    for a_, i_ in enumerate(F):
+                        cF[a_] = c[i_]
+                        for b_, j_ in enumerate(F):
+                            GF[a_, b_] = G[i_, j_]
+                    E, Q = mp.eigsy(GF)
+                    tr = sum(abs(e) for e in E)
+                    sol = mp.zeros(nf, 1)
+                    for k in range(nf):
+                        if E[k] > tr * mp.mpf("1e-26"):
+                            q = Q[:, k]
+                            sol += q * ((q.T * cF)[0] / E[k])
+                    for a_, i_ in enumerate(F):
+                        nu[i_] = sol[a_]
+                g = G * nu - c                                  # P v - beta
+                viol = max([abs(g[a]) for a in range(neq)] + [mp.mpf(0)])
+                for j_ in range(nin):
+                    if j_ in S:
+                        viol = max(viol, abs(g[neq + j_]), -nu[neq + j_] * mp.sqrt(max(G[neq + j_, neq + j_], mp.mpf("1e-300"))))
+                    else:
+                        viol = max(viol, -g[neq + j_])
+                if viol < best[0]:
+                    best = (viol, nu)
+                if best[0] <= tol * scale:
+                    break
             if best[0] <= tol * scale:
-                return x + P.T @ best[1], best[0]
-    return x + P.T @ best[1], best[0]
+                break
+        v = xm + Pm.T * best[1] if K else xm
+        return np.array([float(t) for t in v]), float(best[0])
 
 
 def projectonnormals(s, x, y):

@@ -1,0 +1,326 @@
+"""Randomised differential campaign, HIP path vs the oracle (test infrastructure; run on a GPU box):
+    python tests/fuzz_parity.py --seeds 0:300 [--solve-every 4]
+Per seed: random sizes, density, cone partitions over every cone kind (both sides), random operator format (row blocks / dual tiles /
+forced window panels of both geometries) -- then the operator products, the cone projection at several scales, a tight CG solve and,
+every few seeds, a whole DR / GAPA / FISTA solve of a problem with a known complementary pair.  Prints one line per failure and a summary;
+exit code 1 if anything failed.  tests/test_gpu_fuzz.py runs a short fixed slice of it under pytest."""
+import argparse
+import math
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import fos_oracle as orc  # noqa: E402
+
+
+def random_cones(rng, total, side):
+    """A partition of `total` entries into cones; side 1 = row cones (any kind), 2 = variable cones."""
+    kinds = ["Free", "Zero", "NonNeg", "NonPos", "SOC", "SOCRotated", "SDP", "ExpPrimal", "ExpDual"]
+    out, left = [], total
+    while left > 0:
+        k = kinds[rng.integers(len(kinds))]
+        if k in ("ExpPrimal", "ExpDual"):
+            l = 3
+        elif k == "SDP":
+            order = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 21, 31, 32, 33, 48, 63, 64, 65, 70]))
+            l = order * (order + 1) // 2
+        elif k == "SOC":
+            l = int(rng.choice([1, 2, 3, 5, 17, 64, 65, 200]))
+        elif k == "SOCRotated":
+            l = int(rng.choice([2, 3, 4, 9, 66, 130]))
+        else:
+            l = int(rng.integers(1, 40))
+        if l > left:
+            if k in ("Free", "Zero", "NonNeg", "NonPos"):
+                l = left
+            elif k == "SOC":
+                l = left
+            else:
+                if rng.random() < 0.7:
+                    continue                                   # draw another kind
+                out.append(("Free", left))
+                left = 0
+                break
+        out.append((k, l))
+        left -= l
+    return out
+
+
+def moreau_pairs(rng, cones):
+    K = orc.ConeProduct.from_lengths([(orc.CONE_CODES[k], l) for k, l in cones])
+    n = sum(l for _, l in cones)
+    z = rng.standard_normal(n)
+    s = np.empty(n)
+    K.prox(s, z)
+    return s, s - z          # s in K, y = s - z in K*, s'y = 0
+
+
+def relerr(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(1e-300, np.linalg.norm(b)))
+
+
+def one_seed(pkg, seed, solve):
+    rng = np.random.default_rng([seed, 991])
+    fails = []
+    shape_kind = rng.integers(5)
+    if shape_kind == 0:
+        m, n = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+    elif shape_kind == 1:
+        m, n = int(rng.integers(200, 2500)), int(rng.integers(3, 40))
+    elif shape_kind == 2:
+        m, n = int(rng.integers(3, 40)), int(rng.integers(200, 2500))
+    else:
+        m, n = int(rng.integers(60, 900)), int(rng.integers(60, 900))
+    density = float(rng.choice([0.0, 0.002, 0.02, 0.1, 0.5, 1.0]))
+    if density == 1.0:
+        A = sp.csc_matrix(rng.standard_normal((m, n)))
+    else:
+        A = sp.random(m, n, density=density, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    if rng.random() < 0.3 and m > 8 and n > 8:                         # a dense rectangle inside (dual tiles), a dense row and column
+        A = A.tolil()
+        r0, c0 = int(rng.integers(0, m // 2)), int(rng.integers(0, n // 2))
+        rr, cc = int(rng.integers(4, m - r0)), int(rng.integers(4, n - c0))
+        A[r0:r0 + rr, c0:c0 + cc] = rng.standard_normal((rr, cc))
+        A[int(rng.integers(m)), :] = rng.standard_normal(n)
+        A = A.tocsc()
+    A.sort_indices()
+    K1, K2 = random_cones(rng, m, 1), random_cones(rng, n, 2)
+    wmode = str(rng.choice(["-1", "-1", "0", "1", "2"]))
+    if wmode == "-1":
+        os.environ.pop("FOS_WINDOWS", None)
+    else:
+        os.environ["FOS_WINDOWS"] = wmode
+    tag = "seed %d: %dx%d dens %.3g win %s K1 %s K2 %s" % (seed, m, n, density, wmode, K1[:6], K2[:6])
+    try:
+        s0, y0 = moreau_pairs(rng, K1)
+        x0, r0 = moreau_pairs(rng, K2)
+        x0, s0, y0, r0, b, c = pkg.workloads.normalize_data(x0, s0, y0, r0, A)
+        codes1 = [(orc.CONE_CODES[k], l) for k, l in K1]
+        codes2 = [(orc.CONE_CODES[k], l) for k, l in K2]
+        d = pkg.HipHSDE(A, b, c, K1, K2)
+        try:
+            Q = orc.HSDEMatrixQ(A, b, c)
+            x = rng.standard_normal(d.l)
+            ref = np.empty(d.l)
+            Q.mul(ref, x)
+            e = relerr(d.q_apply(x), ref)
+            if e > 1e-12:
+                fails.append("q_apply %.2e" % e)
+            Q.mul_t(ref, x)
+            e = relerr(d.q_apply(x, transpose=True), ref)
+            if e > 1e-12:
+                fails.append("q_apply' %.2e" % e)
+            z = rng.standard_normal(d.N)
+            zref = np.empty(d.N)
+            orc.KKTMatrix(Q).mul(zref, z)
+            e = relerr(d.kkt_apply(z), zref)
+            if e > 1e-12:
+                fails.append("kkt_apply %.2e" % e)
+            S2 = orc.DualConeProduct(orc.ConeProduct.from_lengths(codes1), orc.ConeProduct.from_lengths(codes2))
+            for trial in range(3):
+                z = rng.standard_normal(d.N) * 10.0 ** rng.uniform(-2, 2)
+                if trial == 2:
+                    z[rng.random(d.N) < 0.3] = 0.0
+                S2.prox(zref, z)
+                out = d.prox_cones(z)
+                e = float(np.linalg.norm(out - zref) / max(1.0, np.linalg.norm(z)))
+                if not e <= 2e-9:
+                    fails.append("prox_cones trial %d %.2e" % (trial, e))
+            # the affine projection at the tolerance floor: both are the exact projection to ~l eps cond
+            H = orc.HSDEMatrix(Q)
+            v = rng.standard_normal(d.N)
+            tol = d.N * np.finfo(float).eps
+            xg, itg = d.cg_kkt(np.zeros(d.N), v, tol, 10000)
+            Md = None
+            if d.N <= 1500:
+                Qd = Q.todense()
+                Md = np.block([[np.eye(d.l), Qd.T], [Qd, -np.eye(d.l)]])
+                xs = np.linalg.solve(Md, v)
+                e = relerr(xg, xs)
+                if e > 1e-8:
+                    fails.append("cg_kkt vs dense solve %.2e (%d its)" % (e, itg))
+        finally:
+            d.close()
+        if solve and d.N <= 1200:
+            prob = pkg.workloads.ConicProblem("fuzz", A, b, c, K1, K2)
+            algname = str(rng.choice(["DR", "GAPA", "FISTA", "Dykstra"]))
+            mk = {"DR": lambda M, **o: M.DR(**o), "GAPA": lambda M, **o: M.GAPA(0.8, 0.5, **o), "FISTA": lambda M, **o: M.FISTA(**o),
+                  "Dykstra": lambda M, **o: M.Dykstra(**o)}[algname]
+            opts = dict(eps=1e-5, verbose=0, max_iters=800, checki=50)
+            model = pkg.solve(prob, mk(pkg, **opts))
+            om = orc.Model(A, b, c, codes1, codes2)
+            sol = orc.solve(om, mk(orc, **opts), out=[])
+            if model.status() != sol.status:
+                # a status may differ only when the stopping residuals are within rounding of eps at the deciding check
+                fails.append("%s status %s vs oracle %s (its %d vs %d)" % (algname, model.status(), sol.status, model.iterations, sol.iterations))
+            elif sol.status == "Optimal":
+                if abs(model.iterations - sol.iterations) > 50:
+                    fails.append("%s iterations %d vs %d" % (algname, model.iterations, sol.iterations))
+                e = float(np.linalg.norm(model.getsolution() - sol.x) / max(1.0, np.linalg.norm(sol.x)))
+                if e > 1e-3:
+                    fails.append("%s solution %.2e" % (algname, e))
+    except Exception as ex:  # noqa: BLE001
+        fails.append("EXCEPTION %s: %s" % (type(ex).__name__, str(ex)[:300]))
+    finally:
+        os.environ.pop("FOS_WINDOWS", None)
+    return tag, fails
+
+
+def one_feas_seed(pkg, seed):
+    """The Feasibility form (no CG in the loop: iterates are comparable to rounding): IndAffine(dense A, b = A x0) n ConeProduct(random cones)
+    or IndBox, a random algorithm with random parameters, optionally wrapped; 20 iterations against the oracle's, then the status of a solve."""
+    rng = np.random.default_rng([seed, 577])
+    n = int(rng.choice([3, 7, 30, 100, 257, 400]))
+    use_box = rng.random() < 0.25
+    cones = None if use_box else random_cones(rng, n, 1)
+    m = max(1, min(n - 1, int(n * rng.uniform(0.05, 0.6))))
+    A = rng.standard_normal((m, n)) / math.sqrt(n)
+    algname = str(rng.choice(["DR", "AP", "GAP", "GAPA", "FISTA", "Dykstra"]))
+    a, a1, a2 = float(rng.uniform(0.3, 1.0)), float(rng.uniform(1.0, 1.9)), float(rng.uniform(1.0, 1.9))
+    beta = float(rng.uniform(0.0, 0.9))
+    wrap = str(rng.choice(["none", "none", "ls", "long"]))
+    tag = "feas seed %d: n %d m %d %s %s wrap %s" % (seed, n, m, "box" if use_box else str(cones[:5]), algname, wrap)
+    fails = []
+
+    def mk(M):
+        if algname == "GAP":
+            alg = M.GAP(a, a1, a2)
+        elif algname == "GAPA":
+            alg = M.GAPA(a, beta)
+        else:
+            alg = getattr(M, algname)()
+        if wrap == "ls" and algname in ("GAP", "GAPA"):
+            return M.LineSearchWrapper(alg, lsinterval=5, **({"out": []} if M is orc else {}))
+        if wrap == "long" and algname in ("GAP", "GAPA", "FISTA", "Dykstra", "DR", "AP"):
+            return M.LongstepWrapper(alg, longinterval=6, nsave=2)
+        return alg
+    try:
+        if use_box:
+            lo, hi = -float(rng.uniform(0, 1)), float(rng.uniform(0.5, 2))
+            x0 = rng.uniform(lo, hi, n)
+            S2h, S2o = pkg.IndBox(lo, hi), orc.IndBox(lo, hi)
+        else:
+            K = orc.ConeProduct.from_lengths([(orc.CONE_CODES[k], l) for k, l in cones])
+            x0 = np.empty(n)
+            K.prox(x0, rng.standard_normal(n))
+            S2h, S2o = pkg.ConeProduct(cones), K
+        b = A @ x0
+        hp = pkg.Feasibility(pkg.IndAffine(A, b), S2h, n)
+
+        def oracle_run(bvec):
+            oalg = mk(orc)
+            omodel = orc.FeasibilityModel(orc.Feasibility(orc.IndAffine(A, bvec), S2o, n), oalg)
+            ost = orc.FeasibilityStatus(omodel, 10 ** 9, 1e-30, 0, 1)
+            xo = np.zeros(n)
+            seq = []
+            for i in range(1, 21):
+                ost.i = i
+                oalg.step(xo, i, ost)
+                seq.append(xo.copy())
+            return seq
+        # LongstepWrapper: once the saved normals are dependent beyond what float64 data can express (sigma_min of the saved rows below 1e-11
+        # sigma_max, or below 1e-9 |x|: converged iterates whose normals x - P(x) ARE rounding noise -- measured: sigma ~ 1e-14 |x| and the
+        # projection still moves x by 1e-3 --, repeated planes that differ by an ulp) the projection is decided by that noise, in the reference's
+        # BigFloat QP as well; iterates are compared up to the first such projection
+        degenerate_at = []
+        orig_proj = orc.project_onto_planes
+
+        def proj_hook(A_, b_, C_, d_, x_, tol=1e-12):
+            sv = np.linalg.svd(np.vstack([A_, C_]), compute_uv=False)
+            if not (sv[-1] > 1e-11 * sv[0] and sv[-1] > 1e-9 * max(1e-300, float(np.abs(x_).max()))):
+                degenerate_at.append(True)
+            else:
+                degenerate_at.append(False)
+            return orig_proj(A_, b_, C_, d_, x_, tol)
+        # GAPA: its step length comes from |<t2 - t1, t1 - x>| / (|t2 - t1| |t1 - x|) (gapa.jl:36-47, :96); when a projection leaves its argument
+        # where it is (x already in the set) a difference is the rounding noise of alpha12 y + (1 - alpha12) x and the quotient -- hence every later
+        # iterate -- is decided by that noise, in the reference as well; iterates are compared up to the first such step
+        noise_steps = []
+        orig_ns = orc.normed_scalar
+
+        def ns_hook(x1, x2, y1, y2, *a_, **k_):
+            d1, d2 = x1 - x2, y1 - y2
+            noise_steps.append(bool(d1 @ d1 <= 1e-22 * max(x1 @ x1, 1e-300) or d2 @ d2 <= 1e-22 * max(y1 @ y1, 1e-300)))
+            return orig_ns(x1, x2, y1, y2, *a_, **k_)
+        orc.project_onto_planes = proj_hook
+        orc.normed_scalar = ns_hook
+        try:
+            ref = oracle_run(b)
+        finally:
+            orc.project_onto_planes = orig_proj
+            orc.normed_scalar = orig_ns
+        first_noise = next((q + 1 for q, flag in enumerate(noise_steps) if flag), None)
+        first_degenerate = None
+        if wrap == "long":
+            for q, flag in enumerate(degenerate_at):
+                if flag:
+                    first_degenerate = 6 * (q + 1)                 # longinterval = 6: projections at iterations 6, 12, 18
+                    break
+        # GAPA's step-length estimate is a quotient of small differences: the oracle's own iterates move by 1e-4 .. 1e-3 when b is changed by
+        # one ulp (measured, seeds 472 / 506 / 542), so GAPA is held to the envelope of that perturbation instead of a fixed tolerance
+        per = oracle_run(b * (1.0 + 2.220446049250313e-16)) if algname == "GAPA" else None
+        d = pkg.HipFeasibility(hp)
+        try:
+            d.set_alg(mk(pkg))
+            d.set_iterate(None)
+            tol = 1e-9 if wrap == "none" else (1e-6 if wrap == "long" else 1e-8)
+            envelope = 0.0
+            for i in range(1, 21):
+                xo = ref[i - 1]
+                d.step(i, 1, 10 ** 9, 1e-30)
+                scale = max(1.0, np.abs(xo).max())
+                e = float(np.abs(d.get_iterate() - xo).max() / scale)
+                if per is not None:
+                    envelope = max(envelope, float(np.abs(per[i - 1] - xo).max() / scale))
+                if first_degenerate is not None and i >= first_degenerate:
+                    break
+                if first_noise is not None and i > first_noise:
+                    break
+                if not e <= tol + 50 * envelope:
+                    fails.append("iterate %d off by %.2e (envelope %.1e)" % (i, e, envelope))
+                    break
+        finally:
+            d.close()
+    except Exception as ex:  # noqa: BLE001
+        fails.append("EXCEPTION %s: %s" % (type(ex).__name__, str(ex)[:300]))
+    return tag, fails
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", default="0:100")
+    ap.add_argument("--solve-every", type=int, default=4)
+    ap.add_argument("--form", default="hsde", choices=["hsde", "feas"])
+    ap.add_argument("--budget", type=float, default=0.0, help="stop starting new seeds after this many seconds")
+    args = ap.parse_args()
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    lo, hi = (int(v) for v in args.seeds.split(":"))
+    import time
+    bad = done = 0
+    t0 = time.time()
+    for seed in range(lo, hi):
+        if args.budget > 0 and time.time() - t0 > args.budget:
+            break
+        if args.form == "feas":
+            tag, fails = one_feas_seed(pkg, seed)
+        else:
+            tag, fails = one_seed(pkg, seed, args.solve_every > 0 and seed % args.solve_every == 0)
+        done += 1
+        if fails:
+            bad += 1
+            print("FAIL", tag, "|", "; ".join(fails), flush=True)
+        if done % 20 == 0:
+            print("... %d seeds, %d with failures, %.0f s" % (done, bad, time.time() - t0), flush=True)
+    print("fuzz: %d seeds (%d:%d), %d with failures, %.0f s" % (done, lo, lo + done, bad, time.time() - t0), flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -8,6 +8,8 @@ agree to rounding; with CG the first iterations are solved to 0.2^sqrt(i) only.)
 import numpy as np
 import pytest
 
+from feasibility_cases import affine_box_instance
+
 pytestmark = pytest.mark.gpu
 
 ALGS = {"DR": lambda M: M.DR(direct=True), "GAP": lambda M: M.GAP(0.8, 1.5, 1.6, direct=True), "GAPA": lambda M: M.GAPA(0.8, 0.5, direct=True),
@@ -78,3 +80,47 @@ def test_longstep_solve_and_error_paths(pkg, oracle):
     with pytest.raises(pkg.lib.FosError):
         d.set_longstep(20, 2)                                     # not around a LineSearchWrapper
     d.close()
+
+
+@pytest.mark.parametrize("algname", ["AP", "GAP"])
+def test_default_nsave_projection_is_extended_precision(pkg, oracle, algname):
+    """The reference's default nsave = 10 saves 22 planes whose normals are nearly dependent (here sigma_max / sigma_min of the saved rows
+    reaches 1e10 .. 1e11), which is why it solves the projection in BigFloat (saveplanes.jl:24).  The device forms the Gram products in
+    double-double, solves the small dual in 113-bit arithmetic and applies the multipliers in double-double; the oracle solves it in 60 digits.
+    On the Feasibility form (no CG noise in the iterates) the two agree through two projections to 1e-8 of the iterate -- a float64 solve
+    through G = P P' loses cond^2 eps = everything here (it was off by 1e-4 at cond 1e8 on the README NNLS)."""
+    orc = oracle
+    mk = {"AP": lambda M: M.AP(), "GAP": lambda M: M.GAP(0.8, 1.5, 1.6)}[algname]
+    A, b = affine_box_instance(m=50, n=100)
+    hp = pkg.Feasibility(pkg.IndAffine(A, b), pkg.IndBox(0.0, np.inf), 100)
+    op = orc.Feasibility(orc.IndAffine(A, b), orc.IndBox(0.0, np.inf), 100)
+    owrap = orc.LongstepWrapper(mk(orc), longinterval=25, nsave=10)
+    omodel = orc.FeasibilityModel(op, owrap)
+    ost = orc.FeasibilityStatus(omodel, 10 ** 9, 1e-30, 0, 1)
+    conds = []
+    orig = orc.project_onto_planes
+
+    def hook(A_, b_, C_, d_, x_, tol=1e-12):
+        sv = np.linalg.svd(np.vstack([A_, C_]), compute_uv=False)
+        conds.append(float(sv[0] / max(sv[-1], 1e-300)))
+        return orig(A_, b_, C_, d_, x_, tol)
+    d = pkg.HipFeasibility(hp)
+    try:
+        orc.project_onto_planes = hook
+        d.set_alg(pkg.LongstepWrapper(mk(pkg), longinterval=25, nsave=10))
+        d.set_iterate(None)
+        xo = np.zeros(100)
+        worst = 0.0
+        for i in range(1, 52):
+            ost.i = i
+            owrap.step(xo, i, ost)
+            d.step(i, 1, 10 ** 9, 1e-30)
+            worst = max(worst, np.abs(d.get_iterate() - xo).max() / max(1.0, np.abs(xo).max()))
+            if i % 25 == 0:
+                log = d.longstep_log()
+                assert log["rows"] == 22 and log["iteration"] == i and log["step"] > 0
+    finally:
+        orc.project_onto_planes = orig
+        d.close()
+    assert len(conds) == 2 and max(conds) > 1e8, conds           # float64 through the Gram matrix would be lost here
+    assert worst <= 1e-8, (worst, conds)
