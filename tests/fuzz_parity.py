@@ -292,11 +292,95 @@ def one_feas_seed(pkg, seed):
     return tag, fails
 
 
+def one_direct_seed(pkg, seed):
+    """The HSDE form with direct = true (the exact S1 projection: no CG noise, iterates comparable to rounding): a random small conic program over every cone
+    kind on both sides, a random algorithm with random parameters, optionally wrapped; 20 iterations of the device step against the oracle's."""
+    rng = np.random.default_rng([seed, 313])
+    m, n = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+    density = float(rng.choice([0.05, 0.2, 0.6, 1.0]))
+    A = sp.csc_matrix(rng.standard_normal((m, n))) if density == 1.0 else sp.random(m, n, density=density, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    A.sort_indices()
+    K1, K2 = random_cones(rng, m, 1), random_cones(rng, n, 2)
+    algname = str(rng.choice(["DR", "AP", "GAP", "GAPA", "FISTA", "Dykstra"]))
+    a, a1, a2 = float(rng.uniform(0.3, 1.0)), float(rng.uniform(1.0, 1.9)), float(rng.uniform(1.0, 1.9))
+    beta = float(rng.uniform(0.0, 0.9))
+    wrap = str(rng.choice(["none", "none", "ls", "long"]))
+    tag = "direct seed %d: %dx%d dens %.2g %s wrap %s K1 %s K2 %s" % (seed, m, n, density, algname, wrap, K1[:5], K2[:5])
+    fails = []
+
+    def mk(M):
+        if algname == "GAP":
+            alg = M.GAP(a, a1, a2, direct=True)
+        elif algname == "GAPA":
+            alg = M.GAPA(a, beta, direct=True)
+        else:
+            alg = getattr(M, algname)(direct=True)
+        if wrap == "ls" and algname in ("GAP", "GAPA"):
+            return M.LineSearchWrapper(alg, lsinterval=5, **({"out": []} if M is orc else {}))
+        if wrap == "long":
+            return M.LongstepWrapper(alg, longinterval=6, nsave=2)
+        return alg
+    try:
+        s0, y0 = moreau_pairs(rng, K1)
+        x0, r0 = moreau_pairs(rng, K2)
+        x0, s0, y0, r0, b, c = pkg.workloads.normalize_data(x0, s0, y0, r0, A)
+        mo = orc.Model(A, b, c, [(orc.CONE_CODES[k], l) for k, l in K1], [(orc.CONE_CODES[k], l) for k, l in K2])
+        degenerate_at, noise_steps = [], []
+        orig_proj, orig_ns = orc.project_onto_planes, orc.normed_scalar
+
+        def proj_hook(A_, b_, C_, d_, x_, tol=1e-12):
+            sv = np.linalg.svd(np.vstack([A_, C_]), compute_uv=False)
+            degenerate_at.append(not (sv[-1] > 1e-11 * sv[0] and sv[-1] > 1e-9 * max(1e-300, float(np.abs(x_).max()))))
+            return orig_proj(A_, b_, C_, d_, x_, tol)
+
+        def ns_hook(x1, x2, y1, y2, *a_, **k_):
+            d1, d2 = x1 - x2, y1 - y2
+            noise_steps.append(bool(d1 @ d1 <= 1e-22 * max(x1 @ x1, 1e-300) or d2 @ d2 <= 1e-22 * max(y1 @ y1, 1e-300)))
+            return orig_ns(x1, x2, y1, y2, *a_, **k_)
+        oalg = mk(orc)
+        oalg.init(mo)
+        xo = orc.hsde_initialvalue(mo)
+        S1 = getattr(oalg, "alg", oalg).S1
+        st = orc.HSDEStatus(mo, 10 ** 9, 1e-9, 0, 1, S1=S1)
+        ref = []
+        orc.project_onto_planes, orc.normed_scalar = proj_hook, ns_hook
+        try:
+            for i in range(1, 21):
+                st.i = i
+                oalg.step(xo, i, st)
+                ref.append(xo.copy())
+        finally:
+            orc.project_onto_planes, orc.normed_scalar = orig_proj, orig_ns
+        first_degenerate = next((6 * (q + 1) for q, flag in enumerate(degenerate_at) if flag), None)
+        first_noise = next((q + 1 for q, flag in enumerate(noise_steps) if flag), None)
+        d = pkg.HipHSDE(A, b, c, K1, K2)
+        try:
+            d.enable_direct(A)
+            d.set_alg(mk(pkg))
+            d.set_iterate(None)
+            tol = 1e-9 if wrap == "none" and algname != "GAPA" else (1e-6 if wrap == "long" or algname == "GAPA" else 1e-8)
+            for i in range(1, 21):
+                d.step(i, 1, 10 ** 9, 1e-9)
+                if first_degenerate is not None and i >= first_degenerate:
+                    break
+                if first_noise is not None and i > first_noise:
+                    break
+                e = float(np.linalg.norm(d.get_iterate() - ref[i - 1]) / max(1.0, np.linalg.norm(ref[i - 1])))
+                if not e <= tol:
+                    fails.append("iterate %d off by %.2e" % (i, e))
+                    break
+        finally:
+            d.close()
+    except Exception as ex:  # noqa: BLE001
+        fails.append("EXCEPTION %s: %s" % (type(ex).__name__, str(ex)[:300]))
+    return tag, fails
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", default="0:100")
     ap.add_argument("--solve-every", type=int, default=4)
-    ap.add_argument("--form", default="hsde", choices=["hsde", "feas"])
+    ap.add_argument("--form", default="hsde", choices=["hsde", "feas", "direct"])
     ap.add_argument("--budget", type=float, default=0.0, help="stop starting new seeds after this many seconds")
     args = ap.parse_args()
     import __graft_entry__ as ge
@@ -310,6 +394,8 @@ def main():
             break
         if args.form == "feas":
             tag, fails = one_feas_seed(pkg, seed)
+        elif args.form == "direct":
+            tag, fails = one_direct_seed(pkg, seed)
         else:
             tag, fails = one_seed(pkg, seed, args.solve_every > 0 and seed % args.solve_every == 0)
         done += 1
