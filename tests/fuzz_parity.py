@@ -376,11 +376,104 @@ def one_direct_seed(pkg, seed):
     return tag, fails
 
 
+def one_big_seed(pkg, seed):
+    """Large operators (10^5 .. 10^6 stacked rows): the formats small problems never reach -- window panels chosen by the builder (both geometries), tall dual
+    tiles, long rows, run-compressed bands, block-diagonal mixes -- checked through the operator products and the cone projection only (scipy does the oracle's
+    products in milliseconds)."""
+    rng = np.random.default_rng([seed, 4242])
+    kind = int(rng.integers(6))
+    if kind == 0:                                          # random sparse, large enough for window panels
+        m, n = int(rng.integers(60000, 260000)), int(rng.integers(60000, 260000))
+        A = sp.random(m, n, density=float(rng.uniform(8, 30)) / n, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    elif kind == 1:                                        # block diagonal sparse (C5's structure)
+        nb = int(rng.integers(2, 9))
+        A = sp.block_diag([sp.random(int(rng.integers(20000, 60000)), int(rng.integers(20000, 60000)), density=15.0 / 40000, format="csc", random_state=rng,
+                                     data_rvs=rng.standard_normal) for _ in range(nb)], format="csc")
+    elif kind == 2:                                        # block diagonal dense (C4's structure): dual tiles, tall stacks
+        nb, r, c_ = int(rng.integers(20, 200)), int(rng.integers(65, 700)), int(rng.integers(4, 48))
+        A = sp.block_diag([rng.standard_normal((r, c_)) for _ in range(nb)], format="csc")
+    elif kind == 3:                                        # dense LP-like rectangle
+        A = sp.csc_matrix(rng.standard_normal((int(rng.integers(300, 1500)), int(rng.integers(2000, 6000)))))
+    elif kind == 4:                                        # banded + a few dense rows and columns
+        n = int(rng.integers(100000, 400000))
+        A = sp.diags([rng.standard_normal(n - abs(k)) for k in (-3, -1, 0, 2)], (-3, -1, 0, 2), format="lil")
+        for _ in range(3):
+            A[int(rng.integers(n)), :2000] = rng.standard_normal(2000)
+        A = A.tocsc()
+    else:                                                  # tall sparse with a dense block on top
+        m, n = int(rng.integers(100000, 300000)), int(rng.integers(200, 3000))
+        A = sp.vstack([sp.csc_matrix(rng.standard_normal((int(rng.integers(64, 400)), n))),
+                       sp.random(m, n, density=10.0 / n, format="csc", random_state=rng, data_rvs=rng.standard_normal)]).tocsc()
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    m, n = A.shape
+    wmode = str(rng.choice(["-1", "-1", "-1", "0", "1", "2"]))
+    if wmode == "-1":
+        os.environ.pop("FOS_WINDOWS", None)
+    else:
+        os.environ["FOS_WINDOWS"] = wmode
+    # a cheap cone mix: elementwise cones and second-order cones of many sizes (PSD / exponential cones are covered by the small seeds)
+    def cones(total):
+        out, left = [], total
+        while left > 0:
+            k = str(rng.choice(["Free", "Zero", "NonNeg", "NonPos", "SOC", "SOC"]))
+            l = int(min(left, rng.choice([1, 3, 50, 1000, 20000])))
+            out.append((k, l))
+            left -= l
+        return out
+    K1, K2 = cones(m), cones(n)
+    tag = "big seed %d: kind %d %dx%d nnz %d win %s" % (seed, kind, m, n, A.nnz, wmode)
+    fails = []
+    try:
+        b, c = rng.standard_normal(m), rng.standard_normal(n)
+        d = pkg.HipHSDE(A, b, c, K1, K2)
+        try:
+            st = d.operator_stats()
+            tag += " fmt blocks %d tiles %d panels %d" % (st["blocks"], st["tiles"], st["win_panels"])
+            Q = orc.HSDEMatrixQ(A, b, c)
+            x = rng.standard_normal(d.l)
+            ref = np.empty(d.l)
+            Q.mul(ref, x)
+            e = relerr(d.q_apply(x), ref)
+            if e > 1e-12:
+                fails.append("q_apply %.2e" % e)
+            Q.mul_t(ref, x)
+            e = relerr(d.q_apply(x, transpose=True), ref)
+            if e > 1e-12:
+                fails.append("q_apply' %.2e" % e)
+            z = rng.standard_normal(d.N)
+            zref = np.empty(d.N)
+            orc.KKTMatrix(Q).mul(zref, z)
+            e = relerr(d.kkt_apply(z), zref)
+            if e > 1e-12:
+                fails.append("kkt_apply %.2e" % e)
+            S2 = orc.DualConeProduct(orc.ConeProduct.from_lengths([(orc.CONE_CODES[k], l) for k, l in K1]),
+                                     orc.ConeProduct.from_lengths([(orc.CONE_CODES[k], l) for k, l in K2]))
+            S2.prox(zref, z)
+            e = float(np.linalg.norm(d.prox_cones(z) - zref) / max(1.0, np.linalg.norm(z)))
+            if not e <= 1e-12:
+                fails.append("prox_cones %.2e" % e)
+            # the affine projection by CG at a loose tolerance: a projection is idempotent and its residual is orthogonal to the range
+            v = rng.standard_normal(d.N)
+            xg, itg = d.cg_kkt(np.zeros(d.N), v, 1e-8 * np.linalg.norm(v), 300)
+            orc.KKTMatrix(Q).mul(zref, xg)
+            e = relerr(zref, v)
+            if e > 1e-6:
+                fails.append("cg_kkt residual %.2e after %d its" % (e, itg))
+        finally:
+            d.close()
+    except Exception as ex:  # noqa: BLE001
+        fails.append("EXCEPTION %s: %s" % (type(ex).__name__, str(ex)[:300]))
+    finally:
+        os.environ.pop("FOS_WINDOWS", None)
+    return tag, fails
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", default="0:100")
     ap.add_argument("--solve-every", type=int, default=4)
-    ap.add_argument("--form", default="hsde", choices=["hsde", "feas", "direct"])
+    ap.add_argument("--form", default="hsde", choices=["hsde", "feas", "direct", "big"])
     ap.add_argument("--budget", type=float, default=0.0, help="stop starting new seeds after this many seconds")
     args = ap.parse_args()
     import __graft_entry__ as ge
@@ -396,6 +489,9 @@ def main():
             tag, fails = one_feas_seed(pkg, seed)
         elif args.form == "direct":
             tag, fails = one_direct_seed(pkg, seed)
+        elif args.form == "big":
+            tag, fails = one_big_seed(pkg, seed)
+            print("ok  " if not fails else "bad ", tag, flush=True)
         else:
             tag, fails = one_seed(pkg, seed, args.solve_every > 0 and seed % args.solve_every == 0)
         done += 1
