@@ -1207,17 +1207,20 @@ int long_project_planes(const LaunchCtx& c, LongPlanes& lp, d2* X, int64_t i) {
     int best_active = 0;
     int64_t tried = 0;
     std::vector<int> F;
-    for (uint32_t mask = 0; mask < (1u << nin); ++mask) {
+    std::vector<qreal> gres((size_t)K);
+    // one candidate support: solve, residuals g = G nu - c, KKT violation (equality residuals, negative multipliers inside the support, violated
+    // inequalities outside it); true when it is the solution
+    auto try_support = [&](uint32_t mask) {
         F.clear();
         for (int a = 0; a < neq; ++a) F.push_back(a);
         for (int j = 0; j < nin; ++j) if (mask & (1u << j)) F.push_back(neq + j);
         long_solve_support(K, G, cvec, F, nu);
         ++tried;
-        // violation: equality residuals, negative multipliers inside the support, violated inequalities outside it
         qreal viol = 0;
         for (int a = 0; a < K; ++a) {
             qreal g = -cvec[(size_t)a];                                       // (G nu - c)_a = P_a v - beta_a
             for (int b2 = 0; b2 < K; ++b2) g += G[(size_t)a * K + b2] * nu[(size_t)b2];
+            gres[(size_t)a] = g;
             qreal va;
             if (a < neq) va = qabs(g);
             else if (mask & (1u << (a - neq))) { const qreal gd = G[(size_t)a * K + a]; const qreal m2 = -nu[(size_t)a] * qsqrt(gd > 0 ? gd : (qreal)1e-300); va = qabs(g) > m2 ? qabs(g) : m2; }
@@ -1225,8 +1228,31 @@ int long_project_planes(const LaunchCtx& c, LongPlanes& lp, d2* X, int64_t i) {
             if (va > viol) viol = va;
         }
         if (viol < best_viol) { best_viol = viol; best_nu = nu; best_active = __builtin_popcount(mask); }
-        if (best_viol <= (qreal)1e-12 * scale) break;
+        return best_viol <= (qreal)1e-12 * scale;
+    };
+    // (i) an active-set walk from the empty support: drop the most negative multiplier, else add the most violated inequality -- a handful of
+    //     solves when it ends at the solution (it is accepted by the same KKT test); (ii) otherwise the enumeration of all supports
+    bool found = false;
+    {
+        uint32_t mask = 0;
+        std::vector<uint32_t> seen;
+        for (int it = 0; it < 4 * nin + 4 && !found; ++it) {
+            if (std::find(seen.begin(), seen.end(), mask) != seen.end()) break;
+            seen.push_back(mask);
+            if (try_support(mask)) { found = true; break; }
+            int drop = -1, add = -1;
+            qreal worst_nu = 0, worst_g = 0;
+            for (int j = 0; j < nin; ++j) {
+                const int a = neq + j;
+                if (mask & (1u << j)) { if (nu[(size_t)a] < worst_nu) { worst_nu = nu[(size_t)a]; drop = j; } }
+                else if (gres[(size_t)a] < worst_g) { worst_g = gres[(size_t)a]; add = j; }
+            }
+            if (drop >= 0) mask &= ~(1u << drop);
+            else if (add >= 0) mask |= 1u << add;
+            else break;
+        }
     }
+    for (uint32_t mask = 0; !found && mask < (1u << nin); ++mask) found = try_support(mask);
     qreal step2 = 0;                                                          // |P' nu|^2 = nu' G nu
     for (int a = 0; a < K; ++a) for (int b2 = 0; b2 < K; ++b2) step2 += best_nu[(size_t)a] * G[(size_t)a * K + b2] * best_nu[(size_t)b2];
     std::vector<double> nu2((size_t)2 * K);                                   // multipliers as (hi, lo) pairs for the double-double update
