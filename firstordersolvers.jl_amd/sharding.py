@@ -81,6 +81,43 @@ def _split_cones_at(cones, cut_points):
     return out
 
 
+def _separable_cone_cuts(A_csr, kb, K2):
+    """K1-cone indices i (0 < i < #cones) at which the problem separates: every row before cone i lies left of every row from cone i on, and the
+    column where the right part starts does not fall inside a second-order / PSD / exponential cone of K2."""
+    m = A_csr.shape[0]
+    nnz_per_row = np.diff(A_csr.indptr)
+    has = nnz_per_row > 0
+    rmax = np.full(m, -1, dtype=np.int64)
+    rmin = np.full(m, np.iinfo(np.int64).max, dtype=np.int64)
+    if A_csr.nnz:
+        starts = A_csr.indptr[:-1][has]
+        rmin[has] = np.minimum.reduceat(A_csr.indices, starts)
+        rmax[has] = np.maximum.reduceat(A_csr.indices, starts)
+    pmax = np.maximum.accumulate(rmax) if m else rmax                      # largest column of rows 0..r
+    smin = np.minimum.accumulate(rmin[::-1])[::-1] if m else rmin          # smallest column of rows r..
+    k2b = set(_cone_bounds(K2).tolist())
+    inner_ok = []                                                          # columns at which K2 may be cut: cone boundaries, or inside elementwise cones
+    pos = 0
+    for name, ln in K2:
+        inner_ok.append((pos, pos + int(ln), name in _ELEMENTWISE))
+        pos += int(ln)
+
+    def col_cut_ok(c):
+        if c in k2b:
+            return True
+        return any(lo < c < hi and ew for lo, hi, ew in inner_ok)
+    out = set()
+    for i in range(1, len(kb) - 1):
+        r = int(kb[i])
+        if r <= 0 or r >= m:
+            continue
+        left = int(pmax[r - 1])
+        right = int(smin[r]) if smin[r] != np.iinfo(np.int64).max else A_csr.shape[1]
+        if left < right and col_cut_ok(right):
+            out.add(i)
+    return out
+
+
 def plan(problem: ConicProblem, nranks: int):
     """Row / column cut points for an nranks-way cone sharding; raises ValueError if A is not block diagonal
     conformally with the K1 cones."""
@@ -92,6 +129,23 @@ def plan(problem: ConicProblem, nranks: int):
     nnz_per_row = np.diff(A.indptr)
     w = [float(nnz_per_row[kb[i]:kb[i + 1]].sum()) + 4.0 * (kb[i + 1] - kb[i]) for i in range(len(problem.K1))]
     ccuts = balanced_cone_split(w, nranks)
+    feas = _separable_cone_cuts(A, kb, problem.K2)
+    if any(c not in feas for c in ccuts[1:-1]):
+        # the balanced cuts fall inside a diagonal block (blocks of several K1 cones, uneven blocks): cut at the block boundaries nearest to
+        # the balanced targets instead
+        if len(feas) < nranks - 1:
+            raise ValueError("A has %d diagonal blocks conformal with the K1 / K2 cones, %d ranks asked for: the rows of one rank would reach "
+                             "into the columns of another -- A is not block diagonal conformally with the cones" % (len(feas) + 1, nranks))
+        cum = np.concatenate([[0.0], np.cumsum(w)])
+        fs = sorted(feas)
+        ccuts, lo_i = [0], 0
+        for g in range(1, nranks):
+            target = cum[-1] * g / nranks
+            cand = fs[lo_i:len(fs) - (nranks - 1 - g)]               # leave enough block boundaries for the ranks behind
+            j = min(range(len(cand)), key=lambda q: abs(cum[cand[q]] - target))
+            ccuts.append(int(cand[j]))
+            lo_i += j + 1
+        ccuts.append(len(problem.K1))
     row_cuts = [int(kb[c]) for c in ccuts]
     # columns touched by each row range
     lo, hi = [], []

@@ -26,7 +26,27 @@ def _problem(pkg, kind):
         return w.c4_block_sdp(nblocks=8, k=16, p=6)
     if kind == "sdp-tiles":          # 36 x 8 dense blocks: stored as dual tiles, so the sharded sums include deferred-row records
         return w.c4_block_sdp(nblocks=6, k=8, p=8)
+    if kind.startswith("rand-"):     # random block-diagonal program, uneven blocks, every cone kind on both sides of every block (tests/fuzz_parity.py generators)
+        return random_block_problem(pkg, int(kind.split("-")[1]))
     return w.c5_mixed(nblocks=4, nb_cols=40, nonneg=12, nsoc=3, socdim=5, npsd=2, k=6, density=0.2)
+
+
+def random_block_problem(pkg, seed):
+    import scipy.sparse as sp
+    import fuzz_parity as fz
+    rng = np.random.default_rng([seed, 8081])
+    blocks, K1, K2 = [], [], []
+    for _ in range(int(rng.integers(4, 8))):
+        m, n = int(rng.integers(8, 70)), int(rng.integers(6, 50))
+        blocks.append(sp.random(m, n, density=float(rng.choice([0.1, 0.4, 1.0])), format="csc", random_state=rng, data_rvs=rng.standard_normal))
+        K1 += fz.random_cones(rng, m, 1)
+        K2 += fz.random_cones(rng, n, 2)
+    A = sp.block_diag(blocks, format="csc")
+    A.sort_indices()
+    s0, y0 = fz.moreau_pairs(rng, K1)
+    x0, r0 = fz.moreau_pairs(rng, K2)
+    x0, s0, y0, r0, b, c = pkg.workloads.normalize_data(x0, s0, y0, r0, A)
+    return pkg.workloads.ConicProblem("rand-blocks-%d" % seed, A, b, c, K1, K2, x0=x0, y0=y0, s0=s0)
 
 
 def _alg(pkg, name):
@@ -114,7 +134,7 @@ def _run(kind, algname):
                 p.kill()
 
 
-@pytest.mark.parametrize("kind,algname", [("sdp", "DR"), ("sdp-tiles", "DR"), ("mixed", "GAPA"), ("mixed", "FISTA")])
+@pytest.mark.parametrize("kind,algname", [("sdp", "DR"), ("sdp-tiles", "DR"), ("mixed", "GAPA"), ("mixed", "FISTA"), ("rand-1", "DR"), ("rand-2", "GAPA"), ("rand-3", "FISTA")])
 def test_two_ranks_one_gpu_match_unsharded(pkg, oracle, kind, algname):
     orc = oracle
     got = _run(kind, algname)
@@ -150,7 +170,8 @@ def test_two_ranks_one_gpu_match_unsharded(pkg, oracle, kind, algname):
     # difference (plain CG on the indefinite KKT system, see tests/test_gpu_parity.py), so the end point is compared
     # inside the envelope those tolerances allow
     z2 = pkg.sharding.local_to_global([got[r]["z2"] for r in range(2)], shards)
-    assert np.linalg.norm(z2 - x2) <= 1e-7 * max(1.0, np.linalg.norm(x2))
+    # (random block problems are worse conditioned than the structured ones: 2e-7 measured there)
+    assert np.linalg.norm(z2 - x2) <= (5e-6 if kind.startswith("rand-") else 1e-7) * max(1.0, np.linalg.norm(x2))
     assert np.linalg.norm(z - x) <= 0.05 * max(1.0, np.linalg.norm(x))
     # global norms and the status sums of the sharded check vs the unsharded one / the oracle on the gathered point
     assert got[0]["res"]["norm_b"] == pytest.approx(res.norm_b, rel=1e-13)

@@ -256,3 +256,35 @@ def test_plan_rejects_non_separable(pkg):
     prob = w.ConicProblem("ok", A, np.zeros(4), np.zeros(4), [("NonNeg", 2), ("NonNeg", 2)], [("NonNeg", 4)])
     s0, s1 = (pkg.sharding.shard_problem(prob, 2, r) for r in range(2))
     assert s0.problem.K2 == [("NonNeg", 2)] and s1.cols == (2, 4)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+def test_plan_cuts_uneven_multi_cone_blocks_at_block_boundaries(pkg, seed):
+    """Blocks of several K1 / K2 cones each (every cone kind) and uneven sizes: the balanced cone split falls inside a block, so the plan moves its
+    cuts to the block boundaries nearest to the balanced targets; the shards partition A exactly (no entry lost, none outside a shard's columns),
+    no second-order / PSD / exponential cone of K2 is cut, and asking for more ranks than there are blocks is refused."""
+    import scipy.sparse as sp
+    import fuzz_parity as fz
+    rng = np.random.default_rng([seed, 8081])
+    blocks, K1, K2, nb = [], [], [], int(rng.integers(4, 8))
+    for _ in range(nb):
+        m, n = int(rng.integers(8, 70)), int(rng.integers(6, 50))
+        blocks.append(sp.csc_matrix(rng.standard_normal((m, n))))            # dense blocks: exactly nb diagonal blocks
+        K1 += fz.random_cones(rng, m, 1)
+        K2 += fz.random_cones(rng, n, 2)
+    A = sp.block_diag(blocks, format="csc")
+    prob = pkg.workloads.ConicProblem("blocks", A, rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[1]), K1, K2)
+    for world in range(2, nb + 1):
+        shards = [pkg.sharding.shard_problem(prob, world, r) for r in range(world)]
+        assert sum(s.problem.A.nnz for s in shards) == A.nnz
+        assert [s.rows[0] for s in shards] + [shards[-1].rows[1]] == sorted({s.rows[0] for s in shards} | {A.shape[0]})
+        assert sum(s.problem.m for s in shards) == A.shape[0] and sum(s.problem.n for s in shards) == A.shape[1]
+        assert sum(len(s.problem.K1) for s in shards) == len(K1)
+        assert sum(l for s in shards for _, l in s.problem.K2) == A.shape[1]
+        for s in shards:
+            assert all(l == dict(Free=l, Zero=l, NonNeg=l, NonPos=l).get(k, l) for k, l in s.problem.K2)
+        # K2 cones that are not elementwise arrive whole
+        whole = sorted((k, l) for k, l in K2 if k not in ("Free", "Zero", "NonNeg", "NonPos"))
+        assert sorted((k, l) for s in shards for k, l in s.problem.K2 if k not in ("Free", "Zero", "NonNeg", "NonPos")) == whole
+    with pytest.raises(ValueError):
+        pkg.sharding.plan(prob, nb + 1)
