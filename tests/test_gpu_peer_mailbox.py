@@ -314,6 +314,18 @@ def _rows_problem(pkg, name):
     if name == "mixed":
         return pkg.workloads.small_mixed()
     import scipy.sparse as sp
+    if name.startswith("rand"):          # a random coupled A under random cones of every kind on both sides (tests/fuzz_parity.py generators)
+        import fuzz_parity as fz
+        rng = np.random.default_rng([int(name[4:] or 0), 9091])
+        m, n = int(rng.integers(120, 260)), int(rng.integers(40, 120))
+        A = sp.random(m, n, density=0.15, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+        K1, K2 = fz.random_cones(rng, m, 1), fz.random_cones(rng, n, 2)
+        while len(K1) < 4:
+            K1 = fz.random_cones(rng, m, 1)
+        s0, y0 = fz.moreau_pairs(rng, K1)
+        x0, r0 = fz.moreau_pairs(rng, K2)
+        x0, s0, y0, r0, b, c = pkg.workloads.normalize_data(x0, s0, y0, r0, A)
+        return pkg.workloads.ConicProblem("rand-rows", A, b, c, K1, K2, x0=x0, y0=y0, s0=s0)
     rng = np.random.default_rng(21)
     K1 = [("NonNeg", 70), ("SOC", 24), ("SOC", 30), ("NonNeg", 40), ("SDP", 36), ("Zero", 20)]
     m, n = sum(l for _, l in K1), 150
@@ -442,7 +454,8 @@ def _worker_rows(rank, world, port, algname, iters, q, transport="host", pname="
 
 @pytest.mark.parametrize("algname,transport,pname", [("DR", "host", "mixed"), ("GAPA", "host", "mixed"), ("DR", "peer", "mixed"), ("GAPA", "peer", "mixed"),
                                                      ("DR", "host", "dense"), ("GAPA", "peer", "dense"), ("GAPA", "peer-rsag", "mixed"), ("DR", "peer-rsag", "dense"),
-                                                     ("DR", "host", "mixed-win"), ("GAPA", "peer", "mixed-win")])
+                                                     ("DR", "host", "mixed-win"), ("GAPA", "peer", "mixed-win"),
+                                                     ("DR", "peer", "rand1"), ("GAPA", "host", "rand2"), ("DR", "peer-rsag", "rand3")])
 def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname, transport, pname):
     """SURVEY 8(f2) with TWO ranks on the one GPU of the test box: each process holds the rows of half of the K1 cones of a
     problem whose A couples everything (workloads.small_mixed), the n-vector A'y and every scalar sum cross the processes
@@ -512,7 +525,8 @@ def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname, transport
     _, res = d0.getsol(force_check=True, eps=1e-6)
     assert g0["cg"][0] == cg[0]
     zz1 = pkg.sharding.rows_local_to_global([g0["z1"], g1["z1"]], shards)
-    assert np.linalg.norm(zz1 - z1) <= 1e-7 * max(1.0, np.linalg.norm(z1))
+    # (the random problems are worse conditioned than small_mixed: 1.3e-6 measured after that first, loosely solved, iteration)
+    assert np.linalg.norm(zz1 - z1) <= (1e-5 if pname.startswith("rand") else 1e-7) * max(1.0, np.linalg.norm(z1))
     zz = pkg.sharding.rows_local_to_global([g0["z"], g1["z"]], shards)
     tol = 1e-3 if g0["cg"] == cg else 0.2
     assert np.linalg.norm(zz - z) <= tol * max(1.0, np.linalg.norm(z))
@@ -540,7 +554,7 @@ def test_row_sharded_two_processes_host_exchange(pkg, oracle, algname, transport
     st1.i = 1
     oalg.step(xo, 1, st1)
     assert abs(g0["cg"][0] - oalg.S1.getcgiter()) <= 1
-    assert np.linalg.norm(zz1 - xo) <= 1e-7 * max(1.0, np.linalg.norm(xo))
+    assert np.linalg.norm(zz1 - xo) <= (1e-5 if pname.startswith("rand") else 1e-7) * max(1.0, np.linalg.norm(xo))
 
 
 def test_row_sharded_three_ranks_reduce_scatter_all_gather(pkg):
