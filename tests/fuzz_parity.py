@@ -3,7 +3,7 @@
 Per seed: random sizes, density, cone partitions over every cone kind (both sides), random operator format (row blocks / dual tiles /
 forced window panels of both geometries) -- then the operator products, the cone projection at several scales, a tight CG solve and,
 every few seeds, a whole DR / GAPA / FISTA solve of a problem with a known complementary pair.  Prints one line per failure and a summary;
-exit code 1 if anything failed.  tests/test_gpu_fuzz.py runs a short fixed slice of it under pytest."""
+exit code 1 if anything failed.  tests/test_gpu_zz_fuzz.py runs a short fixed slice of it under pytest."""
 import argparse
 import math
 import os
