@@ -904,19 +904,23 @@ __global__ __launch_bounds__(VEC_THREADS) void long_plane_kernel(int64_t l, d2* 
 // G = P P' formed in float64 loses cond(P)^2 eps = everything.  Products by FMA (exact), sums by TwoSum, across the workgroup as well; the host
 // adds the workgroups' pairs and solves the small dual in 113-bit arithmetic (solver.cpp, long_project_planes).
 struct dd { double hi, lo; };
+// (plain operators under `fp contract(off)`: the error-free transformations below must not be contracted into FMAs -- the __dadd_rn / __dmul_rn
+//  of this toolchain's headers are a plain + and * compiled with contraction ON, and were fused: checked in the ISA)
 __device__ __forceinline__ dd dd_add(dd a, dd b) {
-    const double s = __dadd_rn(a.hi, b.hi), z = __dadd_rn(s, -a.hi);
-    double e = __dadd_rn(__dadd_rn(a.hi, -__dadd_rn(s, -z)), __dadd_rn(b.hi, -z));
-    e = __dadd_rn(e, __dadd_rn(a.lo, b.lo));
+#pragma clang fp contract(off)
+    const double s = a.hi + b.hi, z = s - a.hi;
+    double e = (a.hi - (s - z)) + (b.hi - z);
+    e = e + (a.lo + b.lo);
     dd r;
-    r.hi = __dadd_rn(s, e);
-    r.lo = __dadd_rn(e, -__dadd_rn(r.hi, -s));
+    r.hi = s + e;
+    r.lo = e - (r.hi - s);
     return r;
 }
 __device__ __forceinline__ void dd_add_prod(dd& acc, double a, double b) {      // acc += a b
+#pragma clang fp contract(off)
     dd p;
-    p.hi = __dmul_rn(a, b);
-    p.lo = __fma_rn(a, b, -p.hi);
+    p.hi = a * b;
+    p.lo = __builtin_fma(a, b, -p.hi);
     acc = dd_add(acc, p);
 }
 template <int NV>
@@ -970,7 +974,7 @@ __global__ __launch_bounds__(VEC_THREADS) void long_apply_kernel(int64_t l, d2* 
             dd_add_prod(sx, wh, r.x); dd_add_prod(sx, wl, r.x);
             dd_add_prod(sy, wh, r.y); dd_add_prod(sy, wl, r.y);
         }
-        x[i] = make_double2(__dadd_rn(sx.hi, sx.lo), __dadd_rn(sy.hi, sy.lo));
+        x[i] = make_double2(sx.hi + sx.lo, sy.hi + sy.lo);
     }
 }
 void launch_long_plane(const LaunchCtx& c, double2* row, const double2* x, const double2* y, double* bpart) {
