@@ -1,6 +1,6 @@
 """A fixed slice of the randomised differential campaign (tests/fuzz_parity.py: random sizes, densities, cone partitions over every cone kind,
 operator formats, algorithms, wrappers -- HIP path against the oracle).  The full campaign (round 4: 3 000 HSDE seeds -- products, projections, CG,
-whole solves --, 6 600 HSDE seeds with direct = true and 3 000 Feasibility seeds -- 20 iterates each --, 600 large operators) found no discrepancy beyond the situations
+whole solves --, 6 600 HSDE seeds with direct = true and 5 000 Feasibility seeds -- 20 iterates each --, 600 large operators) found no discrepancy beyond the situations
 the script documents, in which the reference's own arithmetic is decided by rounding noise.
 (Named to run LAST under `pytest -x`: a campaign slice is the test most exposed to a one-ulp difference between boxes, and must not hide the others.)"""
 import pytest
