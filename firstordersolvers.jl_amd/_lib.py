@@ -76,6 +76,8 @@ PROTOTYPES = {
     "fos_getsol": (C.c_int, [_h, _dp, C.c_int32, C.c_double, C.POINTER(CheckResult)]),
     "fos_get_affine_state": (C.c_int, [_h, _dp, _i64p, _i32p]),
     "fos_set_affine_state": (C.c_int, [_h, _dp, C.c_int64]),
+    "fos_get_alg_state": (C.c_int, [_h, _dp, _dp, _dp]),
+    "fos_set_alg_state": (C.c_int, [_h, _dp, _dp, _dp]),
     "fos_get_cgiter": (C.c_int, [_h, _i64p]),
     "fos_get_alpha12": (C.c_int, [_h, _dp]),
     "fos_get_prox_count": (C.c_int, [_h, _i64p]),

@@ -679,6 +679,7 @@ int fos_feas_set_gapp(fos_feas_handle h, double alpha, double alpha1, double alp
     if (!h || iproj < 1) { set_error("fos_feas_set_gapp: iproj >= 1 is required"); return FOS_EINVAL; }
     h->alg = FOS_ALG_GAPP; h->alpha = alpha; h->alpha1 = alpha1; h->alpha2 = alpha2; h->beta = 0.0; h->gapp_iproj = iproj;
     h->ls_interval = 0;
+    h->lp.interval = 0; h->lp.savepos = 0; h->lp.now = false;          // a fresh algorithm is unwrapped (support_longstep(::GAPP) = false, gapproj.jl:83)
     return FOS_OK;
 }
 int fos_feas_gapp_log(fos_feas_handle h, double* out23) {
@@ -693,6 +694,8 @@ int fos_feas_set_linesearch(fos_feas_handle h, int64_t lsinterval) {
         set_error("this algorithm does not support line search (support_linesearch: GAP and GAPA only, solvers/defaults.jl:22)");
         return FOS_EUNSUPPORTED;
     }
+    // (a search iteration returns before the planes of a saving window are written: the two wrappers exclude each other, both ways)
+    if (lsinterval > 0 && h->lp.interval > 0) { set_error("LineSearchWrapper inside a LongstepWrapper is not supported (fos_feas_set_longstep(h, 0, 0) first)"); return FOS_EUNSUPPORTED; }
     h->ls_interval = lsinterval;
     return FOS_OK;
 }
@@ -707,6 +710,14 @@ int fos_feas_set_longstep(fos_feas_handle h, int64_t longinterval, int64_t nsave
     FOS_HIP(hipSetDevice(h->device));
     const int64_t K = 2 * (nsave + 1);
     if (!h->lp.P || h->lp.nsave != nsave) {
+        FOS_HIP(hipStreamSynchronize(h->stream));
+        for (void* old : {(void*)h->lp.P, (void*)h->lp.bpart, (void*)h->lp.dots, (void*)h->lp.nu}) {       // replaced, not piled up (feas_alloc zeroes the new ones)
+            if (!old) continue;
+            auto it = std::find(h->owned.begin(), h->owned.end(), old);
+            if (it != h->owned.end()) h->owned.erase(it);
+            (void)hipFree(old);
+        }
+        h->lp.P = nullptr; h->lp.bpart = nullptr; h->lp.dots = nullptr; h->lp.nu = nullptr;
         double* q = nullptr;
         FOS_TRY(feas_alloc(h, &q, (size_t)K * h->L)); h->lp.P = reinterpret_cast<double2*>(q);
         FOS_TRY(feas_alloc(h, &h->lp.bpart, (size_t)K * h->grid));

@@ -235,7 +235,9 @@ struct fos_solver {
     struct ProfRec { hipEvent_t a, b; int cls; int j; };
     std::vector<ProfRec> prof_recs;            // event pairs, reused
     size_t prof_used = 0;
-    int64_t prof_seen[FOS_PROF_CLASSES] = {0, 0, 0};
+    int64_t prof_seen[FOS_PROF_CLASSES] = {0, 0, 0, 0};
+    int64_t prof_steps = 0, prof_steps_sampled = 0;   // outer iterations since fos_profile / of them sampled for FOS_PROF_OTHER
+    bool prof_step_on = false;                 // the outer iteration in flight brackets its FOS_PROF_OTHER groups
     static constexpr size_t PROF_CAP = 16384;
 
     static int sum_slots_over_ranks(void* self);      // defined below (needs the RCCL table)
@@ -307,6 +309,15 @@ int dev_alloc(fos_solver* h, T** p, size_t count) {
 }
 
 template <class T>
+void dev_release(fos_solver* h, T** p) {          // frees a dev_alloc'd buffer before the handle's end
+    if (!*p) return;
+    auto it = std::find(h->owned.begin(), h->owned.end(), (void*)*p);
+    if (it != h->owned.end()) h->owned.erase(it);
+    (void)hipFree(*p);
+    *p = nullptr;
+}
+
+template <class T>
 int dev_upload(fos_solver* h, T** p, const std::vector<T>& v) {
     FOS_TRY(dev_alloc(h, p, v.size()));
     if (!v.empty()) FOS_HIP(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -358,6 +369,12 @@ int prof_begin(fos_solver* h, int cls, int j, int64_t ordinal) {
     r.cls = cls; r.j = j;
     if (hipEventRecord(r.a, h->stream) != hipSuccess) return -1;
     return (int)h->prof_used++;
+}
+// FOS_PROF_OTHER: a launch group that is neither sweep, CG vector update nor PSD projection, in a sampled outer iteration; post = 1: the group
+// belongs to the work enqueued (gated) behind a CG solve -- dropped with it when the gate stayed shut (affine_then)
+int prof_begin_other(fos_solver* h, int post) {
+    if (!h->prof || !h->prof_step_on) return -1;
+    return prof_begin(h, FOS_PROF_OTHER, post, 0);
 }
 void prof_end(fos_solver* h, int idx) {
     if (idx >= 0) (void)hipEventRecord(h->prof_recs[idx].b, h->stream);
@@ -502,24 +519,30 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
         // w_0 = M r_0, the sweep every iteration's update starts from (it also adds g_0 = r_0.r_0 unless the first update does)
         CgmIter it0 = merged_desc(0);
         const d2* v = apply_on ? apply_on : x;
+        const int po = prof_begin_other(h, 0);
         launch_cgm_apply(c, it0, v);                                       // :32  mul!(Ap, A, x)
         if (c.between) FOS_TRY(c.between(c.between_arg));
         if (rccl) { launch_reduce1(c, c.S.nwg, 3, 0, 0); FOS_TRY(allreduce(h, 3)); }
         launch_cgm_start(c, it0, rhs, v, tol, maxit);                      // :33-36
+        prof_end(h, po);
         const int pe = prof_begin(h, FOS_PROF_KKT, 0, h->cg_total);
         launch_cgm_sweep(c, it0, close_in_update ? -1 : 0);
         prof_end(h, pe);
     } else if (start_fused) {
         CgmIter it0 = merged_desc(0);
         const d2* v = apply_on ? apply_on : x;
+        const int po = prof_begin_other(h, 0);
         launch_cgm_apply(c, it0, v);                                       // :32  mul!(Ap, A, x)
         launch_cgm_start(c, it0, rhs, v, tol, maxit, h->PB[1]);            // :33-36   (p_1 in buffer 1)
+        prof_end(h, po);
     } else {
         int fr = 0;
+        const int po = prof_begin_other(h, 0);
         FOS_TRY(kkt_apply_full(h, c, apply_on ? apply_on : x, h->AP));    // :32  mul!(Ap, A, x)
         launch_cg_init(c, rhs, h->AP, h->R, h->PB[1]);                     // :33-34   (p_1 in buffer 1)
         FOS_TRY(finish_reduce(h, c, c.vec_blocks, 1, 0, &fr));
         launch_cg_init_finalize(c, h->R, tol, maxit, fr);                  // :35-36
+        prof_end(h, po);
     }
     auto enqueue = [&](int count) -> int {
         if (merged) {
@@ -599,7 +622,7 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     *iters = h->st_host->iter;
     // profiling: launches enqueued past convergence were gated no-ops -- drop their event pairs
     for (size_t k = prof_start; k < h->prof_used; ++k)
-        if (h->prof_recs[k].j > h->st_host->iter) h->prof_recs[k].cls = -1;
+        if (h->prof_recs[k].cls != FOS_PROF_OTHER && h->prof_recs[k].j > h->st_host->iter) h->prof_recs[k].cls = -1;
     h->cg_same_run = (h->st_host->iter == h->last_cg_pred) ? h->cg_same_run + 1 : 0;
     h->last_cg_pred = h->st_host->iter;
     h->cg_total += h->st_host->iter;
@@ -646,7 +669,11 @@ int prox_affine(fos_solver* h, const d2* x, const PostFn* post = nullptr, bool* 
         FOS_HIP(hipMemcpyAsync(h->SOL, x, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));
         h->firstrun = false;
     }
-    if (fused_rhs && !(h->shift_ready && x == h->X)) launch_shift_part2(c, h->RHS, h->SOL, x);           // RHS buffer := y - [0; x2]
+    if (fused_rhs && !(h->shift_ready && x == h->X)) {
+        const int po = prof_begin_other(h, 0);
+        launch_shift_part2(c, h->RHS, h->SOL, x);                       // RHS buffer := y - [0; x2]
+        prof_end(h, po);
+    }
     h->shift_ready = false;                                             // (SOL changes below)
     // :108-112   tol = max(0.2^sqrt(i), size(A,2)*eps())
     const double eps = 2.220446049250313e-16;
@@ -666,9 +693,11 @@ int prox_cones(fos_solver* h, d2* out, const d2* in, const int32_t* gate = nullp
     RoctxRange range("fos:prox_cones (elementwise + SOC + Exp + batched PSD)");
     LaunchCtx c = h->ctx();
     c.gate = gate;
+    const int po = (!ew_done || h->nsoc > 0 || h->nexp > 0) ? prof_begin_other(h, gate ? 1 : 0) : -1;
     if (!ew_done) launch_cones_elementwise(c, out, in, h->ew_op);
     launch_cones_soc(c, out, in, h->soc, h->nsoc);
     launch_cones_exp(c, out, in, h->expc, h->nexp);
+    prof_end(h, po);
     const int pe = h->npsd > 0 ? prof_begin(h, FOS_PROF_PSD, 0, h->prof_seen[FOS_PROF_PSD]++) : -1;
     FOS_TRY(launch_cones_psd(c, out, in, h->psd, h->npsd, h->psd_kmin, h->psd_kmax, h->psd_scratch,
                              h->psd_V[h->psd_cur], h->psd_V[1 - h->psd_cur], h->psd_have_prev, h->psd_stats, h->psd_phase_limit, h->psd_redo));
@@ -963,7 +992,8 @@ int affine_then(fos_solver* h, const LaunchCtx& c, const d2* in, const PostFn& p
     if (!ran) {
         h->psd_cur = psd_cur; h->psd_have_prev = psd_have_prev; h->prof_seen[FOS_PROF_PSD] = psd_seen; h->fista_t = fista_t;
         // (event pairs recorded around no-op launches: forget them; the CG records of this solve stay)
-        for (size_t k = prof_used; k < h->prof_used; ++k) if (h->prof_recs[k].cls == FOS_PROF_PSD) h->prof_recs[k].cls = -1;
+        for (size_t k = prof_used; k < h->prof_used; ++k)
+            if (h->prof_recs[k].cls == FOS_PROF_PSD || (h->prof_recs[k].cls == FOS_PROF_OTHER && h->prof_recs[k].j == 1)) h->prof_recs[k].cls = -1;
         FOS_TRY(post(c));
     }
     return FOS_OK;
@@ -1011,15 +1041,19 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bo
                     h->shift_ready = sh;
                     return check_launch("fused relaxation + PSD projection + final pass");
                 }
+                const int pg = cg.gate ? 1 : 0;
+                int po = prof_begin_other(h, pg);
                 if (fuse_ew) {                       // the relaxation and the elementwise cones of S2! in one pass
                     launch_relax_ew(cg, h->T1, h->T2, h->SOL, h->X, h->alpha1, gapa, h->ew_op);
+                    prof_end(h, po);
                     FOS_TRY(prox_cones(h, h->T2, h->T1, cg.gate, true));
                 } else {
                 if (gapa) launch_relax_a12(cg, h->T1, h->SOL, h->X);                          // gapa.jl:67
                 else launch_axpby(cg, h->T1, h->alpha1, h->SOL, 1 - h->alpha1, h->X);          //   y = a1 y + (1-a1) x     :48
+                prof_end(h, po);
                 FOS_TRY(prox_cones(h, h->T2, h->T1, cg.gate));                                // S2!: prox!(y,S2,x)  :55
                 }
-                if (!will_check) FOS_TRY(step_finish_launch(h, cg));
+                if (!will_check) { po = prof_begin_other(h, pg); FOS_TRY(step_finish_launch(h, cg)); prof_end(h, po); }
                 return FOS_OK;
             };
             FOS_TRY(affine_then(h, c, h->X, post));                      // S1!: prox!(y,S1,x)          :45
@@ -1030,10 +1064,13 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bo
         case FOS_ALG_FISTA: {                                            // fista.jl:28-48
             if (i == 1) FOS_HIP(hipMemcpyAsync(h->Y, h->X, sizeof(d2) * h->l, hipMemcpyDeviceToDevice, h->stream));   // :31-33
             const PostFn post = [h, will_check](const LaunchCtx& cg) -> int {
+                const int pg = cg.gate ? 1 : 0;
+                int po = prof_begin_other(h, pg);
                 launch_axpby(cg, h->T1, h->alpha, h->SOL, 1 - h->alpha, h->Y);                 // :37
                 launch_copy(cg, h->XOLD, h->X);                                               // :39  xold .= x
+                prof_end(h, po);
                 FOS_TRY(prox_cones(h, h->X, h->T1, cg.gate));                                 // :40
-                if (!will_check) FOS_TRY(step_finish_launch(h, cg));
+                if (!will_check) { po = prof_begin_other(h, pg); FOS_TRY(step_finish_launch(h, cg)); prof_end(h, po); }
                 return FOS_OK;
             };
             FOS_TRY(affine_then(h, c, h->Y, post));                      // :35
@@ -1044,10 +1081,13 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bo
         case FOS_ALG_DYKSTRA: {                                          // dykstra.jl:25-36   (p = Y, q = XOLD)
             launch_add(c, h->W, h->X, h->Y);                             // x .+ p
             const PostFn post = [h, will_check](const LaunchCtx& cg) -> int {
+                const int pg = cg.gate ? 1 : 0;
+                int po = prof_begin_other(h, pg);
                 launch_dykstra_corr(cg, h->Y, h->X, h->SOL);                                  // p .= x .+ p .- y            :30
                 launch_add(cg, h->W, h->SOL, h->XOLD);                                        // y .+ q
+                prof_end(h, po);
                 FOS_TRY(prox_cones(h, h->X, h->W, cg.gate));                                  // prox!(x, S2, y .+ q)        :31
-                if (!will_check) FOS_TRY(step_finish_launch(h, cg));
+                if (!will_check) { po = prof_begin_other(h, pg); FOS_TRY(step_finish_launch(h, cg)); prof_end(h, po); }
                 return FOS_OK;
             };
             FOS_TRY(affine_then(h, c, h->W, post));                      // prox!(y, S1, x .+ p)        :28
@@ -1233,10 +1273,12 @@ int long_project_planes(const LaunchCtx& c, LongPlanes& lp, d2* X, int64_t i) {
     // (i) an active-set walk from the empty support: drop the most negative multiplier, else add the most violated inequality -- a handful of
     //     solves when it ends at the solution (it is accepted by the same KKT test); (ii) otherwise the enumeration of all supports
     bool found = false;
+    // budget of candidate supports (FOS_LONG_MAX_SUPPORTS; 0 tries none: the failure path, tests)
+    const int64_t LONG_MAX_SUPPORTS = getenv("FOS_LONG_MAX_SUPPORTS") ? atoll(getenv("FOS_LONG_MAX_SUPPORTS")) : 4096;
     {
         uint32_t mask = 0;
         std::vector<uint32_t> seen;
-        for (int it = 0; it < 4 * nin + 4 && !found; ++it) {
+        for (int it = 0; it < 4 * nin + 4 && !found && tried < LONG_MAX_SUPPORTS; ++it) {
             if (std::find(seen.begin(), seen.end(), mask) != seen.end()) break;
             seen.push_back(mask);
             if (try_support(mask)) { found = true; break; }
@@ -1252,7 +1294,22 @@ int long_project_planes(const LaunchCtx& c, LongPlanes& lp, d2* X, int64_t i) {
             else break;
         }
     }
-    for (uint32_t mask = 0; !found && mask < (1u << nin); ++mask) found = try_support(mask);
+    // (ii) bounded: inconsistent or dependent planes have NO support that passes the KKT test, and 2^nin solves in 113-bit arithmetic (each a
+    // Jacobi eigen-decomposition when Cholesky rejects the block) would hold fos_step for minutes -- at most LONG_MAX_SUPPORTS candidates, smallest
+    // supports first in counting order, and never longer than LONG_MAX_SECONDS
+    const double LONG_MAX_SECONDS = 2.0;
+    const auto t_enum = std::chrono::steady_clock::now();
+    for (uint32_t mask = 0; !found && mask < (1u << nin) && tried < LONG_MAX_SUPPORTS; ++mask) {
+        found = try_support(mask);
+        if ((mask & 63u) == 63u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enum).count() > LONG_MAX_SECONDS) break;
+    }
+    lp.log[6] = found ? 0.0 : 1.0;
+    if (!found) {
+        // no KKT point of the small dual within the budget: the planes do not describe a projection -- the iterate stays as the wrapped
+        // algorithm left it (the reference's QP solver throws here; a step that is not the projection must not be applied silently)
+        lp.log[0] = (double)i; lp.log[1] = (double)best_active; lp.log[2] = (double)(best_viol / scale); lp.log[3] = 0.0; lp.log[4] = (double)K; lp.log[5] = (double)tried;
+        return FOS_OK;
+    }
     qreal step2 = 0;                                                          // |P' nu|^2 = nu' G nu
     for (int a = 0; a < K; ++a) for (int b2 = 0; b2 < K; ++b2) step2 += best_nu[(size_t)a] * G[(size_t)a * K + b2] * best_nu[(size_t)b2];
     std::vector<double> nu2((size_t)2 * K);                                   // multipliers as (hi, lo) pairs for the double-double update
@@ -2022,13 +2079,16 @@ int fos_step(fos_handle h, int64_t i_first, int64_t count, int64_t checki, doubl
         const d2* check_on = nullptr;
         const bool do_check = (i % checki) == 0;                         // HSDEStatus.jl:28
         bool finish_done = false;
+        h->prof_step_on = h->prof && (h->prof_steps++ % h->prof_period) == 0;
+        if (h->prof_step_on) h->prof_steps_sampled += 1;
         FOS_TRY(step_once(h, i, &check_on, do_check, &finish_done));
         fos_check_result r;
         if (do_check) {
             FOS_TRY(status_check(h, check_on, eps, &r));
             h->last_checked = check_on;
         }
-        if (!finish_done) FOS_TRY(step_finish(h, i));
+        if (!finish_done) { const int po = prof_begin_other(h, 0); FOS_TRY(step_finish(h, i)); prof_end(h, po); }
+        h->prof_step_on = false;
         ++done;
         if (do_check) {
             if (res) *res = r;
@@ -2066,6 +2126,7 @@ int fos_set_gapp(fos_handle h, int64_t iproj) {
     if (iproj > 0 && h->alg != FOS_ALG_GAP) { set_error("GAPP is GAP with a projected search: fos_set_alg(FOS_ALG_GAP, ...) first"); return FOS_EUNSUPPORTED; }
     if (iproj > 0 && (h->sharded() || h->row_sharded)) { set_error("GAPP is built for single-GPU handles only (its test norms are global norms)"); return FOS_EUNSUPPORTED; }
     if (iproj > 0 && h->ls_interval > 0) { set_error("GAPP and the LineSearchWrapper exclude each other"); return FOS_EUNSUPPORTED; }
+    if (iproj > 0 && h->lp.interval > 0) { set_error("GAPP inside a LongstepWrapper is not supported (fos_set_longstep(h, 0, 0) first)"); return FOS_EUNSUPPORTED; }
     h->gapp_iproj = iproj;
     return FOS_OK;
 }
@@ -2085,10 +2146,15 @@ int fos_set_longstep(fos_handle h, int64_t longinterval, int64_t nsave) {
     FOS_HIP(hipSetDevice(h->device));
     const int64_t K = 2 * (nsave + 1);
     if (!h->lp.P || h->lp.nsave != nsave) {
+        FOS_HIP(hipStreamSynchronize(h->stream));
+        dev_release(h, &h->lp.P); dev_release(h, &h->lp.bpart); dev_release(h, &h->lp.dots); dev_release(h, &h->lp.nu);    // (a caller sweeping nsave must not pile buffers up)
         FOS_TRY(dev_alloc(h, &h->lp.P, (size_t)K * h->l));
         FOS_TRY(dev_alloc(h, &h->lp.bpart, (size_t)K * h->vec_blocks));
         FOS_TRY(dev_alloc(h, &h->lp.dots, (size_t)h->vec_blocks * 2 * (LONG_KMAX_ROWS + 1)));
         FOS_TRY(dev_alloc(h, &h->lp.nu, (size_t)2 * K));
+        // rows a saving window never wrote (fos_step entered in the middle of one) are zero planes, not uninitialised memory
+        FOS_HIP(hipMemset(h->lp.P, 0, sizeof(d2) * (size_t)K * h->l));
+        FOS_HIP(hipMemset(h->lp.bpart, 0, sizeof(double) * (size_t)K * h->vec_blocks));
     }
     h->lp.interval = longinterval; h->lp.nsave = nsave; h->lp.savepos = 0; h->lp.now = false;
     return FOS_OK;
@@ -2134,6 +2200,34 @@ int fos_set_affine_state(fos_handle h, const double* xinit, int64_t i) {
     FOS_TRY(upload_plain(h, h->SOL, xinit));
     h->firstrun = false;
     h->prox_i = i;
+    return FOS_OK;
+}
+
+// FISTAData (y, xold, t), DykstraData (p, q), GAPAData.alpha12: the algorithm's own state     fista.jl:15-25, dykstra.jl:12-23, gapa.jl:29
+int fos_get_alg_state(fos_handle h, double* a, double* b, double* scal2) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    if (a) FOS_TRY(download_plain(h, a, h->Y));
+    if (b) FOS_TRY(download_plain(h, b, h->XOLD));
+    if (scal2) {
+        FOS_TRY(poll_state(h));
+        scal2[0] = h->fista_t;
+        scal2[1] = h->st_host->alpha12;
+    }
+    return FOS_OK;
+}
+
+int fos_set_alg_state(fos_handle h, const double* a, const double* b, const double* scal2) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    if (a) FOS_TRY(upload_plain(h, h->Y, a));
+    if (b) FOS_TRY(upload_plain(h, h->XOLD, b));
+    if (scal2) {
+        if (!(scal2[0] >= 1.0)) { set_error("fos_set_alg_state: FISTA's t is >= 1 (fista.jl:24,45), got %g", scal2[0]); return FOS_EINVAL; }
+        h->fista_t = scal2[0];
+        FOS_HIP(hipStreamSynchronize(h->stream));
+        FOS_HIP(hipMemcpy(&h->st->alpha12, &scal2[1], sizeof(double), hipMemcpyHostToDevice));
+    }
     return FOS_OK;
 }
 
@@ -2254,6 +2348,7 @@ int fos_profile(fos_handle h, int32_t enable) {
     h->prof = enable != 0;
     h->prof_period = enable > 1 ? enable : 1;
     for (int k = 0; k < FOS_PROF_CLASSES; ++k) h->prof_seen[k] = 0;
+    h->prof_steps = 0; h->prof_steps_sampled = 0; h->prof_step_on = false;
     return FOS_OK;
 }
 
@@ -2273,8 +2368,8 @@ int fos_profile_read_classes(fos_handle h, int64_t* launches3, double* total_ms3
     if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
     FOS_HIP(hipSetDevice(h->device));
     FOS_HIP(hipStreamSynchronize(h->stream));
-    int64_t n[FOS_PROF_CLASSES] = {0, 0, 0};
-    double t[FOS_PROF_CLASSES] = {0.0, 0.0, 0.0};
+    int64_t n[FOS_PROF_CLASSES] = {0, 0, 0, 0};
+    double t[FOS_PROF_CLASSES] = {0.0, 0.0, 0.0, 0.0};
     for (size_t i = 0; i < h->prof_used; ++i) {
         const auto& r = h->prof_recs[i];
         if (r.cls < 0 || r.cls >= FOS_PROF_CLASSES) continue;
@@ -2282,6 +2377,8 @@ int fos_profile_read_classes(fos_handle h, int64_t* launches3, double* total_ms3
         FOS_HIP(hipEventElapsedTime(&ms, r.a, r.b));
         n[r.cls] += 1; t[r.cls] += ms;
     }
+    n[FOS_PROF_OTHER] = h->prof_steps_sampled;           // this class is normalised per sampled OUTER ITERATION (foship.h)
+    h->prof_steps_sampled = 0;
     for (int k = 0; k < FOS_PROF_CLASSES; ++k) {
         if (launches3) launches3[k] = n[k];
         if (total_ms3) total_ms3[k] = t[k];

@@ -246,7 +246,7 @@ class HipHSDE:
         """last projection onto the saved planes: dict(iteration, active inequalities, KKT violation of the small dual, step length, rows, supports tried)"""
         out = np.zeros(8)
         _lib.check(self._lib.fos_longstep_log(self._h, _lib.dptr(out)))
-        return dict(iteration=int(out[0]), active=int(out[1]), violation=float(out[2]), step=float(out[3]), rows=int(out[4]), tried=int(out[5]))
+        return dict(iteration=int(out[0]), active=int(out[1]), violation=float(out[2]), step=float(out[3]), rows=int(out[4]), tried=int(out[5]), failed=bool(out[6]))
 
     def gapp_log(self):
         """(iteration, [21 test norms], alpha_best) of GAPP's last search."""
@@ -308,6 +308,24 @@ class HipHSDE:
     def set_affine_state(self, xinit, i):
         xinit = _lib.as_f64(xinit, self.N)
         _lib.check(self._lib.fos_set_affine_state(self._h, _lib.dptr(xinit), int(i)))
+
+    def get_alg_state(self):
+        """(a, b, t, alpha12): FISTAData.y / .xold / .t (fista.jl:15-25), DykstraData.p / .q (dykstra.jl:12-23), GAPAData.alpha12."""
+        a, b, sc = np.empty(self.N), np.empty(self.N), np.zeros(2)
+        _lib.check(self._lib.fos_get_alg_state(self._h, _lib.dptr(a), _lib.dptr(b), _lib.dptr(sc)))
+        return a, b, float(sc[0]), float(sc[1])
+
+    def set_alg_state(self, a=None, b=None, t=None, alpha12=None):
+        """installs what is given (fos_set_alg_state); t / alpha12 default to the handle's current values"""
+        sc = None
+        if t is not None or alpha12 is not None:
+            cur = np.zeros(2)
+            _lib.check(self._lib.fos_get_alg_state(self._h, None, None, _lib.dptr(cur)))
+            sc = np.array([cur[0] if t is None else float(t), cur[1] if alpha12 is None else float(alpha12)])
+        a = None if a is None else _lib.as_f64(a, self.N)
+        b = None if b is None else _lib.as_f64(b, self.N)
+        _lib.check(self._lib.fos_set_alg_state(self._h, None if a is None else _lib.dptr(a), None if b is None else _lib.dptr(b),
+                                               None if sc is None else _lib.dptr(sc)))
 
     def cgiter(self):
         v = C.c_int64(0)
@@ -436,11 +454,12 @@ class HipHSDE:
         _lib.check(self._lib.fos_debug_set(self._h, int(what), int(value)))
 
     def profile_read_classes(self):
-        """{'kkt' | 'psd' | 'cgvec': (launch groups, summed ms)} of the bracketed launches since the last read."""
-        n = (C.c_int64 * 3)()
-        ms = (C.c_double * 3)()
+        """{'kkt' | 'psd' | 'cgvec': (launch groups, summed ms), 'other': (sampled outer iterations, summed ms of every other launch
+        group in them)} of the bracketed launches since the last read."""
+        n = (C.c_int64 * 4)()
+        ms = (C.c_double * 4)()
         _lib.check(self._lib.fos_profile_read_classes(self._h, n, ms))
-        return {k: (n[i], ms[i]) for i, k in enumerate(("kkt", "psd", "cgvec"))}
+        return {k: (n[i], ms[i]) for i, k in enumerate(("kkt", "psd", "cgvec", "other"))}
 
     def psd_debug(self, collect_stats=True, phase_limit=0):
         _lib.check(self._lib.fos_psd_debug(self._h, 1 if collect_stats else 0, int(phase_limit)))
@@ -864,7 +883,7 @@ class HipFeasibility:
     def longstep_log(self):
         out = np.zeros(8)
         _lib.check(self._lib.fos_feas_longstep_log(self._h, _lib.dptr(out)))
-        return dict(iteration=int(out[0]), active=int(out[1]), violation=float(out[2]), step=float(out[3]), rows=int(out[4]), tried=int(out[5]))
+        return dict(iteration=int(out[0]), active=int(out[1]), violation=float(out[2]), step=float(out[3]), rows=int(out[4]), tried=int(out[5]), failed=bool(out[6]))
 
     def gapp_log(self):
         """(iteration, [21 test norms], alpha_best) of GAPP's last search."""

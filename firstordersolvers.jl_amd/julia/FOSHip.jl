@@ -277,6 +277,24 @@ function getsol(alg::FOSAlgorithm, data::HipData, x)
     return guess
 end
 
+# ---- checkpoint / resume of a device-resident run: the iterate, S1's persistent state (CGdata.xinit, AffinePlusLinear.i:
+#      affinepluslinear.jl:58-69,114) and the algorithm's *Data struct (FISTAData.y/.xold/.t fista.jl:15-25, DykstraData.p/.q
+#      dykstra.jl:12-23, GAPAData.alpha12 gapa.jl:29) -- everything `iterate` would need to go on from iteration i + 1 elsewhere
+function checkpoint(data::HipData, N::Integer)
+    x, xinit, a, b = (Vector{Float64}(undef, N) for _ in 1:4)
+    i, firstrun, scal = Ref{Int64}(0), Ref{Int32}(0), zeros(2)
+    check(ccall((:fos_get_iterate, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, x))
+    check(ccall((:fos_get_affine_state, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ref{Int64}, Ref{Int32}), data.handle, xinit, i, firstrun))
+    check(ccall((:fos_get_alg_state, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), data.handle, a, b, scal))
+    return (x = x, xinit = xinit, i = i[], firstrun = firstrun[] != 0, a = a, b = b, t = scal[1], alpha12 = scal[2])
+end
+function restore!(data::HipData, cp)
+    check(ccall((:fos_set_iterate, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), data.handle, cp.x))
+    cp.firstrun || check(ccall((:fos_set_affine_state, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64), data.handle, cp.xinit, Int64(cp.i)))
+    check(ccall((:fos_set_alg_state, libfoship), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), data.handle, cp.a, cp.b, [cp.t, cp.alpha12]))
+    return data
+end
+
 # ---- Feasibility form [problemforms/Feasibility/Feasibility.jl, FeasibilityStatus.jl]: solve!(Feasibility(S1, S2, n), alg; gpu=true)
 #      with S1, S2 among ProximalOperators.IndAffine (dense A), IndBox -- the sets of test/testfeasibility.jl -- and
 #      FirstOrderSolvers.ConeProduct on the device; any other ProximableFunction through a host callback (fos_feas_set_callback).

@@ -215,7 +215,8 @@ int fos_linesearch_log(fos_handle h, double* out34);
  * (BigFloat, because successive normals are nearly dependent); here its dual in the 2 (nsave + 1) multipliers is solved by enumeration of the active
  * inequalities -- the same unique point -- with the Gram products formed in double-double on the device and the small systems solved in 113-bit arithmetic.
  * nsave <= 15; longinterval >= nsave + 1; 0 switches the wrapper off.  out8 = iteration of the last projection, active inequalities, largest KKT violation of
- * the small dual, |x_new - x|, rows, candidate supports tried, 0, 0. */
+ * the small dual, |x_new - x|, rows, candidate supports tried, failed, 0.  failed = 1: no support passed the KKT test within the budget (4096 candidate
+ * supports or 2 s -- inconsistent or dependent planes): the iterate is left as the wrapped algorithm's step produced it, fos_step still returns FOS_OK. */
 int fos_set_longstep(fos_handle h, int64_t longinterval, int64_t nsave);
 int fos_longstep_log(fos_handle h, double* out8);
 /* GAPP(alpha, alpha1, alpha2; iproj) -- "projected GAP", src/solvers/gapproj.jl:5-81, the last row of the reference's solver table
@@ -236,6 +237,14 @@ int fos_getsol(fos_handle h, double* z_out, int32_t force_check, double eps, fos
  * set: installs xinit (firstrun becomes false) and the counter. */
 int fos_get_affine_state(fos_handle h, double* xinit, int64_t* i, int32_t* firstrun);
 int fos_set_affine_state(fos_handle h, const double* xinit, int64_t i);
+
+/* The algorithm's own *Data struct, for checkpoint/resume and for handing a run over to another implementation mid-solve (the oracle in
+ * tests/test_gpu_fullsize.py, bench.py's cpu_baseline): FISTAData.y, .xold, .t (fista.jl:15-25, updated at :39,:44-46);
+ * DykstraData.p, .q (dykstra.jl:12-23, updated at :29,:33); GAPAData.alpha12 (gapa.jl:29,101).  GAP has none.
+ * a, b: N doubles each in the reference layout -- FISTA: a = y, b = xold; Dykstra: a = p, b = q (NULL: skipped; both are zero behind fos_set_alg);
+ * scal2 = [ t, alpha12 ].  set installs what is non-NULL; the CG warm start and call counter are fos_set_affine_state's. */
+int fos_get_alg_state(fos_handle h, double* a, double* b, double* scal2);
+int fos_set_alg_state(fos_handle h, const double* a, const double* b, const double* scal2);
 
 int fos_get_cgiter(fos_handle h, int64_t* cgiter);         /* getcgiter(data), defaults.jl:25-30 */
 int fos_get_alpha12(fos_handle h, double* alpha12);        /* GAPAData.alpha12 */
@@ -279,12 +288,16 @@ int fos_get_cg_total(fos_handle h, int64_t* total);  /* CG iterations run since 
 int fos_profile_read(fos_handle h, int64_t* launches, double* total_ms, double* bytes_per_launch);
 /* The same records split by class of launch group (arrays of FOS_PROF_CLASSES entries): the KKT sweep of a CG iteration,
  * the batched PSD projection of one cone-prox call (cones.jl:89-94 over all PSD cones), the CG vector update(s) of an
- * iteration.  Resets the records like fos_profile_read. */
+ * iteration (arrays of FOS_PROF_CLASSES = 4 entries).  Resets the records like fos_profile_read. */
 #define FOS_PROF_KKT 0
 #define FOS_PROF_PSD 1
 #define FOS_PROF_CGVEC 2
-#define FOS_PROF_CLASSES 3
-int fos_profile_read_classes(fos_handle h, int64_t* launches3, double* total_ms3);
+/* everything else an outer iteration launches -- the start of a CG solve (start sweep + r_0 kernel), the relaxations, the elementwise / SOC / Exp
+ * cones, the step's last pass -- bracketed group by group in every prof_period-th OUTER ITERATION; for this class launches[] counts the sampled
+ * iterations, so total_ms / launches = milliseconds per outer iteration */
+#define FOS_PROF_OTHER 3
+#define FOS_PROF_CLASSES 4
+int fos_profile_read_classes(fos_handle h, int64_t* launches4, double* total_ms4);
 /* fos_bench_cg_chain: `iters` CG iterations (conjugategradients.jl:37-51; sweep + update [+ p update]) on the current
  * iterate as right-hand side with the stop test disabled, enqueued eagerly (use_graph = 0) or captured ONCE into a hipGraph
  * and replayed `reps` times (use_graph = 1); *ms_per_iter by HIP events.  Measurement only: it answers whether graph replay

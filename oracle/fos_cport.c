@@ -390,6 +390,24 @@ int fosc_gapa_step(fosc* s, double* x, double alpha, double beta, double* alpha1
     return 0;
 }
 
+/* one outer iteration of FISTA(alpha) without the status check; y, xold (N doubles each) and t are FISTAData's, in/out   fista.jl:28-48 */
+int fosc_fista_step(fosc* s, double* x, double alpha, double* y, double* xold, double* t) {
+    const int64_t N = s->N;
+    double* t1 = s->tmp1;
+    fosc_prox_affine(s, t1, y);                                          /* :35 */
+#pragma omp parallel for schedule(static) num_threads(nthreads(s))
+    for (int64_t i = 0; i < N; ++i) t1[i] = alpha * t1[i] + (1 - alpha) * y[i];        /* :37 */
+#pragma omp parallel for schedule(static) num_threads(nthreads(s))
+    for (int64_t i = 0; i < N; ++i) xold[i] = x[i];                                      /* :39 */
+    if (fosc_prox_cones(s, x, t1)) return -1;                            /* :40 */
+    const double told = *t;
+    *t = (1 + sqrt(1 + 4 * told * told)) / 2;                            /* :45 */
+    const double cf = (told - 1) / *t;
+#pragma omp parallel for schedule(static) num_threads(nthreads(s))
+    for (int64_t i = 0; i < N; ++i) y[i] = x[i] + cf * (x[i] - xold[i]);               /* :46 */
+    return 0;
+}
+
 /* ------------------------------------------------------------------ set-up */
 static void* xcalloc(size_t n, size_t sz) { void* p = calloc(n ? n : 1, sz); return p; }
 

@@ -35,6 +35,7 @@ def load():
     lib.fosc_prox_cones.argtypes = [C.c_void_p, f64p, f64p]
     lib.fosc_gap_step.argtypes = [C.c_void_p, f64p, C.c_double, C.c_double, C.c_double]
     lib.fosc_gapa_step.argtypes = [C.c_void_p, f64p, C.c_double, C.c_double, f64p]
+    lib.fosc_fista_step.argtypes = [C.c_void_p, f64p, C.c_double, f64p, f64p, f64p]
     lib.fosc_set_affine_state.argtypes = [C.c_void_p, f64p, C.c_int64]
     lib.fosc_get_cgiter.restype = C.c_int64
     lib.fosc_get_cgiter.argtypes = [C.c_void_p]
@@ -109,6 +110,13 @@ class CPort:
         if self._lib.fosc_gapa_step(self._h, _p(x, C.c_double), alpha, beta, C.byref(a)):
             raise NotImplementedError("cone kind not in the C port")
         return a.value
+
+    def fista_step(self, x, alpha, y, xold, t):
+        """In place on x, y, xold (contiguous float64); returns the new t."""
+        tt = C.c_double(t)
+        if self._lib.fosc_fista_step(self._h, _p(x, C.c_double), alpha, _p(y, C.c_double), _p(xold, C.c_double), C.byref(tt)):
+            raise NotImplementedError("cone kind not in the C port")
+        return tt.value
 
     def set_affine_state(self, xinit, i):
         xinit = np.ascontiguousarray(xinit, dtype=np.float64)

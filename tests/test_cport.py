@@ -62,12 +62,12 @@ def test_operator_and_projections(problems, oracle):
         c.close()
 
 
-@pytest.mark.parametrize("algname", ["DR", "GAP", "GAPA"])
+@pytest.mark.parametrize("algname", ["DR", "GAP", "GAPA", "FISTA"])
 def test_steps_match_oracle(problems, oracle, algname):
     orc = oracle
     for prob in problems[:3]:
         om = orc.Model(prob.A, prob.b, prob.c, _codes(orc, prob.K1), _codes(orc, prob.K2))
-        alg = {"DR": orc.DR, "GAP": orc.GAP, "GAPA": lambda: orc.GAPA(0.9, 0.3)}[algname]()
+        alg = {"DR": orc.DR, "GAP": orc.GAP, "GAPA": lambda: orc.GAPA(0.9, 0.3), "FISTA": lambda: orc.FISTA(0.9)}[algname]()
         alg.init(om)
         x = orc.hsde_initialvalue(om)
         xc = x.copy()
@@ -82,8 +82,15 @@ def test_steps_match_oracle(problems, oracle, algname):
             if i > 1:
                 c.set_affine_state(alg.S1.cgdata.xinit, alg.S1.i)
             a12 = getattr(alg, "alpha12", 2.0)
+            if algname == "FISTA":                          # FISTAData handed over like the rest (fista.jl:15-25; y = x at i == 1, :31-33)
+                yc, xoldc, tc = (x.copy() if i == 1 else alg.y.copy()), alg.xold.copy(), alg.t
             alg.step(x, i, st)
-            if algname == "GAPA":
+            if algname == "FISTA":
+                tc = c.fista_step(xc, alg.alpha, yc, xoldc, tc)
+                assert tc == alg.t
+                assert np.linalg.norm(yc - alg.y) <= 1e-5 * max(1.0, np.linalg.norm(alg.y)), (prob.name, i)
+                assert np.array_equal(xoldc, alg.xold)
+            elif algname == "GAPA":
                 a12 = c.gapa_step(xc, alg.alpha, alg.beta, a12)
                 assert a12 == pytest.approx(alg.alpha12, rel=1e-5)
             else:

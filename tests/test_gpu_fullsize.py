@@ -78,8 +78,14 @@ def _same_step_vs_oracle(pkg, prob, alg, oalg, warm, tol):
     oalg.S1.cgdata.xinit[:] = xinit
     oalg.S1.cgdata.firstrun = False
     oalg.S1.i = pi
+    a, b, t, a12 = d.get_alg_state()                 # the algorithm's own *Data struct (fos_get_alg_state)
     if isinstance(oalg, orc.GAPA):
-        oalg.alpha12 = d.alpha12()
+        oalg.alpha12 = a12
+    elif isinstance(oalg, orc.FISTA):
+        oalg.y[:], oalg.xold[:], oalg.t = a, b, t    # fista.jl:15-25
+    elif isinstance(oalg, orc.Dykstra):
+        oalg.p[:], oalg.q[:] = a, b                  # dykstra.jl:12-23
+    del a, b
     st = orc.HSDEStatus(om, BIG, 1e-8, 0, 0)
     st.i = warm + 1
     xo = z.copy()
@@ -225,9 +231,12 @@ def test_c3_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle):
 
 
 def test_c5_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle):
-    """C5's operator (window panels) and cone stack (NonNeg + 2000 SOC + 72 PSD(64)) under DR -- FISTA's extrapolation state
-    lives on the device only -- outer iteration 241 from the device's state at iteration 240, against the oracle."""
+    """C5 under its own algorithm, FISTA (BASELINE.json configs[4]): the window-panel CG (~140 iterations at the tolerance floor), the cone
+    stack (NonNeg + 2000 SOC + 72 PSD(64)) and fista_extrap_kernel as ONE chain -- outer iteration 241 from the device's state at
+    iteration 240 (iterate, CG warm start, call counter, and FISTA's y, xold, t through fos_get_alg_state) against the oracle's step
+    (fista.jl:28-48), relative 1e-9; then the same operator and cones under DR."""
     prob = pkg.workloads.c5_mixed()
+    _same_step_vs_oracle(pkg, prob, pkg.FISTA(), oracle.FISTA(), 240, 1e-9)
     _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 240, 1e-9)
 
 

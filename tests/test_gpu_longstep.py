@@ -125,3 +125,45 @@ def test_default_nsave_projection_is_extended_precision(pkg, oracle, algname):
         d.close()
     assert len(conds) == 2 and max(conds) > 1e8, conds           # float64 through the Gram matrix would be lost here
     assert worst <= 1e-7, (worst, conds)                         # measured 1.4e-9 (AP), 1.7e-8 (GAP: zero rows, pseudo-inverse)
+
+
+def test_longstep_without_a_kkt_point_leaves_the_iterate(pkg, monkeypatch):
+    """The small dual of the plane projection found no KKT point within its budget (forced: a budget of zero candidate supports --
+    in production: inconsistent or dependent planes): the step must not apply a non-projection -- the iterate stays what the wrapped
+    algorithm's step made it, the log says `failed`, the sweep of an nsave change does not leak, and excluded wrapper pairs are refused both ways."""
+    prob = pkg.workloads.small_mixed()
+    runs = {}
+    for budget in ("0", None):
+        if budget is None:
+            monkeypatch.delenv("FOS_LONG_MAX_SUPPORTS", raising=False)
+        else:
+            monkeypatch.setenv("FOS_LONG_MAX_SUPPORTS", budget)
+        d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+        d.enable_direct(prob.A)
+        d.set_alg(pkg.LongstepWrapper(pkg.DR(direct=True), longinterval=7, nsave=2))
+        d.set_iterate(None)
+        d.step(1, 7, 10 ** 9, 1e-9)
+        runs[budget] = (d.get_iterate(), d.longstep_log())
+        d.close()
+    # the same seven DR steps without any wrapper
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d.enable_direct(prob.A)
+    d.set_alg(pkg.DR(direct=True))
+    d.set_iterate(None)
+    d.step(1, 7, 10 ** 9, 1e-9)
+    plain = d.get_iterate()
+    assert runs["0"][1]["failed"] and runs["0"][1]["tried"] == 0 and runs["0"][1]["step"] == 0.0
+    assert np.linalg.norm(runs["0"][0] - plain) <= 1e-12 * np.linalg.norm(plain)           # unfused vs fused step: rounding only
+    assert not runs[None][1]["failed"] and runs[None][1]["step"] > 0
+    assert np.linalg.norm(runs[None][0] - plain) > 1e-6 * np.linalg.norm(plain)           # (the projection does move the iterate)
+    # nsave swept on one handle, and the exclusions in both directions
+    for nsave in (1, 3, 2, 5):
+        d.set_longstep(20, nsave)
+    with pytest.raises(pkg.lib.FosError):
+        d.set_linesearch(10)
+    d.set_longstep(0, 0)
+    d.set_alg(pkg.GAP(0.8, 1.5, 1.6, direct=True))
+    d.set_longstep(20, 2)
+    with pytest.raises(pkg.lib.FosError):
+        pkg.lib.check(d._lib.fos_set_gapp(d._h, 10))
+    d.close()
