@@ -125,6 +125,10 @@ def main():
                     help="N > 1, C4: strong = the 512-block problem split over the ranks (default, the metric's definition); "
                          "weak = 512 blocks per rank")
     ap.add_argument("--no-weak-extra", action="store_true", help="N > 1: skip the additional weak-scaling measurement")
+    ap.add_argument("--direct", action="store_true",
+                    help="direct = true (HSDE.jl:12-15): S1 = IndAffine([Q -I], 0), the exact affine projection without CG -- on C4 the block form, "
+                         "three KKT sweeps per projection (fos_enable_direct); a secondary line, the headline stays the CG path")
+    ap.add_argument("--no-direct-extra", action="store_true", help="N = 1, C4: skip the additional timing of DR(direct=true)")
     ap.add_argument("--c4-scale", type=float, default=None,
                     help="C4: divide the random symmetric constraint matrices by this instead of 32 (1 = the raw, badly conditioned "
                          "instance: ~4x the CG iterations per outer iteration; not the headline configuration)")
@@ -190,7 +194,8 @@ def main():
     def run_case(weak):
         """Build the (shard of the) problem, warm up to the steady state, time exactly --steps outer iterations."""
         reduction = "in-stream RCCL all-reduce"
-        peer_reason = None             # why the peer mailboxes are NOT the transport (None: they are, or there is one rank)
+        transport = "rccl"
+        peer_reason = None             # why the transports in front of the chosen one were passed over (None: the first was taken, or there is one rank)
         t0 = time.time()
         # FOS_BENCH_SHARD="k/N" (with FOS_FORCE_DIST=1, one process): rank k's shard of an N-rank run on this GPU, in the sharded code path -- what an N-GPU
         # run's ranks would each step (no hop between devices is paid: a projection, labelled as such in config.workload)
@@ -211,17 +216,48 @@ def main():
                     idt.copy_(torch.frombuffer(bytearray(pkg.HipHSDE.comm_unique_id()), dtype=torch.uint8))
                 dist.broadcast(idt, 0)
                 dev.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
-            # scalar sums: peer mailboxes (one xGMI write latency per exchange) when every rank's self test passes,
-            # otherwise the in-stream RCCL all-reduce set up above.  FOS_REDUCTION=rccl|peer|auto (default auto).
-            want = "peer" if host_gloo else os.environ.get("FOS_REDUCTION", "auto")
-            if want == "rccl":
-                peer_reason = os.environ.get("FOS_PEER_FALLBACK_NOTE", "FOS_REDUCTION=rccl")
-            if want != "rccl":
+            # scalar sums, in this order (FOS_REDUCTION=auto, the default): device mailboxes mapped through HIP IPC ("peer": one xGMI write latency
+            # per exchange), mailboxes in pinned host memory ("host": needs no peer access between the devices -- two PCIe latencies), the in-stream
+            # RCCL all-reduce set up above ("rccl").  Each is decided COLLECTIVELY by its self test; the reason a transport was passed over is
+            # recorded.  FOS_REDUCTION=peer|host|rccl forces one; FOS_REDUCTION_SKIP (set by the warm-up fallback below) lists transports that
+            # passed their self test but failed in the warm-up.
+            want = os.environ.get("FOS_REDUCTION", "auto")
+            order = {"auto": ["peer", "host", "rccl"], "peer": ["peer"], "host": ["host"], "rccl": ["rccl"]}[want]
+            if host_gloo:
+                order = [t for t in order if t != "rccl"]          # (no RCCL communicator in this mode)
+            skipped = {t: os.environ.get("FOS_REDUCTION_SKIP_NOTE_" + t.upper(), "failed in the warm-up")
+                       for t in os.environ.get("FOS_REDUCTION_SKIP", "").split(",") if t}
+            reasons = {}
+
+            def gather_reason(why):
+                """every rank learns every rank's reason (the votes only say that SOME rank failed)"""
+                whys = [None] * world
+                dist.all_gather_object(whys, why)
+                return "; ".join("rank %d: %s" % (g, w) for g, w in enumerate(whys) if w) or "a peer failed"
+
+            def selftest_and_enable():
+                why = None
+                dist.barrier()
+                try:
+                    ok = dev.peer_selftest(64)
+                    if not ok:
+                        why = "self test: wrong sums"
+                except Exception as exc:
+                    print("rank %d: mailbox self test raised (%s)" % (rank, exc), file=sys.stderr, flush=True)
+                    ok, why = False, "self test: %s" % exc
+                if agree(ok):
+                    dev.peer_enable(True)
+                    return True, None
+                return False, why
+
+            def try_peer():
                 # first contact between DIFFERENT devices: can this device map its peers' memory at all?  (the IPC mapping below can
                 # succeed where loads and stores over the link do not)  Asked of the runtime, not assumed; a "no" names the pair.
                 why = None
+                if os.environ.get("FOS_BENCH_INJECT") == "peer_open_fail":          # tests only
+                    why = "injected: no peer access"
                 try:
-                    if not host_gloo:
+                    if not host_gloo and why is None:
                         for g in range(torch.cuda.device_count()):
                             if g != local_rank and g < world and not torch.cuda.can_device_access_peer(local_rank, g):
                                 why = "hipDeviceCanAccessPeer(%d, %d) = 0" % (local_rank, g)
@@ -244,26 +280,58 @@ def main():
                         print("rank %d: peer mailboxes unavailable (%s)" % (rank, exc), file=sys.stderr, flush=True)
                         ok, why = False, "open: %s" % exc
                 if agree(ok):
-                    dist.barrier()
-                    try:
-                        ok = dev.peer_selftest(64)
-                        if not ok:
-                            why = "self test: wrong sums"
-                    except Exception as exc:
-                        print("rank %d: peer mailbox self test raised (%s)" % (rank, exc), file=sys.stderr, flush=True)
-                        ok, why = False, "self test: %s" % exc
-                    if agree(ok):
-                        dev.peer_enable(True)
-                        reduction = "peer mailboxes over xGMI (HIP IPC)"
-                if not reduction.startswith("peer"):
-                    # every rank learns every rank's reason (the vote only says that SOME rank failed)
-                    whys = [None] * world
-                    dist.all_gather_object(whys, why)
-                    peer_reason = "; ".join("rank %d: %s" % (g, w) for g, w in enumerate(whys) if w) or "a peer failed"
-                if want == "peer" and not reduction.startswith("peer"):
-                    raise SystemExit("FOS_REDUCTION=peer but the peer mailboxes are not usable")
+                    ok, why2 = selftest_and_enable()
+                    why = why or why2
+                return ok, why
+
+            def try_host():
+                name = [None]
+                if rank == 0:
+                    name[0] = "/foship-%d-%d" % (os.getpid(), time.time_ns() & 0xFFFFFFFF)
+                dist.broadcast_object_list(name, src=0)
+                why = None
+                try:
+                    dev.peer_open_host(world, rank, name[0], timeout_s=20.0)
+                    dev.sync()
+                    ok = True
+                except Exception as exc:                      # no shm / the runtime cannot register it
+                    print("rank %d: host-pinned mailboxes unavailable (%s)" % (rank, exc), file=sys.stderr, flush=True)
+                    ok, why = False, "open: %s" % exc
+                if agree(ok):
+                    ok, why2 = selftest_and_enable()
+                    why = why or why2
+                return ok, why
+
+            chosen = None
+            for tr in order:
+                if tr in skipped:
+                    reasons[tr] = skipped[tr]
+                    continue
+                if tr == "rccl":
+                    chosen = tr
+                    break
+                ok, why = (try_peer if tr == "peer" else try_host)()
+                if ok:
+                    chosen = tr
+                    break
+                reasons[tr] = gather_reason(why)
+                dev.peer_close()                              # the next transport opens its own mailboxes on the same handle
+            if chosen is None:
+                raise SystemExit("no usable transport for the scalar sums (FOS_REDUCTION=%s): %s" % (want, reasons))
+            transport = chosen
+            reduction = {"peer": "peer mailboxes over xGMI (HIP IPC)", "host": "host-pinned mailboxes (POSIX shm + hipHostRegister, PCIe)",
+                         "rccl": "in-stream RCCL all-reduce"}[chosen]
+            peer_reason = "; ".join("%s: %s" % (t, w) for t, w in reasons.items()) or None
+            if want == "rccl":
+                peer_reason = "FOS_REDUCTION=rccl"
         if args.spmv_wg:
             dev.set_tuning(spmv_workgroups=args.spmv_wg)
+        direct_form = None
+        if args.direct:
+            if dist is not None:
+                raise SystemExit("--direct is a single-GPU mode (fos_enable_direct)")
+            dev.enable_direct(prob.A)
+            direct_form = dev.direct_mode()
         dev.set_alg(alg)
         dev.set_iterate(None)
         t_setup = time.time() - t0
@@ -284,20 +352,22 @@ def main():
         it = 0
         if warm > 0:
             try:
-                if os.environ.get("FOS_BENCH_INJECT") == "peer_warmup_fail" and reduction.startswith("peer"):   # tests only
-                    raise pkg.lib.FosError(-5, "injected: peer exchange timed out")
+                inj = os.environ.get("FOS_BENCH_INJECT", "")
+                if dist is not None and inj in ("peer_warmup_fail", "host_warmup_fail", "mailbox_warmup_fail") and \
+                        transport in {"peer_warmup_fail": ("peer",), "host_warmup_fail": ("host",), "mailbox_warmup_fail": ("peer", "host")}[inj]:   # tests only
+                    raise pkg.lib.FosError(-5, "injected: mailbox exchange timed out")
                 done, _, _ = dev.step(1, warm, BIG, 1e-8)
                 dev.sync()
                 ok = True
             except pkg.lib.FosError as exc:                   # e.g. FOS_ECOMM: a mailbox word that never arrived
-                if dist is None or not reduction.startswith("peer"):
+                if dist is None or transport == "rccl":
                     raise
-                print("rank %d: warm-up failed on the peer mailboxes (%s)" % (rank, exc), file=sys.stderr, flush=True)
+                print("rank %d: warm-up failed on the %s mailboxes (%s)" % (rank, transport, exc), file=sys.stderr, flush=True)
                 done, ok = 0, False
-            if dist is not None and reduction.startswith("peer") and not agree(ok):
+            if dist is not None and transport != "rccl" and not agree(ok):
                 # a rank that waits for a silent peer runs into the mailbox time-out too, so every rank arrives here
                 dev.close()
-                raise PeerTransportFailed()
+                raise PeerTransportFailed(transport)
             it += done
         # ---- timed: exactly K outer iterations
         # HIP events around every PROF_PERIOD-th launch group of each class: an event pair per launch costs ~5 % of a C4 step, every
@@ -326,6 +396,8 @@ def main():
             elapsed = float(tt.item())
         cls = dev.profile_read_classes()
         cg_timed = dev.cg_total() - cg0
+        if direct_form in ("block", "dense"):
+            cg_timed = (3 if direct_form == "block" else 2) * args.steps          # no CG: the sweeps of the exact projection, per outer iteration
         sweeps = dev.psd_sweeps()
         dev.profile(False)
         barrier()
@@ -507,7 +579,9 @@ def main():
                 "regime": "steady state: CG tolerance at its floor l*eps = %.3g from outer iteration %d on (affinepluslinear.jl:108-112); "
                           "timed iterations %d..%d" % (l_global * EPS, i_floor, warm + 1, warm + args.steps),
                 "local_m": int(prob.m), "local_n": int(prob.n), "local_nnz": int(prob.nnz),
-                "cg_iters_per_step": round(cg_timed / max(1, args.steps), 2),
+                "cg_iters_per_step": round(cg_timed / max(1, args.steps), 2) if direct_form not in ("block", "dense") else 0,
+                "direct": direct_form,
+                "sweeps_per_step": round(cg_timed / max(1, args.steps), 2),
                 "cg_variant": dev.cg_variant_name(),
                 "cg_launches_per_iteration": 3 if dev.cg_variant_name() == "reference" else 2,
                 "parallelism": "cone-sharded x%d (scalar sums: %s)" % (world, reduction) if dist is not None else "single GPU",
@@ -528,15 +602,20 @@ def main():
         return out, dev, prob, alg, it
 
     weak_main = args.scaling == "weak"
-    try:
-        out, dev, prob, alg, it = run_case(weak_main)
-    except PeerTransportFailed:
-        # the self test passed but the first real exchanges did not: the same job over the in-stream RCCL all-reduce
-        if host_gloo or os.environ.get("FOS_REDUCTION") == "peer":
-            raise SystemExit("peer mailboxes failed during the warm-up and no other transport is allowed")
-        os.environ["FOS_REDUCTION"] = "rccl"
-        os.environ["FOS_PEER_FALLBACK_NOTE"] = "the self test passed, but an exchange of the warm-up timed out on the peer mailboxes (FOS_ECOMM)"
-        out, dev, prob, alg, it = run_case(weak_main)
+    for _attempt in range(3):
+        try:
+            out, dev, prob, alg, it = run_case(weak_main)
+            break
+        except PeerTransportFailed as exc:
+            # the self test passed but the first real exchanges did not: the same job, in this process, over the next transport in the order
+            failed = str(exc.args[0])
+            if os.environ.get("FOS_REDUCTION", "auto") != "auto":
+                raise SystemExit("the %s mailboxes failed during the warm-up and FOS_REDUCTION allows no other transport" % failed)
+            os.environ["FOS_REDUCTION_SKIP"] = ",".join(filter(None, [os.environ.get("FOS_REDUCTION_SKIP", ""), failed]))
+            os.environ["FOS_REDUCTION_SKIP_NOTE_" + failed.upper()] = \
+                "the self test passed, but an exchange of the warm-up timed out on the %s mailboxes (FOS_ECOMM)" % failed
+    else:
+        raise SystemExit("every transport failed during the warm-up")
     if world > 1 and not weak_main and not args.no_weak_extra and args.workload == "C4":
         # the same job once more with 512 blocks PER RANK: weak scaling, reported beside the strong-scaling headline
         dev.close()
@@ -653,6 +732,26 @@ def main():
             }
         finally:
             args.c4_scale = None
+    # ---- the same C4 with DR(direct = true) (HSDE.jl:12-15): the exact projection in the block form, three sweeps instead of ~17 CG iterations
+    if world == 1 and dist is None and args.workload == "C4" and not args.direct and not args.small and not args.no_direct_extra and args.c4_scale is None \
+            and not os.environ.get("FOS_BENCH_SHARD"):
+        args.direct = True
+        try:
+            dout, ddev, _, _, _ = run_case(False)
+            ddev.close()
+            dr = dout["roofline_kkt"] if isinstance(dout["roofline_kkt"], dict) else dout["roofline"]
+            out["direct_true"] = {
+                "workload": dout["config"]["workload"] + ", DR(direct=true)", "value": dout["value"], "unit": dout["unit"], "ms_per_step": dout["ms_per_step"],
+                "steps": dout["steps"], "warmup_effective": dout["warmup_effective"], "form": dout["config"]["direct"],
+                "sweeps_per_step": dout["config"]["sweeps_per_step"],
+                "roofline": {k: dr[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_kernel_ms", "bytes_per_launch")},
+                "time_shares": dout["time_shares"], "residuals_after_run": dout["config"]["residuals_after_run"],
+                "note": "S1 = IndAffine([Q -I], 0) as the reference's `direct = true` option defines it: the EXACT projection, here through the block form "
+                        "(I + A'A block diagonal with 512 blocks of 32 columns, inverted once; three KKT sweeps + one block-diagonal product per projection, "
+                        "no CG).  A different algorithm configuration than the headline (which keeps the reference's default direct = false)",
+            }
+        finally:
+            args.direct = False
     if dist is not None:
         # librccl prints its version banner through C stdio, which a pipe buffers until exit: flush it now so the
         # JSON line below is the last thing on stdout

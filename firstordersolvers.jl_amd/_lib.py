@@ -61,6 +61,8 @@ PROTOTYPES = {
     "fos_comm_init_host": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "fos_peer_export": (C.c_int, [_h, C.c_void_p]),
     "fos_peer_open": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p, C.c_double]),
+    "fos_peer_open_host": (C.c_int, [_h, C.c_int, C.c_int, C.c_char_p, C.c_double]),
+    "fos_peer_close": (C.c_int, [_h]),
     "fos_peer_selftest": (C.c_int, [_h, C.c_int, C.POINTER(C.c_int32)]),
     "fos_peer_vec_export": (C.c_int, [_h, C.c_void_p]),
     "fos_peer_vec_open": (C.c_int, [_h, C.c_void_p]),
@@ -69,6 +71,7 @@ PROTOTYPES = {
     "fos_reset_affine": (C.c_int, [_h]),
     "fos_enable_direct": (C.c_int, [_h, _i64p, _i64p, _dp]),
     "fos_disable_direct": (C.c_int, [_h]),
+    "fos_get_direct_mode": (C.c_int, [_h, _i32p]),
     "fos_set_iterate": (C.c_int, [_h, _dp]),
     "fos_get_iterate": (C.c_int, [_h, _dp]),
     "fos_get_checked": (C.c_int, [_h, _dp]),

@@ -112,14 +112,21 @@ __device__ __forceinline__ bool peer_fold_sum(const PeerBox& pb, uint32_t seq, d
         const int hh = t & 1, v = (t >> 1) % NACC, r = (t >> 1) / NACC;
         const unsigned long long bits = (unsigned long long)__double_as_longlong(sums[v]);
         const uint32_t mine = hh ? (uint32_t)(bits >> 32) : (uint32_t)bits;
-        if (r == pb.rank) {
+        if (r == pb.rank && !pb.loopback) {
             halves[(r * NACC + v) * 2 + hh] = mine;
         } else {
+            const size_t off_in = PEER_BOX_WORDS + ((par + r) * PEER_MAX_VALS + v) * 2 + hh;          // where rank r's word arrives
             if (blockIdx.x == 0) {
-                unsigned long long* dst = pb.box[r] + PEER_BOX_WORDS + ((par + pb.rank) * PEER_MAX_VALS + v) * 2 + hh;
-                __hip_atomic_store(dst, ((unsigned long long)seq << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // one segment for all ranks (`shared`): the word is written once -- by the thread of the first peer (or, looping back, of the rank itself)
+                const bool wr = !pb.shared || pb.loopback ? (r != pb.rank || pb.loopback) : (r == (pb.rank == 0 ? 1 : 0));
+                if (wr) {
+                    unsigned long long* dst = pb.box[r] + PEER_BOX_WORDS + ((par + pb.rank) * PEER_MAX_VALS + v) * 2 + hh;
+                    __hip_atomic_store(dst, ((unsigned long long)seq << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
-            const unsigned long long* src = pb.box[pb.rank] + PEER_BOX_WORDS + ((par + r) * PEER_MAX_VALS + v) * 2 + hh;
+            // host-pinned transport: only workgroup 0 reads the segment (a PCIe round trip per poll); everybody else polls its republication
+            const bool via_relay = pb.relay != nullptr && blockIdx.x != 0;
+            const unsigned long long* src = via_relay ? pb.relay + off_in : pb.box[pb.rank] + off_in;
             const long long t0 = wall_clock64();
             unsigned long long w;
             bool ok;
@@ -128,6 +135,7 @@ __device__ __forceinline__ bool peer_fold_sum(const PeerBox& pb, uint32_t seq, d
                 ok = (uint32_t)(w >> 32) == seq;
             } while (!ok && (wall_clock64() - t0) < pb.timeout_ticks);
             if (!ok) failed = 1;
+            else if (pb.relay != nullptr && blockIdx.x == 0) __hip_atomic_store(pb.relay + off_in, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             halves[(r * NACC + v) * 2 + hh] = (uint32_t)w;
         }
     }

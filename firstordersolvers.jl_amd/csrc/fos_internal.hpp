@@ -82,10 +82,16 @@ struct WinStd {
     // steps of a wavefront's slice u (descending step counts) requested with the window, so that one memory latency covers the window
     // and the matrix; the rest -- and, here, a fourth slice -- is streamed behind the barriers
     static constexpr int PRE0 = 6, PRE1 = 6, PRE2 = 6, PRE3 = 0;
+    static constexpr bool PREFETCH = false;
 };
 struct WinTall {
     static constexpr int COLS = 6144, ROWS = 4032, THREADS = 1024, WG_PER_CU = 1, WAVES = THREADS / 64;
     static constexpr int PRE0 = 8, PRE1 = 4, PRE2 = 2, PRE3 = 2;
+#ifdef FOS_WIN_PREFETCH
+    static constexpr bool PREFETCH = FOS_WIN_PREFETCH != 0;   // the next segment's window requested behind this segment's second barrier (one workgroup per CU: nobody else fills the bubble)
+#else
+    static constexpr bool PREFETCH = true;
+#endif
 };
 static_assert((WinStd::ROWS + 64 * WinStd::WAVES - 1) / (64 * WinStd::WAVES) <= 4 && (WinTall::ROWS + 64 * WinTall::WAVES - 1) / (64 * WinTall::WAVES) <= 4,
               "a WinDesc holds the step counts of four slices per wavefront");
@@ -274,11 +280,20 @@ constexpr size_t PEER_BOX_TOTAL_WORDS = 3 * PEER_BOX_WORDS;
 // counter of executed exchanges), region 1 for the two exchanges of a CG iteration that are FOLDED into the CG vector kernels
 // (every workgroup reduces the local records itself, workgroup 0 also writes them to the peers, every workgroup polls; the
 // sequence number is (CG solve number, iteration, phase), known at launch, its parity = the phase).
+// Second transport, HOST-PINNED mailboxes (round 5; fos_peer_open_host): the same words in ONE segment of pinned host memory (POSIX shm, registered
+// by every rank with hipHostRegister) -- no peer access between the devices and no IPC handle is needed, every box[r] is that one segment
+// (`shared`: a rank writes its words once, not once per peer).  A read of host memory is a PCIe round trip, so of the workgroups of a folded
+// exchange only workgroup 0 polls the segment; it republishes every word it has seen in `relay`, a mailbox-shaped array in local uncached
+// device memory that the other workgroups poll (the words validate themselves there as well).
 struct PeerBox {
     unsigned long long* const* box;   // device table [nranks]: box[r] = mailbox of rank r (own entry: the local allocation)
     uint32_t* seq;                    // device counter of EXECUTED exchanges (gated no-op launches do not count)
     int32_t nranks, rank;
     int64_t timeout_ticks;            // wall_clock64() ticks (100 MHz) an exchange may wait for its peers
+    unsigned long long* relay;        // host-pinned transport: local republication of the peers' words (nullptr: device mailboxes)
+    int32_t shared;                   // 1: all box[r] are one segment
+    int32_t loopback;                 // measurement (FOS_PEER_LOOPBACK=1): a rank's OWN words travel through the mailbox too, so that a single
+                                      // rank pays the store -> poll latency of the transport in every folded exchange
 };
 
 // Row-sharded operators without a collective library: the n-vector exchange of HSDEAffine.jl:51 (A'y = sum over the ranks of
@@ -454,6 +469,15 @@ void launch_dense_scale_identity(const LaunchCtx& c, int64_t L, double* X, doubl
 void launch_dense_symv(const LaunchCtx& c, int64_t ld, const double* G, const double* t, double* w);
 void launch_direct_rhs(const LaunchCtx& c, const double2* W, const double2* x, double* t);
 void launch_direct_finish(const LaunchCtx& c, const double2* x, const double2* W, double2* out);
+
+// direct = true on a block-separable operator (I + A'A block diagonal with blocks of order <= BLKDIR_MAX): vecops.hip, solver.cpp prox_affine_direct_block
+constexpr int BLKDIR_MAX = 64;
+void launch_blkdir_prep(const LaunchCtx& c, const double2* T, const double2* phg, double2* W2, double2* W3, double* partials);
+void launch_blkdir_solve(const LaunchCtx& c, int nblk, const int64_t* goff, const int32_t* ioff, const int32_t* idx, const double* Ginv, const double2* R,
+                         const double2* T, double2* W3);
+void launch_blkdir_kappa(const LaunchCtx& c, const double* partials, const double2* T, const double* prm, int zero);
+void launch_blkdir_combine(const LaunchCtx& c, const double2* T, const double2* W3, const double2* V, const double2* phg, const double2* qphg,
+                           const double* prm, double2* out, double* partials);
 
 // layout conversion at the ABI boundary
 void launch_interleave(const LaunchCtx& c, double2* out, const double* plain);    // plain [part1(l); part2(l)] -> interleaved

@@ -667,6 +667,8 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
             const int nk = min(64, wp.nseg - k0);
             uint4 dv = make_uint4(0u, 0u, 0u, 0u);
             if (lane < nk) dv = *reinterpret_cast<const uint4*>(drec + k0 + lane);
+            d2 wreg[WPT];
+            bool have_w = false;                           // PREFETCH: wreg already holds this segment's window (requested behind the previous segment's barriers)
             for (int k = 0; k < nk; ++k) {
                 WIN_STAMP(0);
                 const int col0 = __builtin_amdgcn_readlane((int)dv.x, k);
@@ -680,11 +682,12 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
                 r1.off = off; off += 64 * (int64_t)r1.T;
                 r2.off = off; off += 64 * (int64_t)r2.T;
                 r3.off = off; off += 64 * (int64_t)r3.T;
-                d2 wreg[WPT];
+                if (!(GEO::PREFETCH && have_w)) {
 #pragma unroll
-                for (int q = 0; q < WPT; ++q) {
-                    const int i = tid + q * WIN_THREADS;
-                    wreg[q] = (i < ncols) ? gat.load(col0 + i) : make_double2(0.0, 0.0);
+                    for (int q = 0; q < WPT; ++q) {
+                        const int i = tid + q * WIN_THREADS;
+                        wreg[q] = (i < ncols) ? gat.load(col0 + i) : make_double2(0.0, 0.0);
+                    }
                 }
                 win_slice_issue<MNT>(S, rs, lane, r0);
                 win_slice_issue<MNT>(S, rs + 1, lane, r1);
@@ -702,6 +705,21 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
                 WIN_STAMP(3);
                 __syncthreads();
                 WIN_STAMP(4);
+                if constexpr (GEO::PREFETCH) {
+                    // the NEXT segment's window is requested here: its registers are free (the window is in LDS), and the request's issue and
+                    // latency pass beside this segment's multiply instead of in front of the next segment's barriers
+                    have_w = k + 1 < nk;
+                    if (have_w) {
+                        const int col0n = __builtin_amdgcn_readlane((int)dv.x, k + 1);
+                        const int ncolsn = __builtin_amdgcn_readlane((int)dv.w, k + 1);
+#pragma unroll
+                        for (int q = 0; q < WPT; ++q) {
+                            const int i = tid + q * WIN_THREADS;
+                            wreg[q] = (i < ncolsn) ? gat.load(col0n + i) : make_double2(0.0, 0.0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);     // (the requests stay in front of the multiply)
+                }
                 win_slice_compute<MNT, NRHS>(S, r0, win, acc, lane);
                 win_slice_compute<MNT, NRHS>(S, r1, win, acc, lane);
                 win_slice_compute<MNT, NRHS>(S, r2, win, acc, lane);

@@ -3,13 +3,18 @@
 // in HBM between fos_create and fos_destroy (the only transfers are N doubles at set/get-iterate and ~100 bytes of
 // scalars per CG poll / convergence check).
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 #include <functional>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <memory>
+#include <thread>
 
 #include "fos_internal.hpp"
 
@@ -177,6 +182,16 @@ struct fos_solver {
     int64_t Gld = 0;
     int direct_iters = 0;                      // Newton-Schulz iterations the set-up took
     double* dvec[2] = {nullptr, nullptr};      // two plain l-vectors
+    // direct = true on a BLOCK-SEPARABLE operator: I + A'A is block diagonal with blocks of order <= BLKDIR_MAX (an SDP with few variables per
+    // block: C4), so the exact projection costs three KKT sweeps -- no CG, no dense l x l inverse (prox_affine_direct_block)
+    bool direct_blk = false;
+    int blk_n = 0;                             // diagonal blocks of I + A'A
+    int64_t* blk_goff = nullptr;               // [blk_n] start of block b's inverse (s_b x s_b, column-major) in blk_ginv
+    int32_t* blk_ioff = nullptr;               // [blk_n + 1] start of block b's column list in blk_idx
+    int32_t* blk_idx = nullptr;
+    double* blk_ginv = nullptr;
+    d2 *blk_phg = nullptr, *blk_qphg = nullptr;   // (D^-1 h, D^-1 M h) and their images under Q, per row
+    double* blk_prm = nullptr;                 // the 3 x 3 inverse of the border system (9), delta = 1 + |[c; b]|^2
 
     // S1 = AffinePlusLinear state (affinepluslinear.jl:58-69)
     int64_t prox_i = 1;
@@ -209,6 +224,11 @@ struct fos_solver {
     std::vector<void*> peer_opened;            // IPC mappings of the peers' mailboxes
     PeerBox peer{};
     bool peer_on = false;
+    // host-pinned mailboxes (fos_peer_open_host): the mapped + registered shm segment, its name (rank 0 unlinks it), the local relay
+    void* host_seg = nullptr;
+    size_t host_seg_bytes = 0;
+    std::string host_seg_name;
+    unsigned long long* peer_relay = nullptr;
     uint32_t cg_epoch = 0;                     // CG solves so far: the sequence space of the folded exchanges
     // ... or through the caller's own collective on host buffers (fos_comm_init_host: MPI.jl, gloo, ...)
     fos_allreduce_fn host_fn = nullptr;
@@ -232,6 +252,7 @@ struct fos_solver {
     bool prof = false;
     int prof_period = 1;                       // every prof_period-th launch of a class is bracketed by events (1: all)
     int64_t cg_total = 0;                      // CG iterations since fos_create
+    int64_t direct_sweeps = 0;                 // sweeps of the block-direct projection since fos_create (profiling ordinal)
     struct ProfRec { hipEvent_t a, b; int cls; int j; };
     std::vector<ProfRec> prof_recs;            // event pairs, reused
     size_t prof_used = 0;
@@ -630,8 +651,49 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     return FOS_OK;
 }
 
+// prox!(y, S1::IndAffine([Q -I], 0), x) on a block-separable operator: the exact projection in THREE KKT sweeps.
+//   The projection of (u, v) onto {v = Q u} is (u^, Q u^) with (I - Q^2) u^ = u - Q v =: g   (Q' = -Q).  With h = [c; b], M = [0 A'; -A 0]:
+//       I - Q^2 = [ P + h h', -M h ; -(M h)', delta ],   P = blkdiag(I + A'A, I + AA'),  delta = 1 + h'h
+//               = D + W C W',   D = blkdiag(P, delta),  W = [ (h; 0), (M h; 0), e_tau ],  C = [1 0 0; 0 0 -1; 0 -1 0]
+//   so by Woodbury  u^ = D^-1 g - [ph, pg, e_tau / delta] kappa,  kappa = (C^-1 + W' D^-1 W)^-1 [ph.g, pg.g, g_tau / delta],  ph = D^-1 (h; 0), pg = D^-1 (M h; 0)
+//   (ph, pg, Q ph, Q pg and the 3 x 3 inverse are formed once).  D^-1 g: the x part is a product with the inverted diagonal blocks of I + A'A,
+//   the y part (I + AA')^-1 g2 = g2 - A q, q = (I + A'A)^-1 A' g2.  Q D^-1 g needs A'(g2 - A q) = q (no sweep) and A x^.  Sweeps, all through the
+//   dual-right-hand-side KKT apply out = (w1 - Q w2, Q w1 - w2):   (1) w = (u, v) -> g;   (2) w = (0, (0, g2, 0)) -> A' g2;   (3) w = ((q,0,0), (x^,0,0)) -> A q, A x^.
+//   `from_T`: h->R already holds g in its first part (set-up: ph, pg); zero_kappa: no border correction (set-up).  Scratch: the CG vectors.
+int prox_affine_direct_block(fos_solver* h, const d2* x, d2* out, bool from_T = false, bool zero_kappa = false) {
+    RoctxRange range("fos:prox_affine_direct_block (3 KKT sweeps + block-diagonal solve)");
+    LaunchCtx c = h->ctx();
+    LaunchCtx cb = c;
+    cb.reduced = c.reduced + 8;                                        // kappa: three doubles nobody else writes during the projection
+    d2 *T = h->R, *W2 = h->PB[0], *Rr = h->AP, *W3 = h->PB[1], *V = h->RHS;
+    double* p1 = h->partials + (size_t)4 * PART_CAP;
+    double* p2 = h->partials + (size_t)5 * PART_CAP;
+    // (profiling: the three sweeps -- each with the deferred-row kernel and the tau-row finalize of a stand-alone apply -- are the KKT class)
+    int pe = -1;
+    if (!from_T) { pe = prof_begin(h, FOS_PROF_KKT, 1, h->direct_sweeps++); FOS_TRY(kkt_apply_full(h, c, x, T)); prof_end(h, pe); }      // T.x = u - Q v = g
+    int po = prof_begin_other(h, 0);
+    launch_blkdir_prep(cb, T, h->blk_phg, W2, W3, p1);
+    launch_blkdir_kappa(cb, p1, T, h->blk_prm, zero_kappa ? 1 : 0);
+    prof_end(h, po);
+    pe = prof_begin(h, FOS_PROF_KKT, 1, h->direct_sweeps++);
+    FOS_TRY(kkt_apply_full(h, c, W2, Rr));                             // Rr.x = -Q (0, g2, 0): its x part is -A' g2
+    prof_end(h, pe);
+    po = prof_begin_other(h, 0);
+    launch_blkdir_solve(cb, h->blk_n, h->blk_goff, h->blk_ioff, h->blk_idx, h->blk_ginv, Rr, T, W3);
+    prof_end(h, po);
+    pe = prof_begin(h, FOS_PROF_KKT, 1, h->direct_sweeps++);
+    FOS_TRY(kkt_apply_full(h, c, W3, V));                              // V.y = -A q, V.x = A x^ on the rows of A; V.x[tau] = c'x^
+    prof_end(h, pe);
+    po = prof_begin_other(h, 0);
+    launch_blkdir_combine(cb, T, W3, V, h->blk_phg, h->blk_qphg, h->blk_prm, out, p2);
+    prof_end(h, po);
+    h->cgiter = 0;
+    return check_launch("block-direct affine projection");
+}
+
 // prox!(y, S1::IndAffine([Q -I], 0), x) with the result left in h->SOL        HSDE.jl:12-15 (direct = true)
 int prox_affine_direct(fos_solver* h, const d2* x) {
+    if (h->direct_blk) return prox_affine_direct_block(h, x, h->SOL);
     RoctxRange range("fos:prox_affine_direct (2 Q sweeps + dense symmetric matvec)");
     LaunchCtx c = h->ctx();
     int fr = 0;
@@ -1211,6 +1273,196 @@ void add_cones(int64_t offset, bool is_K1, int64_t nK, const int32_t* type, cons
     }
 }
 
+// ---- direct = true, block-separable operators: the set-up.  Columns j, j' of A belong to one block when they share a row (connected components of the
+// pattern of A'A); separable = every component has at most BLKDIR_MAX columns.  Per block G_b = I + A_b' A_b is formed on the host (row-wise outer
+// products), inverted through its Cholesky factor and polished by one Newton step in extended precision; ph, pg and the 3 x 3 border system follow
+// from two runs of the device path itself.  *ok = false: not separable (nothing allocated).
+int blkdir_setup(fos_solver* h, const int64_t* colptr, const int64_t* rowval, const double* nzval, bool* ok) {
+    *ok = false;
+    const int64_t n = h->n, m = h->m, l = h->l;
+    if (n < 1 || n > (int64_t)INT32_MAX) return FOS_OK;
+    std::vector<int32_t> parent((size_t)n);
+    for (int64_t j = 0; j < n; ++j) parent[(size_t)j] = (int32_t)j;
+    auto find = [&](int32_t a) { while (parent[(size_t)a] != a) { parent[(size_t)a] = parent[(size_t)parent[(size_t)a]]; a = parent[(size_t)a]; } return a; };
+    {
+        std::vector<int32_t> first((size_t)m, -1);
+        for (int64_t j = 0; j < n; ++j)
+            for (int64_t p = colptr[j] - 1; p < colptr[j + 1] - 1; ++p) {
+                const int64_t r = rowval[p] - 1;
+                if (r < 0 || r >= m) { set_error("fos_enable_direct: row index out of range"); return FOS_EINVAL; }
+                if (first[(size_t)r] < 0) { first[(size_t)r] = (int32_t)j; continue; }
+                const int32_t a = find((int32_t)j), b = find(first[(size_t)r]);
+                if (a != b) parent[(size_t)std::max(a, b)] = std::min(a, b);       // the root of a component is its smallest column
+            }
+    }
+    std::vector<int32_t> cnt((size_t)n, 0), blkid((size_t)n, -1);
+    for (int64_t j = 0; j < n; ++j) cnt[(size_t)find((int32_t)j)] += 1;
+    int nblk = 0;
+    size_t gtotal = 0;
+    for (int64_t j = 0; j < n; ++j)
+        if (cnt[(size_t)j] > 0) {
+            if (cnt[(size_t)j] > BLKDIR_MAX) return FOS_OK;                        // a block of I + A'A too large to invert densely per wavefront
+            blkid[(size_t)j] = nblk++;
+            gtotal += (size_t)cnt[(size_t)j] * (size_t)cnt[(size_t)j];
+        }
+    if (gtotal * sizeof(double) > ((size_t)1 << 31)) return FOS_OK;
+    std::vector<int32_t> ioff((size_t)nblk + 1, 0), idx((size_t)n);
+    std::vector<int64_t> goff((size_t)nblk, 0);
+    for (int64_t j = 0; j < n; ++j) if (cnt[(size_t)j] > 0) ioff[(size_t)blkid[(size_t)j] + 1] = cnt[(size_t)j];
+    for (int b = 0; b < nblk; ++b) { goff[(size_t)b] = b ? goff[(size_t)b - 1] + (int64_t)(ioff[(size_t)b] - ioff[(size_t)b - 1]) * (ioff[(size_t)b] - ioff[(size_t)b - 1]) : 0; ioff[(size_t)b + 1] += ioff[(size_t)b]; }
+    {
+        std::vector<int32_t> fill(ioff.begin(), ioff.end() - 1);
+        for (int64_t j = 0; j < n; ++j) idx[(size_t)fill[(size_t)blkid[(size_t)find((int32_t)j)]]++] = (int32_t)j;      // ascending inside a block
+    }
+    std::vector<double> ginv(gtotal, 0.0);
+    std::vector<int32_t> rowlocal((size_t)m, -1);            // (the blocks' row sets are disjoint: one shared map, no conflicts between threads)
+    std::atomic<int> next{0}, bad{0};
+    auto work = [&]() {
+        std::vector<int32_t> rcount, rstart, ecol;
+        std::vector<double> eval, G;
+        std::vector<long double> Lc, X, Y;
+        for (;;) {
+            const int b = next.fetch_add(1);
+            if (b >= nblk) break;
+            const int32_t i0 = ioff[(size_t)b], sdim = ioff[(size_t)b + 1] - i0;
+            // rows of the block, in order of first appearance; entries bucketed by row
+            int32_t nrows = 0;
+            int64_t nent = 0;
+            rcount.clear();
+            for (int32_t q = 0; q < sdim; ++q) {
+                const int64_t j = idx[(size_t)i0 + q];
+                for (int64_t p = colptr[j] - 1; p < colptr[j + 1] - 1; ++p) {
+                    const int64_t r = rowval[p] - 1;
+                    if (rowlocal[(size_t)r] < 0) { rowlocal[(size_t)r] = nrows++; rcount.push_back(0); }
+                    rcount[(size_t)rowlocal[(size_t)r]] += 1;
+                    ++nent;
+                }
+            }
+            rstart.assign((size_t)nrows + 1, 0);
+            for (int32_t r = 0; r < nrows; ++r) rstart[(size_t)r + 1] = rstart[(size_t)r] + rcount[(size_t)r];
+            ecol.resize((size_t)nent); eval.resize((size_t)nent);
+            std::fill(rcount.begin(), rcount.end(), 0);
+            for (int32_t q = 0; q < sdim; ++q) {
+                const int64_t j = idx[(size_t)i0 + q];
+                for (int64_t p = colptr[j] - 1; p < colptr[j + 1] - 1; ++p) {
+                    const int32_t r = rowlocal[(size_t)(rowval[p] - 1)];
+                    const size_t at = (size_t)rstart[(size_t)r] + (size_t)rcount[(size_t)r]++;
+                    ecol[at] = q; eval[at] = nzval[p];
+                }
+            }
+            G.assign((size_t)sdim * sdim, 0.0);
+            for (int32_t r = 0; r < nrows; ++r)
+                for (int32_t a = rstart[(size_t)r]; a < rstart[(size_t)r + 1]; ++a)
+                    for (int32_t c2 = a; c2 < rstart[(size_t)r + 1]; ++c2) G[(size_t)ecol[(size_t)a] * sdim + ecol[(size_t)c2]] += eval[(size_t)a] * eval[(size_t)c2];
+            for (int32_t a = 0; a < sdim; ++a) {
+                G[(size_t)a * sdim + a] += 1.0;
+                for (int32_t c2 = a + 1; c2 < sdim; ++c2) {          // (entries of a row arrive in ascending column order: the upper triangle was filled)
+                    const double v = G[(size_t)a * sdim + c2] + G[(size_t)c2 * sdim + a];
+                    G[(size_t)a * sdim + c2] = G[(size_t)c2 * sdim + a] = v;
+                }
+            }
+            // X = G^-1 through Cholesky (extended precision: the blocks are tiny), one Newton step X <- X + X (I - G X)
+            Lc.assign((size_t)sdim * sdim, 0.0L);
+            bool pd = true;
+            for (int32_t j = 0; j < sdim && pd; ++j) {
+                long double dj = G[(size_t)j * sdim + j];
+                for (int32_t k = 0; k < j; ++k) dj -= Lc[(size_t)j * sdim + k] * Lc[(size_t)j * sdim + k];
+                if (!(dj > 0.0L)) { pd = false; break; }
+                const long double ljj = sqrtl(dj);
+                Lc[(size_t)j * sdim + j] = ljj;
+                for (int32_t i = j + 1; i < sdim; ++i) {
+                    long double v = G[(size_t)i * sdim + j];
+                    for (int32_t k = 0; k < j; ++k) v -= Lc[(size_t)i * sdim + k] * Lc[(size_t)j * sdim + k];
+                    Lc[(size_t)i * sdim + j] = v / ljj;
+                }
+            }
+            if (!pd) { bad.store(1); continue; }
+            X.assign((size_t)sdim * sdim, 0.0L);
+            Y.assign((size_t)sdim, 0.0L);
+            for (int32_t e = 0; e < sdim; ++e) {
+                for (int32_t i = 0; i < sdim; ++i) { long double v = (i == e) ? 1.0L : 0.0L; for (int32_t k = 0; k < i; ++k) v -= Lc[(size_t)i * sdim + k] * Y[(size_t)k]; Y[(size_t)i] = v / Lc[(size_t)i * sdim + i]; }
+                for (int32_t i = sdim - 1; i >= 0; --i) { long double v = Y[(size_t)i]; for (int32_t k = i + 1; k < sdim; ++k) v -= Lc[(size_t)k * sdim + i] * X[(size_t)e * sdim + k]; X[(size_t)e * sdim + i] = v / Lc[(size_t)i * sdim + i]; }
+            }
+            double* out = ginv.data() + goff[(size_t)b];
+            for (int32_t e = 0; e < sdim; ++e)
+                for (int32_t i = 0; i < sdim; ++i) out[(size_t)e * sdim + i] = (double)((X[(size_t)e * sdim + i] + X[(size_t)i * sdim + e]) / 2);      // symmetric, column-major
+        }
+    };
+    {
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < hw; ++t) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+    }
+    if (bad.load()) { set_error("fos_enable_direct: I + A'A has a block that is not positive definite (non-finite entries in A?)"); return FOS_EINVAL; }
+    // ---- device data
+    FOS_TRY(dev_upload(h, &h->blk_goff, goff));
+    FOS_TRY(dev_upload(h, &h->blk_ioff, ioff));
+    FOS_TRY(dev_upload(h, &h->blk_idx, idx));
+    FOS_TRY(dev_upload(h, &h->blk_ginv, ginv));
+    h->blk_n = nblk;
+    FOS_TRY(dev_alloc(h, &h->blk_phg, (size_t)l));
+    FOS_TRY(dev_alloc(h, &h->blk_qphg, (size_t)l));
+    FOS_TRY(dev_alloc(h, &h->blk_prm, 16));
+    FOS_HIP(hipMemset(h->blk_phg, 0, sizeof(d2) * (size_t)l));
+    FOS_HIP(hipMemset(h->blk_qphg, 0, sizeof(d2) * (size_t)l));
+    // ---- the border: h = [c; b], M h = [A'b; -A c], ph = D^-1 (h; 0), pg = D^-1 (M h; 0) by two runs of the device path without the border terms
+    std::vector<double> cbv((size_t)(n + m));
+    FOS_HIP(hipMemcpy(cbv.data(), h->cb, sizeof(double) * (size_t)(n + m), hipMemcpyDeviceToHost));
+    long double hh2 = 0.0L;
+    for (double v : cbv) hh2 += (long double)v * v;
+    const double delta = (double)(1.0L + hh2);
+    std::vector<double> prm(16, 0.0);
+    prm[9] = delta;
+    FOS_HIP(hipMemcpy(h->blk_prm, prm.data(), sizeof(double) * 16, hipMemcpyHostToDevice));
+    std::vector<double> mh((size_t)(n + m), 0.0);
+    for (int64_t j = 0; j < n; ++j) {
+        long double acc = 0.0L;
+        for (int64_t p = colptr[j] - 1; p < colptr[j + 1] - 1; ++p) {
+            const int64_t r = rowval[p] - 1;
+            acc += (long double)nzval[p] * cbv[(size_t)(n + r)];
+            mh[(size_t)(n + r)] -= nzval[p] * cbv[(size_t)j];
+        }
+        mh[(size_t)j] = (double)acc;
+    }
+    std::vector<d2> tv((size_t)l), res((size_t)l), phg((size_t)l), qphg((size_t)l);
+    for (int pass = 0; pass < 2; ++pass) {
+        const std::vector<double>& src = pass == 0 ? cbv : mh;
+        for (int64_t i = 0; i < l - 1; ++i) tv[(size_t)i] = make_double2(src[(size_t)i], 0.0);
+        tv[(size_t)l - 1] = make_double2(0.0, 0.0);
+        FOS_HIP(hipMemcpy(h->R, tv.data(), sizeof(d2) * (size_t)l, hipMemcpyHostToDevice));
+        FOS_TRY(prox_affine_direct_block(h, nullptr, h->W, true, true));
+        FOS_HIP(hipStreamSynchronize(h->stream));
+        FOS_HIP(hipMemcpy(res.data(), h->W, sizeof(d2) * (size_t)l, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < l; ++i) {
+            if (pass == 0) { phg[(size_t)i].x = res[(size_t)i].x; qphg[(size_t)i].x = res[(size_t)i].y; }
+            else { phg[(size_t)i].y = res[(size_t)i].x; qphg[(size_t)i].y = res[(size_t)i].y; }
+        }
+    }
+    long double hph = 0, hpg = 0, gph = 0, gpg = 0;
+    for (int64_t i = 0; i < l - 1; ++i) {
+        hph += (long double)cbv[(size_t)i] * phg[(size_t)i].x; hpg += (long double)cbv[(size_t)i] * phg[(size_t)i].y;
+        gph += (long double)mh[(size_t)i] * phg[(size_t)i].x; gpg += (long double)mh[(size_t)i] * phg[(size_t)i].y;
+    }
+    // S3 = C^-1 + W' D^-1 W,  C^-1 = [1 0 0; 0 0 -1; 0 -1 0]
+    long double S3[3][3] = {{1 + hph, hpg, 0}, {gph, gpg, -1}, {0, -1, 1 / (long double)delta}}, Inv[3][3];
+    const long double det = S3[0][0] * (S3[1][1] * S3[2][2] - S3[1][2] * S3[2][1]) - S3[0][1] * (S3[1][0] * S3[2][2] - S3[1][2] * S3[2][0]) +
+                            S3[0][2] * (S3[1][0] * S3[2][1] - S3[1][1] * S3[2][0]);
+    if (!(fabsl(det) > 0.0L) || !std::isfinite((double)det)) { set_error("fos_enable_direct: the 3 x 3 border system of the block form is singular"); return FOS_EINVAL; }
+    for (int a = 0; a < 3; ++a)
+        for (int bq = 0; bq < 3; ++bq) {
+            const int a1 = (a + 1) % 3, a2 = (a + 2) % 3, b1 = (bq + 1) % 3, b2 = (bq + 2) % 3;
+            Inv[bq][a] = (S3[a1][b1] * S3[a2][b2] - S3[a1][b2] * S3[a2][b1]) / det;          // adjugate, transposed
+        }
+    for (int a = 0; a < 3; ++a) for (int bq = 0; bq < 3; ++bq) prm[(size_t)(3 * a + bq)] = (double)Inv[a][bq];
+    FOS_HIP(hipMemcpy(h->blk_prm, prm.data(), sizeof(double) * 16, hipMemcpyHostToDevice));
+    FOS_HIP(hipMemcpy(h->blk_phg, phg.data(), sizeof(d2) * (size_t)l, hipMemcpyHostToDevice));
+    FOS_HIP(hipMemcpy(h->blk_qphg, qphg.data(), sizeof(d2) * (size_t)l, hipMemcpyHostToDevice));
+    *ok = true;
+    return FOS_OK;
+}
+
 }  // namespace
 
 namespace fos {
@@ -1666,6 +1918,11 @@ int fos_destroy(fos_handle h) {
     if (h->host_buf) (void)hipHostFree(h->host_buf);
     for (void* q : h->peer_opened) (void)hipIpcCloseMemHandle(q);
     for (void* q : h->vec_opened) (void)hipIpcCloseMemHandle(q);
+    if (h->host_seg) {
+        (void)hipHostUnregister(h->host_seg);
+        (void)munmap(h->host_seg, h->host_seg_bytes);
+        if (h->rank == 0 && !h->host_seg_name.empty()) (void)shm_unlink(h->host_seg_name.c_str());
+    }
     for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (void* p : h->owned) (void)hipFree(p);
     if (h->st_host) (void)hipHostFree(h->st_host);
@@ -1788,9 +2045,95 @@ int fos_peer_open(fos_handle h, int nranks, int rank, const void* handles, doubl
     uint32_t* seq = nullptr;
     FOS_TRY(dev_alloc(h, &seq, 1));
     FOS_HIP(hipMemset(seq, 0, sizeof(uint32_t)));
+    h->peer = PeerBox{};
     h->peer.box = dtab; h->peer.seq = seq; h->peer.nranks = nranks; h->peer.rank = rank;
     h->peer.timeout_ticks = (int64_t)((timeout_s > 0 ? timeout_s : 20.0) * 1e8);
+    h->peer.loopback = (getenv("FOS_PEER_LOOPBACK") && atoi(getenv("FOS_PEER_LOOPBACK")) != 0) ? 1 : 0;
     h->nranks = nranks; h->rank = rank;
+    return FOS_OK;
+}
+
+// Host-pinned mailboxes: ONE shm segment of mailbox size that every rank maps and registers; every box[r] is that segment (PeerBox::shared),
+// workgroup 0 of a folded exchange republishes the peers' words in a local relay (PeerBox::relay).
+int fos_peer_open_host(fos_handle h, int nranks, int rank, const char* shm_name, double timeout_s) {
+    if (!h || !shm_name || shm_name[0] != '/' || nranks < 1 || nranks > PEER_MAX_RANKS || rank < 0 || rank >= nranks) {
+        set_error("bad arguments (shm_name \"/...\", 1 <= nranks <= %d)", PEER_MAX_RANKS); return FOS_EINVAL;
+    }
+    if (!h->peer_opened.empty() || h->peer.box || h->host_seg) { set_error("peer mailboxes are already open (fos_peer_close first)"); return FOS_EINVAL; }
+    if (h->row_sharded) { set_error("host-pinned mailboxes carry the scalar sums of cone-sharded handles only"); return FOS_EUNSUPPORTED; }
+    if (h->comm && (h->nranks != nranks || h->rank != rank)) { set_error("peer ranks differ from the RCCL communicator's"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    const size_t bytes = ((PEER_BOX_TOTAL_WORDS * sizeof(unsigned long long) + 4095) / 4096) * 4096;
+    // every rank creates-or-opens and sizes the segment (idempotent; a fresh segment is zero filled: sequence number 0 is never sent)
+    const int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) { set_error("shm_open(%s): %s", shm_name, strerror(errno)); return FOS_ECOMM; }
+    if (ftruncate(fd, (off_t)bytes) != 0) { const int e = errno; close(fd); set_error("ftruncate(%s, %zu): %s", shm_name, bytes, strerror(e)); return FOS_ECOMM; }
+    void* seg = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (seg == MAP_FAILED) { set_error("mmap(%s): %s", shm_name, strerror(errno)); return FOS_ECOMM; }
+    hipError_t e = hipHostRegister(seg, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    void* dptr = nullptr;
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&dptr, seg, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostUnregister(seg);
+        (void)hipGetLastError();
+        munmap(seg, bytes);
+        set_error("hipHostRegister / hipHostGetDevicePointer(%s): %s", shm_name, hipGetErrorString(e));
+        return FOS_ECOMM;
+    }
+    h->host_seg = seg; h->host_seg_bytes = bytes; h->host_seg_name = shm_name;
+    if (!h->peer_relay) {
+        void* q = nullptr;
+        const size_t rb = PEER_BOX_TOTAL_WORDS * sizeof(unsigned long long);
+        hipError_t er = hipExtMallocWithFlags(&q, rb, hipDeviceMallocUncached);
+        if (er != hipSuccess) { (void)hipGetLastError(); er = hipExtMallocWithFlags(&q, rb, hipDeviceMallocFinegrained); }
+        if (er != hipSuccess) { set_error("hipExtMallocWithFlags(relay): %s", hipGetErrorString(er)); return FOS_ENOMEM; }
+        h->owned.push_back(q);
+        h->peer_relay = reinterpret_cast<unsigned long long*>(q);
+    }
+    FOS_HIP(hipMemset(h->peer_relay, 0, PEER_BOX_TOTAL_WORDS * sizeof(unsigned long long)));
+    std::vector<unsigned long long*> tab((size_t)nranks, reinterpret_cast<unsigned long long*>(dptr));
+    unsigned long long** dtab = nullptr;
+    FOS_TRY(dev_upload(h, &dtab, tab));
+    uint32_t* seq = nullptr;
+    FOS_TRY(dev_alloc(h, &seq, 1));
+    FOS_HIP(hipMemset(seq, 0, sizeof(uint32_t)));
+    h->peer = PeerBox{};
+    h->peer.box = dtab; h->peer.seq = seq; h->peer.nranks = nranks; h->peer.rank = rank;
+    h->peer.timeout_ticks = (int64_t)((timeout_s > 0 ? timeout_s : 20.0) * 1e8);
+    h->peer.relay = h->peer_relay; h->peer.shared = 1;
+    h->peer.loopback = (getenv("FOS_PEER_LOOPBACK") && atoi(getenv("FOS_PEER_LOOPBACK")) != 0) ? 1 : 0;
+    h->nranks = nranks; h->rank = rank;
+    return FOS_OK;
+}
+
+// drop the open mailboxes (device or host): another transport may be opened on the handle afterwards
+int fos_peer_close(fos_handle h) {
+    if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    if (h->peer_on) FOS_TRY(fos_peer_enable(h, 0));
+    for (void* q : h->peer_opened) (void)hipIpcCloseMemHandle(q);
+    h->peer_opened.clear();
+    for (void* q : h->vec_opened) (void)hipIpcCloseMemHandle(q);
+    h->vec_opened.clear();
+    h->vec = VecBox{};
+    if (h->host_seg) {
+        (void)hipHostUnregister(h->host_seg);
+        (void)munmap(h->host_seg, h->host_seg_bytes);
+        if (h->rank == 0 && !h->host_seg_name.empty()) (void)shm_unlink(h->host_seg_name.c_str());
+        h->host_seg = nullptr; h->host_seg_bytes = 0; h->host_seg_name.clear();
+    }
+    if (h->peer_mbox) FOS_HIP(hipMemset(h->peer_mbox, 0, PEER_BOX_TOTAL_WORDS * sizeof(unsigned long long)));   // (a re-opened mailbox starts its sequence numbers again)
+    h->peer = PeerBox{};                       // (the small device tables stay owned by the handle until fos_destroy)
+    h->peer_same_device = false;
+    // a failed exchange leaves its mark in the device state: clear it, the next transport starts clean
+    DevState z;
+    FOS_HIP(hipMemcpy(&z, h->st, sizeof(DevState), hipMemcpyDeviceToHost));
+    z.xchg_failed = 0; z.done = 0;
+    FOS_HIP(hipMemcpy(h->st, &z, sizeof(DevState), hipMemcpyHostToDevice));
+    h->st_host->xchg_failed = 0;
     return FOS_OK;
 }
 
@@ -1938,14 +2281,25 @@ int fos_set_alg(fos_handle h, int alg, double alpha, double alpha1, double alpha
 int fos_enable_direct(fos_handle h, const int64_t* colptr, const int64_t* rowval, const double* nzval) {
     if (!h || !colptr || (!rowval && colptr[h->n] > 1)) { set_error("NULL argument"); return FOS_EINVAL; }
     if (h->sharded()) { set_error("direct=true is a single-GPU mode"); return FOS_EUNSUPPORTED; }
-    if (h->Ginv) { h->direct = true; return FOS_OK; }
+    if (h->Ginv || h->blk_ginv) { h->direct = true; h->direct_blk = h->blk_ginv != nullptr; return FOS_OK; }
     const int64_t l = h->l, nnz = colptr[h->n] - 1;
+    // which exact form (FOS_DIRECT_MODE=block|dense|cg forces one; default: the first that applies)
+    const char* mode_env = getenv("FOS_DIRECT_MODE");
+    const std::string mode = mode_env ? mode_env : "auto";
+    if (nnz != h->nnz) { set_error("fos_enable_direct: A has %lld non-zeros, the handle was created with %lld", (long long)nnz, (long long)h->nnz); return FOS_EINVAL; }
+    // (1) block-separable operators: I + A'A block diagonal with small blocks -> three sweeps per projection, any size (blkdir_setup)
+    if (mode == "auto" || mode == "block") {
+        FOS_HIP(hipSetDevice(h->device));
+        bool ok = false;
+        FOS_TRY(blkdir_setup(h, colptr, rowval, nzval, &ok));
+        if (ok) { h->direct_blk = true; h->direct = true; return FOS_OK; }
+        if (mode == "block") { set_error("FOS_DIRECT_MODE=block: A'A has a diagonal block of more than %d columns", BLKDIR_MAX); return FOS_EUNSUPPORTED; }
+    }
     // beyond what a dense l x l inverse can hold, S1 = IndAffine([Q -I], 0) and S1 = AffinePlusLinear(Q, 0, 0, 1) are still the SAME set (HSDE.jl:12-15 / :22): the
     // exact projection is what the warm-started CG converges to, so "direct" becomes CG run to its tolerance floor l eps from the first call on
     // (no 0.2^sqrt(i) schedule: affinepluslinear.jl:108-112 is what direct = true switches off) -- the reference's sparse factorisation is not rebuilt.
     const int64_t dense_max = getenv("FOS_DIRECT_DENSE_MAX") ? atoll(getenv("FOS_DIRECT_DENSE_MAX")) : 46000;
-    if (l > dense_max) { h->direct_cg = true; h->direct = false; return FOS_OK; }
-    if (nnz != h->nnz) { set_error("fos_enable_direct: A has %lld non-zeros, the handle was created with %lld", (long long)nnz, (long long)h->nnz); return FOS_EINVAL; }
+    if (l > dense_max || mode == "cg") { h->direct_cg = true; h->direct = false; return FOS_OK; }
     FOS_HIP(hipSetDevice(h->device));
     LaunchCtx c = h->ctx();
     const int64_t L = (l + 63) / 64 * 64;
@@ -2030,7 +2384,14 @@ int fos_enable_direct(fos_handle h, const int64_t* colptr, const int64_t* rowval
 
 int fos_disable_direct(fos_handle h) {
     if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
-    h->direct = false; h->direct_cg = false;
+    h->direct = false; h->direct_cg = false; h->direct_blk = false;
+    return FOS_OK;
+}
+
+// which form S1 = IndAffine([Q -I], 0) runs in: 0 = off (AffinePlusLinear's CG schedule), 1 = dense inverse, 2 = block form, 3 = CG at its tolerance floor
+int fos_get_direct_mode(fos_handle h, int32_t* mode) {
+    if (!h || !mode) { set_error("NULL argument"); return FOS_EINVAL; }
+    *mode = h->direct ? (h->direct_blk ? 2 : 1) : (h->direct_cg ? 3 : 0);
     return FOS_OK;
 }
 

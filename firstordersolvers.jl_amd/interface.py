@@ -435,6 +435,12 @@ class HipHSDE:
     def disable_direct(self):
         _lib.check(self._lib.fos_disable_direct(self._h))
 
+    def direct_mode(self):
+        """'off' | 'dense' | 'block' | 'cg': the form S1 = IndAffine([Q -I], 0) runs in (fos_get_direct_mode)"""
+        v = C.c_int32(0)
+        _lib.check(self._lib.fos_get_direct_mode(self._h, C.byref(v)))
+        return ("off", "dense", "block", "cg")[v.value]
+
     def set_tuning(self, spmv_workgroups=0, cg_chunk=0, fuse_p=-1):
         """fuse_p: -1 keeps the library's choice, 0 / 1 force the three- / two-launch CG iteration."""
         _lib.check(self._lib.fos_set_tuning(self._h, spmv_workgroups, cg_chunk, fuse_p))
@@ -516,6 +522,15 @@ class HipHSDE:
         assert len(blob) == 64 * nranks
         buf = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
         _lib.check(self._lib.fos_peer_open(self._h, nranks, rank, buf, float(timeout_s)))
+
+    def peer_open_host(self, nranks, rank, shm_name, timeout_s=0.0):
+        """host-pinned mailboxes (fos_peer_open_host): `shm_name` = "/something-unique-to-the-job", the same on every rank of the node;
+        replaces peer_export + peer_open, then peer_selftest / peer_enable as usual."""
+        _lib.check(self._lib.fos_peer_open_host(self._h, nranks, rank, shm_name.encode(), float(timeout_s)))
+
+    def peer_close(self):
+        """drop the open mailboxes (device or host) so that another transport can be opened on this handle"""
+        _lib.check(self._lib.fos_peer_close(self._h))
 
     def peer_vec_export(self) -> bytes:
         """row-sharded handles: the exchange buffer of the n-vector A'y (after peer_open)"""
@@ -682,7 +697,9 @@ class FOSMathProgModel:
         dev = self.data                                            # model.data persists across optimize! calls, as in the
         dev.set_iterate(opts.get("initx", None))                   # reference (alpha12 / t / y / S1 counters carry over); :10
         status = HSDEStatus(self, checki, eps, verbose, debug, out=self.out)
-        status.direct = bool(self.alg.direct)                      # HSDE.jl:27
+        # HSDE.jl:27 -- the table drops its cg column when S1 runs no CG; beyond the sizes the exact forms cover, direct = true is the same
+        # projection by CG at its tolerance floor (fos_enable_direct): the column stays, the iterations are real
+        status.direct = bool(self.alg.direct) and self.data.direct_mode() in ("dense", "block")
         self.status_obj = status
         t1 = time.time()
         status.printstatusheader()

@@ -109,8 +109,9 @@ for T in (:GAP, :GAPA, :FISTA, :Dykstra, :(FirstOrderSolvers.GAPP))
             # AffinePlusLinear (5 N-vectors of CG state) and DualConeProduct, which the device path never touches.
             # m, n as DualConeProduct's constructor takes them [cones.jl:121]
             sm, sn = model.K1.ranges[end][end], model.K2.ranges[end][end]
+            dmode = Ref{Int32}(0)          # fos_get_direct_mode, read below: 1 dense inverse, 2 block form (no CG: the table drops its cg column), 3 CG at its floor
             status_generator = (mo, checki, eps, verbose, debug) ->
-                HSDEStatus(sm, sn, 0, mo, :Continue, checki, eps, verbose, false, alg.direct, time_ns(), model.init_duration, debug)
+                HSDEStatus(sm, sn, 0, mo, :Continue, checki, eps, verbose, false, alg.direct && dmode[] in (1, 2), time_ns(), model.init_duration, debug)
             data = HipData(model, get(model.options, :device, 0))
             set_alg!(data, alg)
             if haskey(model.options, :cg_variant)      # device-side key: which CG recurrence the affine projection runs (FOS_CG_* of foship.h)
@@ -124,6 +125,7 @@ for T in (:GAP, :GAPA, :FISTA, :Dykstra, :(FirstOrderSolvers.GAPP))
                 A = model.A
                 GC.@preserve A check(ccall((:fos_enable_direct, libfoship), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}),
                                            data.handle, A.colptr, A.rowval, A.nzval))
+                check(ccall((:fos_get_direct_mode, libfoship), Cint, (Ptr{Cvoid}, Ref{Int32}), data.handle, dmode))
             end
             return data, status_generator
         end

@@ -150,6 +150,17 @@ int fos_comm_init_host(fos_handle h, int nranks, int rank, fos_allreduce_fn fn, 
  * An exchange that waits longer than the time-out stops the solve with FOS_ECOMM (never a hang). */
 int fos_peer_export(fos_handle h, void* handle64);
 int fos_peer_open(fos_handle h, int nranks, int rank, const void* handles, double timeout_s);
+/* The same mailboxes in PINNED HOST MEMORY (a third transport between the device mailboxes and the RCCL all-reduce): one POSIX shared-memory
+ * segment `shm_name` ("/name", the same string on every rank of the node, unique to the job) that every rank maps and registers with the HIP
+ * runtime -- it needs neither peer access between the devices nor an IPC handle, so it works wherever the ranks share a host.  An exchange is
+ * one posted PCIe write of the rank's words and PCIe reads by ONE polling workgroup, which republishes what it sees in local device memory for
+ * the others (csrc/fos_internal.hpp, PeerBox::relay): about two PCIe latencies per CG inner product (conjugategradients.jl:39,46) instead of one
+ * xGMI write latency.  Collective; replaces fos_peer_export + fos_peer_open, then fos_peer_selftest / fos_peer_enable as for the device mailboxes.
+ * Cone-sharded handles (row-sharded ones keep their n-vector exchange on RCCL or the device mailboxes).  The segment is unlinked by rank 0's fos_peer_close / fos_destroy.
+ * fos_peer_close: drops whichever mailboxes are open (device or host) so that another transport can be opened on the same handle; the handle falls
+ * back to RCCL if fos_comm_init was called, else to a single GPU. */
+int fos_peer_open_host(fos_handle h, int nranks, int rank, const char* shm_name, double timeout_s);
+int fos_peer_close(fos_handle h);
 int fos_peer_selftest(fos_handle h, int rounds, int32_t* ok);
 /* Row-sharded handles (FOS_CREATE_ROW_SHARDED) over the mailboxes: the n-vector A'y = sum over ranks of A_g'y_g (HSDEAffine.jl:51)
  * also crosses the ranks through peer-mapped memory -- every rank pushes its 2n partial sums into every peer's exchange buffer and
@@ -178,9 +189,16 @@ int fos_reset_affine(fos_handle h);
  * without the cg column (HSDEStatus.jl:44-50,79).  Single-GPU handles only.  fos_disable_direct returns to CG.
  * l > 46000 (C3, C4, C5): the dense inverse does not fit; IndAffine([Q -I], 0) and AffinePlusLinear(Q, 0, 0, 1) being the same set (HSDE.jl:12-15 / :22), the
  * exact projection is then computed by the warm-started CG run to its tolerance floor l eps from the first call on (no 0.2^sqrt(i) schedule) -- the reference's
- * sparse factorisation is not rebuilt; fos_check_result.cgiter reports the CG iterations of that projection. */
+ * sparse factorisation is not rebuilt; fos_check_result.cgiter reports the CG iterations of that projection.
+ * BLOCK-SEPARABLE operators (round 5; tried first, any size): when the columns of A fall into groups of at most 64 that share no row -- I + A'A block diagonal
+ * with small blocks: a block-diagonal SDP with few variables per block (C4: 512 blocks of 32 columns) -- the same exact projection costs THREE KKT sweeps:
+ * I + Q Q' = blkdiag(I + A'A, I + AA', delta) + a rank-3 border, (I + AA')^-1 = I - A (I + A'A)^-1 A', the small blocks inverted once on the host
+ * (csrc/solver.cpp prox_affine_direct_block).  No CG, no l x l matrix; cgiter stays 0.
+ * fos_get_direct_mode: 0 = off, 1 = dense inverse, 2 = block form, 3 = CG at its tolerance floor (the host keeps the table's cg column then).
+ * FOS_DIRECT_MODE=block|dense|cg (environment) forces a form. */
 int fos_enable_direct(fos_handle h, const int64_t* colptr, const int64_t* rowval, const double* nzval);
 int fos_disable_direct(fos_handle h);
+int fos_get_direct_mode(fos_handle h, int32_t* mode);
 
 /* getinitialvalue / option initx (solverwrapper.jl:10, HSDE.jl:40-47): z = 0, tau = kappa = 1 when z == NULL */
 int fos_set_iterate(fos_handle h, const double* z);

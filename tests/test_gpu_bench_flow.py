@@ -78,30 +78,41 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert bad.returncode != 0
 
 
-def test_bench_falls_back_to_rccl_when_the_mailboxes_fail_in_the_warmup():
-    """The mailbox self test can pass and the first real exchanges still fail (a transport that has never run between two
-    devices): every rank votes after the warm-up, and the job runs again over the in-stream RCCL all-reduce.  One rank in a
-    RCCL group of its own (`FOS_FORCE_DIST=1`), the failure injected."""
+@pytest.mark.parametrize("inject,expect", [("peer_warmup_fail", "host-pinned"), ("mailbox_warmup_fail", "RCCL"), ("peer_open_fail", "host-pinned")])
+def test_bench_falls_back_through_the_transports(inject, expect):
+    """The order of transports for the scalar sums is device mailboxes (HIP IPC) -> host-pinned mailboxes -> in-stream RCCL all-reduce, each
+    decided collectively.  A mailbox self test can pass and the first real exchanges still fail (a transport that has never run between
+    two devices): every rank votes after the warm-up, and the job runs again, in the same processes, over the next transport.  One rank in
+    a RCCL group of its own (`FOS_FORCE_DIST=1`), the failures injected: in the warm-up on the device mailboxes, on both kinds of
+    mailboxes, and at the opening of the device mailboxes (no peer access)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "FOS_BENCH_BACKEND")}
-    env.update(FOS_FORCE_DIST="1", FOS_BENCH_INJECT="peer_warmup_fail", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(FOS_FORCE_DIST="1", FOS_BENCH_INJECT=inject, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "2", "--small", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = _last_json(r.stdout)
-    assert "RCCL" in out["config"]["parallelism"] and out["value"] > 0
-    assert "timed out on the peer mailboxes" in out["config"]["peer_fallback_reason"]
-    assert "warm-up failed on the peer mailboxes" in r.stderr
-    # with only the mailboxes allowed the same failure must end the run
+    assert expect in out["config"]["parallelism"] and out["value"] > 0
+    why = out["config"]["peer_fallback_reason"]
+    if inject == "peer_open_fail":
+        assert "peer:" in why and "injected: no peer access" in why
+    else:
+        assert "timed out on the peer mailboxes" in why and "warm-up failed on the peer mailboxes" in r.stderr
+    if inject == "mailbox_warmup_fail":
+        assert "timed out on the host mailboxes" in why and "warm-up failed on the host mailboxes" in r.stderr
+    # with only the device mailboxes allowed the same failure must end the run
     bad = subprocess.run(cmd, cwd=str(ROOT), env=dict(env, FOS_REDUCTION="peer"), capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0
 
 
-@pytest.mark.parametrize("nranks", [4, 8])
-def test_bench_four_and_eight_ranks_on_one_gpu(nranks):
+@pytest.mark.parametrize("transport", ["peer", "host"])
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_bench_ranks_on_one_gpu(nranks, transport):
     """The rank counts the driver launches (2, 4, 8), here sharing the one GPU: cone shards of 1/N of the blocks, every CG iteration's
-    sums through N peer mailboxes.  Same iteration count and residuals as one rank on the same problem (timing is meaningless here)."""
+    sums through N mailboxes -- in device memory mapped through HIP IPC (`peer`) or in ONE pinned host segment every rank registers
+    (`host`: fos_peer_open_host; workgroup 0 polls over PCIe and republishes in a local relay).  Same iteration count and residuals
+    as one rank on the same problem (timing is meaningless here)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(FOS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(FOS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", FOS_REDUCTION=transport)
     base = [sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "3", "--small"]
     rn = subprocess.run(base + ["--gpus", str(nranks), "--no-weak-extra"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
     assert rn.returncode == 0, rn.stdout[-3000:] + rn.stderr[-3000:]
@@ -109,7 +120,7 @@ def test_bench_four_and_eight_ranks_on_one_gpu(nranks):
     r1 = subprocess.run(base + ["--no-cpu-baseline"], cwd=str(ROOT), env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stdout[-3000:] + r1.stderr[-3000:]
     out1 = _last_json(r1.stdout)
-    assert outn["n_gpus"] == nranks and "peer mailboxes" in outn["config"]["parallelism"]
+    assert outn["n_gpus"] == nranks and ("peer mailboxes" if transport == "peer" else "host-pinned mailboxes") in outn["config"]["parallelism"]
     assert outn["config"]["peer_fallback_reason"] is None and len(outn["config"]["all_ranks_ms_per_step"]) == nranks
     assert nranks * outn["config"]["local_m"] == out1["config"]["local_m"]
     ra, rb = out1["config"]["residuals_after_run"], outn["config"]["residuals_after_run"]
@@ -117,3 +128,4 @@ def test_bench_four_and_eight_ranks_on_one_gpu(nranks):
     for k in ("p", "d", "g"):
         assert rb[k] == pytest.approx(ra[k], rel=1e-4), k
     assert outn["config"]["cg_iters_per_step"] == pytest.approx(out1["config"]["cg_iters_per_step"], abs=1.5)
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("foship-")]            # rank 0 unlinked the segment

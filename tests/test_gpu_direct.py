@@ -16,14 +16,43 @@ def _omodel(prob):
     return orc.Model(prob.A, prob.b, prob.c, codes(prob.K1), codes(prob.K2))
 
 
-@pytest.mark.parametrize("which", ["small_mixed", "small_lp", "tile_lp"])
-def test_direct_projection_matches_oracle_and_is_exact(pkg, which):
+def scrambled_block_problem(pkg, seed=5):
+    """A block-diagonal program whose rows and columns are randomly permuted: the diagonal blocks of I + A'A are then NOT contiguous column
+    ranges (blocks of 1 ... 40 columns, among them single columns and an empty column)."""
+    rng = np.random.default_rng(seed)
+    blocks = []
+    for s in (1, 40, 7, 1, 23, 12, 3):
+        mk = int(rng.integers(s, 4 * s + 6))
+        blocks.append(sp.random(mk, s, density=float(rng.choice([0.3, 1.0])), format="csc", random_state=rng, data_rvs=rng.standard_normal))
+    blocks.append(sp.csc_matrix((3, 1)))                      # a column without entries: a block of its own (G = 1)
+    A = sp.block_diag(blocks, format="csc")
+    m, n = A.shape
+    A = A[rng.permutation(m)][:, rng.permutation(n)].tocsc()
+    A.sort_indices()
+    x0 = np.abs(rng.standard_normal(n))
+    s0 = np.abs(rng.standard_normal(m))
+    y0 = np.zeros(m)
+    b = A @ x0 + s0
+    c = rng.standard_normal(n)
+    return pkg.workloads.ConicProblem("scrambled-blocks", A, b, c, [("NonNeg", m)], [("NonNeg", n)], x0=x0, y0=y0, s0=s0)
+
+
+@pytest.mark.parametrize("which,mode,form", [("small_mixed", "auto", "block"), ("small_lp", "auto", "block"), ("tile_lp", "auto", "dense"),
+                                             ("small_mixed", "dense", "dense"), ("small_lp", "dense", "dense"),
+                                             ("block_sdp", "auto", "block"), ("block_sdp", "dense", "dense"), ("scrambled", "auto", "block")])
+def test_direct_projection_matches_oracle_and_is_exact(pkg, which, mode, form, monkeypatch):
     """fos_prox_affine in direct mode vs the oracle's IndAffineDirect (1e-12), feasibility Q u = v and orthogonality of the
-    displacement to rounding; on a row-block operator, one with odd l, and one stored as dual tiles."""
+    displacement to rounding; on a row-block operator, one with odd l, one stored as dual tiles, a block SDP and a scrambled block program --
+    in the form fos_enable_direct chooses (the block form wherever I + A'A has diagonal blocks of at most 64 columns: three sweeps per
+    projection) and in the dense-inverse form."""
     prob = {"small_mixed": pkg.workloads.small_mixed, "small_lp": lambda: pkg.workloads.small_lp(seed=3, m=31, n=61),
-            "tile_lp": lambda: pkg.workloads.small_lp(seed=21, m=96, n=180)}[which]()
+            "tile_lp": lambda: pkg.workloads.small_lp(seed=21, m=96, n=180),
+            "block_sdp": lambda: pkg.workloads.c4_block_sdp(nblocks=8, k=16, p=6), "scrambled": lambda: scrambled_block_problem(pkg)}[which]()
+    if mode != "auto":
+        monkeypatch.setenv("FOS_DIRECT_MODE", mode)
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     d.enable_direct(prob.A)
+    assert d.direct_mode() == form
     S1 = orc.IndAffineDirect(orc.HSDEMatrixQ(prob.A, prob.b, prob.c))
     rng = np.random.default_rng(9)
     l = d.l
@@ -86,11 +115,89 @@ def test_direct_on_dense_lp_is_faster_than_cg_and_reaches_the_optimum(pkg):
     assert md.getobjval() == pytest.approx(float(prob.c @ prob.x0), rel=1e-2, abs=1e-4)
 
 
+def test_block_form_refused_or_passed_over_when_not_separable(pkg, monkeypatch):
+    """A dense 96 x 180 LP couples all 180 columns: no block form (FOS_DIRECT_MODE=block is refused), the default falls through to the dense inverse."""
+    prob = pkg.workloads.small_lp(seed=21, m=96, n=180)
+    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    monkeypatch.setenv("FOS_DIRECT_MODE", "block")
+    with pytest.raises(pkg.lib.FosError):
+        d.enable_direct(prob.A)
+    assert d.direct_mode() == "off"
+    monkeypatch.delenv("FOS_DIRECT_MODE")
+    d.enable_direct(prob.A)
+    assert d.direct_mode() == "dense"
+    d.close()
+
+
+def _projection_certificate(prob, d, x, tol):
+    """y = P(x) onto {(u, v): Q u = v} is the unique point with (i) Q u+ = v+ and (ii) x - y in the row space of [Q -I]: with w = v+ - v,
+    u+ - u = Q w (Q' = -Q).  Checked with the oracle's operator (one scipy SpMV pair each) -- no factorisation needed at any size."""
+    Q = orc.HSDEMatrixQ(prob.A, prob.b, prob.c)
+    l = d.l
+    y = d.prox_affine(x)
+    t = np.empty(l)
+    Q.mul(t, y[:l])
+    assert np.linalg.norm(t - y[l:]) <= tol * np.linalg.norm(y), np.linalg.norm(t - y[l:]) / np.linalg.norm(y)
+    Q.mul(t, y[l:] - x[l:])
+    assert np.linalg.norm((y[:l] - x[:l]) - t) <= tol * np.linalg.norm(x), np.linalg.norm((y[:l] - x[:l]) - t) / np.linalg.norm(x)
+    return y
+
+
+def test_block_form_at_c4_sizes_certificate_cg_and_a_whole_solve(pkg, monkeypatch):
+    """The 64-block shard of C4 and C4 itself (l = 1 081 345; 512 diagonal blocks of 32 columns): the block form's projection carries the
+    oracle-free certificate of the exact projection at 1e-12, equals the warm-started CG at its tolerance floor (FOS_DIRECT_MODE=cg) to 1e-9,
+    costs no CG iteration -- and DR(direct=true) solves C4 to its known optimum."""
+    for nblk, rng_seed in ((64, 1), (512, 2)):
+        prob = pkg.workloads.c4_block_sdp(nblocks=512, block_range=(0, nblk))
+        d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+        d.enable_direct(prob.A)
+        assert d.direct_mode() == "block"
+        rng = np.random.default_rng(rng_seed)
+        ys = []
+        for scale in (1.0, 1e3):
+            x = scale * rng.standard_normal(d.N)
+            ys.append((x, _projection_certificate(prob, d, x, 1e-12)))
+            assert d.cgiter() == 0
+        # idempotent: a point of the set stays
+        y2 = d.prox_affine(ys[0][1])
+        assert np.linalg.norm(y2 - ys[0][1]) <= 1e-12 * np.linalg.norm(ys[0][1])
+        d.close()
+        if nblk == 64:
+            monkeypatch.setenv("FOS_DIRECT_MODE", "cg")
+            dc = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+            dc.enable_direct(prob.A)
+            assert dc.direct_mode() == "cg"
+            x, y = ys[0]
+            ycg = dc.prox_affine(x)
+            assert dc.cgiter() > 0 and np.linalg.norm(ycg - y) <= 1e-9 * np.linalg.norm(y)
+            dc.close()
+            monkeypatch.delenv("FOS_DIRECT_MODE")
+    prob = pkg.workloads.c4_block_sdp()
+    model = pkg.solve(prob, pkg.DR(direct=True, eps=1e-4, max_iters=4000, verbose=0, checki=250))
+    assert model.status() == "Optimal" and "cgiter" not in model.history
+    assert model.getobjval() == pytest.approx(float(prob.c @ prob.x0), rel=5e-3)
+    assert np.max(np.abs(model.getsolution() - prob.x0)) < 1e-3
+
+
+def test_block_form_whole_solves_match_the_oracle(pkg):
+    """DR / GAPA / FISTA / Dykstra with direct=true on a block SDP (8 x PSD(16), block form on the device, dense Cholesky in the oracle): no inexact
+    CG in the loop -- same status, same iteration count, solution to 1e-9."""
+    prob = pkg.workloads.c4_block_sdp(nblocks=8, k=16, p=6)
+    for mk in (lambda M, **o: M.DR(**o), lambda M, **o: M.GAPA(0.8, 0.5, **o), lambda M, **o: M.FISTA(**o), lambda M, **o: M.Dykstra(**o)):
+        opts = dict(eps=1e-6, verbose=0, max_iters=600, checki=50, direct=True)
+        model = pkg.solve(prob, mk(pkg, **opts))
+        sol = orc.solve(_omodel(prob), mk(orc, **opts), out=[])
+        assert model.data.direct_mode() == "block"
+        assert model.status() == sol.status and model.iterations == sol.iterations
+        assert np.max(np.abs(model.getsolution() - sol.x)) <= 1e-9 * max(1.0, np.max(np.abs(sol.x)))
+
+
 def test_direct_beyond_the_dense_size_is_the_same_projection_by_cg(pkg, monkeypatch):
     """l > 46 000 (here forced: FOS_DIRECT_DENSE_MAX = 10): direct = true keeps its meaning -- the EXACT projection onto {Q u = v} from the
     first call on -- computed by the warm-started CG at its tolerance floor instead of the 0.2^sqrt(i) schedule.  Against the oracle's
     IndAffineDirect from the FIRST call (the scheduled CG is five orders of magnitude off there), and on C3 itself (l = 70 001)."""
     monkeypatch.setenv("FOS_DIRECT_DENSE_MAX", "10")
+    monkeypatch.setenv("FOS_DIRECT_MODE", "dense")         # (small_mixed is block separable: the block form would be taken first)
     prob = pkg.workloads.small_mixed()
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     d.enable_direct(prob.A)
@@ -119,9 +226,11 @@ def test_direct_beyond_the_dense_size_is_the_same_projection_by_cg(pkg, monkeypa
         assert np.linalg.norm(d.get_iterate() - xo) <= 1e-8 * max(1.0, np.linalg.norm(xo)), i
     d.close()
     monkeypatch.delenv("FOS_DIRECT_DENSE_MAX")
+    monkeypatch.delenv("FOS_DIRECT_MODE")
     prob = pkg.workloads.c3_socp()                        # l = 70 001: a dense 39 GB inverse is past the limit -> CG at the floor
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     d.enable_direct(prob.A)
+    assert d.direct_mode() == "cg"                        # (random sparse columns couple everything: no block form either)
     x = np.random.default_rng(1).standard_normal(d.N)
     y = d.prox_affine(x)
     l = d.l

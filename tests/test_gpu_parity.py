@@ -536,17 +536,19 @@ def test_first_iterations_match_oracle(pkg, algname):
 @pytest.mark.parametrize("algname", ["FISTA", "Dykstra", "GAPA"])
 def test_algorithm_state_hand_over_mid_solve(pkg, algname):
     """fos_get_alg_state / fos_set_alg_state (FISTAData y, xold, t -- fista.jl:15-25; DykstraData p, q -- dykstra.jl:12-23; GAPAData.alpha12):
-    a run handed over mid-solve goes on exactly as the run that was never interrupted -- device -> oracle (the oracle's next step
-    from the device's state equals the device's next step), oracle -> device, and device -> a second device handle (bit for bit)."""
+    a run handed over mid-solve goes on exactly as the run that was never interrupted -- device -> oracle (the oracle's next steps
+    from the device's state equal the device's), oracle -> device, and device -> a second device handle.  With direct = true, so that no
+    loosely converged CG sits in the loop: at iteration 30 its tolerance is 1e-4 and a 1e-13 difference (a cold against a warm PSD
+    projection) grows to 1e-5 within three steps -- measured on this very test before it ran in direct mode."""
     prob = pkg.workloads.small_mixed()
-    mk = {"FISTA": lambda M: M.FISTA(), "Dykstra": lambda M: M.Dykstra(), "GAPA": lambda M: M.GAPA(0.8, 0.5)}[algname]
+    mk = {"FISTA": lambda M: M.FISTA(direct=True), "Dykstra": lambda M: M.Dykstra(direct=True), "GAPA": lambda M: M.GAPA(0.8, 0.5, direct=True)}[algname]
     BIG, warm = 10 ** 9, 30
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d.enable_direct(prob.A)
     d.set_alg(mk(pkg))
     d.set_iterate(None)
     d.step(1, warm, BIG, 1e-5)
     z = d.get_iterate()
-    xinit, pi, _ = d.get_affine_state()
     a, b, t, a12 = d.get_alg_state()
     if algname == "FISTA":
         assert t > 1.0 and np.linalg.norm(a) > 0 and np.linalg.norm(b) > 0
@@ -554,36 +556,42 @@ def test_algorithm_state_hand_over_mid_solve(pkg, algname):
     mo = omodel(prob)
     alg = mk(orc)
     alg.init(mo)
-    alg.S1.cgdata.xinit[:] = xinit
-    alg.S1.cgdata.firstrun = False
-    alg.S1.i = pi
     if algname == "FISTA":
         alg.y[:], alg.xold[:], alg.t = a, b, t
     elif algname == "Dykstra":
         alg.p[:], alg.q[:] = a, b
     else:
         alg.alpha12 = a12
-    st = orc.HSDEStatus(mo, BIG, 1e-5, 0, 0)
+    st = orc.HSDEStatus(mo, BIG, 1e-5, 0, 0, S1=alg.S1)
     xo = z.copy()
     for i in range(warm + 1, warm + 4):
         st.i = i
         alg.step(xo, i, st)
     # device -> a second handle
     d2 = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d2.enable_direct(prob.A)
     d2.set_alg(mk(pkg))
     d2.set_iterate(z)
-    d2.set_affine_state(xinit, pi)
     d2.set_alg_state(a, b, t, a12)
     d2.step(warm + 1, 3, BIG, 1e-5)
     d.step(warm + 1, 3, BIG, 1e-5)
     zg, zg2 = d.get_iterate(), d2.get_iterate()
-    assert np.array_equal(zg, zg2)                              # the resumed handle repeats the uninterrupted one bit for bit
-    tol = 1e-8 if algname != "GAPA" else 1e-6                   # (three steps of CG at tolerance 0.2^sqrt(i): the envelope of test_first_iterations_match_oracle)
+    # the resumed handle repeats the uninterrupted one -- to rounding: the warm-start bases of the PSD kernels are not part of the hand-over
+    tol = 1e-10 if algname != "GAPA" else 1e-7                  # (GAPA's step-length estimate amplifies rounding: tests/test_gpu_longstep.py)
+    assert relerr(zg, zg2) < tol, relerr(zg, zg2)
     assert relerr(zg, xo) < tol, relerr(zg, xo)
-    assert np.linalg.norm(zg - z) > 1e3 * tol * max(1.0, np.linalg.norm(z))
+    assert np.linalg.norm(zg - z) > 1e4 * tol * max(1.0, np.linalg.norm(z))     # (the steps moved the iterate: the comparison is not vacuous)
+    # without the hand-over the resumed run is a different run
+    d3 = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    d3.enable_direct(prob.A)
+    d3.set_alg(mk(pkg))
+    d3.set_iterate(z)
+    d3.step(warm + 1, 3, BIG, 1e-5)
+    if algname != "GAPA":
+        assert relerr(d3.get_iterate(), zg) > 1e3 * tol
+    d3.close()
     # oracle -> device: the oracle's state after those three steps installed on the second handle, one more step on both
     d2.set_iterate(xo)
-    d2.set_affine_state(alg.S1.cgdata.xinit, alg.S1.i)
     if algname == "FISTA":
         d2.set_alg_state(alg.y, alg.xold, alg.t, None)
     elif algname == "Dykstra":

@@ -53,7 +53,7 @@ def _alg(pkg, name):
     return {"DR": pkg.DR, "GAPA": pkg.GAPA, "FISTA": pkg.FISTA}[name]()
 
 
-def _worker(rank, world, kind, algname, q_out, q_in):
+def _worker(rank, world, kind, algname, q_out, q_in, transport="ipc"):
     """One rank.  The parent relays the 64-byte handles and acts as the barrier (plain multiprocessing queues: no
     torch.distributed, no sockets)."""
     sys.path.insert(0, str(ROOT))
@@ -63,9 +63,14 @@ def _worker(rank, world, kind, algname, q_out, q_in):
         prob = _problem(pkg, kind)
         lp = pkg.sharding.shard_problem(prob, world, rank).problem
         dev = pkg.HipHSDE(lp.A, lp.b, lp.c, lp.K1, lp.K2)
-        q_out.put((rank, "handle", dev.peer_export()))
-        handles = q_in.get(timeout=120)
-        dev.peer_open(world, rank, handles, timeout_s=10.0)
+        if transport.startswith("/"):                           # host-pinned mailboxes: one shm segment of that name (fos_peer_open_host)
+            q_out.put((rank, "handle", b""))
+            q_in.get(timeout=120)
+            dev.peer_open_host(world, rank, transport, timeout_s=10.0)
+        else:
+            q_out.put((rank, "handle", dev.peer_export()))
+            handles = q_in.get(timeout=120)
+            dev.peer_open(world, rank, handles, timeout_s=10.0)
         q_out.put((rank, "opened", None))
         q_in.get(timeout=120)                                   # barrier: every rank has mapped every mailbox
         q_out.put((rank, "selftest", dev.peer_selftest(48)))
@@ -91,13 +96,16 @@ def _worker(rank, world, kind, algname, q_out, q_in):
         q_out.put((rank, "error", repr(exc)))
 
 
-def _run(kind, algname):
+def _run(kind, algname, transport="ipc"):
     import multiprocessing as mp
+    import os
     ctx = mp.get_context("spawn")
     world = 2
+    if transport == "host":
+        transport = "/foship-test-%d" % os.getpid()
     q_out = ctx.Queue()
     q_in = [ctx.Queue() for _ in range(world)]
-    procs = [ctx.Process(target=_worker, args=(r, world, kind, algname, q_out, q_in[r])) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, kind, algname, q_out, q_in[r], transport)) for r in range(world)]
     for p in procs:
         p.start()
 
@@ -134,10 +142,13 @@ def _run(kind, algname):
                 p.kill()
 
 
-@pytest.mark.parametrize("kind,algname", [("sdp", "DR"), ("sdp-tiles", "DR"), ("mixed", "GAPA"), ("mixed", "FISTA"), ("rand-1", "DR"), ("rand-2", "GAPA"), ("rand-3", "FISTA")])
-def test_two_ranks_one_gpu_match_unsharded(pkg, oracle, kind, algname):
+@pytest.mark.parametrize("kind,algname,transport", [("sdp", "DR", "ipc"), ("sdp-tiles", "DR", "ipc"), ("mixed", "GAPA", "ipc"), ("mixed", "FISTA", "ipc"),
+                                                    ("rand-1", "DR", "ipc"), ("rand-2", "GAPA", "ipc"), ("rand-3", "FISTA", "ipc"),
+                                                    ("sdp-tiles", "DR", "host"), ("mixed", "GAPA", "host"), ("rand-3", "FISTA", "host")])
+def test_two_ranks_one_gpu_match_unsharded(pkg, oracle, kind, algname, transport):
+    """transport: `ipc` = mailboxes in device memory mapped through HIP IPC; `host` = one pinned host segment (fos_peer_open_host)."""
     orc = oracle
-    got = _run(kind, algname)
+    got = _run(kind, algname, transport)
     prob = _problem(pkg, kind)
     shards = [pkg.sharding.shard_problem(prob, 2, r) for r in range(2)]
     # both ranks saw the same scalars: identical CG counts, alpha12 history, tau/kappa entries, status values
