@@ -449,6 +449,28 @@ def test_psd_refinement_path(pkg, dev_ops, monkeypatch):
     err, st = project([1e6 * B for B in base])
     err, st = project([1e6 * (B + 1e-4 * D) for B, D in zip(base, drift)])
     assert err <= 5e-13 and (st >= 100).all(), (err, st)
+    # (7) stress of the rotation path: MANY near-coincident and crossing pairs at once (ten per matrix, gaps 1e-8 ... 1e-6, coupled by the change at
+    #     1e-6 ... 1e-5, some gaps changing sign from call to call) over a sequence of calls -- up to the rotation budget and beyond it (then the
+    #     matrix is handed to the Jacobi code): pairs that are still flagged after the rotations of an iteration are left to the next one, and whatever
+    #     mixture of paths a call takes, the projection is LAPACK's to 5e-13
+    lam0 = np.linspace(-1.0, 1.0, k)
+    pairs = [(2 + 6 * q, 3 + 6 * q) for q in range(10)]
+    saw_rot = saw_jacobi = False
+    for t in range(8):
+        mats = []
+        for c_ in range(ncone):
+            lam = lam0.copy()
+            Cc = np.zeros((k, k))
+            for q, (i, j) in enumerate(pairs):
+                gap = (10.0 ** rng.uniform(-8, -6)) * (1 if (t + q + c_) % 3 else -1)      # crossings between calls
+                lam[j] = lam[i] + gap
+                Cc[i, j] = Cc[j, i] = 10.0 ** rng.uniform(-6, -5)
+            mats.append(Q @ (np.diag(lam) + Cc) @ Q.T + 1e-6 * t * drift[c_])
+        err, st = project(mats)
+        assert err <= 5e-13, (t, err, st)
+        saw_rot |= bool(((st >= 100) & ((st - 100) // 16 >= 1)).any())
+        saw_jacobi |= bool((st < 100).any())
+    assert saw_rot or saw_jacobi, "the stress sequence took neither the rotation path nor the Jacobi fallback"
     d.psd_debug(False, 0)
 
 
