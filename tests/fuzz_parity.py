@@ -292,13 +292,28 @@ def one_feas_seed(pkg, seed):
     return tag, fails
 
 
-def one_direct_seed(pkg, seed):
+def one_direct_seed(pkg, seed, blocky=False):
     """The HSDE form with direct = true (the exact S1 projection: no CG noise, iterates comparable to rounding): a random small conic program over every cone
-    kind on both sides, a random algorithm with random parameters, optionally wrapped; 20 iterations of the device step against the oracle's."""
-    rng = np.random.default_rng([seed, 313])
+    kind on both sides, a random algorithm with random parameters, optionally wrapped; 20 iterations of the device step against the oracle's.
+    blocky: A is block diagonal under random row and column permutations (2 ... 9 blocks of 1 ... 64 columns, some of them empty columns) -- the device takes the
+    BLOCK form of the projection (three sweeps, fos_enable_direct), the oracle its dense Cholesky."""
+    rng = np.random.default_rng([seed, 313 + (1000 if blocky else 0)])
     m, n = int(rng.integers(1, 90)), int(rng.integers(1, 90))
     density = float(rng.choice([0.05, 0.2, 0.6, 1.0]))
-    A = sp.csc_matrix(rng.standard_normal((m, n))) if density == 1.0 else sp.random(m, n, density=density, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    if blocky:
+        blocks = []
+        for _ in range(int(rng.integers(2, 10))):
+            sb = int(rng.choice([1, 1, 2, 5, 17, 32, 33, 64]))
+            mb = int(rng.integers(0 if sb == 1 else 1, 3 * sb + 4))
+            blocks.append(sp.random(mb, sb, density=float(rng.choice([0.2, 0.6, 1.0])), format="csc", random_state=rng, data_rvs=rng.standard_normal))
+        A = sp.block_diag(blocks, format="csc")
+        m, n = A.shape
+        if m == 0:
+            A = sp.vstack([A, sp.csc_matrix((1, n))]).tocsc()
+            m = 1
+        A = A[rng.permutation(m)][:, rng.permutation(n)].tocsc()
+    else:
+        A = sp.csc_matrix(rng.standard_normal((m, n))) if density == 1.0 else sp.random(m, n, density=density, format="csc", random_state=rng, data_rvs=rng.standard_normal)
     A.sort_indices()
     K1, K2 = random_cones(rng, m, 1), random_cones(rng, n, 2)
     algname = str(rng.choice(["DR", "AP", "GAP", "GAPA", "FISTA", "Dykstra"]))
@@ -356,6 +371,8 @@ def one_direct_seed(pkg, seed):
         d = pkg.HipHSDE(A, b, c, K1, K2)
         try:
             d.enable_direct(A)
+            if blocky and d.direct_mode() != "block":
+                fails.append("block-separable operator took the %s form" % d.direct_mode())
             d.set_alg(mk(pkg))
             d.set_iterate(None)
             tol = 1e-9 if wrap == "none" and algname != "GAPA" else (1e-6 if wrap == "long" or algname == "GAPA" else 1e-8)
@@ -477,7 +494,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", default="0:100")
     ap.add_argument("--solve-every", type=int, default=4)
-    ap.add_argument("--form", default="hsde", choices=["hsde", "feas", "direct", "big"])
+    ap.add_argument("--form", default="hsde", choices=["hsde", "feas", "direct", "blockdirect", "big"])
     ap.add_argument("--budget", type=float, default=0.0, help="stop starting new seeds after this many seconds")
     args = ap.parse_args()
     import __graft_entry__ as ge
@@ -493,6 +510,8 @@ def main():
             tag, fails = one_feas_seed(pkg, seed)
         elif args.form == "direct":
             tag, fails = one_direct_seed(pkg, seed)
+        elif args.form == "blockdirect":
+            tag, fails = one_direct_seed(pkg, seed, blocky=True)
         elif args.form == "big":
             tag, fails = one_big_seed(pkg, seed)
             print("ok  " if not fails else "bad ", tag, flush=True)

@@ -36,3 +36,13 @@ def test_hsde_direct_iterates_slice(pkg):
         if fails:
             bad.append((tag, fails))
     assert not bad, bad
+
+
+def test_hsde_block_direct_iterates_slice(pkg):
+    """direct = true on randomly permuted block-diagonal operators: the device's block form (three sweeps) against the oracle's dense Cholesky, 20 iterates each."""
+    bad = []
+    for seed in range(0, 100):
+        tag, fails = fuzz_parity.one_direct_seed(pkg, seed, blocky=True)
+        if fails:
+            bad.append((tag, fails))
+    assert not bad, bad
