@@ -355,7 +355,7 @@ struct LaunchCtx {
 
 // KKT apply, 2 RHS interleaved:  out = [I Q'; Q -I] * w   (rows 0..n+m-1; the tau row is written by kkt_finalize).
 // Stand-alone form: sweep (+ deferred-row kernel for operators with dual tiles); partial sums: c.S.npart records at c.S.part_off
-void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate);
+void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate, bool finish_deferred = true);
 // finishes the tau rows of out = M w from the sweep's partial sums (CG init / test entry)
 void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int gate, int from_reduced);
 
@@ -474,10 +474,9 @@ void launch_direct_finish(const LaunchCtx& c, const double2* x, const double2* W
 constexpr int BLKDIR_MAX = 64;
 void launch_blkdir_prep(const LaunchCtx& c, const double2* T, const double2* phg, double2* W2, double2* W3, double* partials);
 void launch_blkdir_solve(const LaunchCtx& c, int nblk, const int64_t* goff, const int32_t* ioff, const int32_t* idx, const double* Ginv, const double2* R,
-                         const double2* T, double2* W3);
-void launch_blkdir_kappa(const LaunchCtx& c, const double* partials, const double2* T, const double* prm, int zero);
+                         const double2* T, double2* W3, double* ctx_rec);
 void launch_blkdir_combine(const LaunchCtx& c, const double2* T, const double2* W3, const double2* V, const double2* phg, const double2* qphg,
-                           const double* prm, double2* out, double* partials);
+                           const double* prm, int zero_kappa, double2* out, const double* prep_partials, double* partials, const double* ctx_rec, int nblk);
 
 // layout conversion at the ABI boundary
 void launch_interleave(const LaunchCtx& c, double2* out, const double* plain);    // plain [part1(l); part2(l)] -> interleaved

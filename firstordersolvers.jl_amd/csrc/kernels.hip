@@ -1299,14 +1299,15 @@ static void launch_plain_sweep(const LaunchCtx& c, const KktArgs& a, bool fold) 
     }
 }
 // stand-alone apply: sweep (+ deferred-row kernel when the operator has dual tiles); leaves c.S.npart records at c.S.part_off
-void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate) {
+void launch_kkt2(const LaunchCtx& c, const double2* w, double2* out, int gate, bool finish_deferred) {
     const KktArgs a = plain_args(c, w, out, gate);
-    if (c.S.ndef > 0) {
+    if (c.S.ndef > 0 && finish_deferred) {
         launch_plain_sweep(c, a, false);
         if (c.between) (void)c.between(c.between_arg);        // row-sharded: the slots are summed over the ranks here
         hipLaunchKernelGGL(kkt2_deferred_kernel, dim3(c.S.nwg_def), dim3(DEF_THREADS), 0, c.stream, c.S, w, out, c.cb, (int)c.n,
                            (int)(c.n + c.m), c.partials, c.st, gate, (int)c.count_repl);
     } else {
+        // (finish_deferred = false: the caller needs only rows the sweep finishes itself -- the slot-spread rows of `out` stay unwritten)
         launch_plain_sweep(c, a, false);
     }
 }

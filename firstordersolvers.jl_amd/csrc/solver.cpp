@@ -192,6 +192,8 @@ struct fos_solver {
     double* blk_ginv = nullptr;
     d2 *blk_phg = nullptr, *blk_qphg = nullptr;   // (D^-1 h, D^-1 M h) and their images under Q, per row
     double* blk_prm = nullptr;                 // the 3 x 3 inverse of the border system (9), delta = 1 + |[c; b]|^2
+    double* blk_ctx = nullptr;                 // [blk_n] the blocks' shares of c'x^ (blkdir_solve_kernel)
+    bool blk_skip_tail = true;                 // the third apply runs without its deferred-row and tau-row kernels (FOS_BLKDIR_FULL_APPLY=1: with them)
 
     // S1 = AffinePlusLinear state (affinepluslinear.jl:58-69)
     int64_t prox_i = 1;
@@ -464,8 +466,11 @@ int global_setup(fos_solver* h) {
 }
 
 // out = [I Q'; Q -I] w, all l rows (sweep + tau-row finalize)
-int kkt_apply_full(fos_solver* h, const LaunchCtx& c, const d2* w, d2* out) {
-    launch_kkt2(c, w, out, 0);
+// deferred = false: the slot-spread rows of `out` (rows of A' under dual tiles) are not finished; tau_row = false: nor is the tau row -- for callers that
+// need neither (the block-direct projection: single-GPU handles only)
+int kkt_apply_full(fos_solver* h, const LaunchCtx& c, const d2* w, d2* out, bool deferred = true, bool tau_row = true) {
+    launch_kkt2(c, w, out, 0, deferred || tau_row);          // (the tau-row kernel reads the records the deferred-row kernel leaves)
+    if (!tau_row) return FOS_OK;
     int fr = 0;
     FOS_TRY(finish_reduce(h, c, c.S.npart, 3, 0, &fr, c.S.part_off));
     launch_kkt_finalize(c, w, out, 0, fr);
@@ -673,19 +678,19 @@ int prox_affine_direct_block(fos_solver* h, const d2* x, d2* out, bool from_T = 
     if (!from_T) { pe = prof_begin(h, FOS_PROF_KKT, 1, h->direct_sweeps++); FOS_TRY(kkt_apply_full(h, c, x, T)); prof_end(h, pe); }      // T.x = u - Q v = g
     int po = prof_begin_other(h, 0);
     launch_blkdir_prep(cb, T, h->blk_phg, W2, W3, p1);
-    launch_blkdir_kappa(cb, p1, T, h->blk_prm, zero_kappa ? 1 : 0);
     prof_end(h, po);
     pe = prof_begin(h, FOS_PROF_KKT, 1, h->direct_sweeps++);
-    FOS_TRY(kkt_apply_full(h, c, W2, Rr));                             // Rr.x = -Q (0, g2, 0): its x part is -A' g2
+    FOS_TRY(kkt_apply_full(h, c, W2, Rr, true, false));                // Rr.x = -Q (0, g2, 0): its x part is -A' g2 (rows of A': the deferred rows; the tau row is not needed)
     prof_end(h, pe);
     po = prof_begin_other(h, 0);
-    launch_blkdir_solve(cb, h->blk_n, h->blk_goff, h->blk_ioff, h->blk_idx, h->blk_ginv, Rr, T, W3);
+    launch_blkdir_solve(cb, h->blk_n, h->blk_goff, h->blk_ioff, h->blk_idx, h->blk_ginv, Rr, T, W3, h->blk_ctx);
     prof_end(h, po);
     pe = prof_begin(h, FOS_PROF_KKT, 1, h->direct_sweeps++);
-    FOS_TRY(kkt_apply_full(h, c, W3, V));                              // V.y = -A q, V.x = A x^ on the rows of A; V.x[tau] = c'x^
+    // V.y = -A q, V.x = A x^ on the rows of A -- rows the sweep finishes itself; with dual tiles neither the rows of A' nor the tau row (c'x^: the solve kernel's records) are needed
+    FOS_TRY(kkt_apply_full(h, c, W3, V, !h->blk_skip_tail, !h->blk_skip_tail));
     prof_end(h, pe);
     po = prof_begin_other(h, 0);
-    launch_blkdir_combine(cb, T, W3, V, h->blk_phg, h->blk_qphg, h->blk_prm, out, p2);
+    launch_blkdir_combine(cb, T, W3, V, h->blk_phg, h->blk_qphg, h->blk_prm, zero_kappa ? 1 : 0, out, p1, p2, h->blk_ctx, h->blk_n);
     prof_end(h, po);
     h->cgiter = 0;
     return check_launch("block-direct affine projection");
@@ -1405,6 +1410,10 @@ int blkdir_setup(fos_solver* h, const int64_t* colptr, const int64_t* rowval, co
     FOS_TRY(dev_alloc(h, &h->blk_phg, (size_t)l));
     FOS_TRY(dev_alloc(h, &h->blk_qphg, (size_t)l));
     FOS_TRY(dev_alloc(h, &h->blk_prm, 16));
+    FOS_TRY(dev_alloc(h, &h->blk_ctx, (size_t)nblk));
+    // (rows of A that the sweep does not finish itself -- rows wider than one tile chunk are slot-spread too -- need the deferred-row kernel behind the third apply)
+    h->blk_skip_tail = !(getenv("FOS_BLKDIR_FULL_APPLY") && atoi(getenv("FOS_BLKDIR_FULL_APPLY")) != 0);
+    for (int32_t r : h->hostS.def_rows) if (r >= n) { h->blk_skip_tail = false; break; }
     FOS_HIP(hipMemset(h->blk_phg, 0, sizeof(d2) * (size_t)l));
     FOS_HIP(hipMemset(h->blk_qphg, 0, sizeof(d2) * (size_t)l));
     // ---- the border: h = [c; b], M h = [A'b; -A c], ph = D^-1 (h; 0), pg = D^-1 (M h; 0) by two runs of the device path without the border terms

@@ -1191,39 +1191,49 @@ __global__ __launch_bounds__(VEC_THREADS) void blkdir_prep_kernel(int64_t l, int
     block_reduce_store<2>(acc, partials + 2 * (int64_t)blockIdx.x);
 }
 // (2) one wavefront per diagonal block of I + A'A (order s <= 64, explicit inverse, column-major): (q, x^) = Ginv (a, g1) with a = A' g2 = -R.x and
-//     g1 = T.x on the block's columns; W3 = (q, x^) there -- the two vectors the third sweep applies A to
+//     g1 = T.x on the block's columns; W3 = (q, x^) there -- the two vectors the third sweep applies A to; ctx_rec[b] = the block's share of c'x^
+//     (the tau row of the third apply is then never needed: no tau-row kernel, no deferred-row kernel behind that sweep)
 __global__ __launch_bounds__(64) void blkdir_solve_kernel(const int64_t* __restrict__ goff, const int32_t* __restrict__ ioff, const int32_t* __restrict__ idx,
-                                                          const double* __restrict__ Ginv, const d2* __restrict__ R, const d2* __restrict__ T, d2* __restrict__ W3) {
+                                                          const double* __restrict__ Ginv, const d2* __restrict__ R, const d2* __restrict__ T, d2* __restrict__ W3,
+                                                          const double* __restrict__ cb, double* __restrict__ ctx_rec) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int i0 = ioff[b], s = ioff[b + 1] - i0;
     __shared__ double ra[64], rg[64];
     int col = -1;
     if (lane < s) { col = idx[i0 + lane]; ra[lane] = -R[col].x; rg[lane] = T[col].x; }
     __syncthreads();
+    double cx = 0.0;
     if (lane < s) {
         const double* __restrict__ G = Ginv + goff[b] + lane;
         double q = 0.0, xh = 0.0;
         for (int j = 0; j < s; ++j) { const double gij = G[(size_t)j * s]; q += gij * ra[j]; xh += gij * rg[j]; }
         W3[col] = make_double2(q, xh);
+        cx = cb[col] * xh;
     }
+    cx = wave_sum(cx);
+    if (lane == 0) ctx_rec[b] = cx;
 }
-// (3) one workgroup: kappa = S3inv [ph.g, pg.g, g_tau / delta] (the multipliers of the three border columns) -> reduced[0..2]; prm = S3inv (9), delta
-__global__ __launch_bounds__(FIN_THREADS) void blkdir_kappa_kernel(const double* __restrict__ partials, int count, const d2* __restrict__ T, int64_t l,
-                                                                   const double* __restrict__ prm, int zero, double* __restrict__ reduced) {
+// kappa = S3inv [ph.g, pg.g, g_tau / delta] (the multipliers of the three border columns) from the prep kernel's records: EVERY workgroup of the kernels
+// that need it adds the same records in the same order (no launch of its own).  prm = S3inv (9), delta
+__device__ __forceinline__ void blkdir_kappa(const double* __restrict__ prep_partials, int count, const d2* __restrict__ T, int64_t l, const double* __restrict__ prm,
+                                             int zero, double* kap /* shared [3] */) {
     __shared__ double sums[2];
-    reduce_partials<2>(partials, count, sums);
+    reduce_partials<2>(prep_partials, count, sums);
     if (threadIdx.x == 0) {
         const double r[3] = {sums[0], sums[1], T[l - 1].x / prm[9]};
-        for (int a = 0; a < 3; ++a) reduced[a] = zero ? 0.0 : prm[3 * a] * r[0] + prm[3 * a + 1] * r[1] + prm[3 * a + 2] * r[2];
+        for (int a = 0; a < 3; ++a) kap[a] = zero ? 0.0 : prm[3 * a] * r[0] + prm[3 * a + 1] * r[1] + prm[3 * a + 2] * r[2];
     }
+    __syncthreads();
 }
-// (4) d = D^-1 g = (x^, g2 - A q, g_tau / delta), Q d = (q + c t^, -A x^ + b t^, .) from the sweeps' results; out = (d - k1 ph - k2 pg, Q d - k1 Qph - k2 Qpg - k3 [c; b] / delta)
+// (3) d = D^-1 g = (x^, g2 - A q, g_tau / delta), Q d = (q + c t^, -A x^ + b t^, .) from the sweeps' results; out = (d - k1 ph - k2 pg, Q d - k1 Qph - k2 Qpg - k3 [c; b] / delta)
 //     for all rows but the tau row; partial sums of b . y^ for that one.  V = M (q, x^): V.y = -A q and V.x = A x^ on the rows of A.
 __global__ __launch_bounds__(VEC_THREADS) void blkdir_combine_kernel(int64_t l, int64_t n, const d2* __restrict__ T, const d2* __restrict__ W3, const d2* __restrict__ V,
                                                                      const d2* __restrict__ phg, const d2* __restrict__ qphg, const double* __restrict__ cb,
-                                                                     const double* __restrict__ prm, const double* __restrict__ reduced, d2* __restrict__ out,
-                                                                     double* __restrict__ partials) {
-    const double k1 = reduced[0], k2 = reduced[1], k3 = reduced[2], delta = prm[9];
+                                                                     const double* __restrict__ prm, int zero, const double* __restrict__ prep_partials, int nprep,
+                                                                     d2* __restrict__ out, double* __restrict__ partials) {
+    __shared__ double kap[3];
+    blkdir_kappa(prep_partials, nprep, T, l, prm, zero, kap);
+    const double k1 = kap[0], k2 = kap[1], k3 = kap[2], delta = prm[9];
     const double th = T[l - 1].x / delta;
     double acc[1] = {0.0};
     GRID_STRIDE(i, l - 1) {
@@ -1236,32 +1246,34 @@ __global__ __launch_bounds__(VEC_THREADS) void blkdir_combine_kernel(int64_t l, 
     }
     block_reduce_store<1>(acc, partials + (int64_t)blockIdx.x);
 }
-// (5) the tau row: u^_tau = g_tau / delta - k3 / delta, (Q u^)_tau = -c'x^ - b'y^ - k1 (Q ph)_tau - k2 (Q pg)_tau   (V.x[tau] = c'x^)
-__global__ __launch_bounds__(FIN_THREADS) void blkdir_tau_kernel(const double* __restrict__ partials, int count, const d2* __restrict__ T, const d2* __restrict__ V,
-                                                                 const d2* __restrict__ qphg, int64_t l, const double* __restrict__ prm,
-                                                                 const double* __restrict__ reduced, d2* __restrict__ out) {
-    __shared__ double sums[1];
+// (4) the tau row: u^_tau = g_tau / delta - k3 / delta, (Q u^)_tau = -c'x^ - b'y^ - k1 (Q ph)_tau - k2 (Q pg)_tau   (c'x^ from the block records)
+__global__ __launch_bounds__(FIN_THREADS) void blkdir_tau_kernel(const double* __restrict__ partials, int count, const double* __restrict__ ctx_rec, int nblk,
+                                                                 const d2* __restrict__ T, const d2* __restrict__ qphg, int64_t l, const double* __restrict__ prm,
+                                                                 int zero, const double* __restrict__ prep_partials, int nprep, d2* __restrict__ out) {
+    __shared__ double kap[3];
+    blkdir_kappa(prep_partials, nprep, T, l, prm, zero, kap);
+    __shared__ double sums[1], sumc[1];
     reduce_partials<1>(partials, count, sums);
+    reduce_partials<1>(ctx_rec, nblk, sumc);
     if (threadIdx.x == 0) {
-        const double k1 = reduced[0], k2 = reduced[1], k3 = reduced[2], delta = prm[9];
+        const double k1 = kap[0], k2 = kap[1], k3 = kap[2], delta = prm[9];
         const d2 qp = qphg[l - 1];
-        out[l - 1] = make_double2(T[l - 1].x / delta - k3 / delta, -V[l - 1].x - sums[0] - k1 * qp.x - k2 * qp.y);
+        out[l - 1] = make_double2(T[l - 1].x / delta - k3 / delta, -sumc[0] - sums[0] - k1 * qp.x - k2 * qp.y);
     }
 }
 void launch_blkdir_prep(const LaunchCtx& c, const double2* T, const double2* phg, double2* W2, double2* W3, double* partials) {
     hipLaunchKernelGGL(blkdir_prep_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, c.n, T, phg, W2, W3, partials);
 }
 void launch_blkdir_solve(const LaunchCtx& c, int nblk, const int64_t* goff, const int32_t* ioff, const int32_t* idx, const double* Ginv, const double2* R,
-                         const double2* T, double2* W3) {
-    if (nblk > 0) hipLaunchKernelGGL(blkdir_solve_kernel, dim3(nblk), dim3(64), 0, c.stream, goff, ioff, idx, Ginv, R, T, W3);
-}
-void launch_blkdir_kappa(const LaunchCtx& c, const double* partials, const double2* T, const double* prm, int zero) {
-    hipLaunchKernelGGL(blkdir_kappa_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, partials, c.vec_blocks, T, c.l, prm, zero, c.reduced);
+                         const double2* T, double2* W3, double* ctx_rec) {
+    if (nblk > 0) hipLaunchKernelGGL(blkdir_solve_kernel, dim3(nblk), dim3(64), 0, c.stream, goff, ioff, idx, Ginv, R, T, W3, c.cb, ctx_rec);
 }
 void launch_blkdir_combine(const LaunchCtx& c, const double2* T, const double2* W3, const double2* V, const double2* phg, const double2* qphg,
-                           const double* prm, double2* out, double* partials) {
-    hipLaunchKernelGGL(blkdir_combine_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, c.n, T, W3, V, phg, qphg, c.cb, prm, c.reduced, out, partials);
-    hipLaunchKernelGGL(blkdir_tau_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, partials, c.vec_blocks, T, V, qphg, c.l, prm, c.reduced, out);
+                           const double* prm, int zero_kappa, double2* out, const double* prep_partials, double* partials, const double* ctx_rec, int nblk) {
+    hipLaunchKernelGGL(blkdir_combine_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, c.n, T, W3, V, phg, qphg, c.cb, prm, zero_kappa, prep_partials,
+                       c.vec_blocks, out, partials);
+    hipLaunchKernelGGL(blkdir_tau_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, partials, c.vec_blocks, ctx_rec, nblk, T, qphg, c.l, prm, zero_kappa, prep_partials,
+                       c.vec_blocks, out);
 }
 
 // ------------------------------------------------------------------------------------------------ layout conversion
