@@ -2072,7 +2072,8 @@ int fos_peer_open_host(fos_handle h, int nranks, int rank, const char* shm_name,
     if (h->row_sharded) { set_error("host-pinned mailboxes carry the scalar sums of cone-sharded handles only"); return FOS_EUNSUPPORTED; }
     if (h->comm && (h->nranks != nranks || h->rank != rank)) { set_error("peer ranks differ from the RCCL communicator's"); return FOS_EINVAL; }
     FOS_HIP(hipSetDevice(h->device));
-    const size_t bytes = ((PEER_BOX_TOTAL_WORDS * sizeof(unsigned long long) + 4095) / 4096) * 4096;
+    // (one more page behind the mailbox words: every rank's device identity, so that ranks which share a device can find out -- fos_peer_selftest)
+    const size_t bytes = ((PEER_BOX_TOTAL_WORDS * sizeof(unsigned long long) + 4095) / 4096) * 4096 + 4096;
     // every rank creates-or-opens and sizes the segment (idempotent; a fresh segment is zero filled: sequence number 0 is never sent)
     const int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
     if (fd < 0) { set_error("shm_open(%s): %s", shm_name, strerror(errno)); return FOS_ECOMM; }
@@ -2092,6 +2093,14 @@ int fos_peer_open_host(fos_handle h, int nranks, int rank, const char* shm_name,
         return FOS_ECOMM;
     }
     h->host_seg = seg; h->host_seg_bytes = bytes; h->host_seg_name = shm_name;
+    {
+        char bus[64] = {0};
+        unsigned long long id = 0x9E3779B97F4A7C15ull;
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), h->device) == hipSuccess) { for (const char* q = bus; *q; ++q) id = (id ^ (unsigned char)*q) * 0x100000001B3ull; }
+        else { (void)hipGetLastError(); id ^= (unsigned long long)(h->device + 1); }
+        volatile unsigned long long* ids = reinterpret_cast<volatile unsigned long long*>(static_cast<char*>(seg) + bytes - 4096);
+        ids[rank] = id | 1ull;                                  // (never zero: a zero entry = that rank has not opened the segment yet)
+    }
     if (!h->peer_relay) {
         void* q = nullptr;
         const size_t rb = PEER_BOX_TOTAL_WORDS * sizeof(unsigned long long);
@@ -2152,6 +2161,14 @@ int fos_peer_selftest(fos_handle h, int rounds, int32_t* ok) {
     if (!h || !ok) { set_error("NULL argument"); return FOS_EINVAL; }
     if (!h->peer.box) { set_error("fos_peer_selftest before fos_peer_open"); return FOS_EINVAL; }
     FOS_HIP(hipSetDevice(h->device));
+    if (h->host_seg) {
+        // host-pinned mailboxes: do ranks share THIS device (tests: several ranks on one GPU)?  Every rank left its device's identity behind the
+        // mailbox words when it opened the segment, and the caller's barrier stands between the opens and this call.  A shared device keeps the
+        // PSD refinement kernel to small batches (it needs whole CUs, which a peer's spinning CG kernel may hold: DESIGN 3)
+        const volatile unsigned long long* ids = reinterpret_cast<const volatile unsigned long long*>(static_cast<const char*>(h->host_seg) + h->host_seg_bytes - 4096);
+        for (int r = 0; r < h->peer.nranks; ++r)
+            if (r != h->peer.rank && ids[r] != 0ull && ids[r] == ids[h->peer.rank]) h->peer_same_device = true;
+    }
     const bool was_on = h->peer_on;
     h->peer_on = true;
     LaunchCtx c = h->ctx();
