@@ -282,6 +282,8 @@ def main():
                 if agree(ok):
                     ok, why2 = selftest_and_enable()
                     why = why or why2
+                else:
+                    ok = False                                # (a rank whose own steps succeeded must not go on alone)
                 return ok, why
 
             def try_host():
@@ -300,6 +302,8 @@ def main():
                 if agree(ok):
                     ok, why2 = selftest_and_enable()
                     why = why or why2
+                else:
+                    ok = False
                 return ok, why
 
             chosen = None
