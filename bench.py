@@ -254,7 +254,8 @@ def main():
                 # first contact between DIFFERENT devices: can this device map its peers' memory at all?  (the IPC mapping below can
                 # succeed where loads and stores over the link do not)  Asked of the runtime, not assumed; a "no" names the pair.
                 why = None
-                if os.environ.get("FOS_BENCH_INJECT") == "peer_open_fail":          # tests only
+                inj_open = os.environ.get("FOS_BENCH_INJECT", "")
+                if inj_open == "peer_open_fail" or (inj_open == "peer_open_fail_rank1" and rank == 1):          # tests only
                     why = "injected: no peer access"
                 try:
                     if not host_gloo and why is None:
