@@ -275,6 +275,8 @@ def main():
                 ok = all(h is not None for h in handles)
                 if ok:
                     try:
+                        if inj_open == "peer_map_fail_rank1" and rank == 1:          # tests only: the mapping fails on ONE rank
+                            raise RuntimeError("injected: IPC mapping failed")
                         dev.peer_open(world, rank, handles, timeout_s=20.0)
                         dev.sync()
                     except Exception as exc:                  # IPC mapping not available between these devices

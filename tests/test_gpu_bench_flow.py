@@ -131,15 +131,17 @@ def test_bench_ranks_on_one_gpu(nranks, transport):
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("foship-")]            # rank 0 unlinked the segment
 
 
-def test_one_rank_without_peer_access_takes_every_rank_to_the_host_segment():
-    """The transports are chosen COLLECTIVELY: when ONE rank cannot open the device mailboxes (injected on rank 1 of two), both ranks pass them over
-    and meet on the host-pinned ones -- a rank whose own steps succeeded does not go on alone (it would wait for its peer's words until the time-out)."""
+@pytest.mark.parametrize("inject,reason", [("peer_open_fail_rank1", "injected: no peer access"), ("peer_map_fail_rank1", "injected: IPC mapping failed")])
+def test_one_rank_without_peer_access_takes_every_rank_to_the_host_segment(inject, reason):
+    """The transports are chosen COLLECTIVELY: when ONE rank cannot use the device mailboxes (injected on rank 1 of two: at the peer-access query, or at the
+    IPC mapping -- where rank 0's own mapping SUCCEEDS), both ranks pass them over and meet on the host-pinned ones -- a rank whose own steps succeeded does not
+    go on alone (it would wait for its peer's words until the time-out)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(FOS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", FOS_BENCH_INJECT="peer_open_fail_rank1")
+    env.update(FOS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", FOS_BENCH_INJECT=inject)
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--small", "--no-weak-extra"]
     r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = _last_json(r.stdout)
     assert "host-pinned mailboxes" in out["config"]["parallelism"] and out["value"] > 0
     why = out["config"]["peer_fallback_reason"]
-    assert "rank 1: injected: no peer access" in why and "rank 0:" not in why
+    assert ("rank 1: open: " + reason if "map" in inject else "rank 1: " + reason) in why and "rank 0:" not in why
