@@ -25,10 +25,17 @@ def _last_json(text):
     raise AssertionError("no JSON line in:\n" + text[-2000:])
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_bench_two_ranks_on_one_gpu_matches_single_rank():
     env = dict(os.environ, FOS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-            "--master-port", "29541", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--small"]
+            "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--small"]
     r2 = subprocess.run(cmd2, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, r2.stdout[-3000:] + r2.stderr[-3000:]
     out2 = _last_json(r2.stdout)
