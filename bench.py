@@ -277,7 +277,7 @@ def main():
                     try:
                         if inj_open == "peer_map_fail_rank1" and rank == 1:          # tests only: the mapping fails on ONE rank
                             raise RuntimeError("injected: IPC mapping failed")
-                        dev.peer_open(world, rank, handles, timeout_s=20.0)
+                        dev.peer_open(world, rank, handles, timeout_s=60.0)
                         dev.sync()
                     except Exception as exc:                  # IPC mapping not available between these devices
                         print("rank %d: peer mailboxes unavailable (%s)" % (rank, exc), file=sys.stderr, flush=True)
@@ -296,7 +296,7 @@ def main():
                 dist.broadcast_object_list(name, src=0)
                 why = None
                 try:
-                    dev.peer_open_host(world, rank, name[0], timeout_s=20.0)
+                    dev.peer_open_host(world, rank, name[0], timeout_s=60.0)
                     dev.sync()
                     ok = True
                 except Exception as exc:                      # no shm / the runtime cannot register it
