@@ -476,7 +476,10 @@ void launch_blkdir_prep(const LaunchCtx& c, const double2* T, const double2* phg
 void launch_blkdir_solve(const LaunchCtx& c, int nblk, const int64_t* goff, const int32_t* ioff, const int32_t* idx, const double* Ginv, const double2* R,
                          const double2* T, double2* W3, double* ctx_rec);
 void launch_blkdir_combine(const LaunchCtx& c, const double2* T, const double2* W3, const double2* V, const double2* phg, const double2* qphg,
-                           const double* prm, int zero_kappa, double2* out, const double* prep_partials, double* partials, const double* ctx_rec, int nblk);
+                           double* prm, int zero_kappa, double2* out, const double* prep_partials, double* partials, int from_reduced);
+void launch_blkdir_tausum(const LaunchCtx& c, const double* partials, const double* ctx_rec, int nblk, double* out1);
+void launch_blkdir_tau(const LaunchCtx& c, const double2* T, const double2* qphg, const double* prm, int zero_kappa, double2* out, const double* prep_partials,
+                       const double* partials, const double* ctx_rec, int nblk, int from_reduced);
 
 // layout conversion at the ABI boundary
 void launch_interleave(const LaunchCtx& c, double2* out, const double* plain);    // plain [part1(l); part2(l)] -> interleaved

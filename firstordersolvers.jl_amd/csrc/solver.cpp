@@ -668,16 +668,21 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
 int prox_affine_direct_block(fos_solver* h, const d2* x, d2* out, bool from_T = false, bool zero_kappa = false) {
     RoctxRange range("fos:prox_affine_direct_block (3 KKT sweeps + block-diagonal solve)");
     LaunchCtx c = h->ctx();
-    LaunchCtx cb = c;
-    cb.reduced = c.reduced + 8;                                        // kappa: three doubles nobody else writes during the projection
+    const LaunchCtx& cb = c;
     d2 *T = h->R, *W2 = h->PB[0], *Rr = h->AP, *W3 = h->PB[1], *V = h->RHS;
     double* p1 = h->partials + (size_t)4 * PART_CAP;
     double* p2 = h->partials + (size_t)5 * PART_CAP;
+    // Cone-sharded handles: D is block diagonal, so everything above is local to a rank -- except the scalars: the tau row of the first apply (summed over
+    // the ranks by kkt_apply_full), the two dots behind kappa and the tau row of the result (c'x^ + b'y^): three exchanges per projection instead of one per
+    // CG iteration.  The sums go through the handle's transport (reduce kernel with the mailbox exchange inside, or reduce kernel + all-reduce).
+    const bool sh = h->sharded();
+    int fr = 0;
     // (profiling: the three sweeps -- each with the deferred-row kernel and the tau-row finalize of a stand-alone apply -- are the KKT class)
     int pe = -1;
     if (!from_T) { pe = prof_begin(h, FOS_PROF_KKT, 1, h->direct_sweeps++); FOS_TRY(kkt_apply_full(h, c, x, T)); prof_end(h, pe); }      // T.x = u - Q v = g
     int po = prof_begin_other(h, 0);
     launch_blkdir_prep(cb, T, h->blk_phg, W2, W3, p1);
+    if (sh) { LaunchCtx c2 = c; c2.partials = p1; launch_reduce1(c2, c.vec_blocks, 3, 0); FOS_TRY(allreduce(h, 3)); fr = 1; }
     prof_end(h, po);
     pe = prof_begin(h, FOS_PROF_KKT, 1, h->direct_sweeps++);
     FOS_TRY(kkt_apply_full(h, c, W2, Rr, true, false));                // Rr.x = -Q (0, g2, 0): its x part is -A' g2 (rows of A': the deferred rows; the tau row is not needed)
@@ -690,7 +695,15 @@ int prox_affine_direct_block(fos_solver* h, const d2* x, d2* out, bool from_T = 
     FOS_TRY(kkt_apply_full(h, c, W3, V, !h->blk_skip_tail, !h->blk_skip_tail));
     prof_end(h, pe);
     po = prof_begin_other(h, 0);
-    launch_blkdir_combine(cb, T, W3, V, h->blk_phg, h->blk_qphg, h->blk_prm, zero_kappa ? 1 : 0, out, p1, p2, h->blk_ctx, h->blk_n);
+    launch_blkdir_combine(cb, T, W3, V, h->blk_phg, h->blk_qphg, h->blk_prm, zero_kappa ? 1 : 0, out, p1, p2, fr);
+    if (sh) {
+        double* p3 = p1;                                               // (the prep records are spent)
+        launch_blkdir_tausum(cb, p2, h->blk_ctx, h->blk_n, p3);
+        LaunchCtx c3 = c; c3.partials = p3;
+        launch_reduce1(c3, 1, 1, 0);
+        FOS_TRY(allreduce(h, 1));
+    }
+    launch_blkdir_tau(cb, T, h->blk_qphg, h->blk_prm, zero_kappa ? 1 : 0, out, p1, p2, h->blk_ctx, h->blk_n, fr);
     prof_end(h, po);
     h->cgiter = 0;
     return check_launch("block-direct affine projection");
@@ -1282,19 +1295,33 @@ void add_cones(int64_t offset, bool is_K1, int64_t nK, const int32_t* type, cons
 // pattern of A'A); separable = every component has at most BLKDIR_MAX columns.  Per block G_b = I + A_b' A_b is formed on the host (row-wise outer
 // products), inverted through its Cholesky factor and polished by one Newton step in extended precision; ph, pg and the 3 x 3 border system follow
 // from two runs of the device path itself.  *ok = false: not separable (nothing allocated).
+// v[0..2] <- their sums over the ranks of a sharded handle (set-up: through the handle's transport, one host round trip); no-op on one GPU
+int global_sum3(fos_solver* h, double* v) {
+    if (!h->sharded()) return FOS_OK;
+    LaunchCtx c = h->ctx();
+    FOS_HIP(hipMemcpyAsync(h->partials, v, sizeof(double) * 3, hipMemcpyHostToDevice, h->stream));
+    launch_reduce1(c, 1, 3, 0);
+    FOS_TRY(allreduce(h, 3));
+    FOS_HIP(hipMemcpyAsync(v, h->reduced, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
+    return poll_state(h);
+}
+
 int blkdir_setup(fos_solver* h, const int64_t* colptr, const int64_t* rowval, const double* nzval, bool* ok) {
     *ok = false;
     const int64_t n = h->n, m = h->m, l = h->l;
-    if (n < 1 || n > (int64_t)INT32_MAX) return FOS_OK;
+    // (sharded handles: every rank takes part in the vote below, whatever its own operator looks like)
+    bool local_ok = !(n < 1 || n > (int64_t)INT32_MAX);
+    if (!local_ok && !h->sharded()) return FOS_OK;
     std::vector<int32_t> parent((size_t)n);
     for (int64_t j = 0; j < n; ++j) parent[(size_t)j] = (int32_t)j;
     auto find = [&](int32_t a) { while (parent[(size_t)a] != a) { parent[(size_t)a] = parent[(size_t)parent[(size_t)a]]; a = parent[(size_t)a]; } return a; };
+    bool bad_index = false;
     {
         std::vector<int32_t> first((size_t)m, -1);
-        for (int64_t j = 0; j < n; ++j)
+        for (int64_t j = 0; j < n && !bad_index; ++j)
             for (int64_t p = colptr[j] - 1; p < colptr[j + 1] - 1; ++p) {
                 const int64_t r = rowval[p] - 1;
-                if (r < 0 || r >= m) { set_error("fos_enable_direct: row index out of range"); return FOS_EINVAL; }
+                if (r < 0 || r >= m) { bad_index = true; local_ok = false; break; }          // (reported behind the vote: the peers of a sharded handle are waiting in it)
                 if (first[(size_t)r] < 0) { first[(size_t)r] = (int32_t)j; continue; }
                 const int32_t a = find((int32_t)j), b = find(first[(size_t)r]);
                 if (a != b) parent[(size_t)std::max(a, b)] = std::min(a, b);       // the root of a component is its smallest column
@@ -1304,13 +1331,20 @@ int blkdir_setup(fos_solver* h, const int64_t* colptr, const int64_t* rowval, co
     for (int64_t j = 0; j < n; ++j) cnt[(size_t)find((int32_t)j)] += 1;
     int nblk = 0;
     size_t gtotal = 0;
-    for (int64_t j = 0; j < n; ++j)
+    for (int64_t j = 0; j < n && local_ok; ++j)
         if (cnt[(size_t)j] > 0) {
-            if (cnt[(size_t)j] > BLKDIR_MAX) return FOS_OK;                        // a block of I + A'A too large to invert densely per wavefront
+            if (cnt[(size_t)j] > BLKDIR_MAX) { local_ok = false; break; }          // a block of I + A'A too large to invert densely per wavefront
             blkid[(size_t)j] = nblk++;
             gtotal += (size_t)cnt[(size_t)j] * (size_t)cnt[(size_t)j];
         }
-    if (gtotal * sizeof(double) > ((size_t)1 << 31)) return FOS_OK;
+    if (gtotal * sizeof(double) > ((size_t)1 << 31)) local_ok = false;
+    {
+        // the form is taken by ALL ranks or by none (its reductions are collective)
+        double vote[3] = {local_ok ? 1.0 : 0.0, 0.0, 0.0};
+        FOS_TRY(global_sum3(h, vote));
+        if (bad_index) { set_error("fos_enable_direct: row index out of range"); return FOS_EINVAL; }
+        if (h->sharded() ? vote[0] != (double)h->nranks : !local_ok) return FOS_OK;
+    }
     std::vector<int32_t> ioff((size_t)nblk + 1, 0), idx((size_t)n);
     std::vector<int64_t> goff((size_t)nblk, 0);
     for (int64_t j = 0; j < n; ++j) if (cnt[(size_t)j] > 0) ioff[(size_t)blkid[(size_t)j] + 1] = cnt[(size_t)j];
@@ -1400,7 +1434,12 @@ int blkdir_setup(fos_solver* h, const int64_t* colptr, const int64_t* rowval, co
         work();
         for (auto& t : pool) t.join();
     }
-    if (bad.load()) { set_error("fos_enable_direct: I + A'A has a block that is not positive definite (non-finite entries in A?)"); return FOS_EINVAL; }
+    {
+        double vote[3] = {bad.load() ? 1.0 : 0.0, 0.0, 0.0};       // (collective again: a rank that failed here must not leave its peers in the sums below)
+        FOS_TRY(global_sum3(h, vote));
+        if (bad.load()) { set_error("fos_enable_direct: I + A'A has a block that is not positive definite (non-finite entries in A?)"); return FOS_EINVAL; }
+        if (vote[0] != 0.0) { set_error("fos_enable_direct: I + A'A has a block that is not positive definite on another rank"); return FOS_EINVAL; }
+    }
     // ---- device data
     FOS_TRY(dev_upload(h, &h->blk_goff, goff));
     FOS_TRY(dev_upload(h, &h->blk_ioff, ioff));
@@ -1421,6 +1460,11 @@ int blkdir_setup(fos_solver* h, const int64_t* colptr, const int64_t* rowval, co
     FOS_HIP(hipMemcpy(cbv.data(), h->cb, sizeof(double) * (size_t)(n + m), hipMemcpyDeviceToHost));
     long double hh2 = 0.0L;
     for (double v : cbv) hh2 += (long double)v * v;
+    {
+        double g3[3] = {(double)hh2, 0.0, 0.0};                    // |[c; b]|^2 over all ranks
+        FOS_TRY(global_sum3(h, g3));
+        hh2 = g3[0];
+    }
     const double delta = (double)(1.0L + hh2);
     std::vector<double> prm(16, 0.0);
     prm[9] = delta;
@@ -1453,6 +1497,12 @@ int blkdir_setup(fos_solver* h, const int64_t* colptr, const int64_t* rowval, co
     for (int64_t i = 0; i < l - 1; ++i) {
         hph += (long double)cbv[(size_t)i] * phg[(size_t)i].x; hpg += (long double)cbv[(size_t)i] * phg[(size_t)i].y;
         gph += (long double)mh[(size_t)i] * phg[(size_t)i].x; gpg += (long double)mh[(size_t)i] * phg[(size_t)i].y;
+    }
+    {
+        double g3[3] = {(double)hph, (double)hpg, (double)gph}, g1[3] = {(double)gpg, 0.0, 0.0};       // the border's dots over all ranks
+        FOS_TRY(global_sum3(h, g3));
+        FOS_TRY(global_sum3(h, g1));
+        if (h->sharded()) { hph = g3[0]; hpg = g3[1]; gph = g3[2]; gpg = g1[0]; }
     }
     // S3 = C^-1 + W' D^-1 W,  C^-1 = [1 0 0; 0 0 -1; 0 -1 0]
     long double S3[3][3] = {{1 + hph, hpg, 0}, {gph, gpg, -1}, {0, -1, 1 / (long double)delta}}, Inv[3][3];
@@ -2306,7 +2356,7 @@ int fos_set_alg(fos_handle h, int alg, double alpha, double alpha1, double alpha
 // entries of G X - I).  Only matrix products are needed: the hand-written fp64 MFMA GEMM of vecops.hip.
 int fos_enable_direct(fos_handle h, const int64_t* colptr, const int64_t* rowval, const double* nzval) {
     if (!h || !colptr || (!rowval && colptr[h->n] > 1)) { set_error("NULL argument"); return FOS_EINVAL; }
-    if (h->sharded()) { set_error("direct=true is a single-GPU mode"); return FOS_EUNSUPPORTED; }
+    if (h->row_sharded) { set_error("direct=true is not available on row-sharded handles"); return FOS_EUNSUPPORTED; }
     if (h->Ginv || h->blk_ginv) { h->direct = true; h->direct_blk = h->blk_ginv != nullptr; return FOS_OK; }
     const int64_t l = h->l, nnz = colptr[h->n] - 1;
     // which exact form (FOS_DIRECT_MODE=block|dense|cg forces one; default: the first that applies)
@@ -2321,6 +2371,9 @@ int fos_enable_direct(fos_handle h, const int64_t* colptr, const int64_t* rowval
         if (ok) { h->direct_blk = true; h->direct = true; return FOS_OK; }
         if (mode == "block") { set_error("FOS_DIRECT_MODE=block: A'A has a diagonal block of more than %d columns", BLKDIR_MAX); return FOS_EUNSUPPORTED; }
     }
+    // cone-sharded handles: only the block form (its three scalar exchanges per projection go through the handle's transport); collective -- every rank
+    // has taken part in blkdir_setup's vote above
+    if (h->sharded()) { set_error("direct=true on a sharded handle needs the block form on every rank (I + A'A block diagonal with blocks of at most %d columns)", BLKDIR_MAX); return FOS_EUNSUPPORTED; }
     // beyond what a dense l x l inverse can hold, S1 = IndAffine([Q -I], 0) and S1 = AffinePlusLinear(Q, 0, 0, 1) are still the SAME set (HSDE.jl:12-15 / :22): the
     // exact projection is what the warm-started CG converges to, so "direct" becomes CG run to its tolerance floor l eps from the first call on
     // (no 0.2^sqrt(i) schedule: affinepluslinear.jl:108-112 is what direct = true switches off) -- the reference's sparse factorisation is not rebuilt.

@@ -1179,16 +1179,16 @@ void launch_direct_finish(const LaunchCtx& c, const double2* x, const double2* W
 // (1) from T = M (u, v) (T.x = g = u - Q v): W2 = (0, g restricted to the rows of A), W3 zeroed outside the x part, partial sums of ph.g and pg.g
 __global__ __launch_bounds__(VEC_THREADS) void blkdir_prep_kernel(int64_t l, int64_t n, const d2* __restrict__ T, const d2* __restrict__ phg,
                                                                   d2* __restrict__ W2, d2* __restrict__ W3, double* __restrict__ partials) {
-    double acc[2] = {0.0, 0.0};
+    double acc[3] = {0.0, 0.0, 0.0};          // (three-wide records: what the sharded reduce kernel takes)
     GRID_STRIDE(i, l) {
         const double g = T[i].x;
         const d2 ph = phg[i];
-        acc[0] += ph.x * g; acc[1] += ph.y * g;
+        if (i < l - 1) { acc[0] += ph.x * g; acc[1] += ph.y * g; }      // (the tau element is replicated on sharded handles; ph, pg are zero there anyway)
         const bool yrow = i >= n && i < l - 1;
         W2[i] = make_double2(0.0, yrow ? g : 0.0);
         if (i >= n) W3[i] = make_double2(0.0, 0.0);
     }
-    block_reduce_store<2>(acc, partials + 2 * (int64_t)blockIdx.x);
+    block_reduce_store<3>(acc, partials + 3 * (int64_t)blockIdx.x);
 }
 // (2) one wavefront per diagonal block of I + A'A (order s <= 64, explicit inverse, column-major): (q, x^) = Ginv (a, g1) with a = A' g2 = -R.x and
 //     g1 = T.x on the block's columns; W3 = (q, x^) there -- the two vectors the third sweep applies A to; ctx_rec[b] = the block's share of c'x^
@@ -1216,9 +1216,11 @@ __global__ __launch_bounds__(64) void blkdir_solve_kernel(const int64_t* __restr
 // kappa = S3inv [ph.g, pg.g, g_tau / delta] (the multipliers of the three border columns) from the prep kernel's records: EVERY workgroup of the kernels
 // that need it adds the same records in the same order (no launch of its own).  prm = S3inv (9), delta
 __device__ __forceinline__ void blkdir_kappa(const double* __restrict__ prep_partials, int count, const d2* __restrict__ T, int64_t l, const double* __restrict__ prm,
-                                             int zero, double* kap /* shared [3] */) {
-    __shared__ double sums[2];
-    reduce_partials<2>(prep_partials, count, sums);
+                                             int zero, double* kap /* shared [3] */, const double* __restrict__ reduced, int from_reduced) {
+    // (sharded handles: the two dots were summed over the ranks into `reduced` between the prep kernel and here)
+    __shared__ double sums[3];
+    if (from_reduced) { if (threadIdx.x < 2) sums[threadIdx.x] = reduced[threadIdx.x]; __syncthreads(); }
+    else reduce_partials<3>(prep_partials, count, sums);
     if (threadIdx.x == 0) {
         const double r[3] = {sums[0], sums[1], T[l - 1].x / prm[9]};
         for (int a = 0; a < 3; ++a) kap[a] = zero ? 0.0 : prm[3 * a] * r[0] + prm[3 * a + 1] * r[1] + prm[3 * a + 2] * r[2];
@@ -1230,10 +1232,12 @@ __device__ __forceinline__ void blkdir_kappa(const double* __restrict__ prep_par
 __global__ __launch_bounds__(VEC_THREADS) void blkdir_combine_kernel(int64_t l, int64_t n, const d2* __restrict__ T, const d2* __restrict__ W3, const d2* __restrict__ V,
                                                                      const d2* __restrict__ phg, const d2* __restrict__ qphg, const double* __restrict__ cb,
                                                                      const double* __restrict__ prm, int zero, const double* __restrict__ prep_partials, int nprep,
-                                                                     d2* __restrict__ out, double* __restrict__ partials) {
+                                                                     d2* __restrict__ out, double* __restrict__ partials, const double* __restrict__ reduced, int from_reduced,
+                                                                     double* __restrict__ kap_out) {
     __shared__ double kap[3];
-    blkdir_kappa(prep_partials, nprep, T, l, prm, zero, kap);
+    blkdir_kappa(prep_partials, nprep, T, l, prm, zero, kap, reduced, from_reduced);
     const double k1 = kap[0], k2 = kap[1], k3 = kap[2], delta = prm[9];
+    if (blockIdx.x == 0 && threadIdx.x < 3) kap_out[threadIdx.x] = kap[threadIdx.x];        // (for the tau-row kernel of a sharded handle: `reduced` is reused by then)
     const double th = T[l - 1].x / delta;
     double acc[1] = {0.0};
     GRID_STRIDE(i, l - 1) {
@@ -1247,14 +1251,30 @@ __global__ __launch_bounds__(VEC_THREADS) void blkdir_combine_kernel(int64_t l, 
     block_reduce_store<1>(acc, partials + (int64_t)blockIdx.x);
 }
 // (4) the tau row: u^_tau = g_tau / delta - k3 / delta, (Q u^)_tau = -c'x^ - b'y^ - k1 (Q ph)_tau - k2 (Q pg)_tau   (c'x^ from the block records)
-__global__ __launch_bounds__(FIN_THREADS) void blkdir_tau_kernel(const double* __restrict__ partials, int count, const double* __restrict__ ctx_rec, int nblk,
-                                                                 const d2* __restrict__ T, const d2* __restrict__ qphg, int64_t l, const double* __restrict__ prm,
-                                                                 int zero, const double* __restrict__ prep_partials, int nprep, d2* __restrict__ out) {
-    __shared__ double kap[3];
-    blkdir_kappa(prep_partials, nprep, T, l, prm, zero, kap);
+//     sharded handles: blkdir_tausum_kernel leaves this rank's c'x^ + b'y^ as one record, the reduce kernel sums it over the ranks into reduced[0],
+//     and kappa comes from where the combine kernel left it (kap_in)
+__global__ __launch_bounds__(FIN_THREADS) void blkdir_tausum_kernel(const double* __restrict__ partials, int count, const double* __restrict__ ctx_rec, int nblk,
+                                                                    double* __restrict__ out1) {
     __shared__ double sums[1], sumc[1];
     reduce_partials<1>(partials, count, sums);
     reduce_partials<1>(ctx_rec, nblk, sumc);
+    if (threadIdx.x == 0) out1[0] = sumc[0] + sums[0];
+}
+__global__ __launch_bounds__(FIN_THREADS) void blkdir_tau_kernel(const double* __restrict__ partials, int count, const double* __restrict__ ctx_rec, int nblk,
+                                                                 const d2* __restrict__ T, const d2* __restrict__ qphg, int64_t l, const double* __restrict__ prm,
+                                                                 int zero, const double* __restrict__ prep_partials, int nprep, d2* __restrict__ out,
+                                                                 const double* __restrict__ reduced, int from_reduced, const double* __restrict__ kap_in) {
+    __shared__ double kap[3];
+    __shared__ double sums[1], sumc[1];
+    if (from_reduced) {
+        if (threadIdx.x < 3) kap[threadIdx.x] = kap_in[threadIdx.x];
+        if (threadIdx.x == 0) { sums[0] = reduced[0]; sumc[0] = 0.0; }
+        __syncthreads();
+    } else {
+        blkdir_kappa(prep_partials, nprep, T, l, prm, zero, kap, nullptr, 0);
+        reduce_partials<1>(partials, count, sums);
+        reduce_partials<1>(ctx_rec, nblk, sumc);
+    }
     if (threadIdx.x == 0) {
         const double k1 = kap[0], k2 = kap[1], k3 = kap[2], delta = prm[9];
         const d2 qp = qphg[l - 1];
@@ -1269,11 +1289,17 @@ void launch_blkdir_solve(const LaunchCtx& c, int nblk, const int64_t* goff, cons
     if (nblk > 0) hipLaunchKernelGGL(blkdir_solve_kernel, dim3(nblk), dim3(64), 0, c.stream, goff, ioff, idx, Ginv, R, T, W3, c.cb, ctx_rec);
 }
 void launch_blkdir_combine(const LaunchCtx& c, const double2* T, const double2* W3, const double2* V, const double2* phg, const double2* qphg,
-                           const double* prm, int zero_kappa, double2* out, const double* prep_partials, double* partials, const double* ctx_rec, int nblk) {
+                           double* prm, int zero_kappa, double2* out, const double* prep_partials, double* partials, int from_reduced) {
     hipLaunchKernelGGL(blkdir_combine_kernel, dim3(c.vec_blocks), dim3(VEC_THREADS), 0, c.stream, c.l, c.n, T, W3, V, phg, qphg, c.cb, prm, zero_kappa, prep_partials,
-                       c.vec_blocks, out, partials);
+                       c.vec_blocks, out, partials, c.reduced, from_reduced, prm + 10);
+}
+void launch_blkdir_tausum(const LaunchCtx& c, const double* partials, const double* ctx_rec, int nblk, double* out1) {
+    hipLaunchKernelGGL(blkdir_tausum_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, partials, c.vec_blocks, ctx_rec, nblk, out1);
+}
+void launch_blkdir_tau(const LaunchCtx& c, const double2* T, const double2* qphg, const double* prm, int zero_kappa, double2* out, const double* prep_partials,
+                       const double* partials, const double* ctx_rec, int nblk, int from_reduced) {
     hipLaunchKernelGGL(blkdir_tau_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, partials, c.vec_blocks, ctx_rec, nblk, T, qphg, c.l, prm, zero_kappa, prep_partials,
-                       c.vec_blocks, out);
+                       c.vec_blocks, out, c.reduced, from_reduced, prm + 10);
 }
 
 // ------------------------------------------------------------------------------------------------ layout conversion

@@ -186,7 +186,7 @@ int fos_reset_affine(fos_handle h);
  * four times that during set-up, ~(2 log2(lambda_max) + 14) l x l x l products) and a projection is two Q sweeps and one
  * dense symmetric matrix-vector product.  A (the arrays fos_create was given) is passed
  * again: the handle keeps only its device format.  No CG runs: fos_check_result.cgiter stays 0 and the host prints the table
- * without the cg column (HSDEStatus.jl:44-50,79).  Single-GPU handles only.  fos_disable_direct returns to CG.
+ * without the cg column (HSDEStatus.jl:44-50,79).  fos_disable_direct returns to CG.  Sharded handles: the block form below only (see there).
  * l > 46000 (C3, C4, C5): the dense inverse does not fit; IndAffine([Q -I], 0) and AffinePlusLinear(Q, 0, 0, 1) being the same set (HSDE.jl:12-15 / :22), the
  * exact projection is then computed by the warm-started CG run to its tolerance floor l eps from the first call on (no 0.2^sqrt(i) schedule) -- the reference's
  * sparse factorisation is not rebuilt; fos_check_result.cgiter reports the CG iterations of that projection.
@@ -194,6 +194,11 @@ int fos_reset_affine(fos_handle h);
  * with small blocks: a block-diagonal SDP with few variables per block (C4: 512 blocks of 32 columns) -- the same exact projection costs THREE KKT sweeps:
  * I + Q Q' = blkdiag(I + A'A, I + AA', delta) + a rank-3 border, (I + AA')^-1 = I - A (I + A'A)^-1 A', the small blocks inverted once on the host
  * (csrc/solver.cpp prox_affine_direct_block).  No CG, no l x l matrix; cgiter stays 0.
+ * CONE-SHARDED handles (fos_comm_init / fos_set_host_allreduce / fos_peer_open*): the block form is the one that shards -- the diagonal blocks are local to the
+ * rank that holds the columns, only the rank-3 border couples the ranks: THREE exchanges of <= 3 doubles per projection through the handle's transport (the
+ * tau row of the first apply with the two border dots, the tau row of the result) and two more at set-up.  fos_enable_direct is then COLLECTIVE (call it on
+ * every rank, after the transport is enabled); it takes the block form when every rank's columns group, and fails with FOS_EUNSUPPORTED on every rank otherwise
+ * (no dense or CG-floor form there).  Row-sharded handles: FOS_EUNSUPPORTED.
  * fos_get_direct_mode: 0 = off, 1 = dense inverse, 2 = block form, 3 = CG at its tolerance floor (the host keeps the table's cg column then).
  * FOS_DIRECT_MODE=block|dense|cg (environment) forces a form. */
 int fos_enable_direct(fos_handle h, const int64_t* colptr, const int64_t* rowval, const double* nzval);

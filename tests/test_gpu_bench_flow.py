@@ -136,6 +136,17 @@ def test_bench_ranks_on_one_gpu(nranks, transport):
         assert rb[k] == pytest.approx(ra[k], rel=1e-4), k
     assert outn["config"]["cg_iters_per_step"] == pytest.approx(out1["config"]["cg_iters_per_step"], abs=1.5)
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("foship-")]            # rank 0 unlinked the segment
+    # the extra line of the same job under DR(direct = true): the block form on every rank, its scalar sums through the same mailboxes, no CG
+    dt = outn["direct_true"]
+    assert "failed" not in dt, dt
+    assert dt["form"] == "block" and dt["value"] > 0 and dt["sweeps_per_step"] == 3 and transport in dt["parallelism"].replace("host-pinned", "host")
+    if nranks == 2:
+        rd = subprocess.run(base + ["--no-cpu-baseline", "--direct"], cwd=str(ROOT), env=dict(os.environ), capture_output=True, text=True, timeout=600)
+        assert rd.returncode == 0, rd.stdout[-3000:] + rd.stderr[-3000:]
+        da, db = _last_json(rd.stdout)["config"]["residuals_after_run"], dt["residuals_after_run"]
+        assert da["iteration"] == db["iteration"]
+        for k in ("p", "d", "g"):                                                        # (no inexact CG in the loop: the order of the sums is all that differs)
+            assert db[k] == pytest.approx(da[k], rel=1e-7), k
 
 
 @pytest.mark.parametrize("inject,reason", [("peer_open_fail_rank1", "injected: no peer access"), ("peer_map_fail_rank1", "injected: IPC mapping failed")])

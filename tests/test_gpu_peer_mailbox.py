@@ -50,10 +50,10 @@ def random_block_problem(pkg, seed):
 
 
 def _alg(pkg, name):
-    return {"DR": pkg.DR, "GAPA": pkg.GAPA, "FISTA": pkg.FISTA}[name]()
+    return {"DR": pkg.DR, "GAPA": pkg.GAPA, "FISTA": pkg.FISTA, "Dykstra": pkg.Dykstra}[name]()
 
 
-def _worker(rank, world, kind, algname, q_out, q_in, transport="ipc"):
+def _worker(rank, world, kind, algname, q_out, q_in, transport="ipc", direct=False):
     """One rank.  The parent relays the 64-byte handles and acts as the barrier (plain multiprocessing queues: no
     torch.distributed, no sockets)."""
     sys.path.insert(0, str(ROOT))
@@ -77,6 +77,9 @@ def _worker(rank, world, kind, algname, q_out, q_in, transport="ipc"):
         if not q_in.get(timeout=120):
             return
         dev.peer_enable(True)
+        if direct:                                              # direct = true on a sharded handle: the block form, its three scalar sums per projection through the mailboxes
+            dev.enable_direct(lp.A)
+            assert dev.direct_mode() == "block"
         dev.set_alg(_alg(pkg, algname))
         dev.set_iterate(None)
         cg, a12 = [], []
@@ -103,7 +106,7 @@ def _worker(rank, world, kind, algname, q_out, q_in, transport="ipc"):
         q_out.put((rank, "error", repr(exc)))
 
 
-def _run(kind, algname, transport="ipc"):
+def _run(kind, algname, transport="ipc", direct=False):
     import multiprocessing as mp
     import os
     ctx = mp.get_context("spawn")
@@ -112,7 +115,7 @@ def _run(kind, algname, transport="ipc"):
         transport = "/foship-test-%d" % os.getpid()
     q_out = ctx.Queue()
     q_in = [ctx.Queue() for _ in range(world)]
-    procs = [ctx.Process(target=_worker, args=(r, world, kind, algname, q_out, q_in[r], transport)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, kind, algname, q_out, q_in[r], transport, direct)) for r in range(world)]
     for p in procs:
         p.start()
 
@@ -212,6 +215,33 @@ def test_two_ranks_one_gpu_match_unsharded(pkg, oracle, kind, algname, transport
     st.checkstatus(zs, override=True)
     for key in ("p", "d", "g", "ctx", "bty"):
         assert got[0]["res"][key] == pytest.approx(st.last[key], rel=1e-9, abs=1e-12), key
+
+
+@pytest.mark.parametrize("kind,algname,transport", [("sdp", "DR", "ipc"), ("sdp-tiles", "GAPA", "host"), ("sdp", "FISTA", "host"), ("sdp-tiles", "Dykstra", "ipc")])
+def test_two_ranks_direct_block_form_matches_unsharded(pkg, kind, algname, transport):
+    """direct = true (HSDE.jl:12-15) on cone-SHARDED handles: the block form of the exact projection -- D = blkdiag(I + A'A, I + AA', delta) is local to a rank, the
+    tau row of the first apply, the two dots behind the border multipliers and the tau row of the result cross the ranks (three exchanges per projection, through
+    either kind of mailboxes).  No inexact CG in the loop: the gathered iterate equals the unsharded handle's to 1e-10 after twelve iterations, both ranks hold the
+    same tau / kappa bits, no CG iteration is counted."""
+    got = _run(kind, algname, transport, direct=True)
+    prob = _problem(pkg, kind)
+    shards = [pkg.sharding.shard_problem(prob, 2, r) for r in range(2)]
+    assert got[0]["cg"] == got[1]["cg"] == [0] * ITERS
+    l0 = shards[0].problem.m + shards[0].problem.n + 1
+    l1 = shards[1].problem.m + shards[1].problem.n + 1
+    assert got[0]["z"][l0 - 1] == got[1]["z"][l1 - 1] and got[0]["z"][-1] == got[1]["z"][-1]
+    dev = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    dev.enable_direct(prob.A)
+    assert dev.direct_mode() == "block"
+    dev.set_alg(_alg(pkg, algname))
+    dev.set_iterate(None)
+    dev.step(1, ITERS, 10 ** 9, 1e-9)
+    x = dev.get_iterate()
+    dev.close()
+    z = pkg.sharding.local_to_global([got[r]["z"] for r in range(2)], shards)
+    tol = 1e-10 if algname != "GAPA" else 1e-7
+    assert np.linalg.norm(z - x) <= tol * max(1.0, np.linalg.norm(x)), np.linalg.norm(z - x) / max(1.0, np.linalg.norm(x))
+
 
 
 def test_selftest_single_rank_and_fallback(pkg):
