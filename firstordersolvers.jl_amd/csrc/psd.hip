@@ -935,6 +935,18 @@ __device__ __forceinline__ void rf_gemm(v4d (&acc)[4], const double* __restrict_
     }
 }
 
+// In-kernel time stamps of the refinement kernel (timing experiments; -DFOS_PSD_STAMPS; tools/psd_stamps.py): workgroup FOS_PSD_STAMP_WG (default 0),
+// lane 0 of every wavefront, consecutive slots: (ticks of the 100 MHz clock) * 64 + phase id
+#ifdef FOS_PSD_STAMPS
+#ifndef FOS_PSD_STAMP_WG
+#define FOS_PSD_STAMP_WG 0
+#endif
+__device__ long long g_psd_stamps[4 * 128];
+#define PSD_STAMP(id) do { if (stamp_on && stamp_slot < 128) { __builtin_amdgcn_sched_barrier(0); g_psd_stamps[w * 128 + stamp_slot++] = wall_clock64() * 64 + (id); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define PSD_STAMP(id) do { } while (0)
+#endif
+
 template <int WPS>
 __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__ out, const d2* __restrict__ in, const ConeDesc* __restrict__ cones,
                                                            const double* __restrict__ vin, double* __restrict__ vout, int have_prev,
@@ -970,6 +982,11 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
     const int jcol = 16 * w + lr;
+#ifdef FOS_PSD_STAMPS
+    const bool stamp_on = blockIdx.x == FOS_PSD_STAMP_WG && lane == 0;
+    int stamp_slot = 0;
+#endif
+    PSD_STAMP(0);
     const int cone = blockIdx.x >> 1, part = blockIdx.x & 1;
     const ConeDesc cd = cones[cone];
     const bool dual = (cd.dual_part == part);
@@ -1008,9 +1025,11 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
             *reinterpret_cast<d2*>(Vl + (e & 63) + (e >> 6) * LD) = vv[q];
         }
     }
+    PSD_STAMP(1);
     for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
     if (lane == 0) red[w] = fro;
     __syncthreads();
+    PSD_STAMP(2);
     const double scale = sqrt((red[0] + red[1]) + (red[2] + red[3]));
     const double noise = RF_NOISE * scale;
     if (phase_limit == 11) return;
@@ -1039,12 +1058,13 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
         for (it = 0;; ++it) {
             if (it >= RF_MAX_IT) { fail = 1; break; }
             ++total_it;
+            PSD_STAMP(3);
             // ---- G = M V (column block w)
             v4d acc[4];
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) acc[ib] = v4d{0.0, 0.0, 0.0, 0.0};
             rf_gemm<16, 4 * LD, WPS == 2 ? 2 : 4>(acc, Ml + lr + lk * LD, Vb);
-            if (phase_limit == 12) return;
+            PSD_STAMP(4);
             // ---- Rayleigh quotients of the block's columns; G' = G - V diag d
             double vv = 0.0, vg = 0.0;
 #pragma unroll
@@ -1058,14 +1078,25 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[ib][r] -= Vb[ib][r] * dj;
             if (lk == 0) dl[jcol] = dj;
+            PSD_STAMP(5);
+            // ONE barrier in front of the second product: d of all blocks is visible, and so is the V the previous iteration stored behind ITS last
+            // barrier (the first product reads M and this wavefront's registers only, so that store needed no barrier of its own)
+            __syncthreads();
+            PSD_STAMP(6);
+            // d_i of this lane's sixteen rows: requested here, in one go, so that their LDS latency passes beside the product (read one by one in
+            // front of their use they cost sixteen exposed round trips: 1.3 us of a 10 us iteration, 5 us beside a second workgroup's products)
+            double di[16];
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) di[4 * ib + r] = dl[16 * ib + 4 * r + lk];
             // ---- N = V' G' (column block w): A operand = columns of V read as rows
             v4d nac[4];
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) nac[ib] = v4d{0.0, 0.0, 0.0, 0.0};
             rf_gemm<16 * LD, 4, WPS == 2 ? 2 : 4>(nac, Vl + lk + lr * LD, acc);
-            __syncthreads();                                   // d of all blocks visible
-            if (phase_limit == 13) return;
-            // ---- E from N; pairs that need a rotation first
+            PSD_STAMP(7);
+            // ---- E from N (straight-line code: selects, no branch per entry); pairs that need a rotation first are flagged
             double conv2 = 0.0;
             int bad = 0;
             v4d ev[4];
@@ -1077,23 +1108,45 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = 16 * ib + 4 * r + lk;
-                        const double n = nac[ib][r];
-                        const double den = dj - dl[i];
+                        const bool isdiag = i == jcol;
+                        const double n = isdiag ? 0.0 : nac[ib][r];
+                        const double den = dj - di[4 * ib + r];
                         const double an = fabs(n), ad = fabs(den);
                         // rounding level (an <= noise): never chased, whatever the gap -- a quotient of two rounding errors would be an
                         // O(theta) "rotation" that is not even skew; small against the gap: first-order correction; else: a rotation first
-                        const bool isdiag = i == jcol, small = an <= noise, ok = an <= theta * ad;
+                        const bool small = an <= noise, ok = an <= theta * ad;
                         double rc = __builtin_amdgcn_rcp(den);
                         rc = rc * (2.0 - den * rc);                  // (E needs a few digits only: the iteration corrects itself)
-                        const double e = isdiag ? ediag : ((small || !ok) ? 0.0 : n * rc);
-                        bad |= (!isdiag && !small && !ok) ? 1 : 0;
+                        double e = (small || !ok) ? 0.0 : n * rc;
+                        bad |= (!small && !ok) ? 1 : 0;
+                        e = isdiag ? ediag : e;
                         conv2 += e * e;
                         ev[ib][r] = e;
                     }
             };
-            make_e();
-            if (__syncthreads_or(bad)) {
-                // ---- rare: exact rotations of the offending pairs on S = N + diag d (in M's array) and on the columns of V
+            v4d vn[4];
+            double c2 = 0.0;
+            for (int pass = 0;; ++pass) {
+                make_e();
+                PSD_STAMP(8);
+                // ---- ||E||_F^2 and the rotation flag of this wavefront
+                conv2 = group16_sum(conv2);                    // (DPP inside the 16-lane rows, then two cross-row exchanges)
+                conv2 += __shfl_xor(conv2, 16, 64);
+                conv2 += __shfl_xor(conv2, 32, 64);
+                const int wbad = __builtin_amdgcn_ballot_w64(bad != 0) != 0ull ? 1 : 0;
+                if (lane == 0) { red[8 + w] = conv2; ired[8 + w] = wbad; }
+                PSD_STAMP(10);
+                // ---- V + V E (column block w), not yet stored; A operand = rows of V
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) vn[ib] = Vb[ib];
+                rf_gemm<16, 4 * LD, WPS == 2 ? 2 : 4>(vn, Vl + lr + lk * LD, ev);
+                PSD_STAMP(11);
+                __syncthreads();                               // every wavefront has read the old V; the four sums and flags are visible
+                PSD_STAMP(12);
+                c2 = (red[8] + red[9]) + (red[10] + red[11]);
+                const int any_bad = (ired[8] | ired[9]) | (ired[10] | ired[11]);
+                if (!any_bad || pass == 1) break;      // (pass 1: a pair can still be flagged only through the difference between (N_ij + N_ji) / 2 and N_ij: left to the next iteration)
+                // ---- rare: exact rotations of the offending pairs on S = N + diag d (in M's array) and on the columns of V; the product above is discarded
 #pragma unroll
                 for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
@@ -1176,34 +1229,29 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
                     __syncthreads();
                 }
                 if (fail) break;
-                make_e();      // (a pair can still be flagged here only through the difference between (N_ij + N_ji) / 2 and N_ij: left to the next iteration)
-            }
-            // ---- ||E||_F^2 over the workgroup
-            conv2 = group16_sum(conv2);                        // (DPP inside the 16-lane rows, then two cross-row exchanges)
-            conv2 += __shfl_xor(conv2, 16, 64);
-            conv2 += __shfl_xor(conv2, 32, 64);
-            if (lane == 0) red[8 + w] = conv2;
-            if (phase_limit == 14) return;
-            // ---- V <- V + V E (column block w); A operand = rows of V
-            v4d vn[4];
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) vn[ib] = Vb[ib];
-            rf_gemm<16, 4 * LD, WPS == 2 ? 2 : 4>(vn, Vl + lr + lk * LD, ev);
-            __syncthreads();                                   // every wavefront has read the old V
+                for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) di[4 * ib + r] = dl[16 * ib + 4 * r + lk];
+            }
+            if (fail) break;
+            // ---- the new V: registers and LDS (visible to the others behind the next barrier: the one in front of the next N product, or the one behind the loop)
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) {
                 Vb[ib] = vn[ib];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Vl[16 * ib + 4 * r + lk + jcol * LD] = vn[ib][r];
             }
-            const double c2 = (red[8] + red[9]) + (red[10] + red[11]);
-            if (it == 0) dbg_c1 = c2 > 0.0 ? min(9, max(0, (int)(-0.5 * log10(c2)))) : 9;
-            if (it == 1) dbg_c2 = c2 > 0.0 ? min(9, max(0, (int)(-0.5 * log10(c2)))) : 9;
-            __syncthreads();
-            if (phase_limit == 15) return;
+            if (it < 2) {       // (debug record: the decimal exponent of ||E||_F, from the binary exponent of its square -- no log10 on this path: its fp64 polynomial cost 4 us beside a second workgroup's products)
+                const int ex = (int)((__double_as_longlong(c2) >> 52) & 0x7FF) - 1023;
+                const int dg = c2 > 0.0 ? min(9, max(0, (int)(-0.150515f * (float)ex))) : 9;
+                if (it == 0) dbg_c1 = dg; else dbg_c2 = dg;
+            }
+            PSD_STAMP(13);
             if (c2 <= RF_ACCEPT2) { ++it; break; }
             if (!(c2 < 1e300)) { fail = 1; break; }            // NaN / overflow: not ours
         }
+        __syncthreads();                                       // the last V is in LDS for everybody (and nobody still reads what a restart overwrites)
         if (!fail || attempt >= 1) break;
     }
     if (fail) {
@@ -1236,6 +1284,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
     }
     if (tid == 0) { *code = 0; *cmask = rmask; if (stats) stats[blockIdx.x] = 100 + 1000 * (attempt == 0) + 16 * nrot + total_it + (rec[4 * nmat] == 77 ? 10000 * dbg_c1 + 100000 * dbg_c2 + 1000000 * (skip != 0ull) : 0); }
     if (phase_limit == 16) return;
+    PSD_STAMP(14);
 
     // ---- one Newton-Schulz step: V <- V (I + (I - V'V) / 2)
     {
@@ -1247,6 +1296,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
         for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
             for (int r = 0; r < 4; ++r) g[ib][r] = ((16 * ib + 4 * r + lk == jcol) ? 0.5 : 0.0) - 0.5 * g[ib][r];
+        PSD_STAMP(15);
         v4d vn[4];
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) vn[ib] = Vb[ib];
@@ -1259,6 +1309,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
         __syncthreads();
     }
     if (phase_limit == 17) return;
+    PSD_STAMP(16);
     // ---- P = V max(diag d, 0) V': the 10 tiles on and below the diagonal, round-robin over the wavefronts, into M's array
     {
         constexpr int NT = 3;
@@ -1290,6 +1341,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
             }
         }
     }
+    PSD_STAMP(17);
     // the new basis (coalesced, from LDS)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -1297,6 +1349,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
         Vn[tid + 256 * q] = *reinterpret_cast<const d2*>(Vl + (e & 63) + (e >> 6) * LD);
     }
     __syncthreads();
+    PSD_STAMP(18);
     if (fz.on) {
         double sv[9], xo[9]; unsigned short ij[9];
 #pragma unroll
@@ -1322,6 +1375,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
                 if (shc) shc[2 * (int64_t)idx] = part == 1 ? sv[q] - xn : sv[q];
             }
         }
+        PSD_STAMP(19);
         return;
     }
     {
@@ -1341,7 +1395,20 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
             if (idx < P64_LEN) y[2 * (int64_t)idx] = xv[q] + v;
         }
     }
+    PSD_STAMP(19);
 }
+
+}  // namespace fos
+// (not part of the ABI: timing experiments -- tools/psd_stamps.py; -1 unless compiled with -DFOS_PSD_STAMPS)
+extern "C" int fos_debug_psd_stamps(long long* out, int n) {
+#ifdef FOS_PSD_STAMPS
+    if (n > 4 * 128) n = 4 * 128;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fos::g_psd_stamps), sizeof(long long) * (size_t)n);
+#else
+    (void)out; (void)n; return -1;
+#endif
+}
+namespace fos {
 
 size_t psd_scratch_bytes(int kmax, int ncones) {
     if (ncones <= 0) return 0;
