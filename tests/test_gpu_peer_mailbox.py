@@ -217,7 +217,8 @@ def test_two_ranks_one_gpu_match_unsharded(pkg, oracle, kind, algname, transport
         assert got[0]["res"][key] == pytest.approx(st.last[key], rel=1e-9, abs=1e-12), key
 
 
-@pytest.mark.parametrize("kind,algname,transport", [("sdp", "DR", "ipc"), ("sdp-tiles", "GAPA", "host"), ("sdp", "FISTA", "host"), ("sdp-tiles", "Dykstra", "ipc")])
+@pytest.mark.parametrize("kind,algname,transport", [("sdp", "DR", "ipc"), ("sdp-tiles", "GAPA", "host"), ("sdp", "FISTA", "host"), ("sdp-tiles", "Dykstra", "ipc"),
+                                                    ("rand-3", "DR", "host"), ("rand-8", "FISTA", "ipc"), ("rand-11", "Dykstra", "host")])
 def test_two_ranks_direct_block_form_matches_unsharded(pkg, kind, algname, transport):
     """direct = true (HSDE.jl:12-15) on cone-SHARDED handles: the block form of the exact projection -- D = blkdiag(I + A'A, I + AA', delta) is local to a rank, the
     tau row of the first apply, the two dots behind the border multipliers and the tau row of the result cross the ranks (three exchanges per projection, through
