@@ -83,6 +83,7 @@ struct WinStd {
     // and the matrix; the rest -- and, here, a fourth slice -- is streamed behind the barriers
     static constexpr int PRE0 = 6, PRE1 = 6, PRE2 = 6, PRE3 = 0;
     static constexpr bool PREFETCH = false;
+    static constexpr bool PIPELINE = false;
 };
 struct WinTall {
     static constexpr int COLS = 6144, ROWS = 4032, THREADS = 1024, WG_PER_CU = 1, WAVES = THREADS / 64;
@@ -91,6 +92,11 @@ struct WinTall {
     static constexpr bool PREFETCH = FOS_WIN_PREFETCH != 0;   // the next segment's window requested behind this segment's second barrier (one workgroup per CU: nobody else fills the bubble)
 #else
     static constexpr bool PREFETCH = true;
+#endif
+#ifdef FOS_WIN_PIPELINE
+    static constexpr bool PIPELINE = FOS_WIN_PIPELINE != 0;   // slot-level software pipeline over the segments (kernels.hip, win_walk)
+#else
+    static constexpr bool PIPELINE = true;
 #endif
 };
 static_assert((WinStd::ROWS + 64 * WinStd::WAVES - 1) / (64 * WinStd::WAVES) <= 4 && (WinTall::ROWS + 64 * WinTall::WAVES - 1) / (64 * WinTall::WAVES) <= 4,

@@ -663,6 +663,92 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
             if constexpr (NRHS == 2) acc[i] = make_double2(0.0, 0.0); else acc[i] = 0.0;
         }
         WIN_STAMP_G(1);
+        if constexpr (GEO::PIPELINE) {
+            // SOFTWARE PIPELINE over the segments, slot by slot (round 5): as soon as slot u of segment k has been multiplied, its registers take the requests of
+            // slot u of segment k + 1 (and segment k + 1's window is requested behind the second barrier, as with PREFETCH) -- so the memory system works on
+            // segment k + 1 WHILE segment k is multiplied out of LDS, with the registers of ONE segment.  A segment then costs max(memory, LDS work) + two barriers
+            // instead of their sum.
+            for (int k0 = 0; k0 < wp.nseg; k0 += 64) {
+                const int nk = min(64, wp.nseg - k0);
+                uint4 dv = make_uint4(0u, 0u, 0u, 0u);
+                if (lane < nk) dv = *reinterpret_cast<const uint4*>(drec + k0 + lane);
+                d2 wreg[WPT];
+                WinSliceRegs<GEO::PRE0> r0; WinSliceRegs<GEO::PRE1> r1; WinSliceRegs<GEO::PRE2> r2; WinSliceRegs<GEO::PRE3> r3;
+                int ncols;
+                {   // prologue: everything of the chunk's first segment
+                    const int col0 = __builtin_amdgcn_readlane((int)dv.x, 0);
+                    const unsigned t01 = (unsigned)__builtin_amdgcn_readlane((int)dv.y, 0), t23 = (unsigned)__builtin_amdgcn_readlane((int)dv.z, 0);
+                    ncols = __builtin_amdgcn_readlane((int)dv.w, 0);
+                    r0.T = (int)(t01 & 0xFFFFu); r1.T = (int)(t01 >> 16); r2.T = (int)(t23 & 0xFFFFu); r3.T = (int)(t23 >> 16);
+                    r0.off = off; off += 64 * (int64_t)r0.T;
+                    r1.off = off; off += 64 * (int64_t)r1.T;
+                    r2.off = off; off += 64 * (int64_t)r2.T;
+                    r3.off = off; off += 64 * (int64_t)r3.T;
+#pragma unroll
+                    for (int q = 0; q < WPT; ++q) {
+                        const int i = tid + q * WIN_THREADS;
+                        wreg[q] = (i < ncols) ? gat.load(col0 + i) : make_double2(0.0, 0.0);
+                    }
+                    win_slice_issue<MNT>(S, rs, lane, r0); rs += r0.T > 0;
+                    win_slice_issue<MNT>(S, rs, lane, r1); rs += r1.T > 0;
+                    win_slice_issue<MNT>(S, rs, lane, r2); rs += r2.T > 0;
+                    win_slice_issue<MNT>(S, rs, lane, r3); rs += r3.T > 0;
+                }
+                for (int k = 0; k < nk; ++k) {
+                    WIN_STAMP(0);
+                    // EVERYTHING requested so far is this segment's: one explicit wait for all of it.  (Left to the compiler, the waits sit inside the predicated
+                    // window stores, so on its books the slots' registers may still be pending at their multiply -- and because the requests issued in between
+                    // are predicated too, i.e. of unknown number, it can only wait for ALL of them there: vmcnt(0) in front of every slot, which drains the very
+                    // requests this pipeline wants in flight.)
+                    __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0), expcnt / lgkmcnt untouched
+                    WIN_STAMP(1);
+                    __syncthreads();                       // the previous window's readers are done (first pass: acc is zeroed)
+                    WIN_STAMP(2);
+#pragma unroll
+                    for (int q = 0; q < WPT; ++q) {
+                        const int i = tid + q * WIN_THREADS;
+                        if (i < ncols) { if constexpr (NRHS == 2) win[i] = wreg[q]; else win[i] = wreg[q].x; }
+                    }
+                    WIN_STAMP(3);
+                    __syncthreads();
+                    WIN_STAMP(4);
+                    const bool nxt = k + 1 < nk;
+                    unsigned t01n = 0u, t23n = 0u;
+                    if (nxt) {
+                        const int col0n = __builtin_amdgcn_readlane((int)dv.x, k + 1);
+                        t01n = (unsigned)__builtin_amdgcn_readlane((int)dv.y, k + 1);
+                        t23n = (unsigned)__builtin_amdgcn_readlane((int)dv.z, k + 1);
+                        ncols = __builtin_amdgcn_readlane((int)dv.w, k + 1);
+#pragma unroll
+                        for (int q = 0; q < WPT; ++q) {
+                            const int i = tid + q * WIN_THREADS;
+                            wreg[q] = (i < ncols) ? gat.load(col0n + i) : make_double2(0.0, 0.0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);     // (the window's requests stay in front of the multiply)
+                    win_slice_compute<MNT, NRHS>(S, r0, win, acc, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                    r0.T = (int)(t01n & 0xFFFFu); r0.off = off; off += 64 * (int64_t)r0.T;
+                    win_slice_issue<MNT>(S, rs, lane, r0); rs += r0.T > 0;
+                    __builtin_amdgcn_sched_barrier(0);
+                    win_slice_compute<MNT, NRHS>(S, r1, win, acc, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                    r1.T = (int)(t01n >> 16); r1.off = off; off += 64 * (int64_t)r1.T;
+                    win_slice_issue<MNT>(S, rs, lane, r1); rs += r1.T > 0;
+                    __builtin_amdgcn_sched_barrier(0);
+                    win_slice_compute<MNT, NRHS>(S, r2, win, acc, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                    r2.T = (int)(t23n & 0xFFFFu); r2.off = off; off += 64 * (int64_t)r2.T;
+                    win_slice_issue<MNT>(S, rs, lane, r2); rs += r2.T > 0;
+                    __builtin_amdgcn_sched_barrier(0);
+                    win_slice_compute<MNT, NRHS>(S, r3, win, acc, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                    r3.T = (int)(t23n >> 16); r3.off = off; off += 64 * (int64_t)r3.T;
+                    win_slice_issue<MNT>(S, rs, lane, r3); rs += r3.T > 0;
+                    WIN_STAMP(5);
+                }
+            }
+        } else
         for (int k0 = 0; k0 < wp.nseg; k0 += 64) {         // (one chunk unless a panel touches more than 64 windows)
             const int nk = min(64, wp.nseg - k0);
             uint4 dv = make_uint4(0u, 0u, 0u, 0u);
