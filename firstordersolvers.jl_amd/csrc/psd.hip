@@ -1085,11 +1085,14 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
             PSD_STAMP(6);
             // d_i of this lane's sixteen rows: requested here, in one go, so that their LDS latency passes beside the product (read one by one in
             // front of their use they cost sixteen exposed round trips: 1.3 us of a 10 us iteration, 5 us beside a second workgroup's products)
-            double di[16];
+            // (two workgroups per CU: 256 registers per lane -- sixteen more live doubles spill; there the other workgroup's products cover the reads, so they stay in E)
+            double di[WPS == 1 ? 16 : 1];
+            if constexpr (WPS == 1) {
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib)
+                for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) di[4 * ib + r] = dl[16 * ib + 4 * r + lk];
+                    for (int r = 0; r < 4; ++r) di[4 * ib + r] = dl[16 * ib + 4 * r + lk];
+            }
             // ---- N = V' G' (column block w): A operand = columns of V read as rows
             v4d nac[4];
 #pragma unroll
@@ -1110,7 +1113,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
                         const int i = 16 * ib + 4 * r + lk;
                         const bool isdiag = i == jcol;
                         const double n = isdiag ? 0.0 : nac[ib][r];
-                        const double den = dj - di[4 * ib + r];
+                        const double den = dj - (WPS == 1 ? di[4 * ib + r] : dl[i]);
                         const double an = fabs(n), ad = fabs(den);
                         // rounding level (an <= noise): never chased, whatever the gap -- a quotient of two rounding errors would be an
                         // O(theta) "rotation" that is not even skew; small against the gap: first-order correction; else: a rotation first
@@ -1229,10 +1232,12 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
                     __syncthreads();
                 }
                 if (fail) break;
+                if constexpr (WPS == 1) {
 #pragma unroll
-                for (int ib = 0; ib < 4; ++ib)
+                    for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) di[4 * ib + r] = dl[16 * ib + 4 * r + lk];
+                        for (int r = 0; r < 4; ++r) di[4 * ib + r] = dl[16 * ib + 4 * r + lk];
+                }
             }
             if (fail) break;
             // ---- the new V: registers and LDS (visible to the others behind the next barrier: the one in front of the next N product, or the one behind the loop)

@@ -23,6 +23,10 @@ for tr in peer host; do
   run c4_shard64_${tr}_loopback FOS_FORCE_DIST=1 FOS_REDUCTION=$tr FOS_PEER_LOOPBACK=1 -- --small --no-cpu-baseline
 done
 run c4_shard64_direct A=1 -- --small --no-cpu-baseline --direct
+# DR(direct = true), block form, in the SHARDED code path (three scalar exchanges per projection through the transport)
+for tr in peer host rccl; do
+  run c4_shard64_direct_sharded_$tr FOS_FORCE_DIST=1 FOS_REDUCTION=$tr -- --small --no-cpu-baseline --direct --steps 200
+done
 run c5_shard1of2_dist1rank FOS_FORCE_DIST=1 FOS_BENCH_SHARD=0/2 -- --workload C5 --no-cpu-baseline
 run c5_shard1of8_dist1rank FOS_FORCE_DIST=1 FOS_BENCH_SHARD=0/8 -- --workload C5 --no-cpu-baseline
 # two ranks of the full C4 on the ONE GPU of the box under both kinds of mailboxes (host coordination over gloo): residuals of the single-rank run
@@ -43,5 +47,6 @@ cp gpurun_out/r04/trace_c4_shard64_host.md $OUT/
 REPS=20 bash tools/pmc_sweep.sh r05final_pmc C4 C2 C3 C5 > $OUT/pmc.log 2>&1
 cp gpurun_out/r05final_pmc/pmc_*.md gpurun_out/r05final_pmc/pmc_*.json $OUT/ 2>/dev/null
 timeout 900 python3 tools/psd_time.py 250 64 128 256 512 > $OUT/psd_time.json 2> /dev/null
+# (in-kernel stamps of the PSD refinement kernel need their own build: touch csrc/psd.hip; make EXTRA=-DFOS_PSD_STAMPS; python tools/psd_stamps.py 250 64 512 -> profiles/r05_psd_stamps.txt)
 hipcc --offload-arch=gfx950 -O3 -Wno-unused-value tools/ub_vmem_issue.hip -o /tmp/ub_vmem 2>/dev/null && /tmp/ub_vmem > $OUT/ub_vmem_issue.txt 2>&1
 ls $OUT
