@@ -1432,7 +1432,11 @@ __global__ __launch_bounds__(VEC_THREADS) void cones_soc_kernel(d2* __restrict__
 constexpr double EXP_TOL = 1e-15;
 constexpr int EXP_MAXIT = 100;
 
+// (No FMA contraction in these three functions, and the same order of operations as the oracle's restatement: for points within ~1e-8 of the cone the dual variable
+//  rho is that small, 1 / rho^2 multiplies rounding errors by 1e16 and the Newton iteration ends on noise -- an alternating projection that converges onto the cone
+//  then sees the device and the CPU restatement drift apart by 1e-7 within twenty iterations (tests/fuzz_parity.py, Feasibility seed 20439) unless both round alike.)
 __device__ double exp_newton_onz(double rho, double y_hat, double z_hat, double w) {
+#pragma clang fp contract(off)
     double t = fmax(fmax(w - z_hat, -z_hat), EXP_TOL);
     for (int it = 0; it < EXP_MAXIT; ++it) {
         const double f = (1.0 / (rho * rho)) * t * (t + z_hat) - y_hat / rho + log(t / rho) + 1.0;
@@ -1445,12 +1449,14 @@ __device__ double exp_newton_onz(double rho, double y_hat, double z_hat, double 
     return t + z_hat;
 }
 __device__ double exp_calc_grad(const double* v, double rho, double warm2, double* x) {
+#pragma clang fp contract(off)
     x[2] = exp_newton_onz(rho, v[1], v[2], warm2);
     x[1] = (1.0 / rho) * (x[2] - v[2]) * x[2];
     x[0] = v[0] - rho;
     return (x[1] == 0) ? x[0] : x[0] + x[1] * log(x[1] / x[2]);
 }
 __device__ void exp_project(const double* v, double* y) {
+#pragma clang fp contract(off)
     const double r = v[0], s = v[1], t = v[2];
     if ((s > 0 && s * exp(r / s) <= t) || (r <= 0 && s == 0 && t >= 0)) { y[0] = r; y[1] = s; y[2] = t; return; }
     if ((-r < 0 && r * exp(s / r) <= -2.718281828459045 * t) || (-r == 0 && -s >= 0 && -t >= 0)) { y[0] = y[1] = y[2] = 0.0; return; }
@@ -1463,6 +1469,7 @@ __device__ void exp_project(const double* v, double* y) {
         g = exp_calc_grad(v, rho, z[1], z);
     }
     double ub = rho;
+    z[1] = v[1];                          // (the bisection's first Newton solve starts from the point itself again, as in the restatement: getRhoUb keeps its iterate to itself)
     for (int it = 0; it < EXP_MAXIT; ++it) {
         rho = (ub + lb) / 2;
         g = exp_calc_grad(v, rho, z[1], z);

@@ -156,6 +156,8 @@ def one_seed(pkg, seed, solve):
             model = pkg.solve(prob, mk(pkg, **opts))
             om = orc.Model(A, b, c, codes1, codes2)
             sol = orc.solve(om, mk(orc, **opts), out=[])
+            if os.environ.get("FOS_FUZZ_VERBOSE"):
+                print("   solve %s: device %s after %d iterations, oracle %s after %d" % (algname, model.status(), model.iterations, sol.status, sol.iterations), flush=True)
             if model.status() != sol.status:
                 # a status may differ only when the stopping residuals are within rounding of eps at the deciding check
                 fails.append("%s status %s vs oracle %s (its %d vs %d)" % (algname, model.status(), sol.status, model.iterations, sol.iterations))
@@ -164,7 +166,13 @@ def one_seed(pkg, seed, solve):
                     fails.append("%s iterations %d vs %d" % (algname, model.iterations, sol.iterations))
                 e = float(np.linalg.norm(model.getsolution() - sol.x) / max(1.0, np.linalg.norm(sol.x)))
                 if e > (3e-2 if algname == "GAPA" else 1e-3):          # (eps = 1e-5 solves; GAPA's step-length estimate amplifies rounding: 7e-3 seen once in 3 000 seeds)
-                    fails.append("%s solution %.2e" % (algname, e))
+                    # the early, loose CG tolerances amplify rounding (tests/test_gpu_parity.py): before calling it a failure, the ORACLE's own end point under a
+                    # one-ulp change of b -- the device is held to 20 x that envelope (seed 20300: FISTA, both stop at iteration 450, 1.6e-3 apart)
+                    om2 = orc.Model(A, b * (1.0 + 2.220446049250313e-16), c, codes1, codes2)
+                    sol2 = orc.solve(om2, mk(orc, **opts), out=[])
+                    env = float(np.linalg.norm(sol2.x - sol.x) / max(1.0, np.linalg.norm(sol.x))) if sol2.status == sol.status else float("inf")
+                    if not e <= 20.0 * env:
+                        fails.append("%s solution %.2e (oracle's own one-ulp envelope %.1e)" % (algname, e, env))
     except Exception as ex:  # noqa: BLE001
         fails.append("EXCEPTION %s: %s" % (type(ex).__name__, str(ex)[:300]))
     finally:
@@ -213,7 +221,7 @@ def one_feas_seed(pkg, seed):
         b = A @ x0
         hp = pkg.Feasibility(pkg.IndAffine(A, b), S2h, n)
 
-        def oracle_run(bvec):
+        def oracle_run(bvec, first_flag=None, flags=None):
             oalg = mk(orc)
             omodel = orc.FeasibilityModel(orc.Feasibility(orc.IndAffine(A, bvec), S2o, n), oalg)
             ost = orc.FeasibilityStatus(omodel, 10 ** 9, 1e-30, 0, 1)
@@ -221,7 +229,10 @@ def one_feas_seed(pkg, seed):
             seq = []
             for i in range(1, 21):
                 ost.i = i
+                n0 = len(flags) if flags is not None else 0
                 oalg.step(xo, i, ost)
+                if flags is not None and first_flag[0] is None and any(flags[n0:]):
+                    first_flag[0] = i                              # (the first iteration with a flagged call)
                 seq.append(xo.copy())
             return seq
         # LongstepWrapper: once the saved normals are dependent beyond what float64 data can express (sigma_min of the saved rows below 1e-11
@@ -248,13 +259,29 @@ def one_feas_seed(pkg, seed):
             d1, d2 = x1 - x2, y1 - y2
             noise_steps.append(bool(d1 @ d1 <= 1e-22 * max(x1 @ x1, 1e-300) or d2 @ d2 <= 1e-22 * max(y1 @ y1, 1e-300)))
             return orig_ns(x1, x2, y1, y2, *a_, **k_)
+        # Exponential cones: the reference's projection (SCS-style bisection on the dual variable rho, a Newton solve inside) loses its accuracy as the point
+        # approaches the cone -- rho -> 0 and 1 / rho^2 multiplies the rounding errors: measured against a 60-digit projection (scratch/dbg_feas20439_cpu.py,
+        # seed 20439) the RESTATED projection itself is off by 1e-10 at distance 1e-7, 2e-9 at 1e-8, 3e-8 at 1e-9.  Iterates are compared up to the first
+        # projection that moves its argument by less than 1e-7 (relative): beyond it the device and the restatement only share the algorithm's noise.
+        exp_close = []
+        orig_exp = orc.prox_exp_primal
+
+        def exp_hook(y_, x_):
+            orig_exp(y_, x_)
+            moved = float(np.abs(np.asarray(y_, dtype=float) - np.asarray(x_, dtype=float)).max())
+            exp_close.append(bool(0.0 < moved < 1e-7 * max(1.0, float(np.abs(x_).max()))))
+        first_exp_close = [None]
         orc.project_onto_planes = proj_hook
         orc.normed_scalar = ns_hook
+        orc.prox_exp_primal = exp_hook
+        orc._PROX[orc.CONE_EXPP] = exp_hook
         try:
-            ref = oracle_run(b)
+            ref = oracle_run(b, first_exp_close, exp_close)
         finally:
             orc.project_onto_planes = orig_proj
             orc.normed_scalar = orig_ns
+            orc.prox_exp_primal = orig_exp
+            orc._PROX[orc.CONE_EXPP] = orig_exp
         first_noise = next((q + 1 for q, flag in enumerate(noise_steps) if flag), None)
         first_degenerate = None
         if wrap == "long":
@@ -281,6 +308,8 @@ def one_feas_seed(pkg, seed):
                 if first_degenerate is not None and i >= first_degenerate:
                     break
                 if first_noise is not None and i > first_noise:
+                    break
+                if first_exp_close[0] is not None and i >= first_exp_close[0]:
                     break
                 if not e <= tol + 50 * envelope:
                     fails.append("iterate %d off by %.2e (envelope %.1e)" % (i, e, envelope))

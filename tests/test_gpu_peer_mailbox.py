@@ -28,6 +28,8 @@ def _problem(pkg, kind):
         return w.c4_block_sdp(nblocks=6, k=8, p=8)
     if kind.startswith("rand-"):     # random block-diagonal program, uneven blocks, every cone kind on both sides of every block (tests/fuzz_parity.py generators)
         return random_block_problem(pkg, int(kind.split("-")[1]))
+    if kind == "mixed-wide":         # blocks of 80 columns: more than the block form of direct = true inverts per wavefront
+        return w.c5_mixed(nblocks=4, nb_cols=80, nonneg=24, nsoc=6, socdim=5, npsd=2, k=6, density=0.2)
     return w.c5_mixed(nblocks=4, nb_cols=40, nonneg=12, nsoc=3, socdim=5, npsd=2, k=6, density=0.2)
 
 
@@ -77,7 +79,15 @@ def _worker(rank, world, kind, algname, q_out, q_in, transport="ipc", direct=Fal
         if not q_in.get(timeout=120):
             return
         dev.peer_enable(True)
-        if direct:                                              # direct = true on a sharded handle: the block form, its three scalar sums per projection through the mailboxes
+        derr = None
+        if direct == "refused":                                 # an operator whose columns do not group: EVERY rank gets the error (the vote is collective), the handle stays on CG
+            try:
+                dev.enable_direct(lp.A)
+                derr = "no error"
+            except Exception as exc:  # noqa: BLE001
+                derr = str(exc)
+            assert dev.direct_mode() == "off"
+        elif direct:                                            # direct = true on a sharded handle: the block form, its three scalar sums per projection through the mailboxes
             dev.enable_direct(lp.A)
             assert dev.direct_mode() == "block"
         dev.set_alg(_alg(pkg, algname))
@@ -98,7 +108,7 @@ def _worker(rank, world, kind, algname, q_out, q_in, transport="ipc", direct=Fal
         dev.set_affine_state(dev.get_iterate(), 2000)
         dev.step(1, 1, 10 ** 9, 1e-9)
         zt, cgt = dev.get_iterate(), dev.cgiter()
-        q_out.put((rank, "result", dict(z=z, z2=z2, cg=cg, a12=a12, zs=zs, zt=zt, cgt=cgt,
+        q_out.put((rank, "result", dict(z=z, z2=z2, cg=cg, a12=a12, zs=zs, zt=zt, cgt=cgt, derr=derr,
                                         res={k: getattr(res, k) for k in ("p", "d", "g", "ctx", "bty", "kappa", "tau", "norm_b", "norm_c")})))
         q_in.get(timeout=120)                                   # keep the mailbox alive until the peer is done too
         dev.close()
@@ -243,6 +253,17 @@ def test_two_ranks_direct_block_form_matches_unsharded(pkg, kind, algname, trans
     tol = 1e-10 if algname != "GAPA" else 1e-7
     assert np.linalg.norm(z - x) <= tol * max(1.0, np.linalg.norm(x)), np.linalg.norm(z - x) / max(1.0, np.linalg.norm(x))
 
+
+
+def test_two_ranks_direct_is_refused_collectively_when_the_columns_do_not_group(pkg):
+    """fos_enable_direct on sharded handles is a collective: an operator whose columns fall into groups of more than 64 has no block form, so BOTH ranks get
+    FOS_EUNSUPPORTED (no dense or CG-floor form on sharded handles), nobody is left waiting in a vote, and the handles go on with the CG projection -- same CG
+    counts on both ranks, finite iterates."""
+    got = _run("mixed-wide", "DR", "ipc", direct="refused")
+    for r in range(2):
+        assert got[r]["derr"] is not None and "block form" in got[r]["derr"], got[r]["derr"]
+    assert got[0]["cg"] == got[1]["cg"] and min(got[0]["cg"]) >= 1
+    assert np.all(np.isfinite(got[0]["z"])) and np.all(np.isfinite(got[1]["z"]))
 
 
 def test_selftest_single_rank_and_fallback(pkg):
