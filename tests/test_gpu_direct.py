@@ -239,3 +239,27 @@ def test_direct_beyond_the_dense_size_is_the_same_projection_by_cg(pkg, monkeypa
     t = np.concatenate([u, d.q_apply(u)])
     assert abs((x - y) @ t) <= 1e-8 * np.linalg.norm(t) * np.linalg.norm(x)                          # displacement orthogonal to it
     d.close()
+
+
+def test_block_form_on_a_one_rank_communicator_equals_the_single_handle(pkg):
+    """direct = true in the SHARDED code path of the block form (the records of the prep and combine kernels reduced locally, all-reduced in stream, the multipliers and
+    the tau row formed from the reduced buffer) with a one-rank RCCL communicator: the same sums in the same order as the single handle -- iterates equal to rounding
+    (the reduce kernel adds the records in another tree than the kernels that fold them: 1e-13), no CG iteration counted, the mode reported as the block form."""
+    prob = pkg.workloads.c4_block_sdp(nblocks=8, k=16, p=6)
+    outs = []
+    for use_comm in (False, True):
+        d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+        if use_comm:
+            d.comm_init(1, 0, pkg.HipHSDE.comm_unique_id())
+        d.enable_direct(prob.A)
+        assert d.direct_mode() == "block"
+        d.set_alg(pkg.DR())
+        d.set_iterate(None)
+        done, checked, res = d.step(1, 40, 40, 1e-6)
+        assert done == 40 and checked and d.cgiter() == 0
+        outs.append((d.get_iterate(), res.p, res.d, res.g))
+        d.close()
+    x0, x1 = outs[0][0], outs[1][0]
+    assert np.linalg.norm(x1 - x0) <= 1e-12 * max(1.0, np.linalg.norm(x0)), np.linalg.norm(x1 - x0)
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert a == pytest.approx(b, rel=1e-9, abs=1e-14)
