@@ -260,7 +260,7 @@ def one_feas_seed(pkg, seed):
             noise_steps.append(bool(d1 @ d1 <= 1e-22 * max(x1 @ x1, 1e-300) or d2 @ d2 <= 1e-22 * max(y1 @ y1, 1e-300)))
             return orig_ns(x1, x2, y1, y2, *a_, **k_)
         # Exponential cones: the reference's projection (SCS-style bisection on the dual variable rho, a Newton solve inside) loses its accuracy as the point
-        # approaches the cone -- rho -> 0 and 1 / rho^2 multiplies the rounding errors: measured against a 60-digit projection (scratch/dbg_feas20439_cpu.py,
+        # approaches the cone -- rho -> 0 and 1 / rho^2 multiplies the rounding errors: measured against a 60-digit projection (tools/exp_cone_accuracy.py,
         # seed 20439) the RESTATED projection itself is off by 1e-10 at distance 1e-7, 2e-9 at 1e-8, 3e-8 at 1e-9.  Iterates are compared up to the first
         # projection that moves its argument by less than 1e-7 (relative): beyond it the device and the restatement only share the algorithm's noise.
         exp_close = []
