@@ -8,12 +8,6 @@ namespace fos {
 
 typedef double2 d2;
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -21,14 +15,43 @@ __device__ __forceinline__ double dpp_f64(double v) {
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
+// v + (v of the lane 16 / 32 away), every lane, without the LDS crossbar: gfx950's v_permlane{16,32}_swap exchanges the odd
+// 16-lane rows (the upper 32 lanes) of one register with the even rows (the lower 32 lanes) of another; fed the same value
+// twice it leaves [r0 r0 r2 r2] / [r1 r1 r3 r3] (resp. [lo lo] / [hi hi]), whose sum is the pairwise total in every lane.
+template <int W>
+__device__ __forceinline__ double swap_sum(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    if constexpr (W == 16) {
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    } else {
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+}
+
+// The sum over the 64 lanes in EVERY lane (the same bits in each: every step adds a lane's value and its partner's, commutatively): four DPP steps inside the
+// rows of 16 lanes, then the two row exchanges of gfx950 -- no trip through the LDS crossbar (the six ds_bpermute round trips of a __shfl_xor butterfly were
+// ~0.3 us per sum: three of them sat at the tail of every workgroup of every sweep and in the prologue of every CG vector kernel).
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_f64<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);      // row_half_mirror
+    v += dpp_f64<0x140>(v);      // row_mirror
+    v = swap_sum<16>(v);
+    v = swap_sum<32>(v);
+    return v;
+}
 // sum over aligned groups of `tpr` lanes (tpr a power of two, wave-uniform); every lane of a group gets the total
 __device__ __forceinline__ double group_sum(double v, int tpr) {
     if (tpr >= 2) v += dpp_f64<0xB1>(v);       // quad_perm [1,0,3,2]
     if (tpr >= 4) v += dpp_f64<0x4E>(v);       // quad_perm [2,3,0,1]
     if (tpr >= 8) v += dpp_f64<0x141>(v);      // row_half_mirror
     if (tpr >= 16) v += dpp_f64<0x140>(v);     // row_mirror
-    if (tpr >= 32) v += __shfl_xor(v, 16, 64);
-    if (tpr >= 64) v += __shfl_xor(v, 32, 64);
+    if (tpr >= 32) v = swap_sum<16>(v);
+    if (tpr >= 64) v = swap_sum<32>(v);
     return v;
 }
 

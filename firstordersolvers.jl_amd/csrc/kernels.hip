@@ -157,23 +157,6 @@ __device__ __forceinline__ void finish_row(const DevBlkCsr& S, Epi& epi, int row
     epi.row(row, a1, a2, pr);
 }
 
-// v + (v of the lane 16 / 32 away), every lane, without the LDS crossbar: gfx950's v_permlane{16,32}_swap exchanges the odd
-// 16-lane rows (the upper 32 lanes) of one register with the even rows (the lower 32 lanes) of another; fed the same value
-// twice it leaves [r0 r0 r2 r2] / [r1 r1 r3 r3] (resp. [lo lo] / [hi hi]), whose sum is the pairwise total in every lane.
-template <int W>
-__device__ __forceinline__ double swap_sum(double v) {
-    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-    if constexpr (W == 16) {
-        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
-    } else {
-        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-        return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
-    }
-}
-
 // Column sums of a dual tile.  Every lane holds p[u] = (its row's value in column u) x (its row's vector element) for 8
 // consecutive columns; returns, in EVERY lane, the sum over all 64 lanes for column (lane & 7).  Three halving stages
 // inside each group of 8 lanes (a lane keeps half of its values and trades the other half with a partner that keeps

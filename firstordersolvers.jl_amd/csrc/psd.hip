@@ -21,10 +21,9 @@
 //     for the common 8-lane case).
 // Accuracy: absolute error O(k eps ||M||), the class of LAPACK's dspev that the reference calls.
 #include "fos_internal.hpp"
+#include "dev_common.hpp"      // dpp_f64, swap_sum, wave_sum
 
 namespace fos {
-
-typedef double2 d2;
 
 constexpr int PSD_THREADS = 256;
 constexpr int PSD_MAX_SWEEPS = 40;
@@ -53,14 +52,7 @@ __device__ __forceinline__ void idx_to_ij(int idx, int k, int& i, int& j) {
     i = jj + (idx - (jj * k - (jj * (jj - 1)) / 2));
 }
 
-// ---- in-register reductions over a lane group
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
+// ---- in-register reductions over a lane group (dpp_f64: dev_common.hpp)
 // sum over aligned groups of 8 lanes: lane i + lane 7-i (row_half_mirror), then xor 2, xor 1 inside the quad
 __device__ __forceinline__ double group8_sum(double v) {
     v += dpp_f64<0x141>(v);        // row_half_mirror
@@ -75,13 +67,10 @@ __device__ __forceinline__ double group16_sum(double v) {
 }
 __device__ __forceinline__ double group32_sum(double v) {
     v = group16_sum(v);
-    v += __shfl_xor(v, 16, 64);
+    v = swap_sum<16>(v);           // (gfx950 row exchange instead of a ds_bpermute round trip: dev_common.hpp)
     return v;
 }
-__device__ __forceinline__ double group_sum(double v, int tpp) {
-    for (int off = tpp >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+// (group_sum(v, tpp), any power of two: dev_common.hpp)
 
 // 1/sqrt(x) to ~1 ulp: hardware estimate + two Newton steps (no IEEE division/sqrt sequences on the critical path)
 __device__ __forceinline__ double fast_rsqrt(double x) {
@@ -201,7 +190,7 @@ __device__ __forceinline__ void psd_block(d2* __restrict__ out, const d2* __rest
         G[i + (size_t)j * ld] = v;
         G[j + (size_t)i * ld] = v;
     }
-    for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
+    fro = wave_sum(fro);
     if ((tid & 63) == 0) red[tid >> 6] = fro;
     __syncthreads();
     // WARM needs every shifted eigenvalue strictly positive (well defined column directions): sigma > |lambda_min|
@@ -673,7 +662,7 @@ __global__ __launch_bounds__(64) void psd64_wave_kernel(d2* __restrict__ out, co
             }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
+    fro = wave_sum(fro);
     const double sigma = (WARM ? 1.001 : 0.505) * sqrt(fro);
     __syncthreads();
     G[lane + lane * LD] += sigma;
@@ -861,8 +850,8 @@ __device__ __forceinline__ double fast_rcp(double x) {
 }
 // sum over the four lanes l, l^16, l^32, l^48 (the four row groups of a tile column): the same bits in each
 __device__ __forceinline__ double colgroup_sum(double v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    v = swap_sum<16>(v);
+    v = swap_sum<32>(v);
     return v;
 }
 // the packed input of a thread (9 entries) -> M in LDS (both triangles, diagonal scaled by sqrt(2)); returns the thread's share of ||M||_F^2
@@ -1026,7 +1015,7 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
         }
     }
     PSD_STAMP(1);
-    for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
+    fro = wave_sum(fro);
     if (lane == 0) red[w] = fro;
     __syncthreads();
     PSD_STAMP(2);
@@ -1134,8 +1123,8 @@ __global__ __launch_bounds__(256, WPS) void psd64_refine_kernel(d2* __restrict__
                 PSD_STAMP(8);
                 // ---- ||E||_F^2 and the rotation flag of this wavefront
                 conv2 = group16_sum(conv2);                    // (DPP inside the 16-lane rows, then two cross-row exchanges)
-                conv2 += __shfl_xor(conv2, 16, 64);
-                conv2 += __shfl_xor(conv2, 32, 64);
+                conv2 = swap_sum<16>(conv2);
+                conv2 = swap_sum<32>(conv2);
                 const int wbad = __builtin_amdgcn_ballot_w64(bad != 0) != 0ull ? 1 : 0;
                 if (lane == 0) { red[8 + w] = conv2; ired[8 + w] = wbad; }
                 PSD_STAMP(10);
