@@ -227,9 +227,11 @@ __device__ __forceinline__ double wave_sum_records(const double* __restrict__ re
     double v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = (lane + 64 * k < count) ? rec[lane + 64 * k] : 0.0;
-    double s = 0.0;
+    // (the sum starts from v[0], not from 0.0: the compiler placed `0.0 + v[0]` -- not foldable, -0.0 -- inside the predicated block of the FIRST load, with a
+    //  vmcnt(0) behind it, so the other fifteen loads went out only after that round trip: two memory latencies instead of one in every prologue that closes a CG iteration)
+    double s = v[0];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s += v[k];
+    for (int k = 1; k < 16; ++k) s += v[k];
     return wave_sum(s);
 }
 
