@@ -117,6 +117,51 @@ __device__ __forceinline__ void partials_combine(const double (&acc)[NACC], doub
     __syncthreads();
 }
 
+// The exchange of a SINGLE workgroup (region 0 of the mailboxes: reduce_kernel<true>, blkdir_tau_kernel<true>): sums[0..nacc) (shared) -> every rank's
+// mailbox, poll the own mailbox for the peers' words of the next sequence number, add in rank order -> out[0..nacc) (the same bits on every rank).  Returns
+// false (the solve is stopped, the host reports it) when a peer does not answer in time.  Call with all threads of the workgroup.
+__device__ __forceinline__ bool peer_exchange_wg(const PeerBox& pb, const double* sums, int nacc, double* out, DevState* st) {
+    __shared__ uint32_t xw_halves[PEER_MAX_RANKS * PEER_MAX_VALS * 2];
+    __shared__ int xw_failed;
+    const int t = threadIdx.x;
+    if (t == 0) xw_failed = 0;
+    __syncthreads();
+    const uint32_t seq = *pb.seq + 1u;                 // this exchange (same number on every rank)
+    const size_t par = (size_t)(seq & 1u) * PEER_MAX_RANKS;
+    if (t < pb.nranks * nacc * 2) {                    // thread = (peer rank r, value v, half hh)
+        const int hh = t & 1, v = (t >> 1) % nacc, r = (t >> 1) / nacc;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(sums[v]);
+        const unsigned long long word = ((unsigned long long)seq << 32) | (hh ? (bits >> 32) : (bits & 0xFFFFFFFFull));
+        unsigned long long* dst = pb.box[r] + ((par + pb.rank) * PEER_MAX_VALS + v) * 2 + hh;
+        __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long* src = pb.box[pb.rank] + ((par + r) * PEER_MAX_VALS + v) * 2 + hh;
+        const long long t0 = wall_clock64();
+        unsigned long long w;
+        bool ok;
+        do {
+            w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            ok = (uint32_t)(w >> 32) == seq;
+        } while (!ok && (wall_clock64() - t0) < pb.timeout_ticks);
+        if (!ok) xw_failed = 1;
+        xw_halves[(r * PEER_MAX_VALS + v) * 2 + hh] = (uint32_t)w;
+    }
+    __syncthreads();
+    if (xw_failed) {                                   // a peer never arrived: stop the solve, the host reports it
+        if (t == 0) { st->xchg_failed = 1; st->done = 1; }
+        return false;
+    }
+    if (t < nacc) {
+        double s = 0.0;
+        for (int r = 0; r < pb.nranks; ++r) {          // rank order: every rank computes the same bits
+            const unsigned long long lo = xw_halves[(r * PEER_MAX_VALS + t) * 2], hi = xw_halves[(r * PEER_MAX_VALS + t) * 2 + 1];
+            s += __longlong_as_double((long long)((hi << 32) | lo));
+        }
+        out[t] = s;
+    }
+    if (t == 0) *pb.seq = seq;
+    return true;
+}
+
 // Folded peer exchange (fos_internal.hpp, region 1 of the mailboxes): called by EVERY workgroup of a CG kernel with the
 // same local sums; workgroup 0 also stores them into the peers' mailboxes; all poll their own mailbox for the peers' words of
 // sequence number `seq` and add in rank order.  Returns false (and stops the solve) when a peer does not answer in time.

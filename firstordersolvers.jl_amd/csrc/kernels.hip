@@ -1123,44 +1123,7 @@ __global__ __launch_bounds__(FIN_THREADS) void reduce_kernel(const double* __res
     if constexpr (!PEER) {
         if ((int)threadIdx.x < nacc) reduced[threadIdx.x] = sums[threadIdx.x];
     } else {
-        __shared__ uint32_t halves[PEER_MAX_RANKS * PEER_MAX_VALS * 2];
-        __shared__ int failed;
-        const int t = threadIdx.x;
-        if (t == 0) failed = 0;
-        __syncthreads();
-        const uint32_t seq = *pb.seq + 1u;                 // this exchange (same number on every rank)
-        const size_t par = (size_t)(seq & 1u) * PEER_MAX_RANKS;
-        if (t < pb.nranks * nacc * 2) {                    // thread = (peer rank r, value v, half hh)
-            const int hh = t & 1, v = (t >> 1) % nacc, r = (t >> 1) / nacc;
-            const unsigned long long bits = (unsigned long long)__double_as_longlong(sums[v]);
-            const unsigned long long word = ((unsigned long long)seq << 32) | (hh ? (bits >> 32) : (bits & 0xFFFFFFFFull));
-            unsigned long long* dst = pb.box[r] + ((par + pb.rank) * PEER_MAX_VALS + v) * 2 + hh;
-            __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            const unsigned long long* src = pb.box[pb.rank] + ((par + r) * PEER_MAX_VALS + v) * 2 + hh;
-            const long long t0 = wall_clock64();
-            unsigned long long w;
-            bool ok;
-            do {
-                w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                ok = (uint32_t)(w >> 32) == seq;
-            } while (!ok && (wall_clock64() - t0) < pb.timeout_ticks);
-            if (!ok) failed = 1;
-            halves[(r * PEER_MAX_VALS + v) * 2 + hh] = (uint32_t)w;
-        }
-        __syncthreads();
-        if (failed) {                                      // a peer never arrived: stop the solve, the host reports it
-            if (t == 0) { st->xchg_failed = 1; st->done = 1; }
-            return;
-        }
-        if (t < nacc) {
-            double s = 0.0;
-            for (int r = 0; r < pb.nranks; ++r) {          // rank order: every rank computes the same bits
-                const unsigned long long lo = halves[(r * PEER_MAX_VALS + t) * 2], hi = halves[(r * PEER_MAX_VALS + t) * 2 + 1];
-                s += __longlong_as_double((long long)((hi << 32) | lo));
-            }
-            reduced[t] = s;
-        }
-        if (t == 0) *pb.seq = seq;
+        (void)peer_exchange_wg(pb, sums, nacc, reduced, st);
     }
 }
 

@@ -696,14 +696,19 @@ int prox_affine_direct_block(fos_solver* h, const d2* x, d2* out, bool from_T = 
     prof_end(h, pe);
     po = prof_begin_other(h, 0);
     launch_blkdir_combine(cb, T, W3, V, h->blk_phg, h->blk_qphg, h->blk_prm, zero_kappa ? 1 : 0, out, p1, p2, fr);
-    if (sh) {
-        double* p3 = p1;                                               // (the prep records are spent)
-        launch_blkdir_tausum(cb, p2, h->blk_ctx, h->blk_n, p3);
-        LaunchCtx c3 = c; c3.partials = p3;
-        launch_reduce1(c3, 1, 1, 0);
-        FOS_TRY(allreduce(h, 1));
+    if (sh && h->peer_on && cb.peer) {
+        // mailbox transports: the tau kernel sums the rank's record, exchanges it and forms the tau row itself (one launch instead of three)
+        launch_blkdir_tau(cb, T, h->blk_qphg, h->blk_prm, zero_kappa ? 1 : 0, out, p1, p2, h->blk_ctx, h->blk_n, 2);
+    } else {
+        if (sh) {
+            double* p3 = p1;                                           // (the prep records are spent)
+            launch_blkdir_tausum(cb, p2, h->blk_ctx, h->blk_n, p3);
+            LaunchCtx c3 = c; c3.partials = p3;
+            launch_reduce1(c3, 1, 1, 0);
+            FOS_TRY(allreduce(h, 1));
+        }
+        launch_blkdir_tau(cb, T, h->blk_qphg, h->blk_prm, zero_kappa ? 1 : 0, out, p1, p2, h->blk_ctx, h->blk_n, fr);
     }
-    launch_blkdir_tau(cb, T, h->blk_qphg, h->blk_prm, zero_kappa ? 1 : 0, out, p1, p2, h->blk_ctx, h->blk_n, fr);
     prof_end(h, po);
     h->cgiter = 0;
     return check_launch("block-direct affine projection");

@@ -1260,13 +1260,28 @@ __global__ __launch_bounds__(FIN_THREADS) void blkdir_tausum_kernel(const double
     reduce_partials<1>(ctx_rec, nblk, sumc);
     if (threadIdx.x == 0) out1[0] = sumc[0] + sums[0];
 }
+//     PEER (mailbox transports): this kernel does the three steps itself -- the rank's record, its exchange through the mailboxes (the single-workgroup
+//     exchange of reduce_kernel<true>), the tau row -- ONE launch instead of three on the latency chain of every projection
+template <bool PEER>
 __global__ __launch_bounds__(FIN_THREADS) void blkdir_tau_kernel(const double* __restrict__ partials, int count, const double* __restrict__ ctx_rec, int nblk,
                                                                  const d2* __restrict__ T, const d2* __restrict__ qphg, int64_t l, const double* __restrict__ prm,
                                                                  int zero, const double* __restrict__ prep_partials, int nprep, d2* __restrict__ out,
-                                                                 const double* __restrict__ reduced, int from_reduced, const double* __restrict__ kap_in) {
+                                                                 const double* __restrict__ reduced, int from_reduced, const double* __restrict__ kap_in,
+                                                                 DevState* st, PeerBox pb) {
     __shared__ double kap[3];
     __shared__ double sums[1], sumc[1];
-    if (from_reduced) {
+    if constexpr (PEER) {
+        if (st->xchg_failed) return;
+        __shared__ double loc[1];
+        reduce_partials<1>(partials, count, sums);
+        reduce_partials<1>(ctx_rec, nblk, sumc);
+        if (threadIdx.x == 0) loc[0] = sumc[0] + sums[0];          // (the same expression as blkdir_tausum_kernel)
+        if (threadIdx.x < 3) kap[threadIdx.x] = kap_in[threadIdx.x];
+        __syncthreads();
+        if (!peer_exchange_wg(pb, loc, 1, sums, st)) return;
+        if (threadIdx.x == 0) sumc[0] = 0.0;
+        __syncthreads();
+    } else if (from_reduced) {
         if (threadIdx.x < 3) kap[threadIdx.x] = kap_in[threadIdx.x];
         if (threadIdx.x == 0) { sums[0] = reduced[0]; sumc[0] = 0.0; }
         __syncthreads();
@@ -1296,10 +1311,15 @@ void launch_blkdir_combine(const LaunchCtx& c, const double2* T, const double2* 
 void launch_blkdir_tausum(const LaunchCtx& c, const double* partials, const double* ctx_rec, int nblk, double* out1) {
     hipLaunchKernelGGL(blkdir_tausum_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, partials, c.vec_blocks, ctx_rec, nblk, out1);
 }
+// from_reduced: 0 = one GPU; 1 = the rank sums were all-reduced into c.reduced[0] (tausum + reduce + all-reduce in front); 2 = mailbox transport: this launch exchanges them itself
 void launch_blkdir_tau(const LaunchCtx& c, const double2* T, const double2* qphg, const double* prm, int zero_kappa, double2* out, const double* prep_partials,
                        const double* partials, const double* ctx_rec, int nblk, int from_reduced) {
-    hipLaunchKernelGGL(blkdir_tau_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, partials, c.vec_blocks, ctx_rec, nblk, T, qphg, c.l, prm, zero_kappa, prep_partials,
-                       c.vec_blocks, out, c.reduced, from_reduced, prm + 10);
+    if (from_reduced == 2 && c.peer)
+        hipLaunchKernelGGL(blkdir_tau_kernel<true>, dim3(1), dim3(FIN_THREADS), 0, c.stream, partials, c.vec_blocks, ctx_rec, nblk, T, qphg, c.l, prm, zero_kappa, prep_partials,
+                           c.vec_blocks, out, c.reduced, 1, prm + 10, c.st, *c.peer);
+    else
+        hipLaunchKernelGGL(blkdir_tau_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, c.stream, partials, c.vec_blocks, ctx_rec, nblk, T, qphg, c.l, prm, zero_kappa, prep_partials,
+                           c.vec_blocks, out, c.reduced, from_reduced, prm + 10, c.st, PeerBox{});
 }
 
 // ------------------------------------------------------------------------------------------------ layout conversion
