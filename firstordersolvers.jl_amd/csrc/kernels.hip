@@ -797,24 +797,32 @@ __device__ __forceinline__ void win_walk(const DevBlkCsr& S, const G& gat, Epi& 
             }
         }
         WIN_STAMP_G(2);
+        // row epilogue, two rows of a thread at a time (all four at once spills): what the FIRST two need from memory besides their sums is requested here, in front of
+        // the barrier that ends the walk, so that its latency passes beside the barrier instead of behind it; the second pair's while the first is finished
+        RowPre pa{}, pb{};
+        {
+            const int i = tid, i2 = tid + WIN_THREADS;
+            if (i < wp.nrows) pa = epi.pre(wp.row0 + i);
+            if (i2 < wp.nrows) pb = epi.pre(wp.row0 + i2);
+        }
         __syncthreads();
         WIN_STAMP_G(3);
-        // row epilogue, two rows of a thread at a time: what they need from memory is requested together (all four at once spills)
         for (int i = tid; i < wp.nrows; i += 2 * WIN_THREADS) {
-            const int i2 = i + WIN_THREADS;
+            const int i2 = i + WIN_THREADS, i3 = i + 2 * WIN_THREADS, i4 = i + 3 * WIN_THREADS;
             const bool h2 = i2 < wp.nrows;
-            const RowPre pa = epi.pre(wp.row0 + i);
-            RowPre pb = pa;
-            if (h2) pb = epi.pre(wp.row0 + i2);
+            RowPre na{}, nb{};                                 // the next pair
+            if (i3 < wp.nrows) na = epi.pre(wp.row0 + i3);
+            if (i4 < wp.nrows) nb = epi.pre(wp.row0 + i4);
             if constexpr (NRHS == 2) { const d2 a = acc[i]; win_finish_row<DEFER>(S, epi, wp.row0 + i, a.x, a.y, pa); }
             else win_finish_row<DEFER>(S, epi, wp.row0 + i, acc[i], 0.0, pa);
             if (h2) {
                 if constexpr (NRHS == 2) { const d2 a = acc[i2]; win_finish_row<DEFER>(S, epi, wp.row0 + i2, a.x, a.y, pb); }
                 else win_finish_row<DEFER>(S, epi, wp.row0 + i2, acc[i2], 0.0, pb);
             }
+            pa = na; pb = nb;
         }
         WIN_STAMP_G(4);
-        __syncthreads();                                   // before the next panel zeroes acc
+        if (p + (int)gridDim.x < S.npanel) __syncthreads();    // before the next panel zeroes acc (wave-uniform: p is the workgroup's)
     }
 }
 
