@@ -5,7 +5,8 @@ import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package()
 wl = sys.argv[1] if len(sys.argv) > 1 else "C4"
-prob = {"C4": pkg.workloads.c4_block_sdp, "C2": pkg.workloads.c2_lp, "C3": pkg.workloads.c3_socp, "C5": pkg.workloads.c5_mixed}[wl]()
+prob = {"C4": pkg.workloads.c4_block_sdp, "C2": pkg.workloads.c2_lp, "C3": pkg.workloads.c3_socp, "C5": pkg.workloads.c5_mixed,
+        "C4S": lambda: pkg.workloads.c4_block_sdp(nblocks=512, block_range=(0, 64))}[wl]()          # C4S: the 64 blocks one of eight ranks holds
 d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
 d.set_iterate(np.random.default_rng(0).standard_normal(d.N))
 ms = d.bench_kkt(50)
@@ -24,6 +25,10 @@ for a in np.arange(0.0, T, T / 12):
     b = a + T / 12
     res = ((s < b) & (e > a)).sum()
     print("  %5.1f - %5.1f us: resident workgroups (any overlap) %5d, starting %5d, ending %5d" % (a, b, res, ((s >= a) & (s < b)).sum(), ((e >= a) & (e < b)).sum()))
+allst = np.array(buf[:], dtype=np.int64).reshape(16384, 2)
+widx = np.nonzero(allst[:, 0] > 0)[0]
+order = np.argsort(-(e - s))[:24]
+print("slowest workgroups (blockIdx: start, duration us):", ", ".join("%d: %.1f %.1f" % (widx[k], s[k], (e - s)[k]) for k in order))
 if len(sys.argv) > 2:                                       # end times by XCD (blockIdx % 8) and by dispatch round (blockIdx // 256)
     idx = np.nonzero(np.array(buf[:], dtype=np.int64).reshape(16384, 2)[:, 0] > 0)[0]
     long_ = (e - s) > 0.5 * (e - s).max()
