@@ -462,10 +462,14 @@ def main():
         vec_n, vec_ms = cls["cgvec"]
         avg_vec_ms = vec_ms / max(1, vec_n)
         oth_n, oth_ms = cls["other"]                          # (sampled outer iterations, ms of every other launch group in them)
+        res_n, res_ms = cls.get("resident", (0, 0.0))         # FOS_CG_RESIDENT: whole CG solves run as one launch each (sampled solves, ms)
+        avg_res_ms = res_ms / max(1, res_n)
+        RES_KEY = "cg_resident_solve (ONE launch per CG solve: tiles and CG vectors in registers / LDS)"
         raw = {
             "kkt_sweep": avg_kernel_ms * cg_timed / (1e3 * elapsed) if elapsed > 0 else 0.0,
             "cg_vector_updates": avg_vec_ms * cg_timed / (1e3 * elapsed) if elapsed > 0 else 0.0,
             "psd_projection": avg_psd_ms * args.steps / (1e3 * elapsed) if elapsed > 0 and psd_n else 0.0,
+            RES_KEY: avg_res_ms * args.steps / (1e3 * elapsed) if elapsed > 0 and res_n else 0.0,      # (one solve per outer iteration)
             "other_launches (CG start sweep + r0 kernel, relaxations, elementwise/SOC/Exp cones, last pass)":
                 (oth_ms / oth_n) * args.steps / (1e3 * elapsed) if elapsed > 0 and oth_n else 0.0,
         }
@@ -477,15 +481,43 @@ def main():
         shares = {k: round(v / norm, 4) for k, v in raw.items()}
         shares["gaps_and_host_poll"] = round(max(0.0, 1.0 - raw_sum / norm), 4)
         shares["event_brackets_sum_before_normalisation"] = round(raw_sum, 4)
-        dominant = max((k for k in ("kkt_sweep", "cg_vector_updates", "psd_projection")), key=lambda k: shares[k] or 0.0)
+        dominant = max((k for k in ("kkt_sweep", "cg_vector_updates", "psd_projection", RES_KEY)), key=lambda k: shares[k] or 0.0)
+        if not res_n:
+            shares.pop(RES_KEY, None)
+        roof_res = None
+        if res_n:
+            # the resident solve reads the operator ONCE per solve (tiles -> registers) and the vectors x, rhs, v once, writes x once; between
+            # that nothing moves through HBM: its time is iterations x (sweep out of registers + one exchange of four doubles), i.e. latency
+            res_bytes = 8.0 * ost["vals"] + 48.0 * ost["blocks"] + 16.0 * nmr * 4 + 8.0 * nmr
+            its = cg_timed / max(1, args.steps)
+            roof_res = {
+                "bound": "hbm",
+                "kernel": "cg_resident_kernel: a whole CG solve (conjugategradients.jl:31-55) as one persistent launch -- dual tiles and CG vectors "
+                          "held in registers / LDS, four sums per iteration exchanged between workgroups as self-validating words",
+                "achieved": round(res_bytes / (avg_res_ms * 1e-3) / 1e9, 1) if avg_res_ms > 0 else 0.0,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(res_bytes / (avg_res_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_res_ms > 0 else 0.0,
+                "bytes_per_launch": res_bytes,
+                "bytes_basis": "the operator's stored tiles ONCE per solve + x, rhs, v in, x out; nothing else crosses HBM between the first and the last iteration",
+                "note": "NOT bandwidth bound by construction: the launch's time is iterations x (register-resident sweep + one exchange); the fraction of the "
+                        "HBM peak says how little HBM matters, the figure of merit is `us_per_cg_iteration` against the launch-per-iteration form's",
+                "avg_kernel_ms": round(avg_res_ms, 5), "launches_timed": res_n,
+                "cg_iterations_per_solve": round(its, 2),
+                "us_per_cg_iteration": round(1e3 * avg_res_ms / max(1e-9, its + 1), 3),
+                "resident_plan": dev.resident_stats(),
+                "kernel_share_of_step": shares.get(RES_KEY),
+                "traffic": None,
+            }
         # N > 1: every rank sweeps its own shard at the same time; the job's SpMV rate is the sum over ranks
         agg = None
         if dist is not None:
-            tt = torch.tensor([achieved], dtype=torch.float64, device=tdev)
+            tt = torch.tensor([roof_res["achieved"] if roof_res else achieved], dtype=torch.float64, device=tdev)
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
             agg = {"achieved_all_ranks": round(float(tt[0]), 1),
                    "frac_of_n_gpus_peak": round(float(tt[0]) / (HBM_PEAK_GBS * world), 4),
-                   "note": "this rank's KKT sweep on its shard is what `achieved` prices; the sum over the ranks is the job's rate"}
+                   "note": "this rank's KKT sweep (or resident solve) on its shard is what `achieved` prices; the sum over the ranks is the job's rate"}
+        if roof_res is not None:
+            roof_res["all_ranks"] = agg
         kname = "kkt2_kernel"
         if ost.get("win_panels", 0):                        # window panels; more than 2016 rows per panel = the tall geometry (fos_internal.hpp, WinTall)
             tall = nmr / ost["win_panels"] > 2016
@@ -588,7 +620,8 @@ def main():
                 "direct": direct_form,
                 "sweeps_per_step": round(cg_timed / max(1, args.steps), 2),
                 "cg_variant": dev.cg_variant_name(),
-                "cg_launches_per_iteration": 3 if dev.cg_variant_name() == "reference" else 2,
+                "cg_launches_per_iteration": {"reference": 3, "resident": 0}.get(dev.cg_variant_name(), 2),
+                "cg_launches_per_solve": 1 if dev.cg_variant_name() == "resident" else None,
                 "parallelism": "cone-sharded x%d (scalar sums: %s)" % (world, reduction) if dist is not None else "single GPU",
                 "peer_fallback_reason": peer_reason, "transport": transport if dist is not None else None,
                 "all_ranks_ms_per_step": per_rank_ms,
@@ -600,9 +633,11 @@ def main():
             },
             "dominant_kernel": dominant,
             "time_shares": shares,
-            "roofline": roof_kkt if dominant != "psd_projection" or roof_psd is None else roof_psd,
-            "roofline_kkt": roof_kkt if dominant == "psd_projection" and roof_psd is not None else "= roofline",
+            "roofline": roof_res if (dominant == RES_KEY and roof_res is not None) else (roof_kkt if dominant != "psd_projection" or roof_psd is None else roof_psd),
+            "roofline_kkt": (roof_kkt if dominant == "psd_projection" and roof_psd is not None else "= roofline") if not res_n else
+                            "no KKT sweep launches: the CG solves ran resident (roofline_resident)",
             "roofline_psd": roof_psd,
+            "roofline_resident": roof_res,
         }
         return out, dev, prob, alg, it
 
@@ -628,7 +663,7 @@ def main():
         out["weak_scaling"] = {k: wout[k] for k in ("value", "unit", "ms_per_step", "scaling", "warmup_effective")}
         out["weak_scaling"]["config"] = {k: wout["config"][k] for k in ("workload", "local_m", "local_n", "local_nnz", "cg_iters_per_step", "parallelism")}
         rk = wout["roofline_kkt"] if isinstance(wout["roofline_kkt"], dict) else wout["roofline"]
-        out["weak_scaling"]["roofline_kkt"] = {k: rk[k] for k in ("achieved", "frac", "avg_kernel_ms", "all_ranks")}
+        out["weak_scaling"]["roofline_kkt"] = {k: rk.get(k) for k in ("achieved", "frac", "avg_kernel_ms", "all_ranks")}
     if world > 1 and dist is not None and args.workload == "C4" and not args.direct and not args.no_direct_extra and not weak_main \
             and out["config"].get("transport") in ("peer", "host"):
         # the same sharded job under DR(direct = true): the block form's diagonal blocks are local to a rank, its three scalar sums per projection ride

@@ -15,7 +15,7 @@ FOS_OK = 0
 CONE_CODES = {"Free": 0, "Zero": 1, "NonNeg": 2, "NonPos": 3, "SOC": 4, "SOCRotated": 5, "SDP": 6,
               "ExpPrimal": 7, "ExpDual": 8}
 ALG_GAP, ALG_GAPA, ALG_FISTA, ALG_DYKSTRA = 0, 1, 2, 3
-CG_REFERENCE, CG_FUSED_P, CG_MERGED_SWEEP, CG_MERGED_UPDATE = 0, 1, 2, 3
+CG_REFERENCE, CG_FUSED_P, CG_MERGED_SWEEP, CG_MERGED_UPDATE, CG_RESIDENT = 0, 1, 2, 3, 4
 DEBUG_PUPDATE_DELAY = 1
 STATUS_NAMES = {0: "Continue", 1: "Optimal", 2: "Unbounded", 3: "Infeasible"}
 
@@ -100,11 +100,13 @@ PROTOTYPES = {
     "fos_psd_stats": (C.c_int, [_h, _i32p, C.c_int64, _i64p]),
     "fos_sync": (C.c_int, [_h]),
     "fos_host_stacked_spmv": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, C.c_int32, C.c_int32, _i64p]),
+    "fos_host_resident_cg": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, C.c_int32, _dp, _dp, C.c_double, C.c_int64, _i64p, _i64p]),
     "fos_host_stacked_spmv_mode": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, C.c_int32, _i64p]),
     "fos_window_stats": (C.c_int, [_h, _i64p]),
     "fos_set_tuning": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32]),
     "fos_set_cg_variant": (C.c_int, [_h, C.c_int32]),
     "fos_get_cg_variant": (C.c_int, [_h, _i32p]),
+    "fos_resident_stats": (C.c_int, [_h, _i64p]),
     "fos_debug_set": (C.c_int, [_h, C.c_int32, C.c_int64]),
     "fos_set_gapp": (C.c_int, [_h, C.c_int64]),
     "fos_gapp_log": (C.c_int, [_h, _dp]),

@@ -21,6 +21,7 @@
 // Row blocks are then split among the persistent wavefronts of the SpMV grid, balanced by stored entries.
 #include <algorithm>
 #include <cstdarg>
+#include <cmath>
 #include <cstdlib>
 
 #include "fos_internal.hpp"
@@ -413,7 +414,11 @@ int build_stacked_csr(int64_t m, int64_t n, const int64_t* colptr, const int64_t
             // worth it only if the lane-major tile (64 lanes x padded steps) stores no more than the two copies it replaces
             const int64_t nch = (alen[i] + tcmax - 1) / tcmax;
             const int64_t steps = (alen[i] - (nch - 1) * tcmax + TILE_GROUP - 1) / TILE_GROUP * TILE_GROUP + (nch - 1) * tcmax;
-            if (j - i >= TILE_MIN_ROWS && 64 * steps <= 2 * (j - i) * alen[i]) {
+            // (round 6: the ragged LAST group of a stack of full tiles over the same columns is a tile whatever its padding -- a block of 136 or
+            //  528 rows then consists of tiles only, which is what the resident CG solve needs; one tile more per block)
+            const bool continues_stack = !groups.empty() && groups.back().R == 64 && groups.back().i0 + 64 == i &&
+                                         groups.back().c0 == first_col[n + i] && groups.back().C == alen[i] && nch == 1;
+            if ((j - i >= TILE_MIN_ROWS && 64 * steps <= 2 * (j - i) * alen[i]) || continues_stack) {
                 Group g;
                 g.i0 = i; g.R = (int)(j - i); g.c0 = first_col[n + i]; g.C = alen[i];
                 g.nchunk = (int)((g.C + tcmax - 1) / tcmax);
@@ -1017,6 +1022,185 @@ int host_stacked_spmv(const HostBlkCsr& S, const double* v, double* out, std::st
     if (defer)
         for (int64_t r = 0; r < S.nrows; ++r)
             if (S.row_defer[r] >= 0 && swept[r] != 1) return fail("deferred row with entries not swept exactly once:", r);
+    return FOS_OK;
+}
+
+// The plan of a RESIDENT CG solve (fos_internal.hpp, resident.hip): which workgroup holds which tiles.  Qualifies: an operator that is
+// nothing but single-height dual tiles with complete rows (every row of A inside ONE tile: at most 64 columns per unit), whose units --
+// the tiles over one run of columns -- have disjoint column ranges that cover all n columns (a block-diagonal A with dense blocks: C4 and
+// its shards), and whose largest workgroup share fits the registers: at most 12 tiles of <= 32 steps (one per wavefront), 16 (two per
+// wavefront of eight) or 8 tiles of <= 64 steps.
+bool build_resident_plan(const HostBlkCsr& S, int64_t m, int64_t n, int gmax, ResPlan* out) {
+    *out = ResPlan();
+    auto no = [&](const char* why) { out->why = why; out->G = 0; out->wg.clear(); return false; };
+    if (!S.wpanel.empty()) return no("window panels");
+    if (S.row_sharded) return no("row-sharded operator");
+    if (S.nblk <= 0 || (int64_t)S.blk.size() != S.nblk) return no("no row blocks");
+    if (gmax < 1) return no("no workgroups");
+    struct Unit { int32_t blk0, nblk, c0, tc, T; };
+    std::vector<Unit> units;
+    int64_t rows = 0;
+    int tmax = 0;
+    for (int32_t b = 0; b < S.nblk; ++b) {
+        const BlkDesc& d = S.blk[b];
+        if (d.kind() != BLK_TILE) return no("a row block that is not a dual tile");
+        if (d.tall() != 1) return no("tall tiles");
+        if (d.meta[2] >= 0) return no("rows spread over column chunks");
+        if (d.steps() > 64 || d.steps() < 1) return no("tile wider than 64 steps");
+        if (d.row0 < n) return no("tile outside the rows of A");
+        rows += d.nrows();
+        tmax = std::max(tmax, d.steps());
+        if (!units.empty() && units.back().c0 == d.meta[0] && units.back().tc == d.meta[3] && units.back().T == d.steps()) units.back().nblk += 1;
+        else units.push_back(Unit{b, 1, d.meta[0], d.meta[3], d.steps()});
+    }
+    if (rows != m) return no("rows of A outside the tiles");
+    {   // disjoint column ranges that cover [0, n)
+        std::vector<std::pair<int32_t, int32_t>> rng;
+        for (const Unit& u : units) rng.emplace_back(u.c0, u.tc);
+        std::sort(rng.begin(), rng.end());
+        int64_t at = 0;
+        for (const auto& r : rng) {
+            if (r.first != at) return no("the units' column ranges overlap or leave columns out");
+            at += r.second;
+        }
+        if (at != n) return no("columns of A outside the units");
+    }
+    if ((int64_t)units.size() > gmax) return no("more units than workgroups");
+    if (gmax > RES_GMAX) gmax = RES_GMAX;
+    // tiles per workgroup: the smallest tp whose workgroup count fits
+    int64_t total = S.nblk;
+    int tp = (int)std::max<int64_t>(1, (total + gmax - 1) / gmax);
+    for (;; ++tp) {
+        int64_t G = 0;
+        bool ok = true;
+        for (const Unit& u : units) {
+            const int w = (u.nblk + tp - 1) / tp;
+            if (w > RES_WPU_MAX) ok = false;
+            G += w;
+        }
+        if (ok && G <= gmax) break;
+        if (tp > RES_SLOTS) return no("a workgroup would hold more than 16 tiles");
+    }
+    int tiles_max = 0;
+    for (const Unit& u : units) {
+        const int w = (u.nblk + tp - 1) / tp;
+        for (int k = 0; k < w; ++k) {
+            const int t0 = (int)((int64_t)k * u.nblk / w), t1 = (int)((int64_t)(k + 1) * u.nblk / w);
+            tiles_max = std::max(tiles_max, t1 - t0);
+        }
+    }
+    int nw, rpt;
+    if (tmax <= 32 && tiles_max <= 12) { nw = tiles_max; rpt = 1; }
+    else if (tmax <= 32 && tiles_max <= 16) { nw = 8; rpt = 2; }
+    else if (tiles_max <= 8) { nw = tiles_max; rpt = 1; }
+    else return no("a workgroup's tiles do not fit the registers");
+    out->tmax = tmax <= 32 ? 32 : 64;
+    out->nw = nw; out->rpt = rpt; out->tiles_wg_max = tiles_max; out->units = (int)units.size();
+    for (const Unit& u : units) {
+        const int w = (u.nblk + tp - 1) / tp;
+        const int wg0 = (int)out->wg.size();
+        for (int k = 0; k < w; ++k) {
+            const int t0 = (int)((int64_t)k * u.nblk / w), t1 = (int)((int64_t)(k + 1) * u.nblk / w);
+            out->wg.push_back(ResWG{u.blk0 + t0, t1 - t0, u.c0, u.tc, u.T, wg0, w, k});
+        }
+    }
+    out->G = (int)out->wg.size();
+    return true;
+}
+
+// Host emulation of the resident CG solve (resident.hip): the same plan walked workgroup by workgroup -- tiles out of the tile storage,
+// a workgroup's partial column sums, the unit's totals over its workgroups, the four sums of an iteration as per-workgroup partials (rows by
+// their lanes, a unit's columns once, by its first workgroup, the bilinear share of w.r by whoever holds the partial column sum) -- and the
+// merged-reduction recurrence around it.  Checks the plan and the arithmetic without a GPU (CPU tests); not a product path.
+int host_resident_cg(const HostBlkCsr& S, const ResPlan& P, int64_t m, int64_t n, const double* cb, double2* x, const double2* rhs, const double2* v0,
+                     double tol, int maxit, int* iters) {
+    const int64_t nm = n + m, l = nm + 1;
+    std::vector<double2> r((size_t)l), p((size_t)l, double2{0.0, 0.0}), sv((size_t)l, double2{0.0, 0.0}), w((size_t)l), g(v0, v0 + l);
+    std::vector<std::vector<double2>> colpart(P.wg.size());
+    auto sweep = [&](const double2 gt, double (&tot)[4]) {
+        tot[1] = tot[2] = tot[3] = 0.0;
+        for (size_t q = 0; q < P.wg.size(); ++q) {
+            const ResWG& me = P.wg[q];
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            std::vector<double2>& cp = colpart[q];
+            cp.assign((size_t)me.tc, double2{0.0, 0.0});
+            for (int ti = 0; ti < me.nblk; ++ti) {
+                const BlkDesc& d = S.blk[me.blk0 + ti];
+                for (int lane = 0; lane < d.nrows(); ++lane) {
+                    const int64_t row = d.row0 + lane;
+                    double u1 = 0.0, u2 = 0.0;
+                    for (int t = 0; t < me.tc; ++t) {
+                        const double a = S.val[d.nnz0 + 64 * (int64_t)t + lane];
+                        u1 += a * g[me.c0 + t].x; u2 += a * g[me.c0 + t].y;
+                        cp[t].x += a * g[row].x; cp[t].y += a * g[row].y;
+                    }
+                    const double c = cb[row];
+                    const double q1 = -(u1 - gt.x * c), q2 = -(u2 - gt.y * c);
+                    w[row] = double2{g[row].x - q2, q1 - g[row].y};
+                    acc[1] += w[row].x * g[row].x + w[row].y * g[row].y;
+                    acc[2] += c * g[row].x; acc[3] += c * g[row].y;
+                }
+            }
+            for (int t = 0; t < me.tc; ++t) {
+                const double2 gc = g[me.c0 + t];
+                const double cc = cb[me.c0 + t];
+                acc[1] += cp[t].x * gc.y - cp[t].y * gc.x;
+                if (me.idx == 0) {
+                    acc[1] += (gc.x * gc.x - gc.y * gc.y) + cc * (gt.x * gc.y - gt.y * gc.x);
+                    acc[2] += cc * gc.x; acc[3] += cc * gc.y;
+                }
+            }
+            for (int k = 1; k < 4; ++k) tot[k] += acc[k];
+        }
+        for (size_t q = 0; q < P.wg.size(); ++q) {              // a unit's column sums: its workgroups in order
+            const ResWG& me = P.wg[q];
+            if (me.idx != 0) continue;
+            for (int t = 0; t < me.tc; ++t) {
+                double2 ct{0.0, 0.0};
+                for (int k = 0; k < me.wpu; ++k) { ct.x += colpart[me.wg0 + k][t].x; ct.y += colpart[me.wg0 + k][t].y; }
+                const double2 gc = g[me.c0 + t];
+                const double cc = cb[me.c0 + t];
+                const double q1 = ct.x + gt.x * cc, q2 = ct.y + gt.y * cc;
+                w[me.c0 + t] = double2{gc.x - q2, q1 - gc.y};
+            }
+        }
+    };
+    auto rr_sum = [&]() { double sacc = 0.0; for (int64_t i = 0; i < nm; ++i) sacc += r[i].x * r[i].x + r[i].y * r[i].y; return sacc; };
+    double tot[4] = {0.0, 0.0, 0.0, 0.0};
+    double2 gt = g[nm];
+    sweep(gt, tot);
+    {
+        const double2 wt{gt.x + tot[3], -tot[2] - gt.y};
+        for (int64_t i = 0; i < nm; ++i) r[i] = double2{rhs[i].x - w[i].x, rhs[i].y - w[i].y};
+        r[nm] = double2{rhs[nm].x - wt.x, rhs[nm].y - wt.y};
+    }
+    double g_prev = 0.0, a_prev = 0.0;
+    int it = 0;
+    for (int i = 0;; ++i) {
+        g = r;
+        gt = r[nm];
+        tot[0] = rr_sum();
+        sweep(gt, tot);
+        const double gam = tot[0] + (gt.x * gt.x + gt.y * gt.y);
+        if (i > 0 && (std::sqrt(gam) <= tol || i >= maxit)) { it = i; break; }
+        const double2 wt{gt.x + tot[3], -tot[2] - gt.y};
+        w[nm] = wt;
+        const double delta = tot[1] + (wt.x * gt.x + wt.y * gt.y);
+        double beta = 0.0, alpha;
+        if (i == 0) alpha = gam / delta;
+        else { beta = gam / g_prev; alpha = gam / (delta - beta * gam / a_prev); }
+        g_prev = gam; a_prev = alpha;
+        for (int64_t k = 0; k < l; ++k) {
+            if (i == 0) { p[k] = r[k]; sv[k] = w[k]; }
+            else {
+                p[k].x = p[k].x * beta + r[k].x; p[k].y = p[k].y * beta + r[k].y;
+                sv[k].x = sv[k].x * beta + w[k].x; sv[k].y = sv[k].y * beta + w[k].y;
+            }
+            x[k].x += alpha * p[k].x; x[k].y += alpha * p[k].y;
+            r[k].x -= alpha * sv[k].x; r[k].y -= alpha * sv[k].y;
+        }
+    }
+    *iters = it;
     return FOS_OK;
 }
 

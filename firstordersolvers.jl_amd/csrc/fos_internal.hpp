@@ -420,6 +420,40 @@ void launch_cgm_apply(const LaunchCtx& c, const CgmIter& it, const double2* v);
 void launch_cgm_start(const LaunchCtx& c, const CgmIter& it, const double2* rhs, const double2* v, double tol, int maxit,
                       double2* p_out = nullptr);     // p_out: also p_1 = r_0 (the reference recurrence started this way)
 
+// RESIDENT CG (round 6; resident.hip): the merged-reduction recurrence above as ONE launch per solve, for operators that are
+// nothing but dual tiles of a block-separable A (a block-diagonal SDP: C4 and its shards) and small enough per workgroup to be
+// HELD IN REGISTERS.  A UNIT = the tiles over one run of <= 64 columns of A (one diagonal block); its tiles are dealt to `wpu`
+// consecutive workgroups, one tile per (wavefront, slot): lane = row keeps its row's values, its vector elements x, r, p, s, w
+// and [c;b] in registers for the whole solve, the unit's <= 64 column elements are replicated in every workgroup of the unit.
+// Per iteration nothing crosses workgroups but (i) the four sums {r.r, w.r, [c;b].r1, [c;b].r2} -- every workgroup publishes its
+// record as self-validating words (the mailboxes' trick) and adds all G records in workgroup order: the same bits everywhere, no
+// grid barrier, no L2 write-back or invalidate -- and (ii) the unit's column sums between its `wpu` workgroups, the same way.
+// Across GPUs the four sums go on through the handle's mailboxes (peer_fold_sum), exactly as in cgm_update_kernel.
+struct ResWG { int32_t blk0, nblk, c0, tc, T, wg0, wpu, idx; };     // 32 bytes: tiles blk0 .. blk0 + nblk - 1 of S.blk, the unit's columns [c0, c0 + tc), T steps;
+                                                                    // the unit's workgroups wg0 .. wg0 + wpu - 1, this one is number idx
+constexpr int RES_GMAX = 512;        // workgroups of a resident solve (records every workgroup adds)
+constexpr int RES_WPU_MAX = 16;      // workgroups per unit
+constexpr int RES_SLOTS = 16;        // tiles per workgroup
+struct ResPlan {                     // host
+    int G = 0, nw = 0, rpt = 0, tmax = 0, tiles_wg_max = 0, units = 0;
+    std::vector<ResWG> wg;
+    std::string why;                 // why the operator does not qualify (G == 0)
+};
+// the plan for at most `gmax` workgroups; false (and why) when the operator does not qualify
+bool build_resident_plan(const HostBlkCsr& S, int64_t m, int64_t n, int gmax, ResPlan* out);
+// host emulation of the resident solve over the same plan (CPU tests of the plan and of the arithmetic; csr_build.cpp)
+int host_resident_cg(const HostBlkCsr& S, const ResPlan& P, int64_t m, int64_t n, const double* cb, double2* x, const double2* rhs, const double2* v0,
+                     double tol, int maxit, int* iters);
+struct ResLaunch {
+    const ResWG* wg; int G, nw, rpt, tmax;
+    unsigned long long* grec;        // [2][G][4][2] words: the workgroups' records of the four sums
+    unsigned long long* crec;        // [2][G][tmax][2][2] words: the workgroups' column sums (units of more than one workgroup)
+    int64_t timeout_ticks;
+};
+// x (in: the start iterate, out: the solution), r_0 = rhs - M v; fold != nullptr: the sums cross the ranks through the mailboxes
+void launch_cg_resident(const LaunchCtx& c, const ResLaunch& rl, double2* x, const double2* rhs, const double2* v, double tol, int maxit,
+                        const PeerBox* fold, uint32_t seq_base);
+
 // single right-hand side Q apply on component `comp` of an interleaved vector
 //   Q_PLAIN : out_plain[i] = sign * (Q v)_i            (rows 0..n+m-1; tau row by q1_finalize)
 //   Q_RHS   : out[i] = (x[i].x - (Q x.y)_i, 0)         (affinepluslinear.jl:94-95 with beta=1, q=0, b=0)

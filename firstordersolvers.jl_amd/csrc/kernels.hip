@@ -157,31 +157,7 @@ __device__ __forceinline__ void finish_row(const DevBlkCsr& S, Epi& epi, int row
     epi.row(row, a1, a2, pr);
 }
 
-// Column sums of a dual tile.  Every lane holds p[u] = (its row's value in column u) x (its row's vector element) for 8
-// consecutive columns; returns, in EVERY lane, the sum over all 64 lanes for column (lane & 7).  Three halving stages
-// inside each group of 8 lanes (a lane keeps half of its values and trades the other half with a partner that keeps
-// the complementary half: i <-> 7-i, i <-> i^2, i <-> i^1), then three full additions (i^8, i^16, i^32): 7 + 3 adds
-// instead of 8 x 6, and a fixed summation order.
-__device__ __forceinline__ double tile_colsum8(const double (&p)[8], int lane) {
-    const bool b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
-    double q[4], r[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const double keep = b2 ? p[4 + j] : p[j], send = b2 ? p[j] : p[4 + j];
-        q[j] = keep + dpp_f64<0x141>(send);            // row_half_mirror: columns 4 b2 + j
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const double keep = b1 ? q[2 + j] : q[j], send = b1 ? q[j] : q[2 + j];
-        r[j] = keep + dpp_f64<0x4E>(send);             // quad_perm [2,3,0,1]: columns 4 b2 + 2 b1 + j
-    }
-    const double keep = b0 ? r[1] : r[0], send = b0 ? r[0] : r[1];
-    double s = keep + dpp_f64<0xB1>(send);             // quad_perm [1,0,3,2]: column lane & 7
-    s += dpp_f64<0x128>(s);                            // row_ror:8  (lane ^ 8)
-    s = swap_sum<16>(s);                               // + the neighbouring row of 16 lanes
-    s = swap_sum<32>(s);                               // + the other half of the wavefront
-    return s;
-}
+// (tile_colsum8 -- the column sums of a dual tile -- lives in dev_common.hpp: the resident CG kernel uses it too)
 
 // NR long run-rows over the same column range [c00, c00+cnt): each gathered element feeds NR matrix values
 template <int NR, bool DEFER, class G, class Epi>

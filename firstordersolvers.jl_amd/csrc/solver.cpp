@@ -169,6 +169,12 @@ struct fos_solver {
     uint32_t* def_mask = nullptr;              // bit i: row i of S is finished from partial slots (dual tiles)
     bool fuse_p = false;                       // the p update of CG rides on the next sweep (2 launches per iteration)
     int cg_variant = -1;                       // FOS_CG_*: -1 = the handle's default (sharded: merged reduction, closing in the update)
+    // FOS_CG_RESIDENT (resident.hip): the plan (which workgroup holds which tiles), its device copy and the workgroups' record arrays
+    ResPlan res_plan;
+    ResLaunch res{};
+    bool res_ok = false;                       // this handle's operator qualifies (under the current workgroup budget)
+    bool res_all = false;                      // ... and so does every rank's (sharded: the vote of global_setup)
+    int res_gmax = 0;                          // the budget the plan was made for
 
     // algorithm (gap.jl:6-21, gapa.jl:9-25, fista.jl:6-18, dykstra.jl:5-17)
     int alg = FOS_ALG_GAP;
@@ -258,7 +264,7 @@ struct fos_solver {
     struct ProfRec { hipEvent_t a, b; int cls; int j; };
     std::vector<ProfRec> prof_recs;            // event pairs, reused
     size_t prof_used = 0;
-    int64_t prof_seen[FOS_PROF_CLASSES] = {0, 0, 0, 0};
+    int64_t prof_seen[FOS_PROF_CLASSES] = {0, 0, 0, 0, 0};
     int64_t prof_steps = 0, prof_steps_sampled = 0;   // outer iterations since fos_profile / of them sampled for FOS_PROF_OTHER
     bool prof_step_on = false;                 // the outer iteration in flight brackets its FOS_PROF_OTHER groups
     static constexpr size_t PROF_CAP = 16384;
@@ -412,7 +418,8 @@ int poll_state(fos_solver* h) {
         return FOS_ECOMM;
     }
     if (h->st_host->bar_failed) {
-        set_error("cg_update_kernel: the producer workgroups' flags did not arrive within 5 s; set FOS_CG_PRE=0");
+        set_error("a wait between the workgroups of one launch timed out (cg_update_kernel's producer flags: FOS_CG_PRE=0 switches them off; "
+                  "the resident CG solve's records: FOS_CG_VARIANT=3 runs the launch-per-iteration form)");
         return FOS_EHIP;
     }
     return FOS_OK;
@@ -449,8 +456,50 @@ int wait_cg_mark(fos_solver* h, uint32_t epoch, int32_t batch_id, bool* ended) {
     return FOS_OK;
 }
 
+// FOS_CG_RESIDENT: (re)plan the resident solve for at most `gmax` workgroups -- every one of them must be on the device at once, so ranks that
+// share ONE device (the tests' stand-in for a multi-GPU box) share its CUs
+int resident_setup(fos_solver* h, int gmax) {
+    if (const char* e = getenv("FOS_RESIDENT_GMAX")) gmax = std::max(1, std::min(gmax, atoi(e)));      // (tests: several tiles per workgroup on small problems)
+    if (h->res_gmax == gmax) return FOS_OK;
+    h->res_gmax = gmax;
+    h->res_ok = false;
+    ResPlan plan;
+    if (!build_resident_plan(h->hostS, h->m, h->n, gmax, &plan)) { h->res_plan = plan; h->res_all = false; return FOS_OK; }
+    FOS_HIP(hipStreamSynchronize(h->stream));
+    if (!h->res.grec) {
+        FOS_TRY(dev_alloc(h, &h->res.grec, (size_t)2 * RES_GMAX * 8));
+        FOS_TRY(dev_alloc(h, &h->res.crec, (size_t)2 * RES_GMAX * 64 * 4));
+        FOS_HIP(hipMemset(h->res.grec, 0, sizeof(unsigned long long) * 2 * RES_GMAX * 8));        // sequence number 0 is never sent
+        FOS_HIP(hipMemset(h->res.crec, 0, sizeof(unsigned long long) * 2 * RES_GMAX * 64 * 4));
+    }
+    ResWG* dwg = const_cast<ResWG*>(h->res.wg);
+    dev_release(h, &dwg);
+    FOS_TRY(dev_upload(h, &dwg, plan.wg));
+    h->res.wg = dwg; h->res.G = plan.G; h->res.nw = plan.nw; h->res.rpt = plan.rpt; h->res.tmax = plan.tmax;
+    static const double res_wait_s = getenv("FOS_RESIDENT_WAIT_S") ? atof(getenv("FOS_RESIDENT_WAIT_S")) : 5.0;
+    h->res.timeout_ticks = (int64_t)(res_wait_s * 1e8);
+    h->res_plan = plan;
+    h->res_ok = true;
+    h->res_all = !h->sharded();
+    return FOS_OK;
+}
+
 // sharded set-up: global problem size and norms (tolerance floor, status normalisation) from the shards'
 int global_setup(fos_solver* h) {
+    // the resident CG solve runs on a sharded handle only where EVERY rank's shard qualifies (all ranks must run the same exchanges) and
+    // the sums cross the ranks through mailboxes (no collective call can sit inside a kernel): a vote through the handle's transport
+    FOS_TRY(resident_setup(h, (h->peer_same_device && h->nranks > 1) ? std::max(1, h->cus / h->nranks) : h->cus));
+    h->res_all = false;
+    if (h->peer_on) {
+        LaunchCtx cv = h->ctx();
+        double q = h->res_ok ? 1.0 : 0.0;
+        FOS_HIP(hipMemcpyAsync(h->partials, &q, sizeof(q), hipMemcpyHostToDevice, h->stream));
+        launch_reduce1(cv, 1, 1, 0);
+        FOS_TRY(allreduce(h, 1));
+        FOS_HIP(hipMemcpyAsync(&q, h->reduced, sizeof(q), hipMemcpyDeviceToHost, h->stream));
+        FOS_TRY(poll_state(h));
+        h->res_all = q == (double)h->nranks;
+    }
     LaunchCtx c = h->ctx();
     const bool cnt = !h->row_sharded || h->rank == 0;     // row-sharded: the n columns and c are replicated, counted by rank 0
     double loc[3] = {(double)(h->m + (cnt ? h->n : 0)), h->nb_local * h->nb_local, cnt ? h->nc_local * h->nc_local : 0.0};
@@ -498,6 +547,7 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
     // launches, one reduction point); sharded handles take the latter by default and always close in the update kernel
     int32_t variant = FOS_CG_REFERENCE;
     FOS_TRY(fos_get_cg_variant(h, &variant));
+    const bool resident = variant == FOS_CG_RESIDENT;
     const bool merged = variant == FOS_CG_MERGED_SWEEP || variant == FOS_CG_MERGED_UPDATE;
     const bool close_in_update = variant == FOS_CG_MERGED_UPDATE;
     const bool fuse_p = variant == FOS_CG_FUSED_P;
@@ -540,6 +590,31 @@ int cg_solve(fos_solver* h, d2* x, const d2* rhs, double tol, int maxit, int64_t
         launch_reduce1(c2, c.cg_blocks, 1, 1);
         return allreduce(h, 4);
     };
+    if (resident) {
+        // the whole solve is ONE launch (resident.hip): nothing to enqueue ahead, nothing to predict; what follows the solve is enqueued behind it
+        // (gated on DevState.done, which the launch sets when it ends) and the host reads the iteration count from the mark the launch leaves
+        const int pe = prof_begin(h, FOS_PROF_RESIDENT, 1, h->prof_seen[FOS_PROF_RESIDENT]++);
+        launch_cg_resident(c, h->res, x, rhs, apply_on ? apply_on : x, tol, maxit, fold ? &h->peer : nullptr, seq_base);
+        prof_end(h, pe);
+        if (spec) {
+            LaunchCtx cg = c;
+            cg.gate = &h->st->done;
+            FOS_TRY((*post)(cg));
+            bool ended = false;
+            FOS_TRY(wait_cg_mark(h, (uint32_t)(seq_base >> 11), batch_id, &ended));
+            if (!ended) { set_error("resident CG solve %u ended without its mark", (unsigned)(seq_base >> 11)); return FOS_EHIP; }
+            if (post_ran) *post_ran = true;
+        } else {
+            FOS_TRY(poll_state(h));
+            if (!h->st_host->done) { set_error("resident CG solve %u did not finish", (unsigned)(seq_base >> 11)); return FOS_EHIP; }
+        }
+        *iters = h->st_host->iter;
+        h->cg_same_run = (h->st_host->iter == h->last_cg_pred) ? h->cg_same_run + 1 : 0;
+        h->last_cg_pred = h->st_host->iter;
+        h->cg_total += h->st_host->iter;
+        if (h->st_host->hit_max) h->hit_max_accum = 1;
+        return FOS_OK;
+    }
     if (merged) {
         // start: sweep M v, ONE launch for r = rhs - M v (+ r.r records, tau row, slot-spread rows, the solve's scalars), then
         // w_0 = M r_0, the sweep every iteration's update starts from (it also adds g_0 = r_0.r_0 unless the first update does)
@@ -1883,7 +1958,7 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     // 64-block shard: 13 -> 20 us against 5 us), so it stays an option (fos_set_tuning / FOS_CG_FUSE_P)
     h->fuse_p = false;
     if (const char* e = getenv("FOS_CG_FUSE_P")) h->fuse_p = atoi(e) != 0;
-    if (const char* e = getenv("FOS_CG_VARIANT")) h->cg_variant = std::max(-1, std::min((int)FOS_CG_MERGED_UPDATE, atoi(e)));
+    if (const char* e = getenv("FOS_CG_VARIANT")) h->cg_variant = std::max(-1, std::min((int)FOS_CG_RESIDENT, atoi(e)));
     h->S.npart = h->S.nwg_def > 0 ? h->S.nwg_def : h->S.nwg;
     h->S.part_off = h->S.nwg_def > 0 ? h->S.nwg : 0;
     // free the big host arrays (keep block table for re-partitioning)
@@ -1966,6 +2041,7 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     FOS_HIP(hipMemset(h->reduced, 0, sizeof(double) * 16));
     if (const char* e = getenv("FOS_CG_CHUNK")) h->cg_chunk = std::max(1, atoi(e));
 
+    FOS_TRY(resident_setup(h, cus));                      // FOS_CG_RESIDENT: does the operator qualify, and the plan if so
     FOS_TRY(fos_set_alg(h, FOS_ALG_GAP, 0.8, 1.8, 1.8, 0.0));
     FOS_TRY(fos_set_iterate(h, nullptr));
     FOS_HIP(hipStreamSynchronize(h->stream));
@@ -2329,7 +2405,7 @@ int fos_peer_enable(fos_handle h, int32_t on) {
     h->peer_on = on != 0;
     if (h->sharded()) return global_setup(h);
     h->l_global = h->l; h->nb = h->nb_local; h->nc = h->nc_local;
-    return FOS_OK;
+    return resident_setup(h, h->cus);          // (the whole device is this handle's again)
 }
 
 int fos_set_alg(fos_handle h, int alg, double alpha, double alpha1, double alpha2, double beta) {
@@ -2813,8 +2889,8 @@ int fos_profile_read_classes(fos_handle h, int64_t* launches3, double* total_ms3
     if (!h) { set_error("NULL handle"); return FOS_EINVAL; }
     FOS_HIP(hipSetDevice(h->device));
     FOS_HIP(hipStreamSynchronize(h->stream));
-    int64_t n[FOS_PROF_CLASSES] = {0, 0, 0, 0};
-    double t[FOS_PROF_CLASSES] = {0.0, 0.0, 0.0, 0.0};
+    int64_t n[FOS_PROF_CLASSES] = {0, 0, 0, 0, 0};
+    double t[FOS_PROF_CLASSES] = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (size_t i = 0; i < h->prof_used; ++i) {
         const auto& r = h->prof_recs[i];
         if (r.cls < 0 || r.cls >= FOS_PROF_CLASSES) continue;
@@ -2982,6 +3058,33 @@ int fos_bench_cg_chain(fos_handle h, int32_t iters, int32_t reps, int32_t use_gr
     return FOS_OK;
 }
 
+int fos_host_resident_cg(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval, const double* b, const double* c,
+                         int32_t gmax, double* x, const double* rhs, double tol, int64_t max_iters, int64_t* iters, int64_t* stats8) {
+    if (!colptr || m < 0 || n < 0 || gmax < 1 || (x && (!rhs || !b || !c || max_iters < 1))) { set_error("bad argument"); return FOS_EINVAL; }
+    HostBlkCsr S;
+    const int cus = 256;                       // (the operator as fos_create builds it on a 256-CU device)
+    FOS_TRY(build_stacked_csr(m, n, colptr, rowval, nzval, cus * 12, &S, cus * 28, -1, false, cus * 16));
+    ResPlan P;
+    const bool ok = build_resident_plan(S, m, n, gmax, &P);
+    if (stats8) {
+        stats8[0] = ok ? 1 : 0; stats8[1] = P.G; stats8[2] = P.nw; stats8[3] = P.rpt; stats8[4] = P.units; stats8[5] = P.tiles_wg_max; stats8[6] = P.tmax; stats8[7] = ok ? 1 : 0;
+    }
+    if (!ok) { set_error("FOS_CG_RESIDENT: the operator does not qualify (%s)", P.why.c_str()); return x ? FOS_EUNSUPPORTED : FOS_OK; }
+    if (!x) return FOS_OK;
+    const int64_t l = n + m + 1;
+    std::vector<double> cb((size_t)(n + m));
+    for (int64_t j = 0; j < n; ++j) cb[j] = c[j];
+    for (int64_t i = 0; i < m; ++i) cb[n + i] = b[i];
+    std::vector<double2> xv((size_t)l), rv((size_t)l);
+    for (int64_t i = 0; i < l; ++i) { xv[i] = double2{x[i], x[l + i]}; rv[i] = double2{rhs[i], rhs[l + i]}; }      // plain [part1; part2] -> interleaved
+    std::vector<double2> v0(xv);
+    int it = 0;
+    FOS_TRY(host_resident_cg(S, P, m, n, cb.data(), xv.data(), rv.data(), v0.data(), tol, (int)std::min<int64_t>(max_iters, 1 << 30), &it));
+    for (int64_t i = 0; i < l; ++i) { x[i] = xv[i].x; x[l + i] = xv[i].y; }
+    if (iters) *iters = it;
+    return FOS_OK;
+}
+
 int fos_host_stacked_spmv(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
                           const double* v, double* out, int32_t spmv_workgroups, int32_t resident_waves, int64_t* stats) {
     if (!colptr || !v || !out || m < 0 || n < 0) { set_error("bad argument"); return FOS_EINVAL; }
@@ -3055,7 +3158,11 @@ int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int3
 
 // which CG recurrence the affine projection runs (FOS_CG_*; -1: the handle's default)
 int fos_set_cg_variant(fos_handle h, int32_t variant) {
-    if (!h || variant < -1 || variant > FOS_CG_MERGED_UPDATE) { set_error("unknown CG variant %d", (int)variant); return FOS_EINVAL; }
+    if (!h || variant < -1 || variant > FOS_CG_RESIDENT) { set_error("unknown CG variant %d", (int)variant); return FOS_EINVAL; }
+    if (variant == FOS_CG_RESIDENT && !h->res_ok) {
+        set_error("FOS_CG_RESIDENT: the operator does not qualify (%s)", h->res_plan.why.empty() ? "no plan" : h->res_plan.why.c_str());
+        return FOS_EUNSUPPORTED;
+    }
     h->cg_variant = variant;
     if (variant >= 0) h->fuse_p = variant == FOS_CG_FUSED_P;
     h->last_cg_pred = 0; h->cg_same_run = 0;
@@ -3073,9 +3180,25 @@ int fos_get_cg_variant(fos_handle h, int32_t* variant) {
     // iteration counting and stop test; FOS_CG_VARIANT=0 / fos_set_cg_variant restore the reference recurrence everywhere.
     int v = h->cg_variant >= 0 ? h->cg_variant
             : (h->fuse_p ? FOS_CG_FUSED_P : ((h->sharded() || (h->S.resident && !h->row_sharded && h->l >= 32768)) ? FOS_CG_MERGED_UPDATE : FOS_CG_REFERENCE));
+    // the resident solve: on request wherever the operator qualifies; by default on sharded handles whose sums travel through mailboxes and
+    // whose shards ALL qualify (FOS_RESIDENT_DEFAULT=0: never by default).  Sharded without mailboxes (RCCL, the caller's collective): a
+    // collective call cannot sit inside a kernel -- the launch-per-iteration form of the same recurrence runs instead.
+    static const bool res_default = !(getenv("FOS_RESIDENT_DEFAULT") && atoi(getenv("FOS_RESIDENT_DEFAULT")) == 0);
+    const bool res_usable = h->res_ok && !h->row_sharded && (!h->sharded() || (h->peer_on && fold_env && h->res_all));
+    if (h->cg_variant < 0 && !h->fuse_p && h->sharded() && res_usable && res_default) v = FOS_CG_RESIDENT;
+    if (v == FOS_CG_RESIDENT && !res_usable) v = FOS_CG_MERGED_UPDATE;
     if (v == FOS_CG_MERGED_SWEEP && h->sharded()) v = FOS_CG_MERGED_UPDATE;
     if (v == FOS_CG_MERGED_UPDATE && h->peer_on && !fold_env) v = FOS_CG_REFERENCE;
     *variant = v;
+    return FOS_OK;
+}
+
+int fos_resident_stats(fos_handle h, int64_t* stats8) {
+    if (!h || !stats8) { set_error("NULL argument"); return FOS_EINVAL; }
+    const ResPlan& p = h->res_plan;
+    stats8[0] = h->res_ok ? 1 : 0; stats8[1] = p.G; stats8[2] = p.nw; stats8[3] = p.rpt; stats8[4] = p.units; stats8[5] = p.tiles_wg_max;
+    stats8[6] = p.tmax; stats8[7] = (h->sharded() ? h->res_all : h->res_ok) ? 1 : 0;
+    if (!h->res_ok) set_error("FOS_CG_RESIDENT: %s", p.why.empty() ? "no plan" : p.why.c_str());
     return FOS_OK;
 }
 

@@ -446,15 +446,23 @@ class HipHSDE:
         _lib.check(self._lib.fos_set_tuning(self._h, spmv_workgroups, cg_chunk, fuse_p))
 
     def set_cg_variant(self, variant):
-        """which CG recurrence the affine projection runs: 'reference' | 'fused_p' | 'merged_sweep' | 'merged_update' | None (default)."""
+        """which CG recurrence the affine projection runs: 'reference' | 'fused_p' | 'merged_sweep' | 'merged_update' | 'resident' | None (default).
+        'resident' (one launch per solve, operator and vectors in registers) raises FosError(FOS_EUNSUPPORTED) when the operator does not qualify."""
         codes = {None: -1, "default": -1, "reference": _lib.CG_REFERENCE, "fused_p": _lib.CG_FUSED_P,
-                 "merged_sweep": _lib.CG_MERGED_SWEEP, "merged_update": _lib.CG_MERGED_UPDATE}
+                 "merged_sweep": _lib.CG_MERGED_SWEEP, "merged_update": _lib.CG_MERGED_UPDATE, "resident": _lib.CG_RESIDENT}
         _lib.check(self._lib.fos_set_cg_variant(self._h, codes[variant] if not isinstance(variant, int) else variant))
 
     def cg_variant_name(self):
         v = C.c_int32(0)
         _lib.check(self._lib.fos_get_cg_variant(self._h, C.byref(v)))
-        return ("reference", "fused_p", "merged_sweep", "merged_update")[v.value]
+        return ("reference", "fused_p", "merged_sweep", "merged_update", "resident")[v.value]
+
+    def resident_stats(self):
+        """The plan of the resident CG solve (foship.h fos_resident_stats)."""
+        st = (C.c_int64 * 8)()
+        _lib.check(self._lib.fos_resident_stats(self._h, st))
+        keys = ("qualifies", "workgroups", "waves_per_workgroup", "tiles_per_wave", "units", "max_tiles_per_workgroup", "steps_per_tile", "all_ranks_qualify")
+        return {k: int(st[i]) for i, k in enumerate(keys)}
 
     def debug_set(self, what, value):
         _lib.check(self._lib.fos_debug_set(self._h, int(what), int(value)))
@@ -462,10 +470,10 @@ class HipHSDE:
     def profile_read_classes(self):
         """{'kkt' | 'psd' | 'cgvec': (launch groups, summed ms), 'other': (sampled outer iterations, summed ms of every other launch
         group in them)} of the bracketed launches since the last read."""
-        n = (C.c_int64 * 4)()
-        ms = (C.c_double * 4)()
+        n = (C.c_int64 * 5)()
+        ms = (C.c_double * 5)()
         _lib.check(self._lib.fos_profile_read_classes(self._h, n, ms))
-        return {k: (n[i], ms[i]) for i, k in enumerate(("kkt", "psd", "cgvec", "other"))}
+        return {k: (n[i], ms[i]) for i, k in enumerate(("kkt", "psd", "cgvec", "other", "resident"))}
 
     def psd_debug(self, collect_stats=True, phase_limit=0):
         _lib.check(self._lib.fos_psd_debug(self._h, 1 if collect_stats else 0, int(phase_limit)))

@@ -311,7 +311,7 @@ int fos_get_cg_total(fos_handle h, int64_t* total);  /* CG iterations run since 
 int fos_profile_read(fos_handle h, int64_t* launches, double* total_ms, double* bytes_per_launch);
 /* The same records split by class of launch group (arrays of FOS_PROF_CLASSES entries): the KKT sweep of a CG iteration,
  * the batched PSD projection of one cone-prox call (cones.jl:89-94 over all PSD cones), the CG vector update(s) of an
- * iteration (arrays of FOS_PROF_CLASSES = 4 entries).  Resets the records like fos_profile_read. */
+ * iteration (arrays of FOS_PROF_CLASSES = 5 entries).  Resets the records like fos_profile_read. */
 #define FOS_PROF_KKT 0
 #define FOS_PROF_PSD 1
 #define FOS_PROF_CGVEC 2
@@ -319,8 +319,10 @@ int fos_profile_read(fos_handle h, int64_t* launches, double* total_ms, double* 
  * cones, the step's last pass -- bracketed group by group in every prof_period-th OUTER ITERATION; for this class launches[] counts the sampled
  * iterations, so total_ms / launches = milliseconds per outer iteration */
 #define FOS_PROF_OTHER 3
-#define FOS_PROF_CLASSES 4
-int fos_profile_read_classes(fos_handle h, int64_t* launches4, double* total_ms4);
+/* a whole CG solve run as ONE launch (FOS_CG_RESIDENT): every prof_period-th solve is bracketed */
+#define FOS_PROF_RESIDENT 4
+#define FOS_PROF_CLASSES 5
+int fos_profile_read_classes(fos_handle h, int64_t* launches5, double* total_ms5);
 /* fos_bench_cg_chain: `iters` CG iterations (conjugategradients.jl:37-51; sweep + update [+ p update]) on the current
  * iterate as right-hand side with the stop test disabled, enqueued eagerly (use_graph = 0) or captured ONCE into a hipGraph
  * and replayed `reps` times (use_graph = 1); *ms_per_iter by HIP events.  Measurement only: it answers whether graph replay
@@ -341,6 +343,13 @@ int fos_sync(fos_handle h);
  * matrix entries held in tiles.  Used by the CPU test-suite. */
 int fos_host_stacked_spmv(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
                           const double* v, double* out, int32_t spmv_workgroups, int32_t resident_waves, int64_t* stats);
+/* Host-only check of FOS_CG_RESIDENT (no GPU needed): builds the operator as fos_create does on a 256-CU device, plans the resident solve for at most
+ * `gmax` workgroups (stats8 as fos_resident_stats) and -- x != NULL -- runs conjugategradient!(x, KKTMatrix(Q), rhs; tol, max_iters)
+ * (conjugategradients.jl:31-55) on the HOST by walking the plan the way the kernel does: tiles per workgroup, partial column sums per workgroup, the
+ * unit's totals, per-workgroup partial sums of the four reductions.  x, rhs: plain N = 2 (n + m + 1) vectors.  Returns FOS_EUNSUPPORTED (x != NULL)
+ * when the operator does not qualify; with x == NULL only the plan is made.  Used by the CPU test-suite. */
+int fos_host_resident_cg(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval, const double* b, const double* c,
+                         int32_t gmax, double* x, const double* rhs, double tol, int64_t max_iters, int64_t* iters, int64_t* stats8);
 /* the same with the storage choice forced: window_mode 0 = row blocks / dual tiles, 1 = window panels (any size), -1 = as
  * fos_create decides; stats16 (may be NULL) = the 12 statistics above followed by the 4 of fos_window_stats */
 int fos_host_stacked_spmv_mode(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
@@ -359,12 +368,24 @@ int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int3
  *                         reduction point carrying r.r and w.r; the sweep closes the iteration            (2 launches, single GPU only)
  *   FOS_CG_MERGED_UPDATE  the same, the update kernel closes the iteration: ONE exchange of four doubles per iteration
  *                         when sharded; the sweep of the last iteration runs for nothing                  (2 launches; default for sharded handles)
+ *   FOS_CG_RESIDENT       the arithmetic of FOS_CG_MERGED_UPDATE as ONE launch per SOLVE: the operator's dual tiles and the five CG
+ *                         vectors stay in the registers of persistent workgroups from the first to the last iteration, the four sums
+ *                         of an iteration cross the workgroups (and, sharded, the GPUs) as self-validating words -- no grid barrier.
+ *                         For operators that are nothing but dual tiles of a block-separable A whose share per workgroup fits the
+ *                         register file (a block-diagonal SDP on enough GPUs: the eighth of C4 = 133 KB per CU); sharded: device or
+ *                         host-pinned mailboxes only.  fos_set_cg_variant returns FOS_EUNSUPPORTED when the operator does not qualify
+ *                         (fos_last_error says why); the default of sharded handles on the mailboxes whenever every rank's shard qualifies.
  * variant = -1 restores the handle's default (FOS_CG_REFERENCE on one GPU). */
 #define FOS_CG_REFERENCE     0
 #define FOS_CG_FUSED_P       1
 #define FOS_CG_MERGED_SWEEP  2
 #define FOS_CG_MERGED_UPDATE 3
+#define FOS_CG_RESIDENT      4
 int fos_set_cg_variant(fos_handle h, int32_t variant);
+/* The plan of FOS_CG_RESIDENT for this handle (conjugategradients.jl:31-55 as one launch): stats8 = {qualifies (0 / 1), workgroups, wavefronts
+ * per workgroup, tiles per wavefront, units (runs of columns = diagonal blocks), most tiles in one workgroup, steps per tile (32 / 64),
+ * every rank qualifies (sharded handles: the vote of fos_peer_enable; else = qualifies)}. */
+int fos_resident_stats(fos_handle h, int64_t* stats8);
 int fos_get_cg_variant(fos_handle h, int32_t* variant);   /* the variant the next projection runs (defaults resolved) */
 
 /* test hooks.  FOS_DEBUG_PUPDATE_DELAY: every workgroup but the first of the kernel that closes a CG iteration waits `value`

@@ -61,12 +61,15 @@ def _operator_vs_oracle(prob, d, rng, tol=1e-12):
     assert np.linalg.norm(d.q_apply(e) - ref) <= tol * max(1.0, np.linalg.norm(ref))
 
 
-def _same_step_vs_oracle(pkg, prob, alg, oalg, warm, tol):
+def _same_step_vs_oracle(pkg, prob, alg, oalg, warm, tol, cg_variant=None):
     """ONE outer iteration of the device and of the oracle from the same steady-state point (iterate, CG warm start, call counter,
     GAPA's alpha12 handed over): solverwrapper.jl:23-29 -> step -> prox!(S1) (CG to the tolerance floor) -> prox!(S2) -> relaxations."""
     import fos_oracle as orc
     BIG = 10 ** 12
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+    if cg_variant is not None:
+        d.set_cg_variant(cg_variant)
+        assert d.cg_variant_name() == cg_variant
     d.set_alg(alg)
     d.set_iterate(None)
     done, _, _ = d.step(1, warm, BIG, 1e-8)
