@@ -1079,7 +1079,7 @@ bool build_resident_plan(const HostBlkCsr& S, int64_t m, int64_t n, int gmax, Re
             G += w;
         }
         if (ok && G <= gmax) break;
-        if (tp > RES_SLOTS) return no("a workgroup would hold more than 16 tiles");
+        if (tp > RES_SLOTS) return no("a workgroup would hold more tiles than its registers");
     }
     int tiles_max = 0;
     for (const Unit& u : units) {
@@ -1089,11 +1089,14 @@ bool build_resident_plan(const HostBlkCsr& S, int64_t m, int64_t n, int gmax, Re
             tiles_max = std::max(tiles_max, t1 - t0);
         }
     }
-    int nw, rpt;
-    if (tmax <= 32 && tiles_max <= 12) { nw = tiles_max; rpt = 1; }
-    else if (tmax <= 32 && tiles_max <= 16) { nw = 8; rpt = 2; }
-    else if (tiles_max <= 8) { nw = tiles_max; rpt = 1; }
+    // what a workgroup can hold: kernel <32 steps, 1 tile per wavefront, 12 wavefronts> up to 11 compute wavefronts (+ 1..3 that communicate);
+    // <32, 2, 8> seven compute wavefronts of two tiles + one that communicates; <64, 1, 8> seven of one tile + one
+    int nw, rpt, ncomm;
+    if (tmax <= 32 && tiles_max <= 11) { nw = tiles_max; rpt = 1; ncomm = std::min(3, 12 - nw); }
+    else if (tmax <= 32 && tiles_max <= 14) { nw = 7; rpt = 2; ncomm = 1; }
+    else if (tiles_max <= 7) { nw = tiles_max; rpt = 1; ncomm = 1; }
     else return no("a workgroup's tiles do not fit the registers");
+    out->ncomm = ncomm;
     out->tmax = tmax <= 32 ? 32 : 64;
     out->nw = nw; out->rpt = rpt; out->tiles_wg_max = tiles_max; out->units = (int)units.size();
     for (const Unit& u : units) {

@@ -11,8 +11,10 @@ typedef double2 d2;
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    // (bound_ctrl = true: a source lane that does not exist or is switched off reads as 0 -- what `old = 0` said before, but without the
+    //  v_mov_b32 dst, 0 the tied `old` operand cost in front of EVERY DPP move: 160 of the ~900 vector instructions of a resident tile sweep)
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 // v + (v of the lane 16 / 32 away), every lane, without the LDS crossbar: gfx950's v_permlane{16,32}_swap exchanges the odd
@@ -78,6 +80,23 @@ __device__ __forceinline__ double tile_colsum8(const double (&p)[8], int lane) {
     s += dpp_f64<0x128>(s);                            // row_ror:8  (lane ^ 8)
     s = swap_sum<16>(s);                               // + the neighbouring row of 16 lanes
     s = swap_sum<32>(s);                               // + the other half of the wavefront
+    return s;
+}
+
+// The same sums for products that are ALREADY in the lane's own order (the resident CG kernel chooses the register layout of its tiles: position k of
+// a group holds column (lane & 7) ^ TILE_SORT[k]), so that every halving stage keeps the first half of what it holds and trades the second: no selects
+// (4 v_cndmask per pair in tile_colsum8: 224 of a tile sweep's instructions).  Same pairs, same order of additions, same result in lane (lane & 7).
+__device__ __forceinline__ constexpr int tile_sort(int k) { return k < 4 ? k : 11 - k; }          // {0, 1, 2, 3, 7, 6, 5, 4}
+__device__ __forceinline__ double tile_colsum8_sorted(const double (&p)[8]) {
+    double q[4], r[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = p[j] + dpp_f64<0x141>(p[4 + j]);      // row_half_mirror
+#pragma unroll
+    for (int j = 0; j < 2; ++j) r[j] = q[j] + dpp_f64<0x4E>(q[2 + j]);       // quad_perm [2,3,0,1]
+    double s = r[0] + dpp_f64<0xB1>(r[1]);                                   // quad_perm [1,0,3,2]: column lane & 7
+    s += dpp_f64<0x128>(s);                                                  // row_ror:8  (lane ^ 8)
+    s = swap_sum<16>(s);
+    s = swap_sum<32>(s);
     return s;
 }
 

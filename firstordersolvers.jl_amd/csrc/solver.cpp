@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <rccl/rccl.h>
 #include <functional>
@@ -200,6 +201,7 @@ struct fos_solver {
     double* blk_prm = nullptr;                 // the 3 x 3 inverse of the border system (9), delta = 1 + |[c; b]|^2
     double* blk_ctx = nullptr;                 // [blk_n] the blocks' shares of c'x^ (blkdir_solve_kernel)
     bool blk_skip_tail = true;                 // the third apply runs without its deferred-row and tau-row kernels (FOS_BLKDIR_FULL_APPLY=1: with them)
+    bool blk_ready = false;                    // blkdir_setup ran to its end (a half-finished set-up must not pass for the block form)
 
     // S1 = AffinePlusLinear state (affinepluslinear.jl:58-69)
     int64_t prox_i = 1;
@@ -234,6 +236,7 @@ struct fos_solver {
     bool peer_on = false;
     // host-pinned mailboxes (fos_peer_open_host): the mapped + registered shm segment, its name (rank 0 unlinks it), the local relay
     void* host_seg = nullptr;
+    int host_seg_fd = -1;                      // kept open: fos_peer_selftest asks it whether the mapped segment is still linked under its name
     size_t host_seg_bytes = 0;
     std::string host_seg_name;
     unsigned long long* peer_relay = nullptr;
@@ -467,15 +470,25 @@ int resident_setup(fos_solver* h, int gmax) {
     if (!build_resident_plan(h->hostS, h->m, h->n, gmax, &plan)) { h->res_plan = plan; h->res_all = false; return FOS_OK; }
     FOS_HIP(hipStreamSynchronize(h->stream));
     if (!h->res.grec) {
-        FOS_TRY(dev_alloc(h, &h->res.grec, (size_t)2 * RES_GMAX * 8));
-        FOS_TRY(dev_alloc(h, &h->res.crec, (size_t)2 * RES_GMAX * 64 * 4));
+        // the records live in UNCACHED device memory, as the mailboxes do (measured: an exchange 0.3 us shorter than with ordinary memory and
+        // cache-bypassing accesses -- profiles/r06_res_exp*.txt; FOS_RES_UNCACHED=0: ordinary memory)
+        const bool unc = !(getenv("FOS_RES_UNCACHED") && atoi(getenv("FOS_RES_UNCACHED")) == 0);
+        void *q1 = nullptr, *q2 = nullptr;
+        const size_t b1 = sizeof(unsigned long long) * 2 * RES_GMAX * 8, b2 = sizeof(unsigned long long) * 2 * RES_GMAX * 64 * 4;
+        hipError_t e1 = unc ? hipExtMallocWithFlags(&q1, b1, hipDeviceMallocUncached) : hipErrorUnknown;
+        if (e1 != hipSuccess) { (void)hipGetLastError(); e1 = hipMalloc(&q1, b1); }
+        hipError_t e2 = unc ? hipExtMallocWithFlags(&q2, b2, hipDeviceMallocUncached) : hipErrorUnknown;
+        if (e2 != hipSuccess) { (void)hipGetLastError(); e2 = hipMalloc(&q2, b2); }
+        if (e1 != hipSuccess || e2 != hipSuccess) { set_error("resident CG: allocating the workgroups' record arrays failed"); return FOS_ENOMEM; }
+        h->owned.push_back(q1); h->owned.push_back(q2);
+        h->res.grec = static_cast<unsigned long long*>(q1); h->res.crec = static_cast<unsigned long long*>(q2);
         FOS_HIP(hipMemset(h->res.grec, 0, sizeof(unsigned long long) * 2 * RES_GMAX * 8));        // sequence number 0 is never sent
         FOS_HIP(hipMemset(h->res.crec, 0, sizeof(unsigned long long) * 2 * RES_GMAX * 64 * 4));
     }
     ResWG* dwg = const_cast<ResWG*>(h->res.wg);
     dev_release(h, &dwg);
     FOS_TRY(dev_upload(h, &dwg, plan.wg));
-    h->res.wg = dwg; h->res.G = plan.G; h->res.nw = plan.nw; h->res.rpt = plan.rpt; h->res.tmax = plan.tmax;
+    h->res.wg = dwg; h->res.G = plan.G; h->res.nw = plan.nw; h->res.ncomm = plan.ncomm; h->res.rpt = plan.rpt; h->res.tmax = plan.tmax;
     static const double res_wait_s = getenv("FOS_RESIDENT_WAIT_S") ? atof(getenv("FOS_RESIDENT_WAIT_S")) : 5.0;
     h->res.timeout_ticks = (int64_t)(res_wait_s * 1e8);
     h->res_plan = plan;
@@ -766,8 +779,10 @@ int prox_affine_direct_block(fos_solver* h, const d2* x, d2* out, bool from_T = 
     launch_blkdir_solve(cb, h->blk_n, h->blk_goff, h->blk_ioff, h->blk_idx, h->blk_ginv, Rr, T, W3, h->blk_ctx);
     prof_end(h, po);
     pe = prof_begin(h, FOS_PROF_KKT, 1, h->direct_sweeps++);
-    // V.y = -A q, V.x = A x^ on the rows of A -- rows the sweep finishes itself; with dual tiles neither the rows of A' nor the tau row (c'x^: the solve kernel's records) are needed
-    FOS_TRY(kkt_apply_full(h, c, W3, V, !h->blk_skip_tail, !h->blk_skip_tail));
+    // V.y = -A q, V.x = A x^ on the rows of A -- rows the sweep finishes itself; with dual tiles neither the rows of A' nor the tau row (c'x^: the solve kernel's records) are needed.
+    // The tau row of THIS apply is needed by nobody, and on a sharded handle its reduce would overwrite the prep sums in c.reduced that blkdir_combine reads
+    // (from_reduced) and add an exchange that only some ranks make: never run there.  The deferred-row kernel runs where rows of A are slot-spread.
+    FOS_TRY(kkt_apply_full(h, c, W3, V, !h->blk_skip_tail, !h->blk_skip_tail && !sh));
     prof_end(h, pe);
     po = prof_begin_other(h, 0);
     launch_blkdir_combine(cb, T, W3, V, h->blk_phg, h->blk_qphg, h->blk_prm, zero_kappa ? 1 : 0, out, p1, p2, fr);
@@ -2061,6 +2076,7 @@ int fos_destroy(fos_handle h) {
     if (h->host_seg) {
         (void)hipHostUnregister(h->host_seg);
         (void)munmap(h->host_seg, h->host_seg_bytes);
+        if (h->host_seg_fd >= 0) close(h->host_seg_fd);
         if (h->rank == 0 && !h->host_seg_name.empty()) (void)shm_unlink(h->host_seg_name.c_str());
     }
     for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -2205,13 +2221,33 @@ int fos_peer_open_host(fos_handle h, int nranks, int rank, const char* shm_name,
     FOS_HIP(hipSetDevice(h->device));
     // (one more page behind the mailbox words: every rank's device identity, so that ranks which share a device can find out -- fos_peer_selftest)
     const size_t bytes = ((PEER_BOX_TOTAL_WORDS * sizeof(unsigned long long) + 4095) / 4096) * 4096 + 4096;
-    // every rank creates-or-opens and sizes the segment (idempotent; a fresh segment is zero filled: sequence number 0 is never sent)
-    const int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
-    if (fd < 0) { set_error("shm_open(%s): %s", shm_name, strerror(errno)); return FOS_ECOMM; }
-    if (ftruncate(fd, (off_t)bytes) != 0) { const int e = errno; close(fd); set_error("ftruncate(%s, %zu): %s", shm_name, bytes, strerror(e)); return FOS_ECOMM; }
+    // Rank 0 CREATES the segment -- exclusively, after unlinking whatever a crashed run left under the name: a fresh segment is zero filled (sequence number 0
+    // is never sent), a reused one would carry sequence-tagged words that validate themselves.  The other ranks open it WITHOUT creating, waiting for it to
+    // appear at its full size.  A rank that was quick enough to open a stale segment before rank 0 unlinked it holds an unlinked file: fos_peer_selftest
+    // (behind the caller's barrier) sees st_nlink == 0 on the descriptor kept here and fails the self test.
+    int fd = -1;
+    if (rank == 0) {
+        (void)shm_unlink(shm_name);
+        fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 && errno == EEXIST) { (void)shm_unlink(shm_name); fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600); }
+        if (fd < 0) { set_error("shm_open(%s, O_CREAT | O_EXCL): %s", shm_name, strerror(errno)); return FOS_ECOMM; }
+        if (ftruncate(fd, (off_t)bytes) != 0) { const int e = errno; close(fd); (void)shm_unlink(shm_name); set_error("ftruncate(%s, %zu): %s", shm_name, bytes, strerror(e)); return FOS_ECOMM; }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        const double wait_s = timeout_s > 0 ? std::max(timeout_s, 5.0) : 20.0;
+        for (;;) {
+            fd = shm_open(shm_name, O_RDWR, 0600);
+            if (fd >= 0) {
+                struct stat sb;
+                if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) break;
+                close(fd); fd = -1;
+            } else if (errno != ENOENT) { set_error("shm_open(%s): %s", shm_name, strerror(errno)); return FOS_ECOMM; }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_s) { set_error("shm_open(%s): rank 0 did not create the segment within %.0f s", shm_name, wait_s); return FOS_ECOMM; }
+            usleep(1000);
+        }
+    }
     void* seg = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (seg == MAP_FAILED) { set_error("mmap(%s): %s", shm_name, strerror(errno)); return FOS_ECOMM; }
+    if (seg == MAP_FAILED) { const int e = errno; close(fd); if (rank == 0) (void)shm_unlink(shm_name); set_error("mmap(%s): %s", shm_name, strerror(e)); return FOS_ECOMM; }
     hipError_t e = hipHostRegister(seg, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
     void* dptr = nullptr;
     if (e == hipSuccess) e = hipHostGetDevicePointer(&dptr, seg, 0);
@@ -2220,9 +2256,12 @@ int fos_peer_open_host(fos_handle h, int nranks, int rank, const char* shm_name,
         (void)hipHostUnregister(seg);
         (void)hipGetLastError();
         munmap(seg, bytes);
+        close(fd);
+        if (rank == 0) (void)shm_unlink(shm_name);
         set_error("hipHostRegister / hipHostGetDevicePointer(%s): %s", shm_name, hipGetErrorString(e));
         return FOS_ECOMM;
     }
+    h->host_seg_fd = fd;
     h->host_seg = seg; h->host_seg_bytes = bytes; h->host_seg_name = shm_name;
     {
         char bus[64] = {0};
@@ -2271,6 +2310,7 @@ int fos_peer_close(fos_handle h) {
     if (h->host_seg) {
         (void)hipHostUnregister(h->host_seg);
         (void)munmap(h->host_seg, h->host_seg_bytes);
+        if (h->host_seg_fd >= 0) { close(h->host_seg_fd); h->host_seg_fd = -1; }
         if (h->rank == 0 && !h->host_seg_name.empty()) (void)shm_unlink(h->host_seg_name.c_str());
         h->host_seg = nullptr; h->host_seg_bytes = 0; h->host_seg_name.clear();
     }
@@ -2292,6 +2332,16 @@ int fos_peer_selftest(fos_handle h, int rounds, int32_t* ok) {
     if (!h || !ok) { set_error("NULL argument"); return FOS_EINVAL; }
     if (!h->peer.box) { set_error("fos_peer_selftest before fos_peer_open"); return FOS_EINVAL; }
     FOS_HIP(hipSetDevice(h->device));
+    if (h->host_seg && h->host_seg_fd >= 0) {
+        // (the caller's barrier stands between the opens and this call: rank 0 has unlinked and re-created the segment by now -- a descriptor whose
+        //  file is no longer linked is a segment some crashed run left behind, opened before rank 0 got to it)
+        struct stat sb;
+        if (fstat(h->host_seg_fd, &sb) != 0 || sb.st_nlink == 0) {
+            set_error("rank %d mapped a stale shared-memory segment under %s (a crashed run's): the self test fails, use another transport or name", h->peer.rank, h->host_seg_name.c_str());
+            *ok = 0;
+            return FOS_OK;
+        }
+    }
     if (h->host_seg) {
         // host-pinned mailboxes: do ranks share THIS device (tests: several ranks on one GPU)?  Every rank left its device's identity behind the
         // mailbox words when it opened the segment, and the caller's barrier stands between the opens and this call.  A shared device keeps the
@@ -2438,7 +2488,7 @@ int fos_set_alg(fos_handle h, int alg, double alpha, double alpha1, double alpha
 int fos_enable_direct(fos_handle h, const int64_t* colptr, const int64_t* rowval, const double* nzval) {
     if (!h || !colptr || (!rowval && colptr[h->n] > 1)) { set_error("NULL argument"); return FOS_EINVAL; }
     if (h->row_sharded) { set_error("direct=true is not available on row-sharded handles"); return FOS_EUNSUPPORTED; }
-    if (h->Ginv || h->blk_ginv) { h->direct = true; h->direct_blk = h->blk_ginv != nullptr; return FOS_OK; }
+    if (h->Ginv || (h->blk_ginv && h->blk_ready)) { h->direct = true; h->direct_blk = h->blk_ginv != nullptr && h->blk_ready; return FOS_OK; }
     const int64_t l = h->l, nnz = colptr[h->n] - 1;
     // which exact form (FOS_DIRECT_MODE=block|dense|cg forces one; default: the first that applies)
     const char* mode_env = getenv("FOS_DIRECT_MODE");
@@ -2449,7 +2499,7 @@ int fos_enable_direct(fos_handle h, const int64_t* colptr, const int64_t* rowval
         FOS_HIP(hipSetDevice(h->device));
         bool ok = false;
         FOS_TRY(blkdir_setup(h, colptr, rowval, nzval, &ok));
-        if (ok) { h->direct_blk = true; h->direct = true; return FOS_OK; }
+        if (ok) { h->blk_ready = true; h->direct_blk = true; h->direct = true; return FOS_OK; }
         if (mode == "block") { set_error("FOS_DIRECT_MODE=block: A'A has a diagonal block of more than %d columns", BLKDIR_MAX); return FOS_EUNSUPPORTED; }
     }
     // cone-sharded handles: only the block form (its three scalar exchanges per projection go through the handle's transport); collective -- every rank
