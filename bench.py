@@ -331,6 +331,29 @@ def main():
             peer_reason = "; ".join("%s: %s" % (t, w) for t, w in reasons.items()) or None
             if want == "rccl":
                 peer_reason = "FOS_REDUCTION=rccl"
+        # ---- what a failure analysis of an N-rank run needs, measured here so that the line carries it (no reference equivalent: SURVEY 2.2 C1):
+        # the cost of one exchange on the chosen transport per rank, who can reach whose memory, the resident solve's plan per rank
+        diagnostics = None
+        if dist is not None:
+            try:
+                ex_us = dev.exchange_bench(200)
+            except Exception as exc:  # noqa: BLE001
+                ex_us = "failed: %s" % exc
+            try:
+                nd = torch.cuda.device_count()
+                acc = [[1 if (a == b or torch.cuda.can_device_access_peer(a, b)) else 0 for b in range(nd)] for a in range(nd)] if not host_gloo else None
+            except Exception as exc:  # noqa: BLE001
+                acc = "query failed: %s" % exc
+            try:
+                rst = dev.resident_stats()
+            except Exception as exc:  # noqa: BLE001
+                rst = {"failed": repr(exc)}
+            mine_diag = {"rank": rank, "device": local_rank, "exchange_us": ex_us, "resident": rst, "cg_variant": dev.cg_variant_name()}
+            every_diag = [None] * world
+            dist.all_gather_object(every_diag, mine_diag)
+            diagnostics = {"transport": transport, "per_rank": every_diag, "hipDeviceCanAccessPeer": acc,
+                           "exchange_us_note": "one exchange of four doubles on the chosen transport, 200 back to back in stream (mailboxes: inside one launch)",
+                           "passed_over": reasons}
         if args.spmv_wg:
             dev.set_tuning(spmv_workgroups=args.spmv_wg)
         direct_form = None
@@ -424,13 +447,14 @@ def main():
         stored_bytes = (8.0 * ost["vals"] + 4.0 * ost["cols"] + 48.0 * ost["blocks"] + 16.0 * ost["slots"]
                         + 16.0 * nmr + 8.0 * nmr + 16.0 * nmr)
         # (2) the same from rocprofv3 PMC passes of the latest round's kernels (tools/gpu_profile_r03.sh -> profiles/), when committed
-        traffic, traffic_src = None, None
+        traffic, traffic_src, trace_us = None, None, None
         try:
             cands = sorted(Path(ROOT / "profiles").glob("r0*_kkt_traffic.json"))          # the latest round's PMC passes
             # (a FOS_BENCH_SHARD run sweeps a SHARD: the full-size counter bytes do not describe its launches -- the stored-format model does)
             if cands and not args.small and world == 1 and not emu:
                 ent = json.load(open(cands[-1])).get(args.workload, {})
                 traffic, traffic_src = ent.get("traffic_bytes"), ent.get("source")
+                trace_us = ent.get("kernel_trace_us_in_solve") or ent.get("kernel_trace_us_sweep_alone")
         except Exception:
             traffic = None
         # (3) SURVEY 8(d)'s model of a fused dual-RHS apply on a CSR operator (A and A' each streamed once)
@@ -529,6 +553,11 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac_time_base": "HIP events on the solver's stream around every %d-th sweep of the timed region: the bracket includes the dependent-launch gap "
+                              "in front of the kernel (~5 us on C4); `frac_kernel_trace` prices the same bytes on the kernel's own duration" % PROF_PERIOD,
+            "frac_kernel_trace": (round(traffic / (trace_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic and trace_us else None),
+            "kernel_trace_us": trace_us,
+            "kernel_trace_source": ("rocprofv3 --kernel-trace of the sweep, committed with the PMC passes (%s)" % traffic_src) if trace_us else None,
             "frac_of_measured_copy_6290": round(achieved / 6290.0, 4),
             "bytes_per_launch": moved,
             "bytes_basis": ("HBM-side bytes per launch from rocprofv3 PMC passes of this round's kernels (%s)" % traffic_src) if traffic
@@ -625,6 +654,7 @@ def main():
                 "parallelism": "cone-sharded x%d (scalar sums: %s)" % (world, reduction) if dist is not None else "single GPU",
                 "peer_fallback_reason": peer_reason, "transport": transport if dist is not None else None,
                 "all_ranks_ms_per_step": per_rank_ms,
+                "diagnostics": diagnostics,
                 "residuals_after_run": {"p": chk.p, "d": chk.d, "g": chk.g, "iteration": it},
                 "setup_s": round(t_setup, 2), "generate_s": round(t_gen, 2),
                 "instance_note": ("data scaled as BASELINE.md 3 records (||b|| = ||c|| = 10, A_j / 32): a well-conditioned instance, 17 CG "
@@ -656,6 +686,28 @@ def main():
                 "the self test passed, but an exchange of the warm-up timed out on the %s mailboxes (FOS_ECOMM)" % failed
     else:
         raise SystemExit("every transport failed during the warm-up")
+    if world == 1 and dist is None and not args.direct and out["config"]["cg_variant"] == "reference" and not os.environ.get("FOS_BENCH_SHARD"):
+        # the same job on the merged-reduction recurrence (the default of SHARDED handles: one exchange per CG iteration) -- so that a scaling
+        # ratio of an N > 1 run of this bench divides like by like; same handle, same state, `--steps` more outer iterations
+        try:
+            dev.set_cg_variant("merged_update")
+            dev.step(it + 1, 5, BIG, 1e-8)
+            dev.sync()
+            cg0m = dev.cg_total()
+            tm = time.perf_counter()
+            done_m, _, _ = dev.step(it + 6, args.steps, BIG, 1e-8)
+            dev.sync()
+            torch.cuda.synchronize()
+            dtm = time.perf_counter() - tm
+            it += 5 + done_m
+            out["merged_recurrence_n1"] = {"value": round(done_m / dtm, 4), "unit": "iterations/s", "ms_per_step": round(1e3 * dtm / max(1, done_m), 4),
+                                           "cg_variant": dev.cg_variant_name(), "cg_iters_per_step": round((dev.cg_total() - cg0m) / max(1, done_m), 2),
+                                           "note": "N = 1 on the recurrence sharded handles run by default (two launches and one reduction point per CG "
+                                                   "iteration); `value` is N = 1 on the reference's recurrence (three launches, two reduction points)"}
+        except Exception as exc:  # noqa: BLE001
+            out["merged_recurrence_n1"] = {"failed": repr(exc)}
+        finally:
+            dev.set_cg_variant(None)
     if world > 1 and not weak_main and not args.no_weak_extra and args.workload == "C4":
         # the same job once more with 512 blocks PER RANK: weak scaling, reported beside the strong-scaling headline
         dev.close()
@@ -686,7 +738,8 @@ def main():
             args.direct = False
 
     # ---- CPU baseline (rank 0, N = 1): the C port of the oracle restatement on one core (+ all cores), bounded sample
-    if world == 1 and not args.no_cpu_baseline:
+    def cpu_baseline(dev, prob, alg, it, budget_one=10.0, budget_all=5.0):
+        """Times oracle/fos_cport.c from the device's steady-state point and cross-checks ONE outer iteration against the numpy oracle."""
         sys.path.insert(0, str(ROOT / "oracle"))
         import fos_oracle as orc
         z = dev.get_iterate()
@@ -744,7 +797,7 @@ def main():
                 cp.close()
                 return n_it / dt, n_it, dt, cgs
 
-            v1, n1, dt1, cgs1 = time_cport(1, 10.0)
+            v1, n1, dt1, cgs1 = time_cport(1, budget_one)
             try:                                  # (threadpool_limits(1) above also caps OpenMP's default team size; the C
                 ncores = len(os.sched_getaffinity(0))   # port passes num_threads explicitly, so ask the OS for the core count)
             except Exception:
@@ -757,7 +810,7 @@ def main():
                 pass
             ncores = min(ncores, 32)              # beyond ~32 threads the fork/join of every vector pass dominates (measured:
                                                   # 256 threads are 20x slower than one)
-            vall = time_cport(ncores, 5.0) if ncores > 1 else None
+            vall = time_cport(ncores, budget_all) if ncores > 1 and budget_all > 0 else None
             dev.step(it + 1, 1, BIG, 1e-8)
             zg = dev.get_iterate()
             cpu = {
@@ -772,23 +825,42 @@ def main():
                 "gpu_vs_cpu_same_step_rel_dev": float(np.linalg.norm(zg - xo) / max(1.0, np.linalg.norm(xo))),
                 "gpu_cg_iters_same_step": dev.cgiter(),
             }
-            out["cpu_baseline"] = cpu
+            return cpu
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(dev, prob, alg, it)
     # ---- the C4 instance as SURVEY 8(d) writes it (A_j as drawn, not divided by 32): same size, same code path, twice the CG
     #      iterations per outer iteration -- timed here so that the driver's line carries it beside the headline
     if world == 1 and args.workload == "C4" and args.c4_scale is None and not args.small and not args.no_raw_instance:
         args.c4_scale = 1.0
         try:
-            rout, rdev, _, _, _ = run_case(False)
-            rdev.close()
+            rout, rdev, rprob, ralg, rit = run_case(False)
             rr = rout["roofline_kkt"] if isinstance(rout["roofline_kkt"], dict) else rout["roofline"]
+            rcpu = None
+            if not args.no_cpu_baseline:
+                try:
+                    rcpu = cpu_baseline(rdev, rprob, ralg, rit, budget_one=8.0, budget_all=0.0)      # (a shorter, single-core sample: the default run stays within minutes)
+                except Exception as exc:  # noqa: BLE001
+                    rcpu = {"failed": repr(exc)}
+            rdev.close()
             out["raw_instance"] = {
                 "workload": rout["config"]["workload"], "value": rout["value"], "unit": rout["unit"], "ms_per_step": rout["ms_per_step"],
                 "steps": rout["steps"], "warmup_effective": rout["warmup_effective"],
                 "cg_iters_per_step": rout["config"]["cg_iters_per_step"],
                 "roofline": {k: rr[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_kernel_ms", "bytes_per_launch")},
                 "time_shares": rout["time_shares"], "residuals_after_run": rout["config"]["residuals_after_run"],
+                "cpu_baseline": rcpu,
                 "note": "SURVEY 8(d)'s C4 without the data scaling of the headline instance (BASELINE.md 3): the same operator format, "
                         "kernels and sizes; the KKT matrix is worse conditioned, so CG needs about twice the iterations per outer iteration",
+            }
+            # the same numbers at the top level, under the name the survey's recipe deserves: whoever quotes this line against SURVEY 8(d)'s
+            # instance quotes THIS value; `value` is the instance BASELINE.md 3 records (data scaled, ||b|| = ||c|| = 10, A_j / 32)
+            out["value_as_specified"] = {
+                "value": rout["value"], "unit": rout["unit"], "ms_per_step": rout["ms_per_step"], "cg_iters_per_step": rout["config"]["cg_iters_per_step"],
+                "workload": rout["config"]["workload"],
+                "roofline_frac": rr["frac"],
+                "cpu_baseline": ({k: rcpu[k] for k in ("value", "unit", "cores", "kind", "sample", "gpu_vs_cpu_same_step_rel_dev")} if rcpu and "value" in rcpu else rcpu),
+                "speedup_vs_cpu_port_one_core": (round(rout["value"] / rcpu["value"], 1) if rcpu and rcpu.get("value") else None),
+                "what": "the C4 instance exactly as SURVEY 8(d) writes it (A_j as drawn); details under `raw_instance`",
             }
         finally:
             args.c4_scale = None

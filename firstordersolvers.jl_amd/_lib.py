@@ -64,6 +64,7 @@ PROTOTYPES = {
     "fos_peer_open_host": (C.c_int, [_h, C.c_int, C.c_int, C.c_char_p, C.c_double]),
     "fos_peer_close": (C.c_int, [_h]),
     "fos_peer_selftest": (C.c_int, [_h, C.c_int, C.POINTER(C.c_int32)]),
+    "fos_exchange_bench": (C.c_int, [_h, C.c_int, _dp]),
     "fos_peer_vec_export": (C.c_int, [_h, C.c_void_p]),
     "fos_peer_vec_open": (C.c_int, [_h, C.c_void_p]),
     "fos_peer_enable": (C.c_int, [_h, C.c_int32]),

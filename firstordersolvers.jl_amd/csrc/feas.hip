@@ -725,6 +725,8 @@ int fos_feas_set_longstep(fos_feas_handle h, int64_t longinterval, int64_t nsave
         FOS_TRY(feas_alloc(h, &h->lp.nu, (size_t)2 * K));
     }
     h->lp.interval = longinterval; h->lp.nsave = nsave; h->lp.savepos = 0; h->lp.now = false;
+    h->lp.max_supports = getenv("FOS_LONG_MAX_SUPPORTS") ? atoll(getenv("FOS_LONG_MAX_SUPPORTS")) : 4096;
+    h->lp.log[7] = 0.0;
     return FOS_OK;
 }
 int fos_feas_longstep_log(fos_feas_handle h, double* out8) {

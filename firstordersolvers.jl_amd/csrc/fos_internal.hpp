@@ -465,7 +465,8 @@ void launch_q1_finalize(const LaunchCtx& c, QMode mode, const double2* v, int co
 // CG vector kernels
 void launch_cg_init(const LaunchCtx& c, const double2* rhs, const double2* Ap, double2* r, double2* p);
 void launch_cg_init_finalize(const LaunchCtx& c, const double2* r, double tol, int maxit, int from_reduced);
-void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate, int off = 0);   // partials[off.. +count][nacc] -> reduced[nacc] (+ peer exchange)
+void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate, int off = 0);
+void launch_peer_chain(const LaunchCtx& c, int rounds);     // `rounds` mailbox exchanges of four doubles inside one launch (fos_exchange_bench)   // partials[off.. +count][nacc] -> reduced[nacc] (+ peer exchange)
 
 // outer-loop vector kernels (gap.jl:48,58,78; gapa.jl:67,77,96-103; fista.jl:31-46; dykstra.jl)
 constexpr int LONG_KMAX_ROWS = 32;   // saved planes of a LongstepWrapper: 2 (nsave + 1) <= 32
@@ -478,7 +479,9 @@ struct LongPlanes {
     double* bpart = nullptr;           // [rows][vec_blocks] partial sums of the offsets (x - y).y
     double* dots = nullptr;            // [vec_blocks][33][hi, lo] scratch of the Gram products (double-double)
     double* nu = nullptr;              // [rows][hi, lo] multipliers, device copy
-    double log[8] = {0};               // last projection: iteration, active inequalities, KKT violation, |x_new - x|, rows, supports tried
+    double log[8] = {0};               // last projection: iteration, active inequalities, KKT violation, |x_new - x|, rows, supports tried, [6] given up (0 / 1),
+                                       // [7] projections given up since fos_set_longstep
+    int64_t max_supports = 4096;       // candidate supports a projection may try (FOS_LONG_MAX_SUPPORTS, read at fos_set_longstep)
 };
 struct LaunchCtx;
 void long_save_plane(const LaunchCtx& c, LongPlanes& lp, int which, const double2* y, const double2* x);      // addprojeq (0) / addprojineq (1) at lp.savepos

@@ -1382,6 +1382,21 @@ void launch_reduce1(const LaunchCtx& c, int count, int nacc, int gate, int off) 
     else
         hipLaunchKernelGGL(reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, c.stream, part, count, nacc, c.reduced, c.st, gate, PeerBox{});
 }
+// `rounds` exchanges of four doubles back to back inside ONE launch (region 0 of the mailboxes, the protocol of reduce_kernel<true>): what an exchange
+// costs on the transport the handle uses, without a launch or a host round trip between them (fos_exchange_bench: a diagnostic of N-rank runs)
+__global__ __launch_bounds__(FIN_THREADS) void peer_chain_kernel(PeerBox pb, int rounds, double* __restrict__ reduced, DevState* st) {
+    if (st->xchg_failed) return;
+    __shared__ double sums[4];
+    for (int r = 0; r < rounds; ++r) {
+        if (threadIdx.x < 4) sums[threadIdx.x] = (double)(pb.rank + 1) + 0.25 * threadIdx.x + (double)r;
+        __syncthreads();
+        if (!peer_exchange_wg(pb, sums, 4, reduced, st)) return;
+        __syncthreads();
+    }
+}
+void launch_peer_chain(const LaunchCtx& c, int rounds) {
+    hipLaunchKernelGGL(peer_chain_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, *c.peer, rounds, c.reduced, c.st);
+}
 void launch_kkt_finalize(const LaunchCtx& c, const double2* w, double2* out, int gate, int from_reduced) {
     hipLaunchKernelGGL(kkt_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, c.stream, c.partials + 3 * (size_t)c.S.part_off, c.S.npart, c.reduced,
                        from_reduced, w, out, (int)(c.n + c.m), c.st, gate);

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(LB) void cg_resident_kernel(ResArgs a) {
                 dst = s_sib + ((size_t)si * TMAX + c) * 2 + comp;
                 return a.crec + ((par * a.G + (size_t)(me.wg0 + k)) * (size_t)a.tmax + (size_t)c) * 4 + 2 * comp;
             };
-            constexpr int PU = 8;
+            constexpr int PU = 7;
             bool bad = false;
             for (int base = ctp >= 0 ? ctp : nrec + nsib; base < nrec + nsib; base += PU * nthr) {
                 const unsigned long long* src[PU];
@@ -512,16 +512,16 @@ __global__ __launch_bounds__(LB) void cg_resident_kernel(ResArgs a) {
             // the unit's column sums: its workgroups in order -- the same bits in each of them
             d2 ctot = cp;
             if (me.wpu > 1 && lane < tc) {
-                // (the first three of the other workgroups' sums read together, unpredicated -- clamped index, the value dropped by a select)
+                // (the first four of the other workgroups' sums read together, unpredicated -- clamped index, the value dropped by a select)
                 const d2* sib = reinterpret_cast<const d2*>(s_sib);
-                d2 sv[3];
+                d2 sv[4];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) sv[q] = sib[(size_t)(q < me.wpu - 1 ? q : 0) * TMAX + lane];
+                for (int q = 0; q < 4; ++q) sv[q] = sib[(size_t)(q < me.wpu - 1 ? q : 0) * TMAX + lane];
                 d2 t = make_double2(0.0, 0.0);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {                     // workgroups 0..3 of the unit, in order
+                for (int k = 0; k < 4; ++k) {                     // workgroups 0..3 of the unit, in order (slot si of s_sib: the unit's workgroups without this one)
                     const int si = k < me.idx ? k : k - 1;
-                    d2 part = k == me.idx ? cp : (si == 0 ? sv[0] : (si == 1 ? sv[1] : sv[2]));
+                    d2 part = k == me.idx ? cp : (si == 0 ? sv[0] : (si == 1 ? sv[1] : (si == 2 ? sv[2] : sv[3])));
                     if (k >= me.wpu) part = make_double2(0.0, 0.0);
                     t.x += part.x; t.y += part.y;
                 }

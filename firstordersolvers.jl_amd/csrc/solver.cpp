@@ -1680,7 +1680,8 @@ int long_project_planes(const LaunchCtx& c, LongPlanes& lp, d2* X, int64_t i) {
     //     solves when it ends at the solution (it is accepted by the same KKT test); (ii) otherwise the enumeration of all supports
     bool found = false;
     // budget of candidate supports (FOS_LONG_MAX_SUPPORTS; 0 tries none: the failure path, tests)
-    const int64_t LONG_MAX_SUPPORTS = getenv("FOS_LONG_MAX_SUPPORTS") ? atoll(getenv("FOS_LONG_MAX_SUPPORTS")) : 4096;
+    // (read once, at fos_set_longstep; a COUNT only -- a wall-clock cut-off made the iterate sequence depend on the load of the machine)
+    const int64_t LONG_MAX_SUPPORTS = lp.max_supports;
     {
         uint32_t mask = 0;
         std::vector<uint32_t> seen;
@@ -1702,14 +1703,10 @@ int long_project_planes(const LaunchCtx& c, LongPlanes& lp, d2* X, int64_t i) {
     }
     // (ii) bounded: inconsistent or dependent planes have NO support that passes the KKT test, and 2^nin solves in 113-bit arithmetic (each a
     // Jacobi eigen-decomposition when Cholesky rejects the block) would hold fos_step for minutes -- at most LONG_MAX_SUPPORTS candidates, smallest
-    // supports first in counting order, and never longer than LONG_MAX_SECONDS
-    const double LONG_MAX_SECONDS = 2.0;
-    const auto t_enum = std::chrono::steady_clock::now();
-    for (uint32_t mask = 0; !found && mask < (1u << nin) && tried < LONG_MAX_SUPPORTS; ++mask) {
-        found = try_support(mask);
-        if ((mask & 63u) == 63u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enum).count() > LONG_MAX_SECONDS) break;
-    }
+    // supports first in counting order (deterministic: the same problem projects, or does not, on every run)
+    for (uint32_t mask = 0; !found && mask < (1u << nin) && tried < LONG_MAX_SUPPORTS; ++mask) found = try_support(mask);
     lp.log[6] = found ? 0.0 : 1.0;
+    if (!found) lp.log[7] += 1.0;                              // projections given up since fos_set_longstep (the host mirrors warn when it grows)
     if (!found) {
         // no KKT point of the small dual within the budget: the planes do not describe a projection -- the iterate stays as the wrapped
         // algorithm left it (the reference's QP solver throws here; a step that is not the projection must not be applied silently)
@@ -2382,6 +2379,36 @@ int fos_peer_selftest(fos_handle h, int rounds, int32_t* ok) {
     return FOS_OK;
 }
 
+// What ONE exchange of four doubles costs on the transport this sharded handle uses -- `rounds` of them back to back, in stream, between two events:
+// mailboxes: inside one launch (no launch or host round trip between them); RCCL: `rounds` ncclAllReduce calls.  Collective (every rank, same rounds).
+int fos_exchange_bench(fos_handle h, int rounds, double* us_per_exchange) {
+    if (!h || !us_per_exchange || rounds < 1) { set_error("bad argument"); return FOS_EINVAL; }
+    *us_per_exchange = 0.0;
+    if (!h->sharded() || h->host_fn) { set_error("fos_exchange_bench: the handle has no in-stream transport (mailboxes or RCCL)"); return FOS_EUNSUPPORTED; }
+    FOS_HIP(hipSetDevice(h->device));
+    LaunchCtx c = h->ctx();
+    hipEvent_t e0, e1;
+    FOS_HIP(hipEventCreate(&e0));
+    FOS_HIP(hipEventCreate(&e1));
+    auto run = [&](int n) -> int {
+        if (h->peer_on) { launch_peer_chain(c, n); return FOS_OK; }
+        for (int r = 0; r < n; ++r) FOS_TRY(allreduce(h, 4));
+        return FOS_OK;
+    };
+    int rc = run(4);                                     // warm
+    if (rc == FOS_OK) rc = hipEventRecord(e0, h->stream) == hipSuccess ? FOS_OK : FOS_EHIP;
+    if (rc == FOS_OK) rc = run(rounds);
+    if (rc == FOS_OK) rc = hipEventRecord(e1, h->stream) == hipSuccess ? FOS_OK : FOS_EHIP;
+    if (rc == FOS_OK) rc = poll_state(h);
+    float ms = 0.f;
+    if (rc == FOS_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = FOS_EHIP;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != FOS_OK) return rc;
+    *us_per_exchange = 1e3 * (double)ms / (double)rounds;
+    return FOS_OK;
+}
+
 // Row-sharded handles: the exchange buffer of the n-vector A'y (fos_internal.hpp, VecBox).  Protocol as for the mailboxes, after
 // fos_peer_open (which fixes nranks): fos_peer_vec_export -> the host all-gathers the 64-byte handles -> fos_peer_vec_open.
 int fos_peer_vec_export(fos_handle h, void* handle64) {
@@ -2728,6 +2755,8 @@ int fos_set_longstep(fos_handle h, int64_t longinterval, int64_t nsave) {
         FOS_HIP(hipMemset(h->lp.bpart, 0, sizeof(double) * (size_t)K * h->vec_blocks));
     }
     h->lp.interval = longinterval; h->lp.nsave = nsave; h->lp.savepos = 0; h->lp.now = false;
+    h->lp.max_supports = getenv("FOS_LONG_MAX_SUPPORTS") ? atoll(getenv("FOS_LONG_MAX_SUPPORTS")) : 4096;      // (0 tries none: the failure path, tests)
+    h->lp.log[7] = 0.0;
     return FOS_OK;
 }
 // last projection of the LongstepWrapper: out8 = iteration, active inequalities, largest KKT violation of the small dual, |x_new - x|, rows, supports tried

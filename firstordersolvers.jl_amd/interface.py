@@ -246,7 +246,8 @@ class HipHSDE:
         """last projection onto the saved planes: dict(iteration, active inequalities, KKT violation of the small dual, step length, rows, supports tried)"""
         out = np.zeros(8)
         _lib.check(self._lib.fos_longstep_log(self._h, _lib.dptr(out)))
-        return dict(iteration=int(out[0]), active=int(out[1]), violation=float(out[2]), step=float(out[3]), rows=int(out[4]), tried=int(out[5]), failed=bool(out[6]))
+        return dict(iteration=int(out[0]), active=int(out[1]), violation=float(out[2]), step=float(out[3]), rows=int(out[4]), tried=int(out[5]), failed=bool(out[6]),
+                    given_up=int(out[7]))
 
     def gapp_log(self):
         """(iteration, [21 test norms], alpha_best) of GAPP's last search."""
@@ -556,6 +557,12 @@ class HipHSDE:
         _lib.check(self._lib.fos_peer_selftest(self._h, rounds, C.byref(ok)))
         return bool(ok.value)
 
+    def exchange_bench(self, rounds=200) -> float:
+        """microseconds per exchange of four doubles on the handle's transport (collective; foship.h fos_exchange_bench)."""
+        us = C.c_double(0.0)
+        _lib.check(self._lib.fos_exchange_bench(self._h, int(rounds), C.byref(us)))
+        return float(us.value)
+
     def peer_enable(self, on=True):
         _lib.check(self._lib.fos_peer_enable(self._h, 1 if on else 0))
 
@@ -613,6 +620,13 @@ class HSDEStatus:
         if res.cg_maxiter_hit:
             import warnings
             warnings.warn("CG reached max iterations, result may be inaccurate")     # conjugategradients.jl:53
+        if isinstance(self.model.alg, LongstepWrapper):            # (the reference's QP solver throws where no projection exists; here the step stands and the host is told)
+            gu = self.model.data.longstep_log()["given_up"]
+            if gu > getattr(self, "_long_given_up", 0):
+                import warnings
+                warnings.warn("LongstepWrapper: %d projection(s) onto the saved planes found no KKT point of the small dual within its budget "
+                              "(inconsistent or dependent planes); those iterations kept the wrapped algorithm's iterate" % (gu - getattr(self, "_long_given_up", 0)))
+            self._long_given_up = gu
         self.status = _lib.STATUS_NAMES[res.status]
         if self.status == "Optimal" and self.verbose > 0:
             self._println("Found solution i=%d" % i)               # :55-57
@@ -908,7 +922,8 @@ class HipFeasibility:
     def longstep_log(self):
         out = np.zeros(8)
         _lib.check(self._lib.fos_feas_longstep_log(self._h, _lib.dptr(out)))
-        return dict(iteration=int(out[0]), active=int(out[1]), violation=float(out[2]), step=float(out[3]), rows=int(out[4]), tried=int(out[5]), failed=bool(out[6]))
+        return dict(iteration=int(out[0]), active=int(out[1]), violation=float(out[2]), step=float(out[3]), rows=int(out[4]), tried=int(out[5]), failed=bool(out[6]),
+                    given_up=int(out[7]))
 
     def gapp_log(self):
         """(iteration, [21 test norms], alpha_best) of GAPP's last search."""

@@ -162,6 +162,9 @@ int fos_peer_open(fos_handle h, int nranks, int rank, const void* handles, doubl
 int fos_peer_open_host(fos_handle h, int nranks, int rank, const char* shm_name, double timeout_s);
 int fos_peer_close(fos_handle h);
 int fos_peer_selftest(fos_handle h, int rounds, int32_t* ok);
+/* Diagnostic of an N-rank run (no reference equivalent): the cost of ONE exchange of four doubles on the transport the sharded handle uses --
+ * `rounds` exchanges back to back in stream between two events (mailboxes: inside one launch; RCCL: `rounds` ncclAllReduce calls).  Collective. */
+int fos_exchange_bench(fos_handle h, int rounds, double* us_per_exchange);
 /* Row-sharded handles (FOS_CREATE_ROW_SHARDED) over the mailboxes: the n-vector A'y = sum over ranks of A_g'y_g (HSDEAffine.jl:51)
  * also crosses the ranks through peer-mapped memory -- every rank pushes its 2n partial sums into every peer's exchange buffer and
  * adds what it received in rank order, in stream, no collective library.  After fos_peer_open: fos_peer_vec_export(h, handle64),
@@ -238,8 +241,10 @@ int fos_linesearch_log(fos_handle h, double* out34);
  * (BigFloat, because successive normals are nearly dependent); here its dual in the 2 (nsave + 1) multipliers is solved by enumeration of the active
  * inequalities -- the same unique point -- with the Gram products formed in double-double on the device and the small systems solved in 113-bit arithmetic.
  * nsave <= 15; longinterval >= nsave + 1; 0 switches the wrapper off.  out8 = iteration of the last projection, active inequalities, largest KKT violation of
- * the small dual, |x_new - x|, rows, candidate supports tried, failed, 0.  failed = 1: no support passed the KKT test within the budget (4096 candidate
- * supports or 2 s -- inconsistent or dependent planes): the iterate is left as the wrapped algorithm's step produced it, fos_step still returns FOS_OK. */
+ * the small dual, |x_new - x|, rows, candidate supports tried, failed, projections given up since fos_set_longstep.  failed = 1: no support passed the KKT
+ * test within the budget -- 4096 candidate supports (FOS_LONG_MAX_SUPPORTS, read at fos_set_longstep; a count, so the same problem behaves the same on
+ * every run), inconsistent or dependent planes -- : the iterate is left as the wrapped algorithm's step produced it and fos_step returns FOS_OK (the reference's QP
+ * solver throws there); the host mirrors warn when out8[7] grows. */
 int fos_set_longstep(fos_handle h, int64_t longinterval, int64_t nsave);
 int fos_longstep_log(fos_handle h, double* out8);
 /* GAPP(alpha, alpha1, alpha2; iproj) -- "projected GAP", src/solvers/gapproj.jl:5-81, the last row of the reference's solver table

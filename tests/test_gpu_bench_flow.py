@@ -25,6 +25,18 @@ def _last_json(text):
     raise AssertionError("no JSON line in:\n" + text[-2000:])
 
 
+def _check_diagnostics(out, nranks):
+    """What a failure analysis of an N-rank run needs is IN the line (bench.py `config.diagnostics`): the transport, why the ones in front of it were passed
+    over, one exchange's cost on it per rank, who can reach whose memory, every rank's CG variant and resident-solve plan."""
+    dg = out["config"]["diagnostics"]
+    assert dg["transport"] == out["config"]["transport"] and isinstance(dg["passed_over"], dict)
+    assert len(dg["per_rank"]) == nranks and sorted(r["rank"] for r in dg["per_rank"]) == list(range(nranks))
+    for r in dg["per_rank"]:
+        assert isinstance(r["exchange_us"], float) and 0.0 < r["exchange_us"] < 5e4, r
+        assert r["cg_variant"] == out["config"]["cg_variant"] and "qualifies" in r["resident"] and "all_ranks_qualify" in r["resident"]
+    assert "hipDeviceCanAccessPeer" in dg
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -54,6 +66,7 @@ def test_bench_two_ranks_on_one_gpu_matches_single_rank():
     assert out1["config"]["peer_fallback_reason"] is None
     assert out2["roofline"]["all_ranks"]["achieved_all_ranks"] >= out2["roofline"]["achieved"]
     assert "cpu_baseline" not in out2                       # N = 1 only
+    _check_diagnostics(out2, 2)
     # each rank holds half of the blocks
     assert 2 * out2["config"]["local_m"] == out1["config"]["local_m"] and 2 * out2["config"]["local_nnz"] == out1["config"]["local_nnz"]
     # the weak-scaling extra: twice the blocks in total, the single-rank shard size per rank
@@ -79,7 +92,9 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = _last_json(r.stdout)
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0
-    assert out["config"]["cg_variant"] == "merged_update" and out["config"]["cg_launches_per_iteration"] == 2
+    # (sharded handles on the mailboxes: the resident solve -- one launch per CG solve -- when every rank's shard qualifies, as the reduced block SDP's
+    #  do; otherwise the merged-reduction recurrence, two launches per iteration)
+    assert (out["config"]["cg_variant"], out["config"]["cg_launches_per_iteration"], out["config"]["cg_launches_per_solve"]) in (("resident", 0, 1), ("merged_update", 2, None))
     # a failing child must fail the call: an unknown workload makes every rank exit non-zero
     bad = subprocess.run(cmd + ["--workload", "nope"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0
@@ -129,6 +144,7 @@ def test_bench_ranks_on_one_gpu(nranks, transport):
     out1 = _last_json(r1.stdout)
     assert outn["n_gpus"] == nranks and ("peer mailboxes" if transport == "peer" else "host-pinned mailboxes") in outn["config"]["parallelism"]
     assert outn["config"]["peer_fallback_reason"] is None and len(outn["config"]["all_ranks_ms_per_step"]) == nranks
+    _check_diagnostics(outn, nranks)
     assert nranks * outn["config"]["local_m"] == out1["config"]["local_m"]
     ra, rb = out1["config"]["residuals_after_run"], outn["config"]["residuals_after_run"]
     assert ra["iteration"] == rb["iteration"]

@@ -51,9 +51,9 @@ def test_certificates_small_all_kinds(pkg):
     d.close()
 
 
-def test_certificates_c3_full_size(pkg):
+def test_certificates_c3_full_size(pkg, fullsize):
     """1000 x SOC(50): random input and a mid-solve iterate."""
-    prob = pkg.workloads.c3_socp()
+    prob = fullsize("C3")
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     rng = np.random.default_rng(31)
     _, w = _certify(d, prob, rng.standard_normal(d.N), 1e-12)
@@ -65,10 +65,10 @@ def test_certificates_c3_full_size(pkg):
     d.close()
 
 
-def test_certificates_c5_full_size(pkg):
+def test_certificates_c5_full_size(pkg, fullsize):
     """l ~ 1e6: NonNeg(31250) + 250 x SOC(50) + 9 x PSD(64) per block, 8 blocks; random input, then consecutive FISTA iterates
     (the second and third PSD projections start from the previous eigenvector basis: the warm-started path)."""
-    prob = pkg.workloads.c5_mixed()
+    prob = fullsize("C5")
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     rng = np.random.default_rng(51)
     _, w = _certify(d, prob, rng.standard_normal(d.N), 2e-11)
@@ -84,9 +84,9 @@ def test_certificates_c5_full_size(pkg):
     d.close()
 
 
-def test_certificates_c4_full_size_warm_started_psd(pkg):
+def test_certificates_c4_full_size_warm_started_psd(pkg, fullsize):
     """512 x PSD(64), both copies: a cold projection, then projections of slowly drifting inputs (warm start, MFMA products)."""
-    prob = pkg.workloads.c4_block_sdp()
+    prob = fullsize("C4")
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     rng = np.random.default_rng(41)
     z = rng.standard_normal(d.N)
@@ -109,12 +109,12 @@ def _device_vs_oracle_residuals(d, prob, res, i):
     return z
 
 
-def test_c5_fista_driven_to_iteration_cap_full_size(pkg):
+def test_c5_fista_driven_to_iteration_cap_full_size(pkg, fullsize):
     """BASELINE config 5 (mixed cones, n ~ 1e6, FISTA, residuals vs the CPU restatement): 1500 iterations at full size; at every
     check (every 500) the device's p, d, g, c'x, b'y agree with the oracle's formulas on the same point to 1e-9 relative (the
     BASELINE tolerance is 1e-8), the residuals fall monotonically from check to check, and the objective c'x / tau approaches the
     known optimal value c'x0 (x0 itself is not unique: A has more columns than rows)."""
-    prob = pkg.workloads.c5_mixed()
+    prob = fullsize("C5")
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     d.set_alg(pkg.FISTA())
     d.set_iterate(None)
@@ -131,10 +131,10 @@ def test_c5_fista_driven_to_iteration_cap_full_size(pkg):
     d.close()
 
 
-def test_c2_dr_driven_to_iteration_cap_full_size(pkg):
+def test_c2_dr_driven_to_iteration_cap_full_size(pkg, fullsize):
     """BASELINE config 2 (dense 5000 x 10000 LP, DR): 1200 iterations at full size; device residuals vs the oracle's formulas on
     the returned point at every check, monotone decrease, objective towards the known optimum c'x0."""
-    prob = pkg.workloads.c2_lp()
+    prob = fullsize("C2")
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     d.set_alg(pkg.DR())
     d.set_iterate(None)

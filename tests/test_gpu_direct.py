@@ -143,7 +143,7 @@ def _projection_certificate(prob, d, x, tol):
     return y
 
 
-def test_block_form_at_c4_sizes_certificate_cg_and_a_whole_solve(pkg, monkeypatch):
+def test_block_form_at_c4_sizes_certificate_cg_and_a_whole_solve(pkg, monkeypatch, fullsize):
     """The 64-block shard of C4 and C4 itself (l = 1 081 345; 512 diagonal blocks of 32 columns): the block form's projection carries the
     oracle-free certificate of the exact projection at 1e-12, equals the warm-started CG at its tolerance floor (FOS_DIRECT_MODE=cg) to 1e-9,
     costs no CG iteration -- and DR(direct=true) solves C4 to its known optimum."""
@@ -172,7 +172,7 @@ def test_block_form_at_c4_sizes_certificate_cg_and_a_whole_solve(pkg, monkeypatc
             assert dc.cgiter() > 0 and np.linalg.norm(ycg - y) <= 1e-9 * np.linalg.norm(y)
             dc.close()
             monkeypatch.delenv("FOS_DIRECT_MODE")
-    prob = pkg.workloads.c4_block_sdp()
+    prob = fullsize("C4")
     model = pkg.solve(prob, pkg.DR(direct=True, eps=1e-4, max_iters=4000, verbose=0, checki=250))
     assert model.status() == "Optimal" and "cgiter" not in model.history
     assert model.getobjval() == pytest.approx(float(prob.c @ prob.x0), rel=5e-3)
@@ -192,7 +192,7 @@ def test_block_form_whole_solves_match_the_oracle(pkg):
         assert np.max(np.abs(model.getsolution() - sol.x)) <= 1e-9 * max(1.0, np.max(np.abs(sol.x)))
 
 
-def test_direct_beyond_the_dense_size_is_the_same_projection_by_cg(pkg, monkeypatch):
+def test_direct_beyond_the_dense_size_is_the_same_projection_by_cg(pkg, monkeypatch, fullsize):
     """l > 46 000 (here forced: FOS_DIRECT_DENSE_MAX = 10): direct = true keeps its meaning -- the EXACT projection onto {Q u = v} from the
     first call on -- computed by the warm-started CG at its tolerance floor instead of the 0.2^sqrt(i) schedule.  Against the oracle's
     IndAffineDirect from the FIRST call (the scheduled CG is five orders of magnitude off there), and on C3 itself (l = 70 001)."""
@@ -227,7 +227,7 @@ def test_direct_beyond_the_dense_size_is_the_same_projection_by_cg(pkg, monkeypa
     d.close()
     monkeypatch.delenv("FOS_DIRECT_DENSE_MAX")
     monkeypatch.delenv("FOS_DIRECT_MODE")
-    prob = pkg.workloads.c3_socp()                        # l = 70 001: a dense 39 GB inverse is past the limit -> CG at the floor
+    prob = fullsize("C3")                        # l = 70 001: a dense 39 GB inverse is past the limit -> CG at the floor
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     d.enable_direct(prob.A)
     assert d.direct_mode() == "cg"                        # (random sparse columns couple everything: no block form either)

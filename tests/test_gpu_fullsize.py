@@ -119,8 +119,8 @@ def _projection_properties(d, rng):
 
 
 @pytest.fixture(scope="module")
-def c4(pkg):
-    prob = pkg.workloads.c4_block_sdp()
+def c4(pkg, fullsize):
+    prob = fullsize("C4")
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     yield prob, d
     d.close()
@@ -167,9 +167,9 @@ def test_c4_dr_reaches_known_optimum(pkg, c4):
     assert np.linalg.eigvalsh(M).min() > -1e-3
 
 
-def test_c2_full_size_operators_and_progress(pkg):
+def test_c2_full_size_operators_and_progress(pkg, fullsize):
     """Dense 5000 x 10000 LP (all long run-rows): operator properties at full size; DR residuals decrease."""
-    prob = pkg.workloads.c2_lp()
+    prob = fullsize("C2")
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     assert prob.nnz == 5000 * 10000
     rng = np.random.default_rng(1)
@@ -184,9 +184,9 @@ def test_c2_full_size_operators_and_progress(pkg):
     d.close()
 
 
-def test_c3_full_size_gapa(pkg):
+def test_c3_full_size_gapa(pkg, fullsize):
     """Sparse SOCP (1000 x SOC(50), nnz ~ 1e6), GAPA: operator properties; reaches Optimal at eps=1e-4 near the known optimum."""
-    prob = pkg.workloads.c3_socp()
+    prob = fullsize("C3")
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     _operator_properties(d, np.random.default_rng(2))
     _operator_vs_oracle(prob, d, np.random.default_rng(12))
@@ -197,12 +197,12 @@ def test_c3_full_size_gapa(pkg):
     assert model.getobjval() == pytest.approx(float(prob.c @ prob.x0), rel=2e-2, abs=1e-3)
 
 
-def test_c5_full_size_fista_residuals_vs_oracle(pkg, oracle):
+def test_c5_full_size_fista_residuals_vs_oracle(pkg, oracle, fullsize):
     """Mixed-cone HSDE, l ~ 1e6 (NonNeg + SOC + PSD, 8 blocks), FISTA: operator / projection properties at full size, and the
     residuals p, d, g, c'x, b'y the device reports at a check against the oracle's residual formulas (HSDEStatus.jl:27-71) on
     the SAME point -- relative 1e-9 (the BASELINE tolerance is 1e-8)."""
     orc = oracle
-    prob = pkg.workloads.c5_mixed()
+    prob = fullsize("C5")
     assert 9.9e5 < prob.m + prob.n + 1 < 1.01e6
     d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
     _operator_properties(d, np.random.default_rng(4))
@@ -226,43 +226,50 @@ def test_c5_full_size_fista_residuals_vs_oracle(pkg, oracle):
     d.close()
 
 
-def test_c3_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle):
+def test_c3_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle, fullsize):
     """C3 (GAPA), outer iteration 261 from the device's state at iteration 260 (past the CG tolerance floor, ~97 CG iterations):
     the device's iterate against the oracle's, relative 1e-9 (BASELINE tolerance 1e-8)."""
-    prob = pkg.workloads.c3_socp()
+    prob = fullsize("C3")
     _same_step_vs_oracle(pkg, prob, pkg.GAPA(), oracle.GAPA(), 260, 1e-9)
 
 
-def test_c5_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle):
+def test_c5_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle, fullsize):
     """C5 under its own algorithm, FISTA (BASELINE.json configs[4]): the window-panel CG (~140 iterations at the tolerance floor), the cone
     stack (NonNeg + 2000 SOC + 72 PSD(64)) and fista_extrap_kernel as ONE chain -- outer iteration 241 from the device's state at
     iteration 240 (iterate, CG warm start, call counter, and FISTA's y, xold, t through fos_get_alg_state) against the oracle's step
     (fista.jl:28-48), relative 1e-9; then the same operator and cones under DR."""
-    prob = pkg.workloads.c5_mixed()
+    prob = fullsize("C5")
     _same_step_vs_oracle(pkg, prob, pkg.FISTA(), oracle.FISTA(), 240, 1e-9)
     _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 240, 1e-9)
 
 
-def test_c4_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle):
+def test_c4_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle, fullsize):
     """C4 (DR, 512 x PSD(64): dual tiles, 17 CG iterations at the tolerance floor, the batched 1024-matrix PSD projection), outer
     iteration 201 from the device's state at iteration 200 against the oracle's step (solverwrapper.jl:23-29, gap.jl:61-80) --
     relative 1e-9 (BASELINE tolerance 1e-8).  The numpy oracle needs ~2 s for this step."""
-    prob = pkg.workloads.c4_block_sdp()
+    prob = fullsize("C4")
     _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 200, 1e-9)
 
 
-def test_c4_shard_one_steady_state_iteration_vs_oracle(pkg, oracle):
+def test_c4_raw_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle, fullsize):
+    """C4 exactly as SURVEY 8(d) writes it -- the blocks A_j as drawn, NOT divided by k / 2 (`c4_block_sdp(scale=1)`: bench.py's `value_as_specified`;
+    the KKT matrix is worse conditioned, ~35 CG iterations per projection at the tolerance floor instead of 17) -- outer iteration 201 from the device's
+    state at iteration 200 against the oracle's step (solverwrapper.jl:23-29, gap.jl:61-80, affinepluslinear.jl:108-118), relative 1e-9."""
+    _same_step_vs_oracle(pkg, fullsize("C4raw"), pkg.DR(), oracle.DR(), 200, 1e-9)
+
+
+def test_c4_shard_one_steady_state_iteration_vs_oracle(pkg, oracle, fullsize):
     """What one of eight ranks holds of C4 (64 blocks, 128 matrices per projection: the small-batch PSD path -- refinement by matrix
     products from an extrapolated basis, psd64_refine_kernel), outer iterations 201 and 231 against the oracle's step, 1e-9."""
-    prob = pkg.workloads.c4_block_sdp(nblocks=512, block_range=(0, 64))
+    prob = fullsize("C4shard64")
     _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 200, 1e-9)
     _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 230, 1e-9)
     # GAPA: another sequence of matrices for the basis extrapolation (alpha12 changes from step to step)
     _same_step_vs_oracle(pkg, prob, pkg.GAPA(), oracle.GAPA(), 200, 1e-9)
 
 
-def test_c2_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle):
+def test_c2_full_size_one_steady_state_iteration_vs_oracle(pkg, oracle, fullsize):
     """C2 (DR, dense 5000 x 10000 LP in tall dual tiles, ~45 CG iterations at the tolerance floor), outer iteration 301 from the
     device's state at iteration 300 against the oracle's step, relative 1e-9.  The numpy oracle needs ~5 s for this step."""
-    prob = pkg.workloads.c2_lp()
+    prob = fullsize("C2")
     _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 300, 1e-9)

@@ -152,7 +152,8 @@ def test_longstep_without_a_kkt_point_leaves_the_iterate(pkg, monkeypatch):
     d.set_iterate(None)
     d.step(1, 7, 10 ** 9, 1e-9)
     plain = d.get_iterate()
-    assert runs["0"][1]["failed"] and runs["0"][1]["tried"] == 0 and runs["0"][1]["step"] == 0.0
+    assert runs["0"][1]["failed"] and runs["0"][1]["tried"] == 0 and runs["0"][1]["step"] == 0.0 and runs["0"][1]["given_up"] == 1
+    assert runs[None][1]["given_up"] == 0
     assert np.linalg.norm(runs["0"][0] - plain) <= 1e-12 * np.linalg.norm(plain)           # unfused vs fused step: rounding only
     assert not runs[None][1]["failed"] and runs[None][1]["step"] > 0
     assert np.linalg.norm(runs[None][0] - plain) > 1e-6 * np.linalg.norm(plain)           # (the projection does move the iterate)

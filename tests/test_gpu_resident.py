@@ -195,9 +195,9 @@ def test_whole_solve_resident_matches_default(pkg):
     assert abs(ma.getobjval() - mb.getobjval()) < 1e-5 * (1 + abs(ma.getobjval()))
 
 
-def test_c4_shard_one_steady_state_iteration_vs_oracle_resident(pkg, oracle):
+def test_c4_shard_one_steady_state_iteration_vs_oracle_resident(pkg, oracle, fullsize):
     """What one of eight ranks holds of C4 (64 blocks = 2112 tiles on 256 workgroups of nine wavefronts: the configuration the resident solve was
     built for), outer iteration 201 from the device's state at iteration 200 against the oracle's step (solverwrapper.jl:23-29, gap.jl:61-80), 1e-9."""
     from test_gpu_fullsize import _same_step_vs_oracle
-    prob = pkg.workloads.c4_block_sdp(nblocks=512, block_range=(0, 64))
+    prob = fullsize("C4shard64")
     _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 200, 1e-9, cg_variant="resident")

@@ -38,6 +38,12 @@ rate = float(np.median(rates)) if rates else 100.0
 print("stamp clock: %.1f ticks per us (from %d pairs)" % (rate, len(rates)))
 st = st.copy().astype(np.float64)
 cal = st[:, :, 62:, :].copy()
+# the launch's own head and tail, on compute wavefront 0 of workgroup 0 (shader clock): entry -> first loop top, last stamp -> exit
+e0, e1 = cal[0, 0, 1, 6], cal[0, 0, 0, 6]
+tops = [st[0, 0, k, 0] for k in range(62) if st[0, 0, k, 0] > 0]
+if e0 > 0 and e1 > e0 and tops:
+    print("workgroup 0, compute wavefront 0: kernel entry -> first sweep %.2f us (tiles and vectors -> registers / LDS), %d exchanges in %.2f us, last loop top -> exit %.2f us; entry -> exit %.2f us"
+          % ((tops[0] - e0) / rate, len(tops), (tops[-1] - tops[0]) / rate, (e1 - tops[-1]) / rate, (e1 - e0) / rate))
 st[:, :, 62:, :] = 0
 st = st / rate * 100.0                      # -> the unit the code below divides by 100
 t00 = st[st > 0].min()
