@@ -176,6 +176,7 @@ struct FeasSet {
     double* psd_V[2] = {nullptr, nullptr};
     int psd_cur = 0, psd_have_prev = 0;
     bool psd_attr_set = false;
+    PsdSign* psd_big = nullptr;     // PSD cones of order > 64 (psd_sign.hip)
 };
 
 }  // namespace fos
@@ -264,6 +265,7 @@ int feas_prox(fos_feas* h, int which, double* y, const double* x) {
         launch_cones_exp(c, h->zout, h->zin, s.expc, s.nexp);
         FOS_TRY(launch_cones_psd(c, h->zout, h->zin, s.psd, s.npsd, s.psd_kmin, s.psd_kmax, s.psd_scratch, s.psd_V[s.psd_cur], s.psd_V[1 - s.psd_cur],
                                  s.psd_have_prev, nullptr, 0));
+        FOS_TRY(launch_cones_psd_sign(c, s.psd_big, h->zout, h->zin));          // cones of order > 64 (psd_sign.hip)
         if (s.npsd > 0 && s.psd_V[0]) { ms.psd_cur = 1 - ms.psd_cur; ms.psd_have_prev = 1; }      // warm start of the next projection
         FEAS_K(feas_from_parts_kernel, h->n, y, (const double2*)h->zout);
     } else if (s.kind == 4) {                                             // any other ProximableFunction: the caller's prox! on host vectors
@@ -467,7 +469,7 @@ int fos_feas_destroy(fos_feas_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* q : h->owned) (void)hipFree(q);
-    for (FeasSet& s : h->S) { if (s.cb_x) (void)hipHostFree(s.cb_x); if (s.cb_y) (void)hipHostFree(s.cb_y); }
+    for (FeasSet& s : h->S) { if (s.cb_x) (void)hipHostFree(s.cb_x); if (s.cb_y) (void)hipHostFree(s.cb_y); psd_sign_destroy(s.psd_big); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return FOS_OK;
@@ -626,6 +628,8 @@ int fos_feas_set_cones(fos_feas_handle h, int32_t which, int64_t ncones, const i
     FOS_TRY(upload(&s.ew_op, ew));
     FOS_TRY(upload(&s.soc, soc));
     FOS_TRY(upload(&s.expc, expc));
+    psd_sign_destroy(s.psd_big); s.psd_big = nullptr;
+    FOS_TRY(psd_sign_setup(psd, &s.psd_big));
     FOS_TRY(upload(&s.psd, psd));
     s.nsoc = (int)soc.size(); s.nexp = (int)expc.size(); s.npsd = (int)psd.size();
     s.psd_kmax = 0;

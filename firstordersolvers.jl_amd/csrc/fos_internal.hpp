@@ -550,6 +550,13 @@ bool psd_fuse_possible(const LaunchCtx& c, int ncones, int kmin, int kmax, const
 int  launch_cones_psd(const LaunchCtx& c, double2* out, const double2* in, const ConeDesc* cones, int ncones,
                       int kmin, int kmax, double* gscratch, const double* vin, double* vout, int have_prev, int* stats, int phase_limit,
                       int32_t* redo = nullptr, const PsdFuse* fuse = nullptr);
+// PSD cones of order > 64: the projection by matrix products only, P = (M + M sign(M)) / 2 with sign(M) from an inverse-free polynomial iteration on the fp64
+// matrix cores (psd_sign.hip).  psd_sign_setup takes those cones OUT of `psd` (what stays goes to the kernels of psd.hip) and allocates their workspace.
+struct PsdSign;
+int psd_sign_setup(std::vector<ConeDesc>& psd, PsdSign** out);
+void psd_sign_destroy(PsdSign* p);
+int psd_sign_count(const PsdSign* p);
+int launch_cones_psd_sign(const LaunchCtx& c, PsdSign* p, double2* out, const double2* in);
 size_t psd_scratch_bytes(int kmax, int ncones);
 size_t psd_basis_doubles(int kmax, int ncones);
 

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cmath>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "fos_internal.hpp"
@@ -122,6 +123,7 @@ struct fos_solver {
     int64_t win_stats[4] = {0, 0, 0, 0};       // window panels: panels, (panel, window) segments, 64-row slices, stored entries
     DevBlkCsr S{};
     std::vector<void*> owned;                  // every hipMalloc'd pointer
+    std::vector<void*> pooled;                 // blocks of the process-wide pool of uncached memory (uncached_acquire): released, never freed
     double* cb = nullptr;
     double nb = 0.0, nc = 0.0;                 // ||b||, ||c|| (global)
     double nb_local = 0.0, nc_local = 0.0;     // this shard's ||b||, ||c||
@@ -139,7 +141,8 @@ struct fos_solver {
     uint8_t* ew_op = nullptr;
     ConeDesc* soc = nullptr; int nsoc = 0;
     ConeDesc* expc = nullptr; int nexp = 0;
-    ConeDesc* psd = nullptr; int npsd = 0; int psd_kmax = 0, psd_kmin = 0;
+    ConeDesc* psd = nullptr; int npsd = 0; int psd_kmax = 0, psd_kmin = 0;       // PSD cones of order <= 64 (psd.hip)
+    PsdSign* psd_big = nullptr;                // ... of order > 64: projected by matrix products (psd_sign.hip)
     double* psd_scratch = nullptr;
     double* psd_V[2] = {nullptr, nullptr};     // warm-start eigenvector bases (ping-pong), orders <= 64
     int psd_cur = 0, psd_have_prev = 0;
@@ -459,6 +462,47 @@ int wait_cg_mark(fos_solver* h, uint32_t epoch, int32_t batch_id, bool* ended) {
     return FOS_OK;
 }
 
+// UNCACHED device memory (the mailboxes, the relay and vector-exchange buffers, the resident solve's record arrays) is kept for the life of the
+// process and handed from handle to handle, never returned to the runtime: on this image (ROCm 7.2), device memory that had been allocated
+// uncached, freed, and handed out again by a later hipMalloc gave a WRONG dense IndAffine set-up several handles later (deterministic;
+// DESIGN_LOG.md "the recycled uncached pages") -- so these pages are never recycled as anything else.  A block serves a later request of
+// the same device for at most its own size and at least half of it.
+namespace {
+struct UncachedBlock { int device; void* p; size_t bytes; bool uncached; };
+std::mutex g_unc_mu;
+std::vector<UncachedBlock> g_unc_free, g_unc_used;
+}
+// falls back to fine-grained memory (what the mailboxes accept), or with `allow_plain` (the records: cache-bypassing accesses work on any
+// memory) to ordinary memory
+static int uncached_acquire(int device, size_t bytes, bool allow_plain, void** out, const char* what) {
+    UncachedBlock r{device, nullptr, 0, false};
+    {
+        std::lock_guard<std::mutex> lk(g_unc_mu);
+        for (size_t i = 0; i < g_unc_free.size(); ++i) {
+            const UncachedBlock& f = g_unc_free[i];
+            if (f.device == device && f.bytes >= bytes && f.bytes / 2 <= bytes) { r = f; g_unc_free.erase(g_unc_free.begin() + (long)i); break; }
+        }
+    }
+    if (!r.p) {
+        static const bool unc = !(getenv("FOS_RES_UNCACHED") && atoi(getenv("FOS_RES_UNCACHED")) == 0);
+        hipError_t e = (unc || !allow_plain) ? hipExtMallocWithFlags(&r.p, bytes, hipDeviceMallocUncached) : hipErrorUnknown;
+        r.uncached = (e == hipSuccess);
+        if (e != hipSuccess && !allow_plain) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&r.p, bytes, hipDeviceMallocFinegrained); }
+        if (e != hipSuccess && allow_plain) { (void)hipGetLastError(); e = hipMalloc(&r.p, bytes); }
+        if (e != hipSuccess) { set_error("hipExtMallocWithFlags(%s, %zu bytes): %s", what, bytes, hipGetErrorString(e)); return FOS_ENOMEM; }
+        r.bytes = bytes;
+    }
+    { std::lock_guard<std::mutex> lk(g_unc_mu); g_unc_used.push_back(r); }
+    *out = r.p;
+    return FOS_OK;
+}
+static void uncached_release(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_unc_mu);
+    for (size_t i = 0; i < g_unc_used.size(); ++i)
+        if (g_unc_used[i].p == p) { g_unc_free.push_back(g_unc_used[i]); g_unc_used.erase(g_unc_used.begin() + (long)i); return; }
+}
+
 // FOS_CG_RESIDENT: (re)plan the resident solve for at most `gmax` workgroups -- every one of them must be on the device at once, so ranks that
 // share ONE device (the tests' stand-in for a multi-GPU box) share its CUs
 int resident_setup(fos_solver* h, int gmax) {
@@ -470,20 +514,15 @@ int resident_setup(fos_solver* h, int gmax) {
     if (!build_resident_plan(h->hostS, h->m, h->n, gmax, &plan)) { h->res_plan = plan; h->res_all = false; return FOS_OK; }
     FOS_HIP(hipStreamSynchronize(h->stream));
     if (!h->res.grec) {
-        // the records live in UNCACHED device memory, as the mailboxes do (measured: an exchange 0.3 us shorter than with ordinary memory and
-        // cache-bypassing accesses -- profiles/r06_res_exp*.txt; FOS_RES_UNCACHED=0: ordinary memory)
-        const bool unc = !(getenv("FOS_RES_UNCACHED") && atoi(getenv("FOS_RES_UNCACHED")) == 0);
+        constexpr size_t b1 = sizeof(unsigned long long) * 2 * RES_GMAX * 8, b2 = sizeof(unsigned long long) * 2 * RES_GMAX * 64 * 4;
         void *q1 = nullptr, *q2 = nullptr;
-        const size_t b1 = sizeof(unsigned long long) * 2 * RES_GMAX * 8, b2 = sizeof(unsigned long long) * 2 * RES_GMAX * 64 * 4;
-        hipError_t e1 = unc ? hipExtMallocWithFlags(&q1, b1, hipDeviceMallocUncached) : hipErrorUnknown;
-        if (e1 != hipSuccess) { (void)hipGetLastError(); e1 = hipMalloc(&q1, b1); }
-        hipError_t e2 = unc ? hipExtMallocWithFlags(&q2, b2, hipDeviceMallocUncached) : hipErrorUnknown;
-        if (e2 != hipSuccess) { (void)hipGetLastError(); e2 = hipMalloc(&q2, b2); }
-        if (e1 != hipSuccess || e2 != hipSuccess) { set_error("resident CG: allocating the workgroups' record arrays failed"); return FOS_ENOMEM; }
-        h->owned.push_back(q1); h->owned.push_back(q2);
+        FOS_TRY(uncached_acquire(h->device, b1, true, &q1, "resident CG records"));
+        h->pooled.push_back(q1);
+        FOS_TRY(uncached_acquire(h->device, b2, true, &q2, "resident CG column records"));
+        h->pooled.push_back(q2);
+        FOS_HIP(hipMemset(q1, 0, b1));                           // sequence number 0 is never sent
+        FOS_HIP(hipMemset(q2, 0, b2));
         h->res.grec = static_cast<unsigned long long*>(q1); h->res.crec = static_cast<unsigned long long*>(q2);
-        FOS_HIP(hipMemset(h->res.grec, 0, sizeof(unsigned long long) * 2 * RES_GMAX * 8));        // sequence number 0 is never sent
-        FOS_HIP(hipMemset(h->res.crec, 0, sizeof(unsigned long long) * 2 * RES_GMAX * 64 * 4));
     }
     ResWG* dwg = const_cast<ResWG*>(h->res.wg);
     dev_release(h, &dwg);
@@ -873,9 +912,10 @@ int prox_cones(fos_solver* h, d2* out, const d2* in, const int32_t* gate = nullp
     launch_cones_soc(c, out, in, h->soc, h->nsoc);
     launch_cones_exp(c, out, in, h->expc, h->nexp);
     prof_end(h, po);
-    const int pe = h->npsd > 0 ? prof_begin(h, FOS_PROF_PSD, 0, h->prof_seen[FOS_PROF_PSD]++) : -1;
+    const int pe = (h->npsd > 0 || h->psd_big) ? prof_begin(h, FOS_PROF_PSD, 0, h->prof_seen[FOS_PROF_PSD]++) : -1;
     FOS_TRY(launch_cones_psd(c, out, in, h->psd, h->npsd, h->psd_kmin, h->psd_kmax, h->psd_scratch,
                              h->psd_V[h->psd_cur], h->psd_V[1 - h->psd_cur], h->psd_have_prev, h->psd_stats, h->psd_phase_limit, h->psd_redo));
+    FOS_TRY(launch_cones_psd_sign(c, h->psd_big, out, in));                  // cones of order > 64
     prof_end(h, pe);
     // (a diagnostic launch truncated before the basis store leaves the previous basis current)
     if (h->npsd > 0 && h->psd_V[0] && (h->psd_phase_limit == 0 || (h->psd_phase_limit >= 4 && h->psd_phase_limit < 11))) { h->psd_cur = 1 - h->psd_cur; h->psd_have_prev = std::min(h->psd_have_prev + 1, 2); }
@@ -1199,7 +1239,7 @@ int step_once(fos_solver* h, int64_t i, const d2** check_on, bool will_check, bo
                 static const bool fuse_psd = !(getenv("FOS_PSD_FUSE") && atoi(getenv("FOS_PSD_FUSE")) == 0);
                 // GAP / DR, no status check in this step, every non-elementwise cone a PSD(64) cone with a basis from the last projection:
                 // relaxation, projection and the step's last pass are ONE launch (PsdFuse, fos_internal.hpp)
-                if (fuse_psd && !gapa && !will_check && h->nsoc == 0 && h->nexp == 0 && !h->ls_interval && !h->gapp_iproj && !h->lp.interval &&
+                if (fuse_psd && !gapa && !will_check && h->nsoc == 0 && h->nexp == 0 && !h->psd_big && !h->ls_interval && !h->gapp_iproj && !h->lp.interval &&
                     psd_fuse_possible(cg, h->npsd, h->psd_kmin, h->psd_kmax, h->psd_V[h->psd_cur], h->psd_V[1 - h->psd_cur], h->psd_have_prev, h->psd_redo,
                                       h->psd_phase_limit)) {
                     RoctxRange range("fos:relaxation + PSD projection + final pass (one launch)");
@@ -2016,6 +2056,7 @@ int fos_create2(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowv
     ew[l - 1] = (uint8_t)(EW_MAX0 | (EW_MAX0 << 2));            // tau, kappa  cones.jl:138,141
     FOS_TRY(dev_upload(h, &h->ew_op, ew));
     h->nsoc = (int)soc.size();
+    FOS_TRY(psd_sign_setup(psd, &h->psd_big));            // (orders > 64 leave the list: projected by matrix products)
     h->npsd = (int)psd.size();
     FOS_TRY(dev_upload(h, &h->soc, soc));
     for (auto& cd : psd) h->psd_kmax = std::max(h->psd_kmax, cd.k);
@@ -2077,6 +2118,8 @@ int fos_destroy(fos_handle h) {
         if (h->rank == 0 && !h->host_seg_name.empty()) (void)shm_unlink(h->host_seg_name.c_str());
     }
     for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    psd_sign_destroy(h->psd_big);
+    for (void* p : h->pooled) uncached_release(p);
     for (void* p : h->owned) (void)hipFree(p);
     if (h->st_host) (void)hipHostFree(h->st_host);
     if (h->mark) (void)hipHostFree(h->mark);
@@ -2142,10 +2185,8 @@ int fos_peer_export(fos_handle h, void* handle64) {
     if (!h->peer_mbox) {
         void* q = nullptr;
         const size_t bytes = PEER_BOX_TOTAL_WORDS * sizeof(unsigned long long);    // region 0 + region 1 (four slots)
-        hipError_t e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached);
-        if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained); }
-        if (e != hipSuccess) { set_error("hipExtMallocWithFlags(mailbox): %s", hipGetErrorString(e)); return FOS_ENOMEM; }
-        h->owned.push_back(q);
+        FOS_TRY(uncached_acquire(h->device, bytes, false, &q, "mailbox"));
+        h->pooled.push_back(q);
         FOS_HIP(hipMemset(q, 0, bytes));                         // sequence number 0 is never sent
         h->peer_mbox = reinterpret_cast<unsigned long long*>(q);
     }
@@ -2271,10 +2312,8 @@ int fos_peer_open_host(fos_handle h, int nranks, int rank, const char* shm_name,
     if (!h->peer_relay) {
         void* q = nullptr;
         const size_t rb = PEER_BOX_TOTAL_WORDS * sizeof(unsigned long long);
-        hipError_t er = hipExtMallocWithFlags(&q, rb, hipDeviceMallocUncached);
-        if (er != hipSuccess) { (void)hipGetLastError(); er = hipExtMallocWithFlags(&q, rb, hipDeviceMallocFinegrained); }
-        if (er != hipSuccess) { set_error("hipExtMallocWithFlags(relay): %s", hipGetErrorString(er)); return FOS_ENOMEM; }
-        h->owned.push_back(q);
+        FOS_TRY(uncached_acquire(h->device, rb, false, &q, "relay"));
+        h->pooled.push_back(q);
         h->peer_relay = reinterpret_cast<unsigned long long*>(q);
     }
     FOS_HIP(hipMemset(h->peer_relay, 0, PEER_BOX_TOTAL_WORDS * sizeof(unsigned long long)));
@@ -2421,10 +2460,8 @@ int fos_peer_vec_export(fos_handle h, void* handle64) {
         const size_t doubles = (size_t)2 * g * 2 * (size_t)h->n;
         const size_t bytes = doubles * sizeof(double) + (size_t)4 * g * sizeof(uint32_t) + 64;       // flags: [stage 1 | stage 2][parity][rank]
         void* q = nullptr;
-        hipError_t e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached);
-        if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained); }
-        if (e != hipSuccess) { set_error("hipExtMallocWithFlags(vector exchange buffer, %zu bytes): %s", bytes, hipGetErrorString(e)); return FOS_ENOMEM; }
-        h->owned.push_back(q);
+        FOS_TRY(uncached_acquire(h->device, bytes, false, &q, "vector exchange buffer"));
+        h->pooled.push_back(q);
         FOS_HIP(hipMemset(q, 0, bytes));                         // exchange number 0 is never sent
         h->vec_buf = reinterpret_cast<double*>(q);
         h->vec_nranks = g;

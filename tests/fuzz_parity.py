@@ -312,12 +312,28 @@ def one_feas_seed(pkg, seed):
                 if first_exp_close[0] is not None and i >= first_exp_close[0]:
                     break
                 if not e <= tol + 50 * envelope:
-                    fails.append("iterate %d off by %.2e (envelope %.1e)" % (i, e, envelope))
+                    # which of the two projections is off?  (the same point through each set, device against oracle)
+                    probe = np.random.default_rng(7).standard_normal(n)
+                    diag = []
+                    for which, So in ((1, orc.IndAffine(A, b)), (2, S2o)):
+                        yo = np.empty(n)
+                        So.prox(yo, probe)
+                        diag.append("S%d %.1e" % (which, float(np.abs(d.prox(which, probe) - yo).max())))
+                    d2 = pkg.HipFeasibility(hp)                       # a second handle on the same problem: is the set-up reproducible?
+                    yo = np.empty(n)
+                    orc.IndAffine(A, b).prox(yo, probe)
+                    diag.append("second handle S1 %.1e (its set-up %s); first handle again S1 %.1e" %
+                                (float(np.abs(d2.prox(1, probe) - yo).max()), d2.info(), float(np.abs(d.prox(1, probe) - yo).max())))
+                    d2.close()
+                    fails.append("iterate %d off by %.2e (envelope %.1e; one projection of a probe point, device - oracle: %s; set-up %s)"
+                                 % (i, e, envelope, ", ".join(diag), d.info()))
                     break
         finally:
             d.close()
     except Exception as ex:  # noqa: BLE001
         fails.append("EXCEPTION %s: %s" % (type(ex).__name__, str(ex)[:300]))
+    if fails:
+        print("FUZZ-FAIL", tag, fails, flush=True)
     return tag, fails
 
 
