@@ -115,6 +115,8 @@ PROTOTYPES = {
     "fos_feas_create": (C.c_int, [C.c_int64, C.c_int32, C.POINTER(_h)]),
     "fos_feas_destroy": (C.c_int, [_h]),
     "fos_feas_set_affine": (C.c_int, [_h, C.c_int32, C.c_int64, _dp, _dp]),
+    "fos_feas_set_affine_sparse": (C.c_int, [_h, C.c_int32, C.c_int64, _i64p, _i64p, _dp, _dp]),
+    "fos_feas_affine_stats": (C.c_int, [_h, C.c_int32, _dp]),
     "fos_feas_set_box": (C.c_int, [_h, C.c_int32, C.c_double, C.c_double]),
     "fos_feas_set_box_arrays": (C.c_int, [_h, C.c_int32, _dp, _dp]),
     "fos_feas_set_cones": (C.c_int, [_h, C.c_int32, C.c_int64, _i32p, _i64p]),

@@ -158,7 +158,8 @@ __global__ __launch_bounds__(FEAS_THREADS) void feas_pad_identity_kernel(int64_t
 }
 
 struct FeasSet {
-    int kind = 0;                   // 0 unset, 1 IndAffine, 2 IndBox, 3 ConeProduct, 4 host callback
+    int kind = 0;                   // 0 unset, 1 IndAffine (dense), 2 IndBox, 3 ConeProduct, 4 host callback, 5 IndAffine (sparse A)
+    SparseAffine* sa = nullptr;     // kind 5 (affine_sparse.hip)
     fos_prox_fn cb = nullptr;       // kind 4: prox!(y, S, x) evaluated by the caller on pinned host vectors
     void* cb_ctx = nullptr;
     double *cb_x = nullptr, *cb_y = nullptr;
@@ -268,6 +269,8 @@ int feas_prox(fos_feas* h, int which, double* y, const double* x) {
         FOS_TRY(launch_cones_psd_sign(c, s.psd_big, h->zout, h->zin));          // cones of order > 64 (psd_sign.hip)
         if (s.npsd > 0 && s.psd_V[0]) { ms.psd_cur = 1 - ms.psd_cur; ms.psd_have_prev = 1; }      // warm start of the next projection
         FEAS_K(feas_from_parts_kernel, h->n, y, (const double2*)h->zout);
+    } else if (s.kind == 5) {                                             // IndAffine over a sparse A: CG on the normal equations, exact to the residual's rounding level
+        FOS_TRY(sparse_affine_project(s.sa, h->stream, y, x));
     } else if (s.kind == 4) {                                             // any other ProximableFunction: the caller's prox! on host vectors
         FOS_HIP(hipMemcpyAsync(s.cb_x, x, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
         FOS_HIP(hipStreamSynchronize(h->stream));
@@ -469,7 +472,7 @@ int fos_feas_destroy(fos_feas_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* q : h->owned) (void)hipFree(q);
-    for (FeasSet& s : h->S) { if (s.cb_x) (void)hipHostFree(s.cb_x); if (s.cb_y) (void)hipHostFree(s.cb_y); psd_sign_destroy(s.psd_big); }
+    for (FeasSet& s : h->S) { if (s.cb_x) (void)hipHostFree(s.cb_x); if (s.cb_y) (void)hipHostFree(s.cb_y); psd_sign_destroy(s.psd_big); sparse_affine_destroy(s.sa); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return FOS_OK;
@@ -549,6 +552,26 @@ int fos_feas_set_affine(fos_feas_handle h, int32_t which, int64_t m, const doubl
     cleanup();
     if (rc != FOS_OK) return rc;
     s.kind = 1; s.ns_iters = it; s.ns_resid = resid;
+    return FOS_OK;
+}
+
+// IndAffine(A, b), A a sparse m x n matrix (CSC, 1-based: Julia's SparseMatrixCSC{Float64,Int64}), full row rank: nothing dense is formed, any n
+int fos_feas_set_affine_sparse(fos_feas_handle h, int32_t which, int64_t m, const int64_t* colptr, const int64_t* rowval, const double* nzval, const double* b) {
+    if (!h || which < 1 || which > 2 || m < 1 || m > h->n) { set_error("fos_feas_set_affine_sparse: bad argument (1 <= m <= n, which = 1 | 2)"); return FOS_EINVAL; }
+    FOS_HIP(hipSetDevice(h->device));
+    SparseAffine* sa = nullptr;
+    FOS_TRY(sparse_affine_setup(m, h->n, colptr, rowval, nzval, b, h->cus, &sa));
+    FeasSet& s = h->S[which - 1];
+    sparse_affine_destroy(s.sa);
+    s.sa = sa; s.kind = 5;
+    return FOS_OK;
+}
+
+// out8: projections so far, CG iterations so far, CG iterations / restarts of the last projection, its |A y - b| and the rounding level | |A||y| + |b| |
+// (rows scaled to unit norm), stored entries, lanes per row of A x 1000 + of A'
+int fos_feas_affine_stats(fos_feas_handle h, int32_t which, double* out8) {
+    if (!h || !out8 || which < 1 || which > 2 || h->S[which - 1].kind != 5) { set_error("fos_feas_affine_stats: set %d is not a sparse IndAffine", (int)which); return FOS_EINVAL; }
+    sparse_affine_stats(h->S[which - 1].sa, out8);
     return FOS_OK;
 }
 
@@ -757,7 +780,7 @@ int fos_feas_set_iterate(fos_feas_handle h, const double* x0) {
     FOS_HIP(hipMemcpyAsync(h->a12, &two, sizeof(double), hipMemcpyHostToDevice, h->stream));
     FOS_HIP(hipStreamSynchronize(h->stream));
     h->fista_t = 1.0; h->status = FOS_STATUS_CONTINUE; h->checked = 0; h->err = NAN;
-    for (FeasSet& s : h->S) { s.psd_cur = 0; s.psd_have_prev = 0; }        // a new solve starts its PSD projections cold
+    for (FeasSet& s : h->S) { s.psd_cur = 0; s.psd_have_prev = 0; sparse_affine_reset(s.sa, h->stream); }        // a new solve starts its PSD projections cold, the sparse IndAffine's multipliers at zero
     return feas_check_launch("fos_feas_set_iterate");
 }
 

@@ -557,6 +557,13 @@ int psd_sign_setup(std::vector<ConeDesc>& psd, PsdSign** out);
 void psd_sign_destroy(PsdSign* p);
 int psd_sign_count(const PsdSign* p);
 int launch_cones_psd_sign(const LaunchCtx& c, PsdSign* p, double2* out, const double2* in);
+// IndAffine(A, b) with a sparse A (affine_sparse.hip): exact projection by warm-started CG on the row-scaled normal equations, the true residual re-checked
+struct SparseAffine;
+int sparse_affine_setup(int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval, const double* b, int cus, SparseAffine** out);
+int sparse_affine_project(SparseAffine* a, hipStream_t stream, double* y, const double* x);      // y, x: device vectors of length n, y must not alias x
+void sparse_affine_reset(SparseAffine* a, hipStream_t stream);                                   // a new solve: lambda = 0
+void sparse_affine_stats(const SparseAffine* a, double* out8);
+void sparse_affine_destroy(SparseAffine* a);
 size_t psd_scratch_bytes(int kmax, int ncones);
 size_t psd_basis_doubles(int kmax, int ncones);
 

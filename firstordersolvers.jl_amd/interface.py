@@ -788,12 +788,19 @@ def solve(problem, alg, device=0, out=None):
 # ProximalOperators objects; the device path takes the two set types below (the ones test/testfeasibility.jl uses).
 
 class IndAffine:
-    """ProximalOperators.IndAffine(A, b): {x : A x = b}, dense A (m x n, full row rank)."""
+    """ProximalOperators.IndAffine(A, b): {x : A x = b}, A m x n of full row rank.  A dense A (n <= 46 000) becomes a dense projector on the
+    device (fos_feas_set_affine); a scipy.sparse A stays sparse at any n (fos_feas_set_affine_sparse: warm-started CG on the row-scaled normal
+    equations, ended by the recomputed residual) -- `sparse=True / False` forces either form."""
 
-    def __init__(self, A, b):
-        if sp.issparse(A):                                              # (a sparse A is handed over dense: the projector is dense anyway)
-            A = A.toarray()
-        self.A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
+    DENSE_MAX = 46000
+
+    def __init__(self, A, b, sparse=None):
+        self.sparse = bool(sp.issparse(A) or np.shape(A)[1] > self.DENSE_MAX) if sparse is None else bool(sparse)
+        if self.sparse:
+            self.A = sp.csc_matrix(A, dtype=np.float64)
+            self.A.sum_duplicates(); self.A.sort_indices()
+        else:
+            self.A = np.ascontiguousarray(A.toarray() if sp.issparse(A) else np.asarray(A, dtype=np.float64))
         self.b = np.ascontiguousarray(np.asarray(b, dtype=np.float64))
         if self.A.ndim != 2 or self.b.shape != (self.A.shape[0],):
             raise ValueError("IndAffine(A, b): A must be m x n and b of length m")
@@ -854,7 +861,14 @@ class HipFeasibility:
             if isinstance(S, IndAffine):
                 if S.A.shape[1] != self.n:
                     raise ValueError("IndAffine: A has %d columns, the problem has n = %d" % (S.A.shape[1], self.n))
-                _lib.check(self._lib.fos_feas_set_affine(self._h, which, S.A.shape[0], _lib.dptr(S.A), _lib.dptr(S.b)))
+                if S.sparse:
+                    i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+                    colptr = np.ascontiguousarray(S.A.indptr, dtype=np.int64) + 1          # Julia 1-based
+                    rowval = np.ascontiguousarray(S.A.indices, dtype=np.int64) + 1
+                    nzval = np.ascontiguousarray(S.A.data, dtype=np.float64)
+                    _lib.check(self._lib.fos_feas_set_affine_sparse(self._h, which, S.A.shape[0], i64(colptr), i64(rowval), _lib.dptr(nzval), _lib.dptr(S.b)))
+                else:
+                    _lib.check(self._lib.fos_feas_set_affine(self._h, which, S.A.shape[0], _lib.dptr(S.A), _lib.dptr(S.b)))
             elif isinstance(S, IndBox) and S.arrays:
                 lo = np.ascontiguousarray(np.broadcast_to(S.lo, (self.n,)), dtype=np.float64)
                 hi = np.ascontiguousarray(np.broadcast_to(S.hi, (self.n,)), dtype=np.float64)
@@ -974,6 +988,13 @@ class HipFeasibility:
         res = (C.c_double * 2)()
         _lib.check(self._lib.fos_feas_info(self._h, C.byref(a12), its, res))
         return {"alpha12": a12.value, "ns_iters": list(its), "ns_resid": list(res)}
+
+    def affine_stats(self, which):
+        """the sparse IndAffine's counters (fos_feas_affine_stats)"""
+        o = np.zeros(8)
+        _lib.check(self._lib.fos_feas_affine_stats(self._h, which, _lib.dptr(o)))
+        return {"projections": int(o[0]), "cg_iterations": int(o[1]), "last_cg_iterations": int(o[2]), "last_restarts": int(o[3]), "last_residual": o[4],
+                "last_rounding_level": o[5], "nnz": int(o[6]), "lanes_per_row": (int(o[7]) // 1000, int(o[7]) % 1000)}
 
 
 class FeasibilityModel:

@@ -407,6 +407,11 @@ int fos_debug_set(fos_handle h, int32_t what, int64_t value);
  * (fos_feas_set_callback):
  *   fos_feas_set_affine  IndAffine(A, b): A m x n ROW-major, full row rank, n <= 46 000; exact projection x - A'(A A')^-1 (A x - b)
  *                        through a one-time dense inverse formed on the device (Newton-Schulz on the fp64 MFMA GEMM);
+ *   fos_feas_set_affine_sparse  IndAffine(A, b) with A sparse (CSC, 1-based as fos_create's), full row rank, any n: nothing dense is formed; the
+ *                        projection is computed by conjugate gradients on the row-scaled normal equations A A' d = A y - b, warm-started from
+ *                        the previous projection's multipliers, and ends when the RECOMPUTED residual A y - b is at the rounding level of its own
+ *                        evaluation (16 eps | |A||y| + |b| |) -- y - x is in the range of A' by construction (affine_sparse.hip).  Fails
+ *                        loudly (FOS_EINVAL) when that level cannot be reached (A without full row rank).  fos_feas_affine_stats: iteration counts.
  *   fos_feas_set_box     IndBox(lo, hi), scalar bounds (fos_feas_set_box_arrays: array bounds), +-INFINITY allowed;
  *   fos_feas_set_cones   the reference's own ConeProduct (src/cones.jl), any of its nine cone types.
  * `which` = 1 | 2 (S1, S2).  Steps: gap.jl:42-87 (GAP / DR / AP), gapa.jl:61-112, fista.jl:28-56, dykstra.jl:25-44; LineSearchWrapper. */
@@ -414,6 +419,8 @@ typedef struct fos_feas* fos_feas_handle;
 int fos_feas_create(int64_t n, int32_t device, fos_feas_handle* out);
 int fos_feas_destroy(fos_feas_handle h);
 int fos_feas_set_affine(fos_feas_handle h, int32_t which, int64_t m, const double* A, const double* b);
+int fos_feas_set_affine_sparse(fos_feas_handle h, int32_t which, int64_t m, const int64_t* colptr, const int64_t* rowval, const double* nzval, const double* b);
+int fos_feas_affine_stats(fos_feas_handle h, int32_t which, double* out8);
 int fos_feas_set_box(fos_feas_handle h, int32_t which, double lo, double hi);
 int fos_feas_set_box_arrays(fos_feas_handle h, int32_t which, const double* lo, const double* hi);     /* IndBox with array bounds (n each) */
 /* ConeProduct (src/cones.jl:31-94): ncones cones of type[i] (FOS_CONE_*) and len[i] entries, in order, contiguous, covering all n entries;
