@@ -195,7 +195,7 @@ def test_block_form_whole_solves_match_the_oracle(pkg):
 def test_direct_beyond_the_dense_size_is_the_same_projection_by_cg(pkg, monkeypatch, fullsize):
     """l > 46 000 (here forced: FOS_DIRECT_DENSE_MAX = 10): direct = true keeps its meaning -- the EXACT projection onto {Q u = v} from the
     first call on -- computed by the warm-started CG at its tolerance floor instead of the 0.2^sqrt(i) schedule.  Against the oracle's
-    IndAffineDirect from the FIRST call (the scheduled CG is five orders of magnitude off there), and on C3 itself (l = 70 001)."""
+    IndAffineDirect from the FIRST call (the scheduled CG is five orders of magnitude off there), and certified to 1e-12 on C3 and C5 themselves."""
     monkeypatch.setenv("FOS_DIRECT_DENSE_MAX", "10")
     monkeypatch.setenv("FOS_DIRECT_MODE", "dense")         # (small_mixed is block separable: the block form would be taken first)
     prob = pkg.workloads.small_mixed()
@@ -227,18 +227,23 @@ def test_direct_beyond_the_dense_size_is_the_same_projection_by_cg(pkg, monkeypa
     d.close()
     monkeypatch.delenv("FOS_DIRECT_DENSE_MAX")
     monkeypatch.delenv("FOS_DIRECT_MODE")
-    prob = fullsize("C3")                        # l = 70 001: a dense 39 GB inverse is past the limit -> CG at the floor
-    d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
-    d.enable_direct(prob.A)
-    assert d.direct_mode() == "cg"                        # (random sparse columns couple everything: no block form either)
-    x = np.random.default_rng(1).standard_normal(d.N)
-    y = d.prox_affine(x)
-    l = d.l
-    assert np.linalg.norm(d.q_apply(y[:l]) - y[l:]) <= 1e-9 * np.linalg.norm(y)                      # on the set
-    u = np.random.default_rng(2).standard_normal(l)
-    t = np.concatenate([u, d.q_apply(u)])
-    assert abs((x - y) @ t) <= 1e-8 * np.linalg.norm(t) * np.linalg.norm(x)                          # displacement orthogonal to it
-    d.close()
+    # l = 70 001 (C3) and l = 999 761 (C5): a dense inverse is past the limit, random sparse columns couple everything (no block form) -> CG at the
+    # floor.  The projection is certified WITHOUT a factorisation: y is on the set (Q y_u = y_v) and the displacement is in the range of [Q -I]'
+    # (x_u - y_u = Q'w with w = y_v - x_v); sigma_min([Q -I]) >= 1, so the distance to the exact projection is at most the sum of the two defects.
+    for name in ("C3", "C5"):
+        prob = fullsize(name)
+        d = pkg.HipHSDE(prob.A, prob.b, prob.c, prob.K1, prob.K2)
+        d.enable_direct(prob.A)
+        assert d.direct_mode() == "cg"
+        x = np.random.default_rng(1).standard_normal(d.N)
+        l = d.l
+        for rep in range(2):                                  # the second one warm-started
+            y = d.prox_affine(x)
+            on_set = np.linalg.norm(d.q_apply(y[:l]) - y[l:])
+            in_range = np.linalg.norm((x[:l] - y[:l]) - d.q_apply(y[l:] - x[l:], transpose=True))
+            assert on_set + in_range <= 1e-12 * np.linalg.norm(x), (name, rep, on_set, in_range)
+            x = x + 1e-3 * np.random.default_rng(2).standard_normal(d.N)
+        d.close()
 
 
 def test_block_form_on_a_one_rank_communicator_equals_the_single_handle(pkg):
