@@ -512,26 +512,54 @@ def main():
         if res_n:
             # the resident solve reads the operator ONCE per solve (tiles -> registers) and the vectors x, rhs, v once, writes x once; between
             # that nothing moves through HBM: its time is iterations x (sweep out of registers + one exchange of four doubles), i.e. latency
-            res_bytes = 8.0 * ost["vals"] + 48.0 * ost["blocks"] + 16.0 * nmr * 4 + 8.0 * nmr
+            rplan = dev.resident_stats()
             its = cg_timed / max(1, args.steps)
-            roof_res = {
-                "bound": "hbm",
-                "kernel": "cg_resident_kernel: a whole CG solve (conjugategradients.jl:31-55) as one persistent launch -- dual tiles and CG vectors "
-                          "held in registers / LDS, four sums per iteration exchanged between workgroups as self-validating words",
-                "achieved": round(res_bytes / (avg_res_ms * 1e-3) / 1e9, 1) if avg_res_ms > 0 else 0.0,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(res_bytes / (avg_res_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_res_ms > 0 else 0.0,
-                "bytes_per_launch": res_bytes,
-                "bytes_basis": "the operator's stored tiles ONCE per solve + x, rhs, v in, x out; nothing else crosses HBM between the first and the last iteration",
-                "note": "NOT bandwidth bound by construction: the launch's time is iterations x (register-resident sweep + one exchange); the fraction of the "
-                        "HBM peak says how little HBM matters, the figure of merit is `us_per_cg_iteration` against the launch-per-iteration form's",
-                "avg_kernel_ms": round(avg_res_ms, 5), "launches_timed": res_n,
-                "cg_iterations_per_solve": round(its, 2),
-                "us_per_cg_iteration": round(1e3 * avg_res_ms / max(1e-9, its + 1), 3),
-                "resident_plan": dev.resident_stats(),
-                "kernel_share_of_step": shares.get(RES_KEY),
-                "traffic": None,
-            }
+            if rplan.get("form") == "streamed":
+                # STREAMED form: every sweep of a solve (its + 1: the start residual and one per iteration) reads the stored tiles once and, per row of A,
+                # [c; b] (8 B) and x (16 B in, 16 B out); r, w stay in registers, p, s in LDS, the columns in the communication wavefronts -- so the
+                # launch is HBM bound, and what it is priced on is the bound no stored format beats: 8 B per non-zero + 40 B per row, per sweep
+                sweep_bytes = 8.0 * ost["vals"] + 48.0 * ost["blocks"] + 40.0 * prob.m
+                res_bytes = sweep_bytes * (its + 1)
+                roof_res = {
+                    "bound": "hbm",
+                    "kernel": "cg_stream_kernel (FOS_CG_RESIDENT, streamed form): a whole CG solve (conjugategradients.jl:31-55) as one persistent launch -- per "
+                              "iteration ONE pass over the dual tiles does the KKT sweep, its reductions AND the vector updates of the iteration (r, w in "
+                              "registers, p, s in LDS, x in HBM), the four sums cross the workgroups as self-validating words",
+                    "achieved": round(res_bytes / (avg_res_ms * 1e-3) / 1e9, 1) if avg_res_ms > 0 else 0.0,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(res_bytes / (avg_res_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_res_ms > 0 else 0.0,
+                    "frac_time_base": "HIP events on the solver's stream around every %d-th solve of the timed region; the launch's whole duration -- entry, the "
+                                      "start sweep, every iteration's exchange and row update, exit -- not only its streaming phases" % PROF_PERIOD,
+                    "bytes_per_launch": res_bytes, "bytes_per_sweep": sweep_bytes,
+                    "bytes_basis": "ALGORITHMIC: (8 B x stored tile values + 48 B x tiles + 40 B x rows of A) x (CG iterations + 1) sweeps per solve -- the "
+                                   "launch-per-iteration form moved the tiles + 160 B per row and element of x in three launches per iteration",
+                    "algorithmic_bytes_per_launch": res_bytes, "traffic": None,
+                    "avg_kernel_ms": round(avg_res_ms, 5), "launches_timed": res_n,
+                    "cg_iterations_per_solve": round(its, 2),
+                    "us_per_cg_iteration": round(1e3 * avg_res_ms / max(1e-9, its + 1), 3),
+                    "resident_plan": rplan,
+                    "kernel_share_of_step": shares.get(RES_KEY),
+                }
+            else:
+                res_bytes = 8.0 * ost["vals"] + 48.0 * ost["blocks"] + 16.0 * nmr * 4 + 8.0 * nmr
+                roof_res = {
+                    "bound": "hbm",
+                    "kernel": "cg_resident_kernel: a whole CG solve (conjugategradients.jl:31-55) as one persistent launch -- dual tiles and CG vectors "
+                              "held in registers / LDS, four sums per iteration exchanged between workgroups as self-validating words",
+                    "achieved": round(res_bytes / (avg_res_ms * 1e-3) / 1e9, 1) if avg_res_ms > 0 else 0.0,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(res_bytes / (avg_res_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_res_ms > 0 else 0.0,
+                    "bytes_per_launch": res_bytes,
+                    "bytes_basis": "the operator's stored tiles ONCE per solve + x, rhs, v in, x out; nothing else crosses HBM between the first and the last iteration",
+                    "note": "NOT bandwidth bound by construction: the launch's time is iterations x (register-resident sweep + one exchange); the fraction of the "
+                            "HBM peak says how little HBM matters, the figure of merit is `us_per_cg_iteration` against the launch-per-iteration form's",
+                    "avg_kernel_ms": round(avg_res_ms, 5), "launches_timed": res_n,
+                    "cg_iterations_per_solve": round(its, 2),
+                    "us_per_cg_iteration": round(1e3 * avg_res_ms / max(1e-9, its + 1), 3),
+                    "resident_plan": rplan,
+                    "kernel_share_of_step": shares.get(RES_KEY),
+                    "traffic": None,
+                }
         # N > 1: every rank sweeps its own shard at the same time; the job's SpMV rate is the sum over ranks
         agg = None
         if dist is not None:
@@ -686,28 +714,34 @@ def main():
                 "the self test passed, but an exchange of the warm-up timed out on the %s mailboxes (FOS_ECOMM)" % failed
     else:
         raise SystemExit("every transport failed during the warm-up")
-    if world == 1 and dist is None and not args.direct and out["config"]["cg_variant"] == "reference" and not os.environ.get("FOS_BENCH_SHARD"):
-        # the same job on the merged-reduction recurrence (the default of SHARDED handles: one exchange per CG iteration) -- so that a scaling
-        # ratio of an N > 1 run of this bench divides like by like; same handle, same state, `--steps` more outer iterations
-        try:
-            dev.set_cg_variant("merged_update")
-            dev.step(it + 1, 5, BIG, 1e-8)
-            dev.sync()
-            cg0m = dev.cg_total()
-            tm = time.perf_counter()
-            done_m, _, _ = dev.step(it + 6, args.steps, BIG, 1e-8)
-            dev.sync()
-            torch.cuda.synchronize()
-            dtm = time.perf_counter() - tm
-            it += 5 + done_m
-            out["merged_recurrence_n1"] = {"value": round(done_m / dtm, 4), "unit": "iterations/s", "ms_per_step": round(1e3 * dtm / max(1, done_m), 4),
-                                           "cg_variant": dev.cg_variant_name(), "cg_iters_per_step": round((dev.cg_total() - cg0m) / max(1, done_m), 2),
-                                           "note": "N = 1 on the recurrence sharded handles run by default (two launches and one reduction point per CG "
-                                                   "iteration); `value` is N = 1 on the reference's recurrence (three launches, two reduction points)"}
-        except Exception as exc:  # noqa: BLE001
-            out["merged_recurrence_n1"] = {"failed": repr(exc)}
-        finally:
-            dev.set_cg_variant(None)
+    if world == 1 and dist is None and not args.direct and out["config"]["cg_variant"] in ("reference", "resident") and not os.environ.get("FOS_BENCH_SHARD"):
+        # the same job on the other recurrences -- same handle, same state, `--steps` more outer iterations each: the merged-reduction recurrence
+        # with a launch group per iteration (what sharded handles without mailboxes run: a scaling ratio can divide like by like) and, where the
+        # headline ran the resident solve, the reference's recurrence in its three launches per iteration (what `value` was until round 5)
+        extras = [("merged_recurrence_n1", "merged_update",
+                   "N = 1 on the merged-reduction recurrence with a launch group per CG iteration (two launches, one reduction point)")]
+        if out["config"]["cg_variant"] == "resident":
+            extras.insert(0, ("reference_recurrence_n1", "reference",
+                              "N = 1 on the reference's recurrence, three launches and two reduction points per CG iteration (the headline of rounds 1-5); "
+                              "`value` runs the merged recurrence resident: one launch per CG SOLVE"))
+        for key, variant, note in extras:
+            try:
+                dev.set_cg_variant(variant)
+                dev.step(it + 1, 5, BIG, 1e-8)
+                dev.sync()
+                cg0m = dev.cg_total()
+                tm = time.perf_counter()
+                done_m, _, _ = dev.step(it + 6, args.steps, BIG, 1e-8)
+                dev.sync()
+                torch.cuda.synchronize()
+                dtm = time.perf_counter() - tm
+                it += 5 + done_m
+                out[key] = {"value": round(done_m / dtm, 4), "unit": "iterations/s", "ms_per_step": round(1e3 * dtm / max(1, done_m), 4),
+                            "cg_variant": dev.cg_variant_name(), "cg_iters_per_step": round((dev.cg_total() - cg0m) / max(1, done_m), 2), "note": note}
+            except Exception as exc:  # noqa: BLE001
+                out[key] = {"failed": repr(exc)}
+            finally:
+                dev.set_cg_variant(None)
     if world > 1 and not weak_main and not args.no_weak_extra and args.workload == "C4":
         # the same job once more with 512 blocks PER RANK: weak scaling, reported beside the strong-scaling headline
         dev.close()
@@ -721,9 +755,19 @@ def main():
         # the same sharded job under DR(direct = true): the block form's diagonal blocks are local to a rank, its three scalar sums per projection ride
         # the same mailboxes (which time out instead of hanging: a failure here costs the extra line, not the headline)
         args.direct = True
+        dev.close()                                   # (the headline's handle: its mailboxes and device memory are not needed any more at N > 1)
+        d_ok, d_exc = True, None
         try:
             dout, ddev, _, _, _ = run_case(False)
             ddev.close()
+        except (Exception, SystemExit) as exc:  # noqa: BLE001
+            d_ok, d_exc = False, exc
+        # one outcome for the job: a rank whose run failed (its peers then ran into the mailbox time-out, or did not) must not leave the others
+        # reporting a number -- every rank takes part in this vote, whatever happened locally
+        all_ok = agree(d_ok)
+        try:
+            if not all_ok:
+                raise RuntimeError("rank %d: %s" % (rank, repr(d_exc) if d_exc is not None else "another rank's direct = true run failed"))
             out["direct_true"] = {
                 "workload": dout["config"]["workload"] + ", DR(direct=true)", "value": dout["value"], "unit": dout["unit"], "ms_per_step": dout["ms_per_step"],
                 "steps": dout["steps"], "warmup_effective": dout["warmup_effective"], "form": dout["config"]["direct"], "scaling": dout["scaling"],

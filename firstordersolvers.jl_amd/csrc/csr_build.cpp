@@ -1065,7 +1065,41 @@ bool build_resident_plan(const HostBlkCsr& S, int64_t m, int64_t n, int gmax, Re
         }
         if (at != n) return no("columns of A outside the units");
     }
-    if ((int64_t)units.size() > gmax) return no("more units than workgroups");
+    // ---- the STREAMED form (resident.hip, cg_stream_kernel): whole units per workgroup, consecutive ones whose column ranges adjoin, at most 64
+    // columns and 70 tiles per workgroup, tiles of at most 32 steps; one workgroup per CU
+    auto stream_plan = [&](const char* why_not_registers) -> bool {
+        const bool allow = !(getenv("FOS_RESIDENT_STREAM") && atoi(getenv("FOS_RESIDENT_STREAM")) == 0);
+        constexpr int RS_GMAX = 256, RS_NCOMP = 7, RS_NT_MAX = 10;
+        if (!allow || tmax > 32) return no(why_not_registers);
+        const int gm = std::min(gmax, RS_GMAX);
+        const int nu = (int)units.size();
+        const int upw = (nu + gm - 1) / gm;
+        std::vector<ResWG> wgs;
+        int tiles_max = 0;
+        for (int u0 = 0; u0 < nu; u0 += upw) {
+            const int u1 = std::min(nu, u0 + upw);
+            int tcw = 0, tiles = 0;
+            for (int u = u0; u < u1; ++u) {
+                if (u > u0 && (units[u].c0 != units[u - 1].c0 + units[u - 1].tc || units[u].blk0 != units[u - 1].blk0 + units[u - 1].nblk)) return no(why_not_registers);
+                tcw += units[u].tc; tiles += units[u].nblk;
+            }
+            if (tcw > 64 || tiles > RS_NT_MAX * RS_NCOMP) return no(why_not_registers);
+            tiles_max = std::max(tiles_max, tiles);
+            wgs.push_back(ResWG{units[u0].blk0, tiles, units[u0].c0, tcw, 32, (int)wgs.size(), 1, 0});
+        }
+        // tiles per compute wavefront: wavefront w walks tiles [w nblk / 7, (w + 1) nblk / 7)
+        int nt = 0;
+        for (const ResWG& w : wgs)
+            for (int k = 0; k < RS_NCOMP; ++k) nt = std::max(nt, (int)((int64_t)(k + 1) * w.nblk / RS_NCOMP - (int64_t)k * w.nblk / RS_NCOMP));
+        out->stream = 1; out->nt = nt <= 3 ? 3 : (nt <= 5 ? 5 : 10);
+        out->nw = RS_NCOMP; out->ncomm = 1; out->rpt = 0; out->tmax = 32; out->tiles_wg_max = tiles_max; out->units = nu;
+        out->wg = wgs; out->G = (int)wgs.size();
+        out->why.clear();
+        return true;
+    };
+    const bool stream_first = getenv("FOS_RESIDENT_STREAM") && atoi(getenv("FOS_RESIDENT_STREAM")) == 2;       // (tests: the streamed form where the register form would do)
+    if (stream_first) return stream_plan("the streamed form was asked for and does not fit");
+    if ((int64_t)units.size() > gmax) return stream_plan("more units than workgroups");
     if (gmax > RES_GMAX) gmax = RES_GMAX;
     // tiles per workgroup: the smallest tp whose workgroup count fits
     int64_t total = S.nblk;
@@ -1079,7 +1113,7 @@ bool build_resident_plan(const HostBlkCsr& S, int64_t m, int64_t n, int gmax, Re
             G += w;
         }
         if (ok && G <= gmax) break;
-        if (tp > RES_SLOTS) return no("a workgroup would hold more tiles than its registers");
+        if (tp > RES_SLOTS) return stream_plan("a workgroup would hold more tiles than its registers");
     }
     int tiles_max = 0;
     for (const Unit& u : units) {
@@ -1095,7 +1129,7 @@ bool build_resident_plan(const HostBlkCsr& S, int64_t m, int64_t n, int gmax, Re
     if (tmax <= 32 && tiles_max <= 11) { nw = tiles_max; rpt = 1; ncomm = std::min(3, 12 - nw); }
     else if (tmax <= 32 && tiles_max <= 14) { nw = 7; rpt = 2; ncomm = 1; }
     else if (tiles_max <= 7) { nw = tiles_max; rpt = 1; ncomm = 1; }
-    else return no("a workgroup's tiles do not fit the registers");
+    else return stream_plan("a workgroup's tiles do not fit the registers");
     out->ncomm = ncomm;
     out->tmax = tmax <= 32 ? 32 : 64;
     out->nw = nw; out->rpt = rpt; out->tiles_wg_max = tiles_max; out->units = (int)units.size();
@@ -1132,10 +1166,11 @@ int host_resident_cg(const HostBlkCsr& S, const ResPlan& P, int64_t m, int64_t n
                 for (int lane = 0; lane < d.nrows(); ++lane) {
                     const int64_t row = d.row0 + lane;
                     double u1 = 0.0, u2 = 0.0;
-                    for (int t = 0; t < me.tc; ++t) {
+                    const int tc0 = d.meta[0], tcn = d.meta[3];          // the tile's own columns (streamed form: a part of the workgroup's)
+                    for (int t = 0; t < tcn; ++t) {
                         const double a = S.val[d.nnz0 + 64 * (int64_t)t + lane];
-                        u1 += a * g[me.c0 + t].x; u2 += a * g[me.c0 + t].y;
-                        cp[t].x += a * g[row].x; cp[t].y += a * g[row].y;
+                        u1 += a * g[tc0 + t].x; u2 += a * g[tc0 + t].y;
+                        cp[tc0 - me.c0 + t].x += a * g[row].x; cp[tc0 - me.c0 + t].y += a * g[row].y;
                     }
                     const double c = cb[row];
                     const double q1 = -(u1 - gt.x * c), q2 = -(u2 - gt.y * c);

@@ -436,6 +436,7 @@ constexpr int RES_WPU_MAX = 16;      // workgroups per unit
 constexpr int RES_SLOTS = 16;        // tiles per workgroup
 struct ResPlan {                     // host
     int G = 0, nw = 0, ncomm = 0, rpt = 0, tmax = 0, tiles_wg_max = 0, units = 0;      // nw compute wavefronts + ncomm communication wavefronts per workgroup
+    int stream = 0, nt = 0;          // stream: the STREAMED form (tiles re-read every iteration, whole units per workgroup); nt: tiles per compute wavefront
     std::vector<ResWG> wg;
     std::string why;                 // why the operator does not qualify (G == 0)
 };
@@ -445,7 +446,7 @@ bool build_resident_plan(const HostBlkCsr& S, int64_t m, int64_t n, int gmax, Re
 int host_resident_cg(const HostBlkCsr& S, const ResPlan& P, int64_t m, int64_t n, const double* cb, double2* x, const double2* rhs, const double2* v0,
                      double tol, int maxit, int* iters);
 struct ResLaunch {
-    const ResWG* wg; int G, nw, ncomm, rpt, tmax;
+    const ResWG* wg; int G, nw, ncomm, rpt, tmax, stream, nt, tiles_wg_max;
     unsigned long long* grec;        // [2][G][4][2] words: the workgroups' records of the four sums
     unsigned long long* crec;        // [2][G][tmax][2][2] words: the workgroups' column sums (units of more than one workgroup)
     int64_t timeout_ticks;

@@ -600,6 +600,349 @@ __global__ __launch_bounds__(LB) void cg_resident_kernel(ResArgs a) {
     }
 }
 
+// =====================================================================================================================================
+// STREAMED form of the resident solve (round 6): for block-separable operators whose tiles do NOT fit the register file (the whole of C4: 273 MB
+// of tiles against 128 MB of registers; its shards on two and four GPUs).  What stays on chip is everything BUT the matrix: a workgroup owns whole
+// units (consecutive ones, <= 64 columns together), its compute wavefronts walk their tiles once per iteration -- a tile's values are read from
+// HBM / L2 (plain coalesced 512-byte steps), multiplied, and dropped -- while the rows' r and w live in registers, p and s in LDS, x in global
+// memory (read and written once per iteration), the columns and the tau element in the communication wavefronts' registers.  Per CG iteration the
+// chip then reads the matrix once + 40 B per row, where sweep + update kernels read and write the matrix + 160 B per row and pay two launches.
+// Same exchange (records of self-validating words, no grid barrier), same recurrence, same summation order rules as the register form above;
+// a unit lives in ONE workgroup, so column sums never cross workgroups.
+constexpr int RS_GMAX = 256;          // workgroups (= records) of the streamed form: one per CU
+constexpr int RS_NCOMP = 7;           // compute wavefronts per workgroup (+ 1 that communicates): two wavefronts per SIMD, 256 registers each
+
+// a tile in NATURAL column order (as stored): row sums against the workgroup's column elements at gcol (LDS, uniform addresses: broadcasts),
+// column sums ADDED to the wavefront's own array (lanes 0..7, program order inside the wavefront)
+template <int TMAX>
+__device__ __forceinline__ void res_tile_plain(const double (&val)[TMAX], int T, const d2 g, const d2* __restrict__ gcol, d2* __restrict__ colacc, int lane,
+                                               double& u1, double& u2) {
+    u1 = 0.0; u2 = 0.0;
+#pragma unroll
+    for (int grp = 0; grp < TMAX / TILE_GROUP; ++grp) {
+        if (grp * TILE_GROUP < T) {                                  // wave-uniform
+            double p[TILE_GROUP];
+#pragma unroll
+            for (int u = 0; u < TILE_GROUP; ++u) {
+                const d2 xc = gcol[grp * TILE_GROUP + u];
+                u1 += val[grp * TILE_GROUP + u] * xc.x; u2 += val[grp * TILE_GROUP + u] * xc.y;
+                p[u] = val[grp * TILE_GROUP + u] * g.x;
+            }
+            const double s1 = tile_colsum8(p, lane);
+#pragma unroll
+            for (int u = 0; u < TILE_GROUP; ++u) p[u] = val[grp * TILE_GROUP + u] * g.y;
+            const double s2 = tile_colsum8(p, lane);
+            if (lane < TILE_GROUP) {
+                d2 o = colacc[grp * TILE_GROUP + lane];
+                o.x += s1; o.y += s2;
+                colacc[grp * TILE_GROUP + lane] = o;
+            }
+        }
+    }
+}
+
+template <int TMAX, int NT>
+__global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs a) {
+    __shared__ __attribute__((aligned(16))) d2 s_gcol[64];                   // the workgroup's column elements of the vector being swept (v, then r)
+    __shared__ double s_red[16][4];
+    __shared__ double s_ctl[RC_COUNT];
+    __shared__ uint32_t s_halves[PEER_MAX_RANKS * 8];
+    __shared__ int s_cnt, s_failed;
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    d2* const s_colpart = reinterpret_cast<d2*>(s_dyn);                       // [RS_NCOMP][64]: a compute wavefront's column sums of a sweep
+    double* const s_all = reinterpret_cast<double*>(s_colpart + RS_NCOMP * 64);     // [4][RS_GMAX], zero beyond G
+    d2* const s_ps = reinterpret_cast<d2*>(s_all + 4 * RS_GMAX);              // [tiles][2][64]: the rows' p and s
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = (int)(blockDim.x >> 6);
+    constexpr int ncomp = RS_NCOMP;
+    const int ncomm = nw - ncomp;
+    const ResWG me = a.wg[blockIdx.x];
+    const int tc = me.tc, c0 = me.c0, nm = a.nm;
+    DevState* st = a.st;
+    if (a.pb.nranks > 0 && st->xchg_failed) return;
+    if (tid == 0) { s_cnt = 0; s_failed = 0; }
+
+    if (wv < ncomp) {
+        // =========================================================== COMPUTE wavefronts: their tiles streamed once per iteration
+        const int t0 = (int)((long long)wv * me.nblk / ncomp), cnt = (int)((long long)(wv + 1) * me.nblk / ncomp) - t0;        // <= NT (the plan's promise)
+        // (the tiles' descriptors are read again in every iteration, by scalar loads: kept in registers across the loop, they and everything derived
+        //  from them -- addresses, masks, offsets of every tile -- were hoisted out of it and spilled by the hundred)
+        d2 rr[NT], ww[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            rr[q] = ww[q] = make_double2(0.0, 0.0);
+            if (q < cnt) {
+                const BlkDesc d = a.blk[me.blk0 + t0 + q];
+                if (lane < d.nrows()) rr[q] = a.v[d.row0 + lane];
+            }
+        }
+        d2 gt = a.v[nm];
+        d2* const mycol = s_colpart + wv * 64;
+        __syncthreads();                                   // (0) the communication wavefronts have staged the v columns
+        for (int i = -1;; ++i) {
+            mycol[lane] = make_double2(0.0, 0.0);
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                if (q < cnt) {                             // wave-uniform
+                    const BlkDesc d = a.blk[me.blk0 + t0 + q];
+                    const int T = d.steps(), coff = d.meta[0] - c0;
+                    const bool valid = lane < d.nrows();
+                    const double* __restrict__ vp = a.val + d.nnz0 + lane;
+                    double val[TMAX];
+                    // (requesting a wavefront's first tile BEFORE the exchange in front of it was measured: 70.5 against 66.3 us per iteration --
+                    //  the bulk loads delay the exchange's words)
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t) val[t] = ((t & ~7) < T) ? __builtin_nontemporal_load(vp + 64 * t) : 0.0;       // (zero-padded storage beyond the tile's rows)
+                    const double c = valid ? a.cb[d.row0 + lane] : 0.0;
+                    const d2 gq = rr[q];
+                    double u1, u2;
+                    res_tile_plain<TMAX>(val, T, gq, s_gcol + coff, mycol + coff, lane, u1, u2);
+                    const double q1 = -(u1 - gt.x * c), q2 = -(u2 - gt.y * c);           // rows of A: EpiKkt::row, i >= n   (HSDEAffine.jl:52,55)
+                    d2 w = make_double2(gq.x - q2, q1 - gq.y);                           // affinepluslinear.jl:45-48
+                    if (!valid) w = make_double2(0.0, 0.0);
+                    ww[q] = w;
+                    acc[0] += gq.x * gq.x + gq.y * gq.y;
+                    acc[1] += w.x * gq.x + w.y * gq.y;
+                    acc[2] += c * gq.x;
+                    acc[3] += c * gq.y;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double v = wave_sum(acc[k]);
+                if (lane == 0) s_red[wv][k] = v;
+            }
+            __syncthreads();                               // (A) column sums and the wavefronts' sums are in LDS
+            __syncthreads();                               // (B) alpha, beta, the new columns and tau element
+            const double stopf = s_ctl[RC_STOP];
+            if (stopf != 0.0) break;
+            const double alpha = s_ctl[RC_ALPHA], beta = s_ctl[RC_BETA];
+            gt = make_double2(s_ctl[RC_GTX], s_ctl[RC_GTY]);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                if (q < cnt) {
+                    const BlkDesc d = a.blk[me.blk0 + t0 + q];
+                    const bool valid = lane < d.nrows();
+                    const int row = d.row0 + lane;
+                    const size_t e = (size_t)(t0 + q) * 128 + lane;
+                    const d2 w = ww[q];
+                    if (i < 0) {
+                        const d2 rh = valid ? a.rhs[row] : make_double2(0.0, 0.0);
+                        rr[q] = make_double2(rh.x - w.x, rh.y - w.y);                    // r_0 = rhs - M v      conjugategradients.jl:33
+                    } else {
+                        d2 pq, sq, xq = valid ? a.x[row] : make_double2(0.0, 0.0);
+                        if (i == 0) { pq = rr[q]; sq = w; }
+                        else {
+                            pq = s_ps[e]; sq = s_ps[e + 64];
+                            pq.x = pq.x * beta + rr[q].x; pq.y = pq.y * beta + rr[q].y;  // p .*= beta ; p .+= r     :49-50
+                            sq.x = sq.x * beta + w.x; sq.y = sq.y * beta + w.y;          // s = M p by the same recurrence
+                        }
+                        xq.x += alpha * pq.x; xq.y += alpha * pq.y;                      // :40
+                        rr[q].x -= alpha * sq.x; rr[q].y -= alpha * sq.y;                // :41
+                        s_ps[e] = pq; s_ps[e + 64] = sq;
+                        if (valid) a.x[row] = xq;
+                    }
+                }
+            }
+        }
+        return;
+    }
+
+    // =============================================================== COMMUNICATION wavefronts (the register form's, a unit = this workgroup alone)
+    const int cw = wv - ncomp, ct = tid - 64 * ncomp;
+    const bool c0wave = cw == 0;
+    d2 cx = make_double2(0.0, 0.0), cr = cx, cpv = cx, csv = cx, crhs = cx;
+    double cc = 0.0;
+    d2 gt = a.v[nm], xt = a.x[nm], pt = make_double2(0.0, 0.0), stt = pt;
+    const d2 rhst = a.rhs[nm];
+    for (int q = ct; q < 4 * RS_GMAX; q += 64 * ncomm) s_all[q] = 0.0;
+    for (int q = ct + ncomp * 4; q < 16 * 4; q += 64 * ncomm) (&s_red[0][0])[q] = 0.0;
+    if (c0wave) {
+        if (lane < tc) { cr = a.v[c0 + lane]; cx = a.x[c0 + lane]; crhs = a.rhs[c0 + lane]; cc = a.cb[c0 + lane]; }
+        s_gcol[lane] = cr;
+        if (blockIdx.x == 0 && lane == 0) { st->tol = a.tol; st->maxit = a.maxit; st->hit_max = 0; st->rn_old = 0.0; }
+    }
+    __syncthreads();                                           // (0)
+    double colG = 0.0;
+    double g_prev = 0.0, a_prev = 0.0, gam = 0.0;
+    int iter = 0;
+    uint32_t nx = 0;
+    for (int i = -1;; ++i) {
+        const uint32_t seq = a.seq_base + (uint32_t)(i + 1);
+        const size_t par = (size_t)(seq & 1u);
+        unsigned long long* grec = a.grec + par * (size_t)a.G * 8;
+        nx += 1;
+        __syncthreads();                                       // (A)
+        d2 cp = make_double2(0.0, 0.0);
+        if (c0wave) {
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            {
+                d2 o[ncomp];
+#pragma unroll
+                for (int s = 0; s < ncomp; ++s) o[s] = s_colpart[s * 64 + lane];           // (all in flight together, added in wavefront order)
+#pragma unroll
+                for (int s = 0; s < ncomp; ++s) { cp.x += o[s].x; cp.y += o[s].y; }
+            }
+            if (lane < tc) {
+                acc[0] = colG;
+                acc[1] = (cp.x * cr.y - cp.y * cr.x) + (cr.x * cr.x - cr.y * cr.y) + cc * (gt.x * cr.y - gt.y * cr.x);
+                acc[2] = cc * cr.x;
+                acc[3] = cc * cr.y;
+            }
+            double mine[4];
+            {
+                double rv[12];
+                const int k4 = lane & 3;
+#pragma unroll
+                for (int w = 0; w < 12; ++w) rv[w] = s_red[w][k4];                      // (rows beyond ncomp were zeroed once)
+                double sacc = 0.0;
+#pragma unroll
+                for (int w = 0; w < 12; ++w) sacc += rv[w];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(sacc), k), hi = __builtin_amdgcn_readlane(__double2hiint(sacc), k);
+                    mine[k] = __hiloint2double(hi, lo) + wave_sum(acc[k]);
+                }
+            }
+            if (i < 0) mine[0] = 0.0;
+            if (lane < 8) {
+                const int k = lane >> 1;
+                res_publish_half(grec + (size_t)blockIdx.x * 8 + 2 * k, seq, k == 0 ? mine[0] : (k == 1 ? mine[1] : (k == 2 ? mine[2] : mine[3])), lane & 1);
+            }
+            if (lane < 4) s_all[(size_t)lane * RS_GMAX + blockIdx.x] = lane == 0 ? mine[0] : (lane == 1 ? mine[1] : (lane == 2 ? mine[2] : mine[3]));
+        }
+        {
+            // the other workgroups' 4 record values each, as ONE list dealt to the communication threads (8 items of a thread requested and polled together)
+            const int nrec = 4 * a.G, nthr = 64 * ncomm;
+            const int sleepn = (a.flags >> 8) & 0x7F;
+            constexpr int PU = 8;
+            bool bad = false;
+            for (int base = ct; base < nrec; base += PU * nthr) {
+                const unsigned long long* src[PU];
+                double* dst[PU];
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    const int idx = base + u * nthr;
+                    src[u] = nullptr; dst[u] = nullptr;
+                    if (idx < nrec) {
+                        const int wg = idx >> 2, k = idx & 3;
+                        dst[u] = s_all + (size_t)k * RS_GMAX + wg;
+                        src[u] = wg == (int)blockIdx.x ? nullptr : grec + (size_t)wg * 8 + 2 * k;
+                    }
+                }
+                long long tstart = 0;
+                for (uint32_t spin = 1;; ++spin) {
+                    unsigned long long lo[PU], hi[PU];
+#pragma unroll
+                    for (int u = 0; u < PU; ++u) if (src[u]) { lo[u] = res_ld_word(src[u]); hi[u] = res_ld_word(src[u] + 1); }
+                    bool pending = false;
+#pragma unroll
+                    for (int u = 0; u < PU; ++u) {
+                        if (src[u]) {
+                            if ((uint32_t)(lo[u] >> 32) == seq && (uint32_t)(hi[u] >> 32) == seq) {
+                                *dst[u] = __longlong_as_double((long long)((hi[u] << 32) | (lo[u] & 0xFFFFFFFFull)));
+                                src[u] = nullptr;
+                            } else pending = true;
+                        }
+                    }
+                    if (!pending) break;
+                    if ((spin & 255u) == 0u) {
+                        const long long now = wall_clock64();
+                        if (tstart == 0) tstart = now;
+                        else if (now - tstart >= a.timeout_ticks) { bad = true; break; }
+                    }
+                    if (sleepn >= 2) __builtin_amdgcn_s_sleep(2); else if (sleepn >= 1) __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (bad) s_failed = 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_fetch_add(&s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (c0wave) {
+            {
+                long long tstart = 0;
+                for (uint32_t spin = 1; __hip_atomic_load(&s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(nx * (uint32_t)ncomm); ++spin) {
+                    if ((spin & 4095u) == 0u) {
+                        const long long now = wall_clock64();
+                        if (tstart == 0) tstart = now;
+                        else if (now - tstart >= 2 * a.timeout_ticks) { s_failed = 1; break; }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            bool failed = __hip_atomic_load(&s_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+            double tot[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double rv[RS_GMAX / 64];
+#pragma unroll
+                for (int j = 0; j < RS_GMAX / 64; ++j) rv[j] = s_all[(size_t)k * RS_GMAX + lane + 64 * j];
+                double sacc = 0.0;
+#pragma unroll
+                for (int j = 0; j < RS_GMAX / 64; ++j) sacc += rv[j];
+                tot[k] = wave_sum(sacc);
+            }
+            if (!failed && a.pb.nranks > 0) failed = !res_peer_fold4(a.pb, seq, tot, blockIdx.x == 0, s_halves);
+            // column `lane` of w = M g (EpiKkt::row, i < n: HSDEAffine.jl:51,54) and the tau row (HSDEAffine.jl:57)
+            const double q1 = cp.x + gt.x * cc, q2 = cp.y + gt.y * cc;
+            const d2 cwv = make_double2(cr.x - q2, q1 - cr.y);
+            const d2 wt = make_double2(gt.x + tot[3], -tot[2] - gt.y);
+            double stopf = failed ? 2.0 : 0.0, alpha = 0.0, beta = 0.0;
+            if (!failed) {
+                if (i < 0) {
+                    cr = make_double2(crhs.x - cwv.x, crhs.y - cwv.y);                  // r_0 = rhs - M v      conjugategradients.jl:32-36
+                    gt = make_double2(rhst.x - wt.x, rhst.y - wt.y);
+                } else {
+                    gam = tot[0] + (gt.x * gt.x + gt.y * gt.y);
+                    if (i > 0 && (sqrt(gam) <= a.tol || i >= a.maxit)) { iter = i; stopf = 1.0; }       // conjugategradients.jl:42 for iteration i
+                    else {
+                        const double delta = tot[1] + (wt.x * gt.x + wt.y * gt.y);
+                        if (i == 0) alpha = gam / delta;
+                        else {
+                            beta = gam / g_prev;
+                            alpha = gam / (delta - beta * gam / a_prev);
+                        }
+                        g_prev = gam; a_prev = alpha;
+                        auto upd = [&](const d2 wi, d2& ri, d2& pi, d2& si, d2& xi) {
+                            if (i == 0) { pi = ri; si = wi; }
+                            else {
+                                pi.x = pi.x * beta + ri.x; pi.y = pi.y * beta + ri.y;
+                                si.x = si.x * beta + wi.x; si.y = si.y * beta + wi.y;
+                            }
+                            xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+                            ri.x -= alpha * si.x; ri.y -= alpha * si.y;
+                        };
+                        if (lane < tc) upd(cwv, cr, cpv, csv, cx);
+                        upd(wt, gt, pt, stt, xt);
+                    }
+                }
+            }
+            if (stopf == 0.0) {
+                colG = lane < tc ? cr.x * cr.x + cr.y * cr.y : 0.0;
+                s_gcol[lane] = lane < tc ? cr : make_double2(0.0, 0.0);
+            }
+            if (lane == 0) { s_ctl[RC_ALPHA] = alpha; s_ctl[RC_BETA] = beta; s_ctl[RC_GTX] = gt.x; s_ctl[RC_GTY] = gt.y; s_ctl[RC_STOP] = stopf; }
+        }
+        __syncthreads();                                       // (B)
+        if (s_ctl[RC_STOP] != 0.0) break;
+    }
+    if (c0wave) {
+        const bool ok = s_ctl[RC_STOP] == 1.0;
+        if (ok && lane < tc) a.x[c0 + lane] = cx;
+        if (blockIdx.x == 0 && lane == 0) {
+            if (ok) {
+                a.x[nm] = xt;
+                st->rr = gam;
+                cg_signal_stop(st, iter, a.maxit, gam, a.seq_base >> 11);
+            } else {
+                if (a.pb.nranks > 0) st->xchg_failed = 1;
+                st->bar_failed = 1; st->done = 1;
+            }
+        }
+    }
+}
+
 // dynamic LDS above the default limit needs an opt-in per kernel (a table update; a failure surfaces through the launch check)
 template <class K>
 static void res_lds_optin(K kernel, size_t bytes) {
@@ -617,6 +960,15 @@ void launch_cg_resident(const LaunchCtx& c, const ResLaunch& rl, double2* x, con
     a.ncomp = rl.nw;
     static const int res_flags = getenv("FOS_RES_FLAGS") ? atoi(getenv("FOS_RES_FLAGS")) : (2 << 8);
     a.flags = res_flags;
+    if (rl.stream) {
+        // (the compute wavefronts' sums land in s_red[wv]: RS_NCOMP rows, the others zeroed once)
+        dim3 grid(rl.G), block(64 * (RS_NCOMP + 1));
+        const size_t lds = (size_t)RS_NCOMP * 64 * sizeof(d2) + (size_t)4 * RS_GMAX * sizeof(double) + (size_t)rl.tiles_wg_max * 128 * sizeof(d2);
+        if (rl.nt <= 3) { res_lds_optin(cg_stream_kernel<32, 3>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 3>), grid, block, lds, c.stream, a); }
+        else if (rl.nt <= 5) { res_lds_optin(cg_stream_kernel<32, 5>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 5>), grid, block, lds, c.stream, a); }
+        else { res_lds_optin(cg_stream_kernel<32, 10>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 10>), grid, block, lds, c.stream, a); }
+        return;
+    }
     dim3 grid(rl.G), block(64 * (rl.nw + rl.ncomm));
     auto lds_bytes = [&](size_t nslot, size_t tmax) {
         return nslot * 64 * 4 * sizeof(d2) + nslot * tmax * sizeof(d2) + (size_t)(RES_WPU_MAX - 1) * tmax * 2 * sizeof(double) + (size_t)4 * RES_GMAX * sizeof(double);

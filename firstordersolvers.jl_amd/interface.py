@@ -463,7 +463,10 @@ class HipHSDE:
         st = (C.c_int64 * 8)()
         _lib.check(self._lib.fos_resident_stats(self._h, st))
         keys = ("qualifies", "workgroups", "waves_per_workgroup", "tiles_per_wave", "units", "max_tiles_per_workgroup", "steps_per_tile", "all_ranks_qualify")
-        return {k: int(st[i]) for i, k in enumerate(keys)}
+        out = {k: int(st[i]) for i, k in enumerate(keys)}
+        out["form"] = "streamed" if out["tiles_per_wave"] < 0 else "registers"        # streamed: tiles re-read every iteration (resident.hip, cg_stream_kernel)
+        out["tiles_per_wave"] = abs(out["tiles_per_wave"])
+        return out
 
     def debug_set(self, what, value):
         _lib.check(self._lib.fos_debug_set(self._h, int(what), int(value)))

@@ -388,7 +388,8 @@ int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int3
 #define FOS_CG_RESIDENT      4
 int fos_set_cg_variant(fos_handle h, int32_t variant);
 /* The plan of FOS_CG_RESIDENT for this handle (conjugategradients.jl:31-55 as one launch): stats8 = {qualifies (0 / 1), workgroups, wavefronts
- * per workgroup, tiles per wavefront, units (runs of columns = diagonal blocks), most tiles in one workgroup, steps per tile (32 / 64),
+ * per workgroup, tiles per wavefront (NEGATIVE: the streamed form -- tiles re-read from memory every iteration, whole units per workgroup, for operators
+ * whose tiles exceed the register file), units (runs of columns = diagonal blocks), most tiles in one workgroup, steps per tile (32 / 64),
  * every rank qualifies (sharded handles: the vote of fos_peer_enable; else = qualifies)}. */
 int fos_resident_stats(fos_handle h, int64_t* stats8);
 int fos_get_cg_variant(fos_handle h, int32_t* variant);   /* the variant the next projection runs (defaults resolved) */

@@ -46,6 +46,12 @@ CASES = [
     ("two-tiles-per-wave", [(64 * 13 + 20, 16)] * 2, "2", dict(workgroups=2, waves_per_workgroup=7, tiles_per_wave=2, max_tiles_per_workgroup=14)),
     ("wide-tiles", [(130, 50), (200, 40)], None, dict(steps_per_tile=64)),
     ("psd16-blocks", [(136, 12)] * 5, None, dict(workgroups=15)),                                             # 64 + 64 + 8 rows: the ragged last tile
+    # the STREAMED form (FOS_RESIDENT_STREAM=2 asks for it where the register form would do): tiles re-read every iteration, whole units per workgroup
+    ("stream-one-unit-per-workgroup", [(700, 24)] * 4, None, dict(form="streamed", workgroups=4, max_tiles_per_workgroup=11, tiles_per_wave=3)),
+    ("stream-two-units-per-workgroup", [(300, 20)] * 6, "3", dict(form="streamed", workgroups=3, max_tiles_per_workgroup=10)),
+    ("stream-many-tiles", [(64 * 30 + 10, 32)] * 2, "1", dict(form="streamed", workgroups=1, max_tiles_per_workgroup=62, tiles_per_wave=10)),
+    ("stream-ragged-units", [(136, 12)] * 5, "2", dict(form="streamed", workgroups=2, max_tiles_per_workgroup=9)),
+    ("stream-five-tiles-per-wave", [(64 * 17, 30)] * 4, "2", dict(form="streamed", workgroups=2, max_tiles_per_workgroup=34, tiles_per_wave=5)),
 ]
 
 
@@ -54,6 +60,8 @@ def test_resident_cg_matches_oracle_merged_update_and_dense_solve(pkg, case, mon
     name, shapes, gmax, want = case
     if gmax:
         monkeypatch.setenv("FOS_RESIDENT_GMAX", gmax)
+    if name.startswith("stream"):
+        monkeypatch.setenv("FOS_RESIDENT_STREAM", "2")
     rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000 + 7)
     A = block_op(rng, shapes)
     m, n = A.shape

@@ -54,8 +54,9 @@ def test_which_operators_qualify(pkg):
     # fewer workgroups than tiles: several tiles per workgroup; than units: does not qualify
     rc, st, _, _ = host_resident(pkg, A, b(A), c(A), 8)
     assert st["qualifies"] == 1 and st["workgroups"] == 8 and st["max_tiles_per_workgroup"] == 3 and st["waves_per_workgroup"] == 3
+    # fewer workgroups than units: the STREAMED form -- whole consecutive units per workgroup, tiles re-read every iteration (tiles_per_wave < 0)
     rc, st, _, _ = host_resident(pkg, A, b(A), c(A), 7)
-    assert st["qualifies"] == 0
+    assert st["qualifies"] == 1 and st["tiles_per_wave"] < 0 and st["workgroups"] == 4 and st["max_tiles_per_workgroup"] == 6
     # wide blocks (33..64 columns): 64-step tiles
     A = block_sdp(rng, 4, 200, 40)
     rc, st, _, _ = host_resident(pkg, A, b(A), c(A), 256)
@@ -79,7 +80,9 @@ def test_c4_shard_plans(pkg):
     blk = sp.csc_matrix(np.ones((2080, 32)))
     for nblocks, want in ((64, dict(qualifies=1, workgroups=256, max_tiles_per_workgroup=9, waves_per_workgroup=9, tiles_per_wave=1, units=64)),
                           (32, dict(qualifies=1, workgroups=224, max_tiles_per_workgroup=5, waves_per_workgroup=5, units=32)),
-                          (128, dict(qualifies=0))):             # 17 tiles per workgroup: more than the registers hold
+                          (128, dict(qualifies=1, workgroups=128, max_tiles_per_workgroup=33, tiles_per_wave=-5, units=128)),   # 17 per workgroup are more than the
+                          (256, dict(qualifies=1, workgroups=256, max_tiles_per_workgroup=33, tiles_per_wave=-5, units=256)),   # registers hold: the streamed form
+                          (512, dict(qualifies=1, workgroups=256, max_tiles_per_workgroup=66, tiles_per_wave=-10, units=512))):  # the whole of C4: two units per CU
         A = sp.block_diag([blk] * nblocks, format="csc")
         rc, st, _, _ = host_resident(pkg, A, np.zeros(A.shape[0]), np.zeros(A.shape[1]), 256)
         assert rc == 0
@@ -97,11 +100,13 @@ def _ocg(M, x0, rhs, tol, maxit, fn=None):
     return x, it
 
 
-def test_host_walk_of_the_plan_matches_the_oracle(pkg):
+def test_host_walk_of_the_plan_matches_the_oracle(pkg, monkeypatch):
     """conjugategradient! over KKTMatrix(HSDEMatrixQ(A, b, c)) by the plan's walk: the first iterations to rounding against the oracle's merged
-    recurrence, the stop rule and the iteration count at a loose and at the floor tolerance -- with one, several and split units per workgroup."""
+    recurrence, the stop rule and the iteration count at a loose and at the floor tolerance -- with one, several and split units per workgroup,
+    and in the streamed form (several whole units per workgroup: gmax below the number of units, or FOS_RESIDENT_STREAM=2)."""
     rng = np.random.default_rng(3)
-    for name, A, gmaxes in (("one-tile-units", block_sdp(rng, 6, 48, 12), (256, 6)),
+    for name, A, gmaxes in (("one-tile-units", block_sdp(rng, 6, 48, 12), (256, 6, 2)),
+                            ("stream-asked-for", block_sdp(rng, 5, 136, 12), (256, 2)),
                             ("split-units", block_sdp(rng, 3, 300, 20), (256, 7, 3)),
                             ("wide", block_sdp(rng, 2, 130, 50), (256, 2)),
                             ("uneven", sp.block_diag([sp.csc_matrix(rng.standard_normal((r, cc)) / 8) for r, cc in ((70, 8), (200, 31), (40, 16), (64, 12))], format="csc"), (256, 5))):
@@ -111,10 +116,15 @@ def test_host_walk_of_the_plan_matches_the_oracle(pkg):
         M = orc.KKTMatrix(Q)
         N = 2 * (m + n + 1)
         rhs, x0 = rng.standard_normal(N), rng.standard_normal(N)
+        if name.startswith("stream"):
+            monkeypatch.setenv("FOS_RESIDENT_STREAM", "2")
+        else:
+            monkeypatch.delenv("FOS_RESIDENT_STREAM", raising=False)
         for gmax in gmaxes:
             for k in (1, 2, 7):
                 rc, st, x, it = host_resident(pkg, A, b, c, gmax, x0, rhs, 1e-300, k)
                 assert rc == 0 and st["qualifies"] == 1, (name, gmax, pkg.lib.load().fos_last_error())
+                assert (st["tiles_per_wave"] < 0) == (name.startswith("stream") or (name == "one-tile-units" and gmax == 2)), (name, gmax, st)
                 xo, ito = _ocg(M, x0, rhs, 1e-300, k)
                 assert it == ito == k, (name, gmax, k, it, ito)
                 # (CG on the indefinite KKT system from a random start amplifies rounding: the yardstick is how far the oracle's OWN two
