@@ -515,11 +515,12 @@ def main():
             rplan = dev.resident_stats()
             its = cg_timed / max(1, args.steps)
             if rplan.get("form") == "streamed":
-                # STREAMED form: every sweep of a solve (its + 1: the start residual and one per iteration) reads the stored tiles once and, per row of A,
-                # [c; b] (8 B) and x (16 B in, 16 B out); r, w stay in registers, p, s in LDS, the columns in the communication wavefronts -- so the
-                # launch is HBM bound, and what it is priced on is the bound no stored format beats: 8 B per non-zero + 40 B per row, per sweep
-                sweep_bytes = 8.0 * ost["vals"] + 48.0 * ost["blocks"] + 40.0 * prob.m
-                res_bytes = sweep_bytes * (its + 1)
+                # STREAMED form: every sweep of a solve (its + 2: the start residual, one per iteration, and the one behind the last update whose
+                # exchange finds the stop) reads the stored tiles once and [c; b] of its rows (8 B per row of A); r, w AND x stay in registers,
+                # p, s in LDS, the columns in the communication wavefront; per solve v, rhs, x come in and x goes out once -- so the launch is HBM
+                # bound, and it is priced on the bound no stored format beats: 8 B per non-zero, per sweep
+                sweep_bytes = 8.0 * ost["vals"] + 48.0 * ost["blocks"] + 8.0 * prob.m
+                res_bytes = sweep_bytes * (its + 2) + 4 * 16.0 * nmr
                 roof_res = {
                     "bound": "hbm",
                     "kernel": "cg_stream_kernel (FOS_CG_RESIDENT, streamed form): a whole CG solve (conjugategradients.jl:31-55) as one persistent launch -- per "
@@ -531,12 +532,15 @@ def main():
                     "frac_time_base": "HIP events on the solver's stream around every %d-th solve of the timed region; the launch's whole duration -- entry, the "
                                       "start sweep, every iteration's exchange and row update, exit -- not only its streaming phases" % PROF_PERIOD,
                     "bytes_per_launch": res_bytes, "bytes_per_sweep": sweep_bytes,
-                    "bytes_basis": "ALGORITHMIC: (8 B x stored tile values + 48 B x tiles + 40 B x rows of A) x (CG iterations + 1) sweeps per solve -- the "
-                                   "launch-per-iteration form moved the tiles + 160 B per row and element of x in three launches per iteration",
+                    "bytes_basis": "ALGORITHMIC: (8 B x stored tile values + 48 B x tiles + 8 B x rows of A) x (CG iterations + 2) sweeps per solve + v, rhs, x "
+                                   "in and x out once -- the launch-per-iteration form moved the tiles + 160 B per row and element of x in three launches "
+                                   "per iteration, so a lower fraction here sits beside FEWER bytes and a shorter iteration (`us_per_cg_iteration`)",
                     "algorithmic_bytes_per_launch": res_bytes, "traffic": None,
                     "avg_kernel_ms": round(avg_res_ms, 5), "launches_timed": res_n,
                     "cg_iterations_per_solve": round(its, 2),
-                    "us_per_cg_iteration": round(1e3 * avg_res_ms / max(1e-9, its + 1), 3),
+                    "us_per_cg_iteration": round(1e3 * avg_res_ms / max(1e-9, its + 2), 3),
+                    "us_per_cg_iteration_note": "launch duration / (iterations + 2 sweeps); in-kernel stamps (profiles/r06_stream_stamps.txt): sweep 41-50 us "
+                                                "(the tiles at 5.5-6.6 TB/s), exchange 9, row update 1",
                     "resident_plan": rplan,
                     "kernel_share_of_step": shares.get(RES_KEY),
                 }

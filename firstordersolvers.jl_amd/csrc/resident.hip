@@ -623,12 +623,17 @@ __device__ __forceinline__ void res_tile_plain(const double (&val)[TMAX], int T,
         if (grp * TILE_GROUP < T) {                                  // wave-uniform
             double p[TILE_GROUP];
 #pragma unroll
-            for (int u = 0; u < TILE_GROUP; ++u) {
-                const d2 xc = gcol[grp * TILE_GROUP + u];
-                u1 += val[grp * TILE_GROUP + u] * xc.x; u2 += val[grp * TILE_GROUP + u] * xc.y;
-                p[u] = val[grp * TILE_GROUP + u] * g.x;
+            for (int h = 0; h < 2; ++h) {                            // (four column elements = 16 registers in flight at a time)
+#pragma unroll
+                for (int u = 4 * h; u < 4 * h + 4; ++u) {
+                    const d2 xc = gcol[grp * TILE_GROUP + u];
+                    u1 += val[grp * TILE_GROUP + u] * xc.x; u2 += val[grp * TILE_GROUP + u] * xc.y;
+                    p[u] = val[grp * TILE_GROUP + u] * g.x;
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             const double s1 = tile_colsum8(p, lane);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < TILE_GROUP; ++u) p[u] = val[grp * TILE_GROUP + u] * g.y;
             const double s2 = tile_colsum8(p, lane);
@@ -637,6 +642,7 @@ __device__ __forceinline__ void res_tile_plain(const double (&val)[TMAX], int T,
                 o.x += s1; o.y += s2;
                 colacc[grp * TILE_GROUP + lane] = o;
             }
+            __builtin_amdgcn_sched_barrier(0);                       // (keeps the next group's LDS reads from being hoisted up here)
         }
     }
 }
@@ -659,26 +665,35 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
     const ResWG me = a.wg[blockIdx.x];
     const int tc = me.tc, c0 = me.c0, nm = a.nm;
     DevState* st = a.st;
+#ifdef FOS_RES_STAMPS
+    int stamp_slot = -1, stamp_it = 0;
+    {
+        const int b = (int)blockIdx.x;
+        const int wslot = b == 0 ? 0 : (b == 1 ? 1 : (b == a.G / 2 ? 2 : (b == a.G - 1 ? 3 : -1)));
+        if (wslot >= 0 && lane == 0 && wv < 16) stamp_slot = wslot * 16 + wv;
+    }
+#endif
     if (a.pb.nranks > 0 && st->xchg_failed) return;
     if (tid == 0) { s_cnt = 0; s_failed = 0; }
+    RES_STAMP_CAL(63);
 
     if (wv < ncomp) {
         // =========================================================== COMPUTE wavefronts: their tiles streamed once per iteration
         const int t0 = (int)((long long)wv * me.nblk / ncomp), cnt = (int)((long long)(wv + 1) * me.nblk / ncomp) - t0;        // <= NT (the plan's promise)
         // (the tiles' descriptors are read again in every iteration, by scalar loads: kept in registers across the loop, they and everything derived
         //  from them -- addresses, masks, offsets of every tile -- were hoisted out of it and spilled by the hundred)
-        d2 rr[NT], ww[NT];
+        d2 rr[NT], ww[NT], xx[NT];
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
-            rr[q] = ww[q] = make_double2(0.0, 0.0);
+            rr[q] = ww[q] = xx[q] = make_double2(0.0, 0.0);
             if (q < cnt) {
                 const BlkDesc d = a.blk[me.blk0 + t0 + q];
-                if (lane < d.nrows()) rr[q] = a.v[d.row0 + lane];
+                if (lane < d.nrows()) { rr[q] = a.v[d.row0 + lane]; xx[q] = a.x[d.row0 + lane]; }
             }
         }
-        d2 gt = a.v[nm];
         d2* const mycol = s_colpart + wv * 64;
         __syncthreads();                                   // (0) the communication wavefronts have staged the v columns
+        RES_STAMP(0);
         for (int i = -1;; ++i) {
             mycol[lane] = make_double2(0.0, 0.0);
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -689,36 +704,44 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
                     const int T = d.steps(), coff = d.meta[0] - c0;
                     const bool valid = lane < d.nrows();
                     const double* __restrict__ vp = a.val + d.nnz0 + lane;
-                    double val[TMAX];
                     // (requesting a wavefront's first tile BEFORE the exchange in front of it was measured: 70.5 against 66.3 us per iteration --
                     //  the bulk loads delay the exchange's words)
-#pragma unroll
-                    for (int t = 0; t < TMAX; ++t) val[t] = ((t & ~7) < T) ? __builtin_nontemporal_load(vp + 64 * t) : 0.0;       // (zero-padded storage beyond the tile's rows)
-                    const double c = valid ? a.cb[d.row0 + lane] : 0.0;
                     const d2 gq = rr[q];
                     double u1, u2;
-                    res_tile_plain<TMAX>(val, T, gq, s_gcol + coff, mycol + coff, lane, u1, u2);
+                    {
+                        double val[TMAX];
+#pragma unroll
+                        for (int t = 0; t < TMAX; ++t) val[t] = ((t & ~7) < T) ? __builtin_nontemporal_load(vp + 64 * t) : 0.0;   // (zero-padded storage beyond the tile's rows)
+                        res_tile_plain<TMAX>(val, T, gq, s_gcol + coff, mycol + coff, lane, u1, u2);
+                    }
+                    const double c = valid ? a.cb[d.row0 + lane] : 0.0;
+                    const d2 gt = make_double2(s_ctl[RC_GTX], s_ctl[RC_GTY]);            // (read here, not held across the tile: registers)
                     const double q1 = -(u1 - gt.x * c), q2 = -(u2 - gt.y * c);           // rows of A: EpiKkt::row, i >= n   (HSDEAffine.jl:52,55)
                     d2 w = make_double2(gq.x - q2, q1 - gq.y);                           // affinepluslinear.jl:45-48
                     if (!valid) w = make_double2(0.0, 0.0);
                     ww[q] = w;
-                    acc[0] += gq.x * gq.x + gq.y * gq.y;
-                    acc[1] += w.x * gq.x + w.y * gq.y;
                     acc[2] += c * gq.x;
                     acc[3] += c * gq.y;
                 }
+            }
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {                 // (r.r and w.r from the registers, in tile order: dummies beyond cnt are zeros)
+                acc[0] += rr[q].x * rr[q].x + rr[q].y * rr[q].y;
+                acc[1] += ww[q].x * rr[q].x + ww[q].y * rr[q].y;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double v = wave_sum(acc[k]);
                 if (lane == 0) s_red[wv][k] = v;
             }
+            RES_STAMP(1);                                   // swept
             __syncthreads();                               // (A) column sums and the wavefronts' sums are in LDS
+            RES_STAMP(2);
             __syncthreads();                               // (B) alpha, beta, the new columns and tau element
+            RES_STAMP(3);
             const double stopf = s_ctl[RC_STOP];
             if (stopf != 0.0) break;
             const double alpha = s_ctl[RC_ALPHA], beta = s_ctl[RC_BETA];
-            gt = make_double2(s_ctl[RC_GTX], s_ctl[RC_GTY]);
 #pragma unroll
             for (int q = 0; q < NT; ++q) {
                 if (q < cnt) {
@@ -731,21 +754,35 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
                         const d2 rh = valid ? a.rhs[row] : make_double2(0.0, 0.0);
                         rr[q] = make_double2(rh.x - w.x, rh.y - w.y);                    // r_0 = rhs - M v      conjugategradients.jl:33
                     } else {
-                        d2 pq, sq, xq = valid ? a.x[row] : make_double2(0.0, 0.0);
+                        d2 pq, sq;
                         if (i == 0) { pq = rr[q]; sq = w; }
                         else {
                             pq = s_ps[e]; sq = s_ps[e + 64];
                             pq.x = pq.x * beta + rr[q].x; pq.y = pq.y * beta + rr[q].y;  // p .*= beta ; p .+= r     :49-50
                             sq.x = sq.x * beta + w.x; sq.y = sq.y * beta + w.y;          // s = M p by the same recurrence
                         }
-                        xq.x += alpha * pq.x; xq.y += alpha * pq.y;                      // :40
+                        xx[q].x += alpha * pq.x; xx[q].y += alpha * pq.y;                // :40
                         rr[q].x -= alpha * sq.x; rr[q].y -= alpha * sq.y;                // :41
                         s_ps[e] = pq; s_ps[e + 64] = sq;
-                        if (valid) a.x[row] = xq;
                     }
+                }
+                if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);     // (two tiles' p and s in flight at a time: all of them together were 80 registers on top of r, w, x)
+            }
+            RES_STAMP(4);                                   // updated
+            RES_STAMP_NEXT();
+            RES_STAMP(0);
+        }
+        // ---- the solution leaves the registers (an exchange that failed leaves x as it was: the caller gets an error, not a half-updated iterate)
+        if (s_ctl[RC_STOP] == 1.0) {
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                if (q < cnt) {
+                    const BlkDesc d = a.blk[me.blk0 + t0 + q];
+                    if (lane < d.nrows()) a.x[d.row0 + lane] = xx[q];
                 }
             }
         }
+        RES_STAMP_CAL(62);
         return;
     }
 
@@ -761,6 +798,7 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
     if (c0wave) {
         if (lane < tc) { cr = a.v[c0 + lane]; cx = a.x[c0 + lane]; crhs = a.rhs[c0 + lane]; cc = a.cb[c0 + lane]; }
         s_gcol[lane] = cr;
+        if (lane == 0) { s_ctl[RC_GTX] = gt.x; s_ctl[RC_GTY] = gt.y; s_ctl[RC_STOP] = 0.0; }      // (the compute wavefronts read the tau element here, from the start)
         if (blockIdx.x == 0 && lane == 0) { st->tol = a.tol; st->maxit = a.maxit; st->hit_max = 0; st->rn_old = 0.0; }
     }
     __syncthreads();                                           // (0)
@@ -768,12 +806,14 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
     double g_prev = 0.0, a_prev = 0.0, gam = 0.0;
     int iter = 0;
     uint32_t nx = 0;
+    RES_STAMP(0);
     for (int i = -1;; ++i) {
         const uint32_t seq = a.seq_base + (uint32_t)(i + 1);
         const size_t par = (size_t)(seq & 1u);
         unsigned long long* grec = a.grec + par * (size_t)a.G * 8;
         nx += 1;
         __syncthreads();                                       // (A)
+        RES_STAMP(1);
         d2 cp = make_double2(0.0, 0.0);
         if (c0wave) {
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -812,6 +852,7 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
             }
             if (lane < 4) s_all[(size_t)lane * RS_GMAX + blockIdx.x] = lane == 0 ? mine[0] : (lane == 1 ? mine[1] : (lane == 2 ? mine[2] : mine[3]));
         }
+        RES_STAMP(2);                                           // published
         {
             // the other workgroups' 4 record values each, as ONE list dealt to the communication threads (8 items of a thread requested and polled together)
             const int nrec = 4 * a.G, nthr = 64 * ncomm;
@@ -859,6 +900,7 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_fetch_add(&s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        RES_STAMP(3);                                           // this wavefront's words have arrived
         if (c0wave) {
             {
                 long long tstart = 0;
@@ -871,6 +913,7 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
+            RES_STAMP(4);
             bool failed = __hip_atomic_load(&s_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
             double tot[4];
 #pragma unroll
@@ -884,6 +927,7 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
                 tot[k] = wave_sum(sacc);
             }
             if (!failed && a.pb.nranks > 0) failed = !res_peer_fold4(a.pb, seq, tot, blockIdx.x == 0, s_halves);
+            RES_STAMP(5);                                       // totals (over the ranks)
             // column `lane` of w = M g (EpiKkt::row, i < n: HSDEAffine.jl:51,54) and the tau row (HSDEAffine.jl:57)
             const double q1 = cp.x + gt.x * cc, q2 = cp.y + gt.y * cc;
             const d2 cwv = make_double2(cr.x - q2, q1 - cr.y);
@@ -924,9 +968,14 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
             }
             if (lane == 0) { s_ctl[RC_ALPHA] = alpha; s_ctl[RC_BETA] = beta; s_ctl[RC_GTX] = gt.x; s_ctl[RC_GTY] = gt.y; s_ctl[RC_STOP] = stopf; }
         }
+        RES_STAMP(6);                                           // scalars, columns, tau
         __syncthreads();                                       // (B)
+        RES_STAMP(7);
+        RES_STAMP_NEXT();
+        RES_STAMP(0);
         if (s_ctl[RC_STOP] != 0.0) break;
     }
+    RES_STAMP_CAL(62);
     if (c0wave) {
         const bool ok = s_ctl[RC_STOP] == 1.0;
         if (ok && lane < tc) a.x[c0 + lane] = cx;
