@@ -1083,15 +1083,17 @@ bool build_resident_plan(const HostBlkCsr& S, int64_t m, int64_t n, int gmax, Re
                 if (u > u0 && (units[u].c0 != units[u - 1].c0 + units[u - 1].tc || units[u].blk0 != units[u - 1].blk0 + units[u - 1].nblk)) return no(why_not_registers);
                 tcw += units[u].tc; tiles += units[u].nblk;
             }
-            if (tcw > 64 || tiles > RS_NT_MAX * RS_NCOMP) return no(why_not_registers);
+            if (tcw > 64 || tiles > RS_NT_MAX * RS_NCOMP + 3) return no(why_not_registers);
             tiles_max = std::max(tiles_max, tiles);
             wgs.push_back(ResWG{units[u0].blk0, tiles, units[u0].c0, tcw, 32, (int)wgs.size(), 1, 0});
         }
-        // tiles per compute wavefront: wavefront w walks tiles [w nblk / 7, (w + 1) nblk / 7)
+        // tiles per compute wavefront (resident.hip, rs_split: the communication wavefront walks the last min(nblk % 7, 3) tiles itself)
         int nt = 0;
-        for (const ResWG& w : wgs)
-            for (int k = 0; k < RS_NCOMP; ++k) nt = std::max(nt, (int)((int64_t)(k + 1) * w.nblk / RS_NCOMP - (int64_t)k * w.nblk / RS_NCOMP));
-        out->stream = 1; out->nt = nt <= 3 ? 3 : (nt <= 5 ? 5 : 10);
+        for (const ResWG& w : wgs) {
+            const int per = w.nblk / RS_NCOMP, r = w.nblk % RS_NCOMP, kc = std::min(r, 3);
+            nt = std::max(nt, per + (r - kc > 0 ? 1 : 0));
+        }
+        out->stream = 1; out->nt = nt <= 3 ? 3 : (nt <= 5 ? 5 : (nt <= 9 ? 9 : 10));
         out->nw = RS_NCOMP; out->ncomm = 1; out->rpt = 0; out->tmax = 32; out->tiles_wg_max = tiles_max; out->units = nu;
         out->wg = wgs; out->G = (int)wgs.size();
         out->why.clear();

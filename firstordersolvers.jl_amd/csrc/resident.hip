@@ -647,6 +647,112 @@ __device__ __forceinline__ void res_tile_plain(const double (&val)[TMAX], int T,
     }
 }
 
+constexpr int RS_NTC = 3;             // tiles the communication wavefront sweeps itself (it waits at barrier (A) otherwise): 66 tiles = 7 x 9 + 3
+
+// which tiles of a workgroup wavefront w walks (w < RS_NCOMP: compute; w == RS_NCOMP: the communication wavefront, the LAST tiles)
+__host__ __device__ inline void rs_split(int nblk, int w, int& t0, int& cnt) {
+    const int per = nblk / RS_NCOMP, r = nblk % RS_NCOMP, kc = r < RS_NTC ? r : RS_NTC, rem = r - kc;
+    if (w < RS_NCOMP) { cnt = per + (w < rem ? 1 : 0); t0 = w * per + (w < rem ? w : rem); }
+    else { cnt = kc; t0 = nblk - kc; }
+}
+
+// the rows of a wavefront's tiles that never leave the registers: residual, w = M r of the last sweep, the iterate
+template <int NT> struct RsRows { d2 rr[NT], ww[NT], xx[NT]; };
+
+template <int NT>
+__device__ __forceinline__ void rs_rows_load(const ResArgs& a, int blk_first, int cnt, int lane, RsRows<NT>& R) {
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        R.rr[q] = R.ww[q] = R.xx[q] = make_double2(0.0, 0.0);
+        if (q < cnt) {
+            const BlkDesc d = a.blk[blk_first + q];
+            if (lane < d.nrows()) { R.rr[q] = a.v[d.row0 + lane]; R.xx[q] = a.x[d.row0 + lane]; }
+        }
+    }
+}
+template <int NT>
+__device__ __forceinline__ void rs_rows_store(const ResArgs& a, int blk_first, int cnt, int lane, const RsRows<NT>& R) {
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        if (q < cnt) {
+            const BlkDesc d = a.blk[blk_first + q];
+            if (lane < d.nrows()) a.x[d.row0 + lane] = R.xx[q];
+        }
+    }
+}
+
+// one sweep of a wavefront's tiles: w = M g on their rows (g = R.rr), their column sums into the wavefront's array, the four sums of the rows
+// (the tiles' descriptors are read again in every sweep, by scalar loads: kept in registers across the solve, they and everything derived from
+//  them -- addresses, masks, offsets of every tile -- were hoisted out of the loop and spilled by the hundred; a branch per tile for the same reason)
+template <int TMAX, int NT>
+__device__ __forceinline__ void rs_sweep(const ResArgs& a, int blk_first, int cnt, int c0, int lane, const d2* __restrict__ s_gcol, const double* s_ctl,
+                                         d2* __restrict__ mycol, RsRows<NT>& R, double (&acc)[4]) {
+    mycol[lane] = make_double2(0.0, 0.0);
+    acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        if (q < cnt) {                             // wave-uniform
+            const BlkDesc d = a.blk[blk_first + q];
+            const int T = d.steps(), coff = d.meta[0] - c0;
+            const bool valid = lane < d.nrows();
+            const double* __restrict__ vp = a.val + d.nnz0 + lane;
+            // (requesting a wavefront's first tile BEFORE the exchange in front of it was measured: 70.5 against 66.3 us per iteration --
+            //  the bulk loads delay the exchange's words)
+            const d2 gq = R.rr[q];
+            double u1, u2;
+            {
+                double val[TMAX];
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t) val[t] = ((t & ~7) < T) ? __builtin_nontemporal_load(vp + 64 * t) : 0.0;   // (zero-padded storage beyond the tile's rows)
+                res_tile_plain<TMAX>(val, T, gq, s_gcol + coff, mycol + coff, lane, u1, u2);
+            }
+            const double c = valid ? a.cb[d.row0 + lane] : 0.0;
+            const d2 gt = make_double2(s_ctl[RC_GTX], s_ctl[RC_GTY]);            // (read here, not held across the tile: registers)
+            const double q1 = -(u1 - gt.x * c), q2 = -(u2 - gt.y * c);           // rows of A: EpiKkt::row, i >= n   (HSDEAffine.jl:52,55)
+            d2 w = make_double2(gq.x - q2, q1 - gq.y);                           // affinepluslinear.jl:45-48
+            if (!valid) w = make_double2(0.0, 0.0);
+            R.ww[q] = w;
+            acc[2] += c * gq.x;
+            acc[3] += c * gq.y;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {                 // (r.r and w.r from the registers, in tile order: slots beyond cnt hold zeros)
+        acc[0] += R.rr[q].x * R.rr[q].x + R.rr[q].y * R.rr[q].y;
+        acc[1] += R.ww[q].x * R.rr[q].x + R.ww[q].y * R.rr[q].y;
+    }
+}
+
+// the rows' share of an iteration's update: i < 0: r_0 = rhs - M v; else (w, r, p, s, x) -> (p, s, x, r)   conjugategradients.jl:39-41,49-50
+template <int NT>
+__device__ __forceinline__ void rs_update(const ResArgs& a, int blk_first, int slot_first, int cnt, int lane, int i, double alpha, double beta,
+                                          d2* __restrict__ s_ps, RsRows<NT>& R) {
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        if (q < cnt) {
+            const size_t e = (size_t)(slot_first + q) * 128 + lane;
+            const d2 w = R.ww[q];
+            if (i < 0) {
+                const BlkDesc d = a.blk[blk_first + q];
+                const d2 rh = lane < d.nrows() ? a.rhs[d.row0 + lane] : make_double2(0.0, 0.0);
+                R.rr[q] = make_double2(rh.x - w.x, rh.y - w.y);                  // r_0 = rhs - M v      conjugategradients.jl:33
+            } else {
+                d2 pq, sq;
+                if (i == 0) { pq = R.rr[q]; sq = w; }
+                else {
+                    pq = s_ps[e]; sq = s_ps[e + 64];
+                    pq.x = pq.x * beta + R.rr[q].x; pq.y = pq.y * beta + R.rr[q].y;      // p .*= beta ; p .+= r     :49-50
+                    sq.x = sq.x * beta + w.x; sq.y = sq.y * beta + w.y;                  // s = M p by the same recurrence
+                }
+                R.xx[q].x += alpha * pq.x; R.xx[q].y += alpha * pq.y;                    // :40
+                R.rr[q].x -= alpha * sq.x; R.rr[q].y -= alpha * sq.y;                    // :41
+                s_ps[e] = pq; s_ps[e + 64] = sq;
+            }
+        }
+        if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);     // (two tiles' p and s in flight at a time: all of them together were 80 registers on top of r, w, x)
+    }
+}
+
 template <int TMAX, int NT>
 __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs a) {
     __shared__ __attribute__((aligned(16))) d2 s_gcol[64];                   // the workgroup's column elements of the vector being swept (v, then r)
@@ -655,8 +761,8 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
     __shared__ uint32_t s_halves[PEER_MAX_RANKS * 8];
     __shared__ int s_cnt, s_failed;
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-    d2* const s_colpart = reinterpret_cast<d2*>(s_dyn);                       // [RS_NCOMP][64]: a compute wavefront's column sums of a sweep
-    double* const s_all = reinterpret_cast<double*>(s_colpart + RS_NCOMP * 64);     // [4][RS_GMAX], zero beyond G
+    d2* const s_colpart = reinterpret_cast<d2*>(s_dyn);                       // [RS_NCOMP + 1][64]: a wavefront's column sums of a sweep
+    double* const s_all = reinterpret_cast<double*>(s_colpart + (RS_NCOMP + 1) * 64);      // [4][RS_GMAX], zero beyond G
     d2* const s_ps = reinterpret_cast<d2*>(s_all + 4 * RS_GMAX);              // [tiles][2][64]: the rows' p and s
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = (int)(blockDim.x >> 6);
@@ -676,59 +782,19 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
     if (a.pb.nranks > 0 && st->xchg_failed) return;
     if (tid == 0) { s_cnt = 0; s_failed = 0; }
     RES_STAMP_CAL(63);
+    int t0, cnt;
+    rs_split(me.nblk, wv, t0, cnt);                        // (compute wavefronts: cnt <= NT, the communication wavefront: cnt <= RS_NTC -- the plan's promise)
 
     if (wv < ncomp) {
         // =========================================================== COMPUTE wavefronts: their tiles streamed once per iteration
-        const int t0 = (int)((long long)wv * me.nblk / ncomp), cnt = (int)((long long)(wv + 1) * me.nblk / ncomp) - t0;        // <= NT (the plan's promise)
-        // (the tiles' descriptors are read again in every iteration, by scalar loads: kept in registers across the loop, they and everything derived
-        //  from them -- addresses, masks, offsets of every tile -- were hoisted out of it and spilled by the hundred)
-        d2 rr[NT], ww[NT], xx[NT];
-#pragma unroll
-        for (int q = 0; q < NT; ++q) {
-            rr[q] = ww[q] = xx[q] = make_double2(0.0, 0.0);
-            if (q < cnt) {
-                const BlkDesc d = a.blk[me.blk0 + t0 + q];
-                if (lane < d.nrows()) { rr[q] = a.v[d.row0 + lane]; xx[q] = a.x[d.row0 + lane]; }
-            }
-        }
+        RsRows<NT> R;
+        rs_rows_load<NT>(a, me.blk0 + t0, cnt, lane, R);
         d2* const mycol = s_colpart + wv * 64;
-        __syncthreads();                                   // (0) the communication wavefronts have staged the v columns
+        __syncthreads();                                   // (0) the communication wavefront has staged the v columns and the tau element
         RES_STAMP(0);
         for (int i = -1;; ++i) {
-            mycol[lane] = make_double2(0.0, 0.0);
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < NT; ++q) {
-                if (q < cnt) {                             // wave-uniform
-                    const BlkDesc d = a.blk[me.blk0 + t0 + q];
-                    const int T = d.steps(), coff = d.meta[0] - c0;
-                    const bool valid = lane < d.nrows();
-                    const double* __restrict__ vp = a.val + d.nnz0 + lane;
-                    // (requesting a wavefront's first tile BEFORE the exchange in front of it was measured: 70.5 against 66.3 us per iteration --
-                    //  the bulk loads delay the exchange's words)
-                    const d2 gq = rr[q];
-                    double u1, u2;
-                    {
-                        double val[TMAX];
-#pragma unroll
-                        for (int t = 0; t < TMAX; ++t) val[t] = ((t & ~7) < T) ? __builtin_nontemporal_load(vp + 64 * t) : 0.0;   // (zero-padded storage beyond the tile's rows)
-                        res_tile_plain<TMAX>(val, T, gq, s_gcol + coff, mycol + coff, lane, u1, u2);
-                    }
-                    const double c = valid ? a.cb[d.row0 + lane] : 0.0;
-                    const d2 gt = make_double2(s_ctl[RC_GTX], s_ctl[RC_GTY]);            // (read here, not held across the tile: registers)
-                    const double q1 = -(u1 - gt.x * c), q2 = -(u2 - gt.y * c);           // rows of A: EpiKkt::row, i >= n   (HSDEAffine.jl:52,55)
-                    d2 w = make_double2(gq.x - q2, q1 - gq.y);                           // affinepluslinear.jl:45-48
-                    if (!valid) w = make_double2(0.0, 0.0);
-                    ww[q] = w;
-                    acc[2] += c * gq.x;
-                    acc[3] += c * gq.y;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < NT; ++q) {                 // (r.r and w.r from the registers, in tile order: dummies beyond cnt are zeros)
-                acc[0] += rr[q].x * rr[q].x + rr[q].y * rr[q].y;
-                acc[1] += ww[q].x * rr[q].x + ww[q].y * rr[q].y;
-            }
+            double acc[4];
+            rs_sweep<TMAX, NT>(a, me.blk0 + t0, cnt, c0, lane, s_gcol, s_ctl, mycol, R, acc);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double v = wave_sum(acc[k]);
@@ -739,49 +805,14 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
             RES_STAMP(2);
             __syncthreads();                               // (B) alpha, beta, the new columns and tau element
             RES_STAMP(3);
-            const double stopf = s_ctl[RC_STOP];
-            if (stopf != 0.0) break;
-            const double alpha = s_ctl[RC_ALPHA], beta = s_ctl[RC_BETA];
-#pragma unroll
-            for (int q = 0; q < NT; ++q) {
-                if (q < cnt) {
-                    const BlkDesc d = a.blk[me.blk0 + t0 + q];
-                    const bool valid = lane < d.nrows();
-                    const int row = d.row0 + lane;
-                    const size_t e = (size_t)(t0 + q) * 128 + lane;
-                    const d2 w = ww[q];
-                    if (i < 0) {
-                        const d2 rh = valid ? a.rhs[row] : make_double2(0.0, 0.0);
-                        rr[q] = make_double2(rh.x - w.x, rh.y - w.y);                    // r_0 = rhs - M v      conjugategradients.jl:33
-                    } else {
-                        d2 pq, sq;
-                        if (i == 0) { pq = rr[q]; sq = w; }
-                        else {
-                            pq = s_ps[e]; sq = s_ps[e + 64];
-                            pq.x = pq.x * beta + rr[q].x; pq.y = pq.y * beta + rr[q].y;  // p .*= beta ; p .+= r     :49-50
-                            sq.x = sq.x * beta + w.x; sq.y = sq.y * beta + w.y;          // s = M p by the same recurrence
-                        }
-                        xx[q].x += alpha * pq.x; xx[q].y += alpha * pq.y;                // :40
-                        rr[q].x -= alpha * sq.x; rr[q].y -= alpha * sq.y;                // :41
-                        s_ps[e] = pq; s_ps[e + 64] = sq;
-                    }
-                }
-                if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);     // (two tiles' p and s in flight at a time: all of them together were 80 registers on top of r, w, x)
-            }
+            if (s_ctl[RC_STOP] != 0.0) break;
+            rs_update<NT>(a, me.blk0 + t0, t0, cnt, lane, i, s_ctl[RC_ALPHA], s_ctl[RC_BETA], s_ps, R);
             RES_STAMP(4);                                   // updated
             RES_STAMP_NEXT();
             RES_STAMP(0);
         }
         // ---- the solution leaves the registers (an exchange that failed leaves x as it was: the caller gets an error, not a half-updated iterate)
-        if (s_ctl[RC_STOP] == 1.0) {
-#pragma unroll
-            for (int q = 0; q < NT; ++q) {
-                if (q < cnt) {
-                    const BlkDesc d = a.blk[me.blk0 + t0 + q];
-                    if (lane < d.nrows()) a.x[d.row0 + lane] = xx[q];
-                }
-            }
-        }
+        if (s_ctl[RC_STOP] == 1.0) rs_rows_store<NT>(a, me.blk0 + t0, cnt, lane, R);
         RES_STAMP_CAL(62);
         return;
     }
@@ -794,7 +825,11 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
     d2 gt = a.v[nm], xt = a.x[nm], pt = make_double2(0.0, 0.0), stt = pt;
     const d2 rhst = a.rhs[nm];
     for (int q = ct; q < 4 * RS_GMAX; q += 64 * ncomm) s_all[q] = 0.0;
-    for (int q = ct + ncomp * 4; q < 16 * 4; q += 64 * ncomm) (&s_red[0][0])[q] = 0.0;
+    for (int q = ct + (ncomp + 1) * 4; q < 16 * 4; q += 64 * ncomm) (&s_red[0][0])[q] = 0.0;
+    // (this wavefront waits at barrier (A) while the others sweep: it walks the workgroup's last RS_NTC tiles itself -- 66 tiles are 7 x 9 + 3)
+    RsRows<RS_NTC> R;
+    rs_rows_load<RS_NTC>(a, me.blk0 + t0, c0wave ? cnt : 0, lane, R);
+    d2* const mycol = s_colpart + ncomp * 64;
     if (c0wave) {
         if (lane < tc) { cr = a.v[c0 + lane]; cx = a.x[c0 + lane]; crhs = a.rhs[c0 + lane]; cc = a.cb[c0 + lane]; }
         s_gcol[lane] = cr;
@@ -812,17 +847,26 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
         const size_t par = (size_t)(seq & 1u);
         unsigned long long* grec = a.grec + par * (size_t)a.G * 8;
         nx += 1;
+        if (c0wave) {
+            double racc[4];
+            rs_sweep<TMAX, RS_NTC>(a, me.blk0 + t0, cnt, c0, lane, s_gcol, s_ctl, mycol, R, racc);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double v = wave_sum(racc[k]);
+                if (lane == 0) s_red[ncomp][k] = v;
+            }
+        }
         __syncthreads();                                       // (A)
         RES_STAMP(1);
         d2 cp = make_double2(0.0, 0.0);
         if (c0wave) {
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             {
-                d2 o[ncomp];
+                d2 o[ncomp + 1];
 #pragma unroll
-                for (int s = 0; s < ncomp; ++s) o[s] = s_colpart[s * 64 + lane];           // (all in flight together, added in wavefront order)
+                for (int s = 0; s < ncomp + 1; ++s) o[s] = s_colpart[s * 64 + lane];       // (all in flight together, added in wavefront order)
 #pragma unroll
-                for (int s = 0; s < ncomp; ++s) { cp.x += o[s].x; cp.y += o[s].y; }
+                for (int s = 0; s < ncomp + 1; ++s) { cp.x += o[s].x; cp.y += o[s].y; }
             }
             if (lane < tc) {
                 acc[0] = colG;
@@ -974,10 +1018,12 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
         RES_STAMP_NEXT();
         RES_STAMP(0);
         if (s_ctl[RC_STOP] != 0.0) break;
+        if (c0wave) rs_update<RS_NTC>(a, me.blk0 + t0, t0, cnt, lane, i, s_ctl[RC_ALPHA], s_ctl[RC_BETA], s_ps, R);
     }
     RES_STAMP_CAL(62);
     if (c0wave) {
         const bool ok = s_ctl[RC_STOP] == 1.0;
+        if (ok) rs_rows_store<RS_NTC>(a, me.blk0 + t0, cnt, lane, R);
         if (ok && lane < tc) a.x[c0 + lane] = cx;
         if (blockIdx.x == 0 && lane == 0) {
             if (ok) {
@@ -1012,9 +1058,10 @@ void launch_cg_resident(const LaunchCtx& c, const ResLaunch& rl, double2* x, con
     if (rl.stream) {
         // (the compute wavefronts' sums land in s_red[wv]: RS_NCOMP rows, the others zeroed once)
         dim3 grid(rl.G), block(64 * (RS_NCOMP + 1));
-        const size_t lds = (size_t)RS_NCOMP * 64 * sizeof(d2) + (size_t)4 * RS_GMAX * sizeof(double) + (size_t)rl.tiles_wg_max * 128 * sizeof(d2);
+        const size_t lds = (size_t)(RS_NCOMP + 1) * 64 * sizeof(d2) + (size_t)4 * RS_GMAX * sizeof(double) + (size_t)rl.tiles_wg_max * 128 * sizeof(d2);
         if (rl.nt <= 3) { res_lds_optin(cg_stream_kernel<32, 3>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 3>), grid, block, lds, c.stream, a); }
         else if (rl.nt <= 5) { res_lds_optin(cg_stream_kernel<32, 5>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 5>), grid, block, lds, c.stream, a); }
+        else if (rl.nt <= 9) { res_lds_optin(cg_stream_kernel<32, 9>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 9>), grid, block, lds, c.stream, a); }
         else { res_lds_optin(cg_stream_kernel<32, 10>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 10>), grid, block, lds, c.stream, a); }
         return;
     }

@@ -116,7 +116,9 @@ def test_error_paths(pkg):
         A2 = np.vstack([A[:5], A[:5]])
         pkg.HipFeasibility(pkg.Feasibility(pkg.IndAffine(A2, np.ones(10)), pkg.IndBox(0.0, 1.0), n))
     with pytest.raises(pkg.lib.FosError):                      # the dense projector is bounded (two boxes of that length are fine)
-        pkg.HipFeasibility(pkg.Feasibility(pkg.IndAffine(np.ones((1, 50000)), np.ones(1)), pkg.IndBox(0.0, 1.0), 50000))
+        pkg.HipFeasibility(pkg.Feasibility(pkg.IndAffine(np.ones((1, 50000)), np.ones(1), sparse=False), pkg.IndBox(0.0, 1.0), 50000))
+    wide = pkg.HipFeasibility(pkg.Feasibility(pkg.IndAffine(np.ones((1, 50000)), np.ones(1)), pkg.IndBox(0.0, 1.0), 50000))      # (by default a matrix that wide takes the sparse form)
+    assert abs(wide.prox(1, np.zeros(50000)).sum() - 1.0) < 1e-12
     big = pkg.HipFeasibility(pkg.Feasibility(pkg.IndBox(0.0, 1.0), pkg.IndBox(0.5, 2.0), 3_000_001))
     big.set_alg(pkg.AP())
     big.set_iterate(np.full(3_000_001, -1.0))

@@ -49,7 +49,7 @@ CASES = [
     # the STREAMED form (FOS_RESIDENT_STREAM=2 asks for it where the register form would do): tiles re-read every iteration, whole units per workgroup
     ("stream-one-unit-per-workgroup", [(700, 24)] * 4, None, dict(form="streamed", workgroups=4, max_tiles_per_workgroup=11, tiles_per_wave=3)),
     ("stream-two-units-per-workgroup", [(300, 20)] * 6, "3", dict(form="streamed", workgroups=3, max_tiles_per_workgroup=10)),
-    ("stream-many-tiles", [(64 * 30 + 10, 32)] * 2, "1", dict(form="streamed", workgroups=1, max_tiles_per_workgroup=62, tiles_per_wave=10)),
+    ("stream-many-tiles", [(64 * 30 + 10, 32)] * 2, "1", dict(form="streamed", workgroups=1, max_tiles_per_workgroup=62, tiles_per_wave=9)),
     ("stream-ragged-units", [(136, 12)] * 5, "2", dict(form="streamed", workgroups=2, max_tiles_per_workgroup=9)),
     ("stream-five-tiles-per-wave", [(64 * 17, 30)] * 4, "2", dict(form="streamed", workgroups=2, max_tiles_per_workgroup=34, tiles_per_wave=5)),
 ]
