@@ -521,6 +521,16 @@ def main():
                 # bound, and it is priced on the bound no stored format beats: 8 B per non-zero, per sweep
                 sweep_bytes = 8.0 * ost["vals"] + 48.0 * ost["blocks"] + 8.0 * prob.m
                 res_bytes = sweep_bytes * (its + 2) + 4 * 16.0 * nmr
+                stream_traffic, stream_traffic_src = None, None
+                try:
+                    cands = sorted(Path(ROOT / "profiles").glob("r0*_stream_traffic.json"))
+                    if cands and not os.environ.get("FOS_BENCH_SHARD") and dist is None:
+                        tj = json.load(open(cands[-1])).get(args.workload)
+                        if tj:
+                            stream_traffic = tj["bytes_per_sweep"] * (its + 2)
+                            stream_traffic_src = "HBM-side bytes per sweep from separate --pmc passes of the same kernel (%s) x (iterations + 2) sweeps" % tj["source"]
+                except Exception:  # noqa: BLE001
+                    pass
                 roof_res = {
                     "bound": "hbm",
                     "kernel": "cg_stream_kernel (FOS_CG_RESIDENT, streamed form): a whole CG solve (conjugategradients.jl:31-55) as one persistent launch -- per "
@@ -535,7 +545,9 @@ def main():
                     "bytes_basis": "ALGORITHMIC: (8 B x stored tile values + 48 B x tiles + 8 B x rows of A) x (CG iterations + 2) sweeps per solve + v, rhs, x "
                                    "in and x out once -- the launch-per-iteration form moved the tiles + 160 B per row and element of x in three launches "
                                    "per iteration, so a lower fraction here sits beside FEWER bytes and a shorter iteration (`us_per_cg_iteration`)",
-                    "algorithmic_bytes_per_launch": res_bytes, "traffic": None,
+                    "algorithmic_bytes_per_launch": res_bytes, "traffic": stream_traffic,
+                    "traffic_basis": stream_traffic_src,
+                    "traffic_over_algorithmic": (round(stream_traffic / res_bytes, 4) if stream_traffic else None),
                     "avg_kernel_ms": round(avg_res_ms, 5), "launches_timed": res_n,
                     "cg_iterations_per_solve": round(its, 2),
                     "us_per_cg_iteration": round(1e3 * avg_res_ms / max(1e-9, its + 2), 3),

@@ -1084,8 +1084,15 @@ bool build_resident_plan(const HostBlkCsr& S, int64_t m, int64_t n, int gmax, Re
                 tcw += units[u].tc; tiles += units[u].nblk;
             }
             if (tcw > 64 || tiles > RS_NT_MAX * RS_NCOMP + 3) return no(why_not_registers);
-            tiles_max = std::max(tiles_max, tiles);
-            wgs.push_back(ResWG{units[u0].blk0, tiles, units[u0].c0, tcw, 32, (int)wgs.size(), 1, 0});
+            // fewer units than half of the workgroups (a shard of a four-GPU run: 128 blocks on 256 CUs): a unit's tiles are dealt to `split`
+            // workgroups, which exchange their column sums as the register form's do
+            const int split = upw == 1 ? std::max(1, std::min({4, gm / nu, tiles})) : 1;
+            const int wg0 = (int)wgs.size();
+            for (int k = 0; k < split; ++k) {
+                const int ta = (int)((int64_t)k * tiles / split), tb = (int)((int64_t)(k + 1) * tiles / split);
+                wgs.push_back(ResWG{units[u0].blk0 + ta, tb - ta, units[u0].c0, tcw, 32, wg0, split, k});
+                tiles_max = std::max(tiles_max, tb - ta);
+            }
         }
         // tiles per compute wavefront (resident.hip, rs_split: the communication wavefront walks the last min(nblk % 7, 3) tiles itself)
         int nt = 0;

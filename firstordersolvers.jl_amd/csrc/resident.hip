@@ -610,6 +610,7 @@ __global__ __launch_bounds__(LB) void cg_resident_kernel(ResArgs a) {
 // Same exchange (records of self-validating words, no grid barrier), same recurrence, same summation order rules as the register form above;
 // a unit lives in ONE workgroup, so column sums never cross workgroups.
 constexpr int RS_GMAX = 256;          // workgroups (= records) of the streamed form: one per CU
+constexpr int RS_WPU_MAX = 4;         // workgroups a unit may be split over in the streamed form (fewer units than CUs: a shard of a four-GPU run)
 constexpr int RS_NCOMP = 7;           // compute wavefronts per workgroup (+ 1 that communicates): two wavefronts per SIMD, 256 registers each
 
 // a tile in NATURAL column order (as stored): row sums against the workgroup's column elements at gcol (LDS, uniform addresses: broadcasts),
@@ -763,7 +764,8 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     d2* const s_colpart = reinterpret_cast<d2*>(s_dyn);                       // [RS_NCOMP + 1][64]: a wavefront's column sums of a sweep
     double* const s_all = reinterpret_cast<double*>(s_colpart + (RS_NCOMP + 1) * 64);      // [4][RS_GMAX], zero beyond G
-    d2* const s_ps = reinterpret_cast<d2*>(s_all + 4 * RS_GMAX);              // [tiles][2][64]: the rows' p and s
+    double* const s_sib = s_all + 4 * RS_GMAX;                                // [RS_WPU_MAX - 1][64][2]: the column sums of the unit's other workgroups
+    d2* const s_ps = reinterpret_cast<d2*>(s_sib + (RS_WPU_MAX - 1) * 64 * 2);    // [tiles][2][64]: the rows' p and s
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = (int)(blockDim.x >> 6);
     constexpr int ncomp = RS_NCOMP;
@@ -819,7 +821,7 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
 
     // =============================================================== COMMUNICATION wavefronts (the register form's, a unit = this workgroup alone)
     const int cw = wv - ncomp, ct = tid - 64 * ncomp;
-    const bool c0wave = cw == 0;
+    const bool c0wave = cw == 0, leader = me.idx == 0;              // (a unit split over wpu workgroups: its columns are counted once, by the first)
     d2 cx = make_double2(0.0, 0.0), cr = cx, cpv = cx, csv = cx, crhs = cx;
     double cc = 0.0;
     d2 gt = a.v[nm], xt = a.x[nm], pt = make_double2(0.0, 0.0), stt = pt;
@@ -869,10 +871,13 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
                 for (int s = 0; s < ncomp + 1; ++s) { cp.x += o[s].x; cp.y += o[s].y; }
             }
             if (lane < tc) {
-                acc[0] = colG;
-                acc[1] = (cp.x * cr.y - cp.y * cr.x) + (cr.x * cr.x - cr.y * cr.y) + cc * (gt.x * cr.y - gt.y * cr.x);
-                acc[2] = cc * cr.x;
-                acc[3] = cc * cr.y;
+                acc[1] = cp.x * cr.y - cp.y * cr.x;                                      // this workgroup's share of (w.g) of column `lane` (i < n)
+                if (leader) {                                                            // the slot-free part and the other sums: once per column
+                    acc[0] = colG;
+                    acc[1] += (cr.x * cr.x - cr.y * cr.y) + cc * (gt.x * cr.y - gt.y * cr.x);
+                    acc[2] = cc * cr.x;
+                    acc[3] = cc * cr.y;
+                }
             }
             double mine[4];
             {
@@ -895,15 +900,20 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
                 res_publish_half(grec + (size_t)blockIdx.x * 8 + 2 * k, seq, k == 0 ? mine[0] : (k == 1 ? mine[1] : (k == 2 ? mine[2] : mine[3])), lane & 1);
             }
             if (lane < 4) s_all[(size_t)lane * RS_GMAX + blockIdx.x] = lane == 0 ? mine[0] : (lane == 1 ? mine[1] : (lane == 2 ? mine[2] : mine[3]));
+            if (me.wpu > 1 && lane < tc) {
+                unsigned long long* p = a.crec + ((par * a.G + blockIdx.x) * (size_t)a.tmax + (size_t)lane) * 4;
+                res_publish_half(p, seq, cp.x, 0); res_publish_half(p, seq, cp.x, 1);
+                res_publish_half(p + 2, seq, cp.y, 0); res_publish_half(p + 2, seq, cp.y, 1);
+            }
         }
         RES_STAMP(2);                                           // published
         {
             // the other workgroups' 4 record values each, as ONE list dealt to the communication threads (8 items of a thread requested and polled together)
-            const int nrec = 4 * a.G, nthr = 64 * ncomm;
+            const int nrec = 4 * a.G, nsib = (me.wpu - 1) * tc * 2, nthr = 64 * ncomm;
             const int sleepn = (a.flags >> 8) & 0x7F;
             constexpr int PU = 8;
             bool bad = false;
-            for (int base = ct; base < nrec; base += PU * nthr) {
+            for (int base = ct; base < nrec + nsib; base += PU * nthr) {
                 const unsigned long long* src[PU];
                 double* dst[PU];
 #pragma unroll
@@ -914,6 +924,11 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
                         const int wg = idx >> 2, k = idx & 3;
                         dst[u] = s_all + (size_t)k * RS_GMAX + wg;
                         src[u] = wg == (int)blockIdx.x ? nullptr : grec + (size_t)wg * 8 + 2 * k;
+                    } else if (idx < nrec + nsib) {                  // then the column sums of the unit's other workgroups, in order
+                        const int j = idx - nrec, comp = j & 1, c = (j >> 1) % tc, si = (j >> 1) / tc;
+                        const int kk = si < me.idx ? si : si + 1;
+                        dst[u] = s_sib + ((size_t)si * 64 + c) * 2 + comp;
+                        src[u] = a.crec + ((par * a.G + (size_t)(me.wg0 + kk)) * (size_t)a.tmax + (size_t)c) * 4 + 2 * comp;
                     }
                 }
                 long long tstart = 0;
@@ -972,8 +987,20 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
             }
             if (!failed && a.pb.nranks > 0) failed = !res_peer_fold4(a.pb, seq, tot, blockIdx.x == 0, s_halves);
             RES_STAMP(5);                                       // totals (over the ranks)
+            // the unit's column sums: its workgroups in order -- the same bits in each of them
+            d2 ctot = cp;
+            if (me.wpu > 1 && lane < tc) {
+                const d2* sib = reinterpret_cast<const d2*>(s_sib);
+                d2 t = make_double2(0.0, 0.0);
+                for (int kk = 0; kk < me.wpu; ++kk) {
+                    d2 part = cp;
+                    if (kk != me.idx) part = sib[(size_t)(kk < me.idx ? kk : kk - 1) * 64 + lane];
+                    t.x += part.x; t.y += part.y;
+                }
+                ctot = t;
+            }
             // column `lane` of w = M g (EpiKkt::row, i < n: HSDEAffine.jl:51,54) and the tau row (HSDEAffine.jl:57)
-            const double q1 = cp.x + gt.x * cc, q2 = cp.y + gt.y * cc;
+            const double q1 = ctot.x + gt.x * cc, q2 = ctot.y + gt.y * cc;
             const d2 cwv = make_double2(cr.x - q2, q1 - cr.y);
             const d2 wt = make_double2(gt.x + tot[3], -tot[2] - gt.y);
             double stopf = failed ? 2.0 : 0.0, alpha = 0.0, beta = 0.0;
@@ -1007,7 +1034,7 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
                 }
             }
             if (stopf == 0.0) {
-                colG = lane < tc ? cr.x * cr.x + cr.y * cr.y : 0.0;
+                colG = (leader && lane < tc) ? cr.x * cr.x + cr.y * cr.y : 0.0;
                 s_gcol[lane] = lane < tc ? cr : make_double2(0.0, 0.0);
             }
             if (lane == 0) { s_ctl[RC_ALPHA] = alpha; s_ctl[RC_BETA] = beta; s_ctl[RC_GTX] = gt.x; s_ctl[RC_GTY] = gt.y; s_ctl[RC_STOP] = stopf; }
@@ -1024,7 +1051,7 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
     if (c0wave) {
         const bool ok = s_ctl[RC_STOP] == 1.0;
         if (ok) rs_rows_store<RS_NTC>(a, me.blk0 + t0, cnt, lane, R);
-        if (ok && lane < tc) a.x[c0 + lane] = cx;
+        if (ok && leader && lane < tc) a.x[c0 + lane] = cx;
         if (blockIdx.x == 0 && lane == 0) {
             if (ok) {
                 a.x[nm] = xt;
@@ -1058,7 +1085,8 @@ void launch_cg_resident(const LaunchCtx& c, const ResLaunch& rl, double2* x, con
     if (rl.stream) {
         // (the compute wavefronts' sums land in s_red[wv]: RS_NCOMP rows, the others zeroed once)
         dim3 grid(rl.G), block(64 * (RS_NCOMP + 1));
-        const size_t lds = (size_t)(RS_NCOMP + 1) * 64 * sizeof(d2) + (size_t)4 * RS_GMAX * sizeof(double) + (size_t)rl.tiles_wg_max * 128 * sizeof(d2);
+        const size_t lds = (size_t)(RS_NCOMP + 1) * 64 * sizeof(d2) + (size_t)4 * RS_GMAX * sizeof(double) + (size_t)(RS_WPU_MAX - 1) * 64 * 2 * sizeof(double) +
+                           (size_t)rl.tiles_wg_max * 128 * sizeof(d2);
         if (rl.nt <= 3) { res_lds_optin(cg_stream_kernel<32, 3>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 3>), grid, block, lds, c.stream, a); }
         else if (rl.nt <= 5) { res_lds_optin(cg_stream_kernel<32, 5>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 5>), grid, block, lds, c.stream, a); }
         else if (rl.nt <= 9) { res_lds_optin(cg_stream_kernel<32, 9>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 9>), grid, block, lds, c.stream, a); }

@@ -47,7 +47,9 @@ CASES = [
     ("wide-tiles", [(130, 50), (200, 40)], None, dict(steps_per_tile=64)),
     ("psd16-blocks", [(136, 12)] * 5, None, dict(workgroups=15)),                                             # 64 + 64 + 8 rows: the ragged last tile
     # the STREAMED form (FOS_RESIDENT_STREAM=2 asks for it where the register form would do): tiles re-read every iteration, whole units per workgroup
-    ("stream-one-unit-per-workgroup", [(700, 24)] * 4, None, dict(form="streamed", workgroups=4, max_tiles_per_workgroup=11, tiles_per_wave=3)),
+    ("stream-units-split-four-ways", [(700, 24)] * 4, None, dict(form="streamed", workgroups=16, max_tiles_per_workgroup=3, tiles_per_wave=3)),
+    ("stream-units-split-two-ways", [(64 * 17, 30)] * 2, "4", dict(form="streamed", workgroups=4, max_tiles_per_workgroup=9)),
+    ("stream-one-unit-per-workgroup", [(700, 24)] * 4, "4", dict(form="streamed", workgroups=4, max_tiles_per_workgroup=11, tiles_per_wave=3)),
     ("stream-two-units-per-workgroup", [(300, 20)] * 6, "3", dict(form="streamed", workgroups=3, max_tiles_per_workgroup=10)),
     ("stream-many-tiles", [(64 * 30 + 10, 32)] * 2, "1", dict(form="streamed", workgroups=1, max_tiles_per_workgroup=62, tiles_per_wave=9)),
     ("stream-ragged-units", [(136, 12)] * 5, "2", dict(form="streamed", workgroups=2, max_tiles_per_workgroup=9)),

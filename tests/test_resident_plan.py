@@ -80,7 +80,7 @@ def test_c4_shard_plans(pkg):
     blk = sp.csc_matrix(np.ones((2080, 32)))
     for nblocks, want in ((64, dict(qualifies=1, workgroups=256, max_tiles_per_workgroup=9, waves_per_workgroup=9, tiles_per_wave=1, units=64)),
                           (32, dict(qualifies=1, workgroups=224, max_tiles_per_workgroup=5, waves_per_workgroup=5, units=32)),
-                          (128, dict(qualifies=1, workgroups=128, max_tiles_per_workgroup=33, tiles_per_wave=-5, units=128)),   # 17 per workgroup are more than the
+                          (128, dict(qualifies=1, workgroups=256, max_tiles_per_workgroup=17, tiles_per_wave=-3, units=128)),   # 17 per workgroup are more than the
                           (256, dict(qualifies=1, workgroups=256, max_tiles_per_workgroup=33, tiles_per_wave=-5, units=256)),   # registers hold: the streamed form
                           (512, dict(qualifies=1, workgroups=256, max_tiles_per_workgroup=66, tiles_per_wave=-9, units=512))):  # the whole of C4: two units per CU
         A = sp.block_diag([blk] * nblocks, format="csc")
@@ -106,7 +106,8 @@ def test_host_walk_of_the_plan_matches_the_oracle(pkg, monkeypatch):
     and in the streamed form (several whole units per workgroup: gmax below the number of units, or FOS_RESIDENT_STREAM=2)."""
     rng = np.random.default_rng(3)
     for name, A, gmaxes in (("one-tile-units", block_sdp(rng, 6, 48, 12), (256, 6, 2)),
-                            ("stream-asked-for", block_sdp(rng, 5, 136, 12), (256, 2)),
+                            ("stream-asked-for", block_sdp(rng, 5, 136, 12), (256, 2)),        # 256: every unit split over its three tiles
+                            ("stream-split", block_sdp(rng, 2, 600, 24), (4, 5)),
                             ("split-units", block_sdp(rng, 3, 300, 20), (256, 7, 3)),
                             ("wide", block_sdp(rng, 2, 130, 50), (256, 2)),
                             ("uneven", sp.block_diag([sp.csc_matrix(rng.standard_normal((r, cc)) / 8) for r, cc in ((70, 8), (200, 31), (40, 16), (64, 12))], format="csc"), (256, 5))):

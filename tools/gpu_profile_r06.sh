@@ -27,6 +27,11 @@ for tr in peer host; do
   run c4_shard64_${tr}_launch_per_iteration FOS_FORCE_DIST=1 FOS_REDUCTION=$tr FOS_RESIDENT_DEFAULT=0 -- --small --no-cpu-baseline
 done
 run c4_shard64_direct A=1 -- --small --no-cpu-baseline --direct
+# what one of TWO / FOUR ranks holds (256 / 128 blocks: the streamed form of the resident solve), sharded code path, one rank
+run c4_shard1of2_dist1rank FOS_FORCE_DIST=1 FOS_REDUCTION=peer FOS_BENCH_SHARD=0/2 -- --no-cpu-baseline
+run c4_shard1of4_dist1rank FOS_FORCE_DIST=1 FOS_REDUCTION=peer FOS_BENCH_SHARD=0/4 -- --no-cpu-baseline
+# C4 on one GPU with the launch-per-iteration recurrences as the measured configuration (FOS_RESIDENT_DEFAULT=0: the headline of rounds 1-5)
+run c4_launch_per_iteration FOS_RESIDENT_DEFAULT=0 -- --no-cpu-baseline
 # DR(direct = true), block form, in the SHARDED code path (three scalar exchanges per projection through the transport)
 for tr in peer host rccl; do
   run c4_shard64_direct_sharded_$tr FOS_FORCE_DIST=1 FOS_REDUCTION=$tr -- --small --no-cpu-baseline --direct --steps 200
@@ -49,6 +54,11 @@ cp gpurun_out/r04/trace_c4_shard64_peer.md $OUT/
 bash tools/r04_trace.sh c4_shard64_host "FOS_FORCE_DIST=1 FOS_REDUCTION=host" --small > /dev/null 2>&1
 cp gpurun_out/r04/trace_c4_shard64_host.md $OUT/
 REPS=20 bash tools/pmc_sweep.sh r06final_pmc C4 C2 C3 C5 > $OUT/pmc.log 2>&1
+# the streamed resident solve alone: HBM-side bytes per launch of 22 sweeps, counters, kernel-trace duration
+PROG=tools/stream_only.py KPAT=cg_stream REPS=8 bash tools/pmc_sweep.sh r06final_stream C4 > $OUT/pmc_stream.log 2>&1
+cp gpurun_out/r06final_stream/pmc_C4.md $OUT/pmc_c4_stream.md; cp gpurun_out/r06final_stream/pmc_C4.json $OUT/pmc_c4_stream.json
+# in-kernel stamps of the streamed solve on the whole of C4 (the stamps build of the library travels with the tree when it was built: make VARIANT=res_stamps EXTRA=-DFOS_RES_STAMPS)
+[ -f firstordersolvers.jl_amd/csrc/libfoship_res_stamps.so ] && FOSHIP_LIB=firstordersolvers.jl_amd/csrc/libfoship_res_stamps.so timeout 300 python3 tools/res_stamps.py 512 > $OUT/stream_stamps.txt 2>&1
 cp gpurun_out/r06final_pmc/pmc_*.md gpurun_out/r06final_pmc/pmc_*.json $OUT/ 2>/dev/null
 timeout 900 python3 tools/psd_time.py 250 64 128 256 512 > $OUT/psd_time.json 2> /dev/null
 timeout 900 python3 tools/psd_orders.py > $OUT/psd_orders_final.txt 2> /dev/null

@@ -8,10 +8,13 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 TAG=${1:-pmc}; shift
 REPS=${REPS:-20}
+PROG=${PROG:-tools/kkt_only.py}     # the program profiled; KPAT: which kernels are tabulated (tools/stream_only.py + KPAT=cg_stream: the streamed resident solve)
+export KPAT=${KPAT:-kkt2}
+export PROG
 for WL in "$@"; do
   OUT=gpurun_out/$TAG/$WL
   rm -rf $OUT; mkdir -p $OUT
-  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 tools/kkt_only.py $WL 0 $REPS > $OUT/trace.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $PROG $WL 0 $REPS > $OUT/trace.log 2>&1
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" \
              "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum" \
@@ -19,7 +22,7 @@ for WL in "$@"; do
              "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAVES" \
              "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU"; do
     i=$((i+1))
-    timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 tools/kkt_only.py $WL 0 $REPS > $OUT/p$i.log 2>&1
+    timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $PROG $WL 0 $REPS > $OUT/p$i.log 2>&1
   done
   python3 - "$OUT" "$WL" "$TAG" <<'PY'
 import csv, glob, collections, sys, os
@@ -28,14 +31,14 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "kkt2" in k:
+        if os.environ.get("KPAT", "kkt2") in k:
             acc[k.split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 dur = collections.defaultdict(list)
 for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "kkt2" in r["Kernel_Name"]:
+        if os.environ.get("KPAT", "kkt2") in r["Kernel_Name"]:
             dur[r["Kernel_Name"].split("(")[0][:60]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-lines = ["# %s: KKT sweep alone (`python3 tools/kkt_only.py %s`), rocprofv3 --pmc, one pass per counter group" % (wl, wl), "",
+lines = ["# %s: kernels matching '%s' of `python3 %s %s`, rocprofv3 --pmc, one pass per counter group" % (wl, os.environ.get("KPAT", "kkt2"), os.environ.get("PROG", "tools/kkt_only.py"), wl), "",
          open(out + "/trace.log").read().strip().splitlines()[-1] if os.path.exists(out + "/trace.log") else "", ""]
 for k in sorted(acc):
     d = dur.get(k, [])
