@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--direct", action="store_true",
                     help="direct = true (HSDE.jl:12-15): S1 = IndAffine([Q -I], 0), the exact affine projection without CG -- on C4 the block form, "
                          "three KKT sweeps per projection (fos_enable_direct); a secondary line, the headline stays the CG path")
+    ap.add_argument("--no-recurrence-extras", action="store_true",
+                    help="N = 1: skip the additional timings of the same job on the launch-per-iteration recurrences (reference_recurrence_n1, merged_recurrence_n1)")
     ap.add_argument("--no-direct-extra", action="store_true", help="N = 1, C4: skip the additional timing of DR(direct=true)")
     ap.add_argument("--c4-scale", type=float, default=None,
                     help="C4: divide the random symmetric constraint matrices by this instead of 32 (1 = the raw, badly conditioned "
@@ -730,7 +732,8 @@ def main():
                 "the self test passed, but an exchange of the warm-up timed out on the %s mailboxes (FOS_ECOMM)" % failed
     else:
         raise SystemExit("every transport failed during the warm-up")
-    if world == 1 and dist is None and not args.direct and out["config"]["cg_variant"] in ("reference", "resident") and not os.environ.get("FOS_BENCH_SHARD"):
+    if world == 1 and dist is None and not args.direct and not args.no_recurrence_extras and out["config"]["cg_variant"] in ("reference", "resident") \
+            and not os.environ.get("FOS_BENCH_SHARD"):
         # the same job on the other recurrences -- same handle, same state, `--steps` more outer iterations each: the merged-reduction recurrence
         # with a launch group per iteration (what sharded handles without mailboxes run: a scaling ratio can divide like by like) and, where the
         # headline ran the resident solve, the reference's recurrence in its three launches per iteration (what `value` was until round 5)
