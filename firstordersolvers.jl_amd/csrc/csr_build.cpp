@@ -1133,10 +1133,11 @@ bool build_resident_plan(const HostBlkCsr& S, int64_t m, int64_t n, int gmax, Re
         }
     }
     // what a workgroup can hold: kernel <32 steps, 1 tile per wavefront, 12 wavefronts> up to 11 compute wavefronts (+ 1..3 that communicate);
-    // <32, 2, 8> seven compute wavefronts of two tiles + one that communicates; <64, 1, 8> seven of one tile + one
+    // <32, 2, 8> / <32, 3, 8> seven compute wavefronts of two / three tiles + one that communicates; <64, 1, 8> seven of one tile + one
     int nw, rpt, ncomm;
     if (tmax <= 32 && tiles_max <= 11) { nw = tiles_max; rpt = 1; ncomm = std::min(3, 12 - nw); }
     else if (tmax <= 32 && tiles_max <= 14) { nw = 7; rpt = 2; ncomm = 1; }
+    else if (tmax <= 32 && tiles_max <= 21) { nw = 7; rpt = 3; ncomm = 1; }          // (a shard of a four-GPU run of C4: 17 tiles per workgroup)
     else if (tiles_max <= 7) { nw = tiles_max; rpt = 1; ncomm = 1; }
     else return stream_plan("a workgroup's tiles do not fit the registers");
     out->ncomm = ncomm;

@@ -433,7 +433,7 @@ struct ResWG { int32_t blk0, nblk, c0, tc, T, wg0, wpu, idx; };     // 32 bytes:
                                                                     // the unit's workgroups wg0 .. wg0 + wpu - 1, this one is number idx
 constexpr int RES_GMAX = 512;        // workgroups of a resident solve (records every workgroup adds)
 constexpr int RES_WPU_MAX = 16;      // workgroups per unit
-constexpr int RES_SLOTS = 16;        // tiles per workgroup
+constexpr int RES_SLOTS = 21;        // tiles per workgroup
 struct ResPlan {                     // host
     int G = 0, nw = 0, ncomm = 0, rpt = 0, tmax = 0, tiles_wg_max = 0, units = 0;      // nw compute wavefronts + ncomm communication wavefronts per workgroup
     int stream = 0, nt = 0;          // stream: the STREAMED form (tiles re-read every iteration, whole units per workgroup); nt: tiles per compute wavefront

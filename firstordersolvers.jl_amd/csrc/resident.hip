@@ -1098,7 +1098,8 @@ void launch_cg_resident(const LaunchCtx& c, const ResLaunch& rl, double2* x, con
         return nslot * 64 * 4 * sizeof(d2) + nslot * tmax * sizeof(d2) + (size_t)(RES_WPU_MAX - 1) * tmax * 2 * sizeof(double) + (size_t)4 * RES_GMAX * sizeof(double);
     };
     if (rl.tmax <= 32 && rl.rpt == 1) { const size_t lds = lds_bytes(12, 32); res_lds_optin(cg_resident_kernel<32, 1, 768>, lds); hipLaunchKernelGGL((cg_resident_kernel<32, 1, 768>), grid, block, lds, c.stream, a); }
-    else if (rl.tmax <= 32) { const size_t lds = lds_bytes(16, 32); res_lds_optin(cg_resident_kernel<32, 2, 512>, lds); hipLaunchKernelGGL((cg_resident_kernel<32, 2, 512>), grid, block, lds, c.stream, a); }
+    else if (rl.tmax <= 32 && rl.rpt == 2) { const size_t lds = lds_bytes(16, 32); res_lds_optin(cg_resident_kernel<32, 2, 512>, lds); hipLaunchKernelGGL((cg_resident_kernel<32, 2, 512>), grid, block, lds, c.stream, a); }
+    else if (rl.tmax <= 32) { const size_t lds = lds_bytes(24, 32); res_lds_optin(cg_resident_kernel<32, 3, 512>, lds); hipLaunchKernelGGL((cg_resident_kernel<32, 3, 512>), grid, block, lds, c.stream, a); }
     else { const size_t lds = lds_bytes(8, 64); res_lds_optin(cg_resident_kernel<64, 1, 512>, lds); hipLaunchKernelGGL((cg_resident_kernel<64, 1, 512>), grid, block, lds, c.stream, a); }
 }
 

@@ -44,6 +44,7 @@ CASES = [
     ("waves", [(300, 20)] * 3, "3", dict(workgroups=3, waves_per_workgroup=5, tiles_per_wave=1)),            # a unit per workgroup, five wavefronts
     ("split-and-waves", [(600, 24)] * 2 + [(200, 9)], "7", dict(workgroups=7)),                              # 10 + 10 + 4 tiles over 7 workgroups
     ("two-tiles-per-wave", [(64 * 13 + 20, 16)] * 2, "2", dict(workgroups=2, waves_per_workgroup=7, tiles_per_wave=2, max_tiles_per_workgroup=14)),
+    ("three-tiles-per-wave", [(64 * 20 + 20, 16)] * 2, "2", dict(workgroups=2, waves_per_workgroup=7, tiles_per_wave=3, max_tiles_per_workgroup=21, form="registers")),
     ("wide-tiles", [(130, 50), (200, 40)], None, dict(steps_per_tile=64)),
     ("psd16-blocks", [(136, 12)] * 5, None, dict(workgroups=15)),                                             # 64 + 64 + 8 rows: the ragged last tile
     # the STREAMED form (FOS_RESIDENT_STREAM=2 asks for it where the register form would do): tiles re-read every iteration, whole units per workgroup

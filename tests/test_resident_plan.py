@@ -80,8 +80,8 @@ def test_c4_shard_plans(pkg):
     blk = sp.csc_matrix(np.ones((2080, 32)))
     for nblocks, want in ((64, dict(qualifies=1, workgroups=256, max_tiles_per_workgroup=9, waves_per_workgroup=9, tiles_per_wave=1, units=64)),
                           (32, dict(qualifies=1, workgroups=224, max_tiles_per_workgroup=5, waves_per_workgroup=5, units=32)),
-                          (128, dict(qualifies=1, workgroups=256, max_tiles_per_workgroup=17, tiles_per_wave=-3, units=128)),   # 17 per workgroup are more than the
-                          (256, dict(qualifies=1, workgroups=256, max_tiles_per_workgroup=33, tiles_per_wave=-5, units=256)),   # registers hold: the streamed form
+                          (128, dict(qualifies=1, workgroups=256, max_tiles_per_workgroup=17, waves_per_workgroup=7, tiles_per_wave=3, units=128)),   # three tiles per wavefront; beyond 21 per workgroup the
+                          (256, dict(qualifies=1, workgroups=256, max_tiles_per_workgroup=33, tiles_per_wave=-5, units=256)),   # registers are full: the streamed form
                           (512, dict(qualifies=1, workgroups=256, max_tiles_per_workgroup=66, tiles_per_wave=-9, units=512))):  # the whole of C4: two units per CU
         A = sp.block_diag([blk] * nblocks, format="csc")
         rc, st, _, _ = host_resident(pkg, A, np.zeros(A.shape[0]), np.zeros(A.shape[1]), 256)
