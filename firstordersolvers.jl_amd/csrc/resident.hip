@@ -754,6 +754,61 @@ __device__ __forceinline__ void rs_update(const ResArgs& a, int blk_first, int s
     }
 }
 
+// An exchange's incoming words, dealt to ALL threads of the workgroup (the compute wavefronts wait for the exchange anyway): item idx < 4 G is value
+// idx & 3 of workgroup idx >> 2's record, the items behind them are the column sums of the unit's other workgroups.  Thread `t` of `nthr` polls items
+// t, t + nthr, ... -- PU of them requested and polled together.  Returns false when a word did not arrive within the time-out.
+__device__ __forceinline__ bool rs_poll(const ResArgs& a, const ResWG& me, unsigned long long* grec, size_t par, uint32_t seq, int t, int nthr,
+                                        double* __restrict__ s_all, double* __restrict__ s_sib) {
+    const int tc = me.tc;
+    const int nrec = 4 * a.G, nsib = (me.wpu - 1) * tc * 2;
+    const int sleepn = (a.flags >> 8) & 0x7F;
+    constexpr int PU = 3;
+    bool bad = false;
+    for (int base = t; base < nrec + nsib; base += PU * nthr) {
+        const unsigned long long* src[PU];
+        double* dst[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int idx = base + u * nthr;
+            src[u] = nullptr; dst[u] = nullptr;
+            if (idx < nrec) {
+                const int wg = idx >> 2, kk = idx & 3;
+                dst[u] = s_all + (size_t)kk * RS_GMAX + wg;
+                src[u] = wg == (int)blockIdx.x ? nullptr : grec + (size_t)wg * 8 + 2 * kk;
+            } else if (idx < nrec + nsib) {
+                const int j = idx - nrec, comp = j & 1, c = (j >> 1) % tc, si = (j >> 1) / tc;
+                const int kk = si < me.idx ? si : si + 1;
+                dst[u] = s_sib + ((size_t)si * 64 + c) * 2 + comp;
+                src[u] = a.crec + ((par * a.G + (size_t)(me.wg0 + kk)) * (size_t)a.tmax + (size_t)c) * 4 + 2 * comp;
+            }
+        }
+        long long tstart = 0;
+        for (uint32_t spin = 1;; ++spin) {
+            unsigned long long lo[PU], hi[PU];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) if (src[u]) { lo[u] = res_ld_word(src[u]); hi[u] = res_ld_word(src[u] + 1); }
+            bool pending = false;
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                if (src[u]) {
+                    if ((uint32_t)(lo[u] >> 32) == seq && (uint32_t)(hi[u] >> 32) == seq) {
+                        *dst[u] = __longlong_as_double((long long)((hi[u] << 32) | (lo[u] & 0xFFFFFFFFull)));
+                        src[u] = nullptr;
+                    } else pending = true;
+                }
+            }
+            if (!pending) break;
+            if ((spin & 255u) == 0u) {
+                const long long now = wall_clock64();
+                if (tstart == 0) tstart = now;
+                else if (now - tstart >= a.timeout_ticks) { bad = true; break; }
+            }
+            if (sleepn >= 2) __builtin_amdgcn_s_sleep(2); else if (sleepn >= 1) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return !bad;
+}
+
 template <int TMAX, int NT>
 __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs a) {
     __shared__ __attribute__((aligned(16))) d2 s_gcol[64];                   // the workgroup's column elements of the vector being swept (v, then r)
@@ -805,6 +860,13 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
             RES_STAMP(1);                                   // swept
             __syncthreads();                               // (A) column sums and the wavefronts' sums are in LDS
             RES_STAMP(2);
+            {   // this wavefront's share of the exchange's incoming words (it would wait at (B) otherwise)
+                const uint32_t seq = a.seq_base + (uint32_t)(i + 1);
+                const size_t par = (size_t)(seq & 1u);
+                if (!rs_poll(a, me, a.grec + par * (size_t)a.G * 8, par, seq, tid, (int)blockDim.x, s_all, s_sib)) s_failed = 1;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_fetch_add(&s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             __syncthreads();                               // (B) alpha, beta, the new columns and tau element
             RES_STAMP(3);
             if (s_ctl[RC_STOP] != 0.0) break;
@@ -908,54 +970,7 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
         }
         RES_STAMP(2);                                           // published
         {
-            // the other workgroups' 4 record values each, as ONE list dealt to the communication threads (8 items of a thread requested and polled together)
-            const int nrec = 4 * a.G, nsib = (me.wpu - 1) * tc * 2, nthr = 64 * ncomm;
-            const int sleepn = (a.flags >> 8) & 0x7F;
-            constexpr int PU = 8;
-            bool bad = false;
-            for (int base = ct; base < nrec + nsib; base += PU * nthr) {
-                const unsigned long long* src[PU];
-                double* dst[PU];
-#pragma unroll
-                for (int u = 0; u < PU; ++u) {
-                    const int idx = base + u * nthr;
-                    src[u] = nullptr; dst[u] = nullptr;
-                    if (idx < nrec) {
-                        const int wg = idx >> 2, k = idx & 3;
-                        dst[u] = s_all + (size_t)k * RS_GMAX + wg;
-                        src[u] = wg == (int)blockIdx.x ? nullptr : grec + (size_t)wg * 8 + 2 * k;
-                    } else if (idx < nrec + nsib) {                  // then the column sums of the unit's other workgroups, in order
-                        const int j = idx - nrec, comp = j & 1, c = (j >> 1) % tc, si = (j >> 1) / tc;
-                        const int kk = si < me.idx ? si : si + 1;
-                        dst[u] = s_sib + ((size_t)si * 64 + c) * 2 + comp;
-                        src[u] = a.crec + ((par * a.G + (size_t)(me.wg0 + kk)) * (size_t)a.tmax + (size_t)c) * 4 + 2 * comp;
-                    }
-                }
-                long long tstart = 0;
-                for (uint32_t spin = 1;; ++spin) {
-                    unsigned long long lo[PU], hi[PU];
-#pragma unroll
-                    for (int u = 0; u < PU; ++u) if (src[u]) { lo[u] = res_ld_word(src[u]); hi[u] = res_ld_word(src[u] + 1); }
-                    bool pending = false;
-#pragma unroll
-                    for (int u = 0; u < PU; ++u) {
-                        if (src[u]) {
-                            if ((uint32_t)(lo[u] >> 32) == seq && (uint32_t)(hi[u] >> 32) == seq) {
-                                *dst[u] = __longlong_as_double((long long)((hi[u] << 32) | (lo[u] & 0xFFFFFFFFull)));
-                                src[u] = nullptr;
-                            } else pending = true;
-                        }
-                    }
-                    if (!pending) break;
-                    if ((spin & 255u) == 0u) {
-                        const long long now = wall_clock64();
-                        if (tstart == 0) tstart = now;
-                        else if (now - tstart >= a.timeout_ticks) { bad = true; break; }
-                    }
-                    if (sleepn >= 2) __builtin_amdgcn_s_sleep(2); else if (sleepn >= 1) __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            if (bad) s_failed = 1;
+            if (!rs_poll(a, me, grec, par, seq, tid, (int)blockDim.x, s_all, s_sib)) s_failed = 1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_fetch_add(&s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -963,7 +978,7 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
         if (c0wave) {
             {
                 long long tstart = 0;
-                for (uint32_t spin = 1; __hip_atomic_load(&s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(nx * (uint32_t)ncomm); ++spin) {
+                for (uint32_t spin = 1; __hip_atomic_load(&s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(nx * (uint32_t)nw); ++spin) {
                     if ((spin & 4095u) == 0u) {
                         const long long now = wall_clock64();
                         if (tstart == 0) tstart = now;
