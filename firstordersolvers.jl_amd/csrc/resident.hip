@@ -121,7 +121,7 @@ __device__ long long g_res_stamps[4 * 16 * 64 * 16];
 #endif
 
 // what the communication wavefronts hand to the compute wavefronts through LDS at the end of an exchange
-enum ResCtl { RC_ALPHA = 0, RC_BETA, RC_GTX, RC_GTY, RC_STOP, RC_COUNT };     // RC_STOP: 0 go on, 1 CG has stopped, 2 an exchange failed
+enum ResCtl { RC_ALPHA = 0, RC_BETA, RC_GTX, RC_GTY, RC_STOP, RC_NEAR, RC_COUNT };     // RC_STOP: 0 go on, 1 CG has stopped, 2 an exchange failed
 
 // The exchange of the four sums across the GPUs by ONE wavefront (the words, slots and sequence numbers of peer_fold_sum, dev_common.hpp --
 // the launch-per-iteration kernels and this one speak the same protocol): lane = (rank r, value v, half hh), two rounds cover 16 ranks.
@@ -687,7 +687,9 @@ __device__ __forceinline__ void rs_rows_store(const ResArgs& a, int blk_first, i
 //  them -- addresses, masks, offsets of every tile -- were hoisted out of the loop and spilled by the hundred; a branch per tile for the same reason)
 template <int TMAX, int NT>
 __device__ __forceinline__ void rs_sweep(const ResArgs& a, int blk_first, int cnt, int c0, int lane, const d2* __restrict__ s_gcol, const double* s_ctl,
-                                         d2* __restrict__ mycol, RsRows<NT>& R, double (&acc)[4]) {
+                                         d2* __restrict__ mycol, RsRows<NT>& R, double (&acc)[4], bool early = false) {
+    // (early: an exchange round that carries r.r alone -- no tile is walked, the other three sums are zero)
+    if (early) cnt = 0;
     mycol[lane] = make_double2(0.0, 0.0);
     acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
 #pragma unroll
@@ -722,6 +724,7 @@ __device__ __forceinline__ void rs_sweep(const ResArgs& a, int blk_first, int cn
         acc[0] += R.rr[q].x * R.rr[q].x + R.rr[q].y * R.rr[q].y;
         acc[1] += R.ww[q].x * R.rr[q].x + R.ww[q].y * R.rr[q].y;
     }
+    if (early) acc[1] = 0.0;
 }
 
 // the rows' share of an iteration's update: i < 0: r_0 = rhs - M v; else (w, r, p, s, x) -> (p, s, x, r)   conjugategradients.jl:39-41,49-50
@@ -849,9 +852,13 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
         d2* const mycol = s_colpart + wv * 64;
         __syncthreads();                                   // (0) the communication wavefront has staged the v columns and the tau element
         RES_STAMP(0);
-        for (int i = -1;; ++i) {
+        // one loop turn = one EXCHANGE ROUND (sequence number xr + 1).  Ordinarily a round is a sweep of iteration i and its sums; an EARLY round
+        // carries r.r alone: the merged recurrence learns |r| only behind the next sweep, so when the last residual norm says the solve is about to
+        // stop (RC_NEAR), the rows' r.r -- the very sum the next sweep would form -- is exchanged first, and a solve that has converged skips that sweep
+        bool early = false;
+        for (int i = -1, xr = 0;; ++xr) {
             double acc[4];
-            rs_sweep<TMAX, NT>(a, me.blk0 + t0, cnt, c0, lane, s_gcol, s_ctl, mycol, R, acc);
+            rs_sweep<TMAX, NT>(a, me.blk0 + t0, cnt, c0, lane, s_gcol, s_ctl, mycol, R, acc, early);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double v = wave_sum(acc[k]);
@@ -861,7 +868,7 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
             __syncthreads();                               // (A) column sums and the wavefronts' sums are in LDS
             RES_STAMP(2);
             {   // this wavefront's share of the exchange's incoming words (it would wait at (B) otherwise)
-                const uint32_t seq = a.seq_base + (uint32_t)(i + 1);
+                const uint32_t seq = a.seq_base + (uint32_t)(xr + 1);
                 const size_t par = (size_t)(seq & 1u);
                 if (!rs_poll(a, me, a.grec + par * (size_t)a.G * 8, par, seq, tid, (int)blockDim.x, s_all, s_sib)) s_failed = 1;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -870,7 +877,11 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
             __syncthreads();                               // (B) alpha, beta, the new columns and tau element
             RES_STAMP(3);
             if (s_ctl[RC_STOP] != 0.0) break;
-            rs_update<NT>(a, me.blk0 + t0, t0, cnt, lane, i, s_ctl[RC_ALPHA], s_ctl[RC_BETA], s_ps, R);
+            if (!early) {
+                rs_update<NT>(a, me.blk0 + t0, t0, cnt, lane, i, s_ctl[RC_ALPHA], s_ctl[RC_BETA], s_ps, R);
+                early = s_ctl[RC_NEAR] != 0.0;
+                ++i;
+            } else early = false;                          // (not converged yet: the sweep of the same iteration follows)
             RES_STAMP(4);                                   // updated
             RES_STAMP_NEXT();
             RES_STAMP(0);
@@ -906,14 +917,15 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
     int iter = 0;
     uint32_t nx = 0;
     RES_STAMP(0);
-    for (int i = -1;; ++i) {
-        const uint32_t seq = a.seq_base + (uint32_t)(i + 1);
+    bool early = false;                                        // (exchange rounds: see the compute wavefronts' loop)
+    for (int i = -1, xr = 0;; ++xr) {
+        const uint32_t seq = a.seq_base + (uint32_t)(xr + 1);
         const size_t par = (size_t)(seq & 1u);
         unsigned long long* grec = a.grec + par * (size_t)a.G * 8;
         nx += 1;
         if (c0wave) {
             double racc[4];
-            rs_sweep<TMAX, RS_NTC>(a, me.blk0 + t0, cnt, c0, lane, s_gcol, s_ctl, mycol, R, racc);
+            rs_sweep<TMAX, RS_NTC>(a, me.blk0 + t0, cnt, c0, lane, s_gcol, s_ctl, mycol, R, racc, early);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double v = wave_sum(racc[k]);
@@ -932,7 +944,8 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
 #pragma unroll
                 for (int s = 0; s < ncomp + 1; ++s) { cp.x += o[s].x; cp.y += o[s].y; }
             }
-            if (lane < tc) {
+            if (lane < tc && early) { if (leader) acc[0] = colG; }                        // (an early round carries r.r alone)
+            else if (lane < tc) {
                 acc[1] = cp.x * cr.y - cp.y * cr.x;                                      // this workgroup's share of (w.g) of column `lane` (i < n)
                 if (leader) {                                                            // the slot-free part and the other sums: once per column
                     acc[0] = colG;
@@ -957,6 +970,7 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
                 }
             }
             if (i < 0) mine[0] = 0.0;
+            if (early) { mine[1] = 0.0; mine[2] = 0.0; mine[3] = 0.0; }
             if (lane < 8) {
                 const int k = lane >> 1;
                 res_publish_half(grec + (size_t)blockIdx.x * 8 + 2 * k, seq, k == 0 ? mine[0] : (k == 1 ? mine[1] : (k == 2 ? mine[2] : mine[3])), lane & 1);
@@ -1018,8 +1032,11 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
             const double q1 = ctot.x + gt.x * cc, q2 = ctot.y + gt.y * cc;
             const d2 cwv = make_double2(cr.x - q2, q1 - cr.y);
             const d2 wt = make_double2(gt.x + tot[3], -tot[2] - gt.y);
-            double stopf = failed ? 2.0 : 0.0, alpha = 0.0, beta = 0.0;
-            if (!failed) {
+            double stopf = failed ? 2.0 : 0.0, alpha = 0.0, beta = 0.0, near = 0.0;
+            if (!failed && early) {
+                gam = tot[0] + (gt.x * gt.x + gt.y * gt.y);                              // |r_i|^2 of the residual the last update left: the sum the sweep would form
+                if (i > 0 && (sqrt(gam) <= a.tol || i >= a.maxit)) { iter = i; stopf = 1.0; }       // conjugategradients.jl:42 for iteration i, without its sweep
+            } else if (!failed) {
                 if (i < 0) {
                     cr = make_double2(crhs.x - cwv.x, crhs.y - cwv.y);                  // r_0 = rhs - M v      conjugategradients.jl:32-36
                     gt = make_double2(rhst.x - wt.x, rhst.y - wt.y);
@@ -1045,14 +1062,20 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
                         };
                         if (lane < tc) upd(cwv, cr, cpv, csv, cx);
                         upd(wt, gt, pt, stt, xt);
+                        // the residual norm falls by a factor of 2 .. 3 per iteration on these systems: within 3 tol (or at the cap) the next test is likely
+                        // to end the solve -- an exchange of r.r alone (7 us) is tried before the sweep (50 us) that would otherwise find it out
+                        near = (sqrt(gam) <= 3.0 * a.tol || i + 1 >= a.maxit) ? 1.0 : 0.0;
                     }
                 }
             }
-            if (stopf == 0.0) {
+            if (stopf == 0.0 && !early) {
                 colG = (leader && lane < tc) ? cr.x * cr.x + cr.y * cr.y : 0.0;
                 s_gcol[lane] = lane < tc ? cr : make_double2(0.0, 0.0);
             }
-            if (lane == 0) { s_ctl[RC_ALPHA] = alpha; s_ctl[RC_BETA] = beta; s_ctl[RC_GTX] = gt.x; s_ctl[RC_GTY] = gt.y; s_ctl[RC_STOP] = stopf; }
+            if (lane == 0) {
+                if (!early) { s_ctl[RC_ALPHA] = alpha; s_ctl[RC_BETA] = beta; s_ctl[RC_GTX] = gt.x; s_ctl[RC_GTY] = gt.y; s_ctl[RC_NEAR] = near; }
+                s_ctl[RC_STOP] = stopf;
+            }
         }
         RES_STAMP(6);                                           // scalars, columns, tau
         __syncthreads();                                       // (B)
@@ -1060,7 +1083,11 @@ __global__ __launch_bounds__(64 * (RS_NCOMP + 1)) void cg_stream_kernel(ResArgs 
         RES_STAMP_NEXT();
         RES_STAMP(0);
         if (s_ctl[RC_STOP] != 0.0) break;
-        if (c0wave) rs_update<RS_NTC>(a, me.blk0 + t0, t0, cnt, lane, i, s_ctl[RC_ALPHA], s_ctl[RC_BETA], s_ps, R);
+        if (!early) {
+            if (c0wave) rs_update<RS_NTC>(a, me.blk0 + t0, t0, cnt, lane, i, s_ctl[RC_ALPHA], s_ctl[RC_BETA], s_ps, R);
+            early = s_ctl[RC_NEAR] != 0.0;
+            ++i;
+        } else early = false;                                  // (not converged yet: the sweep of the same iteration follows)
     }
     RES_STAMP_CAL(62);
     if (c0wave) {
