@@ -517,20 +517,20 @@ def main():
             rplan = dev.resident_stats()
             its = cg_timed / max(1, args.steps)
             if rplan.get("form") == "streamed":
-                # STREAMED form: every sweep of a solve (its + 2: the start residual, one per iteration, and the one behind the last update whose
-                # exchange finds the stop) reads the stored tiles once and [c; b] of its rows (8 B per row of A); r, w AND x stay in registers,
+                # STREAMED form: every sweep of a solve (its + 1 are needed: the start residual and one per iteration; the kernel walks one more when its
+                # early exchange of r.r did not catch the stop) reads the stored tiles once and [c; b] of its rows (8 B per row of A); r, w AND x stay in registers,
                 # p, s in LDS, the columns in the communication wavefront; per solve v, rhs, x come in and x goes out once -- so the launch is HBM
                 # bound, and it is priced on the bound no stored format beats: 8 B per non-zero, per sweep
                 sweep_bytes = 8.0 * ost["vals"] + 48.0 * ost["blocks"] + 8.0 * prob.m
-                res_bytes = sweep_bytes * (its + 2) + 4 * 16.0 * nmr
+                res_bytes = sweep_bytes * (its + 1) + 4 * 16.0 * nmr
                 stream_traffic, stream_traffic_src = None, None
                 try:
                     cands = sorted(Path(ROOT / "profiles").glob("r0*_stream_traffic.json"))
                     if cands and not os.environ.get("FOS_BENCH_SHARD") and dist is None:
                         tj = json.load(open(cands[-1])).get(args.workload)
                         if tj:
-                            stream_traffic = tj["bytes_per_sweep"] * (its + 2)
-                            stream_traffic_src = "HBM-side bytes per sweep from separate --pmc passes of the same kernel (%s) x (iterations + 2) sweeps" % tj["source"]
+                            stream_traffic = tj["bytes_per_sweep"] * (its + 1)
+                            stream_traffic_src = "HBM-side bytes per sweep from separate --pmc passes of the same kernel (%s) x (iterations + 1) sweeps" % tj["source"]
                 except Exception:  # noqa: BLE001
                     pass
                 roof_res = {
@@ -544,7 +544,7 @@ def main():
                     "frac_time_base": "HIP events on the solver's stream around every %d-th solve of the timed region; the launch's whole duration -- entry, the "
                                       "start sweep, every iteration's exchange and row update, exit -- not only its streaming phases" % PROF_PERIOD,
                     "bytes_per_launch": res_bytes, "bytes_per_sweep": sweep_bytes,
-                    "bytes_basis": "ALGORITHMIC: (8 B x stored tile values + 48 B x tiles + 8 B x rows of A) x (CG iterations + 2) sweeps per solve + v, rhs, x "
+                    "bytes_basis": "ALGORITHMIC: (8 B x stored tile values + 48 B x tiles + 8 B x rows of A) x (CG iterations + 1) sweeps per solve + v, rhs, x "
                                    "in and x out once -- the launch-per-iteration form moved the tiles + 160 B per row and element of x in three launches "
                                    "per iteration, so a lower fraction here sits beside FEWER bytes and a shorter iteration (`us_per_cg_iteration`)",
                     "algorithmic_bytes_per_launch": res_bytes, "traffic": stream_traffic,
@@ -552,9 +552,9 @@ def main():
                     "traffic_over_algorithmic": (round(stream_traffic / res_bytes, 4) if stream_traffic else None),
                     "avg_kernel_ms": round(avg_res_ms, 5), "launches_timed": res_n,
                     "cg_iterations_per_solve": round(its, 2),
-                    "us_per_cg_iteration": round(1e3 * avg_res_ms / max(1e-9, its + 2), 3),
-                    "us_per_cg_iteration_note": "launch duration / (iterations + 2 sweeps); in-kernel stamps (profiles/r06_stream_stamps.txt): sweep 41-50 us "
-                                                "(the tiles at 5.5-6.6 TB/s), exchange 9, row update 1",
+                    "us_per_cg_iteration": round(1e3 * avg_res_ms / max(1e-9, its + 1), 3),
+                    "us_per_cg_iteration_note": "launch duration / (iterations + 1 sweeps); in-kernel stamps (profiles/r06_stream_stamps.txt): sweep 43 us "
+                                                "(the tiles at 6.4 TB/s), exchange 7, row update 1",
                     "resident_plan": rplan,
                     "kernel_share_of_step": shares.get(RES_KEY),
                 }

@@ -19,10 +19,10 @@ for f in sorted(os.listdir(src)):
     elif f == "pmc_c4_stream.json":
         v = json.load(open(p))
         k = list(v)[0]
-        json.dump({"C4": {"kernel": k, "sweeps_per_launch": 22, "bytes_per_launch": v[k]["bytes"], "bytes_per_sweep": v[k]["bytes"] / 22,
-                          "kernel_trace_us_per_launch": v[k]["kernel_trace_us"], "kernel_trace_us_per_sweep": v[k]["kernel_trace_us"] / 22,
+        json.dump({"C4": {"kernel": k, "sweeps_per_launch": 21, "bytes_per_launch": v[k]["bytes"], "bytes_per_sweep": v[k]["bytes"] / 21,
+                          "kernel_trace_us_per_launch": v[k]["kernel_trace_us"], "kernel_trace_us_per_sweep": v[k]["kernel_trace_us"] / 21,
                           "source": "profiles/r06_pmc_c4_stream.md",
-                          "note": "HBM-side bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate --pmc passes; launches of exactly 20 CG iterations (tools/stream_only.py)"}},
+                          "note": "HBM-side bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate --pmc passes; launches of exactly 20 CG iterations = 21 sweeps: the start residual and one per iteration, the cap found by an exchange of r.r alone (tools/stream_only.py)"}},
                   open(os.path.join(dst, "r06_stream_traffic.json"), "w"), indent=1)
     elif f in ("psd_time.json", "psd_orders_final.txt", "stream_stamps.txt"):
         shutil.copy(p, os.path.join(dst, "r06_" + f))

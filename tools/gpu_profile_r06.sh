@@ -44,8 +44,9 @@ for tr in peer host; do
 done
 for W in c4 c2 c3 c5; do
   extra=""; [ $W != c4 ] && extra="--workload ${W^^}"
-  bash tools/r04_trace.sh $W "" $extra --no-direct-extra > /dev/null 2>&1
+  STEPS=$([ $W = c4 ] && echo 300 || echo 20) bash tools/r04_trace.sh $W "" $extra --no-direct-extra > /dev/null 2>&1
   cp gpurun_out/r04/trace_$W.md $OUT/trace_$W.md
+  grep -a '^{"metric"' gpurun_out/r04/trace_$W.log | tail -1 > $OUT/bench_${W}_trace_run.json      # the bench line of the traced command itself
 done
 bash tools/r04_trace.sh c4_direct "" --direct > /dev/null 2>&1
 cp gpurun_out/r04/trace_c4_direct.md $OUT/

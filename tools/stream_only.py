@@ -1,6 +1,6 @@
 """The streamed resident CG solve alone: `python tools/stream_only.py C4 0 [solves]` -- `solves` launches of cg_stream_kernel of exactly K = 20
-iterations each (22 sweeps: the start residual, 20 iterations, the one whose exchange finds the stop) on C4 from a random point; used with
-PROG=tools/stream_only.py KPAT=cg_stream bash tools/pmc_sweep.sh <tag> C4  (HBM-side bytes per LAUNCH = 22 sweeps)."""
+iterations each (21 sweeps: the start residual and one per iteration; the cap is found by an exchange of r.r alone) on C4 from a random point; used with
+PROG=tools/stream_only.py KPAT=cg_stream bash tools/pmc_sweep.sh <tag> C4  (HBM-side bytes per LAUNCH = 21 sweeps)."""
 import sys; sys.path.insert(0, '.')
 import numpy as np
 import __graft_entry__ as ge
@@ -20,4 +20,4 @@ for _ in range(reps):
 n, ms = d.profile_read_classes()["resident"]
 nnz = prob.nnz
 print("C4 streamed resident solve: %d launches of %d iterations, %.1f us per launch = %.2f us per sweep; algorithmic bytes per sweep %.1f MB" %
-      (n, K, 1e3 * ms / n, 1e3 * ms / n / (K + 2), (8.0 * nnz + 8.0 * prob.m) / 1e6))
+      (n, K, 1e3 * ms / n, 1e3 * ms / n / (K + 1), (8.0 * nnz + 8.0 * prob.m) / 1e6))
