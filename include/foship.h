@@ -373,14 +373,18 @@ int fos_set_tuning(fos_handle h, int32_t spmv_workgroups, int32_t cg_chunk, int3
  *                         reduction point carrying r.r and w.r; the sweep closes the iteration            (2 launches, single GPU only)
  *   FOS_CG_MERGED_UPDATE  the same, the update kernel closes the iteration: ONE exchange of four doubles per iteration
  *                         when sharded; the sweep of the last iteration runs for nothing                  (2 launches; default for sharded handles)
- *   FOS_CG_RESIDENT       the arithmetic of FOS_CG_MERGED_UPDATE as ONE launch per SOLVE: the operator's dual tiles and the five CG
- *                         vectors stay in the registers of persistent workgroups from the first to the last iteration, the four sums
- *                         of an iteration cross the workgroups (and, sharded, the GPUs) as self-validating words -- no grid barrier.
- *                         For operators that are nothing but dual tiles of a block-separable A whose share per workgroup fits the
- *                         register file (a block-diagonal SDP on enough GPUs: the eighth of C4 = 133 KB per CU); sharded: device or
- *                         host-pinned mailboxes only.  fos_set_cg_variant returns FOS_EUNSUPPORTED when the operator does not qualify
- *                         (fos_last_error says why); the default of sharded handles on the mailboxes whenever every rank's shard qualifies.
- * variant = -1 restores the handle's default (FOS_CG_REFERENCE on one GPU). */
+ *   FOS_CG_RESIDENT       the arithmetic of FOS_CG_MERGED_UPDATE as ONE launch per SOLVE, for operators that are nothing but dual tiles of a
+ *                         block-separable A; the four sums of an iteration cross the workgroups (and, sharded, the GPUs) as self-validating
+ *                         words -- no grid barrier.  Two forms, chosen at fos_create (fos_resident_stats says which):
+ *                           registers  the tiles AND the CG vectors stay on chip from the first to the last iteration (a workgroup's share fits
+ *                                      the register file: up to 21 tiles -- a block-diagonal SDP on enough GPUs, the eighth of C4 = 133 KB per CU);
+ *                           streamed   the tiles are re-read once per iteration, everything else stays on chip (r, w, x in registers, p, s in LDS):
+ *                                      one pass does the sweep, its reductions and the iteration's vector updates (the whole of C4; whole
+ *                                      consecutive units per workgroup, or a unit split over up to four workgroups).
+ *                         Sharded: device or host-pinned mailboxes only.  fos_set_cg_variant returns FOS_EUNSUPPORTED when the operator does
+ *                         not qualify (fos_last_error says why).  The default of sharded handles on the mailboxes whenever every rank's shard
+ *                         qualifies, and of single handles whose streamed plan fills at least half of the device (FOS_RESIDENT_DEFAULT=0: never).
+ * variant = -1 restores the handle's default (on one GPU: FOS_CG_REFERENCE, or the cases named above). */
 #define FOS_CG_REFERENCE     0
 #define FOS_CG_FUSED_P       1
 #define FOS_CG_MERGED_SWEEP  2
