@@ -744,6 +744,8 @@ def main():
                               "N = 1 on the reference's recurrence, three launches and two reduction points per CG iteration (the headline of rounds 1-5); "
                               "`value` runs the merged recurrence resident: one launch per CG SOLVE"))
         for key, variant, note in extras:
+            # (these run BEHIND the headline: the solve has moved on, a step needs fewer CG iterations than in the timed region -- `cg_iters_per_step`
+            #  says how many; a like-for-like rate needs a run of its own: FOS_RESIDENT_DEFAULT=0 / FOS_CG_VARIANT)
             try:
                 dev.set_cg_variant(variant)
                 dev.step(it + 1, 5, BIG, 1e-8)
@@ -756,7 +758,8 @@ def main():
                 dtm = time.perf_counter() - tm
                 it += 5 + done_m
                 out[key] = {"value": round(done_m / dtm, 4), "unit": "iterations/s", "ms_per_step": round(1e3 * dtm / max(1, done_m), 4),
-                            "cg_variant": dev.cg_variant_name(), "cg_iters_per_step": round((dev.cg_total() - cg0m) / max(1, done_m), 2), "note": note}
+                            "cg_variant": dev.cg_variant_name(), "cg_iters_per_step": round((dev.cg_total() - cg0m) / max(1, done_m), 2),
+                            "note": note + " -- measured behind the headline's timed region (compare `cg_iters_per_step` with the headline's)"}
             except Exception as exc:  # noqa: BLE001
                 out[key] = {"failed": repr(exc)}
             finally:
