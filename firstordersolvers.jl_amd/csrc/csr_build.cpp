@@ -1070,7 +1070,8 @@ bool build_resident_plan(const HostBlkCsr& S, int64_t m, int64_t n, int gmax, Re
     auto stream_plan = [&](const char* why_not_registers) -> bool {
         const bool allow = !(getenv("FOS_RESIDENT_STREAM") && atoi(getenv("FOS_RESIDENT_STREAM")) == 0);
         constexpr int RS_GMAX = 256, RS_NCOMP = 7, RS_NT_MAX = 10;
-        if (!allow || tmax > 32) return no(why_not_registers);
+        if (!allow) return no(why_not_registers);
+        const int nt_cap = tmax > 32 ? 5 : RS_NT_MAX;          // (64-step tiles: 128 registers of matrix values, five tiles' r, w, x beside them)
         const int gm = std::min(gmax, RS_GMAX);
         const int nu = (int)units.size();
         const int upw = (nu + gm - 1) / gm;
@@ -1083,7 +1084,7 @@ bool build_resident_plan(const HostBlkCsr& S, int64_t m, int64_t n, int gmax, Re
                 if (u > u0 && (units[u].c0 != units[u - 1].c0 + units[u - 1].tc || units[u].blk0 != units[u - 1].blk0 + units[u - 1].nblk)) return no(why_not_registers);
                 tcw += units[u].tc; tiles += units[u].nblk;
             }
-            if (tcw > 64 || tiles > RS_NT_MAX * RS_NCOMP + 3) return no(why_not_registers);
+            if (tcw > 64 || tiles > nt_cap * RS_NCOMP + 3) return no(why_not_registers);
             // fewer units than half of the workgroups (a shard of a four-GPU run: 128 blocks on 256 CUs): a unit's tiles are dealt to `split`
             // workgroups, which exchange their column sums as the register form's do
             const int split = upw == 1 ? std::max(1, std::min({4, gm / nu, tiles})) : 1;
@@ -1100,8 +1101,9 @@ bool build_resident_plan(const HostBlkCsr& S, int64_t m, int64_t n, int gmax, Re
             const int per = w.nblk / RS_NCOMP, r = w.nblk % RS_NCOMP, kc = std::min(r, 3);
             nt = std::max(nt, per + (r - kc > 0 ? 1 : 0));
         }
+        if (nt > nt_cap) return no(why_not_registers);
         out->stream = 1; out->nt = nt <= 3 ? 3 : (nt <= 5 ? 5 : (nt <= 9 ? 9 : 10));
-        out->nw = RS_NCOMP; out->ncomm = 1; out->rpt = 0; out->tmax = 32; out->tiles_wg_max = tiles_max; out->units = nu;
+        out->nw = RS_NCOMP; out->ncomm = 1; out->rpt = 0; out->tmax = tmax <= 32 ? 32 : 64; out->tiles_wg_max = tiles_max; out->units = nu;
         out->wg = wgs; out->G = (int)wgs.size();
         out->why.clear();
         return true;

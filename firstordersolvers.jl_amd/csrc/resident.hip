@@ -702,12 +702,15 @@ __device__ __forceinline__ void rs_sweep(const ResArgs& a, int blk_first, int cn
             // (requesting a wavefront's first tile BEFORE the exchange in front of it was measured: 70.5 against 66.3 us per iteration --
             //  the bulk loads delay the exchange's words)
             const d2 gq = R.rr[q];
-            double u1, u2;
-            {
-                double val[TMAX];
+            double u1 = 0.0, u2 = 0.0;
 #pragma unroll
-                for (int t = 0; t < TMAX; ++t) val[t] = ((t & ~7) < T) ? __builtin_nontemporal_load(vp + 64 * t) : 0.0;   // (zero-padded storage beyond the tile's rows)
-                res_tile_plain<TMAX>(val, T, gq, s_gcol + coff, mycol + coff, lane, u1, u2);
+            for (int hf = 0; hf < TMAX / 32; ++hf) {       // (32 steps = 64 registers of matrix values at a time; 64-step tiles: two such passes)
+                double val[32];
+#pragma unroll
+                for (int t = 0; t < 32; ++t) val[t] = (((32 * hf + t) & ~7) < T) ? __builtin_nontemporal_load(vp + 64 * (32 * hf + t)) : 0.0;   // (zero-padded storage beyond the tile's rows)
+                double h1, h2;
+                res_tile_plain<32>(val, T - 32 * hf, gq, s_gcol + coff + 32 * hf, mycol + coff + 32 * hf, lane, h1, h2);
+                u1 += h1; u2 += h2;
             }
             const double c = valid ? a.cb[d.row0 + lane] : 0.0;
             const d2 gt = make_double2(s_ctl[RC_GTX], s_ctl[RC_GTY]);            // (read here, not held across the tile: registers)
@@ -1129,7 +1132,9 @@ void launch_cg_resident(const LaunchCtx& c, const ResLaunch& rl, double2* x, con
         dim3 grid(rl.G), block(64 * (RS_NCOMP + 1));
         const size_t lds = (size_t)(RS_NCOMP + 1) * 64 * sizeof(d2) + (size_t)4 * RS_GMAX * sizeof(double) + (size_t)(RS_WPU_MAX - 1) * 64 * 2 * sizeof(double) +
                            (size_t)rl.tiles_wg_max * 128 * sizeof(d2);
-        if (rl.nt <= 3) { res_lds_optin(cg_stream_kernel<32, 3>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 3>), grid, block, lds, c.stream, a); }
+        if (rl.tmax > 32 && rl.nt <= 3) { res_lds_optin(cg_stream_kernel<64, 3>, lds); hipLaunchKernelGGL((cg_stream_kernel<64, 3>), grid, block, lds, c.stream, a); }
+        else if (rl.tmax > 32) { res_lds_optin(cg_stream_kernel<64, 5>, lds); hipLaunchKernelGGL((cg_stream_kernel<64, 5>), grid, block, lds, c.stream, a); }
+        else if (rl.nt <= 3) { res_lds_optin(cg_stream_kernel<32, 3>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 3>), grid, block, lds, c.stream, a); }
         else if (rl.nt <= 5) { res_lds_optin(cg_stream_kernel<32, 5>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 5>), grid, block, lds, c.stream, a); }
         else if (rl.nt <= 9) { res_lds_optin(cg_stream_kernel<32, 9>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 9>), grid, block, lds, c.stream, a); }
         else { res_lds_optin(cg_stream_kernel<32, 10>, lds); hipLaunchKernelGGL((cg_stream_kernel<32, 10>), grid, block, lds, c.stream, a); }

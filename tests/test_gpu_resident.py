@@ -54,6 +54,7 @@ CASES = [
     ("stream-two-units-per-workgroup", [(300, 20)] * 6, "3", dict(form="streamed", workgroups=3, max_tiles_per_workgroup=10)),
     ("stream-many-tiles", [(64 * 30 + 10, 32)] * 2, "1", dict(form="streamed", workgroups=1, max_tiles_per_workgroup=62, tiles_per_wave=9)),
     ("stream-ragged-units", [(136, 12)] * 5, "2", dict(form="streamed", workgroups=2, max_tiles_per_workgroup=9)),
+    ("stream-wide-tiles", [(64 * 9 + 30, 50), (64 * 4, 40), (200, 64)], "3", dict(form="streamed", workgroups=3, steps_per_tile=64)),
     ("stream-five-tiles-per-wave", [(64 * 17, 30)] * 4, "2", dict(form="streamed", workgroups=2, max_tiles_per_workgroup=34, tiles_per_wave=5)),
 ]
 

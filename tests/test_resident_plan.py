@@ -108,6 +108,7 @@ def test_host_walk_of_the_plan_matches_the_oracle(pkg, monkeypatch):
     for name, A, gmaxes in (("one-tile-units", block_sdp(rng, 6, 48, 12), (256, 6, 2)),
                             ("stream-asked-for", block_sdp(rng, 5, 136, 12), (256, 2)),        # 256: every unit split over its three tiles
                             ("stream-split", block_sdp(rng, 2, 600, 24), (4, 5)),
+                            ("stream-wide", block_sdp(rng, 2, 300, 50), (256, 2)),
                             ("split-units", block_sdp(rng, 3, 300, 20), (256, 7, 3)),
                             ("wide", block_sdp(rng, 2, 130, 50), (256, 2)),
                             ("uneven", sp.block_diag([sp.csc_matrix(rng.standard_normal((r, cc)) / 8) for r, cc in ((70, 8), (200, 31), (40, 16), (64, 12))], format="csc"), (256, 5))):
