@@ -3300,7 +3300,7 @@ int fos_get_cg_variant(fos_handle h, int32_t* variant) {
     // the resident solve: on request wherever the operator qualifies; by default on sharded handles whose sums travel through mailboxes and
     // whose shards ALL qualify (FOS_RESIDENT_DEFAULT=0: never by default).  Sharded without mailboxes (RCCL, the caller's collective): a
     // collective call cannot sit inside a kernel -- the launch-per-iteration form of the same recurrence runs instead.
-    static const bool res_default = !(getenv("FOS_RESIDENT_DEFAULT") && atoi(getenv("FOS_RESIDENT_DEFAULT")) == 0);
+    const bool res_default = !(getenv("FOS_RESIDENT_DEFAULT") && atoi(getenv("FOS_RESIDENT_DEFAULT")) == 0);      // (read at every call: bench.py turns it off after a failed warm-up)
     const bool res_usable = h->res_ok && !h->row_sharded && (!h->sharded() || (h->peer_on && fold_env && h->res_all));
     if (h->cg_variant < 0 && !h->fuse_p && h->sharded() && res_usable && res_default) v = FOS_CG_RESIDENT;
     // one GPU: the STREAMED form where it fills at least half of the chip (C4: 66.3 us per CG iteration against 89 for three launches); operators

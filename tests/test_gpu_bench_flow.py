@@ -126,6 +126,22 @@ def test_bench_falls_back_through_the_transports(inject, expect):
     assert bad.returncode != 0
 
 
+def test_bench_retries_a_transport_without_the_resident_solve_before_leaving_it():
+    """A warm-up that fails while the CG solves run resident (one launch per solve, the exchange inside the kernel) is retried on the SAME mailboxes
+    with a launch group per CG iteration before the transport is given up: every rank takes that branch after the collective vote, and the line
+    says so (config.diagnostics.resident_fallback)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "FOS_BENCH_BACKEND")}
+    env.update(FOS_FORCE_DIST="1", FOS_BENCH_INJECT="resident_warmup_fail", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "2", "--small", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert out["value"] > 0 and out["config"]["cg_variant"] == "merged_update" and out["config"]["transport"] == "peer"
+    assert out["config"]["peer_fallback_reason"] is None
+    assert "resident CG solve" in out["config"]["diagnostics"]["resident_fallback"]
+    assert "warm-up failed on the peer mailboxes" in r.stderr
+
+
 @pytest.mark.parametrize("transport", ["peer", "host"])
 @pytest.mark.parametrize("nranks", [2, 4, 8])
 def test_bench_ranks_on_one_gpu(nranks, transport):
