@@ -213,3 +213,49 @@ def test_c4_shard_one_steady_state_iteration_vs_oracle_resident(pkg, oracle, ful
     from test_gpu_fullsize import _same_step_vs_oracle
     prob = fullsize("C4shard64")
     _same_step_vs_oracle(pkg, prob, pkg.DR(), oracle.DR(), 200, 1e-9, cg_variant="resident")
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_resident_forms_on_random_block_structures(pkg, seed, monkeypatch):
+    """Random block-diagonal operators (1 .. 12 blocks of 20 .. 1400 rows and 8 .. 64 columns, random workgroup caps, the streamed form asked for in
+    half of the cases): wherever the planner says the operator qualifies -- tiles in registers with one to three tiles per wavefront, units split
+    over workgroups, the streamed form with whole or split units, 32- and 64-step tiles -- the resident solve and the launch-per-iteration kernels
+    of the same recurrence give the same iterates (fixed iteration counts) and the same solves (tolerance-limited), and the result solves M x = rhs."""
+    rng = np.random.default_rng(9000 + seed)
+    nb = int(rng.integers(1, 13))
+    wide = rng.random() < 0.3
+    shapes = [(int(rng.integers(20, 1400)), int(rng.integers(8, 65 if wide else 33))) for _ in range(nb)]
+    gmax = rng.choice(["", "1", "2", "3", "5", "8", "40"])
+    if gmax:
+        monkeypatch.setenv("FOS_RESIDENT_GMAX", str(gmax))
+    if rng.random() < 0.5:
+        monkeypatch.setenv("FOS_RESIDENT_STREAM", "2")
+    A = block_op(rng, shapes)
+    m, n = A.shape
+    b, c = rng.standard_normal(m), rng.standard_normal(n)
+    d = pkg.HipHSDE(A, b, c, [("Free", m)], [("Free", n)])
+    st = d.resident_stats()
+    if not st["qualifies"]:
+        d.close()
+        pytest.skip("the planner passes on this structure: %s" % (shapes,))
+    M = orc.KKTMatrix(orc.HSDEMatrixQ(A, b, c))
+    rhs, x0 = rng.standard_normal(d.N), rng.standard_normal(d.N)
+    for k in (1, 4):
+        d.set_cg_variant("resident")
+        xr, itr = d.cg_kkt(x0, rhs, 1e-300, k)
+        d.set_cg_variant("merged_update")
+        xm, itm = d.cg_kkt(x0, rhs, 1e-300, k)
+        xo, _ = _ocg(orc.conjugategradient_merged, M, x0, rhs, 1e-300, k)
+        xref, _ = _ocg(orc.conjugategradient, M, x0, rhs, 1e-300, k)
+        env = max(1e-14, relerr(xref, xo))
+        assert itr == itm == k and relerr(xr, xm) <= 50 * env and relerr(xr, xo) <= 50 * env, (seed, st, k, relerr(xr, xm), relerr(xr, xo), env)
+    tol = 1e-9
+    d.set_cg_variant("resident")
+    xr, itr = d.cg_kkt(x0, rhs, tol, 5000)
+    d.set_cg_variant("merged_update")
+    xm, itm = d.cg_kkt(x0, rhs, tol, 5000)
+    assert abs(itr - itm) <= 2 + itm // 20, (seed, st, itr, itm)
+    y = np.empty(d.N)
+    M.mul(y, xr)
+    assert np.linalg.norm(y - rhs) <= 3 * tol, (seed, st)
+    d.close()
