@@ -342,6 +342,13 @@ mutable struct HipFeasData <: FOSSolverData
                 b = Vector{Float64}(S.b)
                 GC.@preserve At b check(ccall((:fos_feas_set_affine, libfoship), Cint, (Ptr{Cvoid}, Int32, Int64, Ptr{Cdouble}, Ptr{Cdouble}),
                                               d.handle, which, Int64(size(S.A, 1)), At, b))
+            elseif S isa ProximalOperators.IndAffine && S.A isa SparseArrays.SparseMatrixCSC
+                # IndAffine(A, b) over a sparse A stays sparse on the device (any n): the arrays of the SparseMatrixCSC as they are (1-based)
+                As = SparseArrays.SparseMatrixCSC{Float64,Int64}(S.A)
+                b = Vector{Float64}(S.b)
+                GC.@preserve As b check(ccall((:fos_feas_set_affine_sparse, libfoship), Cint,
+                                              (Ptr{Cvoid}, Int32, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}),
+                                              d.handle, which, Int64(size(As, 1)), As.colptr, As.rowval, As.nzval, b))
             else                                            # any other ProximableFunction: prox!(y, S, x) on host vectors [Feasibility.jl:2-6]
                 push!(d.sets, Ref{Any}(S))                  # (rooted: the library keeps a pointer to it)
                 check(ccall((:fos_feas_set_callback, libfoship), Cint, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
