@@ -778,11 +778,22 @@ def main():
     if world > 1 and not weak_main and not args.no_weak_extra and args.workload == "C4":
         # the same job once more with 512 blocks PER RANK: weak scaling, reported beside the strong-scaling headline
         dev.close()
-        wout, dev, prob, alg, it = run_case(True)
-        out["weak_scaling"] = {k: wout[k] for k in ("value", "unit", "ms_per_step", "scaling", "warmup_effective")}
-        out["weak_scaling"]["config"] = {k: wout["config"][k] for k in ("workload", "local_m", "local_n", "local_nnz", "cg_iters_per_step", "parallelism")}
-        rk = wout["roofline_kkt"] if isinstance(wout["roofline_kkt"], dict) else wout["roofline"]
-        out["weak_scaling"]["roofline_kkt"] = {k: rk.get(k) for k in ("achieved", "frac", "avg_kernel_ms", "all_ranks")}
+        # (an extra line: whatever goes wrong here -- the warm-up's collective vote, a time-out of the mailboxes, an out-of-memory -- costs this
+        #  line, never the headline; every rank leaves run_case the same way: the vote, or the peers' time-outs behind a rank that failed alone)
+        w_ok, w_exc = True, None
+        try:
+            wout, dev, prob, alg, it = run_case(True)
+        except (Exception, SystemExit) as exc:  # noqa: BLE001
+            w_ok, w_exc = False, exc
+        if dist is not None and not agree(w_ok):
+            if w_ok:
+                dev.close()
+            out["weak_scaling"] = {"failed": repr(w_exc) if w_exc is not None else "another rank's weak-scaling run failed"}
+        else:
+            out["weak_scaling"] = {k: wout[k] for k in ("value", "unit", "ms_per_step", "scaling", "warmup_effective")}
+            out["weak_scaling"]["config"] = {k: wout["config"][k] for k in ("workload", "local_m", "local_n", "local_nnz", "cg_iters_per_step", "parallelism")}
+            rk = wout["roofline_kkt"] if isinstance(wout["roofline_kkt"], dict) else wout["roofline"]
+            out["weak_scaling"]["roofline_kkt"] = {k: rk.get(k) for k in ("achieved", "frac", "avg_kernel_ms", "all_ranks")}
     if world > 1 and dist is not None and args.workload == "C4" and not args.direct and not args.no_direct_extra and not weak_main \
             and out["config"].get("transport") in ("peer", "host"):
         # the same sharded job under DR(direct = true): the block form's diagonal blocks are local to a rank, its three scalar sums per projection ride
